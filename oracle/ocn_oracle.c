@@ -1,0 +1,658 @@
+/*
+ * oracle/ocn_oracle.c -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT.
+ *
+ * A plain-C, strict-IEEE (compile with -ffp-contract=off) CPU restatement of the
+ * NonhydrostaticModel hot path of Oceananigans.jl v0.96.19 on a RectilinearGrid
+ * (x, y regular; z regular or stretched; each direction Periodic / Bounded / Flat).
+ * Every function cites the reference file:line it follows (paths relative to the
+ * reference tree).  Expression shapes (operand order, left-associated n-ary +,
+ * "multiply by computed reciprocal", no FMA contraction) follow the Julia source so
+ * that results are reproducible to the last bit on any IEEE-754 CPU.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (oceananigans.jl_amd/) never links, imports or calls it.
+ *
+ * Parity status: the reference is Julia and cannot be executed in this project
+ * (no julia binary, no network).  This restatement is pinned by the reference's own
+ * property / known-answer tests re-expressed in tests/ (see DESIGN.md "Oracle"),
+ * and by the jldoctest coefficient vectors in src/Advection/reconstruction_coefficients.jl.
+ * Bit-level parity of the WENO arithmetic with a live Julia run is UNPINNED.
+ *
+ * Memory layout (src/Grids/new_data.jl:36-70, src/Grids/grid_utils.jl:66-72):
+ * every field is its OffsetArray *parent*: column-major, x fastest, with halos.
+ * Interior index (i,j,k), 1-based, maps to parent offset
+ *   (i+Hx-1) + sx*((j+Hy-1) + sy*(k+Hz-1)),  sx,sy,sz = parent extents.
+ * Parent extent along a dimension: N+2H, or N+1+2H for a Face-located field in a
+ * Bounded dimension.  Flat dimensions have N=1, H=0.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#define OCN_PERIODIC 0
+#define OCN_BOUNDED 1
+#define OCN_FLAT 2
+
+typedef struct {
+    int32_t Nx, Ny, Nz;
+    int32_t Hx, Hy, Hz;
+    int32_t tx, ty, tz;
+    double dx, dy, dz;  /* regular spacings; dz ignored when dzc != NULL */
+    const double *dzc;  /* dz at centres, element 0 <-> k = 1-Hz, length Nz+2Hz, or NULL */
+    const double *dzf;  /* dz at faces,   element 0 <-> k = 1-Hz, length Nz+2Hz (+1 if Bounded), or NULL */
+} ocn_grid;
+
+/* parent extents for a field at location (fx,fy,fz); f? = 1 for Face */
+static inline int ext(int N, int H, int topo, int face) { return N + 2 * H + ((face && topo == OCN_BOUNDED) ? 1 : 0); }
+
+typedef struct {
+    ptrdiff_t sx, sy, sz; /* parent extents */
+    ptrdiff_t s1, s2, s3; /* strides: 1, sx, sx*sy */
+    ptrdiff_t o;          /* offset of interior (1,1,1) */
+} lay;
+
+static inline lay mklay(const ocn_grid *g, int fx, int fy, int fz)
+{
+    lay L;
+    L.sx = ext(g->Nx, g->Hx, g->tx, fx);
+    L.sy = ext(g->Ny, g->Hy, g->ty, fy);
+    L.sz = ext(g->Nz, g->Hz, g->tz, fz);
+    L.s1 = 1;
+    L.s2 = L.sx;
+    L.s3 = L.sx * L.sy;
+    L.o = g->Hx + L.s2 * g->Hy + L.s3 * g->Hz;
+    return L;
+}
+/* 1-based interior index -> parent offset */
+#define AT(L, i, j, k) ((L).o + ((i)-1) + (L).s2 * ((j)-1) + (L).s3 * ((k)-1))
+
+/* ---- grid metrics: src/Operators/spacings_and_areas_and_volumes.jl:106-140,263-345 ---- */
+static inline double dzc_at(const ocn_grid *g, int k) { return g->dzc ? g->dzc[k + g->Hz - 1] : g->dz; }
+static inline double dzf_at(const ocn_grid *g, int k) { return g->dzf ? g->dzf[k + g->Hz - 1] : g->dz; }
+/* zf: 1 if the z-location is Face */
+static inline double dz_at(const ocn_grid *g, int k, int zf) { return zf ? dzf_at(g, k) : dzc_at(g, k); }
+static inline double Ax_at(const ocn_grid *g, int k, int zf) { return g->dy * dz_at(g, k, zf); } /* Ax = dy*dz */
+static inline double Ay_at(const ocn_grid *g, int k, int zf) { return g->dx * dz_at(g, k, zf); } /* Ay = dx*dz */
+static inline double Az_at(const ocn_grid *g) { return g->dx * g->dy; }                         /* Az = dx*dy */
+static inline double V_at(const ocn_grid *g, int k, int zf) { return Az_at(g) * dz_at(g, k, zf); } /* V = Az*dz */
+
+/* =====================================================================================
+ * Reconstruction coefficients.
+ * src/Advection/reconstruction_coefficients.jl:100-115 (stencil_coefficients): the
+ * Int/Int quotient is a Float64, accumulated in BigFloat, rounded to FT, and the last
+ * coefficient is 1 - sum(others).  Values below are produced by oracle/coefficients.py
+ * (tests/test_oracle_coefficients.py checks them against that generator and against
+ * the reference's jldoctest vectors).
+ * ===================================================================================== */
+/* Centered(order=4): applied to psi[n-2], psi[n-1], psi[n], psi[n+1] for face n
+ * (calc_reconstruction_stencil, reconstruction_coefficients.jl:173-203: coeff[order-idx+1]) */
+static const double C4[4] = {-0.08333333333333326, 0.5833333333333333, 0.5833333333333333, -0.08333333333333333};
+/* WENO{3} per-stencil coefficients coeff_p (weno_interpolants.jl:118-119), stencil r = 0,1,2 */
+static const double W5P[3][3] = {{0.33333333333333337, 0.8333333333333334, -0.16666666666666674},
+                                 {-0.16666666666666669, 0.8333333333333333, 0.3333333333333335},
+                                 {0.33333333333333326, -1.1666666666666667, 1.8333333333333335}};
+/* WENO{2} per-stencil coefficients */
+static const double W3P[2][2] = {{0.5, 0.5}, {-0.5, 1.5}};
+/* smoothness coefficients, weno_interpolants.jl:178-183 */
+static const double W5B[3][6] = {{10, -31, 11, 25, -19, 4}, {4, -13, 5, 13, -13, 4}, {4, -19, 11, 25, -31, 10}};
+static const double W3B[2][3] = {{1, -2, 1}, {1, -2, 1}};
+/* optimal weights C*, weno_interpolants.jl:77-82 */
+static const double W5C[3] = {3.0 / 10.0, 3.0 / 5.0, 1.0 / 10.0};
+static const double W3C[2] = {2.0 / 3.0, 1.0 / 3.0};
+/* const eps = 1f-8 widened to Float64 on use (weno_interpolants.jl:70) */
+static const double WENO_EPS = (double)1e-8f;
+
+/* exported for tests */
+void ocn_oracle_coefficients(double *c4, double *w5p, double *w3p, double *eps)
+{
+    memcpy(c4, C4, sizeof C4);
+    memcpy(w5p, W5P, sizeof W5P);
+    memcpy(w3p, W3P, sizeof W3P);
+    *eps = WENO_EPS;
+}
+
+/* ---- WENO5: weno_interpolants.jl:341-348 (weights), 445-447 (stencils), 475-511 (reconstruction)
+ * S = psi[n-3..n+2] for a reconstruction at face n; left != 0 selects LeftBias. */
+static inline double beta3(const double *p, const double *C)
+{
+    /* smoothness_operation for buffer 3 (weno_interpolants.jl:213-225) */
+    return p[0] * ((C[0] * p[0] + C[1] * p[1]) + C[2] * p[2]) + p[1] * (C[3] * p[1] + C[4] * p[2]) + (p[2] * p[2]) * C[5];
+}
+static inline double weno5(const double S[6], int left)
+{
+    double s0[3], s1[3], s2[3];
+    if (left) {
+        s0[0] = S[2]; s0[1] = S[3]; s0[2] = S[4];
+        s1[0] = S[1]; s1[1] = S[2]; s1[2] = S[3];
+        s2[0] = S[0]; s2[1] = S[1]; s2[2] = S[2];
+    } else {
+        s0[0] = S[3]; s0[1] = S[2]; s0[2] = S[1];
+        s1[0] = S[4]; s1[1] = S[3]; s1[2] = S[2];
+        s2[0] = S[5]; s2[1] = S[4]; s2[2] = S[3];
+    }
+    double b0 = beta3(s0, W5B[0]), b1 = beta3(s1, W5B[1]), b2 = beta3(s2, W5B[2]);
+    double tau = fabs(b0 - b2); /* global_smoothness_indicator(Val(3)), :318 */
+    double q0 = tau / (b0 + WENO_EPS), q1 = tau / (b1 + WENO_EPS), q2 = tau / (b2 + WENO_EPS);
+    double a0 = W5C[0] * (1 + q0 * q0), a1 = W5C[1] * (1 + q1 * q1), a2 = W5C[2] * (1 + q2 * q2); /* :299-306 */
+    double sa = (a0 + a1) + a2;
+    double w0 = a0 / sa, w1 = a1 / sa, w2 = a2 / sa;
+    double p0 = (W5P[0][0] * s0[0] + W5P[0][1] * s0[1]) + W5P[0][2] * s0[2]; /* biased_p :144-145 */
+    double p1 = (W5P[1][0] * s1[0] + W5P[1][1] * s1[1]) + W5P[1][2] * s1[2];
+    double p2 = (W5P[2][0] * s2[0] + W5P[2][1] * s2[1]) + W5P[2][2] * s2[2];
+    return (w0 * p0 + w1 * p1) + w2 * p2;
+}
+/* ---- WENO3 (buffer_scheme of WENO5): S = psi[n-2..n+1] */
+static inline double beta2(const double *p, const double *C) { return p[0] * (C[0] * p[0] + C[1] * p[1]) + (p[1] * p[1]) * C[2]; }
+static inline double weno3(const double S[4], int left)
+{
+    double s0[2], s1[2];
+    if (left) {
+        s0[0] = S[1]; s0[1] = S[2];
+        s1[0] = S[0]; s1[1] = S[1];
+    } else {
+        s0[0] = S[2]; s0[1] = S[1];
+        s1[0] = S[3]; s1[1] = S[2];
+    }
+    double b0 = beta2(s0, W3B[0]), b1 = beta2(s1, W3B[1]);
+    double tau = fabs(b0 - b1);
+    double q0 = tau / (b0 + WENO_EPS), q1 = tau / (b1 + WENO_EPS);
+    double a0 = W3C[0] * (1 + q0 * q0), a1 = W3C[1] * (1 + q1 * q1);
+    double sa = a0 + a1;
+    double w0 = a0 / sa, w1 = a1 / sa;
+    double p0 = W3P[0][0] * s0[0] + W3P[0][1] * s0[1];
+    double p1 = W3P[1][0] * s1[0] + W3P[1][1] * s1[1];
+    return w0 * p0 + w1 * p1;
+}
+
+/* =====================================================================================
+ * Topology-conditional interpolation (topologically_conditional_interpolation.jl:37-128)
+ * A "line accessor" describes a 1-D line through a field (or through the function
+ * metric*field): value(m) = scale(m) * p[m*stride] where m is the index offset from the
+ * face index n along the interpolation direction.
+ * ===================================================================================== */
+typedef struct {
+    const double *p;   /* points at the element with index n (the face index) along the line */
+    ptrdiff_t s;       /* stride along the line */
+    const ocn_grid *g; /* for z-varying metrics */
+    int metric;        /* 0: none, 1: Ax (dy*dz), 2: Ay (dx*dz), 3: Az (dx*dy) */
+    int zf;            /* z-location of the metric (1 Face) */
+    int along_z;       /* 1 if the line runs along z (metric index varies with m) */
+    int k0;            /* z index at m = 0 (1-based) */
+} line;
+
+static inline double lval(const line *L, int m)
+{
+    double v = L->p[m * L->s];
+    if (!L->metric) return v;
+    int k = L->along_z ? L->k0 + m : L->k0;
+    double a = L->metric == 1 ? Ax_at(L->g, k, L->zf) : L->metric == 2 ? Ay_at(L->g, k, L->zf) : Az_at(L->g);
+    return a * v; /* Ax_q(i,j,k,grid,u) = Ax(i,j,k) * u[i,j,k]; products_between_fields_and_grid_metrics.jl:5-14 */
+}
+
+/* symmetric (advecting velocity) interpolation to face n; N = grid size along the line, topo its topology.
+ * WENO{3}.advecting_velocity_scheme = Centered(order=4), buffer chain -> Centered(order=2)
+ * (weno_reconstruction.jl:117-120, upwind_biased_reconstruction.jl:101-107).
+ * `center` selects the *ᶜ variant (interpolating to centre n == face n+1 with the ᶜ halo test):
+ * the caller passes the line already shifted to face n+1 and idx = n. */
+static inline double sym_interp(const line *L, int idx, int N, int topo, int center)
+{
+    if (topo == OCN_FLAT) return lval(L, center ? -1 : 0); /* flat_advective_fluxes.jl:26-44: psi[i,j,k] at the point itself */
+    int hi_ok = 1;
+    if (topo == OCN_BOUNDED) {
+        /* outside_symmetric_halo, required_halo_size(WENO{3}) = 3 (:46-47) */
+        hi_ok = center ? (idx >= 3 && idx <= N + 1 - 3) : (idx >= 3 + 1 && idx <= N + 1 - 3);
+    }
+    if (hi_ok) return ((C4[0] * lval(L, -2) + C4[1] * lval(L, -1)) + C4[2] * lval(L, 0)) + C4[3] * lval(L, 1);
+    /* Centered(order=2): 0.5*psi[n-1] + 0.5*psi[n]  (both deeper fallbacks are Centered2) */
+    return 0.5 * lval(L, -1) + 0.5 * lval(L, 0);
+}
+
+/* biased interpolation to face n (or centre idx = n-1 when center != 0) */
+static inline double bias_interp(const line *L, int idx, int N, int topo, int center, int left)
+{
+    if (topo == OCN_FLAT) return lval(L, center ? -1 : 0);
+    int ok5 = 1, ok3 = 1;
+    if (topo == OCN_BOUNDED) {
+        if (center) { /* outside_biased_haloᶜ :51-52 */
+            ok5 = (idx >= 3) && (idx <= N + 1 - 2) && (idx >= 2) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 2) && (idx <= N + 1 - 1) && (idx >= 1) && (idx <= N + 1 - 2);
+        } else { /* outside_biased_haloᶠ :49-50 */
+            ok5 = (idx >= 4) && (idx <= N + 1 - 2) && (idx >= 3) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 3) && (idx <= N + 1 - 1) && (idx >= 2) && (idx <= N + 1 - 2);
+        }
+    }
+    if (ok5) {
+        double S[6];
+        for (int m = 0; m < 6; ++m) S[m] = lval(L, m - 3);
+        return weno5(S, left);
+    }
+    if (ok3) {
+        double S[4];
+        for (int m = 0; m < 4; ++m) S[m] = lval(L, m - 2);
+        return weno3(S, left);
+    }
+    /* UpwindBiased(order=1): left -> psi[n-1], right -> psi[n] (reconstruction_coefficients.jl:153-157) */
+    return left ? lval(L, -1) : lval(L, 0);
+}
+
+/* =====================================================================================
+ * Momentum advective fluxes, upwind_biased_advective_fluxes.jl:23-93.
+ * dir codes: 0 x, 1 y, 2 z.  Every flux is  U~ * psi^R  with
+ *   U~   = symmetric interpolation, along direction `da`, of (area * advecting velocity)
+ *   psiR = biased interpolation, along direction `db`, of the advected component.
+ * ===================================================================================== */
+typedef struct {
+    const ocn_grid *g;
+    const double *u, *v, *w;
+    lay Lu, Lv, Lw;
+} vel;
+
+static inline int gridN(const ocn_grid *g, int d) { return d == 0 ? g->Nx : d == 1 ? g->Ny : g->Nz; }
+static inline int gridT(const ocn_grid *g, int d) { return d == 0 ? g->tx : d == 1 ? g->ty : g->tz; }
+static inline ptrdiff_t strd(const lay *L, int d) { return d == 0 ? L->s1 : d == 1 ? L->s2 : L->s3; }
+
+/* generic flux: advecting component `ca` (0 u,1 v,2 w) interpolated along `da` (to face or centre),
+ * advected component `cb` interpolated along `db`. (i,j,k) is the flux location index triple as used
+ * by the reference's advective_momentum_flux_* functions. */
+static double mom_flux(const vel *V, int ca, int da, int a_center, int cb, int db, int b_center, int i, int j, int k)
+{
+    const ocn_grid *g = V->g;
+    /* flat_advective_fluxes.jl:8-22: flux *through* a Flat direction is zero */
+    if (gridT(g, ca) == OCN_FLAT) return 0.0;
+    const double *fa = ca == 0 ? V->u : ca == 1 ? V->v : V->w;
+    const lay *La = ca == 0 ? &V->Lu : ca == 1 ? &V->Lv : &V->Lw;
+    const double *fb = cb == 0 ? V->u : cb == 1 ? V->v : V->w;
+    const lay *Lb = cb == 0 ? &V->Lu : cb == 1 ? &V->Lv : &V->Lw;
+    int ijk[3] = {i, j, k};
+
+    line A;
+    A.g = g;
+    A.metric = ca + 1;          /* Ax_q(fcc) for u, Ay_q(cfc) for v, Az_q(ccf) for w */
+    A.zf = (ca == 2);           /* z-location of that metric: w lives on z faces */
+    A.along_z = (da == 2);
+    A.s = strd(La, da);
+    {
+        int q[3] = {i, j, k};
+        if (a_center) q[da] += 1; /* symmetric_interpolate_*ᶜ: inner(..., i+1, ...) reconstruction_coefficients.jl:30-34 */
+        A.p = fa + AT(*La, q[0], q[1], q[2]);
+        A.k0 = q[2];
+    }
+    double ut = sym_interp(&A, ijk[da], gridN(g, da), gridT(g, da), a_center);
+
+    line B;
+    B.g = g;
+    B.metric = 0;
+    B.zf = 0;
+    B.along_z = (db == 2);
+    B.s = strd(Lb, db);
+    {
+        int q[3] = {i, j, k};
+        if (b_center) q[db] += 1;
+        B.p = fb + AT(*Lb, q[0], q[1], q[2]);
+        B.k0 = q[2];
+    }
+    int left = ut > 0; /* bias(u) = ifelse(u > 0, LeftBias(), RightBias()) :21 */
+    double pr = bias_interp(&B, ijk[db], gridN(g, db), gridT(g, db), b_center, left);
+    return ut * pr;
+}
+
+/* named wrappers matching the reference's function names */
+#define F_Uu(V, i, j, k) mom_flux(V, 0, 0, 1, 0, 0, 1, i, j, k) /* :23-29  sym xᶜ of Ax*u ; biased xᶜ of u */
+#define F_Vu(V, i, j, k) mom_flux(V, 1, 0, 0, 0, 1, 0, i, j, k) /* :31-37  sym xᶠ of Ay*v ; biased yᶠ of u */
+#define F_Wu(V, i, j, k) mom_flux(V, 2, 0, 0, 0, 2, 0, i, j, k) /* :39-45  sym xᶠ of Az*w ; biased zᶠ of u */
+#define F_Uv(V, i, j, k) mom_flux(V, 0, 1, 0, 1, 0, 0, i, j, k) /* :47-53  sym yᶠ of Ax*u ; biased xᶠ of v */
+#define F_Vv(V, i, j, k) mom_flux(V, 1, 1, 1, 1, 1, 1, i, j, k) /* :55-61 */
+#define F_Wv(V, i, j, k) mom_flux(V, 2, 1, 0, 1, 2, 0, i, j, k) /* :63-69 */
+#define F_Uw(V, i, j, k) mom_flux(V, 0, 2, 0, 2, 0, 0, i, j, k) /* :71-77 */
+#define F_Vw(V, i, j, k) mom_flux(V, 1, 2, 0, 2, 1, 0, i, j, k) /* :79-85 */
+#define F_Ww(V, i, j, k) mom_flux(V, 2, 2, 1, 2, 2, 1, i, j, k) /* :87-93 */
+
+/* delta operators return zero(FT) along Flat dims (difference_operators.jl:33-49) */
+#define DFLAT(g, d) (gridT(g, d) == OCN_FLAT)
+
+/* K1-K3: compute_Gu!/Gv!/Gw! (compute_nonhydrostatic_tendencies.jl:146-179) with every optional
+ * term `nothing`: G = -div_Uu (momentum_advection_operators.jl:46-83).  Work range follows
+ * launch!(..., :xyz; exclude_periphery=true) (kernel_launching.jl:113-161): Face-located in a
+ * Bounded dim starts at 2. */
+void ocn_oracle_momentum_tendencies(const ocn_grid *g, const double *u, const double *v, const double *w, double *Gu,
+                                    double *Gv, double *Gw)
+{
+    vel V;
+    V.g = g;
+    V.u = u;
+    V.v = v;
+    V.w = w;
+    V.Lu = mklay(g, 1, 0, 0);
+    V.Lv = mklay(g, 0, 1, 0);
+    V.Lw = mklay(g, 0, 0, 1);
+    const int Nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
+    const int ox = (g->tx == OCN_BOUNDED && Nx > 1), oy = (g->ty == OCN_BOUNDED && Ny > 1), oz = (g->tz == OCN_BOUNDED && Nz > 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= Nz; ++k)
+        for (int j = 1; j <= Ny; ++j)
+            for (int i = 1; i <= Nx; ++i) {
+                if (i >= 1 + ox) { /* Gu at (f,c,c) */
+                    double dxF = DFLAT(g, 0) ? 0.0 : F_Uu(&V, i, j, k) - F_Uu(&V, i - 1, j, k);     /* δxᶠᵃᵃ */
+                    double dyF = DFLAT(g, 1) ? 0.0 : F_Vu(&V, i, j + 1, k) - F_Vu(&V, i, j, k);     /* δyᵃᶜᵃ */
+                    double dzF = DFLAT(g, 2) ? 0.0 : F_Wu(&V, i, j, k + 1) - F_Wu(&V, i, j, k);     /* δzᵃᵃᶜ */
+                    double rV = 1 / V_at(g, k, 0);
+                    Gu[AT(V.Lu, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+                }
+                if (j >= 1 + oy) { /* Gv at (c,f,c) */
+                    double dxF = DFLAT(g, 0) ? 0.0 : F_Uv(&V, i + 1, j, k) - F_Uv(&V, i, j, k);     /* δxᶜᵃᵃ */
+                    double dyF = DFLAT(g, 1) ? 0.0 : F_Vv(&V, i, j, k) - F_Vv(&V, i, j - 1, k);     /* δyᵃᶠᵃ */
+                    double dzF = DFLAT(g, 2) ? 0.0 : F_Wv(&V, i, j, k + 1) - F_Wv(&V, i, j, k);     /* δzᵃᵃᶜ */
+                    double rV = 1 / V_at(g, k, 0);
+                    Gv[AT(V.Lv, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+                }
+                if (k >= 1 + oz) { /* Gw at (c,c,f) */
+                    double dxF = DFLAT(g, 0) ? 0.0 : F_Uw(&V, i + 1, j, k) - F_Uw(&V, i, j, k);     /* δxᶜᵃᵃ */
+                    double dyF = DFLAT(g, 1) ? 0.0 : F_Vw(&V, i, j + 1, k) - F_Vw(&V, i, j, k);     /* δyᵃᶜᵃ */
+                    double dzF = DFLAT(g, 2) ? 0.0 : F_Ww(&V, i, j, k) - F_Ww(&V, i, j, k - 1);     /* δzᵃᵃᶠ */
+                    double rV = 1 / V_at(g, k, 1);
+                    Gw[AT(V.Lw, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+                }
+            }
+}
+
+/* K4: tracer tendency  Gc = -div_Uc (tracer_advection_operators.jl:30-34), fluxes
+ * upwind_biased_advective_fluxes.jl:99-121:  Ax * u[i,j,k] * cR  (left-assoc). */
+static double tracer_flux(const vel *V, const double *c, const lay *Lc, int d, int i, int j, int k)
+{
+    const ocn_grid *g = V->g;
+    if (gridT(g, d) == OCN_FLAT) return 0.0;
+    const double *fa = d == 0 ? V->u : d == 1 ? V->v : V->w;
+    const lay *La = d == 0 ? &V->Lu : d == 1 ? &V->Lv : &V->Lw;
+    double ut = fa[AT(*La, i, j, k)];
+    line B;
+    B.g = g;
+    B.metric = 0;
+    B.zf = 0;
+    B.along_z = (d == 2);
+    B.s = strd(Lc, d);
+    B.p = c + AT(*Lc, i, j, k);
+    B.k0 = k;
+    int ijk[3] = {i, j, k};
+    double cr = bias_interp(&B, ijk[d], gridN(g, d), gridT(g, d), 0, ut > 0);
+    double area = d == 0 ? Ax_at(g, k, 0) : d == 1 ? Ay_at(g, k, 0) : Az_at(g);
+    return (area * ut) * cr;
+}
+void ocn_oracle_tracer_tendency(const ocn_grid *g, const double *u, const double *v, const double *w, const double *c,
+                                double *Gc)
+{
+    vel V;
+    V.g = g;
+    V.u = u;
+    V.v = v;
+    V.w = w;
+    V.Lu = mklay(g, 1, 0, 0);
+    V.Lv = mklay(g, 0, 1, 0);
+    V.Lw = mklay(g, 0, 0, 1);
+    lay Lc = mklay(g, 0, 0, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                double dxF = DFLAT(g, 0) ? 0.0 : tracer_flux(&V, c, &Lc, 0, i + 1, j, k) - tracer_flux(&V, c, &Lc, 0, i, j, k);
+                double dyF = DFLAT(g, 1) ? 0.0 : tracer_flux(&V, c, &Lc, 1, i, j + 1, k) - tracer_flux(&V, c, &Lc, 1, i, j, k);
+                double dzF = DFLAT(g, 2) ? 0.0 : tracer_flux(&V, c, &Lc, 2, i, j, k + 1) - tracer_flux(&V, c, &Lc, 2, i, j, k);
+                double rV = 1 / V_at(g, k, 0);
+                Gc[AT(Lc, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+            }
+}
+
+/* =====================================================================================
+ * Time-stepper kernels
+ * ===================================================================================== */
+/* loc: bit0 x-face, bit1 y-face, bit2 z-face.  Range = :xyz with exclude_periphery=true. */
+static void field_range(const ocn_grid *g, int loc, int *i0, int *j0, int *k0)
+{
+    *i0 = 1 + ((loc & 1) && g->tx == OCN_BOUNDED && g->Nx > 1);
+    *j0 = 1 + ((loc & 2) && g->ty == OCN_BOUNDED && g->Ny > 1);
+    *k0 = 1 + ((loc & 4) && g->tz == OCN_BOUNDED && g->Nz > 1);
+}
+/* K5 rk3_substep_field! (runge_kutta_3.jl:194-208) */
+void ocn_oracle_rk3_substep(const ocn_grid *g, int loc, double *U, const double *Gn, const double *Gm, double dt,
+                            double gamma, double zeta, int has_zeta)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int i0, j0, k0;
+    field_range(g, loc, &i0, &j0, &k0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = k0; k <= g->Nz; ++k)
+        for (int j = j0; j <= g->Ny; ++j)
+            for (int i = i0; i <= g->Nx; ++i) {
+                ptrdiff_t a = AT(L, i, j, k);
+                if (has_zeta)
+                    U[a] += dt * (gamma * Gn[a] + zeta * Gm[a]);
+                else
+                    U[a] += (dt * gamma) * Gn[a];
+            }
+}
+/* K6 ab2_step_field! (quasi_adams_bashforth_2.jl:162-175) */
+void ocn_oracle_ab2_step(const ocn_grid *g, int loc, double *U, const double *Gn, const double *Gm, double dt, double chi)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int i0, j0, k0;
+    field_range(g, loc, &i0, &j0, &k0);
+    double not_euler = (chi != -0.5) ? 1.0 : 0.0;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = k0; k <= g->Nz; ++k)
+        for (int j = j0; j <= g->Ny; ++j)
+            for (int i = i0; i <= g->Nx; ++i) {
+                ptrdiff_t a = AT(L, i, j, k);
+                double G = (1.5 + chi) * Gn[a] - ((0.5 + chi) * Gm[a]) * not_euler;
+                U[a] += dt * G;
+            }
+}
+/* K7 _cache_field_tendencies! (store_tendencies.jl:6-9): G⁻ <- Gⁿ over :xyz (interior 1:N) */
+void ocn_oracle_cache_tendency(const ocn_grid *g, int loc, double *Gm, const double *Gn)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) Gm[AT(L, i, j, k)] = Gn[AT(L, i, j, k)];
+}
+
+/* =====================================================================================
+ * Pressure: source term, correction
+ * ===================================================================================== */
+/* divᶜᶜᶜ (divergence_operators.jl:16-19) */
+static inline double div_ccc(const ocn_grid *g, const double *u, const double *v, const double *w, const lay *Lu,
+                             const lay *Lv, const lay *Lw, int i, int j, int k)
+{
+    double dxu = DFLAT(g, 0) ? 0.0 : Ax_at(g, k, 0) * u[AT(*Lu, i + 1, j, k)] - Ax_at(g, k, 0) * u[AT(*Lu, i, j, k)];
+    double dyv = DFLAT(g, 1) ? 0.0 : Ay_at(g, k, 0) * v[AT(*Lv, i, j + 1, k)] - Ay_at(g, k, 0) * v[AT(*Lv, i, j, k)];
+    double dzw = DFLAT(g, 2) ? 0.0 : Az_at(g) * w[AT(*Lw, i, j, k + 1)] - Az_at(g) * w[AT(*Lw, i, j, k)];
+    return (1 / V_at(g, k, 0)) * ((dxu + dyv) + dzw);
+}
+void ocn_oracle_divergence(const ocn_grid *g, const double *u, const double *v, const double *w, double *div /* Nx*Ny*Nz, no halo */)
+{
+    lay Lu = mklay(g, 1, 0, 0), Lv = mklay(g, 0, 1, 0), Lw = mklay(g, 0, 0, 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i)
+                div[(i - 1) + (ptrdiff_t)g->Nx * ((j - 1) + (ptrdiff_t)g->Ny * (k - 1))] = div_ccc(g, u, v, w, &Lu, &Lv, &Lw, i, j, k);
+}
+/* K8 _compute_source_term! (solve_for_pressure.jl:12-17) and K9 _fourier_tridiagonal_source_term!
+ * ZDirection (:33-38).  rhs is an interleaved complex array Nx*Ny*Nz (no halo). */
+void ocn_oracle_source_term(const ocn_grid *g, const double *u, const double *v, const double *w, double dt, int times_dz,
+                            double *rhs_complex)
+{
+    lay Lu = mklay(g, 1, 0, 0), Lv = mklay(g, 0, 1, 0), Lw = mklay(g, 0, 0, 1);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                double d = div_ccc(g, u, v, w, &Lu, &Lv, &Lw, i, j, k);
+                double r = times_dz ? (dzc_at(g, k) * d) / dt : d / dt; /* active * Δz * δ / Δt, left-assoc */
+                ptrdiff_t a = (i - 1) + (ptrdiff_t)g->Nx * ((j - 1) + (ptrdiff_t)g->Ny * (k - 1));
+                rhs_complex[2 * a] = r;
+                rhs_complex[2 * a + 1] = 0.0;
+            }
+}
+/* K13 copy_real_component! (fft_based_poisson_solver.jl:129-137) */
+void ocn_oracle_copy_real(const ocn_grid *g, const double *phi_complex, double *p)
+{
+    lay L = mklay(g, 0, 0, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i)
+                p[AT(L, i, j, k)] = phi_complex[2 * ((i - 1) + (ptrdiff_t)g->Nx * ((j - 1) + (ptrdiff_t)g->Ny * (k - 1)))];
+}
+/* K17 _pressure_correct_velocities! (pressure_correction.jl:31-37); :xyz over 1:N in all dims.
+ * ∂xᶠᶜᶜ = δxᶠᵃᵃ(p)/Δxᶠᶜᶜ (derivative_operators.jl:20-30); δ along a Flat dim is zero. */
+void ocn_oracle_pressure_correct(const ocn_grid *g, double *u, double *v, double *w, const double *p, double dt)
+{
+    lay Lu = mklay(g, 1, 0, 0), Lv = mklay(g, 0, 1, 0), Lw = mklay(g, 0, 0, 1), Lp = mklay(g, 0, 0, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                double pc = p[AT(Lp, i, j, k)];
+                double px = DFLAT(g, 0) ? 0.0 : (pc - p[AT(Lp, i - 1, j, k)]) / g->dx;
+                double py = DFLAT(g, 1) ? 0.0 : (pc - p[AT(Lp, i, j - 1, k)]) / g->dy;
+                double pz = DFLAT(g, 2) ? 0.0 : (pc - p[AT(Lp, i, j, k - 1)]) / dzf_at(g, k);
+                u[AT(Lu, i, j, k)] -= px * dt;
+                v[AT(Lv, i, j, k)] -= py * dt;
+                w[AT(Lw, i, j, k)] -= pz * dt;
+            }
+}
+/* ∇²ᶜᶜᶜ (laplacian_operators.jl:36-40) for the Poisson property tests:
+ * 1/V * (δx(Ax ∂x c) + δy(Ay ∂y c) + δz(Az ∂z c)) */
+void ocn_oracle_laplacian(const ocn_grid *g, const double *p, double *lap /* Nx*Ny*Nz */)
+{
+    lay L = mklay(g, 0, 0, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+#define P(a, b, c) p[AT(L, a, b, c)]
+                double fx1 = Ax_at(g, k, 0) * ((P(i + 1, j, k) - P(i, j, k)) / g->dx), fx0 = Ax_at(g, k, 0) * ((P(i, j, k) - P(i - 1, j, k)) / g->dx);
+                double fy1 = Ay_at(g, k, 0) * ((P(i, j + 1, k) - P(i, j, k)) / g->dy), fy0 = Ay_at(g, k, 0) * ((P(i, j, k) - P(i, j - 1, k)) / g->dy);
+                double fz1 = Az_at(g) * ((P(i, j, k + 1) - P(i, j, k)) / dzf_at(g, k + 1)), fz0 = Az_at(g) * ((P(i, j, k) - P(i, j, k - 1)) / dzf_at(g, k));
+#undef P
+                double sx = DFLAT(g, 0) ? 0.0 : fx1 - fx0, sy = DFLAT(g, 1) ? 0.0 : fy1 - fy0, sz = DFLAT(g, 2) ? 0.0 : fz1 - fz0;
+                lap[(i - 1) + (ptrdiff_t)g->Nx * ((j - 1) + (ptrdiff_t)g->Ny * (k - 1))] = (1 / V_at(g, k, 0)) * ((sx + sy) + sz);
+            }
+}
+
+/* =====================================================================================
+ * Halo fills
+ * ===================================================================================== */
+/* K18 fill_periodic_*_halo! (fill_halo_regions_periodic.jl:40-71): on the parent array, over the
+ * full parent cross-section (corners included).  dir 0/1/2.  (sx,sy,sz) parent extents. */
+void ocn_oracle_fill_periodic(double *c, int sx, int sy, int sz, int dir, int N, int H)
+{
+    ptrdiff_t s[3] = {1, sx, (ptrdiff_t)sx * sy};
+    int e[3] = {sx, sy, sz};
+    int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    for (int b = 0; b < e[d2]; ++b)
+        for (int a = 0; a < e[d1]; ++a) {
+            double *base = c + a * s[d1] + b * s[d2];
+            for (int h = 0; h < H; ++h) {
+                base[h * s[dir]] = base[(N + h) * s[dir]];         /* c[i]     = c[N+i]  (1-based parent) */
+                base[(N + H + h) * s[dir]] = base[(H + h) * s[dir]]; /* c[N+H+i] = c[H+i] */
+            }
+        }
+}
+/* K19 flux (no-flux) fill along z: c[.,.,0] = c[.,.,1], c[.,.,Nz+1] = c[.,.,Nz]
+ * (fill_halo_regions_flux.jl:14-33), over the interior (i,j) range (fill_halo_size for a 2-D :xy side).
+ * Works for any direction `dir`; N = interior size of the field along dir. */
+void ocn_oracle_fill_flux(const ocn_grid *g, int loc, double *c, int dir)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int N[3] = {g->Nx, g->Ny, g->Nz};
+    int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    for (int b = 1; b <= N[d2]; ++b)
+        for (int a = 1; a <= N[d1]; ++a) {
+            int lo[3], hi[3], lo_src[3], hi_src[3];
+            lo[d1] = hi[d1] = lo_src[d1] = hi_src[d1] = a;
+            lo[d2] = hi[d2] = lo_src[d2] = hi_src[d2] = b;
+            lo[dir] = 0;
+            lo_src[dir] = 1;
+            hi[dir] = N[dir] + 1;
+            hi_src[dir] = N[dir];
+            c[AT(L, lo[0], lo[1], lo[2])] = c[AT(L, lo_src[0], lo_src[1], lo_src[2])];
+            c[AT(L, hi[0], hi[1], hi[2])] = c[AT(L, hi_src[0], hi_src[1], hi_src[2])];
+        }
+}
+/* Open (impenetrable) fill: wall-normal velocity on boundary faces set to 0
+ * (fill_halo_regions_open.jl:65-70, boundary_condition.jl:90,113). */
+void ocn_oracle_fill_open(const ocn_grid *g, int loc, double *c, int dir)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int N[3] = {g->Nx, g->Ny, g->Nz};
+    int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    for (int b = 1; b <= N[d2]; ++b)
+        for (int a = 1; a <= N[d1]; ++a) {
+            int lo[3], hi[3];
+            lo[d1] = hi[d1] = a;
+            lo[d2] = hi[d2] = b;
+            lo[dir] = 1;
+            hi[dir] = N[dir] + 1;
+            c[AT(L, lo[0], lo[1], lo[2])] = 0.0;
+            c[AT(L, hi[0], hi[1], hi[2])] = 0.0;
+        }
+}
+
+/* =====================================================================================
+ * Fourier-tridiagonal solver pieces
+ * ===================================================================================== */
+/* K15 compute_main_diagonal! ZDirection (fourier_tridiagonal_poisson_solver.jl:41-51) */
+void ocn_oracle_main_diagonal_z(const ocn_grid *g, const double *lx, const double *ly, double *D /* Nx*Ny*Nz */)
+{
+    const int Nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
+    for (int j = 1; j <= Ny; ++j)
+        for (int i = 1; i <= Nx; ++i) {
+            double lam = lx[i - 1] + ly[j - 1];
+#define DD(k) D[(i - 1) + (ptrdiff_t)Nx * ((j - 1) + (ptrdiff_t)Ny * ((k)-1))]
+            DD(1) = -1 / dzf_at(g, 2) - dzc_at(g, 1) * lam;
+            for (int k = 2; k <= Nz - 1; ++k) DD(k) = -(1 / dzf_at(g, k + 1) + 1 / dzf_at(g, k)) - dzc_at(g, k) * lam;
+            DD(Nz) = -1 / dzf_at(g, Nz) - dzc_at(g, Nz) * lam;
+#undef DD
+        }
+}
+/* complex helpers with Julia's semantics for Complex/Real and Real*Complex (componentwise) */
+/* K14 solve_batched_tridiagonal_system_z! (batched_tridiagonal_solver.jl:209-235).
+ * a,c: real 1-D (Nz-1), b: real 3-D, f/phi: complex 3-D interleaved, t: real 3-D scratch.
+ * phi holds its previous contents on entry (needed for the "not diagonally dominant" guard). */
+void ocn_oracle_tridiag_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f,
+                                double *t, double *phi)
+{
+    const double tiny = 10 * 2.220446049250313e-16; /* 10*eps(Float64) */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int j = 0; j < Ny; ++j)
+        for (int i = 0; i < Nx; ++i) {
+#define IX(k) ((ptrdiff_t)i + (ptrdiff_t)Nx * ((ptrdiff_t)j + (ptrdiff_t)Ny * (k)))
+            double beta = b[IX(0)];
+            phi[2 * IX(0)] = f[2 * IX(0)] / beta;
+            phi[2 * IX(0) + 1] = f[2 * IX(0) + 1] / beta;
+            for (int k = 1; k < Nz; ++k) {
+                double ck = c[k - 1], bk = b[IX(k)], ak = a[k - 1];
+                t[IX(k)] = ck / beta;
+                beta = bk - ak * t[IX(k)];
+                int dd = fabs(beta) > tiny;
+                double sr = (f[2 * IX(k)] - ak * phi[2 * IX(k - 1)]) / beta;
+                double si = (f[2 * IX(k) + 1] - ak * phi[2 * IX(k - 1) + 1]) / beta;
+                if (dd) {
+                    phi[2 * IX(k)] = sr;
+                    phi[2 * IX(k) + 1] = si;
+                }
+            }
+            for (int k = Nz - 2; k >= 0; --k) {
+                phi[2 * IX(k)] -= t[IX(k + 1)] * phi[2 * IX(k + 1)];
+                phi[2 * IX(k) + 1] -= t[IX(k + 1)] * phi[2 * IX(k + 1) + 1];
+            }
+#undef IX
+        }
+}
+
+/* 1-D reconstruction probes for unit tests (order-of-accuracy, known answers) */
+double ocn_oracle_weno5(const double *S6, int left) { return weno5(S6, left); }
+double ocn_oracle_weno3(const double *S4, int left) { return weno3(S4, left); }
+double ocn_oracle_centered4(const double *S4) { return ((C4[0] * S4[0] + C4[1] * S4[1]) + C4[2] * S4[2]) + C4[3] * S4[3]; }
