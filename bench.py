@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of full RK3 time steps of the WENO5 NonhydrostaticModel (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--n 512] [--math fast|strict]
+
+Workload (config.workload): N^3 triply periodic RectilinearGrid, extent (2 pi)^3, halo 3, fp64,
+advection = WENO() (5th order), RungeKutta3, FFT-based pressure solver, no tracers/closure/buoyancy
+(BASELINE.json configs[1]/[2] at --n 256 / 512).  Inputs are synthetic: u, v, w ~ U(-1, 1) from a fixed seed,
+projected to be divergence free by set! (one dt = 1 pressure solve); dt = 0.1 dx / max|u|.
+A "step" is one full time_step!: 3 x (substep, pressure projection, tendencies).  With --gpus N > 1 the same global
+grid is x-slab partitioned over N ranks (strong scaling), one process per GPU, RCCL halo exchange + all-to-all
+transposes.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+ALGO_BYTES_PER_CELL_STEP = 1680.0  # 560 + 584 + 536 B per cell per RK3 step (reference decomposition)
+TENDENCY_BYTES_PER_CELL = 48.0     # fused compute_Gu/Gv/Gw launch: read u, v, w once, write Gu, Gv, Gw (fp64)
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=512, help="grid points per dimension (512 = the metric's config)")
+    ap.add_argument("--math", choices=("fast", "strict"), default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=96, help="grid size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(n, steps):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over k-planes + pocketfft) timed on the host cores
+    on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    rng = np.random.default_rng(1234)
+    g = O.Grid((n, n, n), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology="PPP", halo=(3, 3, 3))
+    m = O.NonhydrostaticModel(g, workers=cores)
+    m.set(u=rng.uniform(-1, 1, (n, n, n)), v=rng.uniform(-1, 1, (n, n, n)), w=rng.uniform(-1, 1, (n, n, n)))
+    dt = 0.1 * g.dx / max(np.abs(m.u).max(), np.abs(m.v).max(), np.abs(m.w).max())
+    m.time_step(dt)  # warm-up (first step also computes the initial tendencies)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.time_step(dt)
+    el = time.perf_counter() - t0
+    return {"value": n ** 3 * steps / el, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} RK3 steps of the same model at {n}^3 (C oracle, OpenMP {cores} threads, scipy pocketfft), {el:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    import oceananigans_jl_amd as ocn
+    ocn._lib.lib()  # fail loudly if the HIP extension is missing
+    ocn.set_math_mode(ocn.MATH_FAST if a.math == "fast" else ocn.MATH_STRICT)
+
+    N = a.n
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(world))
+    else:
+        dist = None
+        arch = ocn.GPU()
+    two_pi = 2 * np.pi
+    grid = ocn.RectilinearGrid(arch, size=(N, N, N), x=(0, two_pi), y=(0, two_pi), z=(0, two_pi),
+                               topology=("Periodic", "Periodic", "Periodic"), halo=(3, 3, 3))
+    model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO())
+
+    # synthetic initial condition generated on the device (fixed seed per rank)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    for f in model.velocities:
+        iv = f.interior_view()
+        iv.copy_(torch.rand(iv.shape, generator=gen, device=iv.device, dtype=torch.float64) * 2 - 1)
+    ocn.set(model)  # halo fills + the dt = 1 projection of set!
+    umax = torch.stack([f.interior_view().abs().max() for f in model.velocities]).max()
+    if dist is not None:
+        dist.all_reduce(umax, op=dist.ReduceOp.MAX)
+    dt = 0.1 * grid.dx / float(umax)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        ocn.time_step(model, dt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ocn.time_step(model, dt)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    finite = bool(torch.isfinite(model.u.data).all())
+
+    # dominant kernel: the fused WENO5 momentum-tendency launch, timed live with events on the launching stream
+    local_cells = grid.Nx * grid.Ny * grid.Nz
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    ocn.compute_tendencies(model)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ocn.compute_tendencies(model)
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / reps
+    achieved = TENDENCY_BYTES_PER_CELL * local_cells / (kern_ms * 1e-3) / 1e9
+
+    value = N ** 3 * a.steps / el
+    out = {
+        "metric": "cell-updates/sec (whole node), 512^3 NonhydrostaticModel WENO5, 1/2/4/8 GPU",
+        "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{N}^3 triply-periodic NonhydrostaticModel, WENO5, RK3, FFTBasedPoissonSolver, fp64",
+                   "grid": [N, N, N], "halo": 3, "math": a.math, "partition": f"x-slab/{world}", "finite": finite},
+        "roofline": {"bound": "hbm", "kernel": "momentum_tendencies (fused compute_Gu/Gv/Gw, WENO5)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL},
+        "step_roofline": {"algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
+                          "achieved_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,
+                          "frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world)},
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+/*
+ * ocn_hip.h -- C ABI of libocn_hip.so, the MI355X (gfx950) implementation of the
+ * NonhydrostaticModel time-stepping hot path of Oceananigans.jl (v0.96.19).
+ *
+ * The reference has no C plugin API: a backend plugs in by Julia multiple dispatch on the
+ * architecture / array type (pattern: ext/OceananigansMetalExt.jl:11-35).  Each entry point
+ * below replaces the `launch!(arch, grid, workspec, kernel!, args...)` of one reference
+ * kernel (src/Utils/kernel_launching.jl:258-302) or one solver call, and takes exactly what
+ * that kernel takes: parent-array device pointers, the grid description, scalars.  The
+ * Julia-side `ccall` bindings a maintainer would add are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Every function returns OCN_SUCCESS (0) or a negative status; ocn_last_error() returns a
+ *    thread-local message (the Julia wrapper rethrows it as ArgumentError / ErrorException).
+ *    The library never aborts and never falls back to a CPU path.
+ *  - All pointers are DEVICE pointers to float64 unless stated.  Arrays are the OffsetArray
+ *    *parents* of the reference (src/Grids/new_data.jl:36-70): column-major, x fastest, halos
+ *    included.  Parent extent per dimension: N+2H, or N+1+2H for a Face-located field in a
+ *    Bounded dimension (src/Grids/grid_utils.jl:66-72).  Flat dimensions have N=1, H=0.
+ *  - Ownership: the caller owns every array; the library keeps no pointer past a call except
+ *    inside explicit handles (ocn_poisson_t, ocn_model_t), mirroring the reference's plans which
+ *    capture `storage` (src/Solvers/fft_based_poisson_solver.jl:65-67).
+ *  - Ordering: work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream) and is asynchronous w.r.t. the host, like KernelAbstractions launches
+ *    (src/Utils/kernel_launching.jl:252-253).  One host thread per handle.
+ *  - Supported scope: RectilinearGrid, x and y regular, z regular or stretched;
+ *    topologies (Periodic,Periodic,{Periodic,Bounded,Flat}); Float64.
+ */
+#ifndef OCN_HIP_H
+#define OCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCN_SUCCESS 0
+#define OCN_ERR_INVALID_ARGUMENT (-1)
+#define OCN_ERR_UNSUPPORTED (-2)
+#define OCN_ERR_HIP (-3)
+#define OCN_ERR_ROCFFT (-4)
+#define OCN_ERR_ALLOC (-5)
+
+/* topology codes: src/Grids/Grids.jl Periodic / Bounded / Flat */
+#define OCN_PERIODIC 0
+#define OCN_BOUNDED 1
+#define OCN_FLAT 2
+/* x-partitioned local grid (src/DistributedComputations/distributed_grids.jl:339-346
+ * turns Periodic into FullyConnected): halos come from neighbour ranks, interior
+ * arithmetic identical to Periodic. */
+#define OCN_FULLY_CONNECTED 3
+
+/* field location bitmask: bit0 = Face in x, bit1 = Face in y, bit2 = Face in z */
+#define OCN_LOC_CCC 0
+#define OCN_LOC_FCC 1 /* u */
+#define OCN_LOC_CFC 2 /* v */
+#define OCN_LOC_CCF 4 /* w */
+
+/* math modes for the WENO tendency kernels (see ocn_set_math_mode) */
+#define OCN_MATH_STRICT 0 /* reference evaluation order, no FMA contraction, IEEE division */
+#define OCN_MATH_FAST 1   /* algebraically identical, FMA + fused-division form */
+
+/* RectilinearGrid (src/Grids/rectilinear_grid.jl:1-23) reduced to what kernels read. */
+typedef struct ocn_grid {
+    int32_t Nx, Ny, Nz;  /* interior size */
+    int32_t Hx, Hy, Hz;  /* halo size */
+    int32_t tx, ty, tz;  /* topology codes */
+    int32_t _pad;
+    double dx, dy, dz;   /* regular spacings (Flat: 1.0); dz ignored when dzc != NULL */
+    double Lx, Ly, Lz;   /* domain extents grid.Lx/Ly/Lz (Flat: 1.0), used by poisson_eigenvalues */
+    const double *dzc;   /* DEVICE: Δzᵃᵃᶜ[k], element 0 <-> k = 1-Hz, length Nz+2Hz; NULL if z regular */
+    const double *dzf;   /* DEVICE: Δzᵃᵃᶠ[k], element 0 <-> k = 1-Hz, length Nz+2Hz; NULL if z regular */
+} ocn_grid;
+
+const char *ocn_last_error(void);
+const char *ocn_version(void);
+
+/* ---- Architectures (src/Architectures.jl:70-146; zeros(arch,...) src/Grids/zeros_and_ones.jl:9;
+ *      sync_device! src/Utils/multi_region_transformation.jl:183-186) ---- */
+int ocn_device_count(int *count);
+int ocn_set_device(int device);
+int ocn_malloc(void **ptr, size_t bytes);            /* zero-initialised, like the reference's zeros() */
+int ocn_free(void *ptr);                             /* unsafe_free! */
+int ocn_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* device_copy_to! */
+int ocn_memset(void *ptr, int value, size_t bytes, void *stream);
+int ocn_sync(void *stream);                          /* sync_device! */
+
+/* Selects the arithmetic variant used by ocn_compute_momentum_tendencies / _tracer_tendency. */
+int ocn_set_math_mode(int mode);
+int ocn_get_math_mode(void);
+
+/* ---- Halo fills: fill_halo_regions! (src/BoundaryConditions/fill_halo_regions.jl:50-67) with the
+ *      default boundary conditions of src/BoundaryConditions/field_boundary_conditions.jl:15-33.
+ *      `fields`/`locs` are HOST arrays of n device pointers / location masks (the tupled fill of
+ *      src/Fields/field_tuples.jl:56-101).  Per field and direction: Periodic -> periodic copy over the
+ *      whole parent cross-section (fill_halo_regions_periodic.jl:40-71); Bounded & Center-located ->
+ *      no-flux mirror of one cell (fill_halo_regions_flux.jl:14-33); Bounded & Face-located -> the
+ *      wall-normal velocity on both boundary faces is set to 0 iff fill_boundary_normal_velocities
+ *      (fill_halo_regions_open.jl:9-70).  Non-periodic fills run before periodic ones
+ *      (fill_halo_regions.jl:148-196).  FullyConnected directions are skipped (communication). ---- */
+int ocn_fill_halo_regions(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n,
+                          int32_t fill_boundary_normal_velocities, void *stream);
+/* single-direction periodic fill, K18 (dir 0/1/2) */
+int ocn_fill_halo_periodic(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, int32_t dir,
+                           void *stream);
+
+/* ---- Tendencies: compute_Gu!/Gv!/Gw! fused (src/Models/NonhydrostaticModels/
+ *      compute_nonhydrostatic_tendencies.jl:57-179, nonhydrostatic_tendency_kernel_functions.jl:47-200)
+ *      for advection = WENO() (5th order), every other term `nothing`.
+ *      range = NULL -> launch!(..., :xyz; exclude_periphery=true); otherwise range[6] =
+ *      {i0,i1,j0,j1,k0,k1} (1-based, inclusive) = KernelParameters, periphery NOT excluded
+ *      (kernel_launching.jl:236-240), used for the interior / buffer split of
+ *      src/Models/interleave_communication_and_computation.jl:29-67. ---- */
+int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                    double *Gv, double *Gw, const int32_t *range, void *stream);
+/* compute_Gc! (compute_nonhydrostatic_tendencies.jl:186-195; tracer_tendency :228-259) */
+int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w,
+                                const double *c, double *Gc, const int32_t *range, void *stream);
+
+/* ---- Time steppers ----
+ * rk3_substep_field! for n fields in one launch (src/TimeSteppers/runge_kutta_3.jl:160-208).
+ * has_zeta = 0 selects the first-stage method  U += (Δt*γ)*Gⁿ. */
+int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn,
+                    const double *const *Gm, const int32_t *locs, double dt, double gamma, double zeta, int32_t has_zeta,
+                    void *stream);
+/* ab2_step_field! (src/TimeSteppers/quasi_adams_bashforth_2.jl:128-175) */
+int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
+                 const int32_t *locs, double dt, double chi, void *stream);
+/* cache_previous_tendencies! (src/TimeSteppers/store_tendencies.jl:6-22) */
+int ocn_cache_previous_tendencies(const ocn_grid *grid, int32_t n, double *const *Gm, const double *const *Gn,
+                                  const int32_t *locs, void *stream);
+
+/* ---- Pressure ----
+ * _pressure_correct_velocities! (src/Models/NonhydrostaticModels/pressure_correction.jl:31-50) */
+int ocn_pressure_correct_velocities(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt,
+                                    void *stream);
+/* divᶜᶜᶜ into a halo-free Nx*Ny*Nz array (src/Operators/divergence_operators.jl:16-19) */
+int ocn_divergence(const ocn_grid *grid, const double *u, const double *v, const double *w, double *div, void *stream);
+
+/* Poisson solver handle = FFTBasedPoissonSolver (src/Solvers/fft_based_poisson_solver.jl:5-125) when z is
+ * regular and Periodic/Flat, FourierTridiagonalPoissonSolver (fourier_tridiagonal_poisson_solver.jl:6-147)
+ * when z is Bounded (regular or stretched) -- the dispatch of
+ * src/Models/NonhydrostaticModels/NonhydrostaticModels.jl:25-62.  The handle owns its storage and rocFFT plans. */
+typedef struct ocn_poisson *ocn_poisson_t;
+int ocn_poisson_create(ocn_poisson_t *solver, const ocn_grid *grid);
+int ocn_poisson_destroy(ocn_poisson_t solver);
+/* compute_source_term! (src/Models/NonhydrostaticModels/solve_for_pressure.jl:12-17,33-38,57-76) */
+int ocn_poisson_compute_source_term(ocn_poisson_t solver, const double *u, const double *v, const double *w, double dt,
+                                    void *stream);
+/* set the source term from a halo-free real Nx*Ny*Nz array R (tests: ∇²ϕ = R;
+ * set_source_term! fourier_tridiagonal_poisson_solver.jl:155-161 applies Δzᶜ) */
+int ocn_poisson_set_source_term(ocn_poisson_t solver, const double *R, void *stream);
+/* solve!(ϕ, solver): writes the interior of the haloed pressure field p (fft_based_poisson_solver.jl:95-125) */
+int ocn_poisson_solve(ocn_poisson_t solver, double *p, void *stream);
+/* solve_for_pressure! = source term + solve (solve_for_pressure.jl:78-82) */
+int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, const double *v, const double *w, double dt,
+                           void *stream);
+
+/* solve!(ϕ, ::BatchedTridiagonalSolver, rhs), z direction (src/Solvers/batched_tridiagonal_solver.jl:100-123,
+ * 203-235).  a, c: real Nz-1; b: real Nx*Ny*Nz; f, phi: complex interleaved Nx*Ny*Nz; t: real scratch. */
+int ocn_batched_tridiagonal_solve_z(int32_t Nx, int32_t Ny, int32_t Nz, const double *a, const double *b, const double *c,
+                                    const double *f, double *t, double *phi, void *stream);
+
+/* ---- Distributed slab-x support (src/DistributedComputations/) ----
+ * Halo staging buffers (src/Fields/field_boundary_buffers.jl:276-308): pack send-west = parent[1+Hx:2Hx,:,:],
+ * send-east = parent[1+nx:nx+Hx,:,:] into dense (Hx, sy, sz) buffers; unpack recv-west -> parent[1:Hx,:,:],
+ * recv-east -> parent[1+nx+Hx:nx+2Hx,:,:]. */
+int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, double *send_west, double *send_east,
+                    void *stream);
+int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const double *recv_west, const double *recv_east,
+                      void *stream);
+/* Transposes between the y-local layout (nx, Ny, Nz) and the x-local layout (Nx, ny, Nz) of complex data
+ * (src/DistributedComputations/distributed_transpose.jl:25-95), R = number of ranks:
+ * pack_y_to_x fills the send buffer (chunk m = j in [m*ny, (m+1)*ny)), unpack_x_from_y reads the received one. */
+int ocn_transpose_pack_y_to_x(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *yfield, double *send,
+                              void *stream);
+int ocn_transpose_unpack_x_from_y(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *recv, double *xfield,
+                                  void *stream);
+int ocn_transpose_pack_x_to_y(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *xfield, double *send,
+                              void *stream);
+int ocn_transpose_unpack_y_from_x(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *recv, double *yfield,
+                                  void *stream);
+
+/* Distributed FFT-based Poisson solver pieces (distributed_fft_based_poisson_solver.jl:141-178), slab-x:
+ * the handle plans  FFT_z,FFT_y on (nx,Ny,Nz)  and  FFT_x on (Nx,ny,Nz); the host moves data between the
+ * two layouts with the transposes above and an all-to-all. */
+typedef struct ocn_dist_poisson *ocn_dist_poisson_t;
+int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, const ocn_grid *local_grid, int32_t rank, int32_t nranks);
+int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
+/* device pointers to the solver's y-local field, x-local field and the two transpose buffers */
+int ocn_dist_poisson_buffers(ocn_dist_poisson_t solver, double **yfield, double **xfield, double **send, double **recv);
+int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w, double dt,
+                                 void *stream);
+int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver, void *stream);
+int ocn_dist_poisson_solve_x(ocn_dist_poisson_t solver, void *stream); /* FFT_x, divide by eigenvalues, IFFT_x */
+int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCN_HIP_H */

@@ -1,0 +1,24 @@
+"""oceananigans.jl_amd -- MI355X-native NonhydrostaticModel time-stepping hot path of Oceananigans.jl.
+
+Host-side mirror of the reference's operator surface (Architectures / Grids / Fields / Advection / Solvers /
+TimeSteppers / Models.NonhydrostaticModels / DistributedComputations) over the C ABI of libocn_hip.so.
+The directory name contains a dot, so import it through the root-level shim:
+
+    import oceananigans_jl_amd as ocn
+"""
+from . import _lib
+from ._lib import MATH_FAST, MATH_STRICT, OcnError
+from .advection import WENO
+from .architectures import CPU, GPU, on_architecture, sync_device, zeros
+from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
+from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
+from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,
+                     cache_previous_tendencies, calculate_pressure_correction, compute_tendencies,
+                     pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_state)
+from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver,
+                      nonhydrostatic_pressure_solver, solve)
+
+
+def set_math_mode(mode):
+    """MATH_STRICT: reference evaluation order (bit-reproducible vs the CPU oracle); MATH_FAST: FMA + fused division."""
+    _lib.call("ocn_set_math_mode", int(mode))

@@ -1,0 +1,111 @@
+"""ctypes binding of libocn_hip.so (include/ocn_hip.h).
+
+The HIP library is the only compute path of this package: if it is missing or a call fails
+we raise -- there is no CPU / PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libocn_hip.so")
+
+OCN_PERIODIC, OCN_BOUNDED, OCN_FLAT, OCN_FULLY_CONNECTED = 0, 1, 2, 3
+LOC_CCC, LOC_FCC, LOC_CFC, LOC_CCF = 0, 1, 2, 4
+MATH_STRICT, MATH_FAST = 0, 1
+
+
+class OcnError(RuntimeError):
+    pass
+
+
+class CGrid(C.Structure):
+    """struct ocn_grid (include/ocn_hip.h)"""
+    _fields_ = [("Nx", C.c_int32), ("Ny", C.c_int32), ("Nz", C.c_int32),
+                ("Hx", C.c_int32), ("Hy", C.c_int32), ("Hz", C.c_int32),
+                ("tx", C.c_int32), ("ty", C.c_int32), ("tz", C.c_int32), ("_pad", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("Lx", C.c_double), ("Ly", C.c_double), ("Lz", C.c_double),
+                ("dzc", C.c_void_p), ("dzf", C.c_void_p)]
+
+
+_lib = None
+
+_vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
+_SIGS = {
+    "ocn_device_count": [C.POINTER(C.c_int)],
+    "ocn_set_device": [C.c_int],
+    "ocn_malloc": [C.POINTER(_vp), C.c_size_t],
+    "ocn_free": [_vp],
+    "ocn_memcpy_h2d": [_vp, _vp, C.c_size_t, _vp],
+    "ocn_memcpy_d2h": [_vp, _vp, C.c_size_t, _vp],
+    "ocn_memcpy_d2d": [_vp, _vp, C.c_size_t, _vp],
+    "ocn_memset": [_vp, C.c_int, C.c_size_t, _vp],
+    "ocn_sync": [_vp],
+    "ocn_set_math_mode": [C.c_int],
+    "ocn_fill_halo_regions": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, _vp],
+    "ocn_fill_halo_periodic": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, _vp],
+    "ocn_compute_momentum_tendencies": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_tracer_tendency": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _i32, _vp],
+    "ocn_ab2_step": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _vp],
+    "ocn_cache_previous_tendencies": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _vp],
+    "ocn_pressure_correct_velocities": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_divergence": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
+    "ocn_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid)],
+    "ocn_poisson_destroy": [_vp],
+    "ocn_poisson_compute_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_poisson_set_source_term": [_vp, _vp, _vp],
+    "ocn_poisson_solve": [_vp, _vp, _vp],
+    "ocn_solve_for_pressure": [_vp, _vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_batched_tridiagonal_solve_z": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_halo_pack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
+    "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
+    "ocn_transpose_pack_y_to_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ocn_transpose_unpack_x_from_y": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ocn_transpose_pack_x_to_y": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ocn_transpose_unpack_y_from_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ocn_dist_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid), _i32, _i32],
+    "ocn_dist_poisson_destroy": [_vp],
+    "ocn_dist_poisson_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "ocn_dist_poisson_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_dist_poisson_forward_yz": [_vp, _vp],
+    "ocn_dist_poisson_solve_x": [_vp, _vp],
+    "ocn_dist_poisson_backward_yz": [_vp, _vp, _vp],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ocn_last_error", "ocn_version", "ocn_get_math_mode"])
+
+
+def lib():
+    """Load libocn_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OcnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C oceananigans.jl_amd/csrc`). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.ocn_last_error.restype = C.c_char_p
+        L.ocn_version.restype = C.c_char_p
+        L.ocn_get_math_mode.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise OcnError(f"libocn_hip error {status}: {lib().ocn_last_error().decode()}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def i32_array(vals):
+    return (C.c_int32 * len(vals))(*vals)

@@ -1,0 +1,316 @@
+// capi.hip -- extern "C" entry points of libocn_hip.so (see include/ocn_hip.h for the contract).
+#include <cstring>
+#include <string>
+
+#include "ocn_internal.h"
+
+namespace ocn {
+
+static thread_local std::string g_last_error;
+static int g_math_mode = OCN_MATH_STRICT;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int validate_grid(const ocn_grid *g)
+{
+    OCN_REQUIRE(g != nullptr, "grid is NULL");
+    OCN_REQUIRE(g->Nx >= 1 && g->Ny >= 1 && g->Nz >= 1, "grid size must be positive, got (%d, %d, %d)", g->Nx, g->Ny, g->Nz);
+    OCN_REQUIRE(g->Hx >= 0 && g->Hy >= 0 && g->Hz >= 0, "negative halo");
+    const int t[3] = {g->tx, g->ty, g->tz};
+    const int N[3] = {g->Nx, g->Ny, g->Nz};
+    const int H[3] = {g->Hx, g->Hy, g->Hz};
+    for (int d = 0; d < 3; ++d) {
+        OCN_REQUIRE(t[d] >= OCN_PERIODIC && t[d] <= OCN_FULLY_CONNECTED, "unknown topology code %d", t[d]);
+        if (t[d] == OCN_FLAT) OCN_REQUIRE(N[d] == 1 && H[d] == 0, "Flat dimension %d must have N = 1, H = 0", d);
+        // halo must not exceed the interior (Grids/input_validation.jl: halo <= size)
+        if (t[d] != OCN_FLAT) OCN_REQUIRE(H[d] <= N[d], "halo %d larger than size %d in dimension %d", H[d], N[d], d);
+    }
+    if (!(g->tx == OCN_PERIODIC || g->tx == OCN_FULLY_CONNECTED) || g->ty != OCN_PERIODIC) {
+        set_error("unsupported topology (%d, %d, %d): x must be Periodic (or FullyConnected), y Periodic", g->tx, g->ty, g->tz);
+        return OCN_ERR_UNSUPPORTED;
+    }
+    if (g->tz == OCN_FULLY_CONNECTED) {
+        set_error("z is never partitioned (distributed_architectures.jl:223-225)");
+        return OCN_ERR_UNSUPPORTED;
+    }
+    OCN_REQUIRE((g->dzc == nullptr) == (g->dzf == nullptr), "dzc and dzf must both be set or both be NULL");
+    OCN_REQUIRE(g->dx > 0 && g->dy > 0 && (g->dzc || g->dz > 0), "spacings must be positive");
+    return OCN_SUCCESS;
+}
+
+// WENO5 reads 3 halo cells (nonhydrostatic_model.jl:183, 243-257 inflates the halo to >= 3)
+static int validate_weno(const ocn_grid *g)
+{
+    int st = validate_grid(g);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(g->Hx >= 3 && g->Hy >= 3 && (g->tz == OCN_FLAT || g->Hz >= 3), "WENO(order=5) needs halo >= 3, got (%d, %d, %d)", g->Hx, g->Hy, g->Hz);
+    OCN_REQUIRE(g->Nx >= 3 && g->Ny >= 3 && (g->tz == OCN_FLAT || g->Nz >= 3),
+                "grid too small for WENO(order=5): adapt_advection_order would lower the order (adapt_advection_order.jl:101-108)");
+    return OCN_SUCCESS;
+}
+
+}  // namespace ocn
+
+using namespace ocn;
+
+extern "C" {
+
+const char *ocn_last_error(void) { return g_last_error.c_str(); }
+const char *ocn_version(void) { return "libocn_hip 0.1 (gfx950)"; }
+
+int ocn_device_count(int *count)
+{
+    OCN_REQUIRE(count, "count is NULL");
+    OCN_CHECK_HIP(hipGetDeviceCount(count));
+    return OCN_SUCCESS;
+}
+int ocn_set_device(int device)
+{
+    OCN_CHECK_HIP(hipSetDevice(device));
+    return OCN_SUCCESS;
+}
+int ocn_malloc(void **ptr, size_t bytes)
+{
+    OCN_REQUIRE(ptr, "ptr is NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return OCN_SUCCESS;
+    hipError_t e = hipMalloc(ptr, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return OCN_ERR_ALLOC;
+    }
+    OCN_CHECK_HIP(hipMemset(*ptr, 0, bytes));
+    return OCN_SUCCESS;
+}
+int ocn_free(void *ptr)
+{
+    if (ptr) OCN_CHECK_HIP(hipFree(ptr));
+    return OCN_SUCCESS;
+}
+int ocn_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    OCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    OCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return OCN_SUCCESS;
+}
+int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    OCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    OCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return OCN_SUCCESS;
+}
+int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    OCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return OCN_SUCCESS;
+}
+int ocn_memset(void *ptr, int value, size_t bytes, void *stream)
+{
+    OCN_CHECK_HIP(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+    return OCN_SUCCESS;
+}
+int ocn_sync(void *stream)
+{
+    OCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return OCN_SUCCESS;
+}
+
+int ocn_set_math_mode(int mode)
+{
+    OCN_REQUIRE(mode == OCN_MATH_STRICT || mode == OCN_MATH_FAST, "unknown math mode %d", mode);
+    g_math_mode = mode;
+    return OCN_SUCCESS;
+}
+int ocn_get_math_mode(void) { return g_math_mode; }
+
+static int make_field_tuple(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, FieldTuple &ft)
+{
+    OCN_REQUIRE(fields && locs, "fields/locs is NULL");
+    OCN_REQUIRE(n >= 1 && n <= MAX_TUPLE, "number of fields %d outside 1..%d", n, MAX_TUPLE);
+    ft.n = n;
+    for (int f = 0; f < n; ++f) {
+        OCN_REQUIRE(fields[f] != nullptr, "field %d is NULL", f);
+        OCN_REQUIRE(locs[f] == OCN_LOC_CCC || locs[f] == OCN_LOC_FCC || locs[f] == OCN_LOC_CFC || locs[f] == OCN_LOC_CCF,
+                    "field %d has unsupported location mask %d", f, locs[f]);
+        ft.f[f] = fields[f];
+        ft.loc[f] = locs[f];
+    }
+    (void)grid;
+    return OCN_SUCCESS;
+}
+
+int ocn_fill_halo_regions(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n,
+                          int32_t fill_boundary_normal_velocities, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    FieldTuple ft;
+    st = make_field_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    return launch_fill_halos(grid, ft, fill_boundary_normal_velocities, -1, as_stream(stream));
+}
+
+int ocn_fill_halo_periodic(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, int32_t dir, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(dir >= 0 && dir <= 2, "dir must be 0, 1 or 2");
+    const int t = dir == 0 ? grid->tx : dir == 1 ? grid->ty : grid->tz;
+    OCN_REQUIRE(t == OCN_PERIODIC, "direction %d is not Periodic", dir);
+    FieldTuple ft;
+    st = make_field_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    return launch_fill_halos(grid, ft, 0, dir, as_stream(stream));
+}
+
+int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                    double *Gv, double *Gw, const int32_t *range, void *stream)
+{
+    int st = validate_weno(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies: null field pointer");
+    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
+    return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
+}
+
+int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                                double *Gc, const int32_t *range, void *stream)
+{
+    int st = validate_weno(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency: null field pointer");
+    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
+    return ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
+}
+
+static int make_step_tuple(int32_t n, double *const *U, const double *const *Gn, double *const *Gm, const int32_t *locs,
+                           bool needU, StepTuple &t)
+{
+    OCN_REQUIRE(n >= 1 && n <= MAX_TUPLE, "number of fields %d outside 1..%d", n, MAX_TUPLE);
+    OCN_REQUIRE(Gn && Gm && locs && (U || !needU), "null tuple pointer");
+    t.n = n;
+    for (int f = 0; f < n; ++f) {
+        OCN_REQUIRE(Gn[f] && Gm[f] && (!needU || U[f]), "field %d: null pointer", f);
+        t.U[f] = needU ? U[f] : nullptr;
+        t.Gn[f] = Gn[f];
+        t.Gm[f] = Gm[f];
+        t.loc[f] = locs[f];
+    }
+    return OCN_SUCCESS;
+}
+
+int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
+                    const int32_t *locs, double dt, double gamma, double zeta, int32_t has_zeta, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    StepTuple t;
+    st = make_step_tuple(n, U, Gn, const_cast<double *const *>(reinterpret_cast<const double *const *>(Gm)), locs, true, t);
+    if (st != OCN_SUCCESS) return st;
+    return launch_stepper(grid, t, has_zeta ? 1 : 0, dt, gamma, zeta, as_stream(stream));
+}
+
+int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
+                 const int32_t *locs, double dt, double chi, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    StepTuple t;
+    st = make_step_tuple(n, U, Gn, const_cast<double *const *>(reinterpret_cast<const double *const *>(Gm)), locs, true, t);
+    if (st != OCN_SUCCESS) return st;
+    const double not_euler = (chi != -0.5) ? 1.0 : 0.0;
+    return launch_stepper(grid, t, 2, dt, chi, not_euler, as_stream(stream));
+}
+
+int ocn_cache_previous_tendencies(const ocn_grid *grid, int32_t n, double *const *Gm, const double *const *Gn,
+                                  const int32_t *locs, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    StepTuple t;
+    st = make_step_tuple(n, nullptr, Gn, Gm, locs, false, t);
+    if (st != OCN_SUCCESS) return st;
+    return launch_stepper(grid, t, 3, 0.0, 0.0, 0.0, as_stream(stream));
+}
+
+int ocn_pressure_correct_velocities(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && p, "ocn_pressure_correct_velocities: null field pointer");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "pressure correction needs halo >= 1");
+    return launch_pressure_correct(grid, u, v, w, p, dt, as_stream(stream));
+}
+
+int ocn_divergence(const ocn_grid *grid, const double *u, const double *v, const double *w, double *div, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && div, "ocn_divergence: null pointer");
+    return launch_source_term(grid, u, v, w, 1.0, 0, div, grid->Nx, (long long)grid->Nx * grid->Ny, as_stream(stream));
+}
+
+int ocn_batched_tridiagonal_solve_z(int32_t Nx, int32_t Ny, int32_t Nz, const double *a, const double *b, const double *c,
+                                    const double *f, double *t, double *phi, void *stream)
+{
+    OCN_REQUIRE(Nx >= 1 && Ny >= 1 && Nz >= 1, "bad sizes (%d, %d, %d)", Nx, Ny, Nz);
+    OCN_REQUIRE(a && b && c && f && t && phi, "ocn_batched_tridiagonal_solve_z: null pointer");
+    return launch_tridiag_z(Nx, Ny, Nz, a, b, c, f, t, phi, as_stream(stream));
+}
+
+int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, double *send_west, double *send_east, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(field && send_west && send_east, "ocn_halo_pack_x: null pointer");
+    return launch_halo_pack_x(grid, field, loc, send_west, send_east, 0, as_stream(stream));
+}
+int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const double *recv_west, const double *recv_east, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(field && recv_west && recv_east, "ocn_halo_unpack_x: null pointer");
+    return launch_halo_pack_x(grid, field, loc, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
+}
+
+static int check_transpose(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const void *a, const void *b)
+{
+    OCN_REQUIRE(nx >= 1 && Ny >= 1 && Nz >= 1 && R >= 1, "bad transpose sizes");
+    OCN_REQUIRE(Ny % R == 0, "Ny = %d must be divisible by the number of ranks %d", Ny, R);
+    OCN_REQUIRE(a && b, "null transpose buffer");
+    return OCN_SUCCESS;
+}
+int ocn_transpose_pack_y_to_x(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *yfield, double *send, void *stream)
+{
+    int st = check_transpose(nx, Ny, Nz, R, yfield, send);
+    if (st != OCN_SUCCESS) return st;
+    return launch_transpose(0, nx, Ny, Nz, R, yfield, send, as_stream(stream));
+}
+int ocn_transpose_unpack_x_from_y(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *recv, double *xfield, void *stream)
+{
+    int st = check_transpose(nx, Ny, Nz, R, recv, xfield);
+    if (st != OCN_SUCCESS) return st;
+    return launch_transpose(1, nx, Ny, Nz, R, recv, xfield, as_stream(stream));
+}
+int ocn_transpose_pack_x_to_y(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *xfield, double *send, void *stream)
+{
+    int st = check_transpose(nx, Ny, Nz, R, xfield, send);
+    if (st != OCN_SUCCESS) return st;
+    return launch_transpose(2, nx, Ny, Nz, R, xfield, send, as_stream(stream));
+}
+int ocn_transpose_unpack_y_from_x(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const double *recv, double *yfield, void *stream)
+{
+    int st = check_transpose(nx, Ny, Nz, R, recv, yfield);
+    if (st != OCN_SUCCESS) return st;
+    return launch_transpose(3, nx, Ny, Nz, R, recv, yfield, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,505 @@
+// kernels.hip -- bandwidth-bound kernels of the NonhydrostaticModel step (K5-K9, K12-K19, K22-K23).
+// Compiled with -ffp-contract=off: these kernels are HBM-bound, so keeping the reference's
+// unfused evaluation order costs nothing and makes them bit-identical to the CPU oracle.
+#include "ocn_internal.h"
+
+namespace ocn {
+
+// ---------------------------------------------------------------------------------------------------
+// Halo fills (fill_halo_regions.jl:50-196, fill_halo_regions_periodic.jl:40-71,
+// fill_halo_regions_flux.jl:14-33, fill_halo_regions_open.jl:65-70)
+//
+// One launch fills every halo cell of every field of the tuple: each halo cell copies from the cell the
+// reference's ordered sequence (non-periodic fills first, then periodic fills over the whole parent
+// cross-section) would have propagated into it.  Source cells are never written by the same launch.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap1(int i, int N) { return i < 1 ? i + N : (i > N ? i - N : i); }
+
+template <int TZ>
+__global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a, int wrap_x, int only_dir)
+{
+    const int f = blockIdx.y;
+    double *__restrict__ c = a.f[f];
+    const int loc = a.loc[f];
+    const Lay L = make_lay(g, loc);
+    const int zface_b = (TZ == OCN_BOUNDED) && (loc & 4);
+    const int nzi = L.sz - 2 * g.Hz;  // planes that are not z-halo planes
+    const long long A = (long long)L.sx * L.sy * 2 * g.Hz;
+    const long long B = (long long)L.sx * 2 * g.Hy * nzi;
+    const long long Cn = wrap_x ? (long long)2 * g.Hx * g.Ny * nzi : 0;
+    const long long total = A + B + Cn;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        int I, J, K;  // 0-based parent coordinates
+        if (t < A) {
+            I = t % L.sx;
+            long long q = t / L.sx;
+            J = q % L.sy;
+            int kk = q / L.sy;  // 0..2Hz-1
+            K = kk < g.Hz ? kk : kk - g.Hz + (L.sz - g.Hz);
+        } else if (t < A + B) {
+            long long s = t - A;
+            I = s % L.sx;
+            long long q = s / L.sx;
+            int jj = q % (2 * g.Hy);
+            K = g.Hz + q / (2 * g.Hy);
+            J = jj < g.Hy ? jj : jj - g.Hy + (L.sy - g.Hy);
+        } else {
+            long long s = t - A - B;
+            int ii = s % (2 * g.Hx);
+            long long q = s / (2 * g.Hx);
+            J = g.Hy + q % g.Ny;
+            K = g.Hz + q / g.Ny;
+            I = ii < g.Hx ? ii : ii - g.Hx + (L.sx - g.Hx);
+        }
+        const int i = I - g.Hx + 1, j = J - g.Hy + 1, k = K - g.Hz + 1;
+        int si = i, sj = j, sk = k;
+        if (only_dir < 0 || only_dir == 0) si = wrap_x ? wrap1(i, g.Nx) : i;
+        if (only_dir < 0 || only_dir == 1) sj = wrap1(j, g.Ny);
+        if (only_dir < 0 || only_dir == 2) {
+            if (TZ == OCN_PERIODIC) sk = wrap1(k, g.Nz);
+            if (TZ == OCN_BOUNDED && !zface_b && only_dir < 0) sk = (k == 0) ? 1 : (k == g.Nz + 1 ? g.Nz : k);  // no-flux mirror
+        }
+        if (si == i && sj == j && sk == k) continue;
+        c[at(L, i, j, k)] = c[at(L, si, sj, sk)];
+    }
+}
+
+// Impenetrable walls: wall-normal velocity on both boundary faces <- 0 (fill_halo_regions_open.jl:65-70)
+__global__ void open_fill_z_kernel(GridDev g, double *__restrict__ w)
+{
+    const Lay L = make_lay(g, OCN_LOC_CCF);
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y;
+    if (i > g.Nx) return;
+    w[at(L, i, j, 1)] = 0.0;
+    w[at(L, i, j, g.Nz + 1)] = 0.0;
+}
+
+int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    if (open_fill && grid->tz == OCN_BOUNDED) {
+        for (int f = 0; f < ft.n; ++f)
+            if (ft.loc[f] == OCN_LOC_CCF)
+                hipLaunchKernelGGL(open_fill_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, stream, g, ft.f[f]);
+    }
+    const int wrap_x = (grid->tx == OCN_PERIODIC);
+    long long maxcells = 0;
+    for (int f = 0; f < ft.n; ++f) {
+        Lay L = make_lay(g, ft.loc[f]);
+        long long nzi = L.sz - 2 * g.Hz;
+        long long tot = (long long)L.sx * L.sy * 2 * g.Hz + (long long)L.sx * 2 * g.Hy * nzi + (wrap_x ? (long long)2 * g.Hx * g.Ny * nzi : 0);
+        if (tot > maxcells) maxcells = tot;
+    }
+    if (maxcells == 0) return OCN_SUCCESS;
+    long long nb = (maxcells + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    dim3 gridDim((unsigned)nb, ft.n);
+    switch (grid->tz) {
+        case OCN_PERIODIC: hipLaunchKernelGGL(fill_halos_kernel<OCN_PERIODIC>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
+        case OCN_BOUNDED: hipLaunchKernelGGL(fill_halos_kernel<OCN_BOUNDED>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
+        case OCN_FLAT: hipLaunchKernelGGL(fill_halos_kernel<OCN_FLAT>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
+        default: set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Time-stepper kernels (runge_kutta_3.jl:194-208, quasi_adams_bashforth_2.jl:162-175, store_tendencies.jl:6-9)
+// mode 0: rk3 first stage  U += (dt*gamma)*Gn
+// mode 1: rk3             U += dt*(gamma*Gn + zeta*Gm)
+// mode 2: ab2             U += dt*((1.5+chi)*Gn - (0.5+chi)*Gm*not_euler)   (c2 = not_euler)
+// mode 3: cache           Gm <- Gn   (U unused)
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, double dt, double c1, double c2)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+#pragma unroll 1
+    for (int f = 0; f < a.n; ++f) {
+        const int loc = a.loc[f];
+        // launch!(..., :xyz; exclude_periphery=true): Face in a Bounded dim starts at 2 (kernel_launching.jl:113-161)
+        if (MODE != 3 && (loc & 4) && g.tz == OCN_BOUNDED && g.Nz > 1 && k < 2) continue;
+        const Lay L = make_lay(g, loc);
+        const long long o = at(L, i, j, k);
+        if (MODE == 0) {
+            a.U[f][o] += (dt * c1) * a.Gn[f][o];
+        } else if (MODE == 1) {
+            a.U[f][o] += dt * (c1 * a.Gn[f][o] + c2 * a.Gm[f][o]);
+        } else if (MODE == 2) {
+            // `* not_euler` with a Julia Bool is a strong zero: 0.0 even when G⁻ holds NaN (quasi_adams_bashforth_2.jl:169)
+            const double G = (1.5 + c1) * a.Gn[f][o] - ((c2 != 0.0) ? (0.5 + c1) * a.Gm[f][o] : 0.0);
+            a.U[f][o] += dt * G;
+        } else {
+            a.Gm[f][o] = a.Gn[f][o];
+        }
+    }
+}
+
+int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1);
+    dim3 nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(stepper_kernel<0>, nb, block, 0, stream, g, st, dt, c1, c2); break;
+        case 1: hipLaunchKernelGGL(stepper_kernel<1>, nb, block, 0, stream, g, st, dt, c1, c2); break;
+        case 2: hipLaunchKernelGGL(stepper_kernel<2>, nb, block, 0, stream, g, st, dt, c1, c2); break;
+        default: hipLaunchKernelGGL(stepper_kernel<3>, nb, block, 0, stream, g, st, dt, c1, c2); break;
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pressure kernels
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dzC(const GridDev &g, int k) { return g.dzc ? g.dzc[k + g.Hz - 1] : g.dz; }
+__device__ __forceinline__ double dzF(const GridDev &g, int k) { return g.dzf ? g.dzf[k + g.Hz - 1] : g.dz; }
+
+// divᶜᶜᶜ (divergence_operators.jl:16-19): 1/V * (δx(Ax u) + δy(Ay v) + δz(Az w)); δ along Flat is 0
+__device__ __forceinline__ double div_ccc(const GridDev &g, const double *__restrict__ u, const double *__restrict__ v,
+                                          const double *__restrict__ w, const Lay &Lu, const Lay &Lv, const Lay &Lw, int i,
+                                          int j, int k)
+{
+    const double dzc = dzC(g, k);
+    const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
+    const double dxu = Ax * u[at(Lu, i + 1, j, k)] - Ax * u[at(Lu, i, j, k)];
+    const double dyv = Ay * v[at(Lv, i, j + 1, k)] - Ay * v[at(Lv, i, j, k)];
+    const double dzw = (g.tz == OCN_FLAT) ? 0.0 : Az * w[at(Lw, i, j, k + 1)] - Az * w[at(Lw, i, j, k)];
+    return (1 / (Az * dzc)) * ((dxu + dyv) + dzw);
+}
+
+// out_mode 0: real divergence; 1: complex rhs = div/dt (K8); 2: complex rhs = (dz*div)/dt (K9);
+//          3: real rhs = div/dt; 4: real rhs = (dz*div)/dt   (real-to-complex FFT path)
+template <int OUT>
+__global__ __launch_bounds__(256) void source_term_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                          const double *__restrict__ w, double dt, double *__restrict__ out,
+                                                          long long ld1, long long ld2)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay Lu = make_lay(g, OCN_LOC_FCC), Lv = make_lay(g, OCN_LOC_CFC), Lw = make_lay(g, OCN_LOC_CCF);
+    const double d = div_ccc(g, u, v, w, Lu, Lv, Lw, i, j, k);
+    const long long o = (i - 1) + ld1 * (j - 1) + ld2 * (k - 1);
+    if (OUT == 0) {
+        out[o] = d;
+    } else if (OUT == 1 || OUT == 2) {
+        const double r = (OUT == 2) ? (dzC(g, k) * d) / dt : d / dt;
+        reinterpret_cast<double2 *>(out)[o] = make_double2(r, 0.0);
+    } else {
+        out[o] = (OUT == 4) ? (dzC(g, k) * d) / dt : d / dt;
+    }
+}
+
+int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
+                       double *out, long long ld1, long long ld2, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1);
+    dim3 nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    switch (out_mode) {
+        case 0: hipLaunchKernelGGL(source_term_kernel<0>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+        case 1: hipLaunchKernelGGL(source_term_kernel<1>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+        case 2: hipLaunchKernelGGL(source_term_kernel<2>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+        case 3: hipLaunchKernelGGL(source_term_kernel<3>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+        default: hipLaunchKernelGGL(source_term_kernel<4>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// set_source_term!: storage <- R (real, halo-free) [* dz] widened to complex (or kept real)
+__global__ void set_source_kernel(int Nx, int Ny, int Nz, const double *__restrict__ R, const double *__restrict__ dzc, int Hz,
+                                  double *__restrict__ out, int complex_out, long long ld1, long long ld2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+    if (i >= Nx) return;
+    double r = R[i + (long long)Nx * (j + (long long)Ny * k)];
+    if (dzc) r = r * dzc[k + Hz];
+    const long long o = i + ld1 * j + ld2 * k;
+    if (complex_out)
+        reinterpret_cast<double2 *>(out)[o] = make_double2(r, 0.0);
+    else
+        out[o] = r;
+}
+int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc, int Hz, double *out, int complex_out,
+                      long long ld1, long long ld2, hipStream_t stream)
+{
+    hipLaunchKernelGGL(set_source_kernel, dim3((Nx + 63) / 64, Ny, Nz), dim3(64), 0, stream, Nx, Ny, Nz, R, dzc, Hz, out, complex_out, ld1, ld2);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// K12: phi_hat = -b_hat / ((lx + ly) + lz); zero mode <- 0 (fft_based_poisson_solver.jl:110-115).
+// nxh = number of stored x modes (Nx for C2C, Nx/2+1 for the Hermitian half spectrum).
+__global__ __launch_bounds__(256) void spectral_solve_kernel(int nxh, int Ny, int Nz, const double *__restrict__ lx,
+                                                             const double *__restrict__ ly, const double *__restrict__ lz,
+                                                             double2 *__restrict__ b, int zero_mode_here, int joff, int koff)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= nxh || j >= Ny) return;
+    const long long o = i + (long long)nxh * (j + (long long)Ny * k);
+    const double lam = (lx[i] + ly[j + joff]) + lz[k + koff];
+    double2 val = b[o];
+    val.x = -val.x / lam;
+    val.y = -val.y / lam;
+    if (zero_mode_here && i == 0 && j == 0 && k == 0) val = make_double2(0.0, 0.0);
+    b[o] = val;
+}
+int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
+                          int zero_mode_here, int joff, int koff, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spectral_solve_kernel, dim3((nxh + 63) / 64, (Ny + 3) / 4, Nz), dim3(64, 4), 0, stream, nxh, Ny, Nz, lx, ly,
+                       lz, reinterpret_cast<double2 *>(b), zero_mode_here, joff, koff);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// K13 copy_real_component! (fft_based_poisson_solver.jl:129-137)
+__global__ __launch_bounds__(256) void copy_real_kernel(GridDev g, const double2 *__restrict__ phi, double *__restrict__ p)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    p[at(L, i, j, k)] = phi[(i - 1) + (long long)g.Nx * ((j - 1) + (long long)g.Ny * (k - 1))].x;
+}
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    hipLaunchKernelGGL(copy_real_kernel, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz), dim3(64, 4), 0, stream, g,
+                       reinterpret_cast<const double2 *>(phi), p);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// K17 _pressure_correct_velocities! (pressure_correction.jl:31-37): :xyz over 1:N in every dimension
+__global__ __launch_bounds__(256) void pressure_correct_kernel(GridDev g, double *__restrict__ u, double *__restrict__ v,
+                                                               double *__restrict__ w, const double *__restrict__ p, double dt)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay Lu = make_lay(g, OCN_LOC_FCC), Lv = make_lay(g, OCN_LOC_CFC), Lw = make_lay(g, OCN_LOC_CCF),
+              Lp = make_lay(g, OCN_LOC_CCC);
+    const double pc = p[at(Lp, i, j, k)];
+    const double px = (pc - p[at(Lp, i - 1, j, k)]) / g.dx;
+    const double py = (pc - p[at(Lp, i, j - 1, k)]) / g.dy;
+    u[at(Lu, i, j, k)] -= px * dt;
+    v[at(Lv, i, j, k)] -= py * dt;
+    if (g.tz == OCN_FLAT) {
+        w[at(Lw, i, j, k)] -= 0.0 * dt;
+    } else {
+        const double pz = (pc - p[at(Lp, i, j, k - 1)]) / dzF(g, k);
+        w[at(Lw, i, j, k)] -= pz * dt;
+    }
+}
+int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    hipLaunchKernelGGL(pressure_correct_kernel, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz), dim3(64, 4), 0, stream, g, u, v, w, p, dt);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fourier-tridiagonal pieces
+// ---------------------------------------------------------------------------------------------------
+// K15 compute_main_diagonal! ZDirection (fourier_tridiagonal_poisson_solver.jl:41-51); nxh stored x modes
+__global__ void main_diagonal_kernel(GridDev g, int nxh, const double *__restrict__ lx, const double *__restrict__ ly,
+                                     double *__restrict__ D)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= nxh) return;
+    const double lam = lx[i] + ly[j];
+    const int Nz = g.Nz;
+    const long long s3 = (long long)nxh * g.Ny;
+    double *d = D + i + (long long)nxh * j;
+    d[0] = -1 / dzF(g, 2) - dzC(g, 1) * lam;
+    for (int k = 2; k <= Nz - 1; ++k) d[(k - 1) * s3] = -(1 / dzF(g, k + 1) + 1 / dzF(g, k)) - dzC(g, k) * lam;
+    d[(Nz - 1) * s3] = -1 / dzF(g, Nz) - dzC(g, Nz) * lam;
+}
+int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    hipLaunchKernelGGL(main_diagonal_kernel, dim3((nxh + 63) / 64, g.Ny), dim3(64), 0, stream, g, nxh, lx, ly, D);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// K14 solve_batched_tridiagonal_system_z! (batched_tridiagonal_solver.jl:209-235).  One thread per (i,j) column,
+// i across lanes so every k-plane access is coalesced; serial Thomas sweep in k.
+__global__ __launch_bounds__(64) void tridiag_z_kernel(int Nx, int Ny, int Nz, const double *__restrict__ a,
+                                                       const double *__restrict__ b, const double *__restrict__ c,
+                                                       const double2 *__restrict__ f, double *__restrict__ t,
+                                                       double2 *__restrict__ phi)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= Nx) return;
+    const long long s3 = (long long)Nx * Ny;
+    const long long o = i + (long long)Nx * j;
+    const double tiny = 10 * 2.220446049250313e-16;
+    double beta = b[o];
+    double2 prev = f[o];
+    prev.x = prev.x / beta;
+    prev.y = prev.y / beta;
+    phi[o] = prev;
+    for (int k = 1; k < Nz; ++k) {
+        const double ck = c[k - 1], ak = a[k - 1], bk = b[o + k * s3];
+        const double tk = ck / beta;
+        t[o + k * s3] = tk;
+        beta = bk - ak * tk;
+        const bool dd = fabs(beta) > tiny;
+        const double2 fk = f[o + k * s3];
+        double2 star;
+        star.x = (fk.x - ak * prev.x) / beta;
+        star.y = (fk.y - ak * prev.y) / beta;
+        if (dd) {
+            phi[o + k * s3] = star;
+            prev = star;
+        } else {
+            prev = phi[o + k * s3];  // keep what storage held (batched_tridiagonal_solver.jl:224-228)
+        }
+    }
+    for (int k = Nz - 2; k >= 0; --k) {
+        const double tk = t[o + (k + 1) * s3];
+        double2 cur = phi[o + k * s3];
+        cur.x -= tk * prev.x;
+        cur.y -= tk * prev.y;
+        phi[o + k * s3] = cur;
+        prev = cur;
+    }
+}
+int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
+                     double *phi, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tridiag_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, stream, Nx, Ny, Nz, a, b, c,
+                       reinterpret_cast<const double2 *>(f), t, reinterpret_cast<double2 *>(phi));
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// zero-mean gauge (fourier_tridiagonal_poisson_solver.jl:142) applied in spectral space: subtracting the volume
+// mean equals subtracting mean_k(phi_hat[0,0,k]) from the (kx,ky) = (0,0) column (the inverse transform carries
+// the 1/(Nx Ny) factor).  One block.
+__global__ void remove_mean_mode_kernel(long long s3, int Nz, double2 *__restrict__ phi)
+{
+    __shared__ double sre[256], sim[256];
+    double re = 0, im = 0;
+    for (int k = threadIdx.x; k < Nz; k += blockDim.x) {
+        re += phi[k * s3].x;
+        im += phi[k * s3].y;
+    }
+    sre[threadIdx.x] = re;
+    sim[threadIdx.x] = im;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            sre[threadIdx.x] += sre[threadIdx.x + s];
+            sim[threadIdx.x] += sim[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    const double mre = sre[0] / Nz, mim = sim[0] / Nz;
+    for (int k = threadIdx.x; k < Nz; k += blockDim.x) {
+        phi[k * s3].x -= mre;
+        phi[k * s3].y -= mim;
+    }
+}
+int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream)
+{
+    hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, stream, s3, Nz, reinterpret_cast<double2 *>(phi));
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Distributed slab-x staging (field_boundary_buffers.jl:276-308) and transposes (distributed_transpose.jl:25-95)
+// ---------------------------------------------------------------------------------------------------
+__global__ void halo_pack_x_kernel(int Hx, int nx, int sx, long long rows, const double *__restrict__ c,
+                                   double *__restrict__ west, double *__restrict__ east, int unpack)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * Hx) return;
+    const int h = t % Hx;
+    const long long row = t / Hx;
+    const double *crow = c + row * sx;
+    if (!unpack) {
+        west[t] = crow[Hx + h];  // parent[1+Hx : 2Hx]
+        east[t] = crow[nx + h];  // parent[1+nx : nx+Hx]
+    } else {
+        double *wrow = const_cast<double *>(crow);
+        wrow[h] = west[t];            // parent[1 : Hx]
+        wrow[nx + Hx + h] = east[t];  // parent[1+nx+Hx : nx+2Hx]
+    }
+}
+int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    Lay L = make_lay(g, loc);
+    long long rows = (long long)L.sy * L.sz;
+    long long n = rows * g.Hx;
+    hipLaunchKernelGGL(halo_pack_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g.Hx, g.Nx, L.sx, rows, field, west, east, unpack);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// y-local (nx,Ny,Nz) <-> x-local (Nx = R*nx, ny = Ny/R, Nz), complex.
+// mode 0 pack y->x : send[i + nx*(k + Nz*j)] = y[i,j,k]                          (:38-42)
+// mode 1 unpack x<-y: x[i,j,k] = recv[i' + nx*(k + Nz*j) + m*nx*ny*Nz], i = m*nx+i' (:51-60)
+// mode 2 pack x->y : send[j + ny*(k + Nz*i)] = x[i,j,k]                          (:31-35)
+// mode 3 unpack y<-x: y[i,j,k] = recv[j' + ny*(k + Nz*i) + m*nx*ny*Nz], j = m*ny+j' (:86-95)
+template <int MODE>
+__global__ __launch_bounds__(256) void transpose_kernel(int nx, int Ny, int Nz, int R, const double2 *__restrict__ src,
+                                                        double2 *__restrict__ dst)
+{
+    const int ny = Ny / R, Nx = nx * R;
+    const long long chunk = (long long)nx * ny * Nz;
+    if (MODE == 0 || MODE == 3) {  // thread over y-field (i fastest)
+        const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+        if (i >= nx) return;
+        const long long yo = i + (long long)nx * (j + (long long)Ny * k);
+        if (MODE == 0) {
+            dst[i + (long long)nx * (k + (long long)Nz * j)] = src[yo];
+        } else {
+            const int m = j / ny, jp = j - m * ny;
+            dst[yo] = src[jp + (long long)ny * (k + (long long)Nz * i) + m * chunk];
+        }
+    } else {  // thread over x-field
+        const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, k = blockIdx.z;
+        if (i >= Nx) return;
+        const long long xo = i + (long long)Nx * (j + (long long)ny * k);
+        if (MODE == 1) {
+            const int m = i / nx, ip = i - m * nx;
+            dst[xo] = src[ip + (long long)nx * (k + (long long)Nz * j) + m * chunk];
+        } else {
+            dst[j + (long long)ny * (k + (long long)Nz * i)] = src[xo];
+        }
+    }
+}
+int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src, double *dst, hipStream_t stream)
+{
+    const int ny = Ny / R, Nx = nx * R;
+    const double2 *s = reinterpret_cast<const double2 *>(src);
+    double2 *d = reinterpret_cast<double2 *>(dst);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(transpose_kernel<0>, dim3((nx + 63) / 64, Ny, Nz), dim3(64), 0, stream, nx, Ny, Nz, R, s, d); break;
+        case 3: hipLaunchKernelGGL(transpose_kernel<3>, dim3((nx + 63) / 64, Ny, Nz), dim3(64), 0, stream, nx, Ny, Nz, R, s, d); break;
+        case 1: hipLaunchKernelGGL(transpose_kernel<1>, dim3((Nx + 63) / 64, ny, Nz), dim3(64), 0, stream, nx, Ny, Nz, R, s, d); break;
+        default: hipLaunchKernelGGL(transpose_kernel<2>, dim3((Nx + 63) / 64, ny, Nz), dim3(64), 0, stream, nx, Ny, Nz, R, s, d); break;
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+}  // namespace ocn

@@ -1,0 +1,86 @@
+// ocn_common.h -- shared host/device helpers for libocn_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ocn_hip.h"
+
+namespace ocn {
+
+void set_error(const char *fmt, ...);
+
+#define OCN_CHECK_HIP(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ocn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OCN_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+#define OCN_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            ocn::set_error(__VA_ARGS__);      \
+            return OCN_ERR_INVALID_ARGUMENT;  \
+        }                                     \
+    } while (0)
+
+// Device-side copy of the grid, plus derived scalars.  Passed by value to kernels.
+struct GridDev {
+    int Nx, Ny, Nz, Hx, Hy, Hz, tx, ty, tz;
+    double dx, dy, dz;
+    const double *dzc, *dzf;
+};
+
+inline GridDev to_dev(const ocn_grid &g)
+{
+    GridDev d;
+    d.Nx = g.Nx; d.Ny = g.Ny; d.Nz = g.Nz;
+    d.Hx = g.Hx; d.Hy = g.Hy; d.Hz = g.Hz;
+    d.tx = g.tx == OCN_FULLY_CONNECTED ? OCN_PERIODIC : g.tx;  // interior arithmetic identical to Periodic
+    d.ty = g.ty; d.tz = g.tz;
+    d.dx = g.dx; d.dy = g.dy; d.dz = g.dz;
+    d.dzc = g.dzc; d.dzf = g.dzf;
+    return d;
+}
+
+// Parent-array layout of a field at location `loc` (bit0 x-face, bit1 y-face, bit2 z-face).
+struct Lay {
+    int sx, sy, sz;       // parent extents
+    long long s2, s3;     // strides of j and k
+    long long o;          // offset of interior (1,1,1)
+};
+
+__host__ __device__ inline int ocn_ext(int N, int H, int topo, int face)
+{
+    return N + 2 * H + ((face && topo == OCN_BOUNDED) ? 1 : 0);
+}
+
+template <class G>
+__host__ __device__ inline Lay make_lay(const G &g, int loc)
+{
+    Lay L;
+    L.sx = ocn_ext(g.Nx, g.Hx, g.tx, loc & 1);
+    L.sy = ocn_ext(g.Ny, g.Hy, g.ty, loc & 2);
+    L.sz = ocn_ext(g.Nz, g.Hz, g.tz, loc & 4);
+    L.s2 = L.sx;
+    L.s3 = (long long)L.sx * L.sy;
+    L.o = g.Hx + L.s2 * g.Hy + L.s3 * g.Hz;
+    return L;
+}
+// 1-based interior index -> parent offset
+__host__ __device__ inline long long at(const Lay &L, int i, int j, int k)
+{
+    return L.o + (i - 1) + L.s2 * (j - 1) + L.s3 * (k - 1);
+}
+
+int validate_grid(const ocn_grid *g);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace ocn

@@ -1,0 +1,52 @@
+// ocn_internal.h -- C++ launchers shared between the translation units of libocn_hip.
+#pragma once
+#include "ocn_common.h"
+
+namespace ocn {
+
+constexpr int MAX_TUPLE = 8;
+
+struct FieldTuple {
+    double *f[MAX_TUPLE];
+    int loc[MAX_TUPLE];
+    int n;
+};
+struct StepTuple {
+    double *U[MAX_TUPLE];
+    const double *Gn[MAX_TUPLE];
+    double *Gm[MAX_TUPLE];  // written by the cache mode, read otherwise
+    int loc[MAX_TUPLE];
+    int n;
+};
+
+int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream);
+int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);
+int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
+                       double *out, long long ld1, long long ld2, hipStream_t stream);
+int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc, int Hz, double *out, int complex_out,
+                      long long ld1, long long ld2, hipStream_t stream);
+int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
+                          int zero_mode_here, int joff, int koff, hipStream_t stream);
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream);
+int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream);
+int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);
+int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
+                     double *phi, hipStream_t stream);
+int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream);
+int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream);
+int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src, double *dst, hipStream_t stream);
+
+}  // namespace ocn
+
+namespace ocn_strict {
+int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                               double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                           double *Gc, const int32_t *range, hipStream_t stream);
+}
+namespace ocn_fast {
+int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                               double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                           double *Gc, const int32_t *range, hipStream_t stream);
+}

@@ -1,0 +1,166 @@
+// ocn_weno.h -- device arithmetic of the WENO5 flux-form momentum/tracer advection
+// (src/Advection/weno_interpolants.jl, centered_reconstruction.jl, upwind_biased_advective_fluxes.jl,
+// topologically_conditional_interpolation.jl).  Included by tendencies.hip, which is compiled
+// twice: OCN_STRICT=1 with -ffp-contract=off (reference evaluation order, bit-reproducible
+// against the CPU oracle) and OCN_STRICT=0 (FMA contraction + single-division weights).
+#pragma once
+#include "ocn_common.h"
+
+#ifndef OCN_STRICT
+#error "define OCN_STRICT to 0 or 1"
+#endif
+
+#if OCN_STRICT
+#define OCN_NS ocn_strict
+#else
+#define OCN_NS ocn_fast
+#endif
+
+namespace OCN_NS {
+
+// Reconstruction coefficients: stencil_coefficients (reconstruction_coefficients.jl:100-115) evaluated as
+// Julia does (Int/Int -> Float64 quotient, BigFloat accumulation, last = 1 - sum).  Same values as
+// oracle/coefficients.py generates; tests/test_library_constants.py compares them.
+#define OCN_C4_0 (-0.08333333333333326)
+#define OCN_C4_1 (0.5833333333333333)
+#define OCN_C4_2 (0.5833333333333333)
+#define OCN_C4_3 (-0.08333333333333333)
+
+#define OCN_W5P_00 (0.33333333333333337)
+#define OCN_W5P_01 (0.8333333333333334)
+#define OCN_W5P_02 (-0.16666666666666674)
+#define OCN_W5P_10 (-0.16666666666666669)
+#define OCN_W5P_11 (0.8333333333333333)
+#define OCN_W5P_12 (0.3333333333333335)
+#define OCN_W5P_20 (0.33333333333333326)
+#define OCN_W5P_21 (-1.1666666666666667)
+#define OCN_W5P_22 (1.8333333333333335)
+
+// const ε = 1f-8, widened to Float64 where used (weno_interpolants.jl:70)
+#define OCN_WENO_EPS (9.99999993922529e-09)
+
+#define OCN_C5_0 (3.0 / 10.0)
+#define OCN_C5_1 (3.0 / 5.0)
+#define OCN_C5_2 (1.0 / 10.0)
+#define OCN_C3_0 (2.0 / 3.0)
+#define OCN_C3_1 (1.0 / 3.0)
+
+// smoothness_operation for buffer 3 (weno_interpolants.jl:178-183, 213-225)
+__device__ __forceinline__ double beta3(double p0, double p1, double p2, double c0, double c1, double c2, double c3,
+                                        double c4, double c5)
+{
+    return p0 * ((c0 * p0 + c1 * p1) + c2 * p2) + p1 * (c3 * p1 + c4 * p2) + (p2 * p2) * c5;
+}
+
+// WENO5 reconstruction at a face from S = psi[n-3..n+2] (weno_interpolants.jl:341-348, 445-447, 475-511)
+__device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
+{
+    // left: psi0=(S2,S3,S4) psi1=(S1,S2,S3) psi2=(S0,S1,S2); right: psi0=(S3,S2,S1) psi1=(S4,S3,S2) psi2=(S5,S4,S3)
+    const double a0 = left ? S2 : S3, a1 = left ? S3 : S2, a2 = left ? S4 : S1;
+    const double b0 = left ? S1 : S4, b1 = left ? S2 : S3, b2 = left ? S3 : S2;
+    const double c0 = left ? S0 : S5, c1 = left ? S1 : S4, c2 = left ? S2 : S3;
+    const double be0 = beta3(a0, a1, a2, 10., -31., 11., 25., -19., 4.);
+    const double be1 = beta3(b0, b1, b2, 4., -13., 5., 13., -13., 4.);
+    const double be2 = beta3(c0, c1, c2, 4., -19., 11., 25., -31., 10.);
+    const double tau = fabs(be0 - be2);
+    const double p0 = (OCN_W5P_00 * a0 + OCN_W5P_01 * a1) + OCN_W5P_02 * a2;
+    const double p1 = (OCN_W5P_10 * b0 + OCN_W5P_11 * b1) + OCN_W5P_12 * b2;
+    const double p2 = (OCN_W5P_20 * c0 + OCN_W5P_21 * c1) + OCN_W5P_22 * c2;
+#if OCN_STRICT
+    const double q0 = tau / (be0 + OCN_WENO_EPS), q1 = tau / (be1 + OCN_WENO_EPS), q2 = tau / (be2 + OCN_WENO_EPS);
+    const double al0 = OCN_C5_0 * (1 + q0 * q0), al1 = OCN_C5_1 * (1 + q1 * q1), al2 = OCN_C5_2 * (1 + q2 * q2);
+    const double sa = (al0 + al1) + al2;
+    const double w0 = al0 / sa, w1 = al1 / sa, w2 = al2 / sa;
+    return (w0 * p0 + w1 * p1) + w2 * p2;
+#else
+    // Same rational function with ONE division: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = beta_r + eps;
+    // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2.
+    const double d0 = be0 + OCN_WENO_EPS, d1 = be1 + OCN_WENO_EPS, d2 = be2 + OCN_WENO_EPS;
+    const double t2 = tau * tau;
+    const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
+    const double n0 = OCN_C5_0 * (e0 + t2) * (e1 * e2);
+    const double n1 = OCN_C5_1 * (e1 + t2) * (e0 * e2);
+    const double n2 = OCN_C5_2 * (e2 + t2) * (e0 * e1);
+    return (n0 * p0 + n1 * p1 + n2 * p2) / (n0 + n1 + n2);
+#endif
+}
+
+// WENO3 (buffer scheme) from S = psi[n-2..n+1]
+__device__ __forceinline__ double weno3(double S0, double S1, double S2, double S3, bool left)
+{
+    const double a0 = left ? S1 : S2, a1 = left ? S2 : S1;
+    const double b0 = left ? S0 : S3, b1 = left ? S1 : S2;
+    const double be0 = a0 * (1. * a0 + -2. * a1) + (a1 * a1) * 1.;
+    const double be1 = b0 * (1. * b0 + -2. * b1) + (b1 * b1) * 1.;
+    const double tau = fabs(be0 - be1);
+    const double q0 = tau / (be0 + OCN_WENO_EPS), q1 = tau / (be1 + OCN_WENO_EPS);
+    const double al0 = OCN_C3_0 * (1 + q0 * q0), al1 = OCN_C3_1 * (1 + q1 * q1);
+    const double sa = al0 + al1;
+    const double w0 = al0 / sa, w1 = al1 / sa;
+    const double p0 = 0.5 * a0 + 0.5 * a1;
+    const double p1 = -0.5 * b0 + 1.5 * b1;
+    return w0 * p0 + w1 * p1;
+}
+
+__device__ __forceinline__ double centered4(double m2, double m1, double z0, double p1)
+{
+    return ((OCN_C4_0 * m2 + OCN_C4_1 * m1) + OCN_C4_2 * z0) + OCN_C4_3 * p1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Topology-conditional interpolation along one line (topologically_conditional_interpolation.jl:37-128).
+// `val(m)` returns the (metric-weighted) value at offset m from the face index n.
+// TOPO is the topology along the line; idx the index the reference tests (i, j or k of the call);
+// CENTER selects the *ᶜ variants (the caller has already shifted the line to face idx+1).
+// ---------------------------------------------------------------------------------------------------
+template <int TOPO, bool CENTER, class V>
+__device__ __forceinline__ double sym_interp(V val, int idx, int N)
+{
+    if (TOPO == OCN_FLAT) return val(CENTER ? -1 : 0);  // flat_advective_fluxes.jl:26-44
+    if (TOPO == OCN_BOUNDED) {
+        const bool hi = CENTER ? (idx >= 3 && idx <= N + 1 - 3) : (idx >= 4 && idx <= N + 1 - 3);  // :46-47, H = 3
+        if (!hi) return 0.5 * val(-1) + 0.5 * val(0);  // Centered(order=2) for every deeper fallback
+    }
+    return centered4(val(-2), val(-1), val(0), val(1));
+}
+
+template <int TOPO, bool CENTER, class V>
+__device__ __forceinline__ double bias_interp(V val, int idx, int N, bool left)
+{
+    if (TOPO == OCN_FLAT) return val(CENTER ? -1 : 0);
+    if (TOPO == OCN_BOUNDED) {
+        bool ok5, ok3;
+        if (CENTER) {  // outside_biased_haloᶜ :51-52 with H = 3 and H = 2
+            ok5 = (idx >= 3) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 2) && (idx <= N + 1 - 2);
+        } else {  // outside_biased_haloᶠ :49-50
+            ok5 = (idx >= 4) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 3) && (idx <= N + 1 - 2);
+        }
+        if (!ok5) {
+            if (ok3) return weno3(val(-2), val(-1), val(0), val(1), left);
+            return left ? val(-1) : val(0);  // UpwindBiased(order=1)
+        }
+    }
+    return weno5(val(-3), val(-2), val(-1), val(0), val(1), val(2), left);
+}
+
+// grid metrics at Center z-location (spacings_and_areas_and_volumes.jl:106-140, 263-345)
+struct Metrics {
+    double dx, dy, dz, Az;
+    const double *dzc, *dzf;
+    int Hz;
+    __device__ __forceinline__ double dzC(int k) const { return dzc ? dzc[k + Hz - 1] : dz; }
+    __device__ __forceinline__ double dzF(int k) const { return dzf ? dzf[k + Hz - 1] : dz; }
+    __device__ __forceinline__ double Ax(int k) const { return dy * dzC(k); }  // Axᶠᶜᶜ = Δy*Δz
+    __device__ __forceinline__ double Ay(int k) const { return dx * dzC(k); }  // Ayᶜᶠᶜ = Δx*Δz
+};
+__device__ __forceinline__ Metrics make_metrics(const ocn::GridDev &g)
+{
+    Metrics M;
+    M.dx = g.dx; M.dy = g.dy; M.dz = g.dz; M.Az = g.dx * g.dy;
+    M.dzc = g.dzc; M.dzf = g.dzf; M.Hz = g.Hz;
+    return M;
+}
+
+}  // namespace OCN_NS

@@ -1,0 +1,251 @@
+"""NonhydrostaticModel and its time steppers.
+
+Mirrors, call for call:
+  NonhydrostaticModel(; grid, advection, tracers, timestepper)   src/Models/NonhydrostaticModels/nonhydrostatic_model.jl:114-239
+  set!(model; u, v, w, ...)                                       .../set_nonhydrostatic_model.jl:33-60
+  update_state!(model; compute_tendencies)                        .../update_nonhydrostatic_model_state.jl:20-57
+  compute_tendencies!(model)                                      .../compute_nonhydrostatic_tendencies.jl:17-139
+  calculate_pressure_correction!, pressure_correct_velocities!    .../pressure_correction.jl:8-50
+  time_step!(model::RungeKutta3, Δt)                              src/TimeSteppers/runge_kutta_3.jl:77-151
+  time_step!(model::QuasiAdamsBashforth2, Δt)                     src/TimeSteppers/quasi_adams_bashforth_2.jl:74-115
+  cache_previous_tendencies!                                      src/TimeSteppers/store_tendencies.jl:12-22
+Julia's `f!` names are spelled `f` here.  closure, buoyancy, coriolis, forcing, stokes_drift are `nothing`
+(their zero fallbacks, e.g. src/TurbulenceClosures/.../nothing_closure.jl:1-10); asking for anything else raises.
+"""
+import math
+
+from . import _lib
+from .advection import WENO
+from .architectures import stream_ptr
+from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
+from .grids import Bounded, Flat
+from .solvers import nonhydrostatic_pressure_solver
+
+
+class Clock:
+    """src/TimeSteppers/clock.jl:16-22"""
+
+    def __init__(self):
+        self.time = 0.0
+        self.last_dt = math.inf
+        self.last_stage_dt = math.inf
+        self.iteration = 0
+        self.stage = 1
+
+
+class RungeKutta3TimeStepper:
+    """src/TimeSteppers/runge_kutta_3.jl:10-63; γ, ζ each rounded once to Float64."""
+
+    def __init__(self, grid, prognostic_fields):
+        self.g1, self.g2, self.g3 = 8 / 15, 5 / 12, 3 / 4
+        self.z2, self.z3 = -17 / 60, -5 / 12
+        self.Gn = [Field(f.loc, grid) for f in prognostic_fields]
+        self.Gm = [Field(f.loc, grid) for f in prognostic_fields]
+
+
+class QuasiAdamsBashforth2TimeStepper:
+    """src/TimeSteppers/quasi_adams_bashforth_2.jl:3-60; χ = 0.1 by default."""
+
+    def __init__(self, grid, prognostic_fields, chi=0.1):
+        self.chi = chi
+        self.Gn = [Field(f.loc, grid) for f in prognostic_fields]
+        self.Gm = [Field(f.loc, grid) for f in prognostic_fields]
+
+
+class NonhydrostaticModel:
+    def __init__(self, grid, advection=None, tracers=(), timestepper="RungeKutta3", closure=None, buoyancy=None,
+                 coriolis=None, forcing=None, stokes_drift=None):
+        for name, val in (("closure", closure), ("buoyancy", buoyancy), ("coriolis", coriolis), ("forcing", forcing),
+                          ("stokes_drift", stokes_drift)):
+            if val is not None:
+                raise NotImplementedError(f"{name} != nothing is outside the MI355X hot-path scope (see DESIGN.md)")
+        if advection is None:
+            raise NotImplementedError("advection = Centered() (the reference default) is not implemented; pass advection=WENO()")
+        if not isinstance(advection, WENO):
+            raise NotImplementedError("only advection = WENO() is implemented")
+        # inflate_grid_halo_size (nonhydrostatic_model.jl:183, 243-257): the reference rebuilds the grid with halo >= 3.
+        # Here the user must build it so; adapt_advection_order (N < 3 lowers the order) is not supported.
+        for d, (N, H, t) in enumerate(zip(grid.size, (grid.Hx, grid.Hy, grid.Hz), grid.topology)):
+            if t != Flat and (H < advection.buffer or N < advection.buffer):
+                raise ValueError(f"WENO(order=5) needs halo >= 3 and size >= 3 in dimension {d + 1} (got N={N}, H={H})")
+        self.grid = grid
+        self.architecture = grid.architecture
+        self.advection = advection
+        self.clock = Clock()
+        self.u, self.v, self.w = XFaceField(grid), YFaceField(grid), ZFaceField(grid)
+        self.velocities = (self.u, self.v, self.w)
+        self.tracer_names = tuple(tracers)
+        self.tracers = tuple(CenterField(grid) for _ in self.tracer_names)
+        self.pNHS = CenterField(grid)
+        self.pressure_solver = nonhydrostatic_pressure_solver(grid)
+        prog = self.prognostic_fields()
+        if timestepper in ("RungeKutta3", ":RungeKutta3"):
+            self.timestepper = RungeKutta3TimeStepper(grid, prog)
+        elif timestepper in ("QuasiAdamsBashforth2", ":QuasiAdamsBashforth2"):
+            self.timestepper = QuasiAdamsBashforth2TimeStepper(grid, prog)
+        else:
+            raise ValueError(f"unknown timestepper {timestepper!r}")
+        self._tuple_cache = {}
+        update_state(self, compute_tendencies=False)
+
+    def prognostic_fields(self):
+        return self.velocities + self.tracers
+
+    def field(self, name):
+        if name in ("u", "v", "w"):
+            return getattr(self, name)
+        if name in self.tracer_names:
+            return self.tracers[self.tracer_names.index(name)]
+        raise ValueError(f"name {name} not found in model.velocities or model.tracers.")
+
+    # cached ctypes tuples (pointers never change after construction)
+    def _tuples(self):
+        c = self._tuple_cache
+        if not c:
+            prog = self.prognostic_fields()
+            ts = self.timestepper
+            c["n"] = len(prog)
+            c["U"] = _lib.ptr_array([f.ptr for f in prog])
+            c["Gn"] = _lib.ptr_array([f.ptr for f in ts.Gn])
+            c["Gm"] = _lib.ptr_array([f.ptr for f in ts.Gm])
+            c["locs"] = _lib.i32_array([f.loc for f in prog])
+        return c
+
+
+def set(model, enforce_incompressibility=True, **kwargs):
+    """set!(model; enforce_incompressibility=true, kwargs...)"""
+    for name, value in kwargs.items():
+        f = model.field(name)
+        f.set(value)
+        fill_halo_regions(f)
+    update_state(model, compute_tendencies=False)
+    if enforce_incompressibility:
+        calculate_pressure_correction(model, 1.0)
+        pressure_correct_velocities(model, 1.0)
+        update_state(model, compute_tendencies=False)
+
+
+def update_state(model, compute_tendencies=True):
+    """update_state!: tupled halo fill of velocities+tracers (fill_boundary_normal_velocities=false), then tendencies."""
+    arch_hook = getattr(model.architecture, "update_state", None)
+    if arch_hook is not None:  # Distributed: async exchange overlapped with interior tendencies
+        return arch_hook(model, compute_tendencies)
+    fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+    if compute_tendencies:
+        compute_tendencies_(model)
+
+
+def compute_tendencies_(model, rng=None):
+    """compute_tendencies! -> compute_interior_tendency_contributions!: K1-K3 fused + K4 per tracer."""
+    g = model.grid
+    Gn = model.timestepper.Gn
+    r = None if rng is None else _lib.i32_array(list(rng))
+    s = stream_ptr()
+    _lib.call("ocn_compute_momentum_tendencies", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+              Gn[2].ptr, r, s)
+    for n, c in enumerate(model.tracers):
+        _lib.call("ocn_compute_tracer_tendency", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr, Gn[3 + n].ptr, r, s)
+
+
+compute_tendencies = compute_tendencies_
+
+
+def calculate_pressure_correction(model, dt):
+    """calculate_pressure_correction!(model, Δt) (pressure_correction.jl:8-20)"""
+    fill_halo_regions(model.velocities)
+    solve_for_pressure(model.pNHS, model.pressure_solver, dt, model.velocities)
+    fill_halo_regions(model.pNHS)
+
+
+def solve_for_pressure(pressure, solver, dt, U):
+    """solve_for_pressure! (solve_for_pressure.jl:78-82)"""
+    solver.compute_source_term(U[0], U[1], U[2], dt)
+    solver.solve(pressure)
+    return pressure
+
+
+def pressure_correct_velocities(model, dt):
+    """pressure_correct_velocities! (pressure_correction.jl:40-50)"""
+    _lib.call("ocn_pressure_correct_velocities", model.grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, model.pNHS.ptr,
+              float(dt), stream_ptr())
+
+
+def cache_previous_tendencies(model):
+    """cache_previous_tendencies! (store_tendencies.jl:12-22)"""
+    t = model._tuples()
+    _lib.call("ocn_cache_previous_tendencies", model.grid.cref, t["n"], t["Gm"], t["Gn"], t["locs"], stream_ptr())
+
+
+def rk3_substep(model, dt, gamma, zeta):
+    """rk3_substep! (runge_kutta_3.jl:160-183) for every prognostic field in one launch"""
+    t = model._tuples()
+    _lib.call("ocn_rk3_substep", model.grid.cref, t["n"], t["U"], t["Gn"], t["Gm"], t["locs"], float(dt), float(gamma),
+              0.0 if zeta is None else float(zeta), 0 if zeta is None else 1, stream_ptr())
+
+
+def ab2_step(model, dt, chi):
+    """ab2_step! (quasi_adams_bashforth_2.jl:128-160)"""
+    t = model._tuples()
+    _lib.call("ocn_ab2_step", model.grid.cref, t["n"], t["U"], t["Gn"], t["Gm"], t["locs"], float(dt), float(chi), stream_ptr())
+
+
+def time_step(model, dt, euler=False):
+    """time_step!(model, Δt)"""
+    if isinstance(model.timestepper, RungeKutta3TimeStepper):
+        return _time_step_rk3(model, dt)
+    return _time_step_qab2(model, dt, euler)
+
+
+def _time_step_rk3(model, dt):
+    ts, clock = model.timestepper, model.clock
+    if clock.iteration == 0:
+        update_state(model, compute_tendencies=True)
+    first_stage_dt = ts.g1 * dt
+    second_stage_dt = (ts.g2 + ts.z2) * dt
+    third_stage_dt = (ts.g3 + ts.z3) * dt
+    t_next = clock.time + dt  # next_time(clock, Δt)
+
+    rk3_substep(model, dt, ts.g1, None)
+    clock.time += first_stage_dt
+    clock.stage = 2
+    clock.last_stage_dt = first_stage_dt
+    calculate_pressure_correction(model, first_stage_dt)
+    pressure_correct_velocities(model, first_stage_dt)
+    cache_previous_tendencies(model)
+    update_state(model, compute_tendencies=True)
+
+    rk3_substep(model, dt, ts.g2, ts.z2)
+    clock.time += second_stage_dt
+    clock.stage = 3
+    clock.last_stage_dt = second_stage_dt
+    calculate_pressure_correction(model, second_stage_dt)
+    pressure_correct_velocities(model, second_stage_dt)
+    cache_previous_tendencies(model)
+    update_state(model, compute_tendencies=True)
+
+    rk3_substep(model, dt, ts.g3, ts.z3)
+    clock.last_stage_dt = t_next - clock.time  # corrected_third_stage_Δt
+    clock.time = t_next
+    clock.iteration += 1
+    clock.stage = 1
+    clock.last_dt = dt
+    calculate_pressure_correction(model, third_stage_dt)
+    pressure_correct_velocities(model, third_stage_dt)
+    update_state(model, compute_tendencies=True)
+
+
+def _time_step_qab2(model, dt, euler=False):
+    ts, clock = model.timestepper, model.clock
+    if clock.iteration == 0:
+        update_state(model, compute_tendencies=True)
+    euler = euler or (dt != clock.last_dt)
+    chi = -0.5 if euler else ts.chi
+    ab2_step(model, dt, chi)
+    clock.time += dt
+    clock.iteration += 1
+    clock.last_dt = dt
+    clock.last_stage_dt = dt
+    calculate_pressure_correction(model, dt)
+    pressure_correct_velocities(model, dt)
+    cache_previous_tendencies(model)
+    update_state(model, compute_tendencies=True)

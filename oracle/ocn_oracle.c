@@ -436,13 +436,15 @@ void ocn_oracle_ab2_step(const ocn_grid *g, int loc, double *U, const double *Gn
     lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
     int i0, j0, k0;
     field_range(g, loc, &i0, &j0, &k0);
-    double not_euler = (chi != -0.5) ? 1.0 : 0.0;
+    /* not_euler is a Julia Bool: x * false is a "strong zero" (0.0 even for NaN x), protecting against
+     * leftover NaNs in G⁻ (quasi_adams_bashforth_2.jl:169) */
+    int not_euler = (chi != -0.5);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = k0; k <= g->Nz; ++k)
         for (int j = j0; j <= g->Ny; ++j)
             for (int i = i0; i <= g->Nx; ++i) {
                 ptrdiff_t a = AT(L, i, j, k);
-                double G = (1.5 + chi) * Gn[a] - ((0.5 + chi) * Gm[a]) * not_euler;
+                double G = (1.5 + chi) * Gn[a] - (not_euler ? (0.5 + chi) * Gm[a] : 0.0);
                 U[a] += dt * G;
             }
 }

@@ -306,14 +306,14 @@ class FourierTridiagonalPoissonSolver:
         self.lx = poisson_eigenvalues(g.Nx, g.Lx, g.tx)
         self.ly = poisson_eigenvalues(g.Ny, g.Ly, g.ty)
         H = g.Hz
-        dzf = g.dzf if g.dzf is not None else np.full(g.Nz + 2 * H + 1, g.dz)
+        dzf = g.dzf if g.dzf is not None else np.full(g.Nz + 2 * H, g.dz)
         # lower = upper = 1/Δzᶠ[q], q = 2..Nz  (:97-99)
         self.a = np.ascontiguousarray([1 / dzf[q + H - 1] for q in range(2, g.Nz + 1)], dtype=np.float64)
         self.D = np.zeros((g.Nx, g.Ny, g.Nz), order="F")
         self._tmpgrid = g
         if g.dzc is None:  # regular z handled by giving the C kernel explicit arrays
             self._dzc = np.full(g.Nz + 2 * H, g.dz)
-            self._dzf = np.full(g.Nz + 2 * H + 1, g.dz)
+            self._dzf = np.full(g.Nz + 2 * H, g.dz)
             cg = _CGrid.from_buffer_copy(g.c)
             cg.dzc = self._dzc.ctypes.data
             cg.dzf = self._dzf.ctypes.data

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): builds oracle/libocn_oracle.so on first use."""
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def ocn():
+    """The product package; GPU tests only."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    import oceananigans_jl_amd as pkg
+    pkg._lib.lib()
+    return pkg

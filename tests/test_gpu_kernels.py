@@ -1,0 +1,192 @@
+"""GPU parity: every HIP kernel behind the C ABI against the CPU oracle, same seeded inputs.
+
+Bar: bit-exact for the strict-math stencil/stepper/halo kernels (integer-like determinism: same IEEE
+operations in the same order); stated fp64 tolerances for the fast-math WENO variant and for anything
+downstream of an FFT (rocFFT vs pocketfft round-off)."""
+import numpy as np
+import pytest
+
+from helpers import from_dev, make_pair, random_parent, stretched_faces, to_dev
+
+pytestmark = pytest.mark.gpu
+
+LOCS = (1, 2, 4)  # u, v, w
+CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi)),
+         ((13, 17, 19), "PPP", (0, 1.0)),
+         ((70, 9, 8), "PPP", (0, 3.0)),
+         ((16, 12, 10), "PPB", (-1.0, 0.0)),
+         ((16, 12, 10), "PPB", "stretched"),
+         ((24, 16, 1), "PPF", None)]
+
+
+def _grid(O, ocn, size, topo, z):
+    if isinstance(z, str):
+        z = stretched_faces(size[2])
+    return make_pair(O, ocn, size, topo, z=z)
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_momentum_tendencies_strict_bitwise(oracle, ocn, size, topo, z):
+    O = oracle
+    rng = np.random.default_rng(1234)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    dG = [ocn.Field(l, pg) for l in LOCS]
+    ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvw"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
+    assert all(np.abs(g).max() > 0 for g in G[:2])
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_momentum_tendencies_fast_tolerance(oracle, ocn, size, topo, z):
+    """fast math = FMA contraction + single-division WENO weights: same rational function, different rounding.
+    Tolerance: 1e-12 relative to max|G| (fp64 eps = 2.2e-16; ~100 flops per reconstruction, cancellation in the
+    flux difference)."""
+    O = oracle
+    rng = np.random.default_rng(4321)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G)
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+        dG = [ocn.Field(l, pg) for l in LOCS]
+        ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    for a, b in zip(G, dG):
+        scale = max(np.abs(a).max(), 1e-300)
+        assert np.abs(from_dev(b) - a).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_tracer_tendency_strict_bitwise(oracle, ocn, size, topo, z):
+    O = oracle
+    rng = np.random.default_rng(99)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng, 0.0, 1.0)
+    Gc = og.zeros(0)
+    O.tracer_tendency(og, u, v, w, c, Gc)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    dc, dGc = to_dev(ocn, pg, 0, c), ocn.Field(0, pg)
+    ocn._lib.call("ocn_compute_tracer_tendency", pg.cref, du.ptr, dv.ptr, dw.ptr, dc.ptr, dGc.ptr, None, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dGc), Gc)
+
+
+def test_tendency_range_matches_full(oracle, ocn):
+    """KernelParameters ranges (interior / buffer split) tile the full :xyz launch exactly."""
+    O = oracle
+    rng = np.random.default_rng(5)
+    og, pg = make_pair(O, ocn, (20, 8, 8), "PPP")
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    full = [ocn.Field(l, pg) for l in LOCS]
+    part = [ocn.Field(l, pg) for l in LOCS]
+    ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, full[0].ptr, full[1].ptr, full[2].ptr, None, 0)
+    for (i0, i1) in ((4, 17), (1, 3), (18, 20)):
+        r = ocn._lib.i32_array([i0, i1, 1, 8, 1, 8])
+        ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, part[0].ptr, part[1].ptr, part[2].ptr, r, 0)
+    ocn.sync_device()
+    for a, b in zip(full, part):
+        np.testing.assert_array_equal(from_dev(a), from_dev(b))
+    # out-of-range is an error, not a fault
+    bad = ocn._lib.i32_array([0, 20, 1, 8, 1, 8])
+    with pytest.raises(ocn.OcnError):
+        ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, part[0].ptr, part[1].ptr, part[2].ptr, bad, 0)
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_halo_fill_bitwise(oracle, ocn, size, topo, z):
+    O = oracle
+    rng = np.random.default_rng(7)
+    og, pg = _grid(O, ocn, size, topo, z)
+    for fbnv in (True, False):
+        hosts = [random_parent(og, l, rng) for l in (1, 2, 4, 0)]
+        devs = [to_dev(ocn, pg, l, a) for l, a in zip((1, 2, 4, 0), hosts)]
+        for a, l in zip(hosts, (1, 2, 4, 0)):
+            O.fill_halo_regions(og, a, l, fill_boundary_normal_velocities=fbnv)
+        ocn.fill_halo_regions(devs, fill_boundary_normal_velocities=fbnv)
+        ocn.sync_device()
+        for a, d in zip(hosts, devs):
+            np.testing.assert_array_equal(from_dev(d), a)
+
+
+def test_halo_fill_single_direction(oracle, ocn):
+    O = oracle
+    rng = np.random.default_rng(8)
+    og, pg = make_pair(O, ocn, (10, 9, 8), "PPP")
+    for d in range(3):
+        a = random_parent(og, 0, rng)
+        dev = to_dev(ocn, pg, 0, a)
+        O.lib().ocn_oracle_fill_periodic(a.ctypes.data_as(O.C.c_void_p), *a.shape, d, (og.Nx, og.Ny, og.Nz)[d], 3)
+        ocn._lib.call("ocn_fill_halo_periodic", pg.cref, ocn._lib.ptr_array([dev.ptr]), ocn._lib.i32_array([0]), 1, d, 0)
+        ocn.sync_device()
+        np.testing.assert_array_equal(from_dev(dev), a)
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_stepper_kernels_bitwise(oracle, ocn, size, topo, z):
+    O = oracle
+    rng = np.random.default_rng(11)
+    og, pg = _grid(O, ocn, size, topo, z)
+    locs = (1, 2, 4, 0)
+    U = [random_parent(og, l, rng) for l in locs]
+    Gn = [random_parent(og, l, rng) for l in locs]
+    Gm = [random_parent(og, l, rng) for l in locs]
+    dU = [to_dev(ocn, pg, l, a) for l, a in zip(locs, U)]
+    dGn = [to_dev(ocn, pg, l, a) for l, a in zip(locs, Gn)]
+    dGm = [to_dev(ocn, pg, l, a) for l, a in zip(locs, Gm)]
+    pa, ia = ocn._lib.ptr_array, ocn._lib.i32_array
+    Up, Gnp, Gmp, lp = pa([f.ptr for f in dU]), pa([f.ptr for f in dGn]), pa([f.ptr for f in dGm]), ia(list(locs))
+    dt = 0.0123
+    # first RK3 stage, later stage, AB2 (regular and Euler), cache
+    for l, a, gn, gm in zip(locs, U, Gn, Gm):
+        O.rk3_substep(og, l, a, gn, gm, dt, 8 / 15, None)
+        O.rk3_substep(og, l, a, gn, gm, dt, 5 / 12, -17 / 60)
+        O.ab2_step(og, l, a, gn, gm, dt, 0.1)
+        O.ab2_step(og, l, a, gn, gm, dt, -0.5)
+    ocn._lib.call("ocn_rk3_substep", pg.cref, 4, Up, Gnp, Gmp, lp, dt, 8 / 15, 0.0, 0, 0)
+    ocn._lib.call("ocn_rk3_substep", pg.cref, 4, Up, Gnp, Gmp, lp, dt, 5 / 12, -17 / 60, 1, 0)
+    ocn._lib.call("ocn_ab2_step", pg.cref, 4, Up, Gnp, Gmp, lp, dt, 0.1, 0)
+    ocn._lib.call("ocn_ab2_step", pg.cref, 4, Up, Gnp, Gmp, lp, dt, -0.5, 0)
+    ocn.sync_device()
+    for a, d in zip(U, dU):
+        np.testing.assert_array_equal(from_dev(d), a)
+    for l, gm, gn in zip(locs, Gm, Gn):
+        O.cache_tendency(og, l, gm, gn)
+    ocn._lib.call("ocn_cache_previous_tendencies", pg.cref, 4, Gmp, Gnp, lp, 0)
+    ocn.sync_device()
+    for a, d in zip(Gm, dGm):
+        np.testing.assert_array_equal(from_dev(d), a)
+
+
+@pytest.mark.parametrize("size,topo,z", CASES)
+def test_pressure_correct_and_divergence_bitwise(oracle, ocn, size, topo, z):
+    import torch
+    O = oracle
+    rng = np.random.default_rng(12)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    p = random_parent(og, 0, rng)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    dp = to_dev(ocn, pg, 0, p)
+    div = O.divergence(og, u, v, w)
+    ddiv = torch.zeros((og.Nz, og.Ny, og.Nx), dtype=torch.float64, device=du.data.device)
+    ocn._lib.call("ocn_divergence", pg.cref, du.ptr, dv.ptr, dw.ptr, ddiv.data_ptr(), 0)
+    O.pressure_correct(og, u, v, w, p, 0.37)
+    ocn._lib.call("ocn_pressure_correct_velocities", pg.cref, du.ptr, dv.ptr, dw.ptr, dp.ptr, 0.37, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(ddiv.cpu().numpy().T, div)
+    for a, d in zip((u, v, w), (du, dv, dw)):
+        np.testing.assert_array_equal(from_dev(d), a)
