@@ -189,7 +189,9 @@ int ocn_transpose_unpack_y_from_x(int32_t nx, int32_t Ny, int32_t Nz, int32_t R,
  * the handle plans  FFT_z,FFT_y on (nx,Ny,Nz)  and  FFT_x on (Nx,ny,Nz); the host moves data between the
  * two layouts with the transposes above and an all-to-all. */
 typedef struct ocn_dist_poisson *ocn_dist_poisson_t;
-int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, const ocn_grid *local_grid, int32_t rank, int32_t nranks);
+/* global_Lx: extent of the *global* domain in x (global_grid.Lx), used for the global eigenvalues λx (:104-106) */
+int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, const ocn_grid *local_grid, int32_t rank, int32_t nranks,
+                            double global_Lx);
 int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
 /* device pointers to the solver's y-local field, x-local field and the two transpose buffers */
 int ocn_dist_poisson_buffers(ocn_dist_poisson_t solver, double **yfield, double **xfield, double **send, double **recv);

@@ -64,7 +64,7 @@ _SIGS = {
     "ocn_transpose_unpack_x_from_y": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "ocn_transpose_pack_x_to_y": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "ocn_transpose_unpack_y_from_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
-    "ocn_dist_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid), _i32, _i32],
+    "ocn_dist_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid), _i32, _i32, _dbl],
     "ocn_dist_poisson_destroy": [_vp],
     "ocn_dist_poisson_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ocn_dist_poisson_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],

@@ -357,12 +357,13 @@ static void free_all(ocn_dist_poisson *s)
         }
 }
 
-extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R)
+extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx)
 {
     OCN_REQUIRE(out && lg, "ocn_dist_poisson_create: null argument");
     int st = ocn::validate_grid(lg);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(R >= 1 && rank >= 0 && rank < R, "ocn_dist_poisson_create: bad rank %d of %d", rank, R);
+    OCN_REQUIRE(global_Lx > 0, "ocn_dist_poisson_create: global_Lx must be positive");
     OCN_REQUIRE(lg->ty == OCN_PERIODIC && lg->tz == OCN_PERIODIC && lg->dzc == nullptr,
                 "ocn_dist_poisson_create: supports (x-partitioned, Periodic, Periodic) regular grids");
     // validate_poisson_solver_distributed_grid (distributed_fft_based_poisson_solver.jl:211-229)
@@ -376,8 +377,8 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     const size_t n = (size_t)nx * Ny * Nz;
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
-    // global eigenvalues; Lx of the *global* domain = R * local Lx
-    TRY(upload(eigenvalues(Nxg, lg->Lx * R, OCN_PERIODIC), &s->lx));
+    // global eigenvalues (distributed_fft_based_poisson_solver.jl:104-106)
+    TRY(upload(eigenvalues(Nxg, global_Lx, OCN_PERIODIC), &s->lx));
     TRY(upload(eigenvalues(Ny, lg->Ly, OCN_PERIODIC), &s->ly));
     TRY(upload(eigenvalues(Nz, lg->Lz, OCN_PERIODIC), &s->lz));
     for (double **p : {&s->yfield, &s->xfield, &s->send, &s->recv}) {

@@ -1,0 +1,330 @@
+"""DistributedComputations, slab-x: mirrors src/DistributedComputations/ for `Partition(R)` along x.
+
+  Distributed(child_arch; partition=Partition(R))           distributed_architectures.jl:167-297
+  RectilinearGrid(arch::Distributed, ...) -> local grid       distributed_grids.jl:75-118 (x becomes FullyConnected, :339-346)
+  fill_halo_regions! with x communication                     halo_communication.jl:100-366, Fields/field_boundary_buffers.jl:276-308
+  interior / buffer tendency split, async exchange            Models/interleave_communication_and_computation.jl:9-67,
+                                                              NonhydrostaticModels/compute_nonhydrostatic_buffer_tendencies.jl:10-83
+  DistributedFFTBasedPoissonSolver                            distributed_fft_based_poisson_solver.jl:10-188
+  transposes + all-to-all                                     distributed_transpose.jl:25-191, transposable_field.jl:4-104
+
+MI355X design: one process per GPU; the data path is RCCL over xGMI through torch.distributed
+(backend "nccl" is RCCL on ROCm).  Halo exchange = one batched send/recv pair per neighbour for the whole
+field tuple (6.4 MB per field-side at 512^3/8) issued asynchronously and overlapped with the interior tendency
+kernel; transposes = one all_to_all_single of equal 33.5 MB chunks (one xGMI link per peer at R = 8).
+The `fabric` (who talks to whom) and the `ops` (pack / unpack / transform kernels) are separate objects so the
+choreography can be exercised on CPU ranks (gloo) in tests; the product ops are the HIP kernels of libocn_hip.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .architectures import GPU, device, stream_ptr
+from .grids import FullyConnected, Periodic, RectilinearGrid
+
+
+class Partition:
+    """Partition(Rx): equal slabs along x.  y/z partitions are outside the north-star scope."""
+
+    def __init__(self, x=1, y=1, z=1):
+        if y != 1 or z != 1:
+            raise NotImplementedError("only slab-x partitions (Partition(R)) are implemented")
+        if x < 1:
+            raise ValueError("partition size must be >= 1")
+        self.x, self.y, self.z = int(x), 1, 1
+
+
+# --------------------------------------------------------------------------------------------------
+# Fabric: point-to-point neighbour exchange and all-to-all between the R ranks.
+# --------------------------------------------------------------------------------------------------
+class TorchDistributedFabric:
+    """torch.distributed process group (nccl = RCCL on GPUs, gloo on CPU ranks in tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("Distributed() needs torch.distributed.init_process_group() (one process per GPU)")
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def start_exchange(self, sends, recvs):
+        """sends: [(tensor, dest_rank)], recvs: [(tensor, src_rank)] in matching order per peer. Returns a waitable."""
+        dist = self.dist
+        ops = [dist.P2POp(dist.irecv, t, src, self.group) for t, src in recvs]
+        ops += [dist.P2POp(dist.isend, t, dst, self.group) for t, dst in sends]
+        return dist.batch_isend_irecv(ops)
+
+    @staticmethod
+    def wait(reqs):
+        for r in reqs:
+            r.wait()
+
+    def all_to_all(self, recv, send):
+        self.dist.all_to_all_single(recv, send, group=self.group)
+
+    def allreduce_max(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return t
+
+
+# --------------------------------------------------------------------------------------------------
+# Ops: the device kernels the choreography calls (HIP; tests may inject CPU restatements).
+# --------------------------------------------------------------------------------------------------
+class HipOps:
+    name = "hip"
+
+    def new_buffer(self, arch, n):
+        return torch.zeros(n, dtype=torch.float64, device=device(arch.child_architecture))
+
+    def local_fill(self, grid, fields, fbnv):
+        _lib.call("ocn_fill_halo_regions", grid.cref, _lib.ptr_array([f.ptr for f in fields]),
+                  _lib.i32_array([f.loc for f in fields]), len(fields), int(bool(fbnv)), stream_ptr())
+
+    def pack_x(self, grid, f, west, east):
+        _lib.call("ocn_halo_pack_x", grid.cref, f.ptr, f.loc, west.data_ptr(), east.data_ptr(), stream_ptr())
+
+    def unpack_x(self, grid, f, west, east):
+        _lib.call("ocn_halo_unpack_x", grid.cref, f.ptr, f.loc, west.data_ptr(), east.data_ptr(), stream_ptr())
+
+    def sync(self):
+        torch.cuda.current_stream().synchronize()
+
+    def make_dist_poisson(self, grid, arch):
+        return _HipDistPoisson(grid, arch)
+
+
+class Distributed:
+    """Distributed(child_architecture; partition): one rank of an x-slab decomposition."""
+
+    def __init__(self, child_architecture=None, partition=None, fabric=None, ops=None):
+        self.child_architecture = child_architecture if child_architecture is not None else GPU()
+        self.fabric = fabric if fabric is not None else TorchDistributedFabric()
+        self.ops = ops if ops is not None else HipOps()
+        self.partition = partition if partition is not None else Partition(self.fabric.size)
+        if self.partition.x != self.fabric.size:
+            raise ValueError(f"Partition({self.partition.x}) does not match the number of ranks {self.fabric.size}")
+        self.local_rank = self.fabric.rank
+        self.ranks = (self.partition.x, 1, 1)
+        R = self.partition.x
+        # neighbours wrap around (distributed_architectures.jl:386-429)
+        self.west_rank = (self.local_rank - 1) % R
+        self.east_rank = (self.local_rank + 1) % R
+        self._buffers = {}
+        self._pending = None
+
+    @property
+    def device(self):
+        return device(self.child_architecture)
+
+    def __repr__(self):
+        return f"Distributed({self.child_architecture}, rank {self.local_rank} of {self.partition.x})"
+
+    # ---- halo communication ------------------------------------------------------------------
+    def _halo_buffers(self, f):
+        key = (f.ptr, f.loc)
+        b = self._buffers.get(key)
+        if b is None:
+            g = f.grid
+            sx, sy, sz = g.parent_shape(f.loc)
+            n = g.Hx * sy * sz  # OneDBuffers: full cross-section, corners travel with the sides (:70-75)
+            b = tuple(self.ops.new_buffer(self, n) for _ in range(4))  # send_w, send_e, recv_w, recv_e
+            self._buffers[key] = b
+        return b
+
+    def start_halo_exchange(self, fields):
+        """Pack + post the x exchange for a tuple of fields (fill_halo_event! with async=true)."""
+        g = fields[0].grid
+        if self.partition.x == 1:
+            return None
+        sends, recvs = [], []
+        for f in fields:
+            sw, se, rw, re = self._halo_buffers(f)
+            self.ops.pack_x(g, f, sw, se)
+        self.ops.sync()  # sync_device! before posting (halo_communication.jl:272, 303)
+        for f in fields:
+            sw, se, rw, re = self._halo_buffers(f)
+            # my west strip becomes the west neighbour's east halo, and vice versa.  Receives are posted in the
+            # order (from east, from west) so that with R = 2 (both neighbours the same peer) they pair up with
+            # the peer's (west, east) sends.
+            sends += [(sw, self.west_rank), (se, self.east_rank)]
+            recvs += [(rw, self.west_rank), (re, self.east_rank)] if self.partition.x > 2 else [(re, self.east_rank), (rw, self.west_rank)]
+        self._pending = (self.fabric.start_exchange(sends, recvs), tuple(fields))
+        return self._pending
+
+    def finish_halo_exchange(self):
+        """synchronize_communication! (distributed_fields.jl:58-75): wait + unpack."""
+        if self._pending is None:
+            return
+        reqs, fields = self._pending
+        self.fabric.wait(reqs)
+        g = fields[0].grid
+        for f in fields:
+            sw, se, rw, re = self._halo_buffers(f)
+            self.ops.unpack_x(g, f, rw, re)
+        self._pending = None
+
+    def fill_halo_regions(self, fields, fbnv=True):
+        """Local (y, z) fills first, communication last (fill_halo_regions.jl:148-196); synchronous."""
+        g = fields[0].grid
+        self.ops.local_fill(g, fields, fbnv)
+        if self.start_halo_exchange(fields) is not None:
+            self.finish_halo_exchange()
+
+    # ---- update_state! with interior / buffer overlap -------------------------------------------
+    def update_state(self, model, compute_tendencies=True):
+        from . import models
+        g = model.grid
+        fields = model.prognostic_fields()
+        self.ops.local_fill(g, fields, False)
+        pending = self.start_halo_exchange(fields)
+        nx, Hx = g.Nx, g.Hx
+        if compute_tendencies:
+            if pending is None:
+                models.compute_tendencies_(model)
+            else:  # interior_tendency_kernel_parameters (interleave_communication_and_computation.jl:29-67)
+                if nx - 2 * Hx >= 1:
+                    models.compute_tendencies_(model, (Hx + 1, nx - Hx, 1, g.Ny, 1, g.Nz))
+        self.finish_halo_exchange()
+        if compute_tendencies and pending is not None:
+            # buffer_tendency_kernel_parameters (compute_nonhydrostatic_buffer_tendencies.jl:28-39)
+            w1 = min(Hx, nx)
+            models.compute_tendencies_(model, (1, w1, 1, g.Ny, 1, g.Nz))
+            e0 = max(nx - Hx + 1, w1 + 1)
+            if e0 <= nx:
+                models.compute_tendencies_(model, (e0, nx, 1, g.Ny, 1, g.Nz))
+
+    def pressure_solver(self, grid):
+        return DistributedFFTBasedPoissonSolver(grid)
+
+
+def distributed_rectilinear_grid(arch, size, x=None, y=None, z=None, topology=(Periodic, Periodic, Periodic), halo=None):
+    """RectilinearGrid(arch::Distributed; ...): the rank-local portion (distributed_grids.jl:75-118)."""
+    R, r = arch.partition.x, arch.local_rank
+    Nx = size[0]
+    if topology[0] != Periodic:
+        raise NotImplementedError("the partitioned x direction must be Periodic")
+    if Nx % R:
+        raise ValueError(f"Nx = {Nx} must be divisible by the number of ranks {R} (equal slabs)")
+    nx = Nx // R
+    if R > 1:
+        # partition_coordinate(c::Tuple, ...) (partition_assemble.jl:63-76), same fp64 arithmetic
+        dl = (float(x[1]) - float(x[0])) / Nx
+        lo = float(x[0])
+        for _ in range(r):
+            lo = lo + dl * nx
+        xl = (lo, lo + dl * nx)
+        topo = (FullyConnected,) + tuple(topology[1:])  # insert_connected_topology (distributed_grids.jl:339-346)
+    else:
+        xl, topo = x, tuple(topology)
+    g = RectilinearGrid(arch, (nx,) + tuple(size[1:]), x=xl, y=y, z=z, topology=topo, halo=halo, _local=True)
+    g.global_size = tuple(size)
+    from fractions import Fraction
+    g.global_Lx = float(Fraction(float(x[1])) - Fraction(float(x[0])))
+    return g
+
+
+class _HipDistPoisson:
+    """Device side of the distributed solver: ocn_dist_poisson_* handle of libocn_hip."""
+
+    def __init__(self, grid, arch):
+        self.grid, self.R = grid, arch.partition.x
+        self._h = C.c_void_p()
+        _lib.call("ocn_dist_poisson_create", C.byref(self._h), grid.cref, arch.local_rank, self.R,
+                  C.c_double(getattr(grid, "global_Lx", grid.Lx * self.R)))
+        ptrs = [C.c_void_p() for _ in range(4)]
+        _lib.call("ocn_dist_poisson_buffers", self._h, *[C.byref(p) for p in ptrs])
+        n = grid.Nx * grid.Ny * grid.Nz * 2
+        # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
+        self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
+        self.recv = _wrap_device_buffer(ptrs[3].value, n, arch.device)
+        self.yfield_ptr, self.xfield_ptr = ptrs[0].value, ptrs[1].value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ocn_dist_poisson_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _dims(self):
+        g = self.grid
+        return g.Nx, g.Ny, g.Nz, self.R
+
+    def source_term(self, u, v, w, dt):
+        _lib.call("ocn_dist_poisson_source_term", self._h, u.ptr, v.ptr, w.ptr, float(dt), stream_ptr())
+
+    def forward_yz(self):
+        _lib.call("ocn_dist_poisson_forward_yz", self._h, stream_ptr())
+
+    def pack_y_to_x(self):
+        _lib.call("ocn_transpose_pack_y_to_x", *self._dims(), self.yfield_ptr, self.send.data_ptr(), stream_ptr())
+
+    def unpack_x_from_y(self, rbuf):
+        _lib.call("ocn_transpose_unpack_x_from_y", *self._dims(), rbuf.data_ptr(), self.xfield_ptr, stream_ptr())
+
+    def solve_x(self):
+        _lib.call("ocn_dist_poisson_solve_x", self._h, stream_ptr())
+
+    def pack_x_to_y(self):
+        _lib.call("ocn_transpose_pack_x_to_y", *self._dims(), self.xfield_ptr, self.send.data_ptr(), stream_ptr())
+
+    def unpack_y_from_x(self, rbuf):
+        _lib.call("ocn_transpose_unpack_y_from_x", *self._dims(), rbuf.data_ptr(), self.yfield_ptr, stream_ptr())
+
+    def backward_yz(self, p):
+        _lib.call("ocn_dist_poisson_backward_yz", self._h, p.ptr, stream_ptr())
+
+
+class DistributedFFTBasedPoissonSolver:
+    """DistributedFFTBasedPoissonSolver for slab-x (Ry == 1), solve! (distributed_fft_based_poisson_solver.jl:141-178):
+    FFT_z, FFT_y local -> y->x all-to-all -> FFT_x -> divide by (λx+λy+λz), rank 0 zeroes mode (1,1,1) -> IFFT_x ->
+    x->y all-to-all -> IFFT_y, IFFT_z -> real part into the local pressure interior."""
+
+    def __init__(self, grid):
+        arch = grid.architecture
+        self.grid, self.arch = grid, arch
+        self.R = arch.partition.x
+        if grid.topology[1] != Periodic or grid.topology[2] != Periodic:
+            raise NotImplementedError("DistributedFFTBasedPoissonSolver: (x-partitioned, Periodic, Periodic) only")
+        if grid.Ny % self.R:
+            raise ValueError(f"Ny = {grid.Ny} must be divisible by Rx = {self.R}")  # :211-229
+        self.impl = arch.ops.make_dist_poisson(grid, arch)
+
+    def compute_source_term(self, u, v, w, dt):
+        self.impl.source_term(u, v, w, dt)
+
+    def _all_to_all(self):
+        """transpose_*!: pack -> sync_device! -> Alltoallv! -> unpack (distributed_transpose.jl:185-191)"""
+        if self.R == 1:
+            return self.impl.send
+        self.arch.ops.sync()
+        self.arch.fabric.all_to_all(self.impl.recv, self.impl.send)
+        return self.impl.recv
+
+    def solve(self, p):
+        impl = self.impl
+        impl.forward_yz()
+        impl.pack_y_to_x()
+        impl.unpack_x_from_y(self._all_to_all())
+        impl.solve_x()
+        impl.pack_x_to_y()
+        impl.unpack_y_from_x(self._all_to_all())
+        impl.backward_yz(p)
+        return p
+
+
+class _DevBuf:
+    """__cuda_array_interface__ view of a library-owned device allocation."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _wrap_device_buffer(ptr, n, dev):
+    return torch.as_tensor(_DevBuf(ptr, n), device=dev)

@@ -32,7 +32,14 @@ class RectilinearGrid:
     `size`/`halo` omit Flat dimensions like the reference (input_validation.jl:61-95).  `z` may be a
     2-tuple (regular) or an array of Nz+1 increasing face positions (stretched, needs Bounded z)."""
 
-    def __init__(self, architecture, size, x=None, y=None, z=None, topology=(Periodic, Periodic, Bounded), halo=None):
+    def __init__(self, architecture, size, x=None, y=None, z=None, topology=(Periodic, Periodic, Bounded), halo=None,
+                 _local=False):
+        if hasattr(architecture, "partition") and not _local:
+            # RectilinearGrid(arch::Distributed, ...) returns the rank-local grid (distributed_grids.jl:75-118)
+            from .distributed import distributed_rectilinear_grid
+            g = distributed_rectilinear_grid(architecture, tuple(size), x=x, y=y, z=z, topology=tuple(topology), halo=halo)
+            self.__dict__.update(g.__dict__)
+            return
         self.architecture = architecture
         topo = tuple(topology)
         for t in topo:
@@ -82,9 +89,9 @@ class RectilinearGrid:
                 D[d] = float("nan")
         self.Lx, self.Ly, self.Lz = L
         self.dx, self.dy, self.dz = D
-        dev = device(child_architecture(architecture))
         self._dzc = self._dzf = None
-        if self._dzc_host is not None:
+        dev = None if architecture is None else device(child_architecture(architecture))  # None: metadata only (tests)
+        if self._dzc_host is not None and dev is not None:
             self._dzc = torch.from_numpy(self._dzc_host).to(dev)
             self._dzf = torch.from_numpy(self._dzf_host).to(dev)
         self.c = _lib.CGrid(self.Nx, self.Ny, self.Nz, self.Hx, self.Hy, self.Hz,

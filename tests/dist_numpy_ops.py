@@ -1,0 +1,112 @@
+"""CPU stand-ins (numpy / scipy / the C oracle) for the device `ops` of oceananigans.jl_amd/distributed.py.
+
+TEST INFRASTRUCTURE: lets the multi-rank choreography (who sends what to whom, in which order; chunk layout of the
+all-to-all) run on CPU ranks over gloo.  The transposes restate src/DistributedComputations/distributed_transpose.jl:25-95
+index for index; pack/unpack restate src/Fields/field_boundary_buffers.jl:276-308."""
+import numpy as np
+import scipy.fft as sfft
+import torch
+
+from oracle import oracle as O
+
+
+class HostArch:
+    """child architecture whose arrays live in host memory (tests only)."""
+    device = torch.device("cpu")
+
+
+def fview(f):
+    """F-ordered [i,j,k] numpy view of a Field's parent tensor."""
+    return f.data.numpy().T
+
+
+class _NumpyDistPoisson:
+    def __init__(self, grid, arch):
+        self.g, self.R, self.rank = grid, arch.partition.x, arch.local_rank
+        nx, Ny, Nz = grid.Nx, grid.Ny, grid.Nz
+        self.ny, self.Nxg = Ny // self.R, nx * self.R
+        self.y = np.zeros((nx, Ny, Nz), dtype=np.complex128, order="F")
+        self.x = np.zeros((self.Nxg, self.ny, Nz), dtype=np.complex128, order="F")
+        n = nx * Ny * Nz * 2
+        self.send, self.recv = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        self.lx = O.poisson_eigenvalues(self.Nxg, grid.global_Lx, O.PERIODIC)
+        self.ly = O.poisson_eigenvalues(Ny, grid.Ly, O.PERIODIC)
+        self.lz = O.poisson_eigenvalues(Nz, grid.Lz, O.PERIODIC)
+        self.og = O.Grid((nx, Ny, Nz), x=(0, grid.Lx), y=(0, grid.Ly), z=(0, grid.Lz), topology="PPP", halo=(grid.Hx, grid.Hy, grid.Hz))
+
+    def _cbuf(self, t):
+        return t.numpy().view(np.complex128)
+
+    def source_term(self, u, v, w, dt):
+        S = O.FFTBasedPoissonSolver(self.og)
+        S.source_term(np.asfortranarray(fview(u)), np.asfortranarray(fview(v)), np.asfortranarray(fview(w)), dt)
+        self.y[...] = S.storage
+
+    def forward_yz(self):
+        self.y[...] = sfft.fftn(self.y, axes=(1, 2))
+
+    def pack_y_to_x(self):  # send[i + nx*(k + Nz*j)] = y[i,j,k]  (:38-42)
+        self._cbuf(self.send)[...] = np.transpose(self.y, (0, 2, 1)).ravel(order="F")
+
+    def unpack_x_from_y(self, rbuf):  # x[i,j,k] = recv[i' + nx*(k + Nz*j) + m*nx*ny*Nz]  (:51-60)
+        nx, ny, Nz = self.g.Nx, self.ny, self.g.Nz
+        r = self._cbuf(rbuf).reshape((nx, Nz, ny, self.R), order="F")
+        for m in range(self.R):
+            self.x[m * nx:(m + 1) * nx] = np.transpose(r[:, :, :, m], (0, 2, 1))
+
+    def solve_x(self):
+        xh = sfft.fft(self.x, axis=0)
+        j0 = self.rank * self.ny
+        lam = (self.lx[:, None, None] + self.ly[None, j0:j0 + self.ny, None]) + self.lz[None, None, :]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xh = -xh / lam
+        if self.rank == 0:
+            xh[0, 0, 0] = 0
+        self.x[...] = sfft.ifft(xh, axis=0)
+
+    def pack_x_to_y(self):  # send[j + ny*(k + Nz*i)] = x[i,j,k]  (:31-35)
+        self._cbuf(self.send)[...] = np.transpose(self.x, (1, 2, 0)).ravel(order="F")
+
+    def unpack_y_from_x(self, rbuf):  # y[i,j,k] = recv[j' + ny*(k + Nz*i) + m*nx*ny*Nz]  (:86-95)
+        nx, ny, Nz = self.g.Nx, self.ny, self.g.Nz
+        r = self._cbuf(rbuf).reshape((ny, Nz, nx, self.R), order="F")
+        for m in range(self.R):
+            self.y[:, m * ny:(m + 1) * ny, :] = np.transpose(r[:, :, :, m], (2, 0, 1))
+
+    def backward_yz(self, p):
+        self.y[...] = sfft.ifftn(self.y, axes=(1, 2))
+        g = self.g
+        fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = self.y.real
+
+
+class NumpyOps:
+    name = "numpy"
+
+    def new_buffer(self, arch, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def local_fill(self, grid, fields, fbnv):
+        for f in fields:  # periodic y, z fills over the whole parent cross-section; x is communication
+            a = fview(f)
+            sx, sy, sz = a.shape
+            for d, (N, H) in ((1, (grid.Ny, grid.Hy)), (2, (grid.Nz, grid.Hz))):
+                tmp = np.asfortranarray(a)
+                O.lib().ocn_oracle_fill_periodic(tmp.ctypes.data_as(O.C.c_void_p), sx, sy, sz, d, N, H)
+                a[...] = tmp
+
+    def pack_x(self, grid, f, west, east):
+        a, H, nx = fview(f), grid.Hx, grid.Nx
+        west.numpy()[...] = a[H:2 * H].ravel(order="F")        # parent[1+Hx : 2Hx, :, :]
+        east.numpy()[...] = a[nx:nx + H].ravel(order="F")      # parent[1+nx : nx+Hx, :, :]
+
+    def unpack_x(self, grid, f, west, east):
+        a, H, nx = fview(f), grid.Hx, grid.Nx
+        shp = (H,) + a.shape[1:]
+        a[0:H] = west.numpy().reshape(shp, order="F")           # parent[1 : Hx]
+        a[nx + H:nx + 2 * H] = east.numpy().reshape(shp, order="F")  # parent[1+nx+Hx : nx+2Hx]
+
+    def sync(self):
+        pass
+
+    def make_dist_poisson(self, grid, arch):
+        return _NumpyDistPoisson(grid, arch)

@@ -1,0 +1,95 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/ocn_hip.h declares;
+argument validation (which runs before any HIP call) reports errors through the status/ocn_last_error contract."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import oceananigans_jl_amd as ocn
+    return ocn
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "ocn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg._lib.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 40
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, f"declared in ocn_hip.h but not exported: {missing}"
+    # and the Python binding table covers the header
+    unbound = [n for n in declared if n not in pkg._lib.EXPORTED_SYMBOLS]
+    assert not unbound, f"declared but not bound in _lib.py: {unbound}"
+
+
+def test_struct_layout_matches_header(pkg):
+    # 10 int32 + 6 double + 2 pointers, natural alignment
+    assert C.sizeof(pkg._lib.CGrid) == 10 * 4 + 6 * 8 + 2 * 8
+    assert pkg._lib.CGrid.dx.offset == 40 and pkg._lib.CGrid.dzc.offset == 88
+
+
+def test_version_and_math_mode(pkg):
+    lib = pkg._lib.lib()
+    assert b"gfx950" in lib.ocn_version()
+    pkg.set_math_mode(pkg.MATH_FAST)
+    assert lib.ocn_get_math_mode() == pkg.MATH_FAST
+    pkg.set_math_mode(pkg.MATH_STRICT)
+    with pytest.raises(pkg.OcnError, match="unknown math mode"):
+        pkg._lib.call("ocn_set_math_mode", 7)
+
+
+def _grid(pkg, **kw):
+    base = dict(Nx=8, Ny=8, Nz=8, Hx=3, Hy=3, Hz=3, tx=0, ty=0, tz=0, _pad=0, dx=1.0, dy=1.0, dz=1.0, Lx=8.0, Ly=8.0, Lz=8.0)
+    base.update(kw)
+    return pkg._lib.CGrid(**base)
+
+
+def test_argument_validation_needs_no_gpu(pkg):
+    call, pa, ia = pkg._lib.call, pkg._lib.ptr_array, pkg._lib.i32_array
+    fake = pa([0x1000])
+    with pytest.raises(pkg.OcnError, match="unsupported topology"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg, tx=1)), fake, ia([0]), 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="Flat dimension"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg, tz=2)), fake, ia([0]), 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="number of fields"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg)), fake, ia([0]), 0, 1, None)
+    with pytest.raises(pkg.OcnError, match="location mask"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg)), fake, ia([3]), 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="halo >= 3"):
+        call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, Hx=2)), 1, 1, 1, 1, 1, 1, None, None)
+    with pytest.raises(pkg.OcnError, match="null field pointer"):
+        call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg)), None, 1, 1, 1, 1, 1, None, None)
+    with pytest.raises(pkg.OcnError, match="larger than size"):
+        call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, Nx=2)), 1, 1, 1, 1, 1, 1, None, None)
+    with pytest.raises(pkg.OcnError, match="divisible"):
+        call("ocn_transpose_pack_y_to_x", 4, 10, 4, 3, 0x1000, 0x1000, None)
+    with pytest.raises(pkg.OcnError, match="is not Periodic"):
+        call("ocn_fill_halo_periodic", C.byref(_grid(pkg, tz=1)), fake, ia([0]), 1, 2, None)
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg._lib, "_lib", None)
+    monkeypatch.setattr(pkg._lib, "LIB_PATH", "/nonexistent/libocn_hip.so")
+    with pytest.raises(pkg.OcnError, match="no CPU fallback"):
+        pkg._lib.lib()
+
+
+def test_gpu_architecture_refuses_without_gpu(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.GPU()
+    with pytest.raises(NotImplementedError):
+        pkg.CPU()

@@ -1,0 +1,146 @@
+"""Slab-x distributed model on ONE GPU: R ranks run as threads of this process and exchange through an in-process
+fabric, so the real HIP pack/unpack/transpose/FFT kernels and the real choreography (async halo exchange overlapped with
+interior tendencies, buffer tendencies, distributed FFT solve) are exercised and compared with the single-rank model.
+(RCCL itself needs one GPU per rank; the fabric-over-torch.distributed path is covered by tests/test_distributed_gloo.py.)"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadWorld:
+    def __init__(self, R):
+        self.R = R
+        self.barrier = threading.Barrier(R, timeout=120)
+        self.lock = threading.Lock()
+        self.mail = {}
+
+    def put(self, key, t):
+        with self.lock:
+            self.mail.setdefault(key, []).append(t)
+
+    def get(self, key):
+        with self.lock:
+            return self.mail[key].pop(0)
+
+
+class ThreadFabric:
+    def __init__(self, world, rank):
+        self.world, self.rank, self.size = world, rank, world.R
+
+    def start_exchange(self, sends, recvs):
+        for t, dst in sends:
+            self.world.put(("p2p", self.rank, dst), t.clone())
+        return recvs
+
+    def wait(self, recvs):
+        torch.cuda.synchronize()
+        self.world.barrier.wait()
+        for t, src in recvs:
+            t.copy_(self.world.get(("p2p", src, self.rank)))
+        torch.cuda.synchronize()
+        self.world.barrier.wait()
+
+    def all_to_all(self, recv, send):
+        n = send.numel() // self.size
+        for m in range(self.size):
+            self.world.put(("a2a", self.rank, m), send[m * n:(m + 1) * n].clone())
+        torch.cuda.synchronize()
+        self.world.barrier.wait()
+        for m in range(self.size):
+            recv[m * n:(m + 1) * n].copy_(self.world.get(("a2a", m, self.rank)))
+        torch.cuda.synchronize()
+        self.world.barrier.wait()
+
+
+def _run_ranks(R, fn):
+    world = ThreadWorld(R)
+    out, errs = [None] * R, []
+
+    def target(r):
+        try:
+            torch.cuda.set_device(0)
+            out[r] = fn(r, ThreadFabric(world, r))
+        except Exception as e:  # noqa
+            import traceback
+            errs.append(f"rank {r}: {traceback.format_exc()}")
+            world.barrier.abort()
+
+    threads = [threading.Thread(target=target, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errs, "\n".join(errs)
+    return out
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_distributed_steps_match_single_rank(ocn, R):
+    P = "Periodic"
+    N = (32, 16, 12)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(1234)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    dt = 0.01
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
+    sm = ocn.NonhydrostaticModel(sg, advection=ocn.WENO())
+    ocn.set(sm, **init)
+    for _ in range(2):
+        ocn.time_step(sm, dt)
+    ocn.sync_device()
+    ref = [f.interior() for f in sm.velocities] + [sm.pNHS.interior()]
+    refG = [f.interior() for f in sm.timestepper.Gn]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        assert g.Nx == N[0] // R and g.topology[0] == "FullyConnected"
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+        assert isinstance(m.pressure_solver, ocn.DistributedFFTBasedPoissonSolver)
+        sl = slice(r * g.Nx, (r + 1) * g.Nx)
+        ocn.set(m, **{k: v[sl] for k, v in init.items()})
+        for _ in range(2):
+            ocn.time_step(m, dt)
+        ocn.sync_device()
+        return [f.interior() for f in m.velocities] + [m.pNHS.interior()], [f.interior() for f in m.timestepper.Gn]
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    for r, (fields, G) in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "p")):
+            tol = 1e-11 * scale if name != "p" else 1e-10 * max(1.0, np.abs(ref[3]).max())
+            assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}"
+        for a, b in zip(G, refG):
+            assert np.abs(a - b[sl]).max() <= 1e-9 * max(1.0, np.abs(b).max())
+
+
+def test_distributed_halo_exchange_on_gpu(ocn):
+    R = 2
+    P = "Periodic"
+    N = (12, 8, 6)
+    rng = np.random.default_rng(0)
+    glob = rng.random(N)
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        g = ocn.RectilinearGrid(arch, size=N, x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, P), halo=(3, 3, 3))
+        f = ocn.CenterField(g)
+        f.set(glob[r * g.Nx:(r + 1) * g.Nx])
+        ocn.fill_halo_regions(f)
+        ocn.sync_device()
+        return f.parent()
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    for r, a in enumerate(outs):
+        I = (np.arange(-3, nx + 3) + r * nx) % N[0]
+        J = np.arange(-3, N[1] + 3) % N[1]
+        K = np.arange(-3, N[2] + 3) % N[2]
+        np.testing.assert_array_equal(a, glob[np.ix_(I, J, K)])

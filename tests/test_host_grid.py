@@ -1,0 +1,60 @@
+"""Host logic of the product (grid generation, argument checks) against the oracle's independent restatement."""
+import numpy as np
+import pytest
+
+from helpers import stretched_faces
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import oceananigans_jl_amd as ocn
+    return ocn
+
+
+@pytest.mark.parametrize("N,ext", [(16, (0, 2 * np.pi)), (13, (-0.3, 1.7)), (7, (1, 2)), (512, (0, 2 * np.pi))])
+def test_regular_spacing_matches_oracle(oracle, pkg, N, ext):
+    og = oracle.Grid((N, N, N), x=ext, y=ext, z=ext, topology="PPP", halo=(3, 3, 3))
+    pg = pkg.RectilinearGrid(None, size=(N, N, N), x=ext, y=ext, z=ext, topology=("Periodic",) * 3, halo=(3, 3, 3))
+    assert (pg.dx, pg.dy, pg.dz) == (og.dx, og.dy, og.dz)
+    assert (pg.Lx, pg.Ly, pg.Lz) == (og.Lx, og.Ly, og.Lz)
+    assert pg.parent_shape(1) == og.shape(1) == (N + 6,) * 3
+
+
+def test_stretched_z_matches_oracle(oracle, pkg):
+    zf = stretched_faces(12, 3.0)
+    og = oracle.Grid((8, 8, 12), x=(0, 1), y=(0, 1), z=zf, topology="PPB", halo=(3, 3, 3))
+    pg = pkg.RectilinearGrid(None, size=(8, 8, 12), x=(0, 1), y=(0, 1), z=zf, topology=("Periodic", "Periodic", "Bounded"))
+    np.testing.assert_array_equal(pg._dzc_host, og.dzc)
+    np.testing.assert_array_equal(pg._dzf_host, og.dzf)
+    assert pg.Lz == og.Lz
+    assert pg.parent_shape(4) == og.shape(4) == (14, 14, 19)  # Face field in a Bounded direction: N+1+2H
+    assert pg.parent_shape(0) == (14, 14, 18)
+
+
+def test_flat_dimension_and_defaults(pkg):
+    g = pkg.RectilinearGrid(None, size=(128, 128), x=(0, 2 * np.pi), y=(0, 2 * np.pi), topology=("Periodic", "Periodic", "Flat"))
+    assert g.size == (128, 128, 1) and (g.Hx, g.Hy, g.Hz) == (3, 3, 0)
+    assert g.dz == 1.0 and g.Lz == 1.0  # Flat metrics (grid_generation.jl:138-155)
+    assert g.parent_shape(4) == (134, 134, 1)
+
+
+def test_grid_argument_errors(pkg):
+    P = "Periodic"
+    with pytest.raises(ValueError, match="must have 3 elements"):
+        pkg.RectilinearGrid(None, size=(8, 8), x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, P))
+    with pytest.raises(ValueError, match="increasing interval"):
+        pkg.RectilinearGrid(None, size=(8, 8, 8), x=(1, 0), y=(0, 1), z=(0, 1), topology=(P, P, P))
+    with pytest.raises(ValueError, match="halo"):
+        pkg.RectilinearGrid(None, size=(2, 8, 8), x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, P), halo=(3, 3, 3))
+    with pytest.raises(ValueError, match="increasing"):
+        pkg.RectilinearGrid(None, size=(8, 8, 2), x=(0, 1), y=(0, 1), z=[0, 2, 1], topology=(P, P, "Bounded"))
+    with pytest.raises(NotImplementedError):
+        pkg.RectilinearGrid(None, size=(8, 8, 2), x=[0, 1, 2, 3, 4, 5, 6, 7, 9], y=(0, 1), z=(0, 1), topology=(P, P, P))
+
+
+def test_weno_scheme_arguments(pkg):
+    assert pkg.WENO().buffer == 3
+    with pytest.raises(ValueError, match="odd orders"):
+        pkg.WENO(order=4)
+    with pytest.raises(NotImplementedError):
+        pkg.WENO(order=7)
