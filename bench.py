@@ -37,17 +37,29 @@ def parse():
     ap.add_argument("--n", type=int, default=512, help="grid points per dimension (512 = the metric's config)")
     ap.add_argument("--math", choices=("fast", "strict"), default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=96, help="grid size of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
+
+
+def host_cores():
+    """CPU threads this process may actually use: the cgroup quota (16 on a 1-GPU box) capped by the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except OSError:
+        pass
+    return n
 
 
 def cpu_baseline(n, steps):
     """The CPU oracle (a port of the reference algorithm, OpenMP over k-planes + pocketfft) timed on the host cores
     on a bounded sample of the same workload."""
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP runtime of the oracle library is loaded
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rng = np.random.default_rng(1234)
     g = O.Grid((n, n, n), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology="PPP", halo=(3, 3, 3))
     m = O.NonhydrostaticModel(g, workers=cores)

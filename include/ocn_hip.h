@@ -148,6 +148,9 @@ int ocn_divergence(const ocn_grid *grid, const double *u, const double *v, const
 typedef struct ocn_poisson *ocn_poisson_t;
 int ocn_poisson_create(ocn_poisson_t *solver, const ocn_grid *grid);
 int ocn_poisson_destroy(ocn_poisson_t solver);
+/* introspection: kind 0 = FFT-based, 1 = Fourier-tridiagonal; r2c = real-to-complex transforms in use;
+ * direct_out = inverse transform writes straight into the pressure interior (no copy_real_component! pass) */
+int ocn_poisson_info(ocn_poisson_t solver, int32_t *kind, int32_t *r2c, int32_t *direct_out);
 /* compute_source_term! (src/Models/NonhydrostaticModels/solve_for_pressure.jl:12-17,33-38,57-76) */
 int ocn_poisson_compute_source_term(ocn_poisson_t solver, const double *u, const double *v, const double *w, double dt,
                                     void *stream);

@@ -53,6 +53,7 @@ _SIGS = {
     "ocn_divergence": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
     "ocn_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid)],
     "ocn_poisson_destroy": [_vp],
+    "ocn_poisson_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "ocn_poisson_compute_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],
     "ocn_poisson_set_source_term": [_vp, _vp, _vp],
     "ocn_poisson_solve": [_vp, _vp, _vp],

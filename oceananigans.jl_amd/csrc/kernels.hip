@@ -263,21 +263,25 @@ int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const doubl
     return OCN_SUCCESS;
 }
 
-// K13 copy_real_component! (fft_based_poisson_solver.jl:129-137)
-__global__ __launch_bounds__(256) void copy_real_kernel(GridDev g, const double2 *__restrict__ phi, double *__restrict__ p)
+// K13 copy_real_component! (fft_based_poisson_solver.jl:129-137); STRIDE = 2 reads the real part of a complex array
+template <int STRIDE>
+__global__ __launch_bounds__(256) void copy_real_kernel(GridDev g, const double *__restrict__ phi, double *__restrict__ p)
 {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny) return;
     const Lay L = make_lay(g, OCN_LOC_CCC);
-    p[at(L, i, j, k)] = phi[(i - 1) + (long long)g.Nx * ((j - 1) + (long long)g.Ny * (k - 1))].x;
+    p[at(L, i, j, k)] = phi[STRIDE * ((i - 1) + (long long)g.Nx * ((j - 1) + (long long)g.Ny * (k - 1)))];
 }
-int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream)
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source)
 {
     GridDev g = to_dev(*grid);
-    hipLaunchKernelGGL(copy_real_kernel, dim3((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz), dim3(64, 4), 0, stream, g,
-                       reinterpret_cast<const double2 *>(phi), p);
+    dim3 nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz), block(64, 4);
+    if (real_source)
+        hipLaunchKernelGGL(copy_real_kernel<1>, nb, block, 0, stream, g, phi, p);
+    else
+        hipLaunchKernelGGL(copy_real_kernel<2>, nb, block, 0, stream, g, phi, p);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

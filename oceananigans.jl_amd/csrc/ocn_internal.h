@@ -27,7 +27,7 @@ int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc
                       long long ld1, long long ld2, hipStream_t stream);
 int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
                           int zero_mode_here, int joff, int koff, hipStream_t stream);
-int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream);
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source);
 int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream);
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,

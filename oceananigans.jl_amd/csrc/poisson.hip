@@ -126,6 +126,7 @@ struct ocn_poisson {
     double *spec2 = nullptr;    // tridiagonal solution (complex nxh*Ny*Nz)
     double *diag = nullptr, *tscr = nullptr, *lower = nullptr;
     Plan fwd, bwd;
+    bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
 };
 
@@ -236,8 +237,16 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
         const size_t pdist = (fft_dims == 3) ? (size_t)Lp.s3 * Lp.sz : (size_t)Lp.s3;
         TRY(make_plan(s->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward, fft_dims, len, batch,
                       rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, rstr, rdist, cstr, cdist, 1.0));
-        TRY(make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
-                      rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, pstr, pdist, scale));
+        int bst = make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
+                            rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, pstr, pdist, scale);
+        if (bst != OCN_SUCCESS) {
+            // rocFFT has no kernel for this strided-output shape: transform into the contiguous real buffer and
+            // copy into the pressure interior (the reference's copy_real_component! pass).
+            s->bwd.destroy();
+            s->direct_out = false;
+            TRY(make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
+                          rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, rstr, rdist, scale));
+        }
     }
 #undef TRY
 #undef TRY_HIP
@@ -250,6 +259,15 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s)
     if (!s) return OCN_SUCCESS;
     free_all(s);
     delete s;
+    return OCN_SUCCESS;
+}
+
+extern "C" int ocn_poisson_info(ocn_poisson_t s, int32_t *kind, int32_t *r2c, int32_t *direct_out)
+{
+    OCN_REQUIRE(s, "ocn_poisson_info: null solver");
+    if (kind) *kind = s->kind;
+    if (r2c) *r2c = !s->c2c;
+    if (direct_out) *direct_out = (!s->c2c && s->direct_out);
     return OCN_SUCCESS;
 }
 
@@ -317,11 +335,17 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
     if (s->c2c) {
         st = s->bwd.exec(sol, nullptr, stream);
         if (st != OCN_SUCCESS) return st;
-        st = ocn::launch_copy_real(g, sol, p, stream);
+        st = ocn::launch_copy_real(g, sol, p, stream, 0);
     } else {
-        ocn::GridDev gd = ocn::to_dev(*g);
-        ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
-        st = s->bwd.exec(sol, p + Lp.o, stream);
+        if (s->direct_out) {
+            ocn::GridDev gd = ocn::to_dev(*g);
+            ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+            st = s->bwd.exec(sol, p + Lp.o, stream);
+        } else {
+            st = s->bwd.exec(sol, s->rhs, stream);
+            if (st != OCN_SUCCESS) return st;
+            st = ocn::launch_copy_real(g, s->rhs, p, stream, /*real_source=*/1);
+        }
     }
     return st;
 }
@@ -460,5 +484,5 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
     int st = s->byz.exec(s->yfield, nullptr, stream);
     if (st != OCN_SUCCESS) return st;
     // copy_real_component! into the local pressure interior; the local grid's parent layout
-    return ocn::launch_copy_real(&s->grid, s->yfield, p, stream);
+    return ocn::launch_copy_real(&s->grid, s->yfield, p, stream, 0);
 }

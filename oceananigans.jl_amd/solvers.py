@@ -25,6 +25,11 @@ class _PoissonHandle:
                 pass
             self._h = None
 
+    def info(self):
+        k, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.call("ocn_poisson_info", self._h, C.byref(k), C.byref(r), C.byref(d))
+        return {"kind": k.value, "r2c": bool(r.value), "direct_out": bool(d.value)}
+
     def compute_source_term(self, u, v, w, dt):
         """compute_source_term!(pressure, solver, Δt, Ũ) (solve_for_pressure.jl:57-76)"""
         _lib.call("ocn_poisson_compute_source_term", self._h, u.ptr, v.ptr, w.ptr, float(dt), stream_ptr())
