@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--math", choices=("fast", "strict"), default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
 
 

@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, do
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny) return;
-#pragma unroll 1
-    for (int f = 0; f < a.n; ++f) {
+#pragma unroll
+    for (int f = 0; f < MAX_TUPLE; ++f) {  // fully unrolled: the loads of all fields are in flight together
+        if (f >= a.n) break;
         const int loc = a.loc[f];
         // launch!(..., :xyz; exclude_periphery=true): Face in a Bounded dim starts at 2 (kernel_launching.jl:113-161)
         if (MODE != 3 && (loc & 4) && g.tz == OCN_BOUNDED && g.Nz > 1 && k < 2) continue;

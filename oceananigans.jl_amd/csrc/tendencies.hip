@@ -8,7 +8,11 @@
 // Kernel "direct": one thread per cell, x fastest across the 64 lanes of a wave so every stencil row is a
 // coalesced 512-B read; the 6 (u) + 6 (v) + 6 (w) face fluxes a cell needs are evaluated in registers.
 // k is blockIdx.z, so all Bounded-z order-reduction tests are wave-uniform (no divergence).
+#include <cstdlib>
+#include <cstring>
+
 #include "ocn_weno.h"
+
 
 namespace OCN_NS {
 
@@ -120,6 +124,187 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Kernel "tiled": each of the 9 momentum fluxes is evaluated ONCE per cell (the reference evaluates each twice,
+// SURVEY.md Appendix B) and shared with the neighbouring cell through LDS.
+//
+//  * a workgroup owns a TX x TY patch of (i,j) columns and marches KZ planes upward in k;
+//  * every thread keeps the z-stencils of its own column (u, v, w at k-2..k+3) in registers, so each global value
+//    enters the workgroup once per (TX+5)x(TY+5) tile instead of once per stencil tap;
+//  * plane k of u, v and planes k, k+1 of w live in LDS with a 3/2-cell ring for the x and y stencils
+//    (own cells come from the register windows, only the ring is re-read from L2);
+//  * fluxes are indexed so that a cell only needs its EAST and NORTH neighbours' values:
+//      x-fluxes owned by thread (i,j): Fuu(i-1) [centre], Fuv(i) [face], Fuw(i) [face]
+//      y-fluxes owned:                 Fvv(j-1) [centre], Fvu(j) [face], Fvw(j) [face]
+//      z-fluxes: top-face Fwu(k+1), Fwv(k+1) and centre Fww(k); the bottom ones are last iteration's registers.
+//    Patches therefore overlap by one column/row: (TX-1) x (TY-1) outputs per TX x TY threads.
+// All flux expressions are the same as in the direct kernel, so strict mode stays bit-identical to the oracle.
+// ---------------------------------------------------------------------------------------------------
+template <int TZ, int TX, int TY, int W>
+__global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
+                                                                    const double *__restrict__ v,
+                                                                    const double *__restrict__ w, double *__restrict__ Gu,
+                                                                    double *__restrict__ Gv, double *__restrict__ Gw, Range r,
+                                                                    int KZ)
+{
+    constexpr int P = OCN_PERIODIC;
+    constexpr int LX = TX + 5, LY = TY + 5, NT = TX * TY;
+    __shared__ double su[LY][LX], sv[LY][LX], sw[2][LY][LX];
+    __shared__ double ex[6][NT];  // Fuu_w, Fuv, Fuw (from the east neighbour), Fvv_s, Fvu, Fvw (from the north one)
+
+    const Metrics M = make_metrics(g);
+    const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
+    const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
+    const int k_start = r.k0 + blockIdx.z * KZ;
+    const int k_end = min(k_start + KZ - 1, r.k1);
+    // own column (clamped into the parent array; clamped duplicates are never written)
+    const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
+    const int i = min(ti0 + tx, imax), j = min(tj0 + ty, jmax);
+    const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
+    const int lx = tx + 3, ly = ty + 3;  // own cell inside the LDS tile
+
+    const double *pu = u + ocn::at(Lu, i, j, 1), *pv = v + ocn::at(Lv, i, j, 1), *pw = w + ocn::at(Lw, i, j, 1);
+    const long long su3 = Lu.s3, sv3 = Lv.s3, sw3 = Lw.s3;
+#define ZU(k) pu[((k)-1) * su3]
+#define ZV(k) pv[((k)-1) * sv3]
+#define ZW(k) pw[((k)-1) * sw3]
+
+    // ring cells of the tile this thread fetches (tile cell c <-> (c % LX, c / LX)); own cells come from registers
+    auto ring_load = [&](const double *__restrict__ f, const Lay &L, int k, double (*dst)[LX]) {
+#pragma unroll
+        for (int c = tid; c < LX * LY; c += NT) {
+            const int cx = c % LX, cy = c / LX;
+            if (cx >= 3 && cx < 3 + TX && cy >= 3 && cy < 3 + TY) continue;
+            const int gi = min(ti0 - 3 + cx, imax), gj = min(tj0 - 3 + cy, jmax);
+            dst[cy][cx] = f[ocn::at(L, gi, gj, k)];
+        }
+    };
+
+    // z-windows: zu/zv hold k-2..k+3, zw holds k-2..k+3 (index m <-> k-2+m)
+    double zu[6], zv[6], zw[6];
+    int k = k_start;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        zu[m] = ZU(k - 2 + m);
+        zv[m] = ZV(k - 2 + m);
+        zw[m] = ZW(k - 2 + m);
+    }
+    // ---- prologue: bottom-face fluxes Fwu(k), Fwv(k) need w-tile(k) and u/v[k-3..k+2]; Fww(k-1) needs w[k-3..k+2]
+    double fwu_bot, fwv_bot, fww_prev;
+    {
+        sw[k & 1][ly][lx] = zw[2];
+        ring_load(w, Lw, k, sw[k & 1]);
+        __syncthreads();
+        const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
+        const double(*swk)[LX] = sw[k & 1];
+        {   // Fwu(k): sym x-face of Az*w at plane k ; biased z-face of u
+            const double a = M.Az;
+            const double wt = sym_interp<P, false>([&](int m) { return a * swk[ly][lx + m]; }, i, Nx);
+            const double S[6] = {um3, zu[0], zu[1], zu[2], zu[3], zu[4]};
+            fwu_bot = wt * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wt > 0);
+        }
+        {   // Fwv(k): sym y-face of Az*w ; biased z-face of v
+            const double a = M.Az;
+            const double wt = sym_interp<P, false>([&](int m) { return a * swk[ly + m][lx]; }, j, Ny);
+            const double S[6] = {vm3, zv[0], zv[1], zv[2], zv[3], zv[4]};
+            fwv_bot = wt * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wt > 0);
+        }
+        {   // Fww(k-1): sym/biased z-centre of w at centre k-1 (line shifted to face k): w[k-3..k+2]
+            const double a = M.Az;
+            const double S[6] = {wm3, zw[0], zw[1], zw[2], zw[3], zw[4]};
+            const double wt = sym_interp<TZ, true>([&](int m) { return a * S[m + 3]; }, k - 1, Nz);
+            fww_prev = wt * bias_interp<TZ, true>([&](int m) { return S[m + 3]; }, k - 1, Nz, wt > 0);
+        }
+    }
+
+    for (; k <= k_end; ++k) {
+        // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident)
+        su[ly][lx] = zu[2];
+        sv[ly][lx] = zv[2];
+        sw[(k + 1) & 1][ly][lx] = zw[3];
+        ring_load(u, Lu, k, su);
+        ring_load(v, Lv, k, sv);
+        ring_load(w, Lw, k + 1, sw[(k + 1) & 1]);
+        __syncthreads();
+        const double(*swk)[LX] = sw[k & 1];
+        const double(*swt)[LX] = sw[(k + 1) & 1];
+        const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
+
+        // ---- x-fluxes (shared with the WEST neighbour's outputs)
+        double fuu, fuv, fuw;
+        {   // Fuu(i-1): centre i-1 == face i of the shifted line: u[i-3..i+2]
+            const double ut = sym_interp<P, true>([&](int m) { return ax * su[ly][lx + m]; }, i - 1, Nx);
+            fuu = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+        }
+        {   // Fuv(i): sym y-face of Ax*u ; biased x-face of v
+            const double ut = sym_interp<P, false>([&](int m) { return ax * su[ly + m][lx]; }, j, Ny);
+            fuv = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
+        }
+        {   // Fuw(i): sym z-face of Ax*u (own column) ; biased x-face of w
+            const double ut = sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
+            fuw = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
+        }
+        // ---- y-fluxes (shared with the SOUTH neighbour's outputs)
+        double fvv, fvu, fvw;
+        {   // Fvv(j-1)
+            const double vt = sym_interp<P, true>([&](int m) { return ay * sv[ly + m][lx]; }, j - 1, Ny);
+            fvv = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+        }
+        {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
+            const double vt = sym_interp<P, false>([&](int m) { return ay * sv[ly][lx + m]; }, i, Nx);
+            fvu = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
+        }
+        {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
+            const double vt = sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
+            fvw = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
+        }
+        // ---- z-fluxes on the top face k+1 and at centre k
+        double fwu_top, fwv_top, fww;
+        {
+            const double wt = sym_interp<P, false>([&](int m) { return az * swt[ly][lx + m]; }, i, Nx);
+            fwu_top = wt * bias_interp<TZ, false>([&](int m) { return zu[3 + m]; }, k + 1, Nz, wt > 0);
+        }
+        {
+            const double wt = sym_interp<P, false>([&](int m) { return az * swt[ly + m][lx]; }, j, Ny);
+            fwv_top = wt * bias_interp<TZ, false>([&](int m) { return zv[3 + m]; }, k + 1, Nz, wt > 0);
+        }
+        {   // Fww(k): line shifted to face k+1: w[k-2..k+3]
+            const double wt = sym_interp<TZ, true>([&](int m) { return az * zw[3 + m]; }, k, Nz);
+            fww = wt * bias_interp<TZ, true>([&](int m) { return zw[3 + m]; }, k, Nz, wt > 0);
+        }
+        ex[0][tid] = fuu; ex[1][tid] = fuv; ex[2][tid] = fuw;
+        ex[3][tid] = fvv; ex[4][tid] = fvu; ex[5][tid] = fvw;
+        __syncthreads();
+        if (writes) {
+            const int e = tid + 1, n = tid + TX;
+            const double rVc = 1 / (M.Az * M.dzC(k));
+            if (i >= r.ou) Gu[ocn::at(Lu, i, j, k)] = -(rVc * (((ex[0][e] - fuu) + (ex[4][n] - fvu)) + (fwu_top - fwu_bot)));
+            if (j >= r.ov) Gv[ocn::at(Lv, i, j, k)] = -(rVc * (((ex[1][e] - fuv) + (ex[3][n] - fvv)) + (fwv_top - fwv_bot)));
+            if (k >= r.ow) {
+                const double rVf = 1 / (M.Az * M.dzF(k));
+                Gw[ocn::at(Lw, i, j, k)] = -(rVf * (((ex[2][e] - fuw) + (ex[5][n] - fvw)) + (fww - fww_prev)));
+            }
+        }
+        fwu_bot = fwu_top; fwv_bot = fwv_top; fww_prev = fww;
+        if (k < k_end) {
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                zu[m] = zu[m + 1];
+                zv[m] = zv[m + 1];
+                zw[m] = zw[m + 1];
+            }
+            zu[5] = ZU(k + 4);
+            zv[5] = ZV(k + 4);
+            zw[5] = ZW(k + 4);
+        }
+    }
+#undef ZU
+#undef ZV
+#undef ZW
+}
+
 // K4 tracer: flux = (A * U[i,j,k]) * cR   (upwind_biased_advective_fluxes.jl:99-121)
 template <int TB>
 __device__ __forceinline__ double tracer_flux(double area, double ut, const double *__restrict__ pc, long long sc, int idx,
@@ -158,6 +343,12 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
     Gc[ocn::at(Lc, i, j, k)] = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
 }
 
+static int tile_variant()
+{
+    const char *e = getenv("OCN_TILE");
+    return e ? atoi(e) : 0;
+}
+
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 {
     if (range) {
@@ -184,6 +375,37 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;
+    static const int force_direct = (getenv("OCN_TENDENCY_KERNEL") && !strcmp(getenv("OCN_TENDENCY_KERNEL"), "direct"));
+    if (!force_direct && grid->tz != OCN_FLAT && wx >= 16 && wy >= 8 && wz >= 4) {
+        // tile variants (TX, TY, min waves/SIMD); OCN_TILE selects one at run time for tuning
+        static const int variant = tile_variant();
+#define OCN_LAUNCH_TILED(TX, TY, W)                                                                                        \
+    do {                                                                                                                   \
+        const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));                                           \
+        int KZ = wz; /* z-chunk: enough workgroups to fill the chip, long enough to amortise the 3-flux prologue */        \
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;                                           \
+        dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                   \
+        if (grid->tz == OCN_PERIODIC)                                                                                      \
+            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v, \
+                               w, Gu, Gv, Gw, r, KZ);                                                                       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v,  \
+                               w, Gu, Gv, Gw, r, KZ);                                                                       \
+    } while (0)
+        switch (variant) {
+            case 1: OCN_LAUNCH_TILED(32, 16, 4); break;
+            case 7: OCN_LAUNCH_TILED(32, 16, 2); break;
+            case 3: OCN_LAUNCH_TILED(64, 4, 3); break;
+            case 4: OCN_LAUNCH_TILED(16, 16, 3); break;
+            case 5: OCN_LAUNCH_TILED(64, 8, 2); break;
+            case 6: OCN_LAUNCH_TILED(32, 8, 4); break;
+            default: OCN_LAUNCH_TILED(32, 8, 3); break;  // fastest measured at 512^3 (6.9 ms vs 9.7 ms direct)
+        }
+#undef OCN_LAUNCH_TILED
+        OCN_CHECK_HIP(hipGetLastError());
+        return OCN_SUCCESS;
+    }
     dim3 block(64, 4, 1);
     dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
     switch (grid->tz) {

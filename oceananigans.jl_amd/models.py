@@ -86,6 +86,7 @@ class NonhydrostaticModel:
         else:
             raise ValueError(f"unknown timestepper {timestepper!r}")
         self._tuple_cache = {}
+        self.copy_cached_tendencies = False
         update_state(self, compute_tendencies=False)
 
     def prognostic_fields(self):
@@ -100,10 +101,10 @@ class NonhydrostaticModel:
 
     # cached ctypes tuples (pointers never change after construction)
     def _tuples(self):
-        c = self._tuple_cache
+        ts = self.timestepper
+        c = self._tuple_cache.setdefault(ts.Gn[0].ptr, {})  # one cached set per role assignment of the G buffers
         if not c:
             prog = self.prognostic_fields()
-            ts = self.timestepper
             c["n"] = len(prog)
             c["U"] = _lib.ptr_array([f.ptr for f in prog])
             c["Gn"] = _lib.ptr_array([f.ptr for f in ts.Gn])
@@ -170,10 +171,21 @@ def pressure_correct_velocities(model, dt):
               float(dt), stream_ptr())
 
 
-def cache_previous_tendencies(model):
-    """cache_previous_tendencies! (store_tendencies.jl:12-22)"""
-    t = model._tuples()
-    _lib.call("ocn_cache_previous_tendencies", model.grid.cref, t["n"], t["Gm"], t["Gn"], t["locs"], stream_ptr())
+def cache_previous_tendencies(model, copy=None):
+    """cache_previous_tendencies! (store_tendencies.jl:12-22): G⁻ <- Gⁿ.
+
+    By default the two tendency tuples swap roles instead of being copied: the next compute_tendencies! overwrites
+    every entry of Gⁿ that any kernel ever reads or writes (interior incl. the never-touched wall faces, which are 0
+    in both buffers), so a swap is indistinguishable from the copy and saves a 48 B/cell pass per stage.
+    `copy=True` (or model.copy_cached_tendencies) runs the reference's copy kernel K7 through the C ABI."""
+    if copy is None:
+        copy = model.copy_cached_tendencies
+    if copy:
+        t = model._tuples()
+        _lib.call("ocn_cache_previous_tendencies", model.grid.cref, t["n"], t["Gm"], t["Gn"], t["locs"], stream_ptr())
+    else:
+        ts = model.timestepper
+        ts.Gn, ts.Gm = ts.Gm, ts.Gn
 
 
 def rk3_substep(model, dt, gamma, zeta):
