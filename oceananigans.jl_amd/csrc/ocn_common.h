@@ -79,6 +79,14 @@ __host__ __device__ inline long long at(const Lay &L, int i, int j, int k)
     return L.o + (i - 1) + L.s2 * (j - 1) + L.s3 * (k - 1);
 }
 
+// Optional epilogue of the tendency launch: the NEXT RK3 substep  Uo = U + dt*(gamma*G + zeta*Gm)  (runge_kutta_3.jl:194-200)
+struct FuseArgs {
+    const double *Gm[3];
+    double *Uo[3];
+    double dt, gamma, zeta;
+    int on;
+};
+
 int validate_grid(const ocn_grid *g);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -40,13 +40,13 @@ int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src,
 
 namespace ocn_strict {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
-                               double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                               double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream);
 }
 namespace ocn_fast {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
-                               double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                               double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream);
 }

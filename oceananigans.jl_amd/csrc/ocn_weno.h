@@ -52,9 +52,22 @@ __device__ __forceinline__ double beta3(double p0, double p1, double p2, double 
     return p0 * ((c0 * p0 + c1 * p1) + c2 * p2) + p1 * (c3 * p1 + c4 * p2) + (p2 * p2) * c5;
 }
 
+#if !OCN_STRICT
+// 1/x to fp64 round-off: v_rcp_f64 seed + two Newton steps (no div_scale / div_fixup: operands here are well inside
+// the normal range: sums of squares bounded below by eps^6 ~ 1e-48 and above by |u|^12).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+#endif
+
 // WENO5 reconstruction at a face from S = psi[n-3..n+2] (weno_interpolants.jl:341-348, 445-447, 475-511)
 __device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
 {
+#if OCN_STRICT
     // left: psi0=(S2,S3,S4) psi1=(S1,S2,S3) psi2=(S0,S1,S2); right: psi0=(S3,S2,S1) psi1=(S4,S3,S2) psi2=(S5,S4,S3)
     const double a0 = left ? S2 : S3, a1 = left ? S3 : S2, a2 = left ? S4 : S1;
     const double b0 = left ? S1 : S4, b1 = left ? S2 : S3, b2 = left ? S3 : S2;
@@ -66,22 +79,35 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double p0 = (OCN_W5P_00 * a0 + OCN_W5P_01 * a1) + OCN_W5P_02 * a2;
     const double p1 = (OCN_W5P_10 * b0 + OCN_W5P_11 * b1) + OCN_W5P_12 * b2;
     const double p2 = (OCN_W5P_20 * c0 + OCN_W5P_21 * c1) + OCN_W5P_22 * c2;
-#if OCN_STRICT
     const double q0 = tau / (be0 + OCN_WENO_EPS), q1 = tau / (be1 + OCN_WENO_EPS), q2 = tau / (be2 + OCN_WENO_EPS);
     const double al0 = OCN_C5_0 * (1 + q0 * q0), al1 = OCN_C5_1 * (1 + q1 * q1), al2 = OCN_C5_2 * (1 + q2 * q2);
     const double sa = (al0 + al1) + al2;
     const double w0 = al0 / sa, w1 = al1 / sa, w2 = al2 / sa;
     return (w0 * p0 + w1 * p1) + w2 * p2;
 #else
-    // Same rational function with ONE division: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = beta_r + eps;
+    // The right-biased stencils are the left-biased ones of the mirrored data: select 5 inputs, then one code path.
+    const double T0 = left ? S0 : S5, T1 = left ? S1 : S4, T2 = left ? S2 : S3, T3 = left ? S3 : S2, T4 = left ? S4 : S1;
+    // smoothness indicators in difference form: the reference polynomial (coefficients 10,-31,11,25,-19,4 etc.) equals
+    // 13/4 D^2 + 3/4 E^2 with D the second difference and E the one-sided first difference of each sub-stencil.
+    const double D0 = __builtin_fma(-2.0, T3, T2) + T4, E0 = __builtin_fma(-4.0, T3, __builtin_fma(3.0, T2, T4));
+    const double D1 = __builtin_fma(-2.0, T2, T1) + T3, E1 = T1 - T3;
+    const double D2 = __builtin_fma(-2.0, T1, T0) + T2, E2 = __builtin_fma(-4.0, T1, __builtin_fma(3.0, T2, T0));
+    const double be0 = __builtin_fma(0.75 * E0, E0, (3.25 * D0) * D0);
+    const double be1 = __builtin_fma(0.75 * E1, E1, (3.25 * D1) * D1);
+    const double be2 = __builtin_fma(0.75 * E2, E2, (3.25 * D2) * D2);
+    const double tau = fabs(be0 - be2);
+    const double p0 = (OCN_W5P_00 * T2 + OCN_W5P_01 * T3) + OCN_W5P_02 * T4;
+    const double p1 = (OCN_W5P_10 * T1 + OCN_W5P_11 * T2) + OCN_W5P_12 * T3;
+    const double p2 = (OCN_W5P_20 * T0 + OCN_W5P_21 * T1) + OCN_W5P_22 * T2;
+    // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = beta_r + eps;
     // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2.
     const double d0 = be0 + OCN_WENO_EPS, d1 = be1 + OCN_WENO_EPS, d2 = be2 + OCN_WENO_EPS;
     const double t2 = tau * tau;
     const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
-    const double n0 = OCN_C5_0 * (e0 + t2) * (e1 * e2);
-    const double n1 = OCN_C5_1 * (e1 + t2) * (e0 * e2);
-    const double n2 = OCN_C5_2 * (e2 + t2) * (e0 * e1);
-    return (n0 * p0 + n1 * p1 + n2 * p2) / (n0 + n1 + n2);
+    const double n0 = (OCN_C5_0 * (e0 + t2)) * (e1 * e2);
+    const double n1 = (OCN_C5_1 * (e1 + t2)) * (e0 * e2);
+    const double n2 = (OCN_C5_2 * (e2 + t2)) * (e0 * e1);
+    return (n0 * p0 + n1 * p1 + n2 * p2) * fast_rcp(n0 + n1 + n2);
 #endif
 }
 
@@ -122,6 +148,28 @@ __device__ __forceinline__ double sym_interp(V val, int idx, int N)
         if (!hi) return 0.5 * val(-1) + 0.5 * val(0);  // Centered(order=2) for every deeper fallback
     }
     return centered4(val(-2), val(-1), val(0), val(1));
+}
+
+// symmetric interpolation of (a * psi) for a metric `a` that is constant along the line: the reference multiplies every
+// stencil value (strict); the interpolation is linear, so fast math factors the metric out.
+template <int TOPO, bool CENTER, class V>
+__device__ __forceinline__ double sym_interp_scaled(V val, double a, int idx, int N)
+{
+#if OCN_STRICT
+    return sym_interp<TOPO, CENTER>([&](int m) { return a * val(m); }, idx, N);
+#else
+    return a * sym_interp<TOPO, CENTER>(val, idx, N);
+#endif
+}
+
+// 1 / V for the tendency prefactor
+__device__ __forceinline__ double recip_volume(double V)
+{
+#if OCN_STRICT
+    return 1 / V;
+#else
+    return fast_rcp(V);
+#endif
 }
 
 template <int TOPO, bool CENTER, class V>

@@ -142,15 +142,18 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
 // ---------------------------------------------------------------------------------------------------
 template <int TZ, int TX, int TY, int W>
 __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
-                                                                    const double *__restrict__ v,
-                                                                    const double *__restrict__ w, double *__restrict__ Gu,
-                                                                    double *__restrict__ Gv, double *__restrict__ Gw, Range r,
-                                                                    int KZ)
+                                                                       const double *__restrict__ v,
+                                                                       const double *__restrict__ w, double *__restrict__ Gu,
+                                                                       double *__restrict__ Gv, double *__restrict__ Gw, Range r,
+                                                                       int KZ, ocn::FuseArgs fz)
 {
     constexpr int P = OCN_PERIODIC;
     constexpr int LX = TX + 5, LY = TY + 5, NT = TX * TY;
+    constexpr int NRING = LX * LY - NT;         // ring cells of one tile
+    constexpr int RPT = (NRING + NT - 1) / NT;  // ring cells per thread (1 or 2)
+    static_assert(RPT <= 2, "tile too small for its ring");
     __shared__ double su[LY][LX], sv[LY][LX], sw[2][LY][LX];
-    __shared__ double ex[6][NT];  // Fuu_w, Fuv, Fuw (from the east neighbour), Fvv_s, Fvu, Fvw (from the north one)
+    __shared__ double ex[6][NT];  // Fuu_w, Fuv, Fuw (read by the west neighbour), Fvv_s, Fvu, Fvw (by the south one)
 
     const Metrics M = make_metrics(g);
     const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
@@ -171,18 +174,33 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #define ZV(k) pv[((k)-1) * sv3]
 #define ZW(k) pw[((k)-1) * sw3]
 
-    // ring cells of the tile this thread fetches (tile cell c <-> (c % LX, c / LX)); own cells come from registers
-    auto ring_load = [&](const double *__restrict__ f, const Lay &L, int k, double (*dst)[LX]) {
+    // Static ring assignment: ring cell q (0 <= q < NRING) <-> tile cell (cx, cy) outside the TX x TY core.
+    int rcx[RPT], rcy[RPT];
+    bool ron[RPT];
+    const double *ru[RPT], *rv[RPT], *rw[RPT];
 #pragma unroll
-        for (int c = tid; c < LX * LY; c += NT) {
-            const int cx = c % LX, cy = c / LX;
-            if (cx >= 3 && cx < 3 + TX && cy >= 3 && cy < 3 + TY) continue;
-            const int gi = min(ti0 - 3 + cx, imax), gj = min(tj0 - 3 + cy, jmax);
-            dst[cy][cx] = f[ocn::at(L, gi, gj, k)];
+    for (int s = 0; s < RPT; ++s) {
+        const int q = tid + s * NT;
+        ron[s] = q < NRING;
+        int cx, cy;
+        if (q < 3 * LX) {  // 3 south rows
+            cx = q % LX; cy = q / LX;
+        } else if (q < 5 * LX) {  // 2 north rows
+            cx = (q - 3 * LX) % LX; cy = 3 + TY + (q - 3 * LX) / LX;
+        } else {  // 3 west + 2 east columns of the core rows
+            const int t = q - 5 * LX, c = t % 5;
+            cy = 3 + t / 5;
+            cx = c < 3 ? c : TX + c;
         }
-    };
+        if (!ron[s]) { cx = 0; cy = 0; }
+        rcx[s] = cx; rcy[s] = cy;
+        const int gi = min(ti0 - 3 + cx, imax), gj = min(tj0 - 3 + cy, jmax);
+        ru[s] = u + ocn::at(Lu, gi, gj, 1);
+        rv[s] = v + ocn::at(Lv, gi, gj, 1);
+        rw[s] = w + ocn::at(Lw, gi, gj, 1);
+    }
 
-    // z-windows: zu/zv hold k-2..k+3, zw holds k-2..k+3 (index m <-> k-2+m)
+    // z-windows: index m <-> k-2+m
     double zu[6], zv[6], zw[6];
     int k = k_start;
 #pragma unroll
@@ -193,112 +211,145 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     }
     // ---- prologue: bottom-face fluxes Fwu(k), Fwv(k) need w-tile(k) and u/v[k-3..k+2]; Fww(k-1) needs w[k-3..k+2]
     double fwu_bot, fwv_bot, fww_prev;
+    double nu[RPT], nv[RPT], nw[RPT];  // prefetched ring values: u(k), v(k), w(k+1)
     {
         sw[k & 1][ly][lx] = zw[2];
-        ring_load(w, Lw, k, sw[k & 1]);
+#pragma unroll
+        for (int s = 0; s < RPT; ++s)
+            if (ron[s]) sw[k & 1][rcy[s]][rcx[s]] = rw[s][(k - 1) * sw3];
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+            nu[s] = ron[s] ? ru[s][(k - 1) * su3] : 0.0;
+            nv[s] = ron[s] ? rv[s][(k - 1) * sv3] : 0.0;
+            nw[s] = ron[s] ? rw[s][k * sw3] : 0.0;
+        }
         const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
         const double(*swk)[LX] = sw[k & 1];
         {   // Fwu(k): sym x-face of Az*w at plane k ; biased z-face of u
             const double a = M.Az;
-            const double wt = sym_interp<P, false>([&](int m) { return a * swk[ly][lx + m]; }, i, Nx);
+            const double wt = sym_interp_scaled<P, false>([&](int m) { return swk[ly][lx + m]; }, a, i, Nx);
             const double S[6] = {um3, zu[0], zu[1], zu[2], zu[3], zu[4]};
             fwu_bot = wt * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wt > 0);
         }
         {   // Fwv(k): sym y-face of Az*w ; biased z-face of v
             const double a = M.Az;
-            const double wt = sym_interp<P, false>([&](int m) { return a * swk[ly + m][lx]; }, j, Ny);
+            const double wt = sym_interp_scaled<P, false>([&](int m) { return swk[ly + m][lx]; }, a, j, Ny);
             const double S[6] = {vm3, zv[0], zv[1], zv[2], zv[3], zv[4]};
             fwv_bot = wt * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wt > 0);
         }
         {   // Fww(k-1): sym/biased z-centre of w at centre k-1 (line shifted to face k): w[k-3..k+2]
             const double a = M.Az;
             const double S[6] = {wm3, zw[0], zw[1], zw[2], zw[3], zw[4]};
-            const double wt = sym_interp<TZ, true>([&](int m) { return a * S[m + 3]; }, k - 1, Nz);
+            const double wt = sym_interp_scaled<TZ, true>([&](int m) { return S[m + 3]; }, a, k - 1, Nz);
             fww_prev = wt * bias_interp<TZ, true>([&](int m) { return S[m + 3]; }, k - 1, Nz, wt > 0);
         }
     }
 
     for (; k <= k_end; ++k) {
-        // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident)
+        // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident) from registers
         su[ly][lx] = zu[2];
         sv[ly][lx] = zv[2];
         sw[(k + 1) & 1][ly][lx] = zw[3];
-        ring_load(u, Lu, k, su);
-        ring_load(v, Lv, k, sv);
-        ring_load(w, Lw, k + 1, sw[(k + 1) & 1]);
+#pragma unroll
+        for (int s = 0; s < RPT; ++s)
+            if (ron[s]) {
+                su[rcy[s]][rcx[s]] = nu[s];
+                sv[rcy[s]][rcx[s]] = nv[s];
+                sw[(k + 1) & 1][rcy[s]][rcx[s]] = nw[s];
+            }
         __syncthreads();
+        // ---- prefetch what the NEXT plane needs; the loads fly under this plane's arithmetic
+        double zu_n = 0, zv_n = 0, zw_n = 0;
+        if (k < k_end) {
+            zu_n = ZU(k + 4);
+            zv_n = ZV(k + 4);
+            zw_n = ZW(k + 4);
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) {
+                    nu[s] = ru[s][k * su3];
+                    nv[s] = rv[s][k * sv3];
+                    nw[s] = rw[s][(k + 1) * sw3];
+                }
+        }
         const double(*swk)[LX] = sw[k & 1];
         const double(*swt)[LX] = sw[(k + 1) & 1];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
 
-        // ---- x-fluxes (shared with the WEST neighbour's outputs)
-        double fuu, fuv, fuw;
+        // ---- x-fluxes (consumed by this cell and its WEST neighbour)
         {   // Fuu(i-1): centre i-1 == face i of the shifted line: u[i-3..i+2]
-            const double ut = sym_interp<P, true>([&](int m) { return ax * su[ly][lx + m]; }, i - 1, Nx);
-            fuu = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+            const double ut = sym_interp_scaled<P, true>([&](int m) { return su[ly][lx + m]; }, ax, i - 1, Nx);
+            ex[0][tid] = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
         }
         {   // Fuv(i): sym y-face of Ax*u ; biased x-face of v
-            const double ut = sym_interp<P, false>([&](int m) { return ax * su[ly + m][lx]; }, j, Ny);
-            fuv = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
+            const double ut = sym_interp_scaled<P, false>([&](int m) { return su[ly + m][lx]; }, ax, j, Ny);
+            ex[1][tid] = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
         }
         {   // Fuw(i): sym z-face of Ax*u (own column) ; biased x-face of w
             const double ut = sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
-            fuw = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
+            ex[2][tid] = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
         }
-        // ---- y-fluxes (shared with the SOUTH neighbour's outputs)
-        double fvv, fvu, fvw;
+        // ---- y-fluxes (consumed by this cell and its SOUTH neighbour)
         {   // Fvv(j-1)
-            const double vt = sym_interp<P, true>([&](int m) { return ay * sv[ly + m][lx]; }, j - 1, Ny);
-            fvv = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+            const double vt = sym_interp_scaled<P, true>([&](int m) { return sv[ly + m][lx]; }, ay, j - 1, Ny);
+            ex[3][tid] = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
         }
         {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
-            const double vt = sym_interp<P, false>([&](int m) { return ay * sv[ly][lx + m]; }, i, Nx);
-            fvu = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
+            const double vt = sym_interp_scaled<P, false>([&](int m) { return sv[ly][lx + m]; }, ay, i, Nx);
+            ex[4][tid] = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
         }
         {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
             const double vt = sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
-            fvw = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
+            ex[5][tid] = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
         }
         // ---- z-fluxes on the top face k+1 and at centre k
         double fwu_top, fwv_top, fww;
         {
-            const double wt = sym_interp<P, false>([&](int m) { return az * swt[ly][lx + m]; }, i, Nx);
+            const double wt = sym_interp_scaled<P, false>([&](int m) { return swt[ly][lx + m]; }, az, i, Nx);
             fwu_top = wt * bias_interp<TZ, false>([&](int m) { return zu[3 + m]; }, k + 1, Nz, wt > 0);
         }
         {
-            const double wt = sym_interp<P, false>([&](int m) { return az * swt[ly + m][lx]; }, j, Ny);
+            const double wt = sym_interp_scaled<P, false>([&](int m) { return swt[ly + m][lx]; }, az, j, Ny);
             fwv_top = wt * bias_interp<TZ, false>([&](int m) { return zv[3 + m]; }, k + 1, Nz, wt > 0);
         }
         {   // Fww(k): line shifted to face k+1: w[k-2..k+3]
-            const double wt = sym_interp<TZ, true>([&](int m) { return az * zw[3 + m]; }, k, Nz);
+            const double wt = sym_interp_scaled<TZ, true>([&](int m) { return zw[3 + m]; }, az, k, Nz);
             fww = wt * bias_interp<TZ, true>([&](int m) { return zw[3 + m]; }, k, Nz, wt > 0);
         }
-        ex[0][tid] = fuu; ex[1][tid] = fuv; ex[2][tid] = fuw;
-        ex[3][tid] = fvv; ex[4][tid] = fvu; ex[5][tid] = fvw;
         __syncthreads();
         if (writes) {
             const int e = tid + 1, n = tid + TX;
-            const double rVc = 1 / (M.Az * M.dzC(k));
-            if (i >= r.ou) Gu[ocn::at(Lu, i, j, k)] = -(rVc * (((ex[0][e] - fuu) + (ex[4][n] - fvu)) + (fwu_top - fwu_bot)));
-            if (j >= r.ov) Gv[ocn::at(Lv, i, j, k)] = -(rVc * (((ex[1][e] - fuv) + (ex[3][n] - fvv)) + (fwv_top - fwv_bot)));
-            if (k >= r.ow) {
-                const double rVf = 1 / (M.Az * M.dzF(k));
-                Gw[ocn::at(Lw, i, j, k)] = -(rVf * (((ex[2][e] - fuw) + (ex[5][n] - fvw)) + (fww - fww_prev)));
+            const double rVc = recip_volume(M.Az * M.dzC(k));
+            const long long ou_ = ocn::at(Lu, i, j, k), ov_ = ocn::at(Lv, i, j, k), ow_ = ocn::at(Lw, i, j, k);
+            if (i >= r.ou) {
+                const double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
+                Gu[ou_] = G;
+                if (fz.on) fz.Uo[0][ou_] = zu[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][ou_]);
             }
+            if (j >= r.ov) {
+                const double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
+                Gv[ov_] = G;
+                if (fz.on) fz.Uo[1][ov_] = zv[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][ov_]);
+            }
+            if (k >= r.ow) {
+                const double rVf = recip_volume(M.Az * M.dzF(k));
+                const double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
+                Gw[ow_] = G;
+                if (fz.on) fz.Uo[2][ow_] = zw[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]);
+            } else if (fz.on) {
+                fz.Uo[2][ow_] = zw[2];  // wall face: neither the tendency nor the substep touch it (exclude_periphery)
+            }
+            if (fz.on && TZ == OCN_BOUNDED && k == Nz) fz.Uo[2][ow_ + sw3] = zw[3];  // top wall face k = Nz+1
         }
         fwu_bot = fwu_top; fwv_bot = fwv_top; fww_prev = fww;
-        if (k < k_end) {
 #pragma unroll
-            for (int m = 0; m < 5; ++m) {
-                zu[m] = zu[m + 1];
-                zv[m] = zv[m + 1];
-                zw[m] = zw[m + 1];
-            }
-            zu[5] = ZU(k + 4);
-            zv[5] = ZV(k + 4);
-            zw[5] = ZW(k + 4);
+        for (int m = 0; m < 5; ++m) {
+            zu[m] = zu[m + 1];
+            zv[m] = zv[m + 1];
+            zw[m] = zw[m + 1];
         }
+        zu[5] = zu_n; zv[5] = zv_n; zw[5] = zw_n;
     }
 #undef ZU
 #undef ZV
@@ -368,8 +419,10 @@ static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 }
 
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
-                               double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+                               double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream)
 {
+    ocn::FuseArgs fz{};
+    if (fuse) fz = *fuse;
     Range r;
     int st = make_range(grid, range, r);
     if (st != OCN_SUCCESS) return st;
@@ -388,10 +441,10 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                   \
         if (grid->tz == OCN_PERIODIC)                                                                                      \
             hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v, \
-                               w, Gu, Gv, Gw, r, KZ);                                                                       \
+                               w, Gu, Gv, Gw, r, KZ, fz);                                                                   \
         else                                                                                                               \
             hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v,  \
-                               w, Gu, Gv, Gw, r, KZ);                                                                       \
+                               w, Gu, Gv, Gw, r, KZ, fz);                                                                   \
     } while (0)
         switch (variant) {
             case 1: OCN_LAUNCH_TILED(32, 16, 4); break;
@@ -405,6 +458,10 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
 #undef OCN_LAUNCH_TILED
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
+    }
+    if (fz.on) {
+        ocn::set_error("fused tendency + substep launch needs the tiled kernel (non-Flat z, range at least 16 x 8 x 4)");
+        return OCN_ERR_UNSUPPORTED;
     }
     dim3 block(64, 4, 1);
     dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);

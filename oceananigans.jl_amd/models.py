@@ -14,6 +14,8 @@ Julia's `f!` names are spelled `f` here.  closure, buoyancy, coriolis, forcing, 
 """
 import math
 
+import torch
+
 from . import _lib
 from .advection import WENO
 from .architectures import stream_ptr
@@ -87,6 +89,10 @@ class NonhydrostaticModel:
             raise ValueError(f"unknown timestepper {timestepper!r}")
         self._tuple_cache = {}
         self.copy_cached_tendencies = False
+        # fused stage boundaries (tendencies + next substep in one launch) need the tiled kernel, no tracers, one rank
+        self.fuse_stage_boundaries = (not self.tracers and grid.topology[2] != Flat and grid.Nx >= 16 and grid.Ny >= 8
+                                      and grid.Nz >= 4 and not hasattr(grid.architecture, "partition"))
+        self._alt_velocities = None
         update_state(self, compute_tendencies=False)
 
     def prognostic_fields(self):
@@ -102,7 +108,7 @@ class NonhydrostaticModel:
     # cached ctypes tuples (pointers never change after construction)
     def _tuples(self):
         ts = self.timestepper
-        c = self._tuple_cache.setdefault(ts.Gn[0].ptr, {})  # one cached set per role assignment of the G buffers
+        c = self._tuple_cache.setdefault((ts.Gn[0].ptr, self.u.ptr), {})  # one cached set per role assignment of the buffers
         if not c:
             prog = self.prognostic_fields()
             c["n"] = len(prog)
@@ -208,10 +214,30 @@ def time_step(model, dt, euler=False):
     return _time_step_qab2(model, dt, euler)
 
 
+def update_state_and_rk3_substep(model, dt, gamma, zeta):
+    """update_state!(model) followed by the next stage's rk3_substep!, with compute_tendencies! and the substep fused into
+    one launch (ocn_compute_momentum_tendencies_rk3).  The substep result lands in a second set of velocity arrays whose
+    storage is then swapped into the model's fields (two swaps per time step: the original storage is back at step end)."""
+    g = model.grid
+    fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+    if model._alt_velocities is None:
+        model._alt_velocities = tuple(torch.zeros_like(f.data) for f in model.velocities)
+    alt = model._alt_velocities
+    Gn, Gm = model.timestepper.Gn, model.timestepper.Gm
+    _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+              Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
+              float(dt), float(gamma), float(zeta), stream_ptr())
+    old = tuple(f.data for f in model.velocities)
+    for f, a in zip(model.velocities, alt):
+        f.data = a
+    model._alt_velocities = old
+
+
 def _time_step_rk3(model, dt):
     ts, clock = model.timestepper, model.clock
     if clock.iteration == 0:
         update_state(model, compute_tendencies=True)
+    fused = model.fuse_stage_boundaries
     first_stage_dt = ts.g1 * dt
     second_stage_dt = (ts.g2 + ts.z2) * dt
     third_stage_dt = (ts.g3 + ts.z3) * dt
@@ -224,18 +250,22 @@ def _time_step_rk3(model, dt):
     calculate_pressure_correction(model, first_stage_dt)
     pressure_correct_velocities(model, first_stage_dt)
     cache_previous_tendencies(model)
-    update_state(model, compute_tendencies=True)
-
-    rk3_substep(model, dt, ts.g2, ts.z2)
+    if fused:
+        update_state_and_rk3_substep(model, dt, ts.g2, ts.z2)
+    else:
+        update_state(model, compute_tendencies=True)
+        rk3_substep(model, dt, ts.g2, ts.z2)
     clock.time += second_stage_dt
     clock.stage = 3
     clock.last_stage_dt = second_stage_dt
     calculate_pressure_correction(model, second_stage_dt)
     pressure_correct_velocities(model, second_stage_dt)
     cache_previous_tendencies(model)
-    update_state(model, compute_tendencies=True)
-
-    rk3_substep(model, dt, ts.g3, ts.z3)
+    if fused:
+        update_state_and_rk3_substep(model, dt, ts.g3, ts.z3)
+    else:
+        update_state(model, compute_tendencies=True)
+        rk3_substep(model, dt, ts.g3, ts.z3)
     clock.last_stage_dt = t_next - clock.time  # corrected_third_stage_Δt
     clock.time = t_next
     clock.iteration += 1

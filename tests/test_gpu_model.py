@@ -186,3 +186,35 @@ def test_tracer_conservation(oracle, ocn):
     c1 = pm.tracers[0].interior()
     assert abs(c1.sum() - c0) <= 1e-10 * abs(c0)
     assert np.abs(c1 - og.interior(om.tracers[0])).max() <= 1e-11
+
+
+@pytest.mark.parametrize("topo,z", [("PPP", (0, 2 * np.pi)), ("PPB", "stretched")])
+def test_fused_stage_boundaries_equal_unfused(ocn, topo, z):
+    """The fused launch (tendencies + next rk3 substep) is bit-identical to the two separate launches (strict math),
+    and the model's velocity storage is back in place after every full step."""
+    rng = np.random.default_rng(77)
+    size = (20, 12, 10)
+    if isinstance(z, str):
+        z = stretched_faces(size[2], 1.0)
+    P, B = "Periodic", "Bounded"
+    kw = dict(size=size, x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=(P, P, P if topo[2] == "P" else B), halo=(3, 3, 3))
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    models = []
+    init = None
+    for fused in (True, False):
+        g = ocn.RectilinearGrid(ocn.GPU(), **kw)
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+        assert m.fuse_stage_boundaries
+        m.fuse_stage_boundaries = fused
+        if init is None:
+            init = {n: rng.uniform(-1, 1, tuple(reversed(f.interior_view().shape))) for n, f in zip("uvw", m.velocities)}
+        ocn.set(m, **init)
+        ptrs = [f.ptr for f in m.velocities]
+        for _ in range(3):
+            ocn.time_step(m, 0.01)
+            assert [f.ptr for f in m.velocities] == ptrs
+        ocn.sync_device()
+        models.append(m)
+    a, b = models
+    for fa, fb in zip(a.velocities + (a.pNHS,) + tuple(a.timestepper.Gn), b.velocities + (b.pNHS,) + tuple(b.timestepper.Gn)):
+        np.testing.assert_array_equal(fa.parent(), fb.parent())
