@@ -119,13 +119,14 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
                                     double *Gv, double *Gw, const int32_t *range, void *stream);
 /* Fused stage boundary of RK3 (no reference counterpart; results identical to the two calls it replaces):
  * compute_Gu!/Gv!/Gw! over :xyz followed by the NEXT stage's rk3_substep_field! (runge_kutta_3.jl:194-200),
- *   G = tendencies(u, v, w);   U_out = U + dt*(gamma*G + zeta*Gm)   (wall faces copied unchanged),
+ *   G = tendencies(u, v, w);   U_out = U + dt*(gamma*G + zeta*Gm)   (has_zeta = 0: U + (dt*gamma)*G, Gm unused;
+ *   wall faces copied unchanged),
  * written to SEPARATE output velocity arrays (other workgroups still read the stencil neighbourhood of U).
  * Needs a non-Flat z direction and an interior of at least 16 x 8 x 4; otherwise OCN_ERR_UNSUPPORTED. */
 int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                         double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
-                                        void *stream);
+                                        int32_t has_zeta, void *stream);
 /* compute_Gc! (compute_nonhydrostatic_tendencies.jl:186-195; tracer_tendency :228-259) */
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w,
                                 const double *c, double *Gc, const int32_t *range, void *stream);

@@ -14,7 +14,7 @@ from .distributed import Distributed, DistributedFFTBasedPoissonSolver, Partitio
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,
-                     cache_previous_tendencies, calculate_pressure_correction, compute_tendencies,
+                     cache_previous_tendencies, calculate_pressure_correction, compute_tendencies, flush_tendencies,
                      pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_state)
 from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver,
                       nonhydrostatic_pressure_solver, solve)

@@ -85,6 +85,7 @@ struct FuseArgs {
     double *Uo[3];
     double dt, gamma, zeta;
     int on;
+    int has_zeta;  // 0: first-stage form  Uo = U + (dt*gamma)*G  (runge_kutta_3.jl:202-208)
 };
 
 int validate_grid(const ocn_grid *g);

@@ -325,18 +325,18 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             if (i >= r.ou) {
                 const double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
                 Gu[ou_] = G;
-                if (fz.on) fz.Uo[0][ou_] = zu[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][ou_]);
+                if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][ou_]) : (fz.dt * fz.gamma) * G);
             }
             if (j >= r.ov) {
                 const double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
                 Gv[ov_] = G;
-                if (fz.on) fz.Uo[1][ov_] = zv[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][ov_]);
+                if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][ov_]) : (fz.dt * fz.gamma) * G);
             }
             if (k >= r.ow) {
                 const double rVf = recip_volume(M.Az * M.dzF(k));
                 const double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
                 Gw[ow_] = G;
-                if (fz.on) fz.Uo[2][ow_] = zw[2] + fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]);
+                if (fz.on) fz.Uo[2][ow_] = zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]) : (fz.dt * fz.gamma) * G);
             } else if (fz.on) {
                 fz.Uo[2][ow_] = zw[2];  // wall face: neither the tendency nor the substep touch it (exclude_periphery)
             }

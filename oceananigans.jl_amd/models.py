@@ -35,23 +35,40 @@ class Clock:
         self.stage = 1
 
 
-class RungeKutta3TimeStepper:
+class _TendencyStore:
+    """Gⁿ / G⁻ tuples of a time stepper.  Reading `Gn` first completes a deferred compute_tendencies! (flush_tendencies)."""
+
+    def __init__(self, grid, prognostic_fields, model=None):
+        self._Gn = [Field(f.loc, grid) for f in prognostic_fields]
+        self._Gm = [Field(f.loc, grid) for f in prognostic_fields]
+        self._model = model
+
+    @property
+    def Gn(self):
+        if self._model is not None:
+            flush_tendencies(self._model)
+        return self._Gn
+
+    @property
+    def Gm(self):
+        return self._Gm
+
+
+class RungeKutta3TimeStepper(_TendencyStore):
     """src/TimeSteppers/runge_kutta_3.jl:10-63; γ, ζ each rounded once to Float64."""
 
-    def __init__(self, grid, prognostic_fields):
+    def __init__(self, grid, prognostic_fields, model=None):
+        super().__init__(grid, prognostic_fields, model)
         self.g1, self.g2, self.g3 = 8 / 15, 5 / 12, 3 / 4
         self.z2, self.z3 = -17 / 60, -5 / 12
-        self.Gn = [Field(f.loc, grid) for f in prognostic_fields]
-        self.Gm = [Field(f.loc, grid) for f in prognostic_fields]
 
 
-class QuasiAdamsBashforth2TimeStepper:
+class QuasiAdamsBashforth2TimeStepper(_TendencyStore):
     """src/TimeSteppers/quasi_adams_bashforth_2.jl:3-60; χ = 0.1 by default."""
 
-    def __init__(self, grid, prognostic_fields, chi=0.1):
+    def __init__(self, grid, prognostic_fields, chi=0.1, model=None):
+        super().__init__(grid, prognostic_fields, model)
         self.chi = chi
-        self.Gn = [Field(f.loc, grid) for f in prognostic_fields]
-        self.Gm = [Field(f.loc, grid) for f in prognostic_fields]
 
 
 class NonhydrostaticModel:
@@ -82,9 +99,9 @@ class NonhydrostaticModel:
         self.pressure_solver = nonhydrostatic_pressure_solver(grid)
         prog = self.prognostic_fields()
         if timestepper in ("RungeKutta3", ":RungeKutta3"):
-            self.timestepper = RungeKutta3TimeStepper(grid, prog)
+            self.timestepper = RungeKutta3TimeStepper(grid, prog, model=self)
         elif timestepper in ("QuasiAdamsBashforth2", ":QuasiAdamsBashforth2"):
-            self.timestepper = QuasiAdamsBashforth2TimeStepper(grid, prog)
+            self.timestepper = QuasiAdamsBashforth2TimeStepper(grid, prog, model=self)
         else:
             raise ValueError(f"unknown timestepper {timestepper!r}")
         self._tuple_cache = {}
@@ -93,6 +110,9 @@ class NonhydrostaticModel:
         self.fuse_stage_boundaries = (not self.tracers and grid.topology[2] != Flat and grid.Nx >= 16 and grid.Ny >= 8
                                       and grid.Nz >= 4 and not hasattr(grid.architecture, "partition"))
         self._alt_velocities = None
+        # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
+        self.defer_final_tendencies = self.fuse_stage_boundaries
+        self._pending_tendencies = False
         update_state(self, compute_tendencies=False)
 
     def prognostic_fields(self):
@@ -108,19 +128,29 @@ class NonhydrostaticModel:
     # cached ctypes tuples (pointers never change after construction)
     def _tuples(self):
         ts = self.timestepper
-        c = self._tuple_cache.setdefault((ts.Gn[0].ptr, self.u.ptr), {})  # one cached set per role assignment of the buffers
+        c = self._tuple_cache.setdefault((ts._Gn[0].ptr, self.u.ptr), {})  # one cached set per role assignment of the buffers
         if not c:
             prog = self.prognostic_fields()
             c["n"] = len(prog)
             c["U"] = _lib.ptr_array([f.ptr for f in prog])
-            c["Gn"] = _lib.ptr_array([f.ptr for f in ts.Gn])
-            c["Gm"] = _lib.ptr_array([f.ptr for f in ts.Gm])
+            c["Gn"] = _lib.ptr_array([f.ptr for f in ts._Gn])
+            c["Gm"] = _lib.ptr_array([f.ptr for f in ts._Gm])
             c["locs"] = _lib.i32_array([f.loc for f in prog])
         return c
 
 
+def flush_tendencies(model):
+    """Completes a compute_tendencies! that `time_step` deferred (model.defer_final_tendencies): the reference leaves
+    Gⁿ = tendencies(state) after every time_step!; this backend may postpone that launch and fuse it with the first
+    substep of the next step.  Anything that reads Gⁿ or is about to modify the state calls this first."""
+    if getattr(model, "_pending_tendencies", False):
+        model._pending_tendencies = False
+        compute_tendencies_(model)
+
+
 def set(model, enforce_incompressibility=True, **kwargs):
     """set!(model; enforce_incompressibility=true, kwargs...)"""
+    flush_tendencies(model)
     for name, value in kwargs.items():
         f = model.field(name)
         f.set(value)
@@ -145,7 +175,8 @@ def update_state(model, compute_tendencies=True):
 def compute_tendencies_(model, rng=None):
     """compute_tendencies! -> compute_interior_tendency_contributions!: K1-K3 fused + K4 per tracer."""
     g = model.grid
-    Gn = model.timestepper.Gn
+    model._pending_tendencies = False
+    Gn = model.timestepper._Gn
     r = None if rng is None else _lib.i32_array(list(rng))
     s = stream_ptr()
     _lib.call("ocn_compute_momentum_tendencies", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
@@ -191,7 +222,7 @@ def cache_previous_tendencies(model, copy=None):
         _lib.call("ocn_cache_previous_tendencies", model.grid.cref, t["n"], t["Gm"], t["Gn"], t["locs"], stream_ptr())
     else:
         ts = model.timestepper
-        ts.Gn, ts.Gm = ts.Gm, ts.Gn
+        ts._Gn, ts._Gm = ts._Gm, ts._Gn
 
 
 def rk3_substep(model, dt, gamma, zeta):
@@ -214,19 +245,21 @@ def time_step(model, dt, euler=False):
     return _time_step_qab2(model, dt, euler)
 
 
-def update_state_and_rk3_substep(model, dt, gamma, zeta):
+def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True):
     """update_state!(model) followed by the next stage's rk3_substep!, with compute_tendencies! and the substep fused into
     one launch (ocn_compute_momentum_tendencies_rk3).  The substep result lands in a second set of velocity arrays whose
     storage is then swapped into the model's fields (two swaps per time step: the original storage is back at step end)."""
     g = model.grid
-    fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+    if fill_halos:
+        fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
     if model._alt_velocities is None:
         model._alt_velocities = tuple(torch.zeros_like(f.data) for f in model.velocities)
     alt = model._alt_velocities
-    Gn, Gm = model.timestepper.Gn, model.timestepper.Gm
+    Gn, Gm = model.timestepper._Gn, model.timestepper._Gm
+    model._pending_tendencies = False
     _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
               Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
-              float(dt), float(gamma), float(zeta), stream_ptr())
+              float(dt), float(gamma), 0.0 if zeta is None else float(zeta), 0 if zeta is None else 1, stream_ptr())
     old = tuple(f.data for f in model.velocities)
     for f, a in zip(model.velocities, alt):
         f.data = a
@@ -243,7 +276,10 @@ def _time_step_rk3(model, dt):
     third_stage_dt = (ts.g3 + ts.z3) * dt
     t_next = clock.time + dt  # next_time(clock, Δt)
 
-    rk3_substep(model, dt, ts.g1, None)
+    if model._pending_tendencies:  # last step's deferred compute_tendencies! fused with this step's first substep
+        update_state_and_rk3_substep(model, dt, ts.g1, None, fill_halos=False)
+    else:
+        rk3_substep(model, dt, ts.g1, None)
     clock.time += first_stage_dt
     clock.stage = 2
     clock.last_stage_dt = first_stage_dt
@@ -273,7 +309,11 @@ def _time_step_rk3(model, dt):
     clock.last_dt = dt
     calculate_pressure_correction(model, third_stage_dt)
     pressure_correct_velocities(model, third_stage_dt)
-    update_state(model, compute_tendencies=True)
+    if fused and model.defer_final_tendencies:
+        update_state(model, compute_tendencies=False)  # halos now; the tendency launch is fused into the next step
+        model._pending_tendencies = True
+    else:
+        update_state(model, compute_tendencies=True)
 
 
 def _time_step_qab2(model, dt, euler=False):
