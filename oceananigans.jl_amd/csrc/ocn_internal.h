@@ -1,5 +1,7 @@
 // ocn_internal.h -- C++ launchers shared between the translation units of libocn_hip.
 #pragma once
+#include <vector>
+
 #include "ocn_common.h"
 
 namespace ocn {
@@ -33,6 +35,14 @@ int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const 
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
                      double *phi, hipStream_t stream);
 int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream);
+// column FFTs (colfft.hip): mode 0 forward (natural -> stage order), 1 inverse (stage order -> natural),
+// 2 forward + spectral solve + inverse.  N in {64, 128, 256, 512}.
+bool colfft_supported(int N);
+int colfft_wavenumber(int N, int p);
+std::vector<double> colfft_twiddles(int N);
+int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
+                  const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
+                  hipStream_t stream);
 int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream);
 int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src, double *dst, hipStream_t stream);
 

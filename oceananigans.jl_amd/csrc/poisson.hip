@@ -126,6 +126,8 @@ struct ocn_poisson {
     double *spec2 = nullptr;    // tridiagonal solution (complex nxh*Ny*Nz)
     double *diag = nullptr, *tscr = nullptr, *lower = nullptr;
     Plan fwd, bwd;
+    bool fused_z = false;       // FFT_z + spectral solve + IFFT_z in one column kernel (colfft.hip); rocFFT does (x, y)
+    double *tw = nullptr, *lz_stage = nullptr;
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
 };
@@ -134,7 +136,7 @@ static void free_all(ocn_poisson *s)
 {
     s->fwd.destroy();
     s->bwd.destroy();
-    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower};
+    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -217,10 +219,21 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
     // Layout of the pressure field interior as an FFT output (r2c path): strides (1, sx, sx*sy)
     ocn::GridDev gd = ocn::to_dev(*grid);
     ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
-    const int fft_dims = (s->kind == 0 && grid->tz == OCN_PERIODIC) ? 3 : 2;
+    {
+        const char *e = std::getenv("OCN_POISSON_FUSED_Z");
+        s->fused_z = s->kind == 0 && grid->tz == OCN_PERIODIC && !s->c2c && ocn::colfft_supported(Nz) && !(e && e[0] == '0');
+    }
+    if (s->fused_z) {
+        TRY(upload(ocn::colfft_twiddles(Nz), &s->tw));
+        std::vector<double> lzn = eigenvalues(Nz, grid->Lz, grid->tz), lzs(Nz);
+        for (int p = 0; p < Nz; ++p) lzs[p] = lzn[ocn::colfft_wavenumber(Nz, p)];  // eigenvalue of each stored position
+        TRY(upload(lzs, &s->lz_stage));
+    }
+    const int fft_dims = (s->kind == 0 && grid->tz == OCN_PERIODIC && !s->fused_z) ? 3 : 2;
     const size_t batch = (fft_dims == 3) ? 1 : (size_t)Nz;
     const size_t len[3] = {(size_t)Nx, (size_t)Ny, (size_t)Nz};
-    const double scale = (fft_dims == 3) ? 1.0 / ((double)Nx * Ny * Nz) : 1.0 / ((double)Nx * Ny);
+    // fused z path: the whole 1/(Nx Ny Nz) normalisation is applied in the column kernel
+    const double scale = s->fused_z ? 1.0 : (fft_dims == 3) ? 1.0 / ((double)Nx * Ny * Nz) : 1.0 / ((double)Nx * Ny);
     if (s->c2c) {
         const size_t str[3] = {1, (size_t)Nx, (size_t)Nx * Ny};
         const size_t dist = (size_t)Nx * Ny * (fft_dims == 3 ? Nz : 1);
@@ -267,7 +280,7 @@ extern "C" int ocn_poisson_info(ocn_poisson_t s, int32_t *kind, int32_t *r2c, in
     OCN_REQUIRE(s, "ocn_poisson_info: null solver");
     if (kind) *kind = s->kind;
     if (r2c) *r2c = !s->c2c;
-    if (direct_out) *direct_out = (!s->c2c && s->direct_out);
+    if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0);
     return OCN_SUCCESS;
 }
 
@@ -322,7 +335,11 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
         st = s->fwd.exec(s->rhs, s->spec, stream);
     if (st != OCN_SUCCESS) return st;
     double *sol = s->spec;
-    if (s->kind == 0) {
+    if (s->kind == 0 && s->fused_z) {
+        const long long plane = (long long)s->nxh * g->Ny;
+        st = ocn::launch_colfft(g->Nz, 2, s->spec, plane, 0, (int)plane, 1, s->tw, s->lx, s->ly, s->lz_stage,
+                                1.0 / ((double)g->Nx * g->Ny * g->Nz), s->nxh, stream);
+    } else if (s->kind == 0) {
         st = ocn::launch_spectral_solve(s->nxh, g->Ny, g->Nz, s->lx, s->ly, s->lz, s->spec, 1, 0, 0, stream);
     } else {
         st = ocn::launch_tridiag_z(s->nxh, g->Ny, g->Nz, s->lower, s->diag, s->lower, s->spec, s->tscr, s->spec2, stream);

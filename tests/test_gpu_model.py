@@ -14,6 +14,10 @@ LOCS = (1, 2, 4)
 POISSON_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi)),
                  ((7, 11, 16), "PPP", (0, 1.0)),      # odd sizes (test_poisson_solvers.jl uses 7, 11)
                  ((32, 16, 8), "PPP", (0, 1.0)),
+                 ((16, 12, 64), "PPP", (0, 1.0)),     # Nz in {64,128,256,512}: fused FFT_z + solve + IFFT_z column kernel
+                 ((20, 16, 128), "PPP", (0, 2.0)),
+                 ((9, 8, 256), "PPP", (0, 1.0)),
+                 ((8, 8, 512), "PPP", (0, 4.0)),
                  ((16, 12, 10), "PPB", (-1.0, 0.0)),
                  ((16, 12, 9), "PPB", "stretched"),
                  ((11, 7, 9), "PPB", "stretched"),
@@ -43,6 +47,8 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
     du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, hosts))
     solver = ocn.nonhydrostatic_pressure_solver(pg)
     phi = ocn.CenterField(pg)
+    if topo == "PPP":
+        assert bool(solver.info()["direct_out"] & 2) == (size[2] in (64, 128, 256, 512))  # fused z kernel in use
     ocn.solve_for_pressure(phi, solver, 1.0, (du, dv, dw))
     ocn.fill_halo_regions(phi)
     ocn.sync_device()
@@ -104,6 +110,7 @@ def test_batched_tridiagonal_solver_bitwise_vs_oracle(oracle, ocn):
 MODEL_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), "RungeKutta3"),
                ((16, 16, 16), "PPP", (0, 2 * np.pi), "QuasiAdamsBashforth2"),
                ((13, 17, 19), "PPP", (0, 1.0), "RungeKutta3"),
+               ((16, 16, 64), "PPP", (0, 8 * np.pi), "RungeKutta3"),
                ((16, 12, 10), "PPB", (-1.0, 0.0), "RungeKutta3"),
                ((16, 12, 10), "PPB", "stretched", "RungeKutta3"),
                ((24, 16, 1), "PPF", None, "RungeKutta3")]
