@@ -148,6 +148,20 @@ def main():
     kern_ms = e0.elapsed_time(e1) / reps
     achieved = TENDENCY_BYTES_PER_CELL * local_cells / (kern_ms * 1e-3) / 1e9
 
+    # HBM traffic of that kernel from the committed PMC profile of this workload (separate rocprofv3 --pmc passes,
+    # calibrated as MI355X_MICROARCH.md prescribes; tools/profile_gpu.sh + tools/summarize_profile.py), per launch
+    traffic = None
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{N}.json")), reverse=True):
+            prof = json.load(open(path))
+            k = [k for k in prof["kernels"] if "momentum_tendencies" in k["name"] and "traffic_bytes" in k]
+            if k and world == 1:
+                traffic = k[0]["traffic_bytes"]
+                break
+    except Exception:
+        traffic = None
+
     value = N ** 3 * a.steps / el
     out = {
         "metric": "cell-updates/sec (whole node), 512^3 NonhydrostaticModel WENO5, 1/2/4/8 GPU",
@@ -158,7 +172,7 @@ def main():
                    "grid": [N, N, N], "halo": 3, "math": a.math, "partition": f"x-slab/{world}", "finite": finite},
         "roofline": {"bound": "hbm", "kernel": "momentum_tendencies (fused compute_Gu/Gv/Gw, WENO5)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL},
+                     "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL},
         "step_roofline": {"algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
                           "achieved_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,
                           "frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world)},

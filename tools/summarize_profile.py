@@ -47,13 +47,16 @@ def main():
     write = load_pmc(d, "pmc_write", "WRITE_SIZE")
     cells = n ** 3
     field_bytes = cells * 8.0
-    # calibration kernel: cache_previous_tendencies = stepper_kernel<3>: reads 3 fields, writes 3 fields (interior)
-    cal = "ocn::stepper_kernel<3>"
+    # calibration kernel of known traffic in our 8 B/lane pattern:
+    #   stepper_kernel<3> (cache_previous_tendencies): reads 3 fields, writes 3;  or, when the host swaps the G buffers
+    #   and that kernel never runs, pressure_correct_kernel: reads p, u, v, w (4 fields), writes u, v, w (3).
     med = lambda v: sorted(v)[len(v) // 2]
     read_factor = write_factor = None
-    if cal in fetch and cal in write:
-        read_factor = 3 * field_bytes / (med(fetch[cal]) * 1024)
-        write_factor = 3 * field_bytes / (med(write[cal]) * 1024)
+    for cal, nr, nw in (("ocn::stepper_kernel<3>", 3, 3), ("ocn::pressure_correct_kernel", 4, 3)):
+        if cal in fetch and cal in write:
+            read_factor = nr * field_bytes / (med(fetch[cal]) * 1024)
+            write_factor = nw * field_bytes / (med(write[cal]) * 1024)
+            break
     out = {"tag": tag, "n": n, "read_calibration_factor": read_factor, "write_calibration_factor": write_factor, "kernels": []}
     for s in stats:
         k = dict(s)
@@ -71,7 +74,7 @@ def main():
         f.write(f"# rocprofv3 summary {tag}, bench.py --n {n}\n\n")
         f.write("Source: `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE); "
                 "see tools/profile_gpu.sh / tools/summarize_profile.py.\n\n")
-        f.write(f"PMC calibration on `{cal}` (known 3 fields read + 3 written): read x{read_factor}, write x{write_factor}\n\n")
+        f.write(f"PMC calibration on `{cal}` (known fields read / written): read x{read_factor}, write x{write_factor}\n\n")
         f.write("| kernel | calls | avg us | % GPU time | HBM traffic/launch (B/cell) | HBM GB/s |\n|---|---|---|---|---|---|\n")
         for k in out["kernels"][:25]:
             t = f"{k['traffic_bytes_per_cell']:.1f}" if "traffic_bytes" in k else "-"
