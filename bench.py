@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- cell-updates/s of full RK3 time steps of the WENO5 NonhydrostaticModel (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--n 512] [--math fast|strict]
+    python bench.py --gpus N --steps K --warmup W [--size 512] [--math fast|strict]
 
 Workload (config.workload): N^3 triply periodic RectilinearGrid, extent (2 pi)^3, halo 3, fp64,
 advection = WENO() (5th order), RungeKutta3, FFT-based pressure solver, no tracers/closure/buoyancy
-(BASELINE.json configs[1]/[2] at --n 256 / 512).  Inputs are synthetic: u, v, w ~ U(-1, 1) from a fixed seed,
+(BASELINE.json configs[1]/[2] at --size 256 / 512).  Inputs are synthetic: u, v, w ~ U(-1, 1) from a fixed seed,
 projected to be divergence free by set! (one dt = 1 pressure solve); dt = 0.1 dx / max|u|.
 A "step" is one full time_step!: 3 x (substep, pressure projection, tendencies).  With --gpus N > 1 the same global
 grid is x-slab partitioned over N ranks (strong scaling), one process per GPU, RCCL halo exchange + all-to-all
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=512, help="grid points per dimension (512 = the metric's config)")
+    ap.add_argument("--size", dest="n", type=int, default=512, help="grid points per dimension (512 = the metric's config)")
     ap.add_argument("--math", choices=("fast", "strict"), default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
@@ -88,10 +88,12 @@ def main():
     ocn.set_math_mode(ocn.MATH_FAST if a.math == "fast" else ocn.MATH_STRICT)
 
     N = a.n
-    if world > 1:
+    if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":  # the env var exercises the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(world))
     else:
         dist = None

@@ -208,6 +208,9 @@ int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, const ocn_grid *local_gr
 int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
 /* device pointers to the solver's y-local field, x-local field and the two transpose buffers */
 int ocn_dist_poisson_buffers(ocn_dist_poisson_t solver, double **yfield, double **xfield, double **send, double **recv);
+/* y extent of the transposed complex data (Ny, or Ny/2+1 padded to a multiple of nranks when real-to-complex transforms
+ * are in use), the number of complex elements of each of the four buffers, and whether r2c is active */
+int ocn_dist_poisson_layout(ocn_dist_poisson_t solver, int32_t *ny_transposed, int64_t *complex_elements, int32_t *r2c);
 int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w, double dt,
                                  void *stream);
 int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver, void *stream);

@@ -381,8 +381,12 @@ extern "C" int ocn_solve_for_pressure(ocn_poisson_t s, double *p, const double *
 struct ocn_dist_poisson {
     ocn_grid grid{};  // local grid
     int rank = 0, R = 1;
-    int nx = 0, ny = 0, Nxg = 0;
+    int nx = 0, Nxg = 0;
+    bool r2c = true;   // real-to-complex over (y, z): half the all-to-all volume of the reference's C2C
+    int nyt = 0;       // y extent of the transposed (complex) data: Ny (c2c) or Ny/2+1 padded to a multiple of R (r2c)
+    int ny = 0;        // nyt / R: y extent of the x-local field
     double *lx = nullptr, *ly = nullptr, *lz = nullptr;
+    double *rhs = nullptr;  // real source term (r2c)
     double *yfield = nullptr, *xfield = nullptr, *send = nullptr, *recv = nullptr;
     Plan fyz, byz, fx, bx;
 };
@@ -390,7 +394,7 @@ struct ocn_dist_poisson {
 static void free_all(ocn_dist_poisson *s)
 {
     s->fyz.destroy(); s->byz.destroy(); s->fx.destroy(); s->bx.destroy();
-    double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->yfield, &s->xfield, &s->send, &s->recv};
+    double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -413,29 +417,63 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     ocn_dist_poisson *s = new ocn_dist_poisson();
     s->grid = *lg;
     s->rank = rank; s->R = R;
-    s->nx = lg->Nx; s->ny = lg->Ny / R; s->Nxg = lg->Nx * R;
-    const int nx = s->nx, Ny = lg->Ny, Nz = lg->Nz, ny = s->ny, Nxg = s->Nxg;
-    const size_t n = (size_t)nx * Ny * Nz;
+    s->nx = lg->Nx; s->Nxg = lg->Nx * R;
+    const int nx = s->nx, Ny = lg->Ny, Nz = lg->Nz, Nxg = s->Nxg;
+    const char *env = std::getenv("OCN_POISSON_C2C");
+    s->r2c = !(env && env[0] == '1');
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
-    // global eigenvalues (distributed_fft_based_poisson_solver.jl:104-106)
+    ocn::GridDev gd = ocn::to_dev(*lg);
+    ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int nyh = Ny / 2 + 1;
+        s->nyt = s->r2c ? ((nyh + R - 1) / R) * R : Ny;
+        s->ny = s->nyt / R;
+        const size_t len[2] = {(size_t)Ny, (size_t)Nz};
+        const size_t cstr[2] = {(size_t)nx, (size_t)nx * s->nyt};
+        int pst;
+        if (s->r2c) {  // real (nx,Ny,Nz) -> Hermitian (nx,nyt,Nz), batched over the nx local columns (distance 1)
+            const size_t rstr[2] = {(size_t)nx, (size_t)nx * Ny};
+            const size_t pstr[2] = {(size_t)Lp.s2, (size_t)Lp.s3};
+            pst = make_plan(s->fyz, rocfft_placement_notinplace, rocfft_transform_type_real_forward, 2, len, nx, rocfft_array_type_real,
+                            rocfft_array_type_hermitian_interleaved, rstr, 1, cstr, 1, 1.0);
+            if (pst == OCN_SUCCESS)  // inverse writes straight into the local pressure interior
+                pst = make_plan(s->byz, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, 2, len, nx,
+                                rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, 1, pstr, 1, 1.0 / ((double)Ny * Nz));
+            if (pst != OCN_SUCCESS) {  // rocFFT has no kernel for this strided real layout: complex path
+                s->fyz.destroy(); s->byz.destroy();
+                s->r2c = false;
+                continue;
+            }
+        } else {  // FFT over (y, z) of the y-local complex field, batched over the nx local columns (no permutedims)
+            TRY(make_plan(s->fyz, rocfft_placement_inplace, rocfft_transform_type_complex_forward, 2, len, nx,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, cstr, 1, cstr, 1, 1.0));
+            TRY(make_plan(s->byz, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 2, len, nx,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, cstr, 1, cstr, 1,
+                          1.0 / ((double)Ny * Nz)));
+        }
+        break;
+    }
+    const int ny = s->ny;
+    const size_t n = (size_t)nx * s->nyt * Nz;  // complex elements of either layout
+    // global eigenvalues (distributed_fft_based_poisson_solver.jl:104-106); padded ky (r2c) get 1 (their data is 0)
     TRY(upload(eigenvalues(Nxg, global_Lx, OCN_PERIODIC), &s->lx));
-    TRY(upload(eigenvalues(Ny, lg->Ly, OCN_PERIODIC), &s->ly));
+    {
+        std::vector<double> ly = eigenvalues(Ny, lg->Ly, OCN_PERIODIC);
+        ly.resize(s->nyt > Ny ? s->nyt : Ny, 1.0);
+        for (int q = Ny / 2 + 1; s->r2c && q < s->nyt; ++q) ly[q] = 1.0;
+        TRY(upload(ly, &s->ly));
+    }
     TRY(upload(eigenvalues(Nz, lg->Lz, OCN_PERIODIC), &s->lz));
     for (double **p : {&s->yfield, &s->xfield, &s->send, &s->recv}) {
         TRY_HIP(hipMalloc((void **)p, n * 2 * sizeof(double)));
         TRY_HIP(hipMemset(*p, 0, n * 2 * sizeof(double)));
     }
-    {   // FFT over (y, z) of the y-local field, batched over the nx local columns (no permutedims)
-        const size_t len[2] = {(size_t)Ny, (size_t)Nz};
-        const size_t str[2] = {(size_t)nx, (size_t)nx * Ny};
-        TRY(make_plan(s->fyz, rocfft_placement_inplace, rocfft_transform_type_complex_forward, 2, len, nx,
-                      rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, 1, str, 1, 1.0));
-        TRY(make_plan(s->byz, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 2, len, nx,
-                      rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, 1, str, 1,
-                      1.0 / ((double)Ny * Nz)));
+    if (s->r2c) {
+        TRY_HIP(hipMalloc((void **)&s->rhs, (size_t)nx * Ny * Nz * sizeof(double)));
+        TRY_HIP(hipMemset(s->rhs, 0, (size_t)nx * Ny * Nz * sizeof(double)));
     }
-    {   // FFT over x of the x-local field
+    {   // FFT over x of the x-local field (Nxg, ny, Nz)
         const size_t len[1] = {(size_t)Nxg};
         const size_t str[1] = {1};
         TRY(make_plan(s->fx, rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len, (size_t)ny * Nz,
@@ -468,17 +506,28 @@ extern "C" int ocn_dist_poisson_buffers(ocn_dist_poisson_t s, double **yfield, d
     return OCN_SUCCESS;
 }
 
+extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int32_t *ny_transposed, int64_t *complex_elements, int32_t *r2c)
+{
+    OCN_REQUIRE(s, "ocn_dist_poisson_layout: null solver");
+    if (ny_transposed) *ny_transposed = s->nyt;
+    if (complex_elements) *complex_elements = (int64_t)s->nx * s->nyt * s->grid.Nz;
+    if (r2c) *r2c = s->r2c;
+    return OCN_SUCCESS;
+}
+
 extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *u, const double *v, const double *w, double dt,
                                             void *stream)
 {
     OCN_REQUIRE(s && u && v && w, "ocn_dist_poisson_source_term: null argument");
     const ocn_grid *g = &s->grid;
+    if (s->r2c) return ocn::launch_source_term(g, u, v, w, dt, 3, s->rhs, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     return ocn::launch_source_term(g, u, v, w, dt, 1, s->yfield, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
 }
 
 extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_forward_yz: null solver");
+    if (s->r2c) return s->fyz.exec(s->rhs, s->yfield, ocn::as_stream(stream));
     return s->fyz.exec(s->yfield, nullptr, ocn::as_stream(stream));
 }
 
@@ -498,6 +547,11 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
 {
     OCN_REQUIRE(s && p, "ocn_dist_poisson_backward_yz: null argument");
     hipStream_t stream = ocn::as_stream(stream_);
+    if (s->r2c) {
+        ocn::GridDev gd = ocn::to_dev(s->grid);
+        ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+        return s->byz.exec(s->yfield, p + Lp.o, stream);
+    }
     int st = s->byz.exec(s->yfield, nullptr, stream);
     if (st != OCN_SUCCESS) return st;
     // copy_real_component! into the local pressure interior; the local grid's parent layout

@@ -144,7 +144,8 @@ class Distributed:
         for f in fields:
             sw, se, rw, re = self._halo_buffers(f)
             self.ops.pack_x(g, f, sw, se)
-        self.ops.sync()  # sync_device! before posting (halo_communication.jl:272, 303)
+        # (the reference calls sync_device! before posting MPI messages, halo_communication.jl:272, 303; torch.distributed
+        #  collectives are ordered after the current stream's work, so no host synchronisation is needed here)
         for f in fields:
             sw, se, rw, re = self._halo_buffers(f)
             # my west strip becomes the west neighbour's east halo, and vice versa.  Receives are posted in the
@@ -237,7 +238,10 @@ class _HipDistPoisson:
                   C.c_double(getattr(grid, "global_Lx", grid.Lx * self.R)))
         ptrs = [C.c_void_p() for _ in range(4)]
         _lib.call("ocn_dist_poisson_buffers", self._h, *[C.byref(p) for p in ptrs])
-        n = grid.Nx * grid.Ny * grid.Nz * 2
+        nyt, nel, r2c = C.c_int32(), C.c_int64(), C.c_int32()
+        _lib.call("ocn_dist_poisson_layout", self._h, C.byref(nyt), C.byref(nel), C.byref(r2c))
+        self.nyt, self.r2c = nyt.value, bool(r2c.value)  # y extent of the transposed data (padded half spectrum if r2c)
+        n = nel.value * 2
         # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
         self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
         self.recv = _wrap_device_buffer(ptrs[3].value, n, arch.device)
@@ -254,7 +258,7 @@ class _HipDistPoisson:
 
     def _dims(self):
         g = self.grid
-        return g.Nx, g.Ny, g.Nz, self.R
+        return g.Nx, self.nyt, g.Nz, self.R
 
     def source_term(self, u, v, w, dt):
         _lib.call("ocn_dist_poisson_source_term", self._h, u.ptr, v.ptr, w.ptr, float(dt), stream_ptr())
@@ -303,7 +307,6 @@ class DistributedFFTBasedPoissonSolver:
         """transpose_*!: pack -> sync_device! -> Alltoallv! -> unpack (distributed_transpose.jl:185-191)"""
         if self.R == 1:
             return self.impl.send
-        self.arch.ops.sync()
         self.arch.fabric.all_to_all(self.impl.recv, self.impl.send)
         return self.impl.recv
 

@@ -71,7 +71,7 @@ def main():
     base = os.path.join("profiles", f"{tag}_{n}")
     json.dump(out, open(base + ".json", "w"), indent=1)
     with open(base + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary {tag}, bench.py --n {n}\n\n")
+        f.write(f"# rocprofv3 summary {tag}, bench.py --size {n}\n\n")
         f.write("Source: `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE); "
                 "see tools/profile_gpu.sh / tools/summarize_profile.py.\n\n")
         f.write(f"PMC calibration on `{cal}` (known fields read / written): read x{read_factor}, write x{write_factor}\n\n")
