@@ -86,6 +86,11 @@ struct FuseArgs {
     double dt, gamma, zeta;
     int on;
     int has_zeta;  // 0: first-stage form  Uo = U + (dt*gamma)*G  (runge_kutta_3.jl:202-208)
+    // optional prologue: the PREVIOUS stage's pressure correction applied to every velocity value as it is loaded,
+    //   u <- u - ((p[i]-p[i-1])/dx)*pc_dt  etc. (pressure_correction.jl:31-37); all-periodic grids only (indices wrap)
+    const double *pc_p;
+    double pc_dt;
+    int pc_on;
 };
 
 int validate_grid(const ocn_grid *g);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
 //    Patches therefore overlap by one column/row: (TX-1) x (TY-1) outputs per TX x TY threads.
 // All flux expressions are the same as in the direct kernel, so strict mode stays bit-identical to the oracle.
 // ---------------------------------------------------------------------------------------------------
-template <int TZ, int TX, int TY, int W>
+template <int TZ, int TX, int TY, int W, bool PC>
 __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
                                                                        const double *__restrict__ v,
                                                                        const double *__restrict__ w, double *__restrict__ Gu,
@@ -170,14 +170,49 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 
     const double *pu = u + ocn::at(Lu, i, j, 1), *pv = v + ocn::at(Lv, i, j, 1), *pw = w + ocn::at(Lw, i, j, 1);
     const long long su3 = Lu.s3, sv3 = Lv.s3, sw3 = Lw.s3;
-#define ZU(k) pu[((k)-1) * su3]
-#define ZV(k) pv[((k)-1) * sv3]
-#define ZW(k) pw[((k)-1) * sw3]
+    // PC: the previous stage's pressure correction is applied on load (indices wrap periodically, so neither the
+    // pressure halos nor re-filled velocity halos are needed): same expression as pressure_correct_kernel.
+    auto wrp = [](int q, int N) { return q < 1 ? q + N : (q > N ? q - N : q); };
+    const double *pC = nullptr, *pWn = nullptr, *pSn = nullptr;  // p columns at (i,j), (i-1,j), (i,j-1)
+    if (PC) {
+        const Lay Lp = ocn::make_lay(g, OCN_LOC_CCC);
+        pC = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j, Ny), 1);
+        pWn = fz.pc_p + ocn::at(Lp, wrp(i - 1, Nx), wrp(j, Ny), 1);
+        pSn = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j - 1, Ny), 1);
+    }
+    const double pcdt = fz.pc_dt;
+#if OCN_STRICT
+#define OCN_PC_GRAD(d, h) ((d) / (h))  // reference expression: difference / spacing
+    const double hx = M.dx, hy = M.dy, hz = M.dz;
+#else
+#define OCN_PC_GRAD(d, h) ((d) * (h))  // fast math: multiply by the reciprocal spacing
+    const double hx = 1.0 / M.dx, hy = 1.0 / M.dy, hz = 1.0 / M.dz;
+#endif
+    auto zz = [&](int kk) { return (long long)(wrp(kk, Nz) - 1) * su3; };  // plane offset of p (same strides when periodic)
+    auto own_u = [&](int kk) {
+        const double raw = pu[(kk - 1) * su3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(pC[zz(kk)] - pWn[zz(kk)], hx) * pcdt;
+    };
+    auto own_v = [&](int kk) {
+        const double raw = pv[(kk - 1) * sv3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(pC[zz(kk)] - pSn[zz(kk)], hy) * pcdt;
+    };
+    auto own_w = [&](int kk) {
+        const double raw = pw[(kk - 1) * sw3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(pC[zz(kk)] - pC[zz(kk - 1)], hz) * pcdt;
+    };
+#define ZU(k) own_u(k)
+#define ZV(k) own_v(k)
+#define ZW(k) own_w(k)
 
     // Static ring assignment: ring cell q (0 <= q < NRING) <-> tile cell (cx, cy) outside the TX x TY core.
     int rcx[RPT], rcy[RPT];
     bool ron[RPT];
     const double *ru[RPT], *rv[RPT], *rw[RPT];
+    const double *rpc[RPT] = {}, *rpw[RPT] = {}, *rps[RPT] = {};
 #pragma unroll
     for (int s = 0; s < RPT; ++s) {
         const int q = tid + s * NT;
@@ -198,7 +233,28 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         ru[s] = u + ocn::at(Lu, gi, gj, 1);
         rv[s] = v + ocn::at(Lv, gi, gj, 1);
         rw[s] = w + ocn::at(Lw, gi, gj, 1);
+        if (PC) {
+            const Lay Lp = ocn::make_lay(g, OCN_LOC_CCC);
+            rpc[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj, Ny), 1);
+            rpw[s] = fz.pc_p + ocn::at(Lp, wrp(gi - 1, Nx), wrp(gj, Ny), 1);
+            rps[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj - 1, Ny), 1);
+        }
     }
+    auto ring_u = [&](int s, int kk) {
+        const double raw = ru[s][(kk - 1) * su3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpw[s][zz(kk)], hx) * pcdt;
+    };
+    auto ring_v = [&](int s, int kk) {
+        const double raw = rv[s][(kk - 1) * sv3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rps[s][zz(kk)], hy) * pcdt;
+    };
+    auto ring_w = [&](int s, int kk) {
+        const double raw = rw[s][(kk - 1) * sw3];
+        if (!PC) return raw;
+        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpc[s][zz(kk - 1)], hz) * pcdt;
+    };
 
     // z-windows: index m <-> k-2+m
     double zu[6], zv[6], zw[6];
@@ -216,13 +272,13 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         sw[k & 1][ly][lx] = zw[2];
 #pragma unroll
         for (int s = 0; s < RPT; ++s)
-            if (ron[s]) sw[k & 1][rcy[s]][rcx[s]] = rw[s][(k - 1) * sw3];
+            if (ron[s]) sw[k & 1][rcy[s]][rcx[s]] = ring_w(s, k);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < RPT; ++s) {
-            nu[s] = ron[s] ? ru[s][(k - 1) * su3] : 0.0;
-            nv[s] = ron[s] ? rv[s][(k - 1) * sv3] : 0.0;
-            nw[s] = ron[s] ? rw[s][k * sw3] : 0.0;
+            nu[s] = ron[s] ? ring_u(s, k) : 0.0;
+            nv[s] = ron[s] ? ring_v(s, k) : 0.0;
+            nw[s] = ron[s] ? ring_w(s, k + 1) : 0.0;
         }
         const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
         const double(*swk)[LX] = sw[k & 1];
@@ -268,9 +324,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #pragma unroll
             for (int s = 0; s < RPT; ++s)
                 if (ron[s]) {
-                    nu[s] = ru[s][k * su3];
-                    nv[s] = rv[s][k * sv3];
-                    nw[s] = rw[s][(k + 1) * sw3];
+                    nu[s] = ring_u(s, k + 1);
+                    nv[s] = ring_v(s, k + 1);
+                    nw[s] = ring_w(s, k + 2);
                 }
         }
         const double(*swk)[LX] = sw[k & 1];
@@ -354,6 +410,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZU
 #undef ZV
 #undef ZW
+#undef OCN_PC_GRAD
 }
 
 // K4 tracer: flux = (A * U[i,j,k]) * cR   (upwind_biased_advective_fluxes.jl:99-121)
@@ -440,12 +497,27 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;                                           \
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                   \
         if (grid->tz == OCN_PERIODIC)                                                                                      \
-            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v, \
-                               w, Gu, Gv, Gw, r, KZ, fz);                                                                   \
+            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, W, false>), nbt, dim3(TX * TY), 0, stream, g, \
+                               u, v, w, Gu, Gv, Gw, r, KZ, fz);                                                             \
         else                                                                                                               \
-            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, W>), nbt, dim3(TX * TY), 0, stream, g, u, v,  \
-                               w, Gu, Gv, Gw, r, KZ, fz);                                                                   \
+            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, W, false>), nbt, dim3(TX * TY), 0, stream, g,  \
+                               u, v, w, Gu, Gv, Gw, r, KZ, fz);                                                             \
     } while (0)
+        if (fz.pc_on) {  // pressure correction on load: all-periodic, single rank, default tile only
+            if (grid->tx != OCN_PERIODIC || grid->tz != OCN_PERIODIC || range != nullptr) {
+                ocn::set_error("pressure correction on load needs a (Periodic, Periodic, Periodic) single-rank grid and the full range");
+                return OCN_ERR_UNSUPPORTED;
+            }
+            constexpr int TX = 32, TY = 8;
+            const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+            int KZ = wz;
+            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;
+            dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu,
+                               Gv, Gw, r, KZ, fz);
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
         switch (variant) {
             case 1: OCN_LAUNCH_TILED(32, 16, 4); break;
             case 7: OCN_LAUNCH_TILED(32, 16, 2); break;

@@ -112,6 +112,8 @@ class NonhydrostaticModel:
         self._alt_velocities = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
         self.defer_final_tendencies = self.fuse_stage_boundaries
+        # fold the pressure correction of stages 1 and 2 into the loads of the fused launch (all-periodic grids)
+        self.correct_on_load = self.fuse_stage_boundaries and all(t == "Periodic" for t in grid.topology)
         self._pending_tendencies = False
         update_state(self, compute_tendencies=False)
 
@@ -188,11 +190,12 @@ def compute_tendencies_(model, rng=None):
 compute_tendencies = compute_tendencies_
 
 
-def calculate_pressure_correction(model, dt):
+def calculate_pressure_correction(model, dt, fill_pressure_halos=True):
     """calculate_pressure_correction!(model, Δt) (pressure_correction.jl:8-20)"""
     fill_halo_regions(model.velocities)
     solve_for_pressure(model.pNHS, model.pressure_solver, dt, model.velocities)
-    fill_halo_regions(model.pNHS)
+    if fill_pressure_halos:
+        fill_halo_regions(model.pNHS)
 
 
 def solve_for_pressure(pressure, solver, dt, U):
@@ -245,7 +248,7 @@ def time_step(model, dt, euler=False):
     return _time_step_qab2(model, dt, euler)
 
 
-def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True):
+def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True, p_correct=None, dt_correct=0.0):
     """update_state!(model) followed by the next stage's rk3_substep!, with compute_tendencies! and the substep fused into
     one launch (ocn_compute_momentum_tendencies_rk3).  The substep result lands in a second set of velocity arrays whose
     storage is then swapped into the model's fields (two swaps per time step: the original storage is back at step end)."""
@@ -259,23 +262,45 @@ def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True):
     model._pending_tendencies = False
     _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
               Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
-              float(dt), float(gamma), 0.0 if zeta is None else float(zeta), 0 if zeta is None else 1, stream_ptr())
+              float(dt), float(gamma), 0.0 if zeta is None else float(zeta), 0 if zeta is None else 1,
+              None if p_correct is None else p_correct.ptr, float(dt_correct), stream_ptr())
     old = tuple(f.data for f in model.velocities)
     for f, a in zip(model.velocities, alt):
         f.data = a
     model._alt_velocities = old
 
 
+def _project_and_advance(model, dt, stage_dt, gamma_next, zeta_next):
+    """Everything between two substeps of RK3 (runge_kutta_3.jl:103-118): pressure projection with the stage Δt,
+    cache_previous_tendencies!, update_state! and the NEXT stage's rk3_substep!, with as many of those folded into one
+    launch as the grid allows (results identical to the unfused sequence, tested bit for bit)."""
+    if model.fuse_stage_boundaries and model.correct_on_load:
+        # pressure_correct_velocities! + update_state! + rk3_substep! in ONE launch: the correction is applied to the
+        # velocities as the tendency kernel loads them, with wrapped indices (the pressure halos are not even needed)
+        calculate_pressure_correction(model, stage_dt, fill_pressure_halos=False)
+        cache_previous_tendencies(model)
+        update_state_and_rk3_substep(model, dt, gamma_next, zeta_next, fill_halos=False, p_correct=model.pNHS, dt_correct=stage_dt)
+        return
+    calculate_pressure_correction(model, stage_dt)
+    pressure_correct_velocities(model, stage_dt)
+    cache_previous_tendencies(model)
+    if model.fuse_stage_boundaries:
+        update_state_and_rk3_substep(model, dt, gamma_next, zeta_next)
+    else:
+        update_state(model, compute_tendencies=True)
+        rk3_substep(model, dt, gamma_next, zeta_next)
+
+
 def _time_step_rk3(model, dt):
     ts, clock = model.timestepper, model.clock
     if clock.iteration == 0:
         update_state(model, compute_tendencies=True)
-    fused = model.fuse_stage_boundaries
     first_stage_dt = ts.g1 * dt
     second_stage_dt = (ts.g2 + ts.z2) * dt
     third_stage_dt = (ts.g3 + ts.z3) * dt
     t_next = clock.time + dt  # next_time(clock, Δt)
 
+    # ---- first stage
     if model._pending_tendencies:  # last step's deferred compute_tendencies! fused with this step's first substep
         update_state_and_rk3_substep(model, dt, ts.g1, None, fill_halos=False)
     else:
@@ -283,25 +308,13 @@ def _time_step_rk3(model, dt):
     clock.time += first_stage_dt
     clock.stage = 2
     clock.last_stage_dt = first_stage_dt
-    calculate_pressure_correction(model, first_stage_dt)
-    pressure_correct_velocities(model, first_stage_dt)
-    cache_previous_tendencies(model)
-    if fused:
-        update_state_and_rk3_substep(model, dt, ts.g2, ts.z2)
-    else:
-        update_state(model, compute_tendencies=True)
-        rk3_substep(model, dt, ts.g2, ts.z2)
+    _project_and_advance(model, dt, first_stage_dt, ts.g2, ts.z2)   # ... ends with the second substep
+    # ---- second stage
     clock.time += second_stage_dt
     clock.stage = 3
     clock.last_stage_dt = second_stage_dt
-    calculate_pressure_correction(model, second_stage_dt)
-    pressure_correct_velocities(model, second_stage_dt)
-    cache_previous_tendencies(model)
-    if fused:
-        update_state_and_rk3_substep(model, dt, ts.g3, ts.z3)
-    else:
-        update_state(model, compute_tendencies=True)
-        rk3_substep(model, dt, ts.g3, ts.z3)
+    _project_and_advance(model, dt, second_stage_dt, ts.g3, ts.z3)  # ... ends with the third substep
+    # ---- third stage
     clock.last_stage_dt = t_next - clock.time  # corrected_third_stage_Δt
     clock.time = t_next
     clock.iteration += 1
@@ -309,7 +322,7 @@ def _time_step_rk3(model, dt):
     clock.last_dt = dt
     calculate_pressure_correction(model, third_stage_dt)
     pressure_correct_velocities(model, third_stage_dt)
-    if fused and model.defer_final_tendencies:
+    if model.fuse_stage_boundaries and model.defer_final_tendencies:
         update_state(model, compute_tendencies=False)  # halos now; the tendency launch is fused into the next step
         model._pending_tendencies = True
     else:

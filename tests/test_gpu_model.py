@@ -208,11 +208,14 @@ def test_fused_stage_boundaries_equal_unfused(ocn, topo, z):
     ocn.set_math_mode(ocn.MATH_STRICT)
     models = []
     init = None
-    for fused in (True, False):
+    for fused in (True, False):  # fused = stage-boundary fusion (+ pressure correction on load when all-periodic)
         g = ocn.RectilinearGrid(ocn.GPU(), **kw)
         m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
         assert m.fuse_stage_boundaries
-        m.fuse_stage_boundaries = m.defer_final_tendencies = fused
+        if fused:
+            assert m.correct_on_load == (topo == "PPP") and m.defer_final_tendencies
+        else:
+            m.fuse_stage_boundaries = m.defer_final_tendencies = m.correct_on_load = False
         if init is None:
             init = {n: rng.uniform(-1, 1, tuple(reversed(f.interior_view().shape))) for n, f in zip("uvw", m.velocities)}
         ocn.set(m, **init)
