@@ -155,8 +155,14 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     __shared__ double su[LY][LX], sv[LY][LX], sw[2][LY][LX];
     __shared__ double ex[6][NT];  // Fuu_w, Fuv, Fuw (read by the west neighbour), Fvv_s, Fvu, Fvw (by the south one)
 
-    const Metrics M = make_metrics(g);
-    const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
+    Metrics M = make_metrics(g);
+    if (TZ == OCN_PERIODIC) M.dzc = M.dzf = nullptr;  // a Periodic z is never stretched: lets the compiler fold the metric loads
+    // x and y are Periodic for every supported grid, so the row/plane strides and the interior offset are the same for
+    // all staggered locations (only the number of z planes differs): one layout serves u, v, w, G and p.
+    const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);
+#define Lu L0
+#define Lv L0
+#define Lw L0
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
@@ -169,13 +175,15 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     const int lx = tx + 3, ly = ty + 3;  // own cell inside the LDS tile
 
     const double *pu = u + ocn::at(Lu, i, j, 1), *pv = v + ocn::at(Lv, i, j, 1), *pw = w + ocn::at(Lw, i, j, 1);
-    const long long su3 = Lu.s3, sv3 = Lv.s3, sw3 = Lw.s3;
+    const long long su3 = L0.s3;
+#define sv3 su3
+#define sw3 su3
     // PC: the previous stage's pressure correction is applied on load (indices wrap periodically, so neither the
     // pressure halos nor re-filled velocity halos are needed): same expression as pressure_correct_kernel.
     auto wrp = [](int q, int N) { return q < 1 ? q + N : (q > N ? q - N : q); };
     const double *pC = nullptr, *pWn = nullptr, *pSn = nullptr;  // p columns at (i,j), (i-1,j), (i,j-1)
     if (PC) {
-        const Lay Lp = ocn::make_lay(g, OCN_LOC_CCC);
+        const Lay &Lp = L0;
         pC = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j, Ny), 1);
         pWn = fz.pc_p + ocn::at(Lp, wrp(i - 1, Nx), wrp(j, Ny), 1);
         pSn = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j - 1, Ny), 1);
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         rv[s] = v + ocn::at(Lv, gi, gj, 1);
         rw[s] = w + ocn::at(Lw, gi, gj, 1);
         if (PC) {
-            const Lay Lp = ocn::make_lay(g, OCN_LOC_CCC);
+            const Lay &Lp = L0;
             rpc[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj, Ny), 1);
             rpw[s] = fz.pc_p + ocn::at(Lp, wrp(gi - 1, Nx), wrp(gj, Ny), 1);
             rps[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj - 1, Ny), 1);
@@ -411,6 +419,11 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZV
 #undef ZW
 #undef OCN_PC_GRAD
+#undef Lu
+#undef Lv
+#undef Lw
+#undef sv3
+#undef sw3
 }
 
 // K4 tracer: flux = (A * U[i,j,k]) * cR   (upwind_biased_advective_fluxes.jl:99-121)

@@ -13,6 +13,7 @@ Julia's `f!` names are spelled `f` here.  closure, buoyancy, coriolis, forcing, 
 (their zero fallbacks, e.g. src/TurbulenceClosures/.../nothing_closure.jl:1-10); asking for anything else raises.
 """
 import math
+import os
 
 import torch
 
@@ -113,7 +114,8 @@ class NonhydrostaticModel:
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
         self.defer_final_tendencies = self.fuse_stage_boundaries
         # fold the pressure correction of stages 1 and 2 into the loads of the fused launch (all-periodic grids)
-        self.correct_on_load = self.fuse_stage_boundaries and all(t == "Periodic" for t in grid.topology)
+        self.correct_on_load = (self.fuse_stage_boundaries and all(t == "Periodic" for t in grid.topology)
+                                and os.environ.get("OCN_CORRECT_ON_LOAD", "1") != "0")
         self._pending_tendencies = False
         update_state(self, compute_tendencies=False)
 
