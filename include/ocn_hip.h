@@ -122,15 +122,17 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
  *   G = tendencies(u, v, w);   U_out = U + dt*(gamma*G + zeta*Gm)   (has_zeta = 0: U + (dt*gamma)*G, Gm unused;
  *   wall faces copied unchanged),
  * written to SEPARATE output velocity arrays (other workgroups still read the stencil neighbourhood of U).
- * Needs a non-Flat z direction and an interior of at least 16 x 8 x 4; otherwise OCN_ERR_UNSUPPORTED.
+ * `range` as in ocn_compute_momentum_tendencies (NULL = :xyz); only cells inside the range are written.
  * p_correct != NULL additionally folds the PREVIOUS stage's _pressure_correct_velocities! (pressure_correction.jl:31-37)
  * into the loads: every velocity value is read as  u - ((p[i]-p[i-1])/dx)*dt_correct  (v, w alike) with periodically
  * wrapped indices, so (u, v, w) are the *uncorrected* fields with valid halos and p needs no halos.
- * (Periodic, Periodic, Periodic) single-rank grids only. */
+ * (Periodic, Periodic, Periodic) single-rank grids with an interior of at least 16 x 8 x 4 and range = NULL only;
+ * otherwise OCN_ERR_UNSUPPORTED. */
 int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                         double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
-                                        int32_t has_zeta, const double *p_correct, double dt_correct, void *stream);
+                                        int32_t has_zeta, const double *p_correct, double dt_correct, const int32_t *range,
+                                        void *stream);
 /* compute_Gc! (compute_nonhydrostatic_tendencies.jl:186-195; tracer_tendency :228-259) */
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w,
                                 const double *c, double *Gc, const int32_t *range, void *stream);

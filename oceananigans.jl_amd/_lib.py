@@ -45,7 +45,7 @@ _SIGS = {
     "ocn_fill_halo_regions": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, _vp],
     "ocn_fill_halo_periodic": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, _vp],
     "ocn_compute_momentum_tendencies": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
-    "ocn_compute_momentum_tendencies_rk3": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, _vp],
+    "ocn_compute_momentum_tendencies_rk3": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, C.POINTER(_i32), _vp],
     "ocn_compute_tracer_tendency": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _i32, _vp],
     "ocn_ab2_step": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _vp],

@@ -184,7 +184,8 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
 int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                         double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
-                                        int32_t has_zeta, const double *p_correct, double dt_correct, void *stream)
+                                        int32_t has_zeta, const double *p_correct, double dt_correct, const int32_t *range,
+                                        void *stream)
 {
     int st = validate_weno(grid);
     if (st != OCN_SUCCESS) return st;
@@ -196,8 +197,8 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     fz.Uo[0] = u_out; fz.Uo[1] = v_out; fz.Uo[2] = w_out;
     fz.dt = dt; fz.gamma = gamma; fz.zeta = zeta; fz.on = 1; fz.has_zeta = has_zeta ? 1 : 0;
     fz.pc_p = p_correct; fz.pc_dt = dt_correct; fz.pc_on = p_correct ? 1 : 0;
-    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, nullptr, &fz, as_stream(stream));
-    return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, nullptr, &fz, as_stream(stream));
+    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
+    return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
                                                                   const double *__restrict__ v,
                                                                   const double *__restrict__ w, double *__restrict__ Gu,
                                                                   double *__restrict__ Gv, double *__restrict__ Gw,
-                                                                  Range r)
+                                                                  Range r, ocn::FuseArgs fz)
 {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzC(k));
-        Gu[ocn::at(Lu, i, j, k)] = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const long long o = ocn::at(Lu, i, j, k);
+        Gu[o] = G;
+        if (fz.on) fz.Uo[0][o] = pu[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][o]) : (fz.dt * fz.gamma) * G);
     }
     // ---- Gv at (c,f,c)  (:63-67)
     if (j >= r.ov) {
@@ -102,7 +105,10 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzC(k));
-        Gv[ocn::at(Lv, i, j, k)] = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const long long o = ocn::at(Lv, i, j, k);
+        Gv[o] = G;
+        if (fz.on) fz.Uo[1][o] = pv[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][o]) : (fz.dt * fz.gamma) * G);
     }
     // ---- Gw at (c,c,f)  (:79-83)
     if (k >= r.ow) {
@@ -120,8 +126,14 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzF(k));
-        Gw[ocn::at(Lw, i, j, k)] = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        const long long o = ocn::at(Lw, i, j, k);
+        Gw[o] = G;
+        if (fz.on) fz.Uo[2][o] = pw[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][o]) : (fz.dt * fz.gamma) * G);
+    } else if (fz.on) {
+        fz.Uo[2][ocn::at(Lw, i, j, k)] = pw[0];  // wall face (exclude_periphery): carried over unchanged
     }
+    if (fz.on && TZ == OCN_BOUNDED && k == Nz) fz.Uo[2][ocn::at(Lw, i, j, Nz + 1)] = pw[sw3];  // top wall face
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -544,16 +556,16 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
     }
-    if (fz.on) {
-        ocn::set_error("fused tendency + substep launch needs the tiled kernel (non-Flat z, range at least 16 x 8 x 4)");
+    if (fz.pc_on) {
+        ocn::set_error("pressure correction on load needs the tiled kernel (non-Flat z, range at least 16 x 8 x 4)");
         return OCN_ERR_UNSUPPORTED;
     }
     dim3 block(64, 4, 1);
     dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
     switch (grid->tz) {
-        case OCN_PERIODIC: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r); break;
-        case OCN_BOUNDED: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r); break;
-        case OCN_FLAT: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_FLAT>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r); break;
+        case OCN_PERIODIC: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r, fz); break;
+        case OCN_BOUNDED: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r, fz); break;
+        case OCN_FLAT: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_FLAT>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r, fz); break;
         default: ocn::set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;
     }
     OCN_CHECK_HIP(hipGetLastError());

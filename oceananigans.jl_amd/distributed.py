@@ -198,6 +198,27 @@ class Distributed:
             if e0 <= nx:
                 models.compute_tendencies_(model, (e0, nx, 1, g.Ny, 1, g.Nz))
 
+    def update_state_fused(self, model, launch, fill_halos=True):
+        """update_state! + the next rk3 substep with the fused launch: same interior / buffer split and overlap as update_state."""
+        g = model.grid
+        fields = model.prognostic_fields()
+        pending = None
+        if fill_halos:
+            self.ops.local_fill(g, fields, False)
+            pending = self.start_halo_exchange(fields)
+        nx, Hx = g.Nx, g.Hx
+        if pending is None:
+            launch()
+            return
+        if nx - 2 * Hx >= 1:
+            launch((Hx + 1, nx - Hx, 1, g.Ny, 1, g.Nz))
+        self.finish_halo_exchange()
+        w1 = min(Hx, nx)
+        launch((1, w1, 1, g.Ny, 1, g.Nz))
+        e0 = max(nx - Hx + 1, w1 + 1)
+        if e0 <= nx:
+            launch((e0, nx, 1, g.Ny, 1, g.Nz))
+
     def pressure_solver(self, grid):
         return DistributedFFTBasedPoissonSolver(grid)
 

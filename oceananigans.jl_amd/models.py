@@ -108,13 +108,14 @@ class NonhydrostaticModel:
         self._tuple_cache = {}
         self.copy_cached_tendencies = False
         # fused stage boundaries (tendencies + next substep in one launch) need the tiled kernel, no tracers, one rank
-        self.fuse_stage_boundaries = (not self.tracers and grid.topology[2] != Flat and grid.Nx >= 16 and grid.Ny >= 8
-                                      and grid.Nz >= 4 and not hasattr(grid.architecture, "partition"))
+        self.fuse_stage_boundaries = not self.tracers
         self._alt_velocities = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
         self.defer_final_tendencies = self.fuse_stage_boundaries
         # fold the pressure correction of stages 1 and 2 into the loads of the fused launch (all-periodic grids)
         self.correct_on_load = (self.fuse_stage_boundaries and all(t == "Periodic" for t in grid.topology)
+                                and grid.Nx >= 16 and grid.Ny >= 8 and grid.Nz >= 4
+                                and not hasattr(grid.architecture, "partition")
                                 and os.environ.get("OCN_CORRECT_ON_LOAD", "1") != "0")
         self._pending_tendencies = False
         update_state(self, compute_tendencies=False)
@@ -253,19 +254,28 @@ def time_step(model, dt, euler=False):
 def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True, p_correct=None, dt_correct=0.0):
     """update_state!(model) followed by the next stage's rk3_substep!, with compute_tendencies! and the substep fused into
     one launch (ocn_compute_momentum_tendencies_rk3).  The substep result lands in a second set of velocity arrays whose
-    storage is then swapped into the model's fields (two swaps per time step: the original storage is back at step end)."""
-    g = model.grid
-    if fill_halos:
-        fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+    storage is then swapped into the model's fields."""
     if model._alt_velocities is None:
         model._alt_velocities = tuple(torch.zeros_like(f.data) for f in model.velocities)
     alt = model._alt_velocities
     Gn, Gm = model.timestepper._Gn, model.timestepper._Gm
     model._pending_tendencies = False
-    _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
-              Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
-              float(dt), float(gamma), 0.0 if zeta is None else float(zeta), 0 if zeta is None else 1,
-              None if p_correct is None else p_correct.ptr, float(dt_correct), stream_ptr())
+    g = model.grid
+
+    def launch(rng=None):
+        _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                  Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
+                  float(dt), float(gamma), 0.0 if zeta is None else float(zeta), 0 if zeta is None else 1,
+                  None if p_correct is None else p_correct.ptr, float(dt_correct),
+                  None if rng is None else _lib.i32_array(list(rng)), stream_ptr())
+
+    hook = getattr(model.architecture, "update_state_fused", None)
+    if hook is not None:  # Distributed: halo exchange overlapped with the interior launch, then the two buffer strips
+        hook(model, launch, fill_halos)
+    else:
+        if fill_halos:
+            fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+        launch()
     old = tuple(f.data for f in model.velocities)
     for f, a in zip(model.velocities, alt):
         f.data = a
