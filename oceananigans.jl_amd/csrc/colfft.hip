@@ -15,6 +15,7 @@
 // returns natural order.  No reordering pass is ever needed: whoever needs the true wavenumber of a stored position (the
 // eigenvalue tables) gets a permuted table from the host (ocn_colfft_position_to_wavenumber).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ocn_internal.h"
@@ -255,7 +256,12 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
         case 64: return launch_n<64, 16>(mode, a, stream);
         case 128: return launch_n<128, 16>(mode, a, stream);
         case 256: return launch_n<256, 8>(mode, a, stream);
-        case 512: return launch_n<512, 8>(mode, a, stream);
+        case 512: {
+            static const int cb = getenv("OCN_COLFFT_CB") ? atoi(getenv("OCN_COLFFT_CB")) : 8;
+            if (cb == 4) return launch_n<512, 4>(mode, a, stream);
+            if (cb == 16) return launch_n<512, 16>(mode, a, stream);
+            return launch_n<512, 8>(mode, a, stream);
+        }
         default: set_error("column FFT length %d is not supported (64, 128, 256, 512)", N); return OCN_ERR_UNSUPPORTED;
     }
 }

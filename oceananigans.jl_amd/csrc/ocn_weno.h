@@ -92,22 +92,28 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double D0 = __builtin_fma(-2.0, T3, T2) + T4, E0 = __builtin_fma(-4.0, T3, __builtin_fma(3.0, T2, T4));
     const double D1 = __builtin_fma(-2.0, T2, T1) + T3, E1 = T1 - T3;
     const double D2 = __builtin_fma(-2.0, T1, T0) + T2, E2 = __builtin_fma(-4.0, T1, __builtin_fma(3.0, T2, T0));
-    const double be0 = __builtin_fma(0.75 * E0, E0, (3.25 * D0) * D0);
-    const double be1 = __builtin_fma(0.75 * E1, E1, (3.25 * D1) * D1);
-    const double be2 = __builtin_fma(0.75 * E2, E2, (3.25 * D2) * D2);
+    // The weights depend on the betas only through tau/(beta + eps), which is invariant under a common scaling of
+    // (beta, eps): work with b_r = beta_r / 0.75 = E^2 + (13/3) D^2 and eps' = eps / 0.75 (one multiply less per beta).
+    const double be0 = __builtin_fma((13.0 / 3.0) * D0, D0, E0 * E0);
+    const double be1 = __builtin_fma((13.0 / 3.0) * D1, D1, E1 * E1);
+    const double be2 = __builtin_fma((13.0 / 3.0) * D2, D2, E2 * E2);
     const double tau = fabs(be0 - be2);
-    const double p0 = (OCN_W5P_00 * T2 + OCN_W5P_01 * T3) + OCN_W5P_02 * T4;
-    const double p1 = (OCN_W5P_10 * T1 + OCN_W5P_11 * T2) + OCN_W5P_12 * T3;
-    const double p2 = (OCN_W5P_20 * T0 + OCN_W5P_21 * T1) + OCN_W5P_22 * T2;
-    // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = beta_r + eps;
-    // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2.
-    const double d0 = be0 + OCN_WENO_EPS, d1 = be1 + OCN_WENO_EPS, d2 = be2 + OCN_WENO_EPS;
+    // per-stencil reconstructions pre-multiplied by the optimal weights C_r (folded into the coefficients at compile time)
+    const double cp0 = ((OCN_C5_0 * OCN_W5P_00) * T2 + (OCN_C5_0 * OCN_W5P_01) * T3) + (OCN_C5_0 * OCN_W5P_02) * T4;
+    const double cp1 = ((OCN_C5_1 * OCN_W5P_10) * T1 + (OCN_C5_1 * OCN_W5P_11) * T2) + (OCN_C5_1 * OCN_W5P_12) * T3;
+    const double cp2 = ((OCN_C5_2 * OCN_W5P_20) * T0 + (OCN_C5_2 * OCN_W5P_21) * T1) + (OCN_C5_2 * OCN_W5P_22) * T2;
+    // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = b_r + eps';
+    // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2:
+    //   m_r = (d_r^2 + tau^2) prod_{s != r} d_s^2,  result = sum (C_r p_r) m_r / sum C_r m_r.
+    const double d0 = be0 + (OCN_WENO_EPS / 0.75), d1 = be1 + (OCN_WENO_EPS / 0.75), d2 = be2 + (OCN_WENO_EPS / 0.75);
     const double t2 = tau * tau;
     const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
-    const double n0 = (OCN_C5_0 * (e0 + t2)) * (e1 * e2);
-    const double n1 = (OCN_C5_1 * (e1 + t2)) * (e0 * e2);
-    const double n2 = (OCN_C5_2 * (e2 + t2)) * (e0 * e1);
-    return (n0 * p0 + n1 * p1 + n2 * p2) * fast_rcp(n0 + n1 + n2);
+    const double m0 = (e0 + t2) * (e1 * e2);
+    const double m1 = (e1 + t2) * (e0 * e2);
+    const double m2 = (e2 + t2) * (e0 * e1);
+    const double num = __builtin_fma(cp2, m2, __builtin_fma(cp1, m1, cp0 * m0));
+    const double den = __builtin_fma(OCN_C5_2, m2, __builtin_fma(OCN_C5_1, m1, OCN_C5_0 * m0));
+    return num * fast_rcp(den);
 #endif
 }
 

@@ -186,7 +186,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
     const int lx = tx + 3, ly = ty + 3;  // own cell inside the LDS tile
 
-    const double *pu = u + ocn::at(Lu, i, j, 1), *pv = v + ocn::at(Lv, i, j, 1), *pw = w + ocn::at(Lw, i, j, 1);
+    // one element offset addresses u, v, w (and G) of the own column: same layout for every field (see above)
+    const long long own0 = ocn::at(L0, i, j, 1);
+    const double *pu = u + own0, *pv = v + own0, *pw = w + own0;
     const long long su3 = L0.s3;
 #define sv3 su3
 #define sw3 su3
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     // Static ring assignment: ring cell q (0 <= q < NRING) <-> tile cell (cx, cy) outside the TX x TY core.
     int rcx[RPT], rcy[RPT];
     bool ron[RPT];
-    const double *ru[RPT], *rv[RPT], *rw[RPT];
+    long long roff[RPT];  // ring cell offset (plane 1), shared by u, v, w
     const double *rpc[RPT] = {}, *rpw[RPT] = {}, *rps[RPT] = {};
 #pragma unroll
     for (int s = 0; s < RPT; ++s) {
@@ -250,9 +252,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         if (!ron[s]) { cx = 0; cy = 0; }
         rcx[s] = cx; rcy[s] = cy;
         const int gi = min(ti0 - 3 + cx, imax), gj = min(tj0 - 3 + cy, jmax);
-        ru[s] = u + ocn::at(Lu, gi, gj, 1);
-        rv[s] = v + ocn::at(Lv, gi, gj, 1);
-        rw[s] = w + ocn::at(Lw, gi, gj, 1);
+        roff[s] = ocn::at(L0, gi, gj, 1);
         if (PC) {
             const Lay &Lp = L0;
             rpc[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj, Ny), 1);
@@ -261,17 +261,17 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         }
     }
     auto ring_u = [&](int s, int kk) {
-        const double raw = ru[s][(kk - 1) * su3];
+        const double raw = u[roff[s] + (kk - 1) * su3];
         if (!PC) return raw;
         return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpw[s][zz(kk)], hx) * pcdt;
     };
     auto ring_v = [&](int s, int kk) {
-        const double raw = rv[s][(kk - 1) * sv3];
+        const double raw = v[roff[s] + (kk - 1) * sv3];
         if (!PC) return raw;
         return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rps[s][zz(kk)], hy) * pcdt;
     };
     auto ring_w = [&](int s, int kk) {
-        const double raw = rw[s][(kk - 1) * sw3];
+        const double raw = w[roff[s] + (kk - 1) * sw3];
         if (!PC) return raw;
         return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpc[s][zz(kk - 1)], hz) * pcdt;
     };
