@@ -482,6 +482,13 @@ static int tile_variant()
     return e ? atoi(e) : 0;
 }
 
+// z-chunking target: the launch should have at least this many workgroups (768 run concurrently: 256 CUs x 3)
+static int min_blocks()
+{
+    static const int v = getenv("OCN_TEND_MIN_BLOCKS") ? atoi(getenv("OCN_TEND_MIN_BLOCKS")) : 8192;
+    return v;
+}
+
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 {
     if (range) {
@@ -519,7 +526,7 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
     do {                                                                                                                   \
         const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));                                           \
         int KZ = wz; /* z-chunk: enough workgroups to fill the chip, long enough to amortise the 3-flux prologue */        \
-        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;                                           \
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;                                    \
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                   \
         if (grid->tz == OCN_PERIODIC)                                                                                      \
             hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, W, false>), nbt, dim3(TX * TY), 0, stream, g, \
@@ -536,7 +543,7 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
             constexpr int TX = 32, TY = 8;
             const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
             int KZ = wz;
-            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;
+            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
             dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
             hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu,
                                Gv, Gw, r, KZ, fz);
