@@ -288,6 +288,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     // ---- prologue: bottom-face fluxes Fwu(k), Fwv(k) need w-tile(k) and u/v[k-3..k+2]; Fww(k-1) needs w[k-3..k+2]
     double fwu_bot, fwv_bot, fww_prev;
     double nu[RPT], nv[RPT], nw[RPT];  // prefetched ring values: u(k), v(k), w(k+1)
+    double pc_prev = 0.0, rp_prev[RPT] = {};  // PC: pressure of the previous plane at the own column / ring cells
     {
         sw[k & 1][ly][lx] = zw[2];
 #pragma unroll
@@ -299,6 +300,11 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             nu[s] = ron[s] ? ring_u(s, k) : 0.0;
             nv[s] = ron[s] ? ring_v(s, k) : 0.0;
             nw[s] = ron[s] ? ring_w(s, k + 1) : 0.0;
+        }
+        if (PC) {
+            pc_prev = pC[zz(k + 3)];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) rp_prev[s] = ron[s] ? rpc[s][zz(k + 1)] : 0.0;
         }
         const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
         const double(*swk)[LX] = sw[k & 1];
@@ -338,16 +344,35 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         // ---- prefetch what the NEXT plane needs; the loads fly under this plane's arithmetic
         double zu_n = 0, zv_n = 0, zw_n = 0;
         if (k < k_end) {
-            zu_n = ZU(k + 4);
-            zv_n = ZV(k + 4);
-            zw_n = ZW(k + 4);
+            if (PC) {
+                // corrected values of the next plane, re-using last plane's pressure values (6 p loads instead of 8)
+                const long long o4 = zz(k + 4), o1 = zz(k + 1), o2 = zz(k + 2);
+                const double pc4 = pC[o4], pw4 = pWn[o4], ps4 = pSn[o4];
+                zu_n = pu[(k + 3) * su3] - OCN_PC_GRAD(pc4 - pw4, hx) * pcdt;
+                zv_n = pv[(k + 3) * sv3] - OCN_PC_GRAD(pc4 - ps4, hy) * pcdt;
+                zw_n = pw[(k + 3) * sw3] - OCN_PC_GRAD(pc4 - pc_prev, hz) * pcdt;
+                pc_prev = pc4;
 #pragma unroll
-            for (int s = 0; s < RPT; ++s)
-                if (ron[s]) {
-                    nu[s] = ring_u(s, k + 1);
-                    nv[s] = ring_v(s, k + 1);
-                    nw[s] = ring_w(s, k + 2);
-                }
+                for (int s = 0; s < RPT; ++s)
+                    if (ron[s]) {
+                        const double pr1 = rp_prev[s], pr2 = rpc[s][o2];
+                        nu[s] = u[roff[s] + k * su3] - OCN_PC_GRAD(pr1 - rpw[s][o1], hx) * pcdt;
+                        nv[s] = v[roff[s] + k * sv3] - OCN_PC_GRAD(pr1 - rps[s][o1], hy) * pcdt;
+                        nw[s] = w[roff[s] + (k + 1) * sw3] - OCN_PC_GRAD(pr2 - pr1, hz) * pcdt;
+                        rp_prev[s] = pr2;
+                    }
+            } else {
+                zu_n = ZU(k + 4);
+                zv_n = ZV(k + 4);
+                zw_n = ZW(k + 4);
+#pragma unroll
+                for (int s = 0; s < RPT; ++s)
+                    if (ron[s]) {
+                        nu[s] = ring_u(s, k + 1);
+                        nv[s] = ring_v(s, k + 1);
+                        nw[s] = ring_w(s, k + 2);
+                    }
+            }
         }
         const double(*swk)[LX] = sw[k & 1];
         const double(*swt)[LX] = sw[(k + 1) & 1];
