@@ -43,6 +43,11 @@ std::vector<double> colfft_twiddles(int N);
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
                   hipStream_t stream);
+// row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p
+bool rowfft_supported(int Nx);
+void rowfft_twiddles(int Nx, std::vector<double> &twM, std::vector<double> &twN);
+int launch_rowfft(const ocn_grid *grid, int inverse, const double *u, const double *v, const double *w, const double *real_in,
+                  double dt, double *spec, double *p, const double *twM, const double *twN, double scale, hipStream_t stream);
 int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream);
 int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src, double *dst, hipStream_t stream);
 

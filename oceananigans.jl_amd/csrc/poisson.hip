@@ -128,6 +128,9 @@ struct ocn_poisson {
     Plan fwd, bwd;
     bool fused_z = false;       // FFT_z + spectral solve + IFFT_z in one column kernel (colfft.hip); rocFFT does (x, y)
     double *tw = nullptr, *lz_stage = nullptr;
+    bool custom_xy = false;     // x passes by rowfft.hip (fused with the source term / the write into p), y passes by colfft.hip
+    double *twMx = nullptr, *twNx = nullptr, *twy = nullptr, *ly_stage = nullptr;
+    bool source_in_rhs = false; // custom_xy: the source was given as a real array (set_source_term!) and still needs its x transform
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
 };
@@ -136,7 +139,7 @@ static void free_all(ocn_poisson *s)
 {
     s->fwd.destroy();
     s->bwd.destroy();
-    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage};
+    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -229,6 +232,20 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
         for (int p = 0; p < Nz; ++p) lzs[p] = lzn[ocn::colfft_wavenumber(Nz, p)];  // eigenvalue of each stored position
         TRY(upload(lzs, &s->lz_stage));
     }
+    {
+        const char *e = std::getenv("OCN_POISSON_CUSTOM_XY");
+        s->custom_xy = s->fused_z && ocn::rowfft_supported(Nx) && ocn::colfft_supported(Ny) && !(e && e[0] == '0');
+    }
+    if (s->custom_xy) {
+        std::vector<double> a, b;
+        ocn::rowfft_twiddles(Nx, a, b);
+        TRY(upload(a, &s->twMx));
+        TRY(upload(b, &s->twNx));
+        TRY(upload(ocn::colfft_twiddles(Ny), &s->twy));
+        std::vector<double> lyn = eigenvalues(Ny, grid->Ly, grid->ty), lys(Ny);
+        for (int p = 0; p < Ny; ++p) lys[p] = lyn[ocn::colfft_wavenumber(Ny, p)];  // y is kept in stage order between its two passes
+        TRY(upload(lys, &s->ly_stage));
+    }
     const int fft_dims = (s->kind == 0 && grid->tz == OCN_PERIODIC && !s->fused_z) ? 3 : 2;
     const size_t batch = (fft_dims == 3) ? 1 : (size_t)Nz;
     const size_t len[3] = {(size_t)Nx, (size_t)Ny, (size_t)Nz};
@@ -280,7 +297,7 @@ extern "C" int ocn_poisson_info(ocn_poisson_t s, int32_t *kind, int32_t *r2c, in
     OCN_REQUIRE(s, "ocn_poisson_info: null solver");
     if (kind) *kind = s->kind;
     if (r2c) *r2c = !s->c2c;
-    if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0);
+    if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0) + 4 * (s->custom_xy ? 1 : 0);
     return OCN_SUCCESS;
 }
 
@@ -290,6 +307,12 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     OCN_REQUIRE(s && u && v && w, "ocn_poisson_compute_source_term: null argument");
     const ocn_grid *g = &s->grid;
     int st;
+    if (s->custom_xy) {  // K8 fused with the forward x transform: the divergence goes straight into the half spectrum
+        st = ocn::launch_rowfft(g, 0, u, v, w, nullptr, dt, s->spec, nullptr, s->twMx, s->twNx, 1.0, ocn::as_stream(stream));
+        s->source_in_rhs = false;
+        s->source_set = (st == OCN_SUCCESS);
+        return st;
+    }
     if (s->c2c)
         st = ocn::launch_source_term(g, u, v, w, dt, s->kind == 1 ? 2 : 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     else
@@ -318,6 +341,7 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
         st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, dzc, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     }
     s->source_set = (st == OCN_SUCCESS);
+    s->source_in_rhs = s->custom_xy;
     return st;
 }
 
@@ -328,6 +352,24 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
     hipStream_t stream = ocn::as_stream(stream_);
     const ocn_grid *g = &s->grid;
     int st;
+    if (s->custom_xy) {
+        const long long plane = (long long)s->nxh * g->Ny;
+        if (s->source_in_rhs) {  // set_source_term! path: x transform of the real array
+            st = ocn::launch_rowfft(g, 0, nullptr, nullptr, nullptr, s->rhs, 1.0, s->spec, nullptr, s->twMx, s->twNx, 1.0, stream);
+            if (st != OCN_SUCCESS) return st;
+            s->source_in_rhs = false;
+        }
+        // FFT_y (stage order out) -> FFT_z + solve + IFFT_z -> IFFT_y -> inverse x transform into the rows of p
+        st = ocn::launch_colfft(g->Ny, 0, s->spec, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn::launch_colfft(g->Nz, 2, s->spec, plane, 0, (int)plane, 1, s->tw, s->lx, s->ly_stage, s->lz_stage,
+                                1.0 / ((double)g->Nx * g->Ny * g->Nz), s->nxh, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn::launch_colfft(g->Ny, 1, s->spec, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        // the packed real inverse returns (Nx/2) x, the normalisation above assumed Nx x: scale by 2
+        return ocn::launch_rowfft(g, 1, nullptr, nullptr, nullptr, nullptr, 1.0, s->spec, p, s->twMx, s->twNx, 2.0, stream);
+    }
     // forward transforms (solve! :104-107)
     if (s->c2c)
         st = s->fwd.exec(s->spec, nullptr, stream);

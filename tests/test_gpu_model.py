@@ -18,6 +18,8 @@ POISSON_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi)),
                  ((20, 16, 128), "PPP", (0, 2.0)),
                  ((9, 8, 256), "PPP", (0, 1.0)),
                  ((8, 8, 512), "PPP", (0, 4.0)),
+                 ((128, 64, 64), "PPP", (0, 1.0)),    # Nx in {128..1024} and Ny, Nz in {64..512}: fully custom transform pipeline
+                 ((256, 128, 64), "PPP", (0, 2.0)),
                  ((16, 12, 10), "PPB", (-1.0, 0.0)),
                  ((16, 12, 9), "PPB", "stretched"),
                  ((11, 7, 9), "PPB", "stretched"),
@@ -49,6 +51,7 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
     phi = ocn.CenterField(pg)
     if topo == "PPP":
         assert bool(solver.info()["direct_out"] & 2) == (size[2] in (64, 128, 256, 512))  # fused z kernel in use
+        assert bool(solver.info()["direct_out"] & 4) == (size[0] in (128, 256) and size[1] in (64, 128))  # custom x, y passes
     ocn.solve_for_pressure(phi, solver, 1.0, (du, dv, dw))
     ocn.fill_halo_regions(phi)
     ocn.sync_device()
@@ -111,6 +114,7 @@ MODEL_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), "RungeKutta3"),
                ((16, 16, 16), "PPP", (0, 2 * np.pi), "QuasiAdamsBashforth2"),
                ((13, 17, 19), "PPP", (0, 1.0), "RungeKutta3"),
                ((16, 16, 64), "PPP", (0, 8 * np.pi), "RungeKutta3"),
+               ((128, 64, 64), "PPP", (0, np.pi), "RungeKutta3"),
                ((16, 12, 10), "PPB", (-1.0, 0.0), "RungeKutta3"),
                ((16, 12, 10), "PPB", "stretched", "RungeKutta3"),
                ((24, 16, 1), "PPF", None, "RungeKutta3")]
