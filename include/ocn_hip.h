@@ -137,6 +137,80 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w,
                                 const double *c, double *Gc, const int32_t *range, void *stream);
 
+/* ---- the other terms of u/v/w_velocity_tendency and tracer_tendency ----
+ * advection schemes */
+#define OCN_ADVECTION_WENO5 0     /* WENO() = WENO(order=5)             src/Advection/weno_reconstruction.jl:98-123 */
+#define OCN_ADVECTION_CENTERED2 1 /* Centered() = Centered(order=2), the reference default  centered_reconstruction.jl:39-60 */
+/* buoyancy formulations (gravity_unit_vector = NegativeZDirection()) */
+#define OCN_BUOYANCY_NONE 0
+#define OCN_BUOYANCY_TRACER 1      /* BuoyancyTracer(): b = tracer `T` slot               buoyancy_tracer.jl:12 */
+#define OCN_BUOYANCY_SEAWATER_TS 2 /* SeawaterBuoyancy(LinearEquationOfState): g(αT - βS) linear_equation_of_state.jl:58-60 */
+#define OCN_BUOYANCY_SEAWATER_T 3  /* ... constant_salinity:     g α T                    :62-63 */
+#define OCN_BUOYANCY_SEAWATER_S 4  /* ... constant_temperature: -g β S                    :65-66 */
+
+/* The keyword arguments of NonhydrostaticModel(; advection, coriolis, closure, buoyancy) (nonhydrostatic_model.jl:114-135)
+ * that change the tendency kernels, plus the device fields those terms read. */
+typedef struct ocn_model_terms {
+    int32_t advection; /* OCN_ADVECTION_* */
+    int32_t coriolis;  /* 0 nothing, 1 FPlane(f)                                            src/Coriolis/f_plane.jl:44-46 */
+    int32_t closure;   /* 0 nothing, 1 ScalarDiffusivity(ν, κ): ThreeDimensionalFormulation, ExplicitTimeDiscretization,
+                          constant coefficients                    abstract_scalar_diffusivity_closure.jl:158-223 */
+    int32_t buoyancy;  /* OCN_BUOYANCY_* */
+    double f;          /* FPlane.f */
+    double nu;         /* ScalarDiffusivity.ν */
+    double g, alpha, beta; /* gravitational_acceleration, thermal_expansion, haline_contraction */
+    const double *T;   /* DEVICE: temperature (or the buoyancy tracer b); NULL if unused */
+    const double *S;   /* DEVICE: salinity; NULL if unused */
+    const double *pHY; /* DEVICE: hydrostatic pressure anomaly pHY′ (model.pressures.pHY′) or NULL = `nothing`
+                          (then w receives z_dot_g_b directly, nonhydrostatic_tendency_kernel_functions.jl:141-143) */
+} ocn_model_terms;
+
+/* compute_Gu!/Gv!/Gw! with every supported term:
+ *   G = ((((-div_𝐯u) + x_dot_g_b) - x_f_cross_U) - ∂x pHY′) - ∂ⱼτ₁ⱼ      (nonhydrostatic_tendency_kernel_functions.jl:66-75,
+ *   128-137, 193-200), evaluated in that order.  terms->advection selects the flux scheme. */
+int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v,
+                                          const double *w, double *Gu, double *Gv, double *Gw, const int32_t *range,
+                                          void *stream);
+/* compute_Gc! with advection scheme terms->advection and, when terms->closure != 0, the diffusive flux divergence
+ *   Gc = -div_Uc - ∇_dot_qᶜ,  q = -κ ∇c      (:250-256; closure_kernel_operators.jl:48-53) */
+int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *u,
+                                      const double *v, const double *w, const double *c, double *Gc, const int32_t *range,
+                                      void *stream);
+/* update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-53): pHY′ by downward integration of the buoyancy
+ * perturbation over i in 0:Nx+1, j in 0:Ny+1 (tracer halos must be filled).  No-op on a z-Flat grid. */
+int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream);
+
+/* Boundary conditions (src/BoundaryConditions/boundary_condition.jl).  The condition evaluates to
+ *   values[(i-1) + Nx*(j-1)]              if values != NULL  (array boundary condition, DEVICE pointer), else
+ *   value + coeff * c[i, j, interior]     (coeff = 0: a plain number; coeff != 0 restates the ContinuousBoundaryFunction
+ *                                          f(x, y, t, c, p) = p * c with field_dependencies = the field itself, whose
+ *                                          argument is c[i, j, Nz] / c[i, j, 1]: continuous_boundary_function.jl:107-115). */
+#define OCN_BC_DEFAULT 0  /* Periodic / no-flux / impenetrable by topology (field_boundary_conditions.jl:15-33) */
+#define OCN_BC_FLUX 1
+#define OCN_BC_VALUE 2
+#define OCN_BC_GRADIENT 3
+typedef struct ocn_bc {
+    int32_t kind;
+    int32_t _pad;
+    double value, coeff;
+    const double *values;
+} ocn_bc;
+/* FieldBoundaryConditions of one field.  Only bottom / top may differ from OCN_BC_DEFAULT (x, y are Periodic in the
+ * supported scope); w (Face in z) keeps its impenetrable default. */
+typedef struct ocn_field_bcs {
+    ocn_bc west, east, south, north, bottom, top;
+} ocn_field_bcs;
+/* fill_halo_regions! with user boundary conditions: Value / Gradient sides are linearly extrapolated into the first halo
+ * cell (fill_halo_regions_value_gradient.jl:5-103), Flux sides get the no-flux fill (fill_halo_regions_flux.jl:14-33).
+ * bcs[f] == NULL keeps field f on its defaults. */
+int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const int32_t *locs,
+                              const ocn_field_bcs *const *bcs, int32_t n, int32_t fill_boundary_normal_velocities,
+                              void *stream);
+/* compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:204-213) = apply_z_bcs! of every field:
+ *   G[i,j,1] += flux*Az/V (bottom),  G[i,j,Nz] -= flux*Az/V (top)      (apply_flux_bcs.jl:107-160) */
+int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *const *fields, const int32_t *locs,
+                       const ocn_field_bcs *const *bcs, int32_t n, void *stream);
+
 /* ---- Time steppers ----
  * rk3_substep_field! for n fields in one launch (src/TimeSteppers/runge_kutta_3.jl:160-208).
  * has_zeta = 0 selects the first-stage method  U += (Δt*γ)*Gⁿ. */

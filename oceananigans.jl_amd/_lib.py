@@ -28,6 +28,27 @@ class CGrid(C.Structure):
                 ("dzc", C.c_void_p), ("dzf", C.c_void_p)]
 
 
+class CModelTerms(C.Structure):
+    """struct ocn_model_terms"""
+    _fields_ = [("advection", C.c_int32), ("coriolis", C.c_int32), ("closure", C.c_int32), ("buoyancy", C.c_int32),
+                ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("T", C.c_void_p), ("S", C.c_void_p), ("pHY", C.c_void_p)]
+
+
+class CBc(C.Structure):
+    """struct ocn_bc"""
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("value", C.c_double), ("coeff", C.c_double), ("values", C.c_void_p)]
+
+
+class CFieldBcs(C.Structure):
+    """struct ocn_field_bcs"""
+    _fields_ = [(n, CBc) for n in ("west", "east", "south", "north", "bottom", "top")]
+
+
+ADVECTION_WENO5, ADVECTION_CENTERED2 = 0, 1
+BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_SEAWATER_TS, BUOYANCY_SEAWATER_T, BUOYANCY_SEAWATER_S = 0, 1, 2, 3, 4
+BC_DEFAULT, BC_FLUX, BC_VALUE, BC_GRADIENT = 0, 1, 2, 3
+
 _lib = None
 
 _vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
@@ -47,6 +68,11 @@ _SIGS = {
     "ocn_compute_momentum_tendencies": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_momentum_tendencies_rk3": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, C.POINTER(_i32), _vp],
     "ocn_compute_tracer_tendency": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_momentum_tendencies_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_tracer_tendency_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_update_hydrostatic_pressure": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp],
+    "ocn_fill_halo_regions_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _i32, _vp],
+    "ocn_apply_flux_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _vp],
     "ocn_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _i32, _vp],
     "ocn_ab2_step": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _vp],
     "ocn_cache_previous_tendencies": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _vp],

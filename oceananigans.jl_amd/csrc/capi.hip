@@ -201,6 +201,144 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
+// ---- SURVEY §8(f) rank 1 ------------------------------------------------------------------------------
+static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
+{
+    OCN_REQUIRE(t != nullptr, "terms is NULL");
+    OCN_REQUIRE(t->advection == OCN_ADVECTION_WENO5 || t->advection == OCN_ADVECTION_CENTERED2, "unknown advection scheme %d", t->advection);
+    OCN_REQUIRE(t->coriolis == 0 || t->coriolis == 1, "unknown coriolis code %d", t->coriolis);
+    OCN_REQUIRE(t->closure == 0 || t->closure == 1, "unknown closure code %d", t->closure);
+    OCN_REQUIRE(t->buoyancy >= OCN_BUOYANCY_NONE && t->buoyancy <= OCN_BUOYANCY_SEAWATER_S, "unknown buoyancy code %d", t->buoyancy);
+    if (t->buoyancy == OCN_BUOYANCY_TRACER || t->buoyancy == OCN_BUOYANCY_SEAWATER_TS || t->buoyancy == OCN_BUOYANCY_SEAWATER_T)
+        OCN_REQUIRE(t->T != nullptr, "buoyancy formulation %d needs the T (or b) tracer", t->buoyancy);
+    if (t->buoyancy == OCN_BUOYANCY_SEAWATER_TS || t->buoyancy == OCN_BUOYANCY_SEAWATER_S)
+        OCN_REQUIRE(t->S != nullptr, "buoyancy formulation %d needs the S tracer", t->buoyancy);
+    OCN_REQUIRE(!t->pHY || t->buoyancy != OCN_BUOYANCY_NONE, "a hydrostatic pressure anomaly exists only with buoyancy (nonhydrostatic_model.jl:143-158)");
+    if (t->advection == OCN_ADVECTION_WENO5) return validate_weno(grid);
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "Centered(order=2) and the closure stencils need halo >= 1");
+    return OCN_SUCCESS;
+}
+
+int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v,
+                                          const double *w, double *Gu, double *Gv, double *Gw, const int32_t *range,
+                                          void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies_terms: null field pointer");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    hipStream_t s = as_stream(stream);
+    if (terms->advection == OCN_ADVECTION_WENO5)
+        st = strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
+                    : ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
+    else
+        st = strict ? ocn_strict::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s)
+                    : ocn_fast::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s);
+    if (st != OCN_SUCCESS) return st;
+    if (!(terms->coriolis || terms->closure || terms->buoyancy)) return OCN_SUCCESS;
+    TermsDev t = to_dev(*terms);
+    return strict ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s)
+                  : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s);
+}
+
+int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *u,
+                                      const double *v, const double *w, const double *c, double *Gc, const int32_t *range,
+                                      void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency_terms: null field pointer");
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    hipStream_t s = as_stream(stream);
+    if (terms->advection == OCN_ADVECTION_WENO5)
+        st = strict ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s)
+                    : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s);
+    else
+        st = strict ? ocn_strict::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s)
+                    : ocn_fast::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s);
+    if (st != OCN_SUCCESS || !terms->closure) return st;
+    return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, c, Gc, range, s)
+                  : ocn_fast::launch_tracer_diffusion(grid, kappa, c, Gc, range, s);
+}
+
+int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(terms != nullptr && pHY != nullptr, "ocn_update_hydrostatic_pressure: null argument");
+    OCN_REQUIRE(terms->buoyancy != OCN_BUOYANCY_NONE, "ocn_update_hydrostatic_pressure: buoyancy is nothing");
+    if (terms->buoyancy != OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->T != nullptr, "T (or b) tracer is NULL");
+    if (terms->buoyancy == OCN_BUOYANCY_SEAWATER_TS || terms->buoyancy == OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->S != nullptr, "S tracer is NULL");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    return launch_hydrostatic_pressure(grid, to_dev(*terms), pHY, as_stream(stream));
+}
+
+static int make_zbc_tuple(const ocn_grid *grid, const int32_t *locs, const ocn_field_bcs *const *bcs, int32_t n, ZBcTuple &z,
+                          bool flux_only, bool &any)
+{
+    any = false;
+    for (int f = 0; f < n; ++f) {
+        z.bottom[f] = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
+        z.top[f] = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
+        if (!bcs || !bcs[f]) continue;
+        const ocn_field_bcs &b = *bcs[f];
+        OCN_REQUIRE(b.west.kind == OCN_BC_DEFAULT && b.east.kind == OCN_BC_DEFAULT && b.south.kind == OCN_BC_DEFAULT &&
+                        b.north.kind == OCN_BC_DEFAULT,
+                    "field %d: only bottom / top boundary conditions are supported (x, y are Periodic)", f);
+        const ocn_bc *side[2] = {&b.bottom, &b.top};
+        for (int sd = 0; sd < 2; ++sd) {
+            const ocn_bc &c = *side[sd];
+            OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+            if (c.kind == OCN_BC_DEFAULT) continue;
+            OCN_REQUIRE(grid->tz == OCN_BOUNDED, "bottom / top boundary conditions need a Bounded z (topology %d)", grid->tz);
+            OCN_REQUIRE(!(locs[f] & 4), "field %d: w keeps its impenetrable bottom / top condition", f);
+            OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions are not supported on a partitioned grid");
+            if (flux_only && c.kind != OCN_BC_FLUX) continue;
+            ZBc &d = sd ? z.top[f] : z.bottom[f];
+            d.kind = c.kind; d.value = c.value; d.coeff = c.coeff; d.values = c.values;
+            any = true;
+        }
+    }
+    return OCN_SUCCESS;
+}
+
+int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const int32_t *locs,
+                              const ocn_field_bcs *const *bcs, int32_t n, int32_t fill_boundary_normal_velocities,
+                              void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    FieldTuple ft;
+    st = make_field_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    ZBcTuple z;
+    bool any;
+    st = make_zbc_tuple(grid, locs, bcs, n, z, false, any);
+    if (st != OCN_SUCCESS) return st;
+    return launch_fill_halos(grid, ft, fill_boundary_normal_velocities, -1, as_stream(stream), any ? &z : nullptr);
+}
+
+int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *const *fields, const int32_t *locs,
+                       const ocn_field_bcs *const *bcs, int32_t n, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    FieldTuple gt, ft;
+    st = make_field_tuple(grid, G, locs, n, gt);
+    if (st != OCN_SUCCESS) return st;
+    st = make_field_tuple(grid, const_cast<double *const *>(fields), locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    ZBcTuple z;
+    bool any;
+    st = make_zbc_tuple(grid, locs, bcs, n, z, true, any);
+    if (st != OCN_SUCCESS) return st;
+    if (!any) return OCN_SUCCESS;
+    return launch_apply_flux_bcs(grid, gt, ft, z, as_stream(stream));
+}
+
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                                 double *Gc, const int32_t *range, void *stream)
 {

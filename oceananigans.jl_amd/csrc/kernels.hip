@@ -15,8 +15,20 @@ namespace ocn {
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wrap1(int i, int N) { return i < 1 ? i + N : (i > N ? i - N : i); }
 
+// ZBcTuple (optional, has_bc): Value / Gradient bottom / top conditions replace the no-flux mirror of the first halo
+// plane by a linear extrapolation (fill_halo_regions_value_gradient.jl:5-103):
+//   ∇c = gradient, or (c¹ - v)/(Δ/2) [bottom], (v - cᴺ)/(Δ/2) [top];   c[0] = c¹ + ∇c*(-Δ),  c[N+1] = cᴺ + ∇c*Δ,
+// Δ = Δzᶜᶜᶠ at the boundary face.  x, y halo columns take the value of their periodic image, as the reference's
+// later Periodic fills would copy it.
+__device__ __forceinline__ double bc_condition(const ZBc &bc, int i, int j, int Nx, double c_int)
+{
+    if (bc.values) return bc.values[(i - 1) + (long long)Nx * (j - 1)];
+    if (bc.coeff != 0.0) return bc.value + bc.coeff * c_int;
+    return bc.value;
+}
+
 template <int TZ>
-__global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a, int wrap_x, int only_dir)
+__global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a, int wrap_x, int only_dir, ZBcTuple zbc, int has_bc)
 {
     const int f = blockIdx.y;
     double *__restrict__ c = a.f[f];
@@ -60,7 +72,20 @@ __global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a
             if (TZ == OCN_BOUNDED && !zface_b && only_dir < 0) sk = (k == 0) ? 1 : (k == g.Nz + 1 ? g.Nz : k);  // no-flux mirror
         }
         if (si == i && sj == j && sk == k) continue;
-        c[at(L, i, j, k)] = c[at(L, si, sj, sk)];
+        double val = c[at(L, si, sj, sk)];
+        if (TZ == OCN_BOUNDED && has_bc && sk != k) {  // first z-halo plane of a Center-in-z field
+            const ZBc &bc = (k == 0) ? zbc.bottom[f] : zbc.top[f];
+            if (bc.kind >= OCN_BC_VALUE) {
+                const int kb = (k == 0) ? 1 : g.Nz + 1;  // boundary face index kᴮ
+                const double D = g.dzf ? g.dzf[kb + g.Hz - 1] : g.dz;
+                const double bv = bc_condition(bc, si, sj, g.Nx, val);
+                double grad;
+                if (bc.kind == OCN_BC_GRADIENT) grad = bv;
+                else grad = (k == 0) ? (val - bv) / (D / 2) : (bv - val) / (D / 2);
+                val = (k == 0) ? val + grad * (-D) : val + grad * D;
+            }
+        }
+        c[at(L, i, j, k)] = val;
     }
 }
 
@@ -74,8 +99,12 @@ __global__ void open_fill_z_kernel(GridDev g, double *__restrict__ w)
     w[at(L, i, j, g.Nz + 1)] = 0.0;
 }
 
-int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream)
+int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream,
+                      const ZBcTuple *zbc_in)
 {
+    ZBcTuple zbc{};
+    const int has_bc = zbc_in != nullptr;
+    if (zbc_in) zbc = *zbc_in;
     GridDev g = to_dev(*grid);
     if (open_fill && grid->tz == OCN_BOUNDED) {
         for (int f = 0; f < ft.n; ++f)
@@ -95,11 +124,88 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
     if (nb > 4096) nb = 4096;
     dim3 gridDim((unsigned)nb, ft.n);
     switch (grid->tz) {
-        case OCN_PERIODIC: hipLaunchKernelGGL(fill_halos_kernel<OCN_PERIODIC>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
-        case OCN_BOUNDED: hipLaunchKernelGGL(fill_halos_kernel<OCN_BOUNDED>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
-        case OCN_FLAT: hipLaunchKernelGGL(fill_halos_kernel<OCN_FLAT>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir); break;
+        case OCN_PERIODIC: hipLaunchKernelGGL(fill_halos_kernel<OCN_PERIODIC>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir, zbc, has_bc); break;
+        case OCN_BOUNDED: hipLaunchKernelGGL(fill_halos_kernel<OCN_BOUNDED>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir, zbc, has_bc); break;
+        case OCN_FLAT: hipLaunchKernelGGL(fill_halos_kernel<OCN_FLAT>, gridDim, dim3(256), 0, stream, g, ft, wrap_x, only_dir, zbc, has_bc); break;
         default: set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;
     }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// apply_z_bcs! for a tuple of fields (apply_flux_bcs.jl:107-160):
+//   bottom: G[i,j,1]  += flux * Az / V(i,j,1)      top: G[i,j,Nz] -= flux * Az(Nz+1) / V(i,j,Nz)
+// Az = Δx*Δy; V at the field's own location (Center in z for u, v, tracers).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void apply_flux_bcs_kernel(GridDev g, FieldTuple G, FieldTuple c, ZBcTuple zbc)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y, f = blockIdx.z;
+    if (i > g.Nx) return;
+    const Lay L = make_lay(g, G.loc[f]);
+    const double Az = g.dx * g.dy;
+    const ZBc &bb = zbc.bottom[f], &bt = zbc.top[f];
+    if (bb.kind == OCN_BC_FLUX) {
+        const long long o = at(L, i, j, 1);
+        const double V = Az * (g.dzc ? g.dzc[1 + g.Hz - 1] : g.dz);
+        G.f[f][o] += bc_condition(bb, i, j, g.Nx, c.f[f][o]) * Az / V;
+    }
+    if (bt.kind == OCN_BC_FLUX) {
+        const long long o = at(L, i, j, g.Nz);
+        const double V = Az * (g.dzc ? g.dzc[g.Nz + g.Hz - 1] : g.dz);
+        G.f[f][o] -= bc_condition(bt, i, j, g.Nx, c.f[f][o]) * Az / V;
+    }
+}
+
+int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    hipLaunchKernelGGL(apply_flux_bcs_kernel, dim3((g.Nx + 63) / 64, g.Ny, G.n), dim3(64), 0, stream, g, G, fields, zbc);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// _update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-20): one thread per (i, j) column of
+// p_kernel_parameters = (0:Nx+1, 0:Ny+1), marching down from k = Nz;  z_dot_g_bᶜᶜᶠ = 1 * ℑzᵃᵃᶠ(b).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double buoyancy_perturbation(const TermsDev &t, long long a)
+{
+    switch (t.buoyancy) {
+        case OCN_BUOYANCY_TRACER: return t.T[a];
+        case OCN_BUOYANCY_SEAWATER_TS: return t.g * (t.alpha * t.T[a] - t.beta * t.S[a]);
+        case OCN_BUOYANCY_SEAWATER_T: return t.g * t.alpha * t.T[a];
+        case OCN_BUOYANCY_SEAWATER_S: return -t.g * t.beta * t.S[a];
+        default: return 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, TermsDev t, double *__restrict__ pHY)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;  // 0 .. N+1
+    if (i > g.Nx + 1 || j > g.Ny + 1) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const int Nz = g.Nz;
+    long long o = at(L, i, j, Nz + 1);
+    double b_up = buoyancy_perturbation(t, o);  // b[k+1]
+    double p = 0.0;
+    for (int k = Nz; k >= 1; --k) {
+        o -= L.s3;
+        const double b = buoyancy_perturbation(t, o);
+        const double zb = 1 * (0.5 * (b + b_up));                       // z_dot_g_bᶜᶜᶠ(k+1)
+        const double dz = g.dzf ? g.dzf[k + 1 + g.Hz - 1] : g.dz;       // Δzᶜᶜᶠ(k+1)
+        p = (k == Nz) ? -zb * dz : p - zb * dz;
+        pHY[o] = p;
+        b_up = b;
+    }
+}
+
+int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream)
+{
+    if (grid->tz == OCN_FLAT || t.buoyancy == OCN_BUOYANCY_NONE) return OCN_SUCCESS;
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 2 + 63) / 64, (g.Ny + 2 + 3) / 4, 1);
+    hipLaunchKernelGGL(hydrostatic_pressure_kernel, nb, block, 0, stream, g, t, pHY);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -93,6 +93,21 @@ struct FuseArgs {
     int pc_on;
 };
 
+// device-side copy of ocn_model_terms (physics.hip)
+struct TermsDev {
+    int coriolis, closure, buoyancy;
+    double f, nu, g, alpha, beta;
+    const double *T, *S, *pHY;
+};
+inline TermsDev to_dev(const ocn_model_terms &m)
+{
+    TermsDev t;
+    t.coriolis = m.coriolis; t.closure = m.closure; t.buoyancy = m.buoyancy;
+    t.f = m.f; t.nu = m.nu; t.g = m.g; t.alpha = m.alpha; t.beta = m.beta;
+    t.T = m.T; t.S = m.S; t.pHY = m.pHY;
+    return t;
+}
+
 int validate_grid(const ocn_grid *g);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -21,7 +21,19 @@ struct StepTuple {
     int n;
 };
 
-int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream);
+// bottom / top boundary conditions of the fields of a FieldTuple (kind 0: default fill)
+struct ZBc {
+    int kind;
+    double value, coeff;
+    const double *values;
+};
+struct ZBcTuple {
+    ZBc bottom[MAX_TUPLE], top[MAX_TUPLE];
+};
+int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream,
+                      const ZBcTuple *zbc = nullptr);
+int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream);
+int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream);
 int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);
 int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
                        double *out, long long ld1, long long ld2, hipStream_t stream);
@@ -58,10 +70,26 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                              double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                            double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
+                            hipStream_t stream);
 }
 namespace ocn_fast {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                              double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                            double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
+                            hipStream_t stream);
 }

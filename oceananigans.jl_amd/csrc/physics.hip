@@ -1,0 +1,368 @@
+// physics.hip -- SURVEY §8(f) rank 1: everything in u/v/w_velocity_tendency and tracer_tendency besides WENO advection.
+//
+//   * advection = Centered(order=2)            src/Advection/centered_advective_fluxes.jl:7-25 (the reference's default scheme)
+//   * coriolis  = FPlane(f)                    src/Coriolis/f_plane.jl:44-46, Operators/interpolation_operators.jl:121-131
+//   * closure   = ScalarDiffusivity(ν, κ)      src/TurbulenceClosures/abstract_scalar_diffusivity_closure.jl:158-223,
+//                                              closure_kernel_operators.jl:27-53, velocity_tracer_gradients.jl:15-27
+//   * buoyancy  = BuoyancyTracer / SeawaterBuoyancy(LinearEquationOfState) through the hydrostatic pressure anomaly
+//                                              src/Models/NonhydrostaticModels/update_hydrostatic_pressure.jl:12-53,
+//                                              BuoyancyFormulations/{buoyancy_tracer.jl:12, linear_equation_of_state.jl:58-66, g_dot_b.jl:1-8}
+//   * flux boundary conditions (top / bottom)  src/BoundaryConditions/apply_flux_bcs.jl:38-160
+//
+// The extra momentum terms are ADDED to a G that already holds the advective tendency, in the reference's order
+//   G = ((((-div_𝐯u - 0) + x_dot_g_b) - x_f_cross_U) - ∂x pHY′) - ∂ⱼτ₁ⱼ      (nonhydrostatic_tendency_kernel_functions.jl:66-75)
+// so the strict build (-ffp-contract=off, true divisions) is bit-identical to the CPU oracle.  The fast build multiplies
+// by reciprocal spacings and lets the compiler contract to FMA.  All kernels are one thread per cell, x fastest across
+// the 64 lanes (512-B coalesced rows); x and y are Periodic in the supported scope, so every field shares one set of
+// strides and active_weighted_ℑxy divides by exactly 1.
+#include "ocn_weno.h"
+
+namespace OCN_NS {
+
+using ocn::GridDev;
+using ocn::Lay;
+using ocn::TermsDev;
+
+struct PRange {
+    int i0, i1, j0, j1, k0, k1;
+    int ow;  // first k written for Gw (periphery exclusion of Face-in-Bounded)
+};
+
+static int make_prange(const ocn_grid *grid, const int32_t *range, PRange &r)
+{
+    if (range) {
+        r.i0 = range[0]; r.i1 = range[1]; r.j0 = range[2]; r.j1 = range[3]; r.k0 = range[4]; r.k1 = range[5];
+        if (r.i0 < 1 || r.i1 > grid->Nx || r.j0 < 1 || r.j1 > grid->Ny || r.k0 < 1 || r.k1 > grid->Nz) {
+            ocn::set_error("tendency range {%d:%d,%d:%d,%d:%d} outside the interior %dx%dx%d", r.i0, r.i1, r.j0, r.j1, r.k0,
+                           r.k1, grid->Nx, grid->Ny, grid->Nz);
+            return OCN_ERR_INVALID_ARGUMENT;
+        }
+        r.ow = 1;
+    } else {
+        r.i0 = 1; r.i1 = grid->Nx; r.j0 = 1; r.j1 = grid->Ny; r.k0 = 1; r.k1 = grid->Nz;
+        r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    }
+    return OCN_SUCCESS;
+}
+
+// a / d  in the strict build;  a * (1/d) with the reciprocal hoisted in the fast build
+#if OCN_STRICT
+#define OCN_DIV(a, d, rd) ((a) / (d))
+#else
+#define OCN_DIV(a, d, rd) ((a) * (rd))
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// Centered(order=2) momentum advection: flux = A(flux location) * sym(U) * sym(u), left-associated
+// ---------------------------------------------------------------------------------------------------
+template <int TZ>
+__global__ __launch_bounds__(256) void momentum_tendencies_centered2(GridDev g, const double *__restrict__ u,
+                                                                     const double *__restrict__ v,
+                                                                     const double *__restrict__ w, double *__restrict__ Gu,
+                                                                     double *__restrict__ Gv, double *__restrict__ Gw, PRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);  // strides and offset shared by all locations (x, y Periodic)
+    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
+    const double *pu = u + o, *pv = v + o, *pw = w + o;
+#define U_(a, b, c) pu[(a) + (b)*s2 + (c)*s3]
+#define V_(a, b, c) pv[(a) + (b)*s2 + (c)*s3]
+#define W_(a, b, c) pw[(a) + (b)*s2 + (c)*s3]
+#define AVG(x, y) (0.5 * (x) + 0.5 * (y))
+    const double Axc = M.Ax(k), Ayc = M.Ay(k), Az = M.Az;
+    {   // Gu
+        const double ue = AVG(U_(0, 0, 0), U_(1, 0, 0)), uw = AVG(U_(-1, 0, 0), U_(0, 0, 0));
+        const double fx = (Axc * ue) * ue - (Axc * uw) * uw;                                             // δxᶠᵃᵃ F_Uu
+        const double fyn = (Ayc * AVG(V_(-1, 1, 0), V_(0, 1, 0))) * AVG(U_(0, 0, 0), U_(0, 1, 0));       // F_Vu(j+1)
+        const double fys = (Ayc * AVG(V_(-1, 0, 0), V_(0, 0, 0))) * AVG(U_(0, -1, 0), U_(0, 0, 0));      // F_Vu(j)
+        double dzF = 0.0;
+        if (!ZF) {
+            const double ft = (Az * AVG(W_(-1, 0, 1), W_(0, 0, 1))) * AVG(U_(0, 0, 0), U_(0, 0, 1));     // F_Wu(k+1)
+            const double fb = (Az * AVG(W_(-1, 0, 0), W_(0, 0, 0))) * AVG(U_(0, 0, -1), U_(0, 0, 0));    // F_Wu(k)
+            dzF = ft - fb;
+        }
+        const double rV = 1 / (Az * M.dzC(k));
+        Gu[o] = -(rV * ((fx + (fyn - fys)) + dzF));
+    }
+    {   // Gv
+        const double fxe = (Axc * AVG(U_(1, -1, 0), U_(1, 0, 0))) * AVG(V_(0, 0, 0), V_(1, 0, 0));       // F_Uv(i+1)
+        const double fxw = (Axc * AVG(U_(0, -1, 0), U_(0, 0, 0))) * AVG(V_(-1, 0, 0), V_(0, 0, 0));      // F_Uv(i)
+        const double vn = AVG(V_(0, 0, 0), V_(0, 1, 0)), vs = AVG(V_(0, -1, 0), V_(0, 0, 0));
+        const double fy = (Ayc * vn) * vn - (Ayc * vs) * vs;                                             // δyᵃᶠᵃ F_Vv
+        double dzF = 0.0;
+        if (!ZF) {
+            const double ft = (Az * AVG(W_(0, -1, 1), W_(0, 0, 1))) * AVG(V_(0, 0, 0), V_(0, 0, 1));     // F_Wv(k+1)
+            const double fb = (Az * AVG(W_(0, -1, 0), W_(0, 0, 0))) * AVG(V_(0, 0, -1), V_(0, 0, 0));    // F_Wv(k)
+            dzF = ft - fb;
+        }
+        const double rV = 1 / (Az * M.dzC(k));
+        Gv[o] = -(rV * (((fxe - fxw) + fy) + dzF));
+    }
+    if (k >= r.ow) {  // Gw: areas and volume at (c,c,f)
+        const double Axf = M.dy * M.dzF(k), Ayf = M.dx * M.dzF(k);
+        // sym_z of u, v to the z face; along a Flat z the value itself (flat_advective_fluxes.jl:26-44)
+        const double uze = ZF ? U_(1, 0, 0) : AVG(U_(1, 0, -1), U_(1, 0, 0)), uzw = ZF ? U_(0, 0, 0) : AVG(U_(0, 0, -1), U_(0, 0, 0));
+        const double vzn = ZF ? V_(0, 1, 0) : AVG(V_(0, 1, -1), V_(0, 1, 0)), vzs = ZF ? V_(0, 0, 0) : AVG(V_(0, 0, -1), V_(0, 0, 0));
+        const double fxe = (Axf * uze) * AVG(W_(0, 0, 0), W_(1, 0, 0));                                  // F_Uw(i+1)
+        const double fxw = (Axf * uzw) * AVG(W_(-1, 0, 0), W_(0, 0, 0));                                 // F_Uw(i)
+        const double fyn = (Ayf * vzn) * AVG(W_(0, 0, 0), W_(0, 1, 0));                                  // F_Vw(j+1)
+        const double fys = (Ayf * vzs) * AVG(W_(0, -1, 0), W_(0, 0, 0));                                 // F_Vw(j)
+        double dzF = 0.0;
+        if (!ZF) {
+            const double wt = AVG(W_(0, 0, 0), W_(0, 0, 1)), wb = AVG(W_(0, 0, -1), W_(0, 0, 0));
+            dzF = (Az * wt) * wt - (Az * wb) * wb;                                                       // δzᵃᵃᶠ F_Ww
+        }
+        const double rV = 1 / (Az * M.dzF(k));
+        Gw[o] = -(rV * (((fxe - fxw) + (fyn - fys)) + dzF));
+    }
+}
+
+// Centered(order=2) tracer advection (+ optional diffusion, see tracer_diffusion below): Ax_q(U) * sym(c)
+template <int TZ>
+__global__ __launch_bounds__(256) void tracer_tendency_centered2(GridDev g, const double *__restrict__ u,
+                                                                 const double *__restrict__ v, const double *__restrict__ w,
+                                                                 const double *__restrict__ c, double *__restrict__ Gc, PRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
+    const double *pu = u + o, *pv = v + o, *pw = w + o, *pc = c + o;
+#define C_(a, b, cc) pc[(a) + (b)*s2 + (cc)*s3]
+    const double Ax = M.Ax(k), Ay = M.Ay(k), Az = M.Az;
+    const double fx = (Ax * U_(1, 0, 0)) * AVG(C_(0, 0, 0), C_(1, 0, 0)) - (Ax * U_(0, 0, 0)) * AVG(C_(-1, 0, 0), C_(0, 0, 0));
+    const double fy = (Ay * V_(0, 1, 0)) * AVG(C_(0, 0, 0), C_(0, 1, 0)) - (Ay * V_(0, 0, 0)) * AVG(C_(0, -1, 0), C_(0, 0, 0));
+    double fzz = 0.0;
+    if (!ZF) fzz = (Az * W_(0, 0, 1)) * AVG(C_(0, 0, 0), C_(0, 0, 1)) - (Az * W_(0, 0, 0)) * AVG(C_(0, 0, -1), C_(0, 0, 0));
+    const double rV = 1 / (Az * M.dzC(k));
+    Gc[o] = -(rV * ((fx + fy) + fzz));
+}
+#undef AVG
+
+// ---------------------------------------------------------------------------------------------------
+// Extra momentum terms: Coriolis, hydrostatic pressure gradient, buoyancy (no pHY′), isotropic viscous stress divergence
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double buoyancy_ccc(const TermsDev &t, long long a)
+{
+    switch (t.buoyancy) {
+        case OCN_BUOYANCY_TRACER: return t.T[a];
+        case OCN_BUOYANCY_SEAWATER_TS: return t.g * (t.alpha * t.T[a] - t.beta * t.S[a]);
+        case OCN_BUOYANCY_SEAWATER_T: return t.g * t.alpha * t.T[a];
+        case OCN_BUOYANCY_SEAWATER_S: return -t.g * t.beta * t.S[a];
+        default: return 0.0;
+    }
+}
+
+template <int TZ>
+__global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev t, const double *__restrict__ u,
+                                                             const double *__restrict__ v, const double *__restrict__ w,
+                                                             double *__restrict__ Gu, double *__restrict__ Gv,
+                                                             double *__restrict__ Gw, PRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
+    const double *pu = u + o, *pv = v + o, *pw = w + o;
+    const double dx = M.dx, dy = M.dy, nu = t.nu;
+    const double dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = ZF ? dzf : M.dzF(k + 1), dzcm = ZF ? dzc : M.dzC(k - 1);
+#if !OCN_STRICT
+    const double rdx = 1 / dx, rdy = 1 / dy, rdzc = 1 / dzc, rdzf = 1 / dzf, rdzf1 = 1 / dzf1, rdzcm = 1 / dzcm;
+#endif
+    // strain-rate pieces (velocity_tracer_gradients.jl); δ along a Flat z is 0
+#define DX(a, b) OCN_DIV((a) - (b), dx, rdx)
+#define DY(a, b) OCN_DIV((a) - (b), dy, rdy)
+#define DZF(a, b) (ZF ? 0.0 : OCN_DIV((a) - (b), dzf, rdzf))      /* derivative at z-face k   */
+#define DZF1(a, b) (ZF ? 0.0 : OCN_DIV((a) - (b), dzf1, rdzf1))   /* derivative at z-face k+1 */
+#define TAU(s) (-2 * (nu * (s)))
+    const double Axc = M.Ax(k), Ayc = M.Ay(k), Az = M.Az;
+
+    {   // ---------------- Gu at (f,c,c)
+        double G = Gu[o];
+        if (t.buoyancy) G = G + 0.0;  // x_dot_g_b = 0 (NegativeZDirection)
+        if (t.coriolis) {             // - x_f_cross_U,  x_f_cross_U = -f * ℑxyᶠᶜᵃ(v) / 1
+            const double vi = 0.5 * (0.5 * (V_(-1, 0, 0) + V_(0, 0, 0)) + 0.5 * (V_(-1, 1, 0) + V_(0, 1, 0)));
+            G = G - (-t.f * vi);
+        }
+        if (t.pHY) G = G - DX(t.pHY[o], t.pHY[o - 1]);  // ∂xᶠᶜᶜ pHY′
+        if (t.closure) {
+            const double t11e = TAU(DX(U_(1, 0, 0), U_(0, 0, 0))), t11w = TAU(DX(U_(0, 0, 0), U_(-1, 0, 0)));
+            const double t12n = TAU(0.5 * (DY(U_(0, 1, 0), U_(0, 0, 0)) + DX(V_(0, 1, 0), V_(-1, 1, 0))));
+            const double t12s = TAU(0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
+            double dzF = 0.0;
+            if (!ZF) {
+                const double t13t = TAU(0.5 * (DZF1(U_(0, 0, 1), U_(0, 0, 0)) + DX(W_(0, 0, 1), W_(-1, 0, 1))));
+                const double t13b = TAU(0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
+                dzF = Az * t13t - Az * t13b;
+            }
+            G = G - 1 / (Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
+        }
+        Gu[o] = G;
+    }
+    {   // ---------------- Gv at (c,f,c)
+        double G = Gv[o];
+        if (t.buoyancy) G = G + 0.0;
+        if (t.coriolis) {  // - y_f_cross_U,  y_f_cross_U = f * ℑxyᶜᶠᵃ(u) / 1
+            const double ui = 0.5 * (0.5 * (U_(0, -1, 0) + U_(1, -1, 0)) + 0.5 * (U_(0, 0, 0) + U_(1, 0, 0)));
+            G = G - t.f * ui;
+        }
+        if (t.pHY) G = G - DY(t.pHY[o], t.pHY[o - s2]);
+        if (t.closure) {
+            const double t12e = TAU(0.5 * (DY(U_(1, 0, 0), U_(1, -1, 0)) + DX(V_(1, 0, 0), V_(0, 0, 0))));
+            const double t12w = TAU(0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
+            const double t22n = TAU(DY(V_(0, 1, 0), V_(0, 0, 0))), t22s = TAU(DY(V_(0, 0, 0), V_(0, -1, 0)));
+            double dzF = 0.0;
+            if (!ZF) {
+                const double t23t = TAU(0.5 * (DZF1(V_(0, 0, 1), V_(0, 0, 0)) + DY(W_(0, 0, 1), W_(0, -1, 1))));
+                const double t23b = TAU(0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+                dzF = Az * t23t - Az * t23b;
+            }
+            G = G - 1 / (Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
+        }
+        Gv[o] = G;
+    }
+    if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
+        double G = Gw[o];
+        if (t.buoyancy) {  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
+            double zb = 0.0;
+            if (!t.pHY) zb = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
+            G = G + zb;
+        }
+        if (t.coriolis) G = G - 0.0;  // z_f_cross_U = 0
+        if (t.closure) {
+            const double Axf = dy * dzf, Ayf = dx * dzf;
+            const double t13e = TAU(0.5 * (DZF(U_(1, 0, 0), U_(1, 0, -1)) + DX(W_(1, 0, 0), W_(0, 0, 0))));
+            const double t13w = TAU(0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
+            const double t23n = TAU(0.5 * (DZF(V_(0, 1, 0), V_(0, 1, -1)) + DY(W_(0, 1, 0), W_(0, 0, 0))));
+            const double t23s = TAU(0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+            double dzF = 0.0;
+            if (!ZF) {
+                const double t33t = TAU(OCN_DIV(W_(0, 0, 1) - W_(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
+                const double t33b = TAU(OCN_DIV(W_(0, 0, 0) - W_(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
+                dzF = Az * t33t - Az * t33b;
+            }
+            G = G - 1 / (Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
+        }
+        Gw[o] = G;
+    }
+}
+
+// Gc <- Gc - ∇_dot_qᶜ,  q = -(κ ∂c)  (closure_kernel_operators.jl:48-53)
+template <int TZ>
+__global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double kappa, const double *__restrict__ c,
+                                                               double *__restrict__ Gc, PRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
+    const double *pc = c + o;
+    const double dx = M.dx, dy = M.dy, dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = ZF ? dzf : M.dzF(k + 1);
+#if !OCN_STRICT
+    const double rdx = 1 / dx, rdy = 1 / dy, rdzf = 1 / dzf, rdzf1 = 1 / dzf1;
+#endif
+    const double Ax = M.Ax(k), Ay = M.Ay(k), Az = M.Az;
+    const double c0 = C_(0, 0, 0);
+    const double qxe = -(kappa * DX(C_(1, 0, 0), c0)), qxw = -(kappa * DX(c0, C_(-1, 0, 0)));
+    const double qyn = -(kappa * DY(C_(0, 1, 0), c0)), qys = -(kappa * DY(c0, C_(0, -1, 0)));
+    double dzF = 0.0;
+    if (!ZF) {
+        const double qzt = -(kappa * DZF1(C_(0, 0, 1), c0)), qzb = -(kappa * DZF(c0, C_(0, 0, -1)));
+        dzF = Az * qzt - Az * qzb;
+    }
+    Gc[o] = Gc[o] - 1 / (Az * dzc) * (((Ax * qxe - Ax * qxw) + (Ay * qyn - Ay * qys)) + dzF);
+}
+#undef U_
+#undef V_
+#undef W_
+#undef C_
+#undef DX
+#undef DY
+#undef DZF
+#undef DZF1
+#undef TAU
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+#define OCN_LAUNCH_TZ(KERNEL, ...)                                                                              \
+    do {                                                                                                        \
+        switch (grid->tz) {                                                                                     \
+            case OCN_PERIODIC: hipLaunchKernelGGL(KERNEL<OCN_PERIODIC>, nb, block, 0, stream, __VA_ARGS__); break; \
+            case OCN_BOUNDED: hipLaunchKernelGGL(KERNEL<OCN_BOUNDED>, nb, block, 0, stream, __VA_ARGS__); break;   \
+            case OCN_FLAT: hipLaunchKernelGGL(KERNEL<OCN_FLAT>, nb, block, 0, stream, __VA_ARGS__); break;         \
+            default: ocn::set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;         \
+        }                                                                                                       \
+        OCN_CHECK_HIP(hipGetLastError());                                                                       \
+    } while (0)
+
+int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                              double *Gw, const int32_t *range, hipStream_t stream)
+{
+    PRange r;
+    int st = make_prange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    OCN_LAUNCH_TZ(momentum_tendencies_centered2, g, u, v, w, Gu, Gv, Gw, r);
+    return OCN_SUCCESS;
+}
+
+int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                            double *Gc, const int32_t *range, hipStream_t stream)
+{
+    PRange r;
+    int st = make_prange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    OCN_LAUNCH_TZ(tracer_tendency_centered2, g, u, v, w, c, Gc, r);
+    return OCN_SUCCESS;
+}
+
+int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double *u, const double *v, const double *w,
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+{
+    PRange r;
+    int st = make_prange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r);
+    return OCN_SUCCESS;
+}
+
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
+                            hipStream_t stream)
+{
+    PRange r;
+    int st = make_prange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    OCN_LAUNCH_TZ(tracer_diffusion_kernel, g, kappa, c, Gc, r);
+    return OCN_SUCCESS;
+}
+
+}  // namespace OCN_NS

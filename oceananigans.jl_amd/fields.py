@@ -18,7 +18,8 @@ class Field:
     `.data` is the parent array (halos included) as a tensor of shape (sz, sy, sx): the same bytes as the
     reference's column-major (sx, sy, sz) OffsetArray parent (src/Grids/new_data.jl:36-70), zero-initialised."""
 
-    def __init__(self, loc, grid, data=None):
+    def __init__(self, loc, grid, data=None, boundary_conditions=None):
+        self.boundary_conditions = boundary_conditions  # FieldBoundaryConditions or None (= defaults)
         if loc not in (_lib.LOC_CCC, _lib.LOC_FCC, _lib.LOC_CFC, _lib.LOC_CCF):
             raise ValueError(f"unsupported field location mask {loc}")
         self.loc = loc
@@ -68,20 +69,20 @@ class Field:
         return self
 
 
-def XFaceField(grid):
-    return Field(_lib.LOC_FCC, grid)
+def XFaceField(grid, boundary_conditions=None):
+    return Field(_lib.LOC_FCC, grid, boundary_conditions=boundary_conditions)
 
 
-def YFaceField(grid):
-    return Field(_lib.LOC_CFC, grid)
+def YFaceField(grid, boundary_conditions=None):
+    return Field(_lib.LOC_CFC, grid, boundary_conditions=boundary_conditions)
 
 
-def ZFaceField(grid):
-    return Field(_lib.LOC_CCF, grid)
+def ZFaceField(grid, boundary_conditions=None):
+    return Field(_lib.LOC_CCF, grid, boundary_conditions=boundary_conditions)
 
 
-def CenterField(grid):
-    return Field(_lib.LOC_CCC, grid)
+def CenterField(grid, boundary_conditions=None):
+    return Field(_lib.LOC_CCC, grid, boundary_conditions=boundary_conditions)
 
 
 def fill_halo_regions(fields, fill_boundary_normal_velocities=True, **_):
@@ -94,6 +95,17 @@ def fill_halo_regions(fields, fill_boundary_normal_velocities=True, **_):
     grid = fields[0].grid
     hook = getattr(grid.architecture, "fill_halo_regions", None)
     if hook is not None:  # Distributed: local fills + x-halo exchange (distributed.py)
+        if any(getattr(f, "boundary_conditions", None) is not None and not f.boundary_conditions.is_default() for f in fields):
+            raise NotImplementedError("user boundary conditions on a Distributed architecture are not implemented")
         return hook(fields, fill_boundary_normal_velocities)
+    bcs = [getattr(f, "boundary_conditions", None) for f in fields]
+    if any(b is not None and not b.is_default() for b in bcs):
+        import ctypes as C
+        arr = (C.POINTER(_lib.CFieldBcs) * len(fields))(*[
+            (C.pointer(b.c_struct(grid)) if b is not None and not b.is_default() else C.POINTER(_lib.CFieldBcs)()) for b in bcs])
+        _lib.call("ocn_fill_halo_regions_bcs", grid.cref, _lib.ptr_array([f.ptr for f in fields]),
+                  _lib.i32_array([f.loc for f in fields]), arr, len(fields), int(bool(fill_boundary_normal_velocities)),
+                  stream_ptr())
+        return
     _lib.call("ocn_fill_halo_regions", grid.cref, _lib.ptr_array([f.ptr for f in fields]),
               _lib.i32_array([f.loc for f in fields]), len(fields), int(bool(fill_boundary_normal_velocities)), stream_ptr())

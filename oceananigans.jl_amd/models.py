@@ -9,8 +9,9 @@ Mirrors, call for call:
   time_step!(model::RungeKutta3, Δt)                              src/TimeSteppers/runge_kutta_3.jl:77-151
   time_step!(model::QuasiAdamsBashforth2, Δt)                     src/TimeSteppers/quasi_adams_bashforth_2.jl:74-115
   cache_previous_tendencies!                                      src/TimeSteppers/store_tendencies.jl:12-22
-Julia's `f!` names are spelled `f` here.  closure, buoyancy, coriolis, forcing, stokes_drift are `nothing`
-(their zero fallbacks, e.g. src/TurbulenceClosures/.../nothing_closure.jl:1-10); asking for anything else raises.
+Julia's `f!` names are spelled `f` here.  forcing, stokes_drift, background_fields are `nothing`; advection is WENO()
+or Centered(); coriolis = FPlane, closure = ScalarDiffusivity, buoyancy = BuoyancyTracer / SeawaterBuoyancy and bottom /
+top Flux / Value / Gradient boundary conditions are the SURVEY §8(f) rank-1 terms (physics.py); anything else raises.
 """
 import math
 import os
@@ -18,7 +19,10 @@ import os
 import torch
 
 from . import _lib
+import ctypes as C
+
 from .advection import WENO
+from .physics import (BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity, SeawaterBuoyancy)
 from .architectures import stream_ptr
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
 from .grids import Bounded, Flat
@@ -74,29 +78,57 @@ class QuasiAdamsBashforth2TimeStepper(_TendencyStore):
 
 class NonhydrostaticModel:
     def __init__(self, grid, advection=None, tracers=(), timestepper="RungeKutta3", closure=None, buoyancy=None,
-                 coriolis=None, forcing=None, stokes_drift=None):
-        for name, val in (("closure", closure), ("buoyancy", buoyancy), ("coriolis", coriolis), ("forcing", forcing),
-                          ("stokes_drift", stokes_drift)):
+                 coriolis=None, forcing=None, stokes_drift=None, boundary_conditions=None,
+                 hydrostatic_pressure_anomaly="default"):
+        for name, val in (("forcing", forcing), ("stokes_drift", stokes_drift)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the MI355X hot-path scope (see DESIGN.md)")
         if advection is None:
-            raise NotImplementedError("advection = Centered() (the reference default) is not implemented; pass advection=WENO()")
-        if not isinstance(advection, WENO):
-            raise NotImplementedError("only advection = WENO() is implemented")
-        # inflate_grid_halo_size (nonhydrostatic_model.jl:183, 243-257): the reference rebuilds the grid with halo >= 3.
-        # Here the user must build it so; adapt_advection_order (N < 3 lowers the order) is not supported.
+            advection = Centered()  # the reference default (nonhydrostatic_model.jl:117)
+        if not isinstance(advection, (WENO, Centered)):
+            raise NotImplementedError("advection must be WENO() or Centered()")
+        if coriolis is not None and not isinstance(coriolis, FPlane):
+            raise NotImplementedError("only coriolis = FPlane(...) is implemented")
+        if closure is not None and not isinstance(closure, ScalarDiffusivity):
+            raise NotImplementedError("only closure = ScalarDiffusivity(...) is implemented")
+        if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
+            raise NotImplementedError("only buoyancy = BuoyancyTracer() or SeawaterBuoyancy(...) is implemented")
+        if isinstance(tracers, str):
+            tracers = (tracers,)
+        tracers = tuple(tracers)
+        if buoyancy is not None:  # validate_buoyancy (BuoyancyFormulations/buoyancy_force.jl:66-76)
+            for req in buoyancy.required_tracers:
+                if req not in tracers:
+                    raise ValueError(f"{type(buoyancy).__name__} requires tracers {buoyancy.required_tracers}, got {tracers}")
+        # inflate_grid_halo_size (nonhydrostatic_model.jl:183, 243-257): the reference rebuilds the grid with the halo the
+        # advection scheme / closure need.  Here the user must build it so; adapt_advection_order is not supported.
         for d, (N, H, t) in enumerate(zip(grid.size, (grid.Hx, grid.Hy, grid.Hz), grid.topology)):
             if t != Flat and (H < advection.buffer or N < advection.buffer):
-                raise ValueError(f"WENO(order=5) needs halo >= 3 and size >= 3 in dimension {d + 1} (got N={N}, H={H})")
+                raise ValueError(f"{advection!r} needs halo >= {advection.buffer} and size >= {advection.buffer} in dimension {d + 1} (got N={N}, H={H})")
         self.grid = grid
         self.architecture = grid.architecture
         self.advection = advection
+        self.coriolis, self.closure, self.buoyancy = coriolis, closure, buoyancy
         self.clock = Clock()
-        self.u, self.v, self.w = XFaceField(grid), YFaceField(grid), ZFaceField(grid)
+        bcs = dict(boundary_conditions or {})
+        for name in bcs:
+            if name not in ("u", "v", "w") + tracers:
+                raise ValueError(f"boundary conditions given for unknown field {name!r}")
+            if not isinstance(bcs[name], FieldBoundaryConditions):
+                raise TypeError("boundary_conditions values must be FieldBoundaryConditions")
+        if "w" in bcs and not bcs["w"].is_default():
+            raise NotImplementedError("w keeps its impenetrable bottom / top boundary condition")
+        self.u, self.v, self.w = XFaceField(grid, bcs.get("u")), YFaceField(grid, bcs.get("v")), ZFaceField(grid)
         self.velocities = (self.u, self.v, self.w)
-        self.tracer_names = tuple(tracers)
-        self.tracers = tuple(CenterField(grid) for _ in self.tracer_names)
+        self.tracer_names = tracers
+        self.tracers = tuple(CenterField(grid, bcs.get(n)) for n in self.tracer_names)
         self.pNHS = CenterField(grid)
+        # nonhydrostatic_model.jl:143-158: pHY′ is a separate CenterField iff buoyancy is not nothing
+        self.pHY = None
+        if buoyancy is not None and hydrostatic_pressure_anomaly == "default":
+            self.pHY = CenterField(grid)
+        elif hydrostatic_pressure_anomaly not in ("default", None):
+            raise ValueError("hydrostatic_pressure_anomaly must be 'default' or None")
         self.pressure_solver = nonhydrostatic_pressure_solver(grid)
         prog = self.prognostic_fields()
         if timestepper in ("RungeKutta3", ":RungeKutta3"):
@@ -107,8 +139,16 @@ class NonhydrostaticModel:
             raise ValueError(f"unknown timestepper {timestepper!r}")
         self._tuple_cache = {}
         self.copy_cached_tendencies = False
+        # anything beyond plain WENO advection goes through the general (unfused) tendency entry points
+        self._has_user_bcs = any(not b.is_default() for b in bcs.values())
+        self._has_flux_bcs = any(b.has_flux() for b in bcs.values())
+        self.general_terms = (isinstance(advection, Centered) or coriolis is not None or closure is not None
+                              or buoyancy is not None or self._has_user_bcs)
+        if self.general_terms and hasattr(grid.architecture, "partition"):
+            raise NotImplementedError("coriolis / closure / buoyancy / boundary conditions on a Distributed architecture are not implemented yet")
+        self._terms = self._make_terms()
         # fused stage boundaries (tendencies + next substep in one launch) need the tiled kernel, no tracers, one rank
-        self.fuse_stage_boundaries = not self.tracers
+        self.fuse_stage_boundaries = not self.tracers and not self.general_terms
         self._alt_velocities = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
         self.defer_final_tendencies = self.fuse_stage_boundaries
@@ -119,6 +159,31 @@ class NonhydrostaticModel:
                                 and os.environ.get("OCN_CORRECT_ON_LOAD", "1") != "0")
         self._pending_tendencies = False
         update_state(self, compute_tendencies=False)
+
+    def _make_terms(self):
+        """struct ocn_model_terms for the C ABI (pointers never change after construction)."""
+        t = _lib.CModelTerms()
+        t.advection = _lib.ADVECTION_CENTERED2 if isinstance(self.advection, Centered) else _lib.ADVECTION_WENO5
+        if self.coriolis is not None:
+            t.coriolis, t.f = 1, self.coriolis.f
+        if self.closure is not None:
+            t.closure, t.nu = 1, self.closure.nu
+        b = self.buoyancy
+        if isinstance(b, BuoyancyTracer):
+            t.buoyancy = _lib.BUOYANCY_TRACER
+            t.T = self.field("b").ptr
+        elif isinstance(b, SeawaterBuoyancy):
+            t.g = b.gravitational_acceleration
+            t.alpha, t.beta = b.equation_of_state.thermal_expansion, b.equation_of_state.haline_contraction
+            if b.constant_salinity is not None:
+                t.buoyancy, t.T = _lib.BUOYANCY_SEAWATER_T, self.field("T").ptr
+            elif b.constant_temperature is not None:
+                t.buoyancy, t.S = _lib.BUOYANCY_SEAWATER_S, self.field("S").ptr
+            else:
+                t.buoyancy, t.T, t.S = _lib.BUOYANCY_SEAWATER_TS, self.field("T").ptr, self.field("S").ptr
+        if self.pHY is not None:
+            t.pHY = self.pHY.ptr
+        return t
 
     def prognostic_fields(self):
         return self.velocities + self.tracers
@@ -173,17 +238,41 @@ def update_state(model, compute_tendencies=True):
     if arch_hook is not None:  # Distributed: async exchange overlapped with interior tendencies
         return arch_hook(model, compute_tendencies)
     fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
+    update_hydrostatic_pressure(model)  # compute_auxiliaries! (update_nonhydrostatic_model_state.jl:59-70)
     if compute_tendencies:
         compute_tendencies_(model)
 
 
+def update_hydrostatic_pressure(model):
+    """update_hydrostatic_pressure!(model) (update_hydrostatic_pressure.jl:25-28)"""
+    if model.pHY is not None:
+        _lib.call("ocn_update_hydrostatic_pressure", model.grid.cref, C.byref(model._terms), model.pHY.ptr, stream_ptr())
+
+
 def compute_tendencies_(model, rng=None):
-    """compute_tendencies! -> compute_interior_tendency_contributions!: K1-K3 fused + K4 per tracer."""
+    """compute_tendencies! -> compute_interior_tendency_contributions!: K1-K3 fused + K4 per tracer, then
+    compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:17-54)."""
     g = model.grid
     model._pending_tendencies = False
     Gn = model.timestepper._Gn
     r = None if rng is None else _lib.i32_array(list(rng))
     s = stream_ptr()
+    if model.general_terms:
+        t = C.byref(model._terms)
+        _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, t, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr,
+                  Gn[1].ptr, Gn[2].ptr, r, s)
+        for n, c in enumerate(model.tracers):
+            kappa = 0.0 if model.closure is None else model.closure.kappa_of(model.tracer_names[n])
+            _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr,
+                      Gn[3 + n].ptr, r, s)
+        if model._has_flux_bcs:
+            prog = model.prognostic_fields()
+            arr = (C.POINTER(_lib.CFieldBcs) * len(prog))(*[
+                (C.pointer(f.boundary_conditions.c_struct(g)) if f.boundary_conditions is not None and f.boundary_conditions.has_flux()
+                 else C.POINTER(_lib.CFieldBcs)()) for f in prog])
+            _lib.call("ocn_apply_flux_bcs", g.cref, _lib.ptr_array([G.ptr for G in Gn]), _lib.ptr_array([f.ptr for f in prog]),
+                      _lib.i32_array([f.loc for f in prog]), arr, len(prog), s)
+        return
     _lib.call("ocn_compute_momentum_tendencies", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
               Gn[2].ptr, r, s)
     for n, c in enumerate(model.tracers):

@@ -1,0 +1,184 @@
+"""Model terms beyond WENO advection, mirroring the reference's constructors:
+
+  Centered(order=2)                               src/Advection/centered_reconstruction.jl:39-60 (the reference's default advection)
+  FPlane(f=...) / FPlane(rotation_rate, latitude) src/Coriolis/f_plane.jl:8-42
+  ScalarDiffusivity(ν=..., κ=...)                 src/TurbulenceClosures/turbulence_closure_implementations/scalar_diffusivity.jl
+  BuoyancyTracer(), SeawaterBuoyancy(...), LinearEquationOfState(...)
+                                                  src/BuoyancyFormulations/{buoyancy_tracer,seawater_buoyancy,linear_equation_of_state}.jl
+  FluxBoundaryCondition, ValueBoundaryCondition, GradientBoundaryCondition, FieldBoundaryConditions
+                                                  src/BoundaryConditions/{boundary_condition,field_boundary_conditions}.jl
+
+Only what the HIP kernels implement is accepted; everything else raises NotImplementedError.
+"""
+import math
+
+import numpy as np
+
+from . import _lib
+from .architectures import on_architecture
+
+
+class Centered:
+    """Centered(order=2)"""
+
+    def __init__(self, order=2, grid=None):
+        if order % 2 != 0:
+            raise ValueError("Centered reconstruction scheme is defined only for even orders")
+        if order != 2 or grid is not None:
+            raise NotImplementedError("the MI355X backend implements Centered(order=2) only")
+        self.order = order
+        self.buffer = 1  # required_halo_size
+
+    code = _lib.ADVECTION_CENTERED2
+
+    def __repr__(self):
+        return "Centered(order=2)"
+
+
+class FPlane:
+    """FPlane(; f, rotation_rate=Ω_Earth, latitude) (f_plane.jl:23-42)"""
+    OMEGA_EARTH = 7.292115e-5  # src/Coriolis/Coriolis.jl
+
+    def __init__(self, f=None, rotation_rate=None, latitude=None):
+        if f is not None and latitude is not None:
+            raise ValueError("Either both keywords rotation_rate and latitude must be specified, or only f must be specified.")
+        if f is None and latitude is None:
+            raise ValueError("Either both keywords rotation_rate and latitude must be specified, or only f must be specified.")
+        if f is None:
+            rotation_rate = self.OMEGA_EARTH if rotation_rate is None else rotation_rate
+            f = 2 * rotation_rate * math.sin(math.radians(latitude))
+        self.f = float(f)
+
+
+class ScalarDiffusivity:
+    """ScalarDiffusivity(; ν=0, κ=0): ExplicitTimeDiscretization, ThreeDimensionalFormulation, constant coefficients.
+    κ is a number (every tracer) or a dict {tracer name: κ}."""
+
+    def __init__(self, nu=0.0, kappa=0.0, time_discretization="Explicit", formulation="ThreeDimensional", **kw):
+        nu = kw.pop("ν", nu)
+        kappa = kw.pop("κ", kappa)
+        if kw:
+            raise TypeError(f"unexpected keyword arguments {sorted(kw)}")
+        if time_discretization != "Explicit":
+            raise NotImplementedError("VerticallyImplicitTimeDiscretization is not implemented")
+        if formulation != "ThreeDimensional":
+            raise NotImplementedError("only the ThreeDimensionalFormulation (isotropic) is implemented")
+        if callable(nu) or callable(kappa) or hasattr(nu, "shape"):
+            raise NotImplementedError("only constant ν, κ are implemented")
+        self.nu = float(nu)
+        self.kappa = kappa
+
+    def kappa_of(self, name):
+        if isinstance(self.kappa, dict):
+            if name not in self.kappa:
+                raise ValueError(f"no diffusivity κ given for tracer {name}")
+            return float(self.kappa[name])
+        return float(self.kappa)
+
+
+class LinearEquationOfState:
+    """linear_equation_of_state.jl:33-35"""
+
+    def __init__(self, thermal_expansion=1.67e-4, haline_contraction=7.80e-4):
+        self.thermal_expansion = float(thermal_expansion)
+        self.haline_contraction = float(haline_contraction)
+
+
+class BuoyancyTracer:
+    required_tracers = ("b",)
+
+
+class SeawaterBuoyancy:
+    """seawater_buoyancy.jl:88-108; g_Earth = 9.80665 (BuoyancyFormulations.jl)"""
+
+    def __init__(self, gravitational_acceleration=9.80665, equation_of_state=None, constant_temperature=None,
+                 constant_salinity=None):
+        eos = LinearEquationOfState() if equation_of_state is None else equation_of_state
+        if not isinstance(eos, LinearEquationOfState):
+            raise NotImplementedError("only LinearEquationOfState is implemented")
+        if constant_temperature is not None and constant_salinity is not None:
+            raise ValueError("constant_temperature and constant_salinity cannot both be set")
+        self.equation_of_state = eos
+        self.gravitational_acceleration = float(gravitational_acceleration)
+        self.constant_temperature = constant_temperature
+        self.constant_salinity = constant_salinity
+
+    @property
+    def required_tracers(self):
+        if self.constant_salinity is not None:
+            return ("T",)
+        if self.constant_temperature is not None:
+            return ("S",)
+        return ("T", "S")
+
+
+# --------------------------------------------------------------------------------------------------------
+# Boundary conditions
+# --------------------------------------------------------------------------------------------------------
+class BoundaryCondition:
+    """BoundaryCondition(classification, condition).  `condition` is a number or an (Nx, Ny) array; `coeff` restates the
+    ContinuousBoundaryFunction  f(x, y, t, c, p) = p * c  with field_dependencies = the field itself as
+    condition + coeff * c[i, j, boundary-adjacent cell] (include/ocn_hip.h: struct ocn_bc)."""
+
+    def __init__(self, kind, condition=0.0, coeff=0.0):
+        self.kind = kind
+        self.coeff = float(coeff)
+        self.values = None
+        self.value = 0.0
+        if np.isscalar(condition):
+            self.value = float(condition)
+        elif callable(condition):
+            raise NotImplementedError("function boundary conditions are not implemented (use a number, an array, or coeff=)")
+        else:
+            self.values = np.ascontiguousarray(np.asarray(condition, dtype=np.float64).T)  # stored [j, i]: x fastest
+        self._device_values = None
+
+    def c_struct(self, grid):
+        ptr = None
+        if self.values is not None:
+            if self.values.shape != (grid.Ny, grid.Nx):
+                raise ValueError(f"array boundary condition has shape {self.values.T.shape}, expected {(grid.Nx, grid.Ny)}")
+            if self._device_values is None:
+                self._device_values = on_architecture(grid.architecture, self.values)
+            ptr = self._device_values.data_ptr()
+        return _lib.CBc(self.kind, 0, self.value, self.coeff, ptr)
+
+
+def FluxBoundaryCondition(condition=0.0, coeff=0.0):
+    return BoundaryCondition(_lib.BC_FLUX, condition, coeff)
+
+
+def ValueBoundaryCondition(condition=0.0):
+    return BoundaryCondition(_lib.BC_VALUE, condition)
+
+
+def GradientBoundaryCondition(condition=0.0):
+    return BoundaryCondition(_lib.BC_GRADIENT, condition)
+
+
+class FieldBoundaryConditions:
+    """FieldBoundaryConditions(; west, east, south, north, bottom, top); unspecified sides keep the topology defaults
+    (field_boundary_conditions.jl:15-33).  The backend supports user conditions at bottom / top only."""
+    SIDES = ("west", "east", "south", "north", "bottom", "top")
+
+    def __init__(self, **sides):
+        for k in sides:
+            if k not in self.SIDES:
+                raise TypeError(f"unknown boundary {k!r}")
+        for k in ("west", "east", "south", "north"):
+            if sides.get(k) is not None:
+                raise NotImplementedError("only bottom / top boundary conditions are implemented (x, y are Periodic)")
+        self.sides = {k: sides.get(k) for k in self.SIDES}
+        self._c = None
+
+    def is_default(self):
+        return all(v is None for v in self.sides.values())
+
+    def has_flux(self):
+        return any(v is not None and v.kind == _lib.BC_FLUX for v in self.sides.values())
+
+    def c_struct(self, grid):
+        if self._c is None:
+            default = _lib.CBc(_lib.BC_DEFAULT, 0, 0.0, 0.0, None)
+            self._c = _lib.CFieldBcs(*[(default if self.sides[k] is None else self.sides[k].c_struct(grid)) for k in self.SIDES])
+        return self._c

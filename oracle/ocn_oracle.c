@@ -246,7 +246,19 @@ typedef struct {
     const ocn_grid *g;
     const double *u, *v, *w;
     lay Lu, Lv, Lw;
+    int scheme; /* 0: WENO(order=5) (the default of every entry point), 1: Centered(order=2) */
 } vel;
+#define OCN_ADV_WENO5 0
+#define OCN_ADV_CENTERED2 1
+
+/* Centered(order=2) interpolation: FT(0.5)*psi[n-1] + FT(0.5)*psi[n]; Centered{1} is a "low order" scheme and has no
+ * topology conditions (topologically_conditional_interpolation.jl:24-27 LOADV); Flat: the value itself
+ * (flat_advective_fluxes.jl:26-44). */
+static inline double c2_interp(const line *L, int topo, int center)
+{
+    if (topo == OCN_FLAT) return lval(L, center ? -1 : 0);
+    return 0.5 * lval(L, -1) + 0.5 * lval(L, 0);
+}
 
 static inline int gridN(const ocn_grid *g, int d) { return d == 0 ? g->Nx : d == 1 ? g->Ny : g->Nz; }
 static inline int gridT(const ocn_grid *g, int d) { return d == 0 ? g->tx : d == 1 ? g->ty : g->tz; }
@@ -277,6 +289,26 @@ static double mom_flux(const vel *V, int ca, int da, int a_center, int cb, int d
         if (a_center) q[da] += 1; /* symmetric_interpolate_*ᶜ: inner(..., i+1, ...) reconstruction_coefficients.jl:30-34 */
         A.p = fa + AT(*La, q[0], q[1], q[2]);
         A.k0 = q[2];
+    }
+    if (V->scheme == OCN_ADV_CENTERED2) {
+        /* centered_advective_fluxes.jl:7-17:  A(flux location) * sym(U) * sym(u), left-associated; the area is NOT
+         * inside the interpolation.  z-location of the flux: Face for Uw, Vw; Center otherwise (Az has no z metric). */
+        A.metric = 0;
+        double ua = c2_interp(&A, gridT(g, da), a_center);
+        line Bc;
+        Bc.g = g;
+        Bc.metric = 0;
+        Bc.zf = 0;
+        Bc.along_z = (db == 2);
+        Bc.s = strd(Lb, db);
+        int q[3] = {i, j, k};
+        if (b_center) q[db] += 1;
+        Bc.p = fb + AT(*Lb, q[0], q[1], q[2]);
+        Bc.k0 = q[2];
+        double ub = c2_interp(&Bc, gridT(g, db), b_center);
+        int zf = (cb == 2 && ca != 2);
+        double area = ca == 0 ? Ax_at(g, k, zf) : ca == 1 ? Ay_at(g, k, zf) : Az_at(g);
+        return (area * ua) * ub;
     }
     double ut = sym_interp(&A, ijk[da], gridN(g, da), gridT(g, da), a_center);
 
@@ -315,10 +347,11 @@ static double mom_flux(const vel *V, int ca, int da, int a_center, int cb, int d
  * term `nothing`: G = -div_Uu (momentum_advection_operators.jl:46-83).  Work range follows
  * launch!(..., :xyz; exclude_periphery=true) (kernel_launching.jl:113-161): Face-located in a
  * Bounded dim starts at 2. */
-void ocn_oracle_momentum_tendencies(const ocn_grid *g, const double *u, const double *v, const double *w, double *Gu,
-                                    double *Gv, double *Gw)
+void ocn_oracle_momentum_tendencies_scheme(const ocn_grid *g, int scheme, const double *u, const double *v, const double *w,
+                                           double *Gu, double *Gv, double *Gw)
 {
     vel V;
+    V.scheme = scheme;
     V.g = g;
     V.u = u;
     V.v = v;
@@ -356,6 +389,12 @@ void ocn_oracle_momentum_tendencies(const ocn_grid *g, const double *u, const do
             }
 }
 
+void ocn_oracle_momentum_tendencies(const ocn_grid *g, const double *u, const double *v, const double *w, double *Gu,
+                                    double *Gv, double *Gw)
+{
+    ocn_oracle_momentum_tendencies_scheme(g, OCN_ADV_WENO5, u, v, w, Gu, Gv, Gw);
+}
+
 /* K4: tracer tendency  Gc = -div_Uc (tracer_advection_operators.jl:30-34), fluxes
  * upwind_biased_advective_fluxes.jl:99-121:  Ax * u[i,j,k] * cR  (left-assoc). */
 static double tracer_flux(const vel *V, const double *c, const lay *Lc, int d, int i, int j, int k)
@@ -374,14 +413,17 @@ static double tracer_flux(const vel *V, const double *c, const lay *Lc, int d, i
     B.p = c + AT(*Lc, i, j, k);
     B.k0 = k;
     int ijk[3] = {i, j, k};
-    double cr = bias_interp(&B, ijk[d], gridN(g, d), gridT(g, d), 0, ut > 0);
     double area = d == 0 ? Ax_at(g, k, 0) : d == 1 ? Ay_at(g, k, 0) : Az_at(g);
+    if (V->scheme == OCN_ADV_CENTERED2) /* centered_advective_fluxes.jl:23-25: Ax_q(U) * sym(c) */
+        return (area * ut) * c2_interp(&B, gridT(g, d), 0);
+    double cr = bias_interp(&B, ijk[d], gridN(g, d), gridT(g, d), 0, ut > 0);
     return (area * ut) * cr;
 }
-void ocn_oracle_tracer_tendency(const ocn_grid *g, const double *u, const double *v, const double *w, const double *c,
-                                double *Gc)
+void ocn_oracle_tracer_tendency_scheme(const ocn_grid *g, int scheme, const double *u, const double *v, const double *w,
+                                       const double *c, double *Gc)
 {
     vel V;
+    V.scheme = scheme;
     V.g = g;
     V.u = u;
     V.v = v;
@@ -400,6 +442,319 @@ void ocn_oracle_tracer_tendency(const ocn_grid *g, const double *u, const double
                 double rV = 1 / V_at(g, k, 0);
                 Gc[AT(Lc, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
             }
+}
+
+void ocn_oracle_tracer_tendency(const ocn_grid *g, const double *u, const double *v, const double *w, const double *c,
+                                double *Gc)
+{
+    ocn_oracle_tracer_tendency_scheme(g, OCN_ADV_WENO5, u, v, w, c, Gc);
+}
+
+/* =====================================================================================
+ * the non-advective terms of u/v/w_velocity_tendency and tracer_tendency
+ * (nonhydrostatic_tendency_kernel_functions.jl:47-259), hydrostatic pressure anomaly, flux /
+ * value / gradient boundary conditions.
+ * ===================================================================================== */
+typedef struct {
+    int32_t coriolis; /* 0 nothing, 1 FPlane (Coriolis/f_plane.jl:44-46) */
+    int32_t closure;  /* 0 nothing, 1 ScalarDiffusivity(ν, κ): ThreeDimensionalFormulation, ExplicitTimeDiscretization, constants */
+    int32_t buoyancy; /* 0 nothing, 1 BuoyancyTracer, 2 SeawaterBuoyancy(LinearEquationOfState) with T and S,
+                         3 ... with T only (constant_salinity), 4 ... with S only (constant_temperature) */
+    int32_t _pad;
+    double f;            /* FPlane.f */
+    double nu;           /* ScalarDiffusivity.ν */
+    double g, alpha, beta; /* gravitational_acceleration, thermal_expansion, haline_contraction */
+} ocn_physics;
+
+/* inactive_cell (Grids/inactive_node.jl:35-95): outside the domain in a Bounded direction */
+static inline int inactive_cell(const ocn_grid *g, int i, int j, int k)
+{
+    int r = 0;
+    if (g->tx == OCN_BOUNDED) r |= (i < 1) | (i > g->Nx);
+    if (g->ty == OCN_BOUNDED) r |= (j < 1) | (j > g->Ny);
+    if (g->tz == OCN_BOUNDED) r |= (k < 1) | (k > g->Nz);
+    return r;
+}
+/* not_peripheral_node at (c,f,c) and (f,c,c) (inactive_node.jl:145-149) as 0/1 */
+static inline double active_cfc(const ocn_grid *g, int i, int j, int k) { return !(inactive_cell(g, i, j, k) | inactive_cell(g, i, j - 1, k)); }
+static inline double active_fcc(const ocn_grid *g, int i, int j, int k) { return !(inactive_cell(g, i, j, k) | inactive_cell(g, i - 1, j, k)); }
+
+/* ℑxyᶠᶜᵃ(q) = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ q) (interpolation_operators.jl:8-26,46); along a Flat dim the interpolation is the identity (:103-110) */
+static inline double ixy_fc(const ocn_grid *g, const double *q, const lay *L, int i, int j, int k)
+{
+#define IXF(jj) (g->tx == OCN_FLAT ? q[AT(*L, i, jj, k)] : 0.5 * (q[AT(*L, i - 1, jj, k)] + q[AT(*L, i, jj, k)]))
+    if (g->ty == OCN_FLAT) return IXF(j);
+    return 0.5 * (IXF(j) + IXF(j + 1));
+#undef IXF
+}
+static inline double ixy_fc_active(const ocn_grid *g, int i, int j, int k)
+{
+#define IXF(jj) (g->tx == OCN_FLAT ? active_cfc(g, i, jj, k) : 0.5 * (active_cfc(g, i - 1, jj, k) + active_cfc(g, i, jj, k)))
+    if (g->ty == OCN_FLAT) return IXF(j);
+    return 0.5 * (IXF(j) + IXF(j + 1));
+#undef IXF
+}
+/* ℑxyᶜᶠᵃ(q) = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ q) */
+static inline double ixy_cf(const ocn_grid *g, const double *q, const lay *L, int i, int j, int k)
+{
+#define IXC(jj) (g->tx == OCN_FLAT ? q[AT(*L, i, jj, k)] : 0.5 * (q[AT(*L, i, jj, k)] + q[AT(*L, i + 1, jj, k)]))
+    if (g->ty == OCN_FLAT) return IXC(j);
+    return 0.5 * (IXC(j - 1) + IXC(j));
+#undef IXC
+}
+static inline double ixy_cf_active(const ocn_grid *g, int i, int j, int k)
+{
+#define IXC(jj) (g->tx == OCN_FLAT ? active_fcc(g, i, jj, k) : 0.5 * (active_fcc(g, i, jj, k) + active_fcc(g, i + 1, jj, k)))
+    if (g->ty == OCN_FLAT) return IXC(j);
+    return 0.5 * (IXC(j - 1) + IXC(j));
+#undef IXC
+}
+
+/* buoyancy_perturbationᶜᶜᶜ (buoyancy_tracer.jl:12, linear_equation_of_state.jl:58-66) */
+static inline double buoyancy_ccc(const ocn_physics *ph, const double *T, const double *S, ptrdiff_t a)
+{
+    switch (ph->buoyancy) {
+        case 1: return T[a];
+        case 2: return ph->g * (ph->alpha * T[a] - ph->beta * S[a]);
+        case 3: return ph->g * ph->alpha * T[a];
+        case 4: return -ph->g * ph->beta * S[a];
+        default: return 0.0;
+    }
+}
+
+/* _update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-20) over p_kernel_parameters (:45-53):
+ * i in 0:Nx+1, j in 0:Ny+1 (1:N along Flat).  z_dot_g_bᶜᶜᶠ = ĝ_z * ℑzᵃᵃᶠ(b), ĝ_z = 1 (g_dot_b.jl:3, buoyancy_force.jl:39).
+ * Nothing happens on a z-Flat grid (:26). */
+void ocn_oracle_update_hydrostatic_pressure(const ocn_grid *g, const ocn_physics *ph, const double *T, const double *S,
+                                            double *pHY)
+{
+    if (g->tz == OCN_FLAT || ph->buoyancy == 0) return;
+    lay L = mklay(g, 0, 0, 0);
+    const int i0 = g->tx == OCN_FLAT ? 1 : 0, i1 = g->tx == OCN_FLAT ? g->Nx : g->Nx + 1;
+    const int j0 = g->ty == OCN_FLAT ? 1 : 0, j1 = g->ty == OCN_FLAT ? g->Ny : g->Ny + 1;
+    const int Nz = g->Nz;
+#pragma omp parallel for schedule(static)
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+#define ZB(k) (1 * (0.5 * (buoyancy_ccc(ph, T, S, AT(L, i, j, (k)-1)) + buoyancy_ccc(ph, T, S, AT(L, i, j, (k))))))
+            pHY[AT(L, i, j, Nz)] = -ZB(Nz + 1) * dzf_at(g, Nz + 1);
+            for (int k = Nz - 1; k >= 1; --k) pHY[AT(L, i, j, k)] = pHY[AT(L, i, j, k + 1)] - ZB(k + 1) * dzf_at(g, k + 1);
+#undef ZB
+        }
+}
+
+/* Adds, to Gu/Gv/Gw that already hold the advective tendency, the remaining terms in the reference's order
+ *   G = ((((-div_𝐯u - 0) + x_dot_g_b) - x_f_cross_U) - ∂x pHY′) - ∂ⱼτ₁ⱼ      (…kernel_functions.jl:66-75, 128-137, 193-200)
+ * x_dot_g_b = y_dot_g_b = 0 for the default NegativeZDirection gravity (g_dot_b.jl:7-8); in Gw the buoyancy term
+ * is z_dot_g_b only when there is no separate hydrostatic pressure (pHY == NULL) (…kernel_functions.jl:141-143).
+ * Same index ranges as the advective kernels (Face-located in Bounded starts at 2). */
+void ocn_oracle_momentum_extra_tendencies(const ocn_grid *g, const ocn_physics *ph, const double *u, const double *v,
+                                          const double *w, const double *T, const double *S, const double *pHY, double *Gu,
+                                          double *Gv, double *Gw)
+{
+    const lay Lu = mklay(g, 1, 0, 0), Lv = mklay(g, 0, 1, 0), Lw = mklay(g, 0, 0, 1), Lc = mklay(g, 0, 0, 0);
+    const int Nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
+    const int ox = (g->tx == OCN_BOUNDED && Nx > 1), oy = (g->ty == OCN_BOUNDED && Ny > 1), oz = (g->tz == OCN_BOUNDED && Nz > 1);
+    const int fx = DFLAT(g, 0), fy = DFLAT(g, 1), fz = DFLAT(g, 2);
+    const double dx = g->dx, dy = g->dy, nu = ph->nu;
+#define U_(i, j, k) u[AT(Lu, i, j, k)]
+#define V_(i, j, k) v[AT(Lv, i, j, k)]
+#define W_(i, j, k) w[AT(Lw, i, j, k)]
+    /* derivative operators (derivative_operators.jl:20-30); δ along Flat = 0 */
+#define DXU_C(i, j, k) (fx ? 0.0 : (U_((i) + 1, j, k) - U_(i, j, k)) / dx)                /* ∂xᶜᶜᶜ u */
+#define DYV_C(i, j, k) (fy ? 0.0 : (V_(i, (j) + 1, k) - V_(i, j, k)) / dy)                /* ∂yᶜᶜᶜ v */
+#define DZW_C(i, j, k) (fz ? 0.0 : (W_(i, j, (k) + 1) - W_(i, j, k)) / dzc_at(g, k))      /* ∂zᶜᶜᶜ w */
+#define DYU_FF(i, j, k) (fy ? 0.0 : (U_(i, j, k) - U_(i, (j)-1, k)) / dy)                 /* ∂yᶠᶠᶜ u */
+#define DXV_FF(i, j, k) (fx ? 0.0 : (V_(i, j, k) - V_((i)-1, j, k)) / dx)                 /* ∂xᶠᶠᶜ v */
+#define DZU_FF(i, j, k) (fz ? 0.0 : (U_(i, j, k) - U_(i, j, (k)-1)) / dzf_at(g, k))       /* ∂zᶠᶜᶠ u */
+#define DXW_FF(i, j, k) (fx ? 0.0 : (W_(i, j, k) - W_((i)-1, j, k)) / dx)                 /* ∂xᶠᶜᶠ w */
+#define DZV_FF(i, j, k) (fz ? 0.0 : (V_(i, j, k) - V_(i, j, (k)-1)) / dzf_at(g, k))       /* ∂zᶜᶠᶠ v */
+#define DYW_FF(i, j, k) (fy ? 0.0 : (W_(i, j, k) - W_(i, (j)-1, k)) / dy)                 /* ∂yᶜᶠᶠ w */
+    /* viscous fluxes, isotropic (abstract_scalar_diffusivity_closure.jl:163-175):  -2 * (ν * Σᵢⱼ), Σ₁₂ = 0.5*(∂y u + ∂x v)
+     * (velocity_tracer_gradients.jl:15-27) */
+#define T11(i, j, k) (-2 * (nu * DXU_C(i, j, k)))
+#define T22(i, j, k) (-2 * (nu * DYV_C(i, j, k)))
+#define T33(i, j, k) (-2 * (nu * DZW_C(i, j, k)))
+#define T12(i, j, k) (-2 * (nu * (0.5 * (DYU_FF(i, j, k) + DXV_FF(i, j, k)))))
+#define T13(i, j, k) (-2 * (nu * (0.5 * (DZU_FF(i, j, k) + DXW_FF(i, j, k)))))
+#define T23(i, j, k) (-2 * (nu * (0.5 * (DZV_FF(i, j, k) + DYW_FF(i, j, k)))))
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= Nz; ++k)
+        for (int j = 1; j <= Ny; ++j)
+            for (int i = 1; i <= Nx; ++i) {
+                const double Axc = Ax_at(g, k, 0), Ayc = Ay_at(g, k, 0), Az = Az_at(g);
+                if (i >= 1 + ox) {
+                    double G = Gu[AT(Lu, i, j, k)];
+                    if (ph->buoyancy) G = G + 0.0; /* x_dot_g_b = 0 */
+                    if (ph->coriolis) { /* x_f_cross_U = -f * active_weighted_ℑxyᶠᶜᶜ(v) (interpolation_operators.jl:127-131) */
+                        double an = ixy_fc_active(g, i, j, k);
+                        double vi = (an == 0) ? 0.0 : ixy_fc(g, v, &Lv, i, j, k) / an;
+                        G = G - (-ph->f * vi);
+                    }
+                    if (pHY) G = G - (fx ? 0.0 : (pHY[AT(Lc, i, j, k)] - pHY[AT(Lc, i - 1, j, k)]) / dx); /* ∂xᶠᶜᶜ pHY′ */
+                    if (ph->closure) { /* ∂ⱼ_τ₁ⱼ (closure_kernel_operators.jl:27-32) */
+                        double dxF = fx ? 0.0 : Axc * T11(i, j, k) - Axc * T11(i - 1, j, k);          /* δxᶠᵃᵃ Ax_qᶜᶜᶜ */
+                        double dyF = fy ? 0.0 : Ayc * T12(i, j + 1, k) - Ayc * T12(i, j, k);          /* δyᵃᶜᵃ Ay_qᶠᶠᶜ */
+                        double dzF = fz ? 0.0 : Az * T13(i, j, k + 1) - Az * T13(i, j, k);            /* δzᵃᵃᶜ Az_qᶠᶜᶠ */
+                        G = G - 1 / V_at(g, k, 0) * ((dxF + dyF) + dzF);
+                    }
+                    Gu[AT(Lu, i, j, k)] = G;
+                }
+                if (j >= 1 + oy) {
+                    double G = Gv[AT(Lv, i, j, k)];
+                    if (ph->buoyancy) G = G + 0.0;
+                    if (ph->coriolis) { /* y_f_cross_U = f * active_weighted_ℑxyᶜᶠᶜ(u) */
+                        double an = ixy_cf_active(g, i, j, k);
+                        double ui = (an == 0) ? 0.0 : ixy_cf(g, u, &Lu, i, j, k) / an;
+                        G = G - ph->f * ui;
+                    }
+                    if (pHY) G = G - (fy ? 0.0 : (pHY[AT(Lc, i, j, k)] - pHY[AT(Lc, i, j - 1, k)]) / dy);
+                    if (ph->closure) { /* ∂ⱼ_τ₂ⱼ (:34-39) */
+                        double dxF = fx ? 0.0 : Axc * T12(i + 1, j, k) - Axc * T12(i, j, k);          /* δxᶜᵃᵃ Ax_qᶠᶠᶜ */
+                        double dyF = fy ? 0.0 : Ayc * T22(i, j, k) - Ayc * T22(i, j - 1, k);          /* δyᵃᶠᵃ Ay_qᶜᶜᶜ */
+                        double dzF = fz ? 0.0 : Az * T23(i, j, k + 1) - Az * T23(i, j, k);            /* δzᵃᵃᶜ Az_qᶜᶠᶠ */
+                        G = G - 1 / V_at(g, k, 0) * ((dxF + dyF) + dzF);
+                    }
+                    Gv[AT(Lv, i, j, k)] = G;
+                }
+                if (k >= 1 + oz) {
+                    double G = Gw[AT(Lw, i, j, k)];
+                    if (ph->buoyancy) { /* maybe_z_dot_g_bᶜᶜᶠ */
+                        double zb = 0.0;
+                        if (!pHY) zb = fz ? buoyancy_ccc(ph, T, S, AT(Lc, i, j, k))
+                                          : 1 * (0.5 * (buoyancy_ccc(ph, T, S, AT(Lc, i, j, k - 1)) + buoyancy_ccc(ph, T, S, AT(Lc, i, j, k))));
+                        G = G + zb;
+                    }
+                    if (ph->coriolis) G = G - 0.0; /* z_f_cross_U = 0 (f_plane.jl:46) */
+                    if (ph->closure) { /* ∂ⱼ_τ₃ⱼ (:41-46): areas and volume at (c,c,f) */
+                        const double Axf = Ax_at(g, k, 1), Ayf = Ay_at(g, k, 1);
+                        double dxF = fx ? 0.0 : Axf * T13(i + 1, j, k) - Axf * T13(i, j, k);          /* δxᶜᵃᵃ Ax_qᶠᶜᶠ */
+                        double dyF = fy ? 0.0 : Ayf * T23(i, j + 1, k) - Ayf * T23(i, j, k);          /* δyᵃᶜᵃ Ay_qᶜᶠᶠ */
+                        double dzF = fz ? 0.0 : Az * T33(i, j, k) - Az * T33(i, j, k - 1);            /* δzᵃᵃᶠ Az_qᶜᶜᶜ */
+                        G = G - 1 / V_at(g, k, 1) * ((dxF + dyF) + dzF);
+                    }
+                    Gw[AT(Lw, i, j, k)] = G;
+                }
+            }
+#undef T11
+#undef T22
+#undef T33
+#undef T12
+#undef T13
+#undef T23
+}
+
+/* Gc <- Gc - ∇_dot_qᶜ (closure_kernel_operators.jl:48-53) with diffusive_flux_x = -(κ * ∂xᶠᶜᶜ c)
+ * (abstract_scalar_diffusivity_closure.jl:221-223) */
+void ocn_oracle_tracer_diffusion(const ocn_grid *g, double kappa, const double *c, double *Gc)
+{
+    const lay L = mklay(g, 0, 0, 0);
+    const int fx = DFLAT(g, 0), fy = DFLAT(g, 1), fz = DFLAT(g, 2);
+#define C_(i, j, k) c[AT(L, i, j, k)]
+#define QX(i, j, k) (-(kappa * ((C_(i, j, k) - C_((i)-1, j, k)) / g->dx)))
+#define QY(i, j, k) (-(kappa * ((C_(i, j, k) - C_(i, (j)-1, k)) / g->dy)))
+#define QZ(i, j, k) (-(kappa * ((C_(i, j, k) - C_(i, j, (k)-1)) / dzf_at(g, k))))
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                const double Ax = Ax_at(g, k, 0), Ay = Ay_at(g, k, 0), Az = Az_at(g);
+                double dxF = fx ? 0.0 : Ax * QX(i + 1, j, k) - Ax * QX(i, j, k);
+                double dyF = fy ? 0.0 : Ay * QY(i, j + 1, k) - Ay * QY(i, j, k);
+                double dzF = fz ? 0.0 : Az * QZ(i, j, k + 1) - Az * QZ(i, j, k);
+                Gc[AT(L, i, j, k)] = Gc[AT(L, i, j, k)] - 1 / V_at(g, k, 0) * ((dxF + dyF) + dzF);
+            }
+#undef C_
+#undef QX
+#undef QY
+#undef QZ
+}
+
+/* Boundary conditions on one side.  kind: 0 default (Periodic / no-flux / impenetrable), 1 Flux, 2 Value, 3 Gradient.
+ * The condition is  value + coeff * c[interior cell next to the boundary]  (coeff = 0 for a plain number; the
+ * coeff form restates a ContinuousBoundaryFunction  f(x, y, t, c, p) = p * c  with field_dependencies = the field itself,
+ * whose argument is c[i, j, Nz] (continuous_boundary_function.jl:107-115, 73-74)), or values[(i-1) + n1*(j-1)]
+ * when `values` != NULL (an array boundary condition, boundary_condition.jl getbc for AbstractArray). */
+typedef struct {
+    int32_t kind, _pad;
+    double value, coeff;
+    const double *values;
+} ocn_bc;
+
+static inline double getbc(const ocn_bc *bc, int a, int b, int n1, double c_int)
+{
+    if (bc->values) return bc->values[(a - 1) + (ptrdiff_t)n1 * (b - 1)];
+    if (bc->coeff != 0.0) return bc->value + bc->coeff * c_int;
+    return bc->value;
+}
+
+/* apply_x/y/z_bcs! (apply_flux_bcs.jl:38-160) along `dir` for a field at `loc`:
+ *   left:   G[1] += flux * A(1, flipped loc) / V(1)          right:  G[N] -= flux * A(N+1, flipped loc) / V(N)  */
+void ocn_oracle_apply_flux_bcs(const ocn_grid *g, int loc, int dir, const ocn_bc *left, const ocn_bc *right, const double *c,
+                               double *G)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int N[3] = {g->Nx, g->Ny, g->Nz};
+    int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    const int zf = (loc >> 2) & 1;
+    for (int b = 1; b <= N[d2]; ++b)
+        for (int a = 1; a <= N[d1]; ++a) {
+            int q[3];
+            q[d1] = a;
+            q[d2] = b;
+            for (int side = 0; side < 2; ++side) {
+                const ocn_bc *bc = side ? right : left;
+                if (!bc || bc->kind != 1) continue;
+                q[dir] = side ? N[dir] : 1;
+                const int kk = q[2];
+                ptrdiff_t o = AT(L, q[0], q[1], q[2]);
+                double area; /* area of the boundary face, with the location flipped along dir */
+                if (dir == 0) area = g->dy * dz_at(g, kk, zf);
+                else if (dir == 1) area = g->dx * dz_at(g, kk, zf);
+                else area = Az_at(g);
+                double vol = V_at(g, kk, zf);
+                double flux = getbc(bc, a, b, N[d1], c[o]);
+                if (side) G[o] -= flux * area / vol;
+                else G[o] += flux * area / vol;
+            }
+        }
+}
+
+/* Value / Gradient halo fill on one pair of sides (fill_halo_regions_value_gradient.jl:5-103): the first halo cell is the
+ * linear extrapolation  c[0] = c[1] + ∇c * (-Δ),  c[N+1] = c[N] + ∇c * Δ,  Δ = spacing at the boundary face (location flipped
+ * along dir); Value: ∇c = (c¹ - v)/(Δ/2) (left), (v - cᴺ)/(Δ/2) (right).  Sides with kind 0/1 get the no-flux fill. */
+void ocn_oracle_fill_value_gradient(const ocn_grid *g, int loc, int dir, const ocn_bc *left, const ocn_bc *right, double *c)
+{
+    lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
+    int N[3] = {g->Nx, g->Ny, g->Nz};
+    int d1 = dir == 0 ? 1 : 0, d2 = dir == 2 ? 1 : 2;
+    const int face = (loc >> dir) & 1;
+    for (int b = 1; b <= N[d2]; ++b)
+        for (int a = 1; a <= N[d1]; ++a) {
+            int q[3], h[3];
+            q[d1] = h[d1] = a;
+            q[d2] = h[d2] = b;
+            for (int side = 0; side < 2; ++side) {
+                const ocn_bc *bc = side ? right : left;
+                q[dir] = side ? N[dir] : 1;
+                h[dir] = side ? N[dir] + 1 : 0;
+                ptrdiff_t oi = AT(L, q[0], q[1], q[2]), oh = AT(L, h[0], h[1], h[2]);
+                if (!bc || bc->kind < 2) {
+                    c[oh] = c[oi];
+                    continue;
+                }
+                const int ib = side ? N[dir] + 1 : 1; /* boundary index iᴮ */
+                double D;
+                if (dir == 0) D = g->dx;
+                else if (dir == 1) D = g->dy;
+                else D = face ? dzc_at(g, ib) : dzf_at(g, ib); /* flipped location */
+                double bv = getbc(bc, a, b, N[d1], c[oi]);
+                double grad;
+                if (bc->kind == 3) grad = bv;
+                else grad = side ? (bv - c[oi]) / (D / 2) : (c[oi] - bv) / (D / 2);
+                c[oh] = side ? c[oi] + grad * D : c[oi] + grad * (-D);
+            }
+        }
 }
 
 /* =====================================================================================

@@ -177,17 +177,62 @@ class Grid:
 # Halo fills: src/BoundaryConditions/fill_halo_regions.jl:50-196 (ordering: Flux/Open-"nothing"
 # first, Periodic last), field_boundary_conditions.jl:15-33 (defaults)
 # --------------------------------------------------------------------------------------
-def fill_halo_regions(g, a, loc, fill_boundary_normal_velocities=True):
+class _CBC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("value", C.c_double), ("coeff", C.c_double), ("values", C.c_void_p)]
+
+
+class BC:
+    """One side's boundary condition: kind in {"flux", "value", "gradient"}; the condition is a number, a 2-D array over
+    the boundary's interior extent, or `value + coeff * c[interior neighbour]` (see ocn_bc in ocn_oracle.c)."""
+    KINDS = {"default": 0, "flux": 1, "value": 2, "gradient": 3}
+
+    def __init__(self, kind, value=0.0, coeff=0.0, values=None):
+        self.kind = self.KINDS[kind]
+        self.value, self.coeff = float(value), float(coeff)
+        self.values = None if values is None else np.asfortranarray(values, dtype=np.float64)
+
+    def c(self):
+        return _CBC(self.kind, 0, self.value, self.coeff, None if self.values is None else self.values.ctypes.data)
+
+
+def FluxBoundaryCondition(v=0.0, **kw):
+    return BC("flux", v, **kw) if np.isscalar(v) else BC("flux", values=v)
+
+
+def ValueBoundaryCondition(v=0.0):
+    return BC("value", v) if np.isscalar(v) else BC("value", values=v)
+
+
+def GradientBoundaryCondition(v=0.0):
+    return BC("gradient", v) if np.isscalar(v) else BC("gradient", values=v)
+
+
+_SIDES = (("west", "east"), ("south", "north"), ("bottom", "top"))
+
+
+def _cbc_ref(bc):
+    return None if bc is None else C.byref(bc.c())
+
+
+def fill_halo_regions(g, a, loc, fill_boundary_normal_velocities=True, bcs=None):
+    """bcs: {"top": BC, "bottom": BC, ...} user boundary conditions of this field (sides not named keep the defaults)."""
     L = lib()
     N = (g.Nx, g.Ny, g.Nz)
     H = (g.Hx, g.Hy, g.Hz)
+    bcs = bcs or {}
     if fill_boundary_normal_velocities:
         for d in range(3):  # fill_open_boundary_regions! (fill_halo_regions_open.jl:9-34)
             if g.topo[d] == BOUNDED and (loc >> d) & 1 and loc in (1, 2, 4):
                 L.ocn_oracle_fill_open(g.cref, loc, _p(a), d)
     for d in range(3):  # non-periodic first
         if g.topo[d] == BOUNDED and not ((loc >> d) & 1):
-            L.ocn_oracle_fill_flux(g.cref, loc, _p(a), d)
+            lo, hi = bcs.get(_SIDES[d][0]), bcs.get(_SIDES[d][1])
+            if (lo is not None and lo.kind >= 2) or (hi is not None and hi.kind >= 2):
+                clo, chi = (None if lo is None else lo.c()), (None if hi is None else hi.c())
+                L.ocn_oracle_fill_value_gradient(g.cref, loc, d, None if clo is None else C.byref(clo),
+                                                 None if chi is None else C.byref(chi), _p(a))
+            else:
+                L.ocn_oracle_fill_flux(g.cref, loc, _p(a), d)
     sx, sy, sz = a.shape
     for d in range(3):
         if g.topo[d] == PERIODIC:
@@ -197,12 +242,64 @@ def fill_halo_regions(g, a, loc, fill_boundary_normal_velocities=True):
 # --------------------------------------------------------------------------------------
 # Kernels (thin wrappers)
 # --------------------------------------------------------------------------------------
-def momentum_tendencies(g, u, v, w, Gu, Gv, Gw):
-    lib().ocn_oracle_momentum_tendencies(g.cref, _p(u), _p(v), _p(w), _p(Gu), _p(Gv), _p(Gw))
+ADV_WENO5, ADV_CENTERED2 = 0, 1
 
 
-def tracer_tendency(g, u, v, w, c, Gc):
-    lib().ocn_oracle_tracer_tendency(g.cref, _p(u), _p(v), _p(w), _p(c), _p(Gc))
+def momentum_tendencies(g, u, v, w, Gu, Gv, Gw, scheme=ADV_WENO5):
+    lib().ocn_oracle_momentum_tendencies_scheme(g.cref, scheme, _p(u), _p(v), _p(w), _p(Gu), _p(Gv), _p(Gw))
+
+
+def tracer_tendency(g, u, v, w, c, Gc, scheme=ADV_WENO5):
+    lib().ocn_oracle_tracer_tendency_scheme(g.cref, scheme, _p(u), _p(v), _p(w), _p(c), _p(Gc))
+
+
+class _CPhysics(C.Structure):
+    _fields_ = [("coriolis", C.c_int32), ("closure", C.c_int32), ("buoyancy", C.c_int32), ("_pad", C.c_int32),
+                ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double)]
+
+
+class Physics:
+    """coriolis = FPlane(f); closure = ScalarDiffusivity(ν, κ); buoyancy = "BuoyancyTracer" or
+    ("SeawaterBuoyancy", g, α, β[, "T" | "S"]) with a LinearEquationOfState."""
+
+    def __init__(self, f=None, nu=None, kappa=None, buoyancy=None):
+        self.f, self.nu, self.kappa = f, nu, kappa
+        self.buoyancy = buoyancy
+        kind, gg, al, be = 0, 0.0, 0.0, 0.0
+        if buoyancy == "BuoyancyTracer":
+            kind = 1
+        elif buoyancy is not None:
+            _, gg, al, be = buoyancy[:4]
+            kind = {None: 2, "T": 3, "S": 4}[buoyancy[4] if len(buoyancy) > 4 else None]
+        self.c = _CPhysics(0 if f is None else 1, 0 if nu is None else 1, kind, 0, 0.0 if f is None else float(f),
+                           0.0 if nu is None else float(nu), float(gg), float(al), float(be))
+
+    @property
+    def ref(self):
+        return C.byref(self.c)
+
+
+def update_hydrostatic_pressure(g, ph, T, S, pHY):
+    lib().ocn_oracle_update_hydrostatic_pressure(g.cref, ph.ref, None if T is None else _p(T), None if S is None else _p(S), _p(pHY))
+
+
+def momentum_extra_tendencies(g, ph, u, v, w, T, S, pHY, Gu, Gv, Gw):
+    lib().ocn_oracle_momentum_extra_tendencies(g.cref, ph.ref, _p(u), _p(v), _p(w), None if T is None else _p(T),
+                                               None if S is None else _p(S), None if pHY is None else _p(pHY), _p(Gu), _p(Gv), _p(Gw))
+
+
+def tracer_diffusion(g, kappa, c, Gc):
+    lib().ocn_oracle_tracer_diffusion(g.cref, C.c_double(kappa), _p(c), _p(Gc))
+
+
+def apply_flux_bcs(g, loc, c, G, bcs):
+    """apply_x_bcs!, apply_y_bcs!, apply_z_bcs! of one field (apply_flux_bcs.jl:13-15)"""
+    for d in range(3):
+        lo, hi = bcs.get(_SIDES[d][0]), bcs.get(_SIDES[d][1])
+        if (lo is not None and lo.kind == 1) or (hi is not None and hi.kind == 1):
+            clo, chi = (None if lo is None else lo.c()), (None if hi is None else hi.c())
+            lib().ocn_oracle_apply_flux_bcs(g.cref, loc, d, None if clo is None else C.byref(clo),
+                                            None if chi is None else C.byref(chi), _p(c), _p(G))
 
 
 def rk3_substep(g, loc, U, Gn, Gm, dt, gamma, zeta):
@@ -367,11 +464,26 @@ class NonhydrostaticModel:
     (set_nonhydrostatic_model.jl:33-60), RK3 `time_step!` (runge_kutta_3.jl:77-151) and
     QAB2 `time_step!` (quasi_adams_bashforth_2.jl:74-115)."""
 
-    def __init__(self, grid, tracers=(), timestepper="RungeKutta3", workers=1):
+    def __init__(self, grid, tracers=(), timestepper="RungeKutta3", workers=1, advection="WENO5", coriolis_f=None,
+                 closure=None, buoyancy=None, boundary_conditions=None, hydrostatic_pressure_anomaly="default"):
+        """advection: "WENO5" | "Centered2"; closure = (ν, {tracer: κ} or κ); buoyancy as in Physics;
+        boundary_conditions = {"u": {"top": BC, ...}, ...} (§8(f) rank 1)."""
         g = self.grid = grid
+        self.scheme = {"WENO5": ADV_WENO5, "Centered2": ADV_CENTERED2}[advection]
+        need = 3 if self.scheme == ADV_WENO5 else 1
         for d, (N, H) in enumerate(((g.Nx, g.Hx), (g.Ny, g.Hy), (g.Nz, g.Hz))):
             if g.topo[d] != FLAT:
-                assert H >= 3 and N >= 3, "WENO5 needs halo >= 3 (nonhydrostatic_model.jl:183,243-257) and N >= 3 (adapt_advection_order)"
+                assert H >= need and N >= need, "WENO5 needs halo >= 3 (nonhydrostatic_model.jl:183,243-257) and N >= 3 (adapt_advection_order)"
+        nu = kappa = None
+        if closure is not None:
+            nu, kappa = closure
+            if not isinstance(kappa, dict):
+                kappa = {n: kappa for n in tracers}
+        self.kappa = kappa
+        self.physics = Physics(f=coriolis_f, nu=nu, kappa=kappa, buoyancy=buoyancy)
+        self.bcs = boundary_conditions or {}
+        # nonhydrostatic_model.jl:143-158: a separate hydrostatic pressure anomaly exists iff buoyancy is not nothing
+        self.pHY = g.zeros(LOC_C) if (buoyancy is not None and hydrostatic_pressure_anomaly == "default") else None
         self.u, self.v, self.w = g.zeros(LOC_U), g.zeros(LOC_V), g.zeros(LOC_W)
         self.p = g.zeros(LOC_C)
         self.tracer_names = tuple(tracers)
@@ -397,23 +509,48 @@ class NonhydrostaticModel:
     def fields(self):
         return [self.u, self.v, self.w] + self.tracers
 
+    @property
+    def names(self):
+        return ("u", "v", "w") + self.tracer_names
+
+    def _buoyancy_tracers(self):
+        b = self.physics.buoyancy
+        t = dict(zip(self.tracer_names, self.tracers))
+        if b is None:
+            return None, None
+        if b == "BuoyancyTracer":
+            return t["b"], None
+        return t.get("T"), t.get("S")
+
     def update_state(self, compute_tendencies=True):
         g = self.grid
-        for f, l in zip(self.fields, self.locs):  # update_nonhydrostatic_model_state.jl:34-35
-            fill_halo_regions(g, f, l, fill_boundary_normal_velocities=False)
+        for f, l, n in zip(self.fields, self.locs, self.names):  # update_nonhydrostatic_model_state.jl:34-35
+            fill_halo_regions(g, f, l, fill_boundary_normal_velocities=False, bcs=self.bcs.get(n))
+        if self.pHY is not None:  # compute_auxiliaries! (:59-70)
+            T, S = self._buoyancy_tracers()
+            update_hydrostatic_pressure(g, self.physics, T, S, self.pHY)
         if compute_tendencies:
             self.compute_tendencies()
 
     def compute_tendencies(self):
-        g = self.grid
-        momentum_tendencies(g, self.u, self.v, self.w, self.Gn[0], self.Gn[1], self.Gn[2])
+        g, ph = self.grid, self.physics
+        momentum_tendencies(g, self.u, self.v, self.w, self.Gn[0], self.Gn[1], self.Gn[2], self.scheme)
+        if ph.c.coriolis or ph.c.closure or ph.c.buoyancy:
+            T, S = self._buoyancy_tracers()
+            momentum_extra_tendencies(g, ph, self.u, self.v, self.w, T, S, self.pHY, self.Gn[0], self.Gn[1], self.Gn[2])
         for n, c in enumerate(self.tracers):
-            tracer_tendency(g, self.u, self.v, self.w, c, self.Gn[3 + n])
+            tracer_tendency(g, self.u, self.v, self.w, c, self.Gn[3 + n], self.scheme)
+            if ph.c.closure:
+                tracer_diffusion(g, self.kappa[self.tracer_names[n]], c, self.Gn[3 + n])
+        # compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:204-213)
+        for f, l, n, G in zip(self.fields, self.locs, self.names, self.Gn):
+            if n in self.bcs:
+                apply_flux_bcs(g, l, f, G, self.bcs[n])
 
     def calculate_pressure_correction(self, dt):  # pressure_correction.jl:8-20
         g = self.grid
-        for f, l in zip((self.u, self.v, self.w), (LOC_U, LOC_V, LOC_W)):
-            fill_halo_regions(g, f, l)
+        for f, l, n in zip((self.u, self.v, self.w), (LOC_U, LOC_V, LOC_W), "uvw"):
+            fill_halo_regions(g, f, l, bcs=self.bcs.get(n))
         self.solver.source_term(self.u, self.v, self.w, dt)
         self.solver.solve(self.p)
         fill_halo_regions(g, self.p, LOC_C)
@@ -429,7 +566,7 @@ class NonhydrostaticModel:
             else:
                 f, l = self.tracers[self.tracer_names.index(name)], LOC_C
             g.interior(f)[...] = val
-            fill_halo_regions(g, f, l)
+            fill_halo_regions(g, f, l, bcs=self.bcs.get(name))
         self.update_state(compute_tendencies=False)
         if enforce_incompressibility:
             self.calculate_pressure_correction(1.0)

@@ -1,0 +1,333 @@
+"""GPU parity for the SURVEY §8(f) rank-1 terms: Centered(order=2) advection, FPlane Coriolis, ScalarDiffusivity,
+buoyancy + hydrostatic pressure anomaly, Flux / Value / Gradient boundary conditions -- every kernel through the
+C ABI against the CPU oracle on the same seeded inputs (bit-exact in strict math), whole models against the oracle
+model, and the reference's analytic tests (test/test_dynamics.jl, test/test_internal_wave_dynamics.jl) on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import from_dev, make_pair, random_parent, stretched_faces, to_dev
+from test_oracle_physics import internal_wave_initial, internal_wave_solution
+
+pytestmark = pytest.mark.gpu
+
+LOCS = (1, 2, 4)
+CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), (3, 3, 3)),
+         ((13, 17, 19), "PPP", (0, 1.0), (1, 2, 3)),
+         ((70, 9, 8), "PPB", (-1.0, 0.0), (3, 3, 3)),
+         ((16, 12, 10), "PPB", "stretched", (3, 3, 3)),
+         ((5, 1, 12), "PPB", "stretched", (1, 1, 1)),
+         ((24, 16, 1), "PPF", None, (3, 3, 0))]
+SEAWATER = ("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4)
+
+
+def _grid(O, ocn, size, topo, z, halo):
+    if isinstance(z, str):
+        z = stretched_faces(size[2])
+    return make_pair(O, ocn, size, topo, z=z, halo=halo)
+
+
+def _terms(ocn, advection=0, f=None, nu=None, buoyancy=0, g=0.0, alpha=0.0, beta=0.0, T=None, S=None, pHY=None):
+    t = ocn._lib.CModelTerms()
+    t.advection = advection
+    if f is not None:
+        t.coriolis, t.f = 1, f
+    if nu is not None:
+        t.closure, t.nu = 1, nu
+    t.buoyancy, t.g, t.alpha, t.beta = buoyancy, g, alpha, beta
+    t.T = None if T is None else T.ptr
+    t.S = None if S is None else S.ptr
+    t.pHY = None if pHY is None else pHY.ptr
+    return t
+
+
+@pytest.mark.parametrize("size,topo,z,halo", CASES)
+def test_centered2_advection_strict_bitwise(oracle, ocn, size, topo, z, halo):
+    O = oracle
+    rng = np.random.default_rng(21)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng)
+    G = [og.zeros(l) for l in LOCS] + [og.zeros(0)]
+    O.momentum_tendencies(og, u, v, w, *G[:3], scheme=O.ADV_CENTERED2)
+    O.tracer_tendency(og, u, v, w, c, G[3], scheme=O.ADV_CENTERED2)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dG = [ocn.Field(l, pg) for l in LOCS + (0,)]
+    t = _terms(ocn, advection=1)
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
+                  dG[2].ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvwc"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
+    assert np.abs(G[0]).max() > 0 and np.abs(G[3]).max() > 0
+
+
+@pytest.mark.parametrize("size,topo,z,halo", CASES)
+@pytest.mark.parametrize("separate_pHY", [True, False])
+def test_all_momentum_terms_strict_bitwise(oracle, ocn, size, topo, z, halo, separate_pHY):
+    """WENO (halo 3 cases) or Centered2 advection + buoyancy + Coriolis + hydrostatic pressure gradient + viscosity,
+    accumulated in the reference's order: bit-identical to the oracle."""
+    O = oracle
+    rng = np.random.default_rng(22)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    weno = min(h for h, t in zip(halo, topo) if t != "F") >= 3 and min(n for n, t in zip(size, topo) if t != "F") >= 3
+    scheme = O.ADV_WENO5 if weno else O.ADV_CENTERED2
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    T, S = random_parent(og, 0, rng, 10, 20), random_parent(og, 0, rng, 30, 35)
+    ph = O.Physics(f=1e-1, nu=2.5e-2, buoyancy=SEAWATER)
+    pHY = og.zeros(0)
+    O.update_hydrostatic_pressure(og, ph, T, S, pHY)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G, scheme=scheme)
+    O.momentum_extra_tendencies(og, ph, u, v, w, T, S, pHY if separate_pHY else None, *G)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dT, dS = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0, 0), (u, v, w, T, S)))
+    dp = ocn.Field(0, pg)
+    t = _terms(ocn, advection=0 if weno else 1, f=1e-1, nu=2.5e-2, buoyancy=2, g=SEAWATER[1], alpha=SEAWATER[2], beta=SEAWATER[3],
+               T=dT, S=dS, pHY=dp if separate_pHY else None)
+    if topo[2] != "F":
+        ocn._lib.call("ocn_update_hydrostatic_pressure", pg.cref, C.byref(t), dp.ptr, 0)
+        ocn.sync_device()
+        np.testing.assert_array_equal(from_dev(dp), pHY, err_msg="pHY′ differs bitwise from the oracle")
+    dG = [ocn.Field(l, pg) for l in LOCS]
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
+                  dG[2].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvw"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
+
+
+@pytest.mark.parametrize("size,topo,z,halo", CASES)
+def test_tracer_diffusion_strict_bitwise(oracle, ocn, size, topo, z, halo):
+    O = oracle
+    rng = np.random.default_rng(23)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng)
+    Gc = og.zeros(0)
+    O.tracer_tendency(og, u, v, w, c, Gc, scheme=O.ADV_CENTERED2)
+    O.tracer_diffusion(og, 0.37, c, Gc)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dG = ocn.Field(0, pg)
+    t = _terms(ocn, advection=1, nu=1.0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.37, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG.ptr, None, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dG), Gc)
+
+
+@pytest.mark.parametrize("size,topo,z,halo", CASES)
+def test_physics_fast_math_tolerance(oracle, ocn, size, topo, z, halo):
+    """fast math multiplies by reciprocal spacings and contracts to FMA: 1e-12 of max|G|."""
+    O = oracle
+    rng = np.random.default_rng(24)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    b = random_parent(og, 0, rng)
+    ph = O.Physics(f=0.3, nu=1e-1, buoyancy="BuoyancyTracer")
+    pHY = og.zeros(0)
+    O.update_hydrostatic_pressure(og, ph, b, None, pHY)
+    G = [og.zeros(l) for l in LOCS] + [og.zeros(0)]
+    O.momentum_tendencies(og, u, v, w, *G[:3], scheme=O.ADV_CENTERED2)
+    O.momentum_extra_tendencies(og, ph, u, v, w, b, None, pHY, *G[:3])
+    O.tracer_tendency(og, u, v, w, b, G[3], scheme=O.ADV_CENTERED2)
+    O.tracer_diffusion(og, 0.2, b, G[3])
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        du, dv, dw, db, dp = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0, 0), (u, v, w, b, pHY)))
+        dG = [ocn.Field(l, pg) for l in LOCS + (0,)]
+        t = _terms(ocn, advection=1, f=0.3, nu=1e-1, buoyancy=1, T=db, pHY=dp)
+        ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
+                      dG[2].ptr, None, 0)
+        ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.2, du.ptr, dv.ptr, dw.ptr, db.ptr, dG[3].ptr, None, 0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    for a, d in zip(G, dG):
+        assert np.abs(from_dev(d) - a).max() <= 1e-12 * max(np.abs(a).max(), 1e-300)
+
+
+@pytest.mark.parametrize("z", [(-1.0, 0.0), "stretched"])
+def test_boundary_condition_fills_and_fluxes_bitwise(oracle, ocn, z):
+    """Value / Gradient / Flux (number, array, `value + coeff * c`) bottom / top conditions: halo fill and
+    apply_z_bcs! against the oracle, bit for bit."""
+    O = oracle
+    rng = np.random.default_rng(25)
+    size = (11, 7, 9)
+    og, pg = _grid(O, ocn, size, "PPB", z, (3, 3, 3))
+    arr = rng.random((size[0], size[1]))
+    cases = {
+        "u": dict(top=("flux", dict(value=-1.3e-4))),
+        "v": dict(bottom=("value", dict(value=0.2)), top=("flux", dict(values=arr))),
+        "T": dict(top=("flux", dict(value=5e-5)), bottom=("gradient", dict(value=0.01))),
+        "S": dict(top=("flux", dict(value=0.0, coeff=-2.7e-7)), bottom=("value", dict(values=arr))),
+    }
+    locs = {"u": 1, "v": 2, "T": 0, "S": 0}
+    mk = {"flux": ocn.FluxBoundaryCondition, "value": ocn.ValueBoundaryCondition, "gradient": ocn.GradientBoundaryCondition}
+    fields, Gs, ofields, oGs, obcs = [], [], [], [], []
+    for name, sides in cases.items():
+        a = random_parent(og, locs[name], rng)
+        Ga = random_parent(og, locs[name], rng)
+        ob = {}
+        pb = {}
+        for side, (kind, kw) in sides.items():
+            ob[side] = O.BC(kind, kw.get("value", 0.0), kw.get("coeff", 0.0), kw.get("values"))
+            cond = kw["values"] if "values" in kw else kw.get("value", 0.0)
+            pb[side] = mk[kind](cond, coeff=kw["coeff"]) if "coeff" in kw else mk[kind](cond)
+        f = to_dev(ocn, pg, locs[name], a)
+        f.boundary_conditions = ocn.FieldBoundaryConditions(**pb)
+        fields.append(f)
+        Gs.append(to_dev(ocn, pg, locs[name], Ga))
+        ofields.append(a)
+        oGs.append(Ga)
+        obcs.append(ob)
+    # a field on default conditions rides along in the same tuple
+    w = random_parent(og, 4, rng)
+    fields.append(to_dev(ocn, pg, 4, w))
+    ocn.fill_halo_regions(fields, fill_boundary_normal_velocities=False)
+    ocn.sync_device()
+    for a, l, ob in zip(ofields + [w], [1, 2, 0, 0, 4], obcs + [None]):
+        O.fill_halo_regions(og, a, l, fill_boundary_normal_velocities=False, bcs=ob)
+    for d, a in zip(fields, ofields + [w]):
+        np.testing.assert_array_equal(from_dev(d), a)
+    # flux contributions
+    arrp = (C.POINTER(ocn._lib.CFieldBcs) * 4)(*[C.pointer(f.boundary_conditions.c_struct(pg)) for f in fields[:4]])
+    ocn._lib.call("ocn_apply_flux_bcs", pg.cref, ocn._lib.ptr_array([G.ptr for G in Gs]), ocn._lib.ptr_array([f.ptr for f in fields[:4]]),
+                  ocn._lib.i32_array([1, 2, 0, 0]), arrp, 4, 0)
+    ocn.sync_device()
+    for a, Ga, l, ob, dG in zip(ofields, oGs, [1, 2, 0, 0], obcs, Gs):
+        before = Ga.copy()
+        O.apply_flux_bcs(og, l, a, Ga, ob)
+        np.testing.assert_array_equal(from_dev(dG), Ga)
+        assert not np.array_equal(before, Ga)
+
+
+PHYS_MODELS = [
+    # (size, z, advection, timestepper)
+    ((16, 12, 10), "stretched", "WENO5", "RungeKutta3"),
+    ((16, 12, 10), (-1.0, 0.0), "Centered2", "QuasiAdamsBashforth2"),
+    ((32, 8, 16), "stretched", "WENO5", "QuasiAdamsBashforth2"),
+]
+
+
+@pytest.mark.parametrize("size,z,adv,ts", PHYS_MODELS)
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_ocean_mixing_model_matches_oracle(oracle, ocn, size, z, adv, ts, mode):
+    """examples/ocean_wind_mixing_and_convection.jl:79-152 minus the LES closure: SeawaterBuoyancy(linear), FPlane, constant
+    ScalarDiffusivity, wind stress on u, heat flux + bottom temperature gradient on T, evaporation (flux ∝ S) on S; 3 steps
+    of the product against the oracle model.  Tolerance 1e-10 of each field's scale (the Poisson solves differ by round-off)."""
+    O = oracle
+    rng = np.random.default_rng(26)
+    if isinstance(z, str):
+        z = stretched_faces(size[2], 32.0)
+    og, pg = make_pair(O, ocn, size, "PPB", x=(0, 64), y=(0, 64), z=z)
+    Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
+    JT = Q / (rho * cp)
+    taux = -1.225 / rho * 2.5e-3 * 10 * 10
+    evap = 1e-3 / 3600
+    obcs = {"u": {"top": O.FluxBoundaryCondition(taux)},
+            "T": {"top": O.FluxBoundaryCondition(JT), "bottom": O.GradientBoundaryCondition(dTdz)},
+            "S": {"top": O.BC("flux", 0.0, -evap)}}
+    om = O.NonhydrostaticModel(og, tracers=("T", "S"), timestepper=ts, advection=adv, coriolis_f=1e-4, closure=(1e-3, {"T": 2e-3, "S": 5e-4}),
+                               buoyancy=SEAWATER, boundary_conditions=obcs)
+    pbcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(taux)),
+            "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(JT), bottom=ocn.GradientBoundaryCondition(dTdz)),
+            "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-evap))}
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO() if adv == "WENO5" else ocn.Centered(), tracers=("T", "S"), timestepper=ts,
+                                     coriolis=ocn.FPlane(f=1e-4), closure=ocn.ScalarDiffusivity(ν=1e-3, κ={"T": 2e-3, "S": 5e-4}),
+                                     buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                     boundary_conditions=pbcs)
+        zc = 0.5 * (og.zf[og.Hz:og.Hz + og.Nz] + og.zf[og.Hz + 1:og.Hz + og.Nz + 1]) if og.zf is not None else (np.arange(og.Nz) + 0.5) * og.dz + z[0]
+        init = {n: 1e-2 * rng.uniform(-1, 1, og.interior(f).shape) for n, f in zip("uvw", (om.u, om.v, om.w))}
+        init["T"] = 20 + dTdz * zc[None, None, :] + 1e-3 * rng.uniform(-1, 1, size)
+        init["S"] = 35 + 1e-3 * rng.uniform(-1, 1, size)
+        om.set(**init)
+        ocn.set(pm, **init)
+        dt = 2.0
+        for _ in range(3):
+            om.time_step(dt)
+            ocn.time_step(pm, dt)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    names = ("u", "v", "w", "T", "S")
+    tol = 1e-10
+    vscale = max(np.abs(om.u).max(), np.abs(om.v).max(), np.abs(om.w).max())
+    for name, a, d in zip(names, om.fields, pm.prognostic_fields()):
+        scale = vscale if name in "uvw" else np.abs(og.interior(a)).max()
+        err = np.abs(og.interior(from_dev(d)) - og.interior(a)).max()
+        assert err <= tol * scale, f"{name}: {err} > {tol * scale}"
+    np.testing.assert_allclose(og.interior_N(from_dev(pm.pHY)), og.interior_N(om.pHY), rtol=1e-11, atol=1e-14)
+    import torch
+    ddiv = torch.zeros((og.Nz, og.Ny, og.Nx), dtype=torch.float64, device=pm.u.data.device)
+    ocn._lib.call("ocn_divergence", pg.cref, pm.u.ptr, pm.v.ptr, pm.w.ptr, ddiv.data_ptr(), 0)
+    assert float(ddiv.abs().max()) < 5e-8
+
+
+@pytest.mark.parametrize("ts", ["QuasiAdamsBashforth2", "RungeKutta3"])
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_taylor_green_vortex(ocn, ts, mode):
+    """test/test_dynamics.jl:215-260 on the GPU: max relative error of u and v < 5e-6 after 10 steps."""
+    N, Nt, nu = 64, 10, 1.0
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        g = ocn.RectilinearGrid(ocn.GPU(), size=(N, N, 2), x=(0, 1), y=(0, 1), z=(0, 1), topology=("Periodic",) * 3, halo=(3, 3, 2))
+        m = ocn.NonhydrostaticModel(g, timestepper=ts, closure=ocn.ScalarDiffusivity(ν=nu))
+        dx = 1 / N
+        dt = (1 / (10 * np.pi)) * dx ** 2 / nu
+        xC = (np.arange(N) + 0.5) * dx
+        u0 = -np.sin(2 * np.pi * xC)[None, :, None] * np.ones((N, 1, 2))
+        v0 = np.sin(2 * np.pi * xC)[:, None, None] * np.ones((1, N, 2))
+        ocn.set(m, u=u0, v=v0)
+        for _ in range(Nt):
+            ocn.time_step(m, dt)
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    decay = np.exp(-4 * np.pi ** 2 * nu * m.clock.time)
+    eu = np.max(np.abs((m.u.interior() - u0 * decay) / (u0 * decay)))
+    ev = np.max(np.abs((m.v.interior() - v0 * decay) / (v0 * decay)))
+    assert eu < 5e-6 and ev < 5e-6, (eu, ev)
+
+
+@pytest.mark.parametrize("stretched", [False, True])
+def test_internal_wave_dynamics(ocn, stretched):
+    """test/test_internal_wave_dynamics.jl on the y-periodic regular and vertically stretched grids
+    (test_dynamics.jl:627-683): relative error of u < 1e-4 after 10 steps."""
+    N, L = 128, 2 * np.pi
+    sol, nu, f, dt = internal_wave_solution(L)
+    zf = None
+    z = (-L, 0)
+    if stretched:  # test_dynamics.jl:642-645: z_faces = collect(znodes(regular grid, Face())); z_faces[Nz÷2] += small
+        zf = -L + np.arange(N + 1) * (L / N)
+        zf[1:-1] += 0.1 * (L / N) * np.sin(np.arange(1, N) * 0.7)
+        z = zf
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(N, 1, N), x=(0, L), y=(0, L), z=z, topology=("Periodic", "Periodic", "Bounded"), halo=(3, 1, 3))
+    m = ocn.NonhydrostaticModel(g, timestepper="QuasiAdamsBashforth2", closure=ocn.ScalarDiffusivity(ν=nu, κ=nu),
+                                buoyancy=ocn.BuoyancyTracer(), tracers="b", coriolis=ocn.FPlane(f=f))
+    ic, xF, zC = internal_wave_initial(sol, N, L, zf)
+    ocn.set(m, **ic)
+    for _ in range(10):
+        ocn.time_step(m, dt)
+    exact = sol["u"](xF[:, None, None], zC[None, None, :], m.clock.time)
+    num = m.u.interior()
+    assert np.mean((num - exact) ** 2) / np.mean(exact ** 2) < 1e-4
+
+
+def test_model_argument_errors(ocn):
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(8, 8, 8), x=(0, 1), y=(0, 1), z=(0, 1), topology=("Periodic", "Periodic", "Bounded"))
+    with pytest.raises(ValueError, match="requires tracers"):
+        ocn.NonhydrostaticModel(g, advection=ocn.WENO(), buoyancy=ocn.BuoyancyTracer())
+    with pytest.raises(NotImplementedError):
+        ocn.NonhydrostaticModel(g, advection=ocn.WENO(), closure="AnisotropicMinimumDissipation")
+    with pytest.raises(NotImplementedError):
+        ocn.FieldBoundaryConditions(west=ocn.FluxBoundaryCondition(1.0))
+    gp = ocn.RectilinearGrid(ocn.GPU(), size=(8, 8, 8), x=(0, 1), y=(0, 1), z=(0, 1), topology=("Periodic",) * 3)
+    with pytest.raises(ocn.OcnError, match="Bounded z"):
+        ocn.NonhydrostaticModel(gp, advection=ocn.WENO(), tracers="c",
+                                boundary_conditions={"c": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(1.0))})

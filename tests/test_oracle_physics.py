@@ -1,0 +1,238 @@
+"""SURVEY §8(f) rank 1 on the CPU oracle: the reference's analytic / budget tests for Coriolis, ScalarDiffusivity,
+buoyancy + hydrostatic pressure and boundary conditions, re-expressed (the reference's own numbers and tolerances).
+
+  test/test_dynamics.jl:17-33     simple diffusion (uniform field stays put)
+  test/test_dynamics.jl:35-50     budgets in isotropic diffusion (mean conserved), all four topologies
+  test/test_dynamics.jl:68-90     diffusion of a cosine, atol = rtol = 1e-6
+  test/test_dynamics.jl:215-260   Taylor-Green vortex, max relative error < 5e-6
+  test/test_internal_wave_dynamics.jl   internal wave packet (closure + BuoyancyTracer + FPlane), relative error < 1e-4
+  test/test_dynamics.jl:355-398   inertial oscillation under FPlane
+The default advection of all of these is Centered(order=2), which is why the oracle restates it.
+"""
+import numpy as np
+import pytest
+
+RK3, AB2 = "RungeKutta3", "QuasiAdamsBashforth2"
+
+
+def _field(m, name):
+    return {"u": m.u, "v": m.v, "w": m.w}.get(name, None) if name in "uvw" else m.tracers[m.tracer_names.index(name)]
+
+
+@pytest.mark.parametrize("ts", [AB2, RK3])
+def test_taylor_green_vortex(oracle, ts):
+    O = oracle
+    N, Nt, nu = 64, 10, 1.0
+    g = O.Grid((N, N, 2), x=(0, 1), y=(0, 1), z=(0, 1))
+    m = O.NonhydrostaticModel(g, advection="Centered2", closure=(nu, None), timestepper=ts)
+    dx = 1 / N
+    dt = (1 / (10 * np.pi)) * dx ** 2 / nu
+    xC = (np.arange(N) + 0.5) * dx
+    u0 = -np.sin(2 * np.pi * xC)[None, :, None] * np.ones((N, 1, 2))
+    v0 = np.sin(2 * np.pi * xC)[:, None, None] * np.ones((1, N, 2))
+    m.set(u=u0, v=v0)
+    for _ in range(Nt):
+        m.time_step(dt)
+    decay = np.exp(-4 * np.pi ** 2 * nu * m.time)
+    eu = np.max(np.abs((g.interior_N(m.u) - u0 * decay) / (u0 * decay)))
+    ev = np.max(np.abs((g.interior_N(m.v) - v0 * decay) / (v0 * decay)))
+    assert eu < 5e-6 and ev < 5e-6, (eu, ev)
+
+
+@pytest.mark.parametrize("ts", [AB2, RK3])
+@pytest.mark.parametrize("name", ["u", "v", "c"])
+def test_diffusion_simple(oracle, name, ts):
+    O = oracle
+    g = O.Grid((1, 1, 16), x=(0, 1), y=(0, 1), z=(0, 1), topology="PPB")
+    m = O.NonhydrostaticModel(g, advection="Centered2", closure=(1.0, 1.0), tracers=("c",), timestepper=ts)
+    f = _field(m, name)
+    g.interior(f)[...] = np.pi
+    m.update_state()
+    for _ in range(10):
+        m.time_step(1.0)
+    assert np.allclose(g.interior(f), np.pi, rtol=np.sqrt(np.finfo(float).eps), atol=0)
+
+
+@pytest.mark.parametrize("ts", [AB2, RK3])
+@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB", "BBB"])
+def test_scalar_diffusivity_budget(oracle, topo, ts):
+    O = oracle
+    rng = np.random.default_rng(7)
+    g = O.Grid((4, 4, 4), x=(0, 1), y=(0, 1), z=(0, 1), topology=topo)
+    names = ["c"] + [n for n, t in zip("uvw", topo) if t == "P"]
+    for name in names:
+        m = O.NonhydrostaticModel(g, advection="Centered2", closure=(1.0, 1.0), tracers=("c",), timestepper=ts)
+        m.set(u=0, v=0, w=0, c=0)
+        m.set(**{name: rng.random((4, 4, 4))})
+        f = _field(m, name)
+        mean0 = np.mean(g.interior_N(f))
+        m.update_state()
+        dt = 1e-4 * g.dz ** 2 / 1.0
+        for _ in range(10):
+            m.time_step(dt)
+        assert np.isclose(mean0, np.mean(g.interior_N(f)), rtol=np.sqrt(np.finfo(float).eps)), (name, topo)
+
+
+@pytest.mark.parametrize("name", ["u", "v", "c"])
+def test_diffusion_cosine(oracle, name):
+    O = oracle
+    N, L = 128, np.pi / 2
+    g = O.Grid((1, 1, N), x=(0, 1), y=(0, 1), z=(0, L), topology="PPB")
+    m = O.NonhydrostaticModel(g, advection="Centered2", closure=(1.0, 1.0), tracers=("c",))
+    z = (np.arange(N) + 0.5) * (L / N)
+    f = _field(m, name)
+    g.interior(f)[...] = np.cos(2 * z)[None, None, :]
+    m.update_state()
+    dt = 1e-6 * g.Lz ** 2 / 1.0
+    for _ in range(5):
+        m.time_step(dt)
+    exact = np.exp(-4 * m.time) * np.cos(2 * z)
+    assert np.allclose(g.interior(f)[0, 0, :], exact, atol=1e-6, rtol=1e-6)
+
+
+def internal_wave_solution(L):
+    """test_internal_wave_dynamics.jl:4-59"""
+    nu = 1e-9
+    z0, delta, a0, mm, kk, f, NN = -L / 3, L / 20, 1e-3, 16, 1, 0.2, 1.0
+    sigma = np.sqrt((NN ** 2 * kk ** 2 + f ** 2 * mm ** 2) / (kk ** 2 + mm ** 2))
+    dt = 0.01 / sigma
+    cg = mm * sigma / (kk ** 2 + mm ** 2) * (f ** 2 / sigma ** 2 - 1)
+    U = a0 * kk * sigma / (sigma ** 2 - f ** 2)
+    V = a0 * kk * f / (sigma ** 2 - f ** 2)
+    W = a0 * mm * sigma / (sigma ** 2 - NN ** 2)
+    B = a0 * mm * NN ** 2 / (sigma ** 2 - NN ** 2)
+    a = lambda x, z, t: np.exp(-(z - cg * t - z0) ** 2 / (2 * delta) ** 2)
+    ph = lambda x, z, t: kk * x + mm * z - sigma * t
+    sol = dict(u=lambda x, z, t: a(x, z, t) * U * np.cos(ph(x, z, t)),
+               v=lambda x, z, t: a(x, z, t) * V * np.sin(ph(x, z, t)),
+               w=lambda x, z, t: a(x, z, t) * W * np.cos(ph(x, z, t)),
+               b=lambda x, z, t: a(x, z, t) * B * np.sin(ph(x, z, t)) + NN ** 2 * z)
+    return sol, nu, f, dt
+
+
+def internal_wave_initial(sol, N, L, zf=None):
+    dx = L / N
+    xF, xC = np.arange(N) * dx, (np.arange(N) + 0.5) * dx
+    if zf is None:
+        zf = -L + np.arange(N + 1) * (L / N)
+    zC = 0.5 * (zf[1:] + zf[:-1])
+    g3 = lambda fn, x, z: fn(x[:, None, None], z[None, None, :], 0.0) * np.ones((1, 1, 1))
+    return dict(u=g3(sol["u"], xF, zC), v=g3(sol["v"], xC, zC), w=g3(sol["w"], xC, zf), b=g3(sol["b"], xC, zC)), xF, zC
+
+
+def test_internal_wave_dynamics(oracle):
+    O = oracle
+    N = 128
+    L = 2 * np.pi
+    sol, nu, f, dt = internal_wave_solution(L)
+    g = O.Grid((N, 1, N), x=(0, L), y=(0, L), z=(-L, 0), topology="PPB")
+    m = O.NonhydrostaticModel(g, advection="Centered2", closure=(nu, nu), buoyancy="BuoyancyTracer", tracers=("b",),
+                              coriolis_f=f, timestepper=AB2, workers=4)
+    ic, xF, zC = internal_wave_initial(sol, N, L)
+    m.set(**ic)
+    for _ in range(10):
+        m.time_step(dt)
+    exact = sol["u"](xF[:, None, None], zC[None, None, :], m.time)
+    num = g.interior_N(m.u)
+    assert np.mean((num - exact) ** 2) / np.mean(exact ** 2) < 1e-4
+
+
+def test_inertial_oscillation_fplane(oracle):
+    """test_dynamics.jl:355-398 with rotation about z: a uniform flow rotates, |U| = 1 after half an inertial period and
+    w stays 0.  (The reference uses a (Flat, Flat, Flat) grid; a small periodic box with uniform fields is the same ODE.)"""
+    O = oracle
+    g = O.Grid((4, 4, 4), x=(0, 1), y=(0, 1), z=(0, 1))
+    m = O.NonhydrostaticModel(g, advection="Centered2", coriolis_f=1.0)
+    m.set(u=1.0)
+    dt, n = 1e-3, int(round(np.pi / 1e-3))
+    for _ in range(n):
+        m.time_step(dt)
+    u, v, w = g.interior_N(m.u), g.interior_N(m.v), g.interior_N(m.w)
+    assert np.all(w == 0)
+    assert np.allclose(np.sqrt(u ** 2 + v ** 2), 1.0, rtol=np.sqrt(np.finfo(float).eps))
+    assert np.allclose(u, np.cos(m.time), atol=1e-6) and np.allclose(v, -np.sin(m.time), atol=1e-6)
+
+
+# ---- hydrostatic pressure and boundary conditions: identities the reference's definitions imply -------------------
+@pytest.mark.parametrize("stretched", [False, True])
+def test_hydrostatic_pressure_balances_buoyancy(oracle, stretched):
+    """update_hydrostatic_pressure.jl:12-20: by construction ∂z pHY′ at every interior face equals ℑz b, and the top
+    value is -b_face(Nz+1) * Δz_face(Nz+1)."""
+    from helpers import stretched_faces
+    O = oracle
+    rng = np.random.default_rng(3)
+    Nz = 12
+    z = stretched_faces(Nz) if stretched else (-1, 0)
+    g = O.Grid((6, 5, Nz), x=(0, 1), y=(0, 1), z=z, topology="PPB")
+    T, S = g.zeros(0), g.zeros(0)
+    T[...] = rng.random(T.shape)
+    S[...] = rng.random(S.shape)
+    ph = O.Physics(buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4))
+    p = g.zeros(0)
+    O.update_hydrostatic_pressure(g, ph, T, S, p)
+    b = 9.80665 * (2e-4 * T - 8e-4 * S)
+    H = g.Hz
+    dzf = g.dzf if g.dzf is not None else np.full(Nz + 2 * H, g.dz)
+    for k in range(2, Nz + 1):  # interior faces (1-based k)
+        lhs = (p[:, :, H + k - 1] - p[:, :, H + k - 2]) / dzf[k + H - 1]
+        rhs = 0.5 * (b[:, :, H + k - 2] + b[:, :, H + k - 1])
+        sl = (slice(g.Hx - 1, g.Hx + g.Nx + 1), slice(g.Hy - 1, g.Hy + g.Ny + 1))  # 0:N+1 (p_kernel_parameters)
+        assert np.allclose(lhs[sl], rhs[sl], rtol=1e-12, atol=1e-15)
+    top = -(0.5 * (b[:, :, H + Nz - 1] + b[:, :, H + Nz])) * dzf[Nz + 1 + H - 1]
+    assert np.array_equal(p[g.Hx:-g.Hx, g.Hy:-g.Hy, H + Nz - 1], top[g.Hx:-g.Hx, g.Hy:-g.Hy])
+
+
+def test_stratified_fluid_remains_at_rest(oracle):
+    """test_dynamics.jl:262-353 with θ = 0 (vertical gravity): a linearly stratified fluid with Gradient boundary conditions
+    stays at rest and keeps ∂z b = N²."""
+    O = oracle
+    N, L, N2 = 16, 2000.0, 1e-5
+    g = O.Grid((4, N, N), x=(0, L), y=(0, L), z=(0, L), topology="PPB")
+    bc = {"b": {"bottom": O.GradientBoundaryCondition(N2), "top": O.GradientBoundaryCondition(N2)}}
+    m = O.NonhydrostaticModel(g, advection="Centered2", buoyancy="BuoyancyTracer", tracers=("b",), boundary_conditions=bc)
+    zC = (np.arange(N) + 0.5) * (L / N)
+    m.set(b=(N2 * zC)[None, None, :] * np.ones((4, N, 1)))
+    for _ in range(6):
+        m.time_step(600.0)
+    b = g.interior_N(m.tracers[0])
+    dbdz = np.diff(b, axis=2) / (L / N)
+    assert np.allclose(dbdz, N2, rtol=np.sqrt(np.finfo(float).eps))
+    assert max(np.abs(g.interior_N(f)).max() for f in (m.u, m.v, m.w)) < 1e-12
+
+
+def test_value_and_gradient_halo_fill(oracle):
+    """fill_halo_regions_value_gradient.jl: after the fill the wall value (Value) / the wall-normal difference (Gradient)
+    are exactly what the condition prescribes (test/test_boundary_conditions.jl's field-level checks)."""
+    from helpers import stretched_faces
+    O = oracle
+    rng = np.random.default_rng(11)
+    Nz = 8
+    g = O.Grid((5, 4, Nz), x=(0, 1), y=(0, 1), z=stretched_faces(Nz), topology="PPB")
+    c = g.zeros(0)
+    g.interior(c)[...] = rng.random((5, 4, Nz))
+    H = g.Hz
+    O.fill_halo_regions(g, c, 0, bcs={"bottom": O.ValueBoundaryCondition(0.25), "top": O.GradientBoundaryCondition(-0.5)})
+    ci = g.interior(c)
+    bottom_halo, top_halo = c[g.Hx:-g.Hx, g.Hy:-g.Hy, H - 1], c[g.Hx:-g.Hx, g.Hy:-g.Hy, H + Nz]
+    assert np.allclose(0.5 * (bottom_halo + ci[:, :, 0]), 0.25, rtol=1e-14)
+    assert np.allclose((top_halo - ci[:, :, -1]) / g.dzf[Nz + 1 + H - 1], -0.5, rtol=1e-13)
+    # x / y halos of the new z-halo planes are the periodic images
+    assert np.array_equal(c[:g.Hx, :, H - 1], c[g.Nx:g.Nx + g.Hx, :, H - 1])
+    assert np.array_equal(c[:, -g.Hy:, H + Nz], c[:, g.Hy:2 * g.Hy, H + Nz])
+
+
+@pytest.mark.parametrize("ts", [AB2, RK3])
+def test_flux_boundary_condition_budget(oracle, ts):
+    """apply_flux_bcs.jl:107-160: with κ > 0, no flow and a top flux J the volume mean of c changes by exactly
+    -J t / Lz (a positive top flux leaves the domain); a bottom flux J adds +J t / Lz."""
+    O = oracle
+    g = O.Grid((4, 4, 8), x=(0, 1), y=(0, 1), z=(-2, 0), topology="PPB")
+    J = 0.3
+    bcs = {"c": {"top": O.FluxBoundaryCondition(J), "bottom": O.FluxBoundaryCondition(2 * J)}}
+    m = O.NonhydrostaticModel(g, advection="Centered2", closure=(1e-2, 1e-2), tracers=("c",), boundary_conditions=bcs, timestepper=ts)
+    m.set(c=1.0)
+    dt = 1e-3
+    for _ in range(5):
+        m.time_step(dt)
+    mean = np.mean(g.interior_N(m.tracers[0]))
+    assert np.isclose(mean, 1.0 + (2 * J - J) * m.time / g.Lz, rtol=1e-13)
