@@ -10,7 +10,8 @@ from . import _lib
 from ._lib import MATH_FAST, MATH_STRICT, OcnError
 from .advection import WENO
 from .architectures import CPU, GPU, on_architecture, sync_device, zeros
-from .distributed import Distributed, DistributedFFTBasedPoissonSolver, Partition, TorchDistributedFabric
+from .distributed import (Distributed, DistributedFFTBasedPoissonSolver, DistributedFourierTridiagonalPoissonSolver, Partition,
+                          TorchDistributedFabric)
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,

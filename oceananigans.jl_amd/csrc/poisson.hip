@@ -431,12 +431,22 @@ struct ocn_dist_poisson {
     double *rhs = nullptr;  // real source term (r2c)
     double *yfield = nullptr, *xfield = nullptr, *send = nullptr, *recv = nullptr;
     Plan fyz, byz, fx, bx;
+    // z Bounded: DistributedFourierTridiagonalPoissonSolver (distributed_fft_tridiagonal_solver.jl:149-351), ZStretched flavour.
+    // FFT in y on the slab, transpose, FFT in x, Thomas sweep in z (z is local in the x-local layout as well, so the
+    // reference's extra transpose pair to a z-local pencil is not needed), inverse x, transpose back, inverse y.
+    bool tri = false;
+    bool ycol = false;             // y transforms by the column-FFT kernel (stage-ordered ky) instead of rocFFT
+    double *tw_y = nullptr;        // column-FFT twiddles
+    double *xsol = nullptr;        // tridiagonal solution (x-local layout)
+    double *diag = nullptr, *lower = nullptr, *tscr = nullptr;
+    double *dzc = nullptr, *dzf = nullptr;
 };
 
 static void free_all(ocn_dist_poisson *s)
 {
     s->fyz.destroy(); s->byz.destroy(); s->fx.destroy(); s->bx.destroy();
-    double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv};
+    double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv,
+                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -451,8 +461,8 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(R >= 1 && rank >= 0 && rank < R, "ocn_dist_poisson_create: bad rank %d of %d", rank, R);
     OCN_REQUIRE(global_Lx > 0, "ocn_dist_poisson_create: global_Lx must be positive");
-    OCN_REQUIRE(lg->ty == OCN_PERIODIC && lg->tz == OCN_PERIODIC && lg->dzc == nullptr,
-                "ocn_dist_poisson_create: supports (x-partitioned, Periodic, Periodic) regular grids");
+    OCN_REQUIRE(lg->ty == OCN_PERIODIC && ((lg->tz == OCN_PERIODIC && lg->dzc == nullptr) || lg->tz == OCN_BOUNDED),
+                "ocn_dist_poisson_create: supports (x-partitioned, Periodic, Periodic) regular grids and (x-partitioned, Periodic, Bounded)");
     // validate_poisson_solver_distributed_grid (distributed_fft_based_poisson_solver.jl:211-229)
     OCN_REQUIRE(lg->Ny % R == 0, "ocn_dist_poisson_create: Ny = %d must be divisible by the number of ranks %d", lg->Ny, R);
     ensure_rocfft();
@@ -465,6 +475,67 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     s->r2c = !(env && env[0] == '1');
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
+    if (lg->tz == OCN_BOUNDED) {
+        s->tri = true;
+        s->r2c = false;
+        s->nyt = Ny;
+        s->ny = Ny / R;
+        const int ny = s->ny, Hz = lg->Hz;
+        const size_t n = (size_t)nx * Ny * Nz;
+        if (lg->dzc) {  // private copies of the z spacings, like the single-GPU solver
+            const size_t nf = (size_t)Nz + 2 * Hz;
+            TRY_HIP(hipMalloc((void **)&s->dzc, nf * sizeof(double)));
+            TRY_HIP(hipMalloc((void **)&s->dzf, nf * sizeof(double)));
+            TRY_HIP(hipMemcpy(s->dzc, lg->dzc, nf * sizeof(double), hipMemcpyDeviceToDevice));
+            TRY_HIP(hipMemcpy(s->dzf, lg->dzf, nf * sizeof(double), hipMemcpyDeviceToDevice));
+            s->grid.dzc = s->dzc;
+            s->grid.dzf = s->dzf;
+        }
+        for (double **p : {&s->yfield, &s->xfield, &s->send, &s->recv, &s->xsol}) {
+            TRY_HIP(hipMalloc((void **)p, n * 2 * sizeof(double)));
+            TRY_HIP(hipMemset(*p, 0, n * 2 * sizeof(double)));
+        }
+        TRY_HIP(hipMalloc((void **)&s->diag, n * sizeof(double)));
+        TRY_HIP(hipMalloc((void **)&s->tscr, n * sizeof(double)));
+        TRY(upload(eigenvalues(Nxg, global_Lx, OCN_PERIODIC), &s->lx));
+        // y transforms: the column-FFT kernel leaves ky in stage order, so the eigenvalue of a stored position is permuted
+        s->ycol = ocn::colfft_supported(Ny);
+        std::vector<double> lyn = eigenvalues(Ny, lg->Ly, OCN_PERIODIC), lys(Ny);
+        for (int q = 0; q < Ny; ++q) lys[q] = s->ycol ? lyn[ocn::colfft_wavenumber(Ny, q)] : lyn[q];
+        TRY(upload(lys, &s->ly));
+        if (s->ycol) {
+            TRY(upload(ocn::colfft_twiddles(Ny), &s->tw_y));
+        } else {  // rocFFT, one z-plane per execution: (nx columns at distance 1) x (Ny points at stride nx)
+            const size_t len[1] = {(size_t)Ny};
+            const size_t str[1] = {(size_t)nx};
+            TRY(make_plan(s->fyz, rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len, nx,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, 1, str, 1, 1.0));
+            TRY(make_plan(s->byz, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 1, len, nx,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, 1, str, 1, 1.0));
+        }
+        {   // x transforms of the x-local field (Nxg, ny, Nz); the inverse reads the tridiagonal solution and carries 1/(Nxg Ny)
+            const size_t len[1] = {(size_t)Nxg};
+            const size_t str[1] = {1};
+            TRY(make_plan(s->fx, rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len, (size_t)ny * Nz,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, Nxg, str, Nxg, 1.0));
+            TRY(make_plan(s->bx, rocfft_placement_notinplace, rocfft_transform_type_complex_inverse, 1, len, (size_t)ny * Nz,
+                          rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, str, Nxg, str, Nxg,
+                          1.0 / ((double)Nxg * Ny)));
+        }
+        // lower = upper = 1/Δzᶠ[q], q = 2..Nz; main diagonal with this rank's ky range (fourier_tridiagonal_poisson_solver.jl:41-51, 97-99)
+        std::vector<double> hf(Nz + 2 * Hz, lg->dz);
+        if (lg->dzf) TRY_HIP(hipMemcpy(hf.data(), lg->dzf, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> low(Nz > 1 ? Nz - 1 : 1, 0.0);
+        for (int q = 2; q <= Nz; ++q) low[q - 2] = 1 / hf[q + Hz - 1];
+        TRY(upload(low, &s->lower));
+        ocn_grid xg = s->grid;  // the x-local layout as a "grid": only Ny, Nz and the z spacings are read
+        xg.Nx = Nxg;
+        xg.Ny = ny;
+        TRY(ocn::launch_main_diagonal(&xg, Nxg, s->lx, s->ly + (size_t)rank * ny, s->diag, nullptr));
+        TRY_HIP(hipDeviceSynchronize());
+        *out = s;
+        return OCN_SUCCESS;
+    }
     ocn::GridDev gd = ocn::to_dev(*lg);
     ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -562,13 +633,31 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
 {
     OCN_REQUIRE(s && u && v && w, "ocn_dist_poisson_source_term: null argument");
     const ocn_grid *g = &s->grid;
+    // _fourier_tridiagonal_source_term! (solve_for_pressure.jl:33-38): rhs = Δzᶜ div(U) / Δt, complex
+    if (s->tri) return ocn::launch_source_term(g, u, v, w, dt, 2, s->yfield, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     if (s->r2c) return ocn::launch_source_term(g, u, v, w, dt, 3, s->rhs, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     return ocn::launch_source_term(g, u, v, w, dt, 1, s->yfield, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+}
+
+// y transform of the slab (nx, Ny, Nz) for the tridiagonal flavour: column-FFT kernel (stage-ordered ky) or rocFFT per plane
+static int dist_tri_y_transform(ocn_dist_poisson *s, int inverse, hipStream_t stream)
+{
+    const int nx = s->nx, Ny = s->grid.Ny, Nz = s->grid.Nz;
+    if (s->ycol)
+        return ocn::launch_colfft(Ny, inverse ? 1 : 0, s->yfield, nx, (long long)nx * Ny, nx, Nz, s->tw_y, nullptr, nullptr,
+                                  nullptr, 1.0, 1, stream);
+    Plan &P = inverse ? s->byz : s->fyz;
+    for (int k = 0; k < Nz; ++k) {
+        int st = P.exec(s->yfield + 2 * (size_t)nx * Ny * k, nullptr, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
+    return OCN_SUCCESS;
 }
 
 extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_forward_yz: null solver");
+    if (s->tri) return dist_tri_y_transform(s, 0, ocn::as_stream(stream));
     if (s->r2c) return s->fyz.exec(s->rhs, s->yfield, ocn::as_stream(stream));
     return s->fyz.exec(s->yfield, nullptr, ocn::as_stream(stream));
 }
@@ -579,6 +668,18 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
     hipStream_t stream = ocn::as_stream(stream_);
     int st = s->fx.exec(s->xfield, nullptr, stream);
     if (st != OCN_SUCCESS) return st;
+    if (s->tri) {
+        const int Nz = s->grid.Nz;
+        st = ocn::launch_tridiag_z(s->Nxg, s->ny, Nz, s->lower, s->diag, s->lower, s->xfield, s->tscr, s->xsol, stream);
+        if (st != OCN_SUCCESS) return st;
+        // zero-mean gauge on the (kx, ky) = (0, 0) column, which lives on rank 0 (stored position 0 is wavenumber 0):
+        // the single-process solver's ϕ .- mean(ϕ) (fourier_tridiagonal_poisson_solver.jl:142)
+        if (s->rank == 0) {
+            st = ocn::launch_remove_mean_mode((long long)s->Nxg * s->ny, Nz, s->xsol, stream);
+            if (st != OCN_SUCCESS) return st;
+        }
+        return s->bx.exec(s->xsol, s->xfield, stream);
+    }
     // λy partitioned to this rank's j range; rank 0 zeroes mode (1,1,1) (distributed_fft_based_poisson_solver.jl:104-116,162-164)
     st = ocn::launch_spectral_solve(s->Nxg, s->ny, s->grid.Nz, s->lx, s->ly, s->lz, s->xfield, s->rank == 0, s->rank * s->ny, 0, stream);
     if (st != OCN_SUCCESS) return st;
@@ -589,6 +690,11 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
 {
     OCN_REQUIRE(s && p, "ocn_dist_poisson_backward_yz: null argument");
     hipStream_t stream = ocn::as_stream(stream_);
+    if (s->tri) {
+        int st = dist_tri_y_transform(s, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        return ocn::launch_copy_real(&s->grid, s->yfield, p, stream, 0);
+    }
     if (s->r2c) {
         ocn::GridDev gd = ocn::to_dev(s->grid);
         ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);

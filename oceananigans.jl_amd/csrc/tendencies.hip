@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
         const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
         const long long o = ocn::at(Lw, i, j, k);
         Gw[o] = G;
-        if (fz.on) fz.Uo[2][o] = pw[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][o]) : (fz.dt * fz.gamma) * G);
+        const bool wall = (TZ == OCN_BOUNDED) && k == 1 && Nz > 1;  // rk3_substep! never steps the wall face
+        if (fz.on) fz.Uo[2][o] = wall ? pw[0] : pw[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][o]) : (fz.dt * fz.gamma) * G);
     } else if (fz.on) {
         fz.Uo[2][ocn::at(Lw, i, j, k)] = pw[0];  // wall face (exclude_periphery): carried over unchanged
     }
@@ -437,7 +438,10 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                 const double rVf = recip_volume(M.Az * M.dzF(k));
                 const double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
                 Gw[ow_] = G;
-                if (fz.on) fz.Uo[2][ow_] = zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]) : (fz.dt * fz.gamma) * G);
+                // rk3_substep! always excludes the wall face (runge_kutta_3.jl:171-174), even when a KernelParameters range
+                // made the tendency kernel write Gw there
+                const bool wall = (TZ == OCN_BOUNDED) && k == 1 && Nz > 1;
+                if (fz.on) fz.Uo[2][ow_] = wall ? zw[2] : zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]) : (fz.dt * fz.gamma) * G);
             } else if (fz.on) {
                 fz.Uo[2][ow_] = zw[2];  // wall face: neither the tendency nor the substep touch it (exclude_periphery)
             }

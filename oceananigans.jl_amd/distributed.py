@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .architectures import GPU, device, stream_ptr
-from .grids import FullyConnected, Periodic, RectilinearGrid
+from .grids import Bounded, FullyConnected, Periodic, RectilinearGrid
 
 
 class Partition:
@@ -220,6 +220,8 @@ class Distributed:
             launch((e0, nx, 1, g.Ny, 1, g.Nz))
 
     def pressure_solver(self, grid):
+        if grid.topology[2] == Bounded:
+            return DistributedFourierTridiagonalPoissonSolver(grid)
         return DistributedFFTBasedPoissonSolver(grid)
 
 
@@ -315,11 +317,15 @@ class DistributedFFTBasedPoissonSolver:
         arch = grid.architecture
         self.grid, self.arch = grid, arch
         self.R = arch.partition.x
-        if grid.topology[1] != Periodic or grid.topology[2] != Periodic:
-            raise NotImplementedError("DistributedFFTBasedPoissonSolver: (x-partitioned, Periodic, Periodic) only")
+        self._check_topology(grid)
         if grid.Ny % self.R:
             raise ValueError(f"Ny = {grid.Ny} must be divisible by Rx = {self.R}")  # :211-229
         self.impl = arch.ops.make_dist_poisson(grid, arch)
+
+    @staticmethod
+    def _check_topology(grid):
+        if grid.topology[1] != Periodic or grid.topology[2] != Periodic:
+            raise NotImplementedError("DistributedFFTBasedPoissonSolver: (x-partitioned, Periodic, Periodic) only")
 
     def compute_source_term(self, u, v, w, dt):
         self.impl.source_term(u, v, w, dt)
@@ -341,6 +347,20 @@ class DistributedFFTBasedPoissonSolver:
         impl.unpack_y_from_x(self._all_to_all())
         impl.backward_yz(p)
         return p
+
+
+class DistributedFourierTridiagonalPoissonSolver(DistributedFFTBasedPoissonSolver):
+    """DistributedFourierTridiagonalPoissonSolver, ZStretched flavour, for slab-x and a Bounded (regular or stretched) z
+    (distributed_fft_tridiagonal_solver.jl:149-292): FFT_y local -> y->x all-to-all -> FFT_x -> batched Thomas sweep in z
+    with this rank's ky range -> IFFT_x -> x->y all-to-all -> IFFT_y -> real part.  z stays local in both layouts, so the
+    reference's additional transposes to a z-local pencil are not needed; the same `solve` choreography as the FFT solver
+    applies with the library's handle in its tridiagonal mode.  The (kx, ky) = (0, 0) column gets the zero-mean gauge of the
+    single-process solver (the reference's distributed solver leaves that constant undetermined)."""
+
+    @staticmethod
+    def _check_topology(grid):
+        if grid.topology[1] != Periodic or grid.topology[2] != Bounded:
+            raise NotImplementedError("DistributedFourierTridiagonalPoissonSolver: (x-partitioned, Periodic, Bounded) only")
 
 
 class _DevBuf:

@@ -79,6 +79,53 @@ class _NumpyDistPoisson:
         fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = self.y.real
 
 
+class _NumpyDistTridiagonal(_NumpyDistPoisson):
+    """z Bounded: FFT_y on the slab -> y->x all-to-all -> FFT_x -> Thomas sweep in z with this rank's ky range -> zero-mean
+    gauge on the (0,0) column (rank 0) -> IFFT_x -> x->y all-to-all -> IFFT_y -> real part
+    (distributed_fft_tridiagonal_solver.jl:260-292 with the z-local pencil transposes elided: z is local throughout)."""
+
+    def __init__(self, grid, arch):
+        self.g, self.R, self.rank = grid, arch.partition.x, arch.local_rank
+        nx, Ny, Nz = grid.Nx, grid.Ny, grid.Nz
+        self.ny, self.Nxg = Ny // self.R, nx * self.R
+        self.y = np.zeros((nx, Ny, Nz), dtype=np.complex128, order="F")
+        self.x = np.zeros((self.Nxg, self.ny, Nz), dtype=np.complex128, order="F")
+        n = nx * Ny * Nz * 2
+        self.send, self.recv = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        zf = getattr(grid, "z_faces", None)
+        z = (0.0, grid.Lz) if zf is None else np.asarray(zf)[grid.Hz:grid.Hz + Nz + 1]
+        halo = (grid.Hx, grid.Hy, grid.Hz)
+        self.og = O.Grid((nx, Ny, Nz), x=(0, grid.Lx), y=(0, grid.Ly), z=z, topology="PPB", halo=halo)
+        self.local = O.FourierTridiagonalPoissonSolver(self.og)
+        # the x-local layout as a grid of its own: Nxg global x modes, this rank's ny stored ky
+        xg = O.Grid((self.Nxg, self.ny, Nz), x=(0, grid.global_Lx), y=(0, grid.Ly), z=z, topology="PPB",
+                    halo=(min(halo[0], self.Nxg), min(halo[1], self.ny), halo[2]))
+        self.xs = O.FourierTridiagonalPoissonSolver(xg)
+        lx = O.poisson_eigenvalues(self.Nxg, grid.global_Lx, O.PERIODIC)
+        ly = np.ascontiguousarray(O.poisson_eigenvalues(Ny, grid.Ly, O.PERIODIC)[self.rank * self.ny:(self.rank + 1) * self.ny])
+        O.lib().ocn_oracle_main_diagonal_z(O.C.byref(self.xs._cg), lx.ctypes.data_as(O.C.c_void_p), ly.ctypes.data_as(O.C.c_void_p),
+                                           self.xs.D.ctypes.data_as(O.C.c_void_p))
+
+    def source_term(self, u, v, w, dt):
+        self.local.source_term(np.asfortranarray(fview(u)), np.asfortranarray(fview(v)), np.asfortranarray(fview(w)), dt)
+        self.y[...] = self.local.source
+
+    def forward_yz(self):
+        self.y[...] = sfft.fft(self.y, axis=1)
+
+    def solve_x(self):
+        xh = np.asfortranarray(sfft.fft(self.x, axis=0))
+        phi = O.batched_tridiagonal_solve_z(self.xs.a, self.xs.D, self.xs.a, xh)
+        if self.rank == 0:
+            phi[0, 0, :] -= np.mean(phi[0, 0, :])
+        self.x[...] = sfft.ifft(phi, axis=0)
+
+    def backward_yz(self, p):
+        self.y[...] = sfft.ifft(self.y, axis=1)
+        g = self.g
+        fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = self.y.real
+
+
 class NumpyOps:
     name = "numpy"
 
@@ -86,10 +133,23 @@ class NumpyOps:
         return torch.zeros(n, dtype=torch.float64)
 
     def local_fill(self, grid, fields, fbnv):
-        for f in fields:  # periodic y, z fills over the whole parent cross-section; x is communication
+        bounded_z = grid.topology[2] == "Bounded"
+        if bounded_z:
+            og = O.Grid((grid.Nx, grid.Ny, grid.Nz), x=(0, 1), y=(0, 1), z=(0, 1), topology="PPB", halo=(grid.Hx, grid.Hy, grid.Hz))
+        for f in fields:  # y, z fills over the whole parent cross-section; x is communication
             a = fview(f)
             sx, sy, sz = a.shape
+            if bounded_z:  # impenetrable w (if asked) and no-flux for the rest, before the periodic fills
+                tmp = np.asfortranarray(a)
+                if f.loc == 4:
+                    if fbnv:
+                        O.lib().ocn_oracle_fill_open(og.cref, f.loc, tmp.ctypes.data_as(O.C.c_void_p), 2)
+                else:
+                    O.lib().ocn_oracle_fill_flux(og.cref, f.loc, tmp.ctypes.data_as(O.C.c_void_p), 2)
+                a[...] = tmp
             for d, (N, H) in ((1, (grid.Ny, grid.Hy)), (2, (grid.Nz, grid.Hz))):
+                if d == 2 and bounded_z:
+                    continue
                 tmp = np.asfortranarray(a)
                 O.lib().ocn_oracle_fill_periodic(tmp.ctypes.data_as(O.C.c_void_p), sx, sy, sz, d, N, H)
                 a[...] = tmp
@@ -109,4 +169,6 @@ class NumpyOps:
         pass
 
     def make_dist_poisson(self, grid, arch):
+        if grid.topology[2] == "Bounded":
+            return _NumpyDistTridiagonal(grid, arch)
         return _NumpyDistPoisson(grid, arch)

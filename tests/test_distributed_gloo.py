@@ -145,6 +145,41 @@ def _poisson_matches_global(rank, world, ocn, arch):
     assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def _tridiagonal_poisson_matches_global(rank, world, ocn, arch):
+    """(x-partitioned, Periodic, Bounded) stretched z: the distributed Fourier-tridiagonal solve equals the single-process
+    FourierTridiagonalPoissonSolver on the assembled field (test_distributed_poisson_solvers.jl:128-148 re-expressed)."""
+    from helpers import stretched_faces
+    from oracle import oracle as O
+    Nx, Ny, Nz = 12, 6 * world, 9
+    zf = stretched_faces(Nz)
+    P = "Periodic"
+    g = ocn.RectilinearGrid(arch, size=(Nx, Ny, Nz), x=(0.0, 3.0), y=(0, 2.0), z=zf, topology=(P, P, "Bounded"), halo=(3, 3, 3))
+    og = O.Grid((Nx, Ny, Nz), x=(0, 3.0), y=(0, 2.0), z=zf, topology="PPB", halo=(3, 3, 3))
+    rng = np.random.default_rng(43)
+    hosts = []
+    for loc in (1, 2, 4):
+        a = og.zeros(loc)
+        og.interior(a)[...] = rng.random(og.interior(a).shape)
+        O.fill_halo_regions(og, a, loc)
+        hosts.append(a)
+    S = O.FourierTridiagonalPoissonSolver(og)
+    p0 = og.zeros(0)
+    S.source_term(*hosts, 0.7)
+    S.solve(p0)
+    nx = g.Nx
+    U = [ocn.Field(loc, g) for loc in (1, 2, 4)]
+    for f, a in zip(U, hosts):
+        f.set(og.interior(a)[rank * nx:(rank + 1) * nx])
+    ocn.fill_halo_regions(U)
+    solver = ocn.nonhydrostatic_pressure_solver(g)
+    assert isinstance(solver, ocn.DistributedFourierTridiagonalPoissonSolver)
+    p = ocn.CenterField(g)
+    ocn.solve_for_pressure(p, solver, 0.7, U)
+    mine = p.interior()
+    ref = og.interior(p0)[rank * nx:(rank + 1) * nx]
+    assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_halo_is_neighbour_id(world):
     _run(world, _halo_is_neighbour_id)
@@ -162,3 +197,8 @@ def test_transpose_round_trip_two_ranks():
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_poisson_matches_global_solve(world):
     _run(world, _poisson_matches_global)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_tridiagonal_poisson_matches_global_solve(world):
+    _run(world, _tridiagonal_poisson_matches_global)
