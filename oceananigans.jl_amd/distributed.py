@@ -81,8 +81,8 @@ class HipOps:
         return torch.zeros(n, dtype=torch.float64, device=device(arch.child_architecture))
 
     def local_fill(self, grid, fields, fbnv):
-        _lib.call("ocn_fill_halo_regions", grid.cref, _lib.ptr_array([f.ptr for f in fields]),
-                  _lib.i32_array([f.loc for f in fields]), len(fields), int(bool(fbnv)), stream_ptr())
+        from .fields import local_fill_halo_regions
+        local_fill_halo_regions(grid, fields, fbnv)
 
     def pack_x(self, grid, f, west, east):
         _lib.call("ocn_halo_pack_x", grid.cref, f.ptr, f.loc, west.data_ptr(), east.data_ptr(), stream_ptr())
@@ -180,6 +180,15 @@ class Distributed:
         from . import models
         g = model.grid
         fields = model.prognostic_fields()
+        if getattr(model, "general_terms", False):
+            # Coriolis / closure / buoyancy / boundary conditions: the hydrostatic pressure anomaly is integrated over
+            # i in 0:nx+1 and needs the exchanged tracer halos, so this path completes the exchange first and computes the
+            # tendencies of the whole slab in one go (no interior / buffer overlap yet)
+            self.fill_halo_regions(fields, False)
+            models.update_hydrostatic_pressure(model)
+            if compute_tendencies:
+                models.compute_tendencies_(model)
+            return
         self.ops.local_fill(g, fields, False)
         pending = self.start_halo_exchange(fields)
         nx, Hx = g.Nx, g.Hx

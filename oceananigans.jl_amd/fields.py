@@ -85,19 +85,9 @@ def CenterField(grid, boundary_conditions=None):
     return Field(_lib.LOC_CCC, grid, boundary_conditions=boundary_conditions)
 
 
-def fill_halo_regions(fields, fill_boundary_normal_velocities=True, **_):
-    """fill_halo_regions!(field or tuple of fields): one launch for the whole tuple."""
-    if isinstance(fields, Field):
-        fields = (fields,)
-    fields = tuple(fields)
-    if not fields:
-        return
-    grid = fields[0].grid
-    hook = getattr(grid.architecture, "fill_halo_regions", None)
-    if hook is not None:  # Distributed: local fills + x-halo exchange (distributed.py)
-        if any(getattr(f, "boundary_conditions", None) is not None and not f.boundary_conditions.is_default() for f in fields):
-            raise NotImplementedError("user boundary conditions on a Distributed architecture are not implemented")
-        return hook(fields, fill_boundary_normal_velocities)
+def local_fill_halo_regions(grid, fields, fill_boundary_normal_velocities=True):
+    """The rank-local part of fill_halo_regions! (one launch for the whole tuple): Periodic copies, no-flux / impenetrable
+    walls, and the fields' own bottom / top Value / Gradient conditions."""
     bcs = [getattr(f, "boundary_conditions", None) for f in fields]
     if any(b is not None and not b.is_default() for b in bcs):
         import ctypes as C
@@ -109,3 +99,17 @@ def fill_halo_regions(fields, fill_boundary_normal_velocities=True, **_):
         return
     _lib.call("ocn_fill_halo_regions", grid.cref, _lib.ptr_array([f.ptr for f in fields]),
               _lib.i32_array([f.loc for f in fields]), len(fields), int(bool(fill_boundary_normal_velocities)), stream_ptr())
+
+
+def fill_halo_regions(fields, fill_boundary_normal_velocities=True, **_):
+    """fill_halo_regions!(field or tuple of fields): one launch for the whole tuple."""
+    if isinstance(fields, Field):
+        fields = (fields,)
+    fields = tuple(fields)
+    if not fields:
+        return
+    grid = fields[0].grid
+    hook = getattr(grid.architecture, "fill_halo_regions", None)
+    if hook is not None:  # Distributed: local fills + x-halo exchange (distributed.py)
+        return hook(fields, fill_boundary_normal_velocities)
+    local_fill_halo_regions(grid, fields, fill_boundary_normal_velocities)

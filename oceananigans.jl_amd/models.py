@@ -144,8 +144,9 @@ class NonhydrostaticModel:
         self._has_flux_bcs = any(b.has_flux() for b in bcs.values())
         self.general_terms = (isinstance(advection, Centered) or coriolis is not None or closure is not None
                               or buoyancy is not None or self._has_user_bcs)
-        if self.general_terms and hasattr(grid.architecture, "partition"):
-            raise NotImplementedError("coriolis / closure / buoyancy / boundary conditions on a Distributed architecture are not implemented yet")
+        if self._has_user_bcs and hasattr(grid.architecture, "partition") and any(
+                s is not None and s.values is not None for b in bcs.values() for s in b.sides.values()):
+            raise NotImplementedError("array boundary conditions on a Distributed architecture are not implemented")
         self._terms = self._make_terms()
         # fused stage boundaries (tendencies + next substep in one launch) need the tiled kernel, no tracers, one rank
         self.fuse_stage_boundaries = not self.tracers and not self.general_terms

@@ -136,6 +136,58 @@ def test_distributed_steps_match_single_rank(ocn, R, topo):
             assert np.abs(a - b[sl]).max() <= 1e-9 * max(1.0, np.abs(b).max())
 
 
+@pytest.mark.parametrize("R", [2, 4])
+def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R):
+    """Config 4's physics (buoyancy, Coriolis, diffusivity, flux / gradient boundary conditions; LES closure replaced by a
+    constant ScalarDiffusivity) on R slab-x ranks against the single-rank model: 2 RK3 steps."""
+    from helpers import stretched_faces
+    P = "Periodic"
+    N = (32, 16, 12)
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
+    rng = np.random.default_rng(77)
+    init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    init["w"] = 1e-2 * rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
+    init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
+    init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
+    dt = 1.0
+
+    def build(grid):
+        bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-3e-4)),
+               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+               "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-2.8e-7))}
+        return ocn.NonhydrostaticModel(grid, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
+                                       closure=ocn.ScalarDiffusivity(ν=1e-3, κ=2e-3),
+                                       buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                       boundary_conditions=bcs)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sm = build(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext))
+    ocn.set(sm, **init)
+    for _ in range(2):
+        ocn.time_step(sm, dt)
+    ocn.sync_device()
+    ref = [f.interior() for f in sm.prognostic_fields()] + [sm.pHY.interior()]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        m = build(ocn.RectilinearGrid(arch, size=N, **ext))
+        nx = m.grid.Nx
+        ocn.set(m, **{k: v[r * nx:(r + 1) * nx] for k, v in init.items()})
+        for _ in range(2):
+            ocn.time_step(m, dt)
+        ocn.sync_device()
+        return [f.interior() for f in m.prognostic_fields()] + [m.pHY.interior()]
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    vscale = max(np.abs(a).max() for a in ref[:3])
+    for r, fields in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "T", "S", "pHY")):
+            scale = vscale if name in "uvw" else np.abs(b).max()
+            assert np.abs(a - b[sl]).max() <= 1e-11 * scale, f"rank {r} field {name}"
+
+
 def test_distributed_halo_exchange_on_gpu(ocn):
     R = 2
     P = "Periodic"
