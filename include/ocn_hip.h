@@ -154,7 +154,9 @@ typedef struct ocn_model_terms {
     int32_t advection; /* OCN_ADVECTION_* */
     int32_t coriolis;  /* 0 nothing, 1 FPlane(f)                                            src/Coriolis/f_plane.jl:44-46 */
     int32_t closure;   /* 0 nothing, 1 ScalarDiffusivity(ν, κ): ThreeDimensionalFormulation, ExplicitTimeDiscretization,
-                          constant coefficients                    abstract_scalar_diffusivity_closure.jl:158-223 */
+                          constant coefficients                    abstract_scalar_diffusivity_closure.jl:158-223;
+                          2 AnisotropicMinimumDissipation: the same isotropic stress with the eddy viscosity field nu_e
+                          (anisotropic_minimum_dissipation.jl:20-21) */
     int32_t buoyancy;  /* OCN_BUOYANCY_* */
     double f;          /* FPlane.f */
     double nu;         /* ScalarDiffusivity.ν */
@@ -163,6 +165,7 @@ typedef struct ocn_model_terms {
     const double *S;   /* DEVICE: salinity; NULL if unused */
     const double *pHY; /* DEVICE: hydrostatic pressure anomaly pHY′ (model.pressures.pHY′) or NULL = `nothing`
                           (then w receives z_dot_g_b directly, nonhydrostatic_tendency_kernel_functions.jl:141-143) */
+    const double *nu_e; /* DEVICE: closure == 2: diffusivity_fields.νₑ (Center field, halos filled); else NULL */
 } ocn_model_terms;
 
 /* compute_Gu!/Gv!/Gw! with every supported term:
@@ -172,10 +175,19 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
                                           const double *w, double *Gu, double *Gv, double *Gw, const int32_t *range,
                                           void *stream);
 /* compute_Gc! with advection scheme terms->advection and, when terms->closure != 0, the diffusive flux divergence
- *   Gc = -div_Uc - ∇_dot_qᶜ,  q = -κ ∇c      (:250-256; closure_kernel_operators.jl:48-53) */
-int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *u,
-                                      const double *v, const double *w, const double *c, double *Gc, const int32_t *range,
-                                      void *stream);
+ *   Gc = -div_Uc - ∇_dot_qᶜ,  q = -κ ∇c      (:250-256; closure_kernel_operators.jl:48-53)
+ * kappa_e != NULL (closure == 2): the tracer's eddy diffusivity field κₑ (Center, halos filled) replaces the number kappa. */
+int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
+                                      const double *u, const double *v, const double *w, const double *c, double *Gc,
+                                      const int32_t *range, void *stream);
+/* compute_diffusivities!(diffusivity_fields, ::AnisotropicMinimumDissipation, model) with Cb = nothing
+ * (anisotropic_minimum_dissipation.jl:125-188): νₑ = max(0, -Cν δ² r / q) and, per tracer, κₑ = max(0, -Cκ δ² ϑ / σ) over the
+ * interior; the caller fills their halos afterwards (update_nonhydrostatic_model_state.jl:48).  Velocity / tracer halos
+ * must be filled; z must not be Flat. */
+int ocn_compute_amd_viscosity(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w, double *nu_e,
+                              void *stream);
+int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const double *u, const double *v, const double *w,
+                                const double *c, double *kappa_e, void *stream);
 /* update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-53): pHY′ by downward integration of the buoyancy
  * perturbation over i in 0:Nx+1, j in 0:Ny+1 (tracer halos must be filled).  No-op on a z-Flat grid. */
 int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream);

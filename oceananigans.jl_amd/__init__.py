@@ -15,10 +15,11 @@ from .distributed import (Distributed, DistributedFFTBasedPoissonSolver, Distrib
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,
-                     cache_previous_tendencies, calculate_pressure_correction, compute_tendencies, flush_tendencies,
+                     cache_previous_tendencies, calculate_pressure_correction, compute_auxiliaries, compute_diffusivities,
+                     compute_tendencies, flush_tendencies,
                      pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_hydrostatic_pressure,
                      update_state)
-from .physics import (BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
+from .physics import (AnisotropicMinimumDissipation, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
                       GradientBoundaryCondition, LinearEquationOfState, ScalarDiffusivity, SeawaterBuoyancy,
                       ValueBoundaryCondition)
 from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver,

@@ -32,7 +32,7 @@ class CModelTerms(C.Structure):
     """struct ocn_model_terms"""
     _fields_ = [("advection", C.c_int32), ("coriolis", C.c_int32), ("closure", C.c_int32), ("buoyancy", C.c_int32),
                 ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
-                ("T", C.c_void_p), ("S", C.c_void_p), ("pHY", C.c_void_p)]
+                ("T", C.c_void_p), ("S", C.c_void_p), ("pHY", C.c_void_p), ("nu_e", C.c_void_p)]
 
 
 class CBc(C.Structure):
@@ -69,7 +69,9 @@ _SIGS = {
     "ocn_compute_momentum_tendencies_rk3": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, C.POINTER(_i32), _vp],
     "ocn_compute_tracer_tendency": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_momentum_tendencies_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
-    "ocn_compute_tracer_tendency_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_tracer_tendency_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_amd_viscosity": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp, _vp],
+    "ocn_compute_amd_diffusivity": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_update_hydrostatic_pressure": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp],
     "ocn_fill_halo_regions_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _i32, _vp],
     "ocn_apply_flux_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _vp],

@@ -207,7 +207,9 @@ static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
     OCN_REQUIRE(t != nullptr, "terms is NULL");
     OCN_REQUIRE(t->advection == OCN_ADVECTION_WENO5 || t->advection == OCN_ADVECTION_CENTERED2, "unknown advection scheme %d", t->advection);
     OCN_REQUIRE(t->coriolis == 0 || t->coriolis == 1, "unknown coriolis code %d", t->coriolis);
-    OCN_REQUIRE(t->closure == 0 || t->closure == 1, "unknown closure code %d", t->closure);
+    OCN_REQUIRE(t->closure >= 0 && t->closure <= 2, "unknown closure code %d", t->closure);
+    OCN_REQUIRE((t->closure == 2) == (t->nu_e != nullptr), "nu_e must be given exactly when closure == 2 (AnisotropicMinimumDissipation)");
+    OCN_REQUIRE(t->closure != 2 || grid->tz != OCN_FLAT, "AnisotropicMinimumDissipation needs a non-Flat z");
     OCN_REQUIRE(t->buoyancy >= OCN_BUOYANCY_NONE && t->buoyancy <= OCN_BUOYANCY_SEAWATER_S, "unknown buoyancy code %d", t->buoyancy);
     if (t->buoyancy == OCN_BUOYANCY_TRACER || t->buoyancy == OCN_BUOYANCY_SEAWATER_TS || t->buoyancy == OCN_BUOYANCY_SEAWATER_T)
         OCN_REQUIRE(t->T != nullptr, "buoyancy formulation %d needs the T (or b) tracer", t->buoyancy);
@@ -244,9 +246,9 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
                   : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s);
 }
 
-int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *u,
-                                      const double *v, const double *w, const double *c, double *Gc, const int32_t *range,
-                                      void *stream)
+int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
+                                      const double *u, const double *v, const double *w, const double *c, double *Gc,
+                                      const int32_t *range, void *stream)
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
@@ -260,8 +262,38 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
         st = strict ? ocn_strict::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s)
                     : ocn_fast::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s);
     if (st != OCN_SUCCESS || !terms->closure) return st;
-    return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, c, Gc, range, s)
-                  : ocn_fast::launch_tracer_diffusion(grid, kappa, c, Gc, range, s);
+    OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
+    return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s)
+                  : ocn_fast::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s);
+}
+
+static int validate_amd(const ocn_grid *grid)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->tz != OCN_FLAT, "AnisotropicMinimumDissipation needs a non-Flat z");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && grid->Hz >= 1, "AnisotropicMinimumDissipation needs halo >= 1");
+    return OCN_SUCCESS;
+}
+
+int ocn_compute_amd_viscosity(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w, double *nu_e,
+                              void *stream)
+{
+    int st = validate_amd(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && nu_e, "ocn_compute_amd_viscosity: null field pointer");
+    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream))
+                                          : ocn_fast::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream));
+}
+
+int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const double *u, const double *v, const double *w,
+                                const double *c, double *kappa_e, void *stream)
+{
+    int st = validate_amd(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && c && kappa_e, "ocn_compute_amd_diffusivity: null field pointer");
+    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_amd_diffusivity(grid, C_kappa, u, v, w, c, kappa_e, as_stream(stream))
+                                          : ocn_fast::launch_amd_diffusivity(grid, C_kappa, u, v, w, c, kappa_e, as_stream(stream));
 }
 
 int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream)

@@ -98,6 +98,7 @@ struct TermsDev {
     int coriolis, closure, buoyancy;
     double f, nu, g, alpha, beta;
     const double *T, *S, *pHY;
+    const double *nu_e;  // eddy viscosity νₑ (ccc, halos filled) of an LES closure, or NULL: the number `nu`
 };
 inline TermsDev to_dev(const ocn_model_terms &m)
 {
@@ -105,6 +106,7 @@ inline TermsDev to_dev(const ocn_model_terms &m)
     t.coriolis = m.coriolis; t.closure = m.closure; t.buoyancy = m.buoyancy;
     t.f = m.f; t.nu = m.nu; t.g = m.g; t.alpha = m.alpha; t.beta = m.beta;
     t.T = m.T; t.S = m.S; t.pHY = m.pHY;
+    t.nu_e = m.nu_e;
     return t;
 }
 

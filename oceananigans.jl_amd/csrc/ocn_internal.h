@@ -76,8 +76,12 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
                             double *Gc, const int32_t *range, hipStream_t stream);
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
-int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
-                            hipStream_t stream);
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                            const int32_t *range, hipStream_t stream);
+int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
+                         hipStream_t stream);
+int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
+                           double *kappa_e, hipStream_t stream);
 }
 namespace ocn_fast {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
@@ -90,6 +94,10 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
                             double *Gc, const int32_t *range, hipStream_t stream);
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
-int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
-                            hipStream_t stream);
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                            const int32_t *range, hipStream_t stream);
+int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
+                         hipStream_t stream);
+int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
+                           double *kappa_e, hipStream_t stream);
 }

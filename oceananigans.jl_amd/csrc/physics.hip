@@ -187,8 +187,22 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
 #define DY(a, b) OCN_DIV((a) - (b), dy, rdy)
 #define DZF(a, b) (ZF ? 0.0 : OCN_DIV((a) - (b), dzf, rdzf))      /* derivative at z-face k   */
 #define DZF1(a, b) (ZF ? 0.0 : OCN_DIV((a) - (b), dzf1, rdzf1))   /* derivative at z-face k+1 */
-#define TAU(s) (-2 * (nu * (s)))
+#define TAU(nuv, s) (-2 * ((nuv) * (s)))
     const double Axc = M.Ax(k), Ayc = M.Ay(k), Az = M.Az;
+    // viscosity at the stress locations: the number ν, or the ccc array νₑ of an eddy-viscosity closure interpolated with
+    // ℑxyᶠᶠᵃ / ℑxzᶠᵃᶠ / ℑyzᵃᶠᶠ (abstract_scalar_diffusivity_closure.jl:291-296)
+    const double *pn = t.nu_e ? t.nu_e + o : nullptr;
+#define NE(a, b, c) pn[(a) + (b)*s2 + (c)*s3]
+    auto nuC = [&](int a, int b, int c) { return pn ? NE(a, b, c) : nu; };
+    auto nuFFC = [&](int a, int b, int c) {
+        return pn ? 0.5 * (0.5 * (NE(a - 1, b - 1, c) + NE(a, b - 1, c)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu;
+    };
+    auto nuFCF = [&](int a, int b, int c) {
+        return pn ? 0.5 * (0.5 * (NE(a - 1, b, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu;
+    };
+    auto nuCFF = [&](int a, int b, int c) {
+        return pn ? 0.5 * (0.5 * (NE(a, b - 1, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a, b - 1, c) + NE(a, b, c))) : nu;
+    };
 
     {   // ---------------- Gu at (f,c,c)
         double G = Gu[o];
@@ -199,13 +213,13 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
         }
         if (t.pHY) G = G - DX(t.pHY[o], t.pHY[o - 1]);  // ∂xᶠᶜᶜ pHY′
         if (t.closure) {
-            const double t11e = TAU(DX(U_(1, 0, 0), U_(0, 0, 0))), t11w = TAU(DX(U_(0, 0, 0), U_(-1, 0, 0)));
-            const double t12n = TAU(0.5 * (DY(U_(0, 1, 0), U_(0, 0, 0)) + DX(V_(0, 1, 0), V_(-1, 1, 0))));
-            const double t12s = TAU(0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
+            const double t11e = TAU(nuC(0, 0, 0), DX(U_(1, 0, 0), U_(0, 0, 0))), t11w = TAU(nuC(-1, 0, 0), DX(U_(0, 0, 0), U_(-1, 0, 0)));
+            const double t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(U_(0, 1, 0), U_(0, 0, 0)) + DX(V_(0, 1, 0), V_(-1, 1, 0))));
+            const double t12s = TAU(nuFFC(0, 0, 0), 0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
             double dzF = 0.0;
             if (!ZF) {
-                const double t13t = TAU(0.5 * (DZF1(U_(0, 0, 1), U_(0, 0, 0)) + DX(W_(0, 0, 1), W_(-1, 0, 1))));
-                const double t13b = TAU(0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
+                const double t13t = TAU(nuFCF(0, 0, 1), 0.5 * (DZF1(U_(0, 0, 1), U_(0, 0, 0)) + DX(W_(0, 0, 1), W_(-1, 0, 1))));
+                const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
                 dzF = Az * t13t - Az * t13b;
             }
             G = G - 1 / (Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
@@ -221,13 +235,13 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
         }
         if (t.pHY) G = G - DY(t.pHY[o], t.pHY[o - s2]);
         if (t.closure) {
-            const double t12e = TAU(0.5 * (DY(U_(1, 0, 0), U_(1, -1, 0)) + DX(V_(1, 0, 0), V_(0, 0, 0))));
-            const double t12w = TAU(0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
-            const double t22n = TAU(DY(V_(0, 1, 0), V_(0, 0, 0))), t22s = TAU(DY(V_(0, 0, 0), V_(0, -1, 0)));
+            const double t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(U_(1, 0, 0), U_(1, -1, 0)) + DX(V_(1, 0, 0), V_(0, 0, 0))));
+            const double t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
+            const double t22n = TAU(nuC(0, 0, 0), DY(V_(0, 1, 0), V_(0, 0, 0))), t22s = TAU(nuC(0, -1, 0), DY(V_(0, 0, 0), V_(0, -1, 0)));
             double dzF = 0.0;
             if (!ZF) {
-                const double t23t = TAU(0.5 * (DZF1(V_(0, 0, 1), V_(0, 0, 0)) + DY(W_(0, 0, 1), W_(0, -1, 1))));
-                const double t23b = TAU(0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+                const double t23t = TAU(nuCFF(0, 0, 1), 0.5 * (DZF1(V_(0, 0, 1), V_(0, 0, 0)) + DY(W_(0, 0, 1), W_(0, -1, 1))));
+                const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
                 dzF = Az * t23t - Az * t23b;
             }
             G = G - 1 / (Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
@@ -244,14 +258,14 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
         if (t.coriolis) G = G - 0.0;  // z_f_cross_U = 0
         if (t.closure) {
             const double Axf = dy * dzf, Ayf = dx * dzf;
-            const double t13e = TAU(0.5 * (DZF(U_(1, 0, 0), U_(1, 0, -1)) + DX(W_(1, 0, 0), W_(0, 0, 0))));
-            const double t13w = TAU(0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
-            const double t23n = TAU(0.5 * (DZF(V_(0, 1, 0), V_(0, 1, -1)) + DY(W_(0, 1, 0), W_(0, 0, 0))));
-            const double t23s = TAU(0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+            const double t13e = TAU(nuFCF(1, 0, 0), 0.5 * (DZF(U_(1, 0, 0), U_(1, 0, -1)) + DX(W_(1, 0, 0), W_(0, 0, 0))));
+            const double t13w = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
+            const double t23n = TAU(nuCFF(0, 1, 0), 0.5 * (DZF(V_(0, 1, 0), V_(0, 1, -1)) + DY(W_(0, 1, 0), W_(0, 0, 0))));
+            const double t23s = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
             double dzF = 0.0;
             if (!ZF) {
-                const double t33t = TAU(OCN_DIV(W_(0, 0, 1) - W_(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
-                const double t33b = TAU(OCN_DIV(W_(0, 0, 0) - W_(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
+                const double t33t = TAU(nuC(0, 0, 0), OCN_DIV(W_(0, 0, 1) - W_(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
+                const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(W_(0, 0, 0) - W_(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
                 dzF = Az * t33t - Az * t33b;
             }
             G = G - 1 / (Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
@@ -262,8 +276,8 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
 
 // Gc <- Gc - ∇_dot_qᶜ,  q = -(κ ∂c)  (closure_kernel_operators.jl:48-53)
 template <int TZ>
-__global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double kappa, const double *__restrict__ c,
-                                                               double *__restrict__ Gc, PRange r)
+__global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double kappa, const double *__restrict__ kappa_e,
+                                                               const double *__restrict__ c, double *__restrict__ Gc, PRange r)
 {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -280,13 +294,21 @@ __global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double
 #endif
     const double Ax = M.Ax(k), Ay = M.Ay(k), Az = M.Az;
     const double c0 = C_(0, 0, 0);
-    const double qxe = -(kappa * DX(C_(1, 0, 0), c0)), qxw = -(kappa * DX(c0, C_(-1, 0, 0)));
-    const double qyn = -(kappa * DY(C_(0, 1, 0), c0)), qys = -(kappa * DY(c0, C_(0, -1, 0)));
+    // κ at the flux faces: the number κ, or κₑ interpolated with ℑxᶠᵃᵃ / ℑyᵃᶠᵃ / ℑzᵃᵃᶠ (abstract_scalar_diffusivity_closure.jl:298-300)
+    const double *pk = kappa_e ? kappa_e + o : nullptr;
+#define KE(a, b, cc) pk[(a) + (b)*s2 + (cc)*s3]
+    const double k0 = pk ? KE(0, 0, 0) : kappa;
+    const double kxe = pk ? 0.5 * (k0 + KE(1, 0, 0)) : kappa, kxw = pk ? 0.5 * (KE(-1, 0, 0) + k0) : kappa;
+    const double kyn = pk ? 0.5 * (k0 + KE(0, 1, 0)) : kappa, kys = pk ? 0.5 * (KE(0, -1, 0) + k0) : kappa;
+    const double qxe = -(kxe * DX(C_(1, 0, 0), c0)), qxw = -(kxw * DX(c0, C_(-1, 0, 0)));
+    const double qyn = -(kyn * DY(C_(0, 1, 0), c0)), qys = -(kys * DY(c0, C_(0, -1, 0)));
     double dzF = 0.0;
     if (!ZF) {
-        const double qzt = -(kappa * DZF1(C_(0, 0, 1), c0)), qzb = -(kappa * DZF(c0, C_(0, 0, -1)));
+        const double kzt = pk ? 0.5 * (k0 + KE(0, 0, 1)) : kappa, kzb = pk ? 0.5 * (KE(0, 0, -1) + k0) : kappa;
+        const double qzt = -(kzt * DZF1(C_(0, 0, 1), c0)), qzb = -(kzb * DZF(c0, C_(0, 0, -1)));
         dzF = Az * qzt - Az * qzb;
     }
+#undef KE
     Gc[o] = Gc[o] - 1 / (Az * dzc) * (((Ax * qxe - Ax * qxw) + (Ay * qyn - Ay * qys)) + dzF);
 }
 #undef U_
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double
 #undef DZF
 #undef DZF1
 #undef TAU
+#undef NE
 
 // ---------------------------------------------------------------------------------------------------
 // launchers
@@ -352,8 +375,8 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
     return OCN_SUCCESS;
 }
 
-int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c, double *Gc, const int32_t *range,
-                            hipStream_t stream)
+int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                            const int32_t *range, hipStream_t stream)
 {
     PRange r;
     int st = make_prange(grid, range, r);
@@ -361,7 +384,7 @@ int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *c,
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
     dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
-    OCN_LAUNCH_TZ(tracer_diffusion_kernel, g, kappa, c, Gc, r);
+    OCN_LAUNCH_TZ(tracer_diffusion_kernel, g, kappa, kappa_e, c, Gc, r);
     return OCN_SUCCESS;
 }
 

@@ -185,7 +185,7 @@ class Distributed:
             # i in 0:nx+1 and needs the exchanged tracer halos, so this path completes the exchange first and computes the
             # tendencies of the whole slab in one go (no interior / buffer overlap yet)
             self.fill_halo_regions(fields, False)
-            models.update_hydrostatic_pressure(model)
+            models.compute_auxiliaries(model)
             if compute_tendencies:
                 models.compute_tendencies_(model)
             return

@@ -22,7 +22,8 @@ from . import _lib
 import ctypes as C
 
 from .advection import WENO
-from .physics import (BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity, SeawaterBuoyancy)
+from .physics import (AnisotropicMinimumDissipation, BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity,
+                      SeawaterBuoyancy)
 from .architectures import stream_ptr
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
 from .grids import Bounded, Flat
@@ -89,8 +90,8 @@ class NonhydrostaticModel:
             raise NotImplementedError("advection must be WENO() or Centered()")
         if coriolis is not None and not isinstance(coriolis, FPlane):
             raise NotImplementedError("only coriolis = FPlane(...) is implemented")
-        if closure is not None and not isinstance(closure, ScalarDiffusivity):
-            raise NotImplementedError("only closure = ScalarDiffusivity(...) is implemented")
+        if closure is not None and not isinstance(closure, (ScalarDiffusivity, AnisotropicMinimumDissipation)):
+            raise NotImplementedError("only closure = ScalarDiffusivity(...) or AnisotropicMinimumDissipation(...) is implemented")
         if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
             raise NotImplementedError("only buoyancy = BuoyancyTracer() or SeawaterBuoyancy(...) is implemented")
         if isinstance(tracers, str):
@@ -129,6 +130,12 @@ class NonhydrostaticModel:
             self.pHY = CenterField(grid)
         elif hydrostatic_pressure_anomaly not in ("default", None):
             raise ValueError("hydrostatic_pressure_anomaly must be 'default' or None")
+        # build_diffusivity_fields (anisotropic_minimum_dissipation.jl:333-341): νₑ and one κₑ per tracer, default conditions
+        self.diffusivity_fields = None
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            if grid.topology[2] == Flat:
+                raise NotImplementedError("AnisotropicMinimumDissipation needs a non-Flat z")
+            self.diffusivity_fields = {"nu_e": CenterField(grid), "kappa_e": tuple(CenterField(grid) for _ in tracers)}
         self.pressure_solver = nonhydrostatic_pressure_solver(grid)
         prog = self.prognostic_fields()
         if timestepper in ("RungeKutta3", ":RungeKutta3"):
@@ -167,7 +174,9 @@ class NonhydrostaticModel:
         t.advection = _lib.ADVECTION_CENTERED2 if isinstance(self.advection, Centered) else _lib.ADVECTION_WENO5
         if self.coriolis is not None:
             t.coriolis, t.f = 1, self.coriolis.f
-        if self.closure is not None:
+        if isinstance(self.closure, AnisotropicMinimumDissipation):
+            t.closure, t.nu_e = 2, self.diffusivity_fields["nu_e"].ptr
+        elif self.closure is not None:
             t.closure, t.nu = 1, self.closure.nu
         b = self.buoyancy
         if isinstance(b, BuoyancyTracer):
@@ -239,9 +248,30 @@ def update_state(model, compute_tendencies=True):
     if arch_hook is not None:  # Distributed: async exchange overlapped with interior tendencies
         return arch_hook(model, compute_tendencies)
     fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
-    update_hydrostatic_pressure(model)  # compute_auxiliaries! (update_nonhydrostatic_model_state.jl:59-70)
+    compute_auxiliaries(model)
     if compute_tendencies:
         compute_tendencies_(model)
+
+
+def compute_auxiliaries(model):
+    """compute_auxiliaries! (update_nonhydrostatic_model_state.jl:59-70) + the diffusivity halo fill (:48)"""
+    compute_diffusivities(model)
+    update_hydrostatic_pressure(model)
+    if model.diffusivity_fields is not None:
+        d = model.diffusivity_fields
+        fill_halo_regions((d["nu_e"],) + d["kappa_e"])
+
+
+def compute_diffusivities(model):
+    """compute_diffusivities!(diffusivity_fields, closure::AnisotropicMinimumDissipation, model)"""
+    d = model.diffusivity_fields
+    if d is None:
+        return
+    g, s = model.grid, stream_ptr()
+    _lib.call("ocn_compute_amd_viscosity", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr, s)
+    for name, c, k in zip(model.tracer_names, model.tracers, d["kappa_e"]):
+        _lib.call("ocn_compute_amd_diffusivity", g.cref, model.closure.Ckappa_of(name), model.u.ptr, model.v.ptr, model.w.ptr,
+                  c.ptr, k.ptr, s)
 
 
 def update_hydrostatic_pressure(model):
@@ -263,8 +293,12 @@ def compute_tendencies_(model, rng=None):
         _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, t, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr,
                   Gn[1].ptr, Gn[2].ptr, r, s)
         for n, c in enumerate(model.tracers):
-            kappa = 0.0 if model.closure is None else model.closure.kappa_of(model.tracer_names[n])
-            _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr,
+            kappa, kappa_e = 0.0, None
+            if model.diffusivity_fields is not None:
+                kappa_e = model.diffusivity_fields["kappa_e"][n].ptr
+            elif model.closure is not None:
+                kappa = model.closure.kappa_of(model.tracer_names[n])
+            _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, kappa_e, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr,
                       Gn[3 + n].ptr, r, s)
         if model._has_flux_bcs:
             prog = model.prognostic_fields()

@@ -76,6 +76,30 @@ class ScalarDiffusivity:
         return float(self.kappa)
 
 
+class AnisotropicMinimumDissipation:
+    """AnisotropicMinimumDissipation(; C = 1/12, Cν = nothing, Cκ = nothing, Cb = nothing)
+    (anisotropic_minimum_dissipation.jl:106-115): ExplicitTimeDiscretization, number (or per-tracer dict) Poincaré constants."""
+
+    def __init__(self, C=1 / 12, Cnu=None, Ckappa=None, Cb=None, **kw):
+        Cnu = kw.pop("Cν", Cnu)
+        Ckappa = kw.pop("Cκ", Ckappa)
+        if kw:
+            raise TypeError(f"unexpected keyword arguments {sorted(kw)}")
+        if Cb is not None:
+            raise NotImplementedError("the buoyancy modification (Cb) is not implemented")
+        self.Cnu = float(C if Cnu is None else Cnu)
+        self.Ckappa = C if Ckappa is None else Ckappa
+        if callable(self.Ckappa) or callable(Cnu):
+            raise NotImplementedError("only number Poincaré constants are implemented")
+
+    def Ckappa_of(self, name):
+        if isinstance(self.Ckappa, dict):
+            if name not in self.Ckappa:
+                raise ValueError(f"no Poincaré constant Cκ given for tracer {name}")
+            return float(self.Ckappa[name])
+        return float(self.Ckappa)
+
+
 class LinearEquationOfState:
     """linear_equation_of_state.jl:33-35"""
 

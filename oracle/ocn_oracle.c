@@ -548,9 +548,9 @@ void ocn_oracle_update_hydrostatic_pressure(const ocn_grid *g, const ocn_physics
  * x_dot_g_b = y_dot_g_b = 0 for the default NegativeZDirection gravity (g_dot_b.jl:7-8); in Gw the buoyancy term
  * is z_dot_g_b only when there is no separate hydrostatic pressure (pHY == NULL) (…kernel_functions.jl:141-143).
  * Same index ranges as the advective kernels (Face-located in Bounded starts at 2). */
-void ocn_oracle_momentum_extra_tendencies(const ocn_grid *g, const ocn_physics *ph, const double *u, const double *v,
-                                          const double *w, const double *T, const double *S, const double *pHY, double *Gu,
-                                          double *Gv, double *Gw)
+void ocn_oracle_momentum_extra_tendencies_nu(const ocn_grid *g, const ocn_physics *ph, const double *u, const double *v,
+                                             const double *w, const double *T, const double *S, const double *pHY,
+                                             const double *nu_e, double *Gu, double *Gv, double *Gw)
 {
     const lay Lu = mklay(g, 1, 0, 0), Lv = mklay(g, 0, 1, 0), Lw = mklay(g, 0, 0, 1), Lc = mklay(g, 0, 0, 0);
     const int Nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
@@ -572,12 +572,19 @@ void ocn_oracle_momentum_extra_tendencies(const ocn_grid *g, const ocn_physics *
 #define DYW_FF(i, j, k) (fy ? 0.0 : (W_(i, j, k) - W_(i, (j)-1, k)) / dy)                 /* ∂yᶜᶠᶠ w */
     /* viscous fluxes, isotropic (abstract_scalar_diffusivity_closure.jl:163-175):  -2 * (ν * Σᵢⱼ), Σ₁₂ = 0.5*(∂y u + ∂x v)
      * (velocity_tracer_gradients.jl:15-27) */
-#define T11(i, j, k) (-2 * (nu * DXU_C(i, j, k)))
-#define T22(i, j, k) (-2 * (nu * DYV_C(i, j, k)))
-#define T33(i, j, k) (-2 * (nu * DZW_C(i, j, k)))
-#define T12(i, j, k) (-2 * (nu * (0.5 * (DYU_FF(i, j, k) + DXV_FF(i, j, k)))))
-#define T13(i, j, k) (-2 * (nu * (0.5 * (DZU_FF(i, j, k) + DXW_FF(i, j, k)))))
-#define T23(i, j, k) (-2 * (nu * (0.5 * (DZV_FF(i, j, k) + DYW_FF(i, j, k)))))
+    /* viscosity at the stress locations: a number, or (nu_e != NULL) the ccc array νₑ of an eddy-viscosity closure
+     * interpolated with ℑxyᶠᶠᵃ / ℑxzᶠᵃᶠ / ℑyzᵃᶠᶠ (abstract_scalar_diffusivity_closure.jl:291-296) */
+#define NE(i, j, k) nu_e[AT(Lc, i, j, k)]
+#define NU_C(i, j, k) (nu_e ? NE(i, j, k) : nu)
+#define NU_FFC(i, j, k) (nu_e ? 0.5 * (0.5 * (NE((i)-1, (j)-1, k) + NE(i, (j)-1, k)) + 0.5 * (NE((i)-1, j, k) + NE(i, j, k))) : nu)
+#define NU_FCF(i, j, k) (nu_e ? 0.5 * (0.5 * (NE((i)-1, j, (k)-1) + NE(i, j, (k)-1)) + 0.5 * (NE((i)-1, j, k) + NE(i, j, k))) : nu)
+#define NU_CFF(i, j, k) (nu_e ? 0.5 * (0.5 * (NE(i, (j)-1, (k)-1) + NE(i, j, (k)-1)) + 0.5 * (NE(i, (j)-1, k) + NE(i, j, k))) : nu)
+#define T11(i, j, k) (-2 * (NU_C(i, j, k) * DXU_C(i, j, k)))
+#define T22(i, j, k) (-2 * (NU_C(i, j, k) * DYV_C(i, j, k)))
+#define T33(i, j, k) (-2 * (NU_C(i, j, k) * DZW_C(i, j, k)))
+#define T12(i, j, k) (-2 * (NU_FFC(i, j, k) * (0.5 * (DYU_FF(i, j, k) + DXV_FF(i, j, k)))))
+#define T13(i, j, k) (-2 * (NU_FCF(i, j, k) * (0.5 * (DZU_FF(i, j, k) + DXW_FF(i, j, k)))))
+#define T23(i, j, k) (-2 * (NU_CFF(i, j, k) * (0.5 * (DZV_FF(i, j, k) + DYW_FF(i, j, k)))))
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 1; k <= Nz; ++k)
         for (int j = 1; j <= Ny; ++j)
@@ -642,18 +649,32 @@ void ocn_oracle_momentum_extra_tendencies(const ocn_grid *g, const ocn_physics *
 #undef T12
 #undef T13
 #undef T23
+#undef NE
+#undef NU_C
+#undef NU_FFC
+#undef NU_FCF
+#undef NU_CFF
+}
+void ocn_oracle_momentum_extra_tendencies(const ocn_grid *g, const ocn_physics *ph, const double *u, const double *v,
+                                          const double *w, const double *T, const double *S, const double *pHY, double *Gu,
+                                          double *Gv, double *Gw)
+{
+    ocn_oracle_momentum_extra_tendencies_nu(g, ph, u, v, w, T, S, pHY, NULL, Gu, Gv, Gw);
 }
 
 /* Gc <- Gc - ∇_dot_qᶜ (closure_kernel_operators.jl:48-53) with diffusive_flux_x = -(κ * ∂xᶠᶜᶜ c)
  * (abstract_scalar_diffusivity_closure.jl:221-223) */
-void ocn_oracle_tracer_diffusion(const ocn_grid *g, double kappa, const double *c, double *Gc)
+/* kappa_e != NULL: the ccc array κₑ of an eddy-diffusivity closure, interpolated to the flux faces with ℑxᶠᵃᵃ / ℑyᵃᶠᵃ / ℑzᵃᵃᶠ
+ * (abstract_scalar_diffusivity_closure.jl:298-300) */
+void ocn_oracle_tracer_diffusion_kappa(const ocn_grid *g, double kappa, const double *kappa_e, const double *c, double *Gc)
 {
     const lay L = mklay(g, 0, 0, 0);
     const int fx = DFLAT(g, 0), fy = DFLAT(g, 1), fz = DFLAT(g, 2);
 #define C_(i, j, k) c[AT(L, i, j, k)]
-#define QX(i, j, k) (-(kappa * ((C_(i, j, k) - C_((i)-1, j, k)) / g->dx)))
-#define QY(i, j, k) (-(kappa * ((C_(i, j, k) - C_(i, (j)-1, k)) / g->dy)))
-#define QZ(i, j, k) (-(kappa * ((C_(i, j, k) - C_(i, j, (k)-1)) / dzf_at(g, k))))
+#define KE(i, j, k) kappa_e[AT(L, i, j, k)]
+#define QX(i, j, k) (-((kappa_e ? 0.5 * (KE((i)-1, j, k) + KE(i, j, k)) : kappa) * ((C_(i, j, k) - C_((i)-1, j, k)) / g->dx)))
+#define QY(i, j, k) (-((kappa_e ? 0.5 * (KE(i, (j)-1, k) + KE(i, j, k)) : kappa) * ((C_(i, j, k) - C_(i, (j)-1, k)) / g->dy)))
+#define QZ(i, j, k) (-((kappa_e ? 0.5 * (KE(i, j, (k)-1) + KE(i, j, k)) : kappa) * ((C_(i, j, k) - C_(i, j, (k)-1)) / dzf_at(g, k))))
 #pragma omp parallel for collapse(2) schedule(static)
     for (int k = 1; k <= g->Nz; ++k)
         for (int j = 1; j <= g->Ny; ++j)
@@ -665,9 +686,14 @@ void ocn_oracle_tracer_diffusion(const ocn_grid *g, double kappa, const double *
                 Gc[AT(L, i, j, k)] = Gc[AT(L, i, j, k)] - 1 / V_at(g, k, 0) * ((dxF + dyF) + dzF);
             }
 #undef C_
+#undef KE
 #undef QX
 #undef QY
 #undef QZ
+}
+void ocn_oracle_tracer_diffusion(const ocn_grid *g, double kappa, const double *c, double *Gc)
+{
+    ocn_oracle_tracer_diffusion_kappa(g, kappa, NULL, c, Gc);
 }
 
 /* Boundary conditions on one side.  kind: 0 default (Periodic / no-flux / impenetrable), 1 Flux, 2 Value, 3 Gradient.
@@ -756,6 +782,131 @@ void ocn_oracle_fill_value_gradient(const ocn_grid *g, int loc, int dir, const o
             }
         }
 }
+
+/* =====================================================================================
+ * AnisotropicMinimumDissipation (Cb = nothing)
+ * turbulence_closure_implementations/anisotropic_minimum_dissipation.jl:125-341, velocity_tracer_gradients.jl:66-140.
+ * Filter widths Δᶠx = 2Δx etc. are the ccc values AT THE GIVEN INDEX for every location (:192-203).
+ * ===================================================================================== */
+typedef struct {
+    const ocn_grid *g;
+    const double *u, *v, *w, *c;
+    lay Lu, Lv, Lw, Lc;
+    double Fx, Fy; /* Δᶠx, Δᶠy */
+} amd_ctx;
+typedef double (*amd_fn)(const amd_ctx *, int, int, int);
+#define AU(i, j, k) A->u[AT(A->Lu, i, j, k)]
+#define AV(i, j, k) A->v[AT(A->Lv, i, j, k)]
+#define AW(i, j, k) A->w[AT(A->Lw, i, j, k)]
+#define AC(i, j, k) A->c[AT(A->Lc, i, j, k)]
+static inline double amd_Fz(const amd_ctx *A, int k) { return 2 * dzc_at(A->g, k); }
+static double n_dx_u(const amd_ctx *A, int i, int j, int k) { return (AU(i + 1, j, k) - AU(i, j, k)) / A->g->dx; }
+static double n_dy_v(const amd_ctx *A, int i, int j, int k) { return (AV(i, j + 1, k) - AV(i, j, k)) / A->g->dy; }
+static double n_dz_w(const amd_ctx *A, int i, int j, int k) { return (AW(i, j, k + 1) - AW(i, j, k)) / dzc_at(A->g, k); }
+static double n_dx_v(const amd_ctx *A, int i, int j, int k) { return A->Fx / A->Fy * ((AV(i, j, k) - AV(i - 1, j, k)) / A->g->dx); }
+static double n_dy_u(const amd_ctx *A, int i, int j, int k) { return A->Fy / A->Fx * ((AU(i, j, k) - AU(i, j - 1, k)) / A->g->dy); }
+static double n_dx_w(const amd_ctx *A, int i, int j, int k) { return A->Fx / amd_Fz(A, k) * ((AW(i, j, k) - AW(i - 1, j, k)) / A->g->dx); }
+static double n_dz_u(const amd_ctx *A, int i, int j, int k) { return amd_Fz(A, k) / A->Fx * ((AU(i, j, k) - AU(i, j, k - 1)) / dzf_at(A->g, k)); }
+static double n_dy_w(const amd_ctx *A, int i, int j, int k) { return A->Fy / amd_Fz(A, k) * ((AW(i, j, k) - AW(i, j - 1, k)) / A->g->dy); }
+static double n_dz_v(const amd_ctx *A, int i, int j, int k) { return amd_Fz(A, k) / A->Fy * ((AV(i, j, k) - AV(i, j, k - 1)) / dzf_at(A->g, k)); }
+static double n_dx_c(const amd_ctx *A, int i, int j, int k) { return A->Fx * ((AC(i, j, k) - AC(i - 1, j, k)) / A->g->dx); }
+static double n_dy_c(const amd_ctx *A, int i, int j, int k) { return A->Fy * ((AC(i, j, k) - AC(i, j - 1, k)) / A->g->dy); }
+static double n_dz_c(const amd_ctx *A, int i, int j, int k) { return amd_Fz(A, k) * ((AC(i, j, k) - AC(i, j, k - 1)) / dzf_at(A->g, k)); }
+static double n_S12(const amd_ctx *A, int i, int j, int k) { return 0.5 * (n_dy_u(A, i, j, k) + n_dx_v(A, i, j, k)); }
+static double n_S13(const amd_ctx *A, int i, int j, int k) { return 0.5 * (n_dz_u(A, i, j, k) + n_dx_w(A, i, j, k)); }
+static double n_S23(const amd_ctx *A, int i, int j, int k) { return 0.5 * (n_dz_v(A, i, j, k) + n_dy_w(A, i, j, k)); }
+#define AMD_SQ(name, f) static double name(const amd_ctx *A, int i, int j, int k) { double t = f(A, i, j, k); return t * t; }
+#define AMD_PR(name, f, g2) static double name(const amd_ctx *A, int i, int j, int k) { return f(A, i, j, k) * g2(A, i, j, k); }
+AMD_SQ(n_dx_v2, n_dx_v) AMD_SQ(n_dy_u2, n_dy_u) AMD_SQ(n_dx_w2, n_dx_w) AMD_SQ(n_dz_u2, n_dz_u) AMD_SQ(n_dy_w2, n_dy_w) AMD_SQ(n_dz_v2, n_dz_v)
+AMD_SQ(n_dx_c2, n_dx_c) AMD_SQ(n_dy_c2, n_dy_c) AMD_SQ(n_dz_c2, n_dz_c)
+AMD_PR(n_dx_v_S12, n_dx_v, n_S12) AMD_PR(n_dy_u_S12, n_dy_u, n_S12) AMD_PR(n_dx_w_S13, n_dx_w, n_S13) AMD_PR(n_dz_u_S13, n_dz_u, n_S13)
+AMD_PR(n_dz_v_S23, n_dz_v, n_S23) AMD_PR(n_dy_w_S23, n_dy_w, n_S23)
+/* interpolations of functions (interpolation_operators.jl:20-26, 44-57) */
+static inline double Ix_c(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i + 1, j, k)); }
+static inline double Iy_c(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i, j + 1, k)); }
+static inline double Iz_c(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i, j, k + 1)); }
+static inline double Ixy_cc(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (Ix_c(A, f, i, j, k) + Ix_c(A, f, i, j + 1, k)); }
+static inline double Ixz_cc(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (Ix_c(A, f, i, j, k) + Ix_c(A, f, i, j, k + 1)); }
+static inline double Iyz_cc(const amd_ctx *A, amd_fn f, int i, int j, int k) { return 0.5 * (Iy_c(A, f, i, j, k) + Iy_c(A, f, i, j, k + 1)); }
+
+static amd_ctx amd_make(const ocn_grid *g, const double *u, const double *v, const double *w, const double *c)
+{
+    amd_ctx A;
+    A.g = g; A.u = u; A.v = v; A.w = w; A.c = c;
+    A.Lu = mklay(g, 1, 0, 0); A.Lv = mklay(g, 0, 1, 0); A.Lw = mklay(g, 0, 0, 1); A.Lc = mklay(g, 0, 0, 0);
+    A.Fx = 2 * g->dx; A.Fy = 2 * g->dy;
+    return A;
+}
+static inline double amd_delta2(const amd_ctx *A, int k)
+{
+    double Fz = amd_Fz(A, k);
+    return 3 / ((1 / (A->Fx * A->Fx) + 1 / (A->Fy * A->Fy)) + 1 / (Fz * Fz));
+}
+static inline double julia_max0(double x) { return (x > 0 || x != x) ? x : 0.0; }
+
+/* _compute_AMD_viscosity! (:125-147) over :xyz; q = norm_tr_∇uᶜᶜᶜ (:263-281), r = norm_uᵢₐ_uⱼₐ_Σᵢⱼᶜᶜᶜ (:208-257) */
+void ocn_oracle_amd_viscosity(const ocn_grid *g, double Cnu, const double *u, const double *v, const double *w, double *nu_e)
+{
+    const amd_ctx ctx = amd_make(g, u, v, w, NULL);
+    const amd_ctx *A = &ctx;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                const double dxu = n_dx_u(A, i, j, k), dyv = n_dy_v(A, i, j, k), dzw = n_dz_w(A, i, j, k);
+                const double q = (((((((dxu * dxu + dyv * dyv) + dzw * dzw) + Ixy_cc(A, n_dx_v2, i, j, k)) + Ixy_cc(A, n_dy_u2, i, j, k)) +
+                                    Ixz_cc(A, n_dx_w2, i, j, k)) + Ixz_cc(A, n_dz_u2, i, j, k)) + Iyz_cc(A, n_dy_w2, i, j, k)) + Iyz_cc(A, n_dz_v2, i, j, k);
+                double nu = 0.0;
+                if (q != 0) {
+                    const double r1 = ((((dxu * (dxu * dxu) + dyv * Ixy_cc(A, n_dx_v2, i, j, k)) + dzw * Ixz_cc(A, n_dx_w2, i, j, k)) +
+                                        2 * dxu * Ixy_cc(A, n_dx_v_S12, i, j, k)) + 2 * dxu * Ixz_cc(A, n_dx_w_S13, i, j, k)) +
+                                      2 * Ixy_cc(A, n_dx_v, i, j, k) * Ixz_cc(A, n_dx_w, i, j, k) * Iyz_cc(A, n_S23, i, j, k);
+                    const double r2 = ((((dxu * Ixy_cc(A, n_dy_u2, i, j, k) + dyv * (dyv * dyv)) + dzw * Iyz_cc(A, n_dy_w2, i, j, k)) +
+                                        2 * dyv * Ixy_cc(A, n_dy_u_S12, i, j, k)) +
+                                       2 * Ixy_cc(A, n_dy_u, i, j, k) * Iyz_cc(A, n_dy_w, i, j, k) * Ixz_cc(A, n_S13, i, j, k)) +
+                                      2 * dyv * Iyz_cc(A, n_dy_w_S23, i, j, k);
+                    const double r3 = ((((dxu * Ixz_cc(A, n_dz_u2, i, j, k) + dyv * Iyz_cc(A, n_dz_v2, i, j, k)) + dzw * (dzw * dzw)) +
+                                        2 * Ixz_cc(A, n_dz_u, i, j, k) * Iyz_cc(A, n_dz_v, i, j, k) * Ixy_cc(A, n_S12, i, j, k)) +
+                                       2 * dzw * Ixz_cc(A, n_dz_u_S13, i, j, k)) + 2 * dzw * Iyz_cc(A, n_dz_v_S23, i, j, k);
+                    const double r = (r1 + r2) + r3;
+                    const double Cb_zeta = 0.0 / amd_Fz(A, k); /* Cb = nothing */
+                    nu = -Cnu * amd_delta2(A, k) * (r - Cb_zeta) / q;
+                }
+                nu_e[AT(A->Lc, i, j, k)] = julia_max0(nu);
+            }
+}
+
+/* _compute_AMD_diffusivity! (:149-169); σ = norm_θᵢ²ᶜᶜᶜ (:325-327), ϑ = norm_uᵢⱼ_cⱼ_cᵢᶜᶜᶜ (:297-323), including the
+ * ℑxzᶜᵃᶜ (not ℑyz) interpolation of norm_∂y_w exactly as the reference writes it (:313) */
+void ocn_oracle_amd_diffusivity(const ocn_grid *g, double Ck, const double *u, const double *v, const double *w, const double *c,
+                                double *kappa_e)
+{
+    const amd_ctx ctx = amd_make(g, u, v, w, c);
+    const amd_ctx *A = &ctx;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->Nz; ++k)
+        for (int j = 1; j <= g->Ny; ++j)
+            for (int i = 1; i <= g->Nx; ++i) {
+                const double sigma = (Ix_c(A, n_dx_c2, i, j, k) + Iy_c(A, n_dy_c2, i, j, k)) + Iz_c(A, n_dz_c2, i, j, k);
+                double kap = 0.0;
+                if (sigma != 0) {
+                    const double cx = Ix_c(A, n_dx_c, i, j, k), cy = Iy_c(A, n_dy_c, i, j, k), cz = Iz_c(A, n_dz_c, i, j, k);
+                    const double cx_ux = (n_dx_u(A, i, j, k) * Ix_c(A, n_dx_c2, i, j, k) + Ixy_cc(A, n_dx_v, i, j, k) * cx * cy) +
+                                         Ixz_cc(A, n_dx_w, i, j, k) * cx * cz;
+                    const double cy_uy = (Ixy_cc(A, n_dy_u, i, j, k) * cy * cx + n_dy_v(A, i, j, k) * Iy_c(A, n_dy_c2, i, j, k)) +
+                                         Ixz_cc(A, n_dy_w, i, j, k) * cy * cz;
+                    const double cz_uz = (Ixz_cc(A, n_dz_u, i, j, k) * cz * cx + Iyz_cc(A, n_dz_v, i, j, k) * cz * cy) +
+                                         n_dz_w(A, i, j, k) * Iz_c(A, n_dz_c2, i, j, k);
+                    const double theta = (cx_ux + cy_uy) + cz_uz;
+                    kap = -Ck * amd_delta2(A, k) * theta / sigma;
+                }
+                kappa_e[AT(A->Lc, i, j, k)] = julia_max0(kap);
+            }
+}
+#undef AU
+#undef AV
+#undef AW
+#undef AC
 
 /* =====================================================================================
  * Time-stepper kernels

@@ -283,13 +283,24 @@ def update_hydrostatic_pressure(g, ph, T, S, pHY):
     lib().ocn_oracle_update_hydrostatic_pressure(g.cref, ph.ref, None if T is None else _p(T), None if S is None else _p(S), _p(pHY))
 
 
-def momentum_extra_tendencies(g, ph, u, v, w, T, S, pHY, Gu, Gv, Gw):
-    lib().ocn_oracle_momentum_extra_tendencies(g.cref, ph.ref, _p(u), _p(v), _p(w), None if T is None else _p(T),
-                                               None if S is None else _p(S), None if pHY is None else _p(pHY), _p(Gu), _p(Gv), _p(Gw))
+def momentum_extra_tendencies(g, ph, u, v, w, T, S, pHY, Gu, Gv, Gw, nu_e=None):
+    lib().ocn_oracle_momentum_extra_tendencies_nu(g.cref, ph.ref, _p(u), _p(v), _p(w), None if T is None else _p(T),
+                                                  None if S is None else _p(S), None if pHY is None else _p(pHY),
+                                                  None if nu_e is None else _p(nu_e), _p(Gu), _p(Gv), _p(Gw))
 
 
-def tracer_diffusion(g, kappa, c, Gc):
-    lib().ocn_oracle_tracer_diffusion(g.cref, C.c_double(kappa), _p(c), _p(Gc))
+def tracer_diffusion(g, kappa, c, Gc, kappa_e=None):
+    lib().ocn_oracle_tracer_diffusion_kappa(g.cref, C.c_double(kappa), None if kappa_e is None else _p(kappa_e), _p(c), _p(Gc))
+
+
+def amd_viscosity(g, Cnu, u, v, w, nu_e):
+    """_compute_AMD_viscosity! over the interior (anisotropic_minimum_dissipation.jl:125-147), Cb = nothing"""
+    lib().ocn_oracle_amd_viscosity(g.cref, C.c_double(Cnu), _p(u), _p(v), _p(w), _p(nu_e))
+
+
+def amd_diffusivity(g, Ck, u, v, w, c, kappa_e):
+    """_compute_AMD_diffusivity! (:149-169)"""
+    lib().ocn_oracle_amd_diffusivity(g.cref, C.c_double(Ck), _p(u), _p(v), _p(w), _p(c), _p(kappa_e))
 
 
 def apply_flux_bcs(g, loc, c, G, bcs):
@@ -475,7 +486,15 @@ class NonhydrostaticModel:
             if g.topo[d] != FLAT:
                 assert H >= need and N >= need, "WENO5 needs halo >= 3 (nonhydrostatic_model.jl:183,243-257) and N >= 3 (adapt_advection_order)"
         nu = kappa = None
-        if closure is not None:
+        self.amd = None
+        if closure is not None and closure[0] == "AMD":  # AnisotropicMinimumDissipation(Cν, Cκ), C = 1/12 by default
+            Cnu = closure[1] if len(closure) > 1 else 1 / 12
+            Ck = closure[2] if len(closure) > 2 else 1 / 12
+            self.amd = (Cnu, Ck if isinstance(Ck, dict) else {n: Ck for n in tracers})
+            self.nu_e = g.zeros(LOC_C)
+            self.kappa_e = [g.zeros(LOC_C) for _ in tracers]
+            nu, kappa = 0.0, {n: 0.0 for n in tracers}
+        elif closure is not None:
             nu, kappa = closure
             if not isinstance(kappa, dict):
                 kappa = {n: kappa for n in tracers}
@@ -526,9 +545,16 @@ class NonhydrostaticModel:
         g = self.grid
         for f, l, n in zip(self.fields, self.locs, self.names):  # update_nonhydrostatic_model_state.jl:34-35
             fill_halo_regions(g, f, l, fill_boundary_normal_velocities=False, bcs=self.bcs.get(n))
-        if self.pHY is not None:  # compute_auxiliaries! (:59-70)
+        if self.amd is not None:  # compute_auxiliaries! (:59-70): compute_diffusivities! ...
+            amd_viscosity(g, self.amd[0], self.u, self.v, self.w, self.nu_e)
+            for n, c in enumerate(self.tracers):
+                amd_diffusivity(g, self.amd[1][self.tracer_names[n]], self.u, self.v, self.w, c, self.kappa_e[n])
+        if self.pHY is not None:  # ... then update_hydrostatic_pressure!
             T, S = self._buoyancy_tracers()
             update_hydrostatic_pressure(g, self.physics, T, S, self.pHY)
+        if self.amd is not None:  # fill_halo_regions!(model.diffusivity_fields; only_local_halos=true) (:48)
+            for a in [self.nu_e] + self.kappa_e:
+                fill_halo_regions(g, a, LOC_C)
         if compute_tendencies:
             self.compute_tendencies()
 
@@ -537,11 +563,13 @@ class NonhydrostaticModel:
         momentum_tendencies(g, self.u, self.v, self.w, self.Gn[0], self.Gn[1], self.Gn[2], self.scheme)
         if ph.c.coriolis or ph.c.closure or ph.c.buoyancy:
             T, S = self._buoyancy_tracers()
-            momentum_extra_tendencies(g, ph, self.u, self.v, self.w, T, S, self.pHY, self.Gn[0], self.Gn[1], self.Gn[2])
+            momentum_extra_tendencies(g, ph, self.u, self.v, self.w, T, S, self.pHY, self.Gn[0], self.Gn[1], self.Gn[2],
+                                      nu_e=self.nu_e if self.amd is not None else None)
         for n, c in enumerate(self.tracers):
             tracer_tendency(g, self.u, self.v, self.w, c, self.Gn[3 + n], self.scheme)
             if ph.c.closure:
-                tracer_diffusion(g, self.kappa[self.tracer_names[n]], c, self.Gn[3 + n])
+                tracer_diffusion(g, self.kappa[self.tracer_names[n]], c, self.Gn[3 + n],
+                                 kappa_e=self.kappa_e[n] if self.amd is not None else None)
         # compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:204-213)
         for f, l, n, G in zip(self.fields, self.locs, self.names, self.Gn):
             if n in self.bcs:

@@ -58,7 +58,7 @@ def test_centered2_advection_strict_bitwise(oracle, ocn, size, topo, z, halo):
     t = _terms(ocn, advection=1)
     ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
                   dG[2].ptr, None, 0)
-    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, None, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
     ocn.sync_device()
     for a, b, name in zip(G, dG, "uvwc"):
         np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
@@ -115,7 +115,7 @@ def test_tracer_diffusion_strict_bitwise(oracle, ocn, size, topo, z, halo):
     du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
     dG = ocn.Field(0, pg)
     t = _terms(ocn, advection=1, nu=1.0)
-    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.37, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG.ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.37, None, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG.ptr, None, 0)
     ocn.sync_device()
     np.testing.assert_array_equal(from_dev(dG), Gc)
 
@@ -143,7 +143,7 @@ def test_physics_fast_math_tolerance(oracle, ocn, size, topo, z, halo):
         t = _terms(ocn, advection=1, f=0.3, nu=1e-1, buoyancy=1, T=db, pHY=dp)
         ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
                       dG[2].ptr, None, 0)
-        ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.2, du.ptr, dv.ptr, dw.ptr, db.ptr, dG[3].ptr, None, 0)
+        ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.2, None, du.ptr, dv.ptr, dw.ptr, db.ptr, dG[3].ptr, None, 0)
         ocn.sync_device()
     finally:
         ocn.set_math_mode(ocn.MATH_STRICT)
@@ -331,3 +331,104 @@ def test_model_argument_errors(ocn):
     with pytest.raises(ocn.OcnError, match="Bounded z"):
         ocn.NonhydrostaticModel(gp, advection=ocn.WENO(), tracers="c",
                                 boundary_conditions={"c": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(1.0))})
+
+
+# ---- AnisotropicMinimumDissipation ---------------------------------------------------------------
+AMD_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), (3, 3, 3)),
+             ((13, 17, 19), "PPP", (0, 1.0), (1, 2, 3)),
+             ((70, 9, 8), "PPB", (-1.0, 0.0), (3, 3, 3)),
+             ((16, 12, 10), "PPB", "stretched", (3, 3, 3))]
+
+
+@pytest.mark.parametrize("size,topo,z,halo", AMD_CASES)
+def test_amd_diffusivities_strict_bitwise(oracle, ocn, size, topo, z, halo):
+    """_compute_AMD_viscosity! / _compute_AMD_diffusivity! and the variable-ν / variable-κ flux divergences: bit for bit."""
+    O = oracle
+    rng = np.random.default_rng(31)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng)
+    nu, ka = og.zeros(0), og.zeros(0)
+    O.amd_viscosity(og, 1 / 12, u, v, w, nu)
+    O.amd_diffusivity(og, 1 / 7, u, v, w, c, ka)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dnu, dka = ocn.Field(0, pg), ocn.Field(0, pg)
+    ocn._lib.call("ocn_compute_amd_viscosity", pg.cref, 1 / 12, du.ptr, dv.ptr, dw.ptr, dnu.ptr, 0)
+    ocn._lib.call("ocn_compute_amd_diffusivity", pg.cref, 1 / 7, du.ptr, dv.ptr, dw.ptr, dc.ptr, dka.ptr, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dnu), nu)
+    np.testing.assert_array_equal(from_dev(dka), ka)
+    assert og.interior_N(nu).max() > 0 and og.interior_N(ka).max() > 0
+    # flux divergences with arbitrary (random, halo-filled) νₑ, κₑ fields
+    nu_r, ka_r = random_parent(og, 0, rng, 0.0, 1e-2), random_parent(og, 0, rng, 0.0, 1e-2)
+    ph = O.Physics(nu=0.0)
+    G = [og.zeros(l) for l in LOCS] + [og.zeros(0)]
+    O.momentum_tendencies(og, u, v, w, *G[:3], scheme=O.ADV_CENTERED2)
+    O.momentum_extra_tendencies(og, ph, u, v, w, None, None, None, *G[:3], nu_e=nu_r)
+    O.tracer_tendency(og, u, v, w, c, G[3], scheme=O.ADV_CENTERED2)
+    O.tracer_diffusion(og, 0.0, c, G[3], kappa_e=ka_r)
+    dnr, dkr = to_dev(ocn, pg, 0, nu_r), to_dev(ocn, pg, 0, ka_r)
+    t = _terms(ocn, advection=1)
+    t.closure, t.nu_e = 2, dnr.ptr
+    dG = [ocn.Field(l, pg) for l in LOCS + (0,)]
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
+                  dG[2].ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, dkr.ptr, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvwc"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
+
+
+@pytest.mark.parametrize("adv,ts", [("WENO5", "RungeKutta3"), ("Centered2", "QuasiAdamsBashforth2")])
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_ocean_wind_mixing_and_convection_matches_oracle(oracle, ocn, adv, ts, mode):
+    """examples/ocean_wind_mixing_and_convection.jl:79-152 as written (SeawaterBuoyancy, FPlane, AnisotropicMinimumDissipation,
+    wind stress, heat flux, bottom temperature gradient, evaporation) on a small stretched grid: 3 steps against the oracle."""
+    O = oracle
+    rng = np.random.default_rng(32)
+    size = (16, 12, 10)
+    z = stretched_faces(size[2], 32.0)
+    og, pg = make_pair(O, ocn, size, "PPB", x=(0, 64), y=(0, 64), z=z)
+    Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
+    JT = Q / (rho * cp)
+    taux = -1.225 / rho * 2.5e-3 * 10 * 10
+    evap = 1e-3 / 3600
+    obcs = {"u": {"top": O.FluxBoundaryCondition(taux)},
+            "T": {"top": O.FluxBoundaryCondition(JT), "bottom": O.GradientBoundaryCondition(dTdz)},
+            "S": {"top": O.BC("flux", 0.0, -evap)}}
+    om = O.NonhydrostaticModel(og, tracers=("T", "S"), timestepper=ts, advection=adv, coriolis_f=1e-4, closure=("AMD",),
+                               buoyancy=SEAWATER, boundary_conditions=obcs)
+    pbcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(taux)),
+            "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(JT), bottom=ocn.GradientBoundaryCondition(dTdz)),
+            "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-evap))}
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO() if adv == "WENO5" else ocn.Centered(), tracers=("T", "S"), timestepper=ts,
+                                     coriolis=ocn.FPlane(f=1e-4), closure=ocn.AnisotropicMinimumDissipation(),
+                                     buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                     boundary_conditions=pbcs)
+        zc = 0.5 * (z[1:] + z[:-1])
+        init = {n: 1e-2 * rng.uniform(-1, 1, og.interior(f).shape) for n, f in zip("uvw", (om.u, om.v, om.w))}
+        init["T"] = 20 + dTdz * zc[None, None, :] + 1e-3 * rng.uniform(-1, 1, size)
+        init["S"] = 35 + 1e-3 * rng.uniform(-1, 1, size)
+        om.set(**init)
+        ocn.set(pm, **init)
+        for _ in range(3):
+            om.time_step(2.0)
+            ocn.time_step(pm, 2.0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    vscale = max(np.abs(om.u).max(), np.abs(om.v).max(), np.abs(om.w).max())
+    for name, a, d in zip(("u", "v", "w", "T", "S"), om.fields, pm.prognostic_fields()):
+        scale = vscale if name in "uvw" else np.abs(og.interior(a)).max()
+        err = np.abs(og.interior(from_dev(d)) - og.interior(a)).max()
+        assert err <= 1e-10 * scale, f"{name}: {err} > {1e-10 * scale}"
+    # νₑ, κₑ are ratios of small numbers (κₑ = -Cκ δ² ϑ/σ with σ ~ |∇c|² ~ 1e-6 here amplifies the 1e-15 round-off differences
+    # of the Poisson solves): 1e-6 of their scale, everywhere incl. halos.  The kernels themselves are bit-exact (above).
+    nus = np.abs(om.nu_e).max()
+    assert nus > 0
+    assert np.abs(from_dev(pm.diffusivity_fields["nu_e"]) - om.nu_e).max() <= 1e-6 * nus
+    for a, d in zip(om.kappa_e, pm.diffusivity_fields["kappa_e"]):
+        assert np.abs(from_dev(d) - a).max() <= 1e-6 * max(np.abs(a).max(), nus)

@@ -5,7 +5,8 @@ spacing, examples/ocean_wind_mixing_and_convection.jl:38-62), WENO5, RK3, Fourie
   tools/bench_config4.py [Nx] [Nz] [steps] [physics]
 physics = 0: advection only (SURVEY §8d first form);  1: the example's physics (:79-152) with the LES closure replaced by a
 constant ScalarDiffusivity: SeawaterBuoyancy(linear EOS), T and S tracers, FPlane(f=1e-4), wind stress, surface heat flux,
-bottom temperature gradient, evaporation.  Prints ms/step and cell-updates/s."""
+bottom temperature gradient, evaporation;  2: the example as written, closure = AnisotropicMinimumDissipation().
+Prints ms/step and cell-updates/s."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -30,7 +31,7 @@ if physics:
            "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(Q / (rho * cp)), bottom=ocn.GradientBoundaryCondition(dTdz)),
            "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-1e-3 / 3600))}
     m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
-                                closure=ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4),
+                                closure=ocn.AnisotropicMinimumDissipation() if physics == 2 else ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4),
                                 buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
                                 boundary_conditions=bcs)
     zc = 0.5 * (z_faces[1:] + z_faces[:-1])
