@@ -188,6 +188,10 @@ int ocn_compute_amd_viscosity(const ocn_grid *grid, double C_nu, const double *u
                               void *stream);
 int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const double *u, const double *v, const double *w,
                                 const double *c, double *kappa_e, void *stream);
+/* Both of the above for νₑ and n_tracers <= 4 tracers in ONE launch (the velocity gradients are evaluated once). */
+int ocn_compute_amd_diffusivities(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w,
+                                  double *nu_e, int32_t n_tracers, const double *C_kappa, const double *const *tracers,
+                                  double *const *kappa_e, void *stream);
 /* update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-53): pHY′ by downward integration of the buoyancy
  * perturbation over i in 0:Nx+1, j in 0:Ny+1 (tracer halos must be filled).  No-op on a z-Flat grid. */
 int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream);

@@ -78,74 +78,161 @@ __device__ __forceinline__ Amd make_amd(const GridDev &g, const double *u, const
     return A;
 }
 
-__global__ __launch_bounds__(256) void amd_viscosity_kernel(GridDev g, double Cnu, const double *__restrict__ u,
-                                                            const double *__restrict__ v, const double *__restrict__ w,
-                                                            double *__restrict__ nu_e)
+// ---------------------------------------------------------------------------------------------------
+// Fused kernel: νₑ and the κₑ of up to OCN_AMD_MAX_TRACERS tracers in one pass.  Every normalised velocity gradient the 30
+// terms need is evaluated ONCE per thread into registers (27 derivatives + the 2 extra ∂y w of the reference's ℑxz quirk)
+// and reused by all terms and all tracers; re-evaluating a pure function gives the same bits, so this is still the
+// reference's arithmetic term for term.  Arrays are indexed [inner][outer] of the interpolation they feed:
+//   ffc quantities [a][b] at (i+a, j+b, k);  fcf [a][d] at (i+a, j, k+d);  cff [b][d] at (i, j+b, k+d).
+// ---------------------------------------------------------------------------------------------------
+constexpr int OCN_AMD_MAX_TRACERS = 4;
+struct AmdTracers {
+    const double *c[OCN_AMD_MAX_TRACERS];
+    double *kappa_e[OCN_AMD_MAX_TRACERS];
+    double Ck[OCN_AMD_MAX_TRACERS];
+    int n;
+};
+
+// ℑ over a 2x2 set: 0.5 * (0.5*(f[0][0] + f[1][0]) + 0.5*(f[0][1] + f[1][1]))
+#define I4(f) (0.5 * (0.5 * (f[0][0] + f[1][0]) + 0.5 * (f[0][1] + f[1][1])))
+#define I4SQ(f) (0.5 * (0.5 * (f[0][0] * f[0][0] + f[1][0] * f[1][0]) + 0.5 * (f[0][1] * f[0][1] + f[1][1] * f[1][1])))
+#define I4PR(f, g) (0.5 * (0.5 * (f[0][0] * g[0][0] + f[1][0] * g[1][0]) + 0.5 * (f[0][1] * g[0][1] + f[1][1] * g[1][1])))
+
+__global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
+                                                        const double *__restrict__ v, const double *__restrict__ w,
+                                                        double *__restrict__ nu_e, AmdTracers tr)
 {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny) return;
     const Amd A = make_amd(g, u, v, w, nullptr, i, j, k);
-    const double dxu = DxU()(A, 0, 0, 0), dyv = DyV()(A, 0, 0, 0), dzw = DzW()(A, 0, 0, 0);
-    const double xv2 = Ixy<Sq<DxV>>(A), yu2 = Ixy<Sq<DyU>>(A), xw2 = Ixz<Sq<DxW>>(A), zu2 = Ixz<Sq<DzU>>(A), yw2 = Iyz<Sq<DyW>>(A),
-                 zv2 = Iyz<Sq<DzV>>(A);
-    const double q = (((((((dxu * dxu + dyv * dyv) + dzw * dzw) + xv2) + yu2) + xw2) + zu2) + yw2) + zv2;
-    double nu = 0.0;
-    if (q != 0) {
-        const double r1 = ((((dxu * (dxu * dxu) + dyv * xv2) + dzw * xw2) + 2 * dxu * Ixy<Pr<DxV, S12>>(A)) + 2 * dxu * Ixz<Pr<DxW, S13>>(A)) +
-                          2 * Ixy<DxV>(A) * Ixz<DxW>(A) * Iyz<S23>(A);
-        const double r2 = ((((dxu * yu2 + dyv * (dyv * dyv)) + dzw * yw2) + 2 * dyv * Ixy<Pr<DyU, S12>>(A)) +
-                           2 * Ixy<DyU>(A) * Iyz<DyW>(A) * Ixz<S13>(A)) + 2 * dyv * Iyz<Pr<DyW, S23>>(A);
-        const double r3 = ((((dxu * zu2 + dyv * zv2) + dzw * (dzw * dzw)) + 2 * Ixz<DzU>(A) * Iyz<DzV>(A) * Ixy<S12>(A)) +
-                           2 * dzw * Ixz<Pr<DzU, S13>>(A)) + 2 * dzw * Iyz<Pr<DzV, S23>>(A);
-        const double r = (r1 + r2) + r3;
-        const double Cb_zeta = 0.0 / A.Fz(0);  // Cb = nothing
-        nu = -Cnu * amd_delta2(A) * (r - Cb_zeta) / q;
+    const long long o = A.u - u;
+    // filter-width ratios and spacings of the two z levels this cell touches (k is uniform across the workgroup)
+    const double dx = A.dx, dy = A.dy, Fx = A.Fx, Fy = A.Fy;
+    const double Fz[2] = {A.Fz(0), A.Fz(1)};
+    const double dzf[2] = {A.M.dzF(k), A.M.dzF(k + 1)};
+    const double dzc0 = A.M.dzC(k);
+#if OCN_STRICT
+#define AMD_D(num, den) ((num) / (den))
+    const double rxy = Fx / Fy, ryx = Fy / Fx;
+    const double rxz[2] = {Fx / Fz[0], Fx / Fz[1]}, rzx[2] = {Fz[0] / Fx, Fz[1] / Fx};
+    const double ryz[2] = {Fy / Fz[0], Fy / Fz[1]}, rzy[2] = {Fz[0] / Fy, Fz[1] / Fy};
+    const double qdx = dx, qdy = dy, qdzc = dzc0;
+    const double qdzf[2] = {dzf[0], dzf[1]};
+#else
+#define AMD_D(num, den) ((num) * (den))  /* den holds the reciprocal */
+    const double rFx = 1 / Fx, rFy = 1 / Fy, rFz[2] = {1 / Fz[0], 1 / Fz[1]};
+    const double rxy = Fx * rFy, ryx = Fy * rFx;
+    const double rxz[2] = {Fx * rFz[0], Fx * rFz[1]}, rzx[2] = {Fz[0] * rFx, Fz[1] * rFx};
+    const double ryz[2] = {Fy * rFz[0], Fy * rFz[1]}, rzy[2] = {Fz[0] * rFy, Fz[1] * rFy};
+    const double qdx = 1 / dx, qdy = 1 / dy, qdzc = 1 / dzc0;
+    const double qdzf[2] = {1 / dzf[0], 1 / dzf[1]};
+#endif
+    double dyu[2][2], dxv[2][2], dzu[2][2], dxw[2][2], dzv[2][2], dyw[2][2], dywq[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            dyu[a][b] = ryx * AMD_D(A.U(a, b, 0) - A.U(a, b - 1, 0), qdy);       // norm_∂y_u at (i+a, j+b, k)
+            dxv[a][b] = rxy * AMD_D(A.V(a, b, 0) - A.V(a - 1, b, 0), qdx);       // norm_∂x_v
+            dzu[a][b] = rzx[b] * AMD_D(A.U(a, 0, b) - A.U(a, 0, b - 1), qdzf[b]);  // norm_∂z_u at (i+a, j, k+b)
+            dxw[a][b] = rxz[b] * AMD_D(A.W(a, 0, b) - A.W(a - 1, 0, b), qdx);      // norm_∂x_w
+            dzv[a][b] = rzy[b] * AMD_D(A.V(0, a, b) - A.V(0, a, b - 1), qdzf[b]);  // norm_∂z_v at (i, j+a, k+b)
+            dyw[a][b] = ryz[b] * AMD_D(A.W(0, a, b) - A.W(0, a - 1, b), qdy);      // norm_∂y_w
+            dywq[a][b] = ryz[b] * AMD_D(A.W(a, 0, b) - A.W(a, -1, b), qdy);        // norm_∂y_w at (i+a, j, k+b): the ℑxz quirk
+        }
     }
-    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
-    nu_e[ocn::at(L, i, j, k)] = julia_max0(nu);
-}
+    const double dxu = AMD_D(A.U(1, 0, 0) - A.U(0, 0, 0), qdx), dyv = AMD_D(A.V(0, 1, 0) - A.V(0, 0, 0), qdy),
+                 dzw = AMD_D(A.W(0, 0, 1) - A.W(0, 0, 0), qdzc);
+    const double d2 = 3 / ((1 / (Fx * Fx) + 1 / (Fy * Fy)) + 1 / (Fz[0] * Fz[0]));
 
-__global__ __launch_bounds__(256) void amd_diffusivity_kernel(GridDev g, double Ck, const double *__restrict__ u,
-                                                              const double *__restrict__ v, const double *__restrict__ w,
-                                                              const double *__restrict__ c, double *__restrict__ kappa_e)
-{
-    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
-    if (i > g.Nx || j > g.Ny) return;
-    const Amd A = make_amd(g, u, v, w, c, i, j, k);
-    const double xc2 = Ix<Sq<DxC>>(A), yc2 = Iy<Sq<DyC>>(A), zc2 = Iz<Sq<DzC>>(A);
-    const double sigma = (xc2 + yc2) + zc2;
-    double kap = 0.0;
-    if (sigma != 0) {
-        const double cx = Ix<DxC>(A), cy = Iy<DyC>(A), cz = Iz<DzC>(A);
-        const double cx_ux = (DxU()(A, 0, 0, 0) * xc2 + Ixy<DxV>(A) * cx * cy) + Ixz<DxW>(A) * cx * cz;
-        // ℑxzᶜᵃᶜ (not ℑyz) of norm_∂y_w, as the reference writes it (anisotropic_minimum_dissipation.jl:313)
-        const double cy_uy = (Ixy<DyU>(A) * cy * cx + DyV()(A, 0, 0, 0) * yc2) + Ixz<DyW>(A) * cy * cz;
-        const double cz_uz = (Ixz<DzU>(A) * cz * cx + Iyz<DzV>(A) * cz * cy) + DzW()(A, 0, 0, 0) * zc2;
-        const double theta = (cx_ux + cy_uy) + cz_uz;
-        kap = -Ck * amd_delta2(A) * theta / sigma;
+    if (nu_e) {
+        double s12[2][2], s13[2][2], s23[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                s12[a][b] = 0.5 * (dyu[a][b] + dxv[a][b]);
+                s13[a][b] = 0.5 * (dzu[a][b] + dxw[a][b]);
+                s23[a][b] = 0.5 * (dzv[a][b] + dyw[a][b]);
+            }
+        const double xv2 = I4SQ(dxv), yu2 = I4SQ(dyu), xw2 = I4SQ(dxw), zu2 = I4SQ(dzu), yw2 = I4SQ(dyw), zv2 = I4SQ(dzv);
+        const double q = (((((((dxu * dxu + dyv * dyv) + dzw * dzw) + xv2) + yu2) + xw2) + zu2) + yw2) + zv2;
+        double nu = 0.0;
+        if (q != 0) {
+            const double r1 = ((((dxu * (dxu * dxu) + dyv * xv2) + dzw * xw2) + 2 * dxu * I4PR(dxv, s12)) + 2 * dxu * I4PR(dxw, s13)) +
+                              2 * I4(dxv) * I4(dxw) * I4(s23);
+            const double r2 = ((((dxu * yu2 + dyv * (dyv * dyv)) + dzw * yw2) + 2 * dyv * I4PR(dyu, s12)) + 2 * I4(dyu) * I4(dyw) * I4(s13)) +
+                              2 * dyv * I4PR(dyw, s23);
+            const double r3 = ((((dxu * zu2 + dyv * zv2) + dzw * (dzw * dzw)) + 2 * I4(dzu) * I4(dzv) * I4(s12)) + 2 * dzw * I4PR(dzu, s13)) +
+                              2 * dzw * I4PR(dzv, s23);
+            const double r = (r1 + r2) + r3;
+            const double Cb_zeta = 0.0 / Fz[0];  // Cb = nothing
+            nu = -Cnu * d2 * (r - Cb_zeta) / q;
+        }
+        nu_e[o] = julia_max0(nu);
     }
-    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
-    kappa_e[ocn::at(L, i, j, k)] = julia_max0(kap);
+    if (tr.n > 0) {
+        const double ixy_dxv = I4(dxv), ixz_dxw = I4(dxw), ixy_dyu = I4(dyu), ixz_dywq = I4(dywq), ixz_dzu = I4(dzu), iyz_dzv = I4(dzv);
+#pragma unroll
+        for (int n = 0; n < OCN_AMD_MAX_TRACERS; ++n) {
+            if (n >= tr.n) break;
+            const double *pc = tr.c[n] + o;
+            const long long s2 = A.s2, s3 = A.s3;
+            const double c0 = pc[0];
+            const double gx0 = Fx * AMD_D(c0 - pc[-1], qdx), gx1 = Fx * AMD_D(pc[1] - c0, qdx);               // norm_∂x_c at i, i+1
+            const double gy0 = Fy * AMD_D(c0 - pc[-s2], qdy), gy1 = Fy * AMD_D(pc[s2] - c0, qdy);             // norm_∂y_c at j, j+1
+            const double gz0 = Fz[0] * AMD_D(c0 - pc[-s3], qdzf[0]), gz1 = Fz[1] * AMD_D(pc[s3] - c0, qdzf[1]);  // norm_∂z_c at k, k+1
+            const double xc2 = 0.5 * (gx0 * gx0 + gx1 * gx1), yc2 = 0.5 * (gy0 * gy0 + gy1 * gy1), zc2 = 0.5 * (gz0 * gz0 + gz1 * gz1);
+            const double sigma = (xc2 + yc2) + zc2;
+            double kap = 0.0;
+            if (sigma != 0) {
+                const double cx = 0.5 * (gx0 + gx1), cy = 0.5 * (gy0 + gy1), cz = 0.5 * (gz0 + gz1);
+                const double cx_ux = (dxu * xc2 + ixy_dxv * cx * cy) + ixz_dxw * cx * cz;
+                const double cy_uy = (ixy_dyu * cy * cx + dyv * yc2) + ixz_dywq * cy * cz;  // ℑxz of norm_∂y_w, as the reference (:313)
+                const double cz_uz = (ixz_dzu * cz * cx + iyz_dzv * cz * cy) + dzw * zc2;
+                const double theta = (cx_ux + cy_uy) + cz_uz;
+                kap = -tr.Ck[n] * d2 * theta / sigma;
+            }
+            tr.kappa_e[n][o] = julia_max0(kap);
+        }
+    }
+#undef AMD_D
+}
+#undef I4
+#undef I4SQ
+#undef I4PR
+
+int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream)
+{
+    if (ntr > OCN_AMD_MAX_TRACERS) {
+        ocn::set_error("at most %d tracers per AMD launch, got %d", OCN_AMD_MAX_TRACERS, ntr);
+        return OCN_ERR_INVALID_ARGUMENT;
+    }
+    AmdTracers tr{};
+    tr.n = ntr;
+    for (int n = 0; n < ntr; ++n) {
+        tr.c[n] = c[n];
+        tr.kappa_e[n] = kappa_e[n];
+        tr.Ck[n] = Ck[n];
+    }
+    GridDev g = ocn::to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
 }
 
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream)
 {
-    GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
-    hipLaunchKernelGGL(amd_viscosity_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e);
-    OCN_CHECK_HIP(hipGetLastError());
-    return OCN_SUCCESS;
+    return launch_amd_fused(grid, Cnu, u, v, w, nu_e, 0, nullptr, nullptr, nullptr, stream);
 }
 
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
                            double *kappa_e, hipStream_t stream)
 {
-    GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
-    hipLaunchKernelGGL(amd_diffusivity_kernel, nb, block, 0, stream, g, Ck, u, v, w, c, kappa_e);
-    OCN_CHECK_HIP(hipGetLastError());
-    return OCN_SUCCESS;
+    return launch_amd_fused(grid, 0.0, u, v, w, nullptr, 1, &Ck, &c, &kappa_e, stream);
 }
 
 }  // namespace OCN_NS

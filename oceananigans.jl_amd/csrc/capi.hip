@@ -286,6 +286,21 @@ int ocn_compute_amd_viscosity(const ocn_grid *grid, double C_nu, const double *u
                                           : ocn_fast::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream));
 }
 
+int ocn_compute_amd_diffusivities(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w,
+                                  double *nu_e, int32_t n_tracers, const double *C_kappa, const double *const *tracers,
+                                  double *const *kappa_e, void *stream)
+{
+    int st = validate_amd(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && nu_e, "ocn_compute_amd_diffusivities: null field pointer");
+    OCN_REQUIRE(n_tracers >= 0 && n_tracers <= 4, "ocn_compute_amd_diffusivities: n_tracers = %d outside 0..4", n_tracers);
+    OCN_REQUIRE(n_tracers == 0 || (C_kappa && tracers && kappa_e), "ocn_compute_amd_diffusivities: null tracer arrays");
+    for (int n = 0; n < n_tracers; ++n) OCN_REQUIRE(tracers[n] && kappa_e[n], "ocn_compute_amd_diffusivities: tracer %d is NULL", n);
+    return g_math_mode == OCN_MATH_STRICT
+               ? ocn_strict::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream))
+               : ocn_fast::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream));
+}
+
 int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const double *u, const double *v, const double *w,
                                 const double *c, double *kappa_e, void *stream)
 {

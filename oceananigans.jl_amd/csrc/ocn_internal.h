@@ -78,6 +78,8 @@ int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const do
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
+int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream);
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream);
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
@@ -96,6 +98,8 @@ int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const do
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
+int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream);
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream);
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,

@@ -268,6 +268,12 @@ def compute_diffusivities(model):
     if d is None:
         return
     g, s = model.grid, stream_ptr()
+    nt = len(model.tracers)
+    if nt <= 4:  # νₑ and every κₑ in one launch
+        Ck = (C.c_double * max(nt, 1))(*[model.closure.Ckappa_of(n) for n in model.tracer_names])
+        _lib.call("ocn_compute_amd_diffusivities", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr, nt,
+                  Ck, _lib.ptr_array([c.ptr for c in model.tracers] or [None]), _lib.ptr_array([k.ptr for k in d["kappa_e"]] or [None]), s)
+        return
     _lib.call("ocn_compute_amd_viscosity", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr, s)
     for name, c, k in zip(model.tracer_names, model.tracers, d["kappa_e"]):
         _lib.call("ocn_compute_amd_diffusivity", g.cref, model.closure.Ckappa_of(name), model.u.ptr, model.v.ptr, model.w.ptr,
