@@ -227,6 +227,12 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
 int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *const *fields, const int32_t *locs,
                        const ocn_field_bcs *const *bcs, int32_t n, void *stream);
 
+/* ---- NaN check ----
+ * hasnan(field) = any(isnan, parent(field)) (src/Models/nan_checker.jl:33).  Scans n_elements doubles (the whole parent array)
+ * and sets *flag_device (a DEVICE int32 the caller zeroed) to 1 if any is NaN; asynchronous, the caller reads the flag when
+ * it wants the answer.  field must be 16-byte aligned (any ocn_malloc / torch allocation is). */
+int ocn_hasnan(const double *field, int64_t n_elements, int32_t *flag_device, void *stream);
+
 /* ---- Time steppers ----
  * rk3_substep_field! for n fields in one launch (src/TimeSteppers/runge_kutta_3.jl:160-208).
  * has_zeta = 0 selects the first-stage method  U += (Δt*γ)*Gⁿ. */

@@ -201,6 +201,14 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
+int ocn_hasnan(const double *field, int64_t n_elements, int32_t *flag_device, void *stream)
+{
+    OCN_REQUIRE(field && flag_device, "ocn_hasnan: null pointer");
+    OCN_REQUIRE(n_elements >= 0, "ocn_hasnan: negative element count");
+    OCN_REQUIRE((reinterpret_cast<uintptr_t>(field) & 15) == 0, "ocn_hasnan: field must be 16-byte aligned");
+    return launch_hasnan(field, n_elements, flag_device, as_stream(stream));
+}
+
 // ---- SURVEY §8(f) rank 1 ------------------------------------------------------------------------------
 static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
 {

@@ -211,6 +211,36 @@ int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// hasnan(field) = any(isnan, parent(field)) (src/Models/nan_checker.jl:33): grid-stride scan, flag <- 1 on the first NaN.
+// 16-B loads; the flag lives in device memory so the default NaNChecker callback costs one read pass and no host sync
+// until the caller looks at the flag.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hasnan_kernel(const double *__restrict__ a, long long n, int *__restrict__ flag)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool bad = false;
+    const long long n2 = n / 2;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a);
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n2; t += stride) {
+        const double2 x = a2[t];
+        bad |= (x.x != x.x) | (x.y != x.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) bad |= (a[n - 1] != a[n - 1]);
+    if (bad) *flag = 1;
+}
+
+int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream)
+{
+    if (n <= 0) return OCN_SUCCESS;
+    long long nb = (n / 2 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(hasnan_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a, n, flag);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Time-stepper kernels (runge_kutta_3.jl:194-208, quasi_adams_bashforth_2.jl:162-175, store_tendencies.jl:6-9)
 // mode 0: rk3 first stage  U += (dt*gamma)*Gn
 // mode 1: rk3             U += dt*(gamma*Gn + zeta*Gm)

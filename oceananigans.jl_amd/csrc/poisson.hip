@@ -147,7 +147,9 @@ static void free_all(ocn_poisson *s)
         }
 }
 
-extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
+static int poisson_plans_self_test(ocn_poisson *s);
+
+static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool force_c2c)
 {
     OCN_REQUIRE(out && grid, "ocn_poisson_create: null argument");
     int st = ocn::validate_grid(grid);
@@ -159,7 +161,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
     s->grid = *grid;
     const int Nx = grid->Nx, Ny = grid->Ny, Nz = grid->Nz, Hz = grid->Hz;
     const char *env = std::getenv("OCN_POISSON_C2C");
-    s->c2c = env && env[0] == '1';
+    s->c2c = force_c2c || (env && env[0] == '1');
     if (grid->tz == OCN_BOUNDED) {
         s->kind = 1;  // nonhydrostatic_pressure_solver dispatch (NonhydrostaticModels.jl:25-62); see DESIGN.md for z regular+Bounded
     } else {
@@ -267,8 +269,10 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
         const size_t pdist = (fft_dims == 3) ? (size_t)Lp.s3 * Lp.sz : (size_t)Lp.s3;
         TRY(make_plan(s->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward, fft_dims, len, batch,
                       rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, rstr, rdist, cstr, cdist, 1.0));
-        int bst = make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
-                            rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, pstr, pdist, scale);
+        const char *ed = std::getenv("OCN_POISSON_DIRECT_OUT");
+        int bst = (ed && ed[0] == '0') ? OCN_ERR_UNSUPPORTED
+                                       : make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
+                                                   rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, pstr, pdist, scale);
         if (bst != OCN_SUCCESS) {
             // rocFFT has no kernel for this strided-output shape: transform into the contiguous real buffer and
             // copy into the pressure interior (the reference's copy_real_component! pass).
@@ -280,9 +284,103 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid)
     }
 #undef TRY
 #undef TRY_HIP
+    // rocFFT real-transform plans have been observed to return wrong results when certain other real plans already exist in
+    // the process (e.g. a 16^3 3-D R2C plan followed by a batched 32x8 2-D one, rocFFT of ROCm 7.2): every plan pair is
+    // verified by a forward + inverse round trip before the handle is handed out; a failing real pair is replaced by
+    // complex plans, a failing complex pair is an error.
+    if (!s->custom_xy) {
+        st = poisson_plans_self_test(s);
+        if (st != OCN_SUCCESS) {
+            const bool was_c2c = s->c2c;
+            free_all(s);
+            delete s;
+            if (was_c2c) return st;
+            return poisson_create_impl(out, grid, true);
+        }
+    }
     *out = s;
     return OCN_SUCCESS;
 }
+
+// forward then inverse transform of a pseudo-random field must reproduce it (times the plans' net scale)
+static int poisson_plans_self_test(ocn_poisson *s)
+{
+    const ocn_grid *g = &s->grid;
+    const int Nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
+    const size_t n = (size_t)Nx * Ny * Nz;
+    const bool three_d = (s->kind == 0 && g->tz == OCN_PERIODIC && !s->fused_z);
+    const double count = (double)Nx * Ny * (three_d ? Nz : 1);
+    const double net = s->fused_z ? count : 1.0;  // inverse plans carry 1/count unless the column kernel applies it
+    std::vector<double> in(n), outv;
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (size_t q = 0; q < n; ++q) {  // splitmix-style generator, values in (-1, 1)
+        x += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        in[q] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+    double err = 0.0;
+    if (s->c2c) {
+        std::vector<double> c(2 * n, 0.0);
+        for (size_t q = 0; q < n; ++q) c[2 * q] = in[q];
+        OCN_CHECK_HIP(hipMemcpy(s->spec, c.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
+        int st = s->fwd.exec(s->spec, nullptr, nullptr);
+        if (st != OCN_SUCCESS) return st;
+        st = s->bwd.exec(s->spec, nullptr, nullptr);
+        if (st != OCN_SUCCESS) return st;
+        OCN_CHECK_HIP(hipDeviceSynchronize());
+        OCN_CHECK_HIP(hipMemcpy(c.data(), s->spec, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < n; ++q) {
+            err = std::fmax(err, std::fabs(c[2 * q] - net * in[q]));
+            err = std::fmax(err, std::fabs(c[2 * q + 1]));
+        }
+        OCN_CHECK_HIP(hipMemset(s->spec, 0, 2 * n * sizeof(double)));
+    } else {
+        ocn::GridDev gd = ocn::to_dev(*g);
+        ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+        const size_t np = (size_t)Lp.sx * Lp.sy * Lp.sz;
+        double *tmp = nullptr;
+        OCN_CHECK_HIP(hipMemcpy(s->rhs, in.data(), n * sizeof(double), hipMemcpyHostToDevice));
+        int st = s->fwd.exec(s->rhs, s->spec, nullptr);
+        if (st != OCN_SUCCESS) return st;
+        if (s->direct_out) {
+            OCN_CHECK_HIP(hipMalloc((void **)&tmp, np * sizeof(double)));
+            OCN_CHECK_HIP(hipMemset(tmp, 0, np * sizeof(double)));
+            st = s->bwd.exec(s->spec, tmp + Lp.o, nullptr);
+        } else {
+            st = s->bwd.exec(s->spec, s->rhs, nullptr);
+        }
+        if (st != OCN_SUCCESS) {
+            if (tmp) (void)hipFree(tmp);
+            return st;
+        }
+        OCN_CHECK_HIP(hipDeviceSynchronize());
+        if (s->direct_out) {
+            outv.resize(np);
+            OCN_CHECK_HIP(hipMemcpy(outv.data(), tmp, np * sizeof(double), hipMemcpyDeviceToHost));
+            (void)hipFree(tmp);
+            for (int k = 0; k < Nz; ++k)
+                for (int j = 0; j < Ny; ++j)
+                    for (int i = 0; i < Nx; ++i)
+                        err = std::fmax(err, std::fabs(outv[Lp.o + i + Lp.s2 * j + Lp.s3 * k] - net * in[i + (size_t)Nx * (j + (size_t)Ny * k)]));
+        } else {
+            outv.resize(n);
+            OCN_CHECK_HIP(hipMemcpy(outv.data(), s->rhs, n * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t q = 0; q < n; ++q) err = std::fmax(err, std::fabs(outv[q] - net * in[q]));
+        }
+        OCN_CHECK_HIP(hipMemset(s->rhs, 0, n * sizeof(double)));
+        OCN_CHECK_HIP(hipMemset(s->spec, 0, (size_t)s->nxh * Ny * Nz * 2 * sizeof(double)));
+    }
+    if (!(err <= 1e-9 * net)) {
+        ocn::set_error("rocFFT %s plan pair for %dx%dx%d failed its round-trip self test (max error %.3e)", s->c2c ? "complex" : "real", Nx, Ny, Nz, err);
+        return OCN_ERR_ROCFFT;
+    }
+    return OCN_SUCCESS;
+}
+
+extern "C" int ocn_poisson_create(ocn_poisson_t *out, const ocn_grid *grid) { return poisson_create_impl(out, grid, false); }
 
 extern "C" int ocn_poisson_destroy(ocn_poisson_t s)
 {
@@ -454,7 +552,61 @@ static void free_all(ocn_dist_poisson *s)
         }
 }
 
+static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c);
+
 extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx)
+{
+    return dist_create_impl(out, lg, rank, R, global_Lx, false);
+}
+
+// real (y, z) plan pair of the slab: forward + inverse must reproduce a pseudo-random field (see poisson_plans_self_test)
+static int dist_real_plans_self_test(ocn_dist_poisson *s)
+{
+    const ocn_grid *g = &s->grid;
+    const int nx = g->Nx, Ny = g->Ny, Nz = g->Nz;
+    const size_t n = (size_t)nx * Ny * Nz;
+    std::vector<double> in(n);
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (size_t q = 0; q < n; ++q) {
+        x += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        in[q] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+    ocn::GridDev gd = ocn::to_dev(*g);
+    ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+    const size_t np = (size_t)Lp.sx * Lp.sy * Lp.sz;
+    double *tmp = nullptr;
+    OCN_CHECK_HIP(hipMalloc((void **)&tmp, np * sizeof(double)));
+    OCN_CHECK_HIP(hipMemset(tmp, 0, np * sizeof(double)));
+    OCN_CHECK_HIP(hipMemcpy(s->rhs, in.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    int st = s->fyz.exec(s->rhs, s->yfield, nullptr);
+    if (st == OCN_SUCCESS) st = s->byz.exec(s->yfield, tmp + Lp.o, nullptr);
+    if (st != OCN_SUCCESS) {
+        (void)hipFree(tmp);
+        return st;
+    }
+    OCN_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<double> outv(np);
+    OCN_CHECK_HIP(hipMemcpy(outv.data(), tmp, np * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(tmp);
+    double err = 0.0;
+    for (int k = 0; k < Nz; ++k)
+        for (int j = 0; j < Ny; ++j)
+            for (int i = 0; i < nx; ++i)
+                err = std::fmax(err, std::fabs(outv[Lp.o + i + Lp.s2 * j + Lp.s3 * k] - in[i + (size_t)nx * (j + (size_t)Ny * k)]));
+    OCN_CHECK_HIP(hipMemset(s->rhs, 0, n * sizeof(double)));
+    OCN_CHECK_HIP(hipMemset(s->yfield, 0, (size_t)nx * s->nyt * Nz * 2 * sizeof(double)));
+    if (!(err <= 1e-9)) {
+        ocn::set_error("rocFFT real (y, z) plan pair for the %dx%dx%d slab failed its round-trip self test (max error %.3e)", nx, Ny, Nz, err);
+        return OCN_ERR_ROCFFT;
+    }
+    return OCN_SUCCESS;
+}
+
+static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c)
 {
     OCN_REQUIRE(out && lg, "ocn_dist_poisson_create: null argument");
     int st = ocn::validate_grid(lg);
@@ -472,7 +624,7 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     s->nx = lg->Nx; s->Nxg = lg->Nx * R;
     const int nx = s->nx, Ny = lg->Ny, Nz = lg->Nz, Nxg = s->Nxg;
     const char *env = std::getenv("OCN_POISSON_C2C");
-    s->r2c = !(env && env[0] == '1');
+    s->r2c = !force_c2c && !(env && env[0] == '1');
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
     if (lg->tz == OCN_BOUNDED) {
@@ -597,6 +749,11 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *
     }
 #undef TRY
 #undef TRY_HIP
+    if (s->r2c && dist_real_plans_self_test(s) != OCN_SUCCESS) {  // see poisson_create_impl: fall back to complex plans
+        free_all(s);
+        delete s;
+        return dist_create_impl(out, lg, rank, R, global_Lx, true);
+    }
     *out = s;
     return OCN_SUCCESS;
 }

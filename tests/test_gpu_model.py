@@ -67,6 +67,40 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
     assert err <= 1e-10 * max(1.0, np.abs(p0).max())
 
 
+def test_two_solver_handles_coexist(oracle, ocn):
+    """Regression: with a 16^3 (P,P,P) solver alive, the real-to-complex rocFFT plans of a (32, 8, 16) (P,P,B) solver returned
+    garbage (a rocFFT plan-cache interaction); every plan pair is now round-trip tested at creation and replaced by complex
+    plans if it fails.  Both handles must solve correctly, in either creation order."""
+    O = oracle
+
+    def residual(size, topo, z, keep):
+        og, pg = make_pair(O, ocn, size, topo, x=(0, 64), y=(0, 64), z=z)
+        rng = np.random.default_rng(1)
+        U = []
+        for loc in (1, 2, 4):
+            a = og.zeros(loc)
+            og.interior(a)[...] = rng.uniform(-1, 1, og.interior(a).shape)
+            O.fill_halo_regions(og, a, loc)
+            U.append(a)
+        R = O.divergence(og, *U)
+        dU = [to_dev(ocn, pg, l, a) for l, a in zip((1, 2, 4), U)]
+        S = ocn.nonhydrostatic_pressure_solver(pg)
+        keep.append(S)
+        p = ocn.CenterField(pg)
+        ocn.solve_for_pressure(p, S, 1.0, dU)
+        ocn.fill_halo_regions(p)
+        ocn.sync_device()
+        return np.linalg.norm(O.laplacian(og, from_dev(p)) - R) / np.linalg.norm(R)
+
+    A = ((16, 16, 16), "PPP", (0, 64))
+    B = ((32, 8, 16), "PPB", stretched_faces(16, 32.0))
+    for order in ((A, B), (B, A)):
+        keep = []
+        for case in order:
+            assert residual(*case, keep) < 1e-12
+        del keep
+
+
 def test_poisson_set_source_term(oracle, ocn):
     """solve!(ϕ, solver, b): ∇²ϕ = b for a zero-mean b."""
     O = oracle
@@ -233,3 +267,52 @@ def test_fused_stage_boundaries_equal_unfused(ocn, topo, z):
     a, b = models
     for fa, fb in zip(a.velocities + (a.pNHS,) + tuple(a.timestepper.Gn), b.velocities + (b.pNHS,) + tuple(b.timestepper.Gn)):
         np.testing.assert_array_equal(fa.parent(), fb.parent())
+
+
+def test_hasnan_and_nan_checker(ocn):
+    """src/Models/nan_checker.jl:33-52: hasnan(field) scans the whole parent array (halos included); NaNChecker names the field."""
+    import torch
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(9, 7, 5), x=(0, 1), y=(0, 1), z=(0, 1), topology=("Periodic",) * 3)
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers="c")
+    assert not ocn.hasnan(m) and not ocn.hasnan(m.tracers[0])
+    chk = ocn.NaNChecker({"u": m.u, "c": m.tracers[0]})
+    assert chk(m) is None
+    m.tracers[0].data.view(-1)[-1] = float("nan")  # the very last (odd-count) element, in a halo
+    assert ocn.hasnan(m.tracers[0]) and not ocn.hasnan(m)
+    assert chk(m) == "c"
+    with pytest.raises(RuntimeError, match="NaN found in field c"):
+        ocn.NaNChecker({"c": m.tracers[0]}, erroring=True)(m)
+    m.u.data[2, 3, 4] = float("nan")
+    assert ocn.hasnan(m)
+
+
+@pytest.mark.parametrize("ts", ["RungeKutta3", "QuasiAdamsBashforth2"])
+def test_checkpoint_pickup_is_exact(ocn, ts, tmp_path):
+    """OutputWriters/checkpointer.jl:177-288 (test_checkpointer.jl idea): run 2 steps, checkpoint, run 2 more; a fresh model
+    restored from the checkpoint and run 2 steps ends bit-identical."""
+    rng = np.random.default_rng(3)
+    N = (16, 12, 10)
+
+    def build():
+        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 1), y=(0, 1), z=stretched_faces(N[2], 1.0), topology=("Periodic", "Periodic", "Bounded"))
+        return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("b",), timestepper=ts, buoyancy=ocn.BuoyancyTracer(),
+                                       closure=ocn.ScalarDiffusivity(ν=1e-3, κ=1e-3))
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    m = build()
+    ocn.set(m, u=rng.uniform(-1, 1, N), v=rng.uniform(-1, 1, N), b=rng.uniform(0, 1, N))
+    dt = 2e-3
+    for _ in range(2):
+        ocn.time_step(m, dt)
+    path = ocn.write_checkpoint(m, str(tmp_path / "checkpoint_iteration2"))
+    for _ in range(2):
+        ocn.time_step(m, dt)
+    r = build()
+    ocn.set_from_checkpoint(r, path)
+    assert r.clock.iteration == 2 and r.clock.time == 2 * dt if ts != "RungeKutta3" else r.clock.iteration == 2
+    for _ in range(2):
+        ocn.time_step(r, dt)
+    ocn.sync_device()
+    for a, b in zip(m.prognostic_fields(), r.prognostic_fields()):
+        np.testing.assert_array_equal(a.parent(), b.parent())
+    assert r.clock.time == m.clock.time
