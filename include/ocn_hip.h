@@ -227,6 +227,22 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
 int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *const *fields, const int32_t *locs,
                        const ocn_field_bcs *const *bcs, int32_t n, void *stream);
 
+/* One RK3 stage boundary of a model with the §8(f) terms in as few passes as possible (no reference counterpart; results
+ * identical to ocn_compute_*_tendencies_terms + ocn_apply_flux_bcs + ocn_rk3_substep, bit for bit in strict math):
+ * the tendencies of the current state INCLUDING the bottom / top flux boundary contributions land in G, and the NEXT stage's
+ *   U_out = U + Δt (γ G + ζ G⁻)   (has_zeta = 0:  U_out = U + (Δt γ) G)
+ * is written to a second storage (must not alias the inputs; the wall faces of w are carried over).  bcs_* may be NULL. */
+int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
+                                              const ocn_field_bcs *bcs_v, const double *u, const double *v, const double *w,
+                                              double *Gu, double *Gv, double *Gw, const double *Gmu, const double *Gmv,
+                                              const double *Gmw, double *u_out, double *v_out, double *w_out, double dt,
+                                              double gamma, double zeta, int32_t has_zeta, const int32_t *range, void *stream);
+/* same for one tracer; advection must be OCN_ADVECTION_WENO5 (advection, diffusion, boundary flux and substep are ONE kernel) */
+int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
+                                          const ocn_field_bcs *bcs_c, const double *u, const double *v, const double *w,
+                                          const double *c, double *Gc, const double *Gmc, double *c_out, double dt, double gamma,
+                                          double zeta, int32_t has_zeta, const int32_t *range, void *stream);
+
 /* ---- NaN check ----
  * hasnan(field) = any(isnan, parent(field)) (src/Models/nan_checker.jl:33).  Scans n_elements doubles (the whole parent array)
  * and sets *flag_device (a DEVICE int32 the caller zeroed) to 1 if any is NaN; asynchronous, the caller reads the flag when

@@ -360,6 +360,84 @@ static int make_zbc_tuple(const ocn_grid *grid, const int32_t *locs, const ocn_f
     return OCN_SUCCESS;
 }
 
+static int flux_side(const ocn_grid *grid, const ocn_field_bcs *b, const char *name, ZBc &bottom, ZBc &top)
+{
+    bottom = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
+    top = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
+    if (!b) return OCN_SUCCESS;
+    OCN_REQUIRE(b->west.kind == OCN_BC_DEFAULT && b->east.kind == OCN_BC_DEFAULT && b->south.kind == OCN_BC_DEFAULT &&
+                    b->north.kind == OCN_BC_DEFAULT, "%s: only bottom / top boundary conditions are supported", name);
+    const ocn_bc *side[2] = {&b->bottom, &b->top};
+    for (int sd = 0; sd < 2; ++sd) {
+        const ocn_bc &c = *side[sd];
+        OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "%s: unknown boundary condition kind %d", name, c.kind);
+        if (c.kind != OCN_BC_FLUX) continue;
+        OCN_REQUIRE(grid->tz == OCN_BOUNDED, "bottom / top boundary conditions need a Bounded z (topology %d)", grid->tz);
+        OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions are not supported on a partitioned grid");
+        ZBc &d = sd ? top : bottom;
+        d.kind = c.kind; d.value = c.value; d.coeff = c.coeff; d.values = c.values;
+    }
+    return OCN_SUCCESS;
+}
+
+int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
+                                              const ocn_field_bcs *bcs_v, const double *u, const double *v, const double *w,
+                                              double *Gu, double *Gv, double *Gw, const double *Gmu, const double *Gmv,
+                                              const double *Gmw, double *u_out, double *v_out, double *w_out, double dt,
+                                              double gamma, double zeta, int32_t has_zeta, const int32_t *range, void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && Gu && Gv && Gw && u_out && v_out && w_out, "ocn_compute_momentum_tendencies_terms_rk3: null field pointer");
+    OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_terms_rk3: G⁻ pointers are required when has_zeta != 0");
+    OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_terms_rk3: outputs must not alias the inputs");
+    MomentumFinal mf{};
+    st = flux_side(grid, bcs_u, "u", mf.bottom[0], mf.top[0]);
+    if (st != OCN_SUCCESS) return st;
+    st = flux_side(grid, bcs_v, "v", mf.bottom[1], mf.top[1]);
+    if (st != OCN_SUCCESS) return st;
+    mf.sub[0] = SubstepDev{Gmu, u_out};
+    mf.sub[1] = SubstepDev{Gmv, v_out};
+    mf.sub[2] = SubstepDev{Gmw, w_out};
+    mf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    hipStream_t s = as_stream(stream);
+    if (terms->advection == OCN_ADVECTION_WENO5)
+        st = strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
+                    : ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
+    else
+        st = strict ? ocn_strict::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s)
+                    : ocn_fast::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s);
+    if (st != OCN_SUCCESS) return st;
+    TermsDev t = to_dev(*terms);
+    return strict ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s, &mf)
+                  : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s, &mf);
+}
+
+int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
+                                          const ocn_field_bcs *bcs_c, const double *u, const double *v, const double *w,
+                                          const double *c, double *Gc, const double *Gmc, double *c_out, double dt, double gamma,
+                                          double zeta, int32_t has_zeta, const int32_t *range, void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(terms->advection == OCN_ADVECTION_WENO5, "ocn_compute_tracer_tendency_terms_rk3: advection must be WENO5");
+    OCN_REQUIRE(u && v && w && c && Gc && c_out, "ocn_compute_tracer_tendency_terms_rk3: null field pointer");
+    OCN_REQUIRE(!has_zeta || Gmc, "ocn_compute_tracer_tendency_terms_rk3: G⁻ is required when has_zeta != 0");
+    OCN_REQUIRE(c_out != c, "ocn_compute_tracer_tendency_terms_rk3: the output must not alias the input");
+    OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
+    TracerFuse tf{};
+    tf.diffusion = terms->closure != 0;
+    tf.kappa = kappa;
+    tf.kappa_e = kappa_e;
+    st = flux_side(grid, bcs_c, "tracer", tf.bottom, tf.top);
+    if (st != OCN_SUCCESS) return st;
+    tf.sub = SubstepDev{Gmc, c_out};
+    tf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
+    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream), &tf)
+                                          : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream), &tf);
+}
+
 int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const int32_t *locs,
                               const ocn_field_bcs *const *bcs, int32_t n, int32_t fill_boundary_normal_velocities,
                               void *stream)

@@ -20,13 +20,6 @@ __device__ __forceinline__ int wrap1(int i, int N) { return i < 1 ? i + N : (i >
 //   ∇c = gradient, or (c¹ - v)/(Δ/2) [bottom], (v - cᴺ)/(Δ/2) [top];   c[0] = c¹ + ∇c*(-Δ),  c[N+1] = cᴺ + ∇c*Δ,
 // Δ = Δzᶜᶜᶠ at the boundary face.  x, y halo columns take the value of their periodic image, as the reference's
 // later Periodic fills would copy it.
-__device__ __forceinline__ double bc_condition(const ZBc &bc, int i, int j, int Nx, double c_int)
-{
-    if (bc.values) return bc.values[(i - 1) + (long long)Nx * (j - 1)];
-    if (bc.coeff != 0.0) return bc.value + bc.coeff * c_int;
-    return bc.value;
-}
-
 template <int TZ>
 __global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a, int wrap_x, int only_dir, ZBcTuple zbc, int has_bc)
 {

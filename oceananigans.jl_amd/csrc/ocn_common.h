@@ -110,6 +110,44 @@ inline TermsDev to_dev(const ocn_model_terms &m)
     return t;
 }
 
+// bottom / top boundary condition of one field (kind 0: default fill / no flux)
+struct ZBc {
+    int kind;
+    double value, coeff;
+    const double *values;
+};
+// value of a boundary condition at (i, j): array entry, value + coeff * c[boundary cell], or the number
+__host__ __device__ inline double bc_condition(const ZBc &bc, int i, int j, int Nx, double c_int)
+{
+    if (bc.values) return bc.values[(i - 1) + (long long)Nx * (j - 1)];
+    if (bc.coeff != 0.0) return bc.value + bc.coeff * c_int;
+    return bc.value;
+}
+// the NEXT stage's rk3 substep of one field, as the epilogue of its tendency kernel:  out = U + dt*(gamma*G + zeta*Gm)
+struct SubstepDev {
+    const double *Gm;
+    double *out;
+};
+struct SubstepCoef {
+    double dt, gamma, zeta;
+    int on, has_zeta;
+};
+// everything the tracer tendency kernel can fold in besides advection (physics.hip / tendencies.hip)
+struct TracerFuse {
+    int diffusion;          // add -∇_dot_qᶜ
+    double kappa;
+    const double *kappa_e;  // eddy diffusivity field or NULL
+    ZBc bottom, top;        // flux boundary conditions (kind OCN_BC_FLUX) folded into Gc
+    SubstepDev sub;
+    SubstepCoef sc;
+};
+// flux boundary conditions of u, v and the substeps of u, v, w for the momentum "finaliser" (momentum_extra_kernel)
+struct MomentumFinal {
+    ZBc bottom[2], top[2];
+    SubstepDev sub[3];
+    SubstepCoef sc;
+};
+
 int validate_grid(const ocn_grid *g);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

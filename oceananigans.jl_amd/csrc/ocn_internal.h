@@ -22,11 +22,6 @@ struct StepTuple {
 };
 
 // bottom / top boundary conditions of the fields of a FieldTuple (kind 0: default fill)
-struct ZBc {
-    int kind;
-    double value, coeff;
-    const double *values;
-};
 struct ZBcTuple {
     ZBc bottom[MAX_TUPLE], top[MAX_TUPLE];
 };
@@ -70,13 +65,14 @@ namespace ocn_strict {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
-                           double *Gc, const int32_t *range, hipStream_t stream);
+                           double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                               double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                             double *Gc, const int32_t *range, hipStream_t stream);
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
-                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream,
+                          const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
@@ -90,13 +86,14 @@ namespace ocn_fast {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
-                           double *Gc, const int32_t *range, hipStream_t stream);
+                           double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                               double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                             double *Gc, const int32_t *range, hipStream_t stream);
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
-                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream,
+                          const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,

@@ -163,10 +163,12 @@ __device__ __forceinline__ double buoyancy_ccc(const TermsDev &t, long long a)
 }
 
 template <int TZ>
+// `mf`: the flux boundary contributions of u, v (apply_flux_bcs.jl:107-160) and the NEXT stage's rk3 substep of u, v, w into a
+// second storage, folded into this last pass over G (same operations as apply_flux_bcs_kernel / stepper_kernel).
 __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev t, const double *__restrict__ u,
                                                              const double *__restrict__ v, const double *__restrict__ w,
                                                              double *__restrict__ Gu, double *__restrict__ Gv,
-                                                             double *__restrict__ Gw, PRange r)
+                                                             double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf)
 {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -224,7 +226,12 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
             }
             G = G - 1 / (Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
         }
+        if (TZ == OCN_BOUNDED) {
+            if (k == 1 && mf.bottom[0].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[0], i, j, g.Nx, pu[0]) * Az / (Az * M.dzC(1));
+            if (k == g.Nz && mf.top[0].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[0], i, j, g.Nx, pu[0]) * Az / (Az * M.dzC(g.Nz));
+        }
         Gu[o] = G;
+        if (mf.sc.on) mf.sub[0].out[o] = pu[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     {   // ---------------- Gv at (c,f,c)
         double G = Gv[o];
@@ -246,7 +253,12 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
             }
             G = G - 1 / (Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
         }
+        if (TZ == OCN_BOUNDED) {
+            if (k == 1 && mf.bottom[1].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[1], i, j, g.Nx, pv[0]) * Az / (Az * M.dzC(1));
+            if (k == g.Nz && mf.top[1].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[1], i, j, g.Nx, pv[0]) * Az / (Az * M.dzC(g.Nz));
+        }
         Gv[o] = G;
+        if (mf.sc.on) mf.sub[1].out[o] = pv[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
         double G = Gw[o];
@@ -271,7 +283,12 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
             G = G - 1 / (Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
         }
         Gw[o] = G;
+        const bool wall = (TZ == OCN_BOUNDED) && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face
+        if (mf.sc.on) mf.sub[2].out[o] = wall ? pw[0] : pw[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[2].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+    } else if (mf.sc.on) {
+        mf.sub[2].out[o] = pw[0];  // wall face (exclude_periphery): carried over unchanged
     }
+    if (mf.sc.on && TZ == OCN_BOUNDED && k == g.Nz) mf.sub[2].out[o + s3] = pw[s3];  // top wall face k = Nz+1
 }
 
 // Gc <- Gc - ∇_dot_qᶜ,  q = -(κ ∂c)  (closure_kernel_operators.jl:48-53)
@@ -363,15 +380,18 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
 }
 
 int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double *u, const double *v, const double *w,
-                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+                          double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream,
+                          const ocn::MomentumFinal *fin)
 {
+    ocn::MomentumFinal mf{};
+    if (fin) mf = *fin;
     PRange r;
     int st = make_prange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
     dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
-    OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r);
+    OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r, mf);
     return OCN_SUCCESS;
 }
 

@@ -476,10 +476,15 @@ __device__ __forceinline__ double tracer_flux(double area, double ut, const doub
     return (area * ut) * cr;
 }
 
+// `tf` folds the rest of tracer_tendency and of the stage boundary into the same pass: -∇_dot_qᶜ (closure_kernel_operators.jl:48-53,
+// κ a number or the field κₑ), the bottom / top flux boundary contributions (apply_flux_bcs.jl:107-160) and the NEXT stage's
+// rk3 substep into a second storage.  Same operations in the same order as the separate kernels (physics.hip
+// tracer_diffusion_kernel, kernels.hip apply_flux_bcs_kernel, stepper_kernel): bit-identical in the strict build.
 template <int TZ>
 __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const double *__restrict__ u,
                                                               const double *__restrict__ v, const double *__restrict__ w,
-                                                              const double *__restrict__ c, double *__restrict__ Gc, Range r)
+                                                              const double *__restrict__ c, double *__restrict__ Gc, Range r,
+                                                              ocn::TracerFuse tf)
 {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -502,7 +507,38 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
         dzF = fz1 - fz0;
     }
     const double rV = 1 / (M.Az * M.dzC(k));
-    Gc[ocn::at(Lc, i, j, k)] = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+    double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+    const long long o = ocn::at(Lc, i, j, k);
+    if (tf.diffusion) {
+        const long long s2 = Lc.s2, s3 = Lc.s3;
+        const double dx = M.dx, dy = M.dy, dzc = M.dzC(k);
+        const double c0 = pc[0];
+        const double *pk = tf.kappa_e ? tf.kappa_e + o : nullptr;
+        const double k0 = pk ? pk[0] : tf.kappa;
+        const double kxe = pk ? 0.5 * (k0 + pk[1]) : tf.kappa, kxw = pk ? 0.5 * (pk[-1] + k0) : tf.kappa;
+        const double kyn = pk ? 0.5 * (k0 + pk[s2]) : tf.kappa, kys = pk ? 0.5 * (pk[-s2] + k0) : tf.kappa;
+#if OCN_STRICT
+#define OCN_TD(a, d) ((a) / (d))
+#else
+#define OCN_TD(a, d) ((a) * (1 / (d)))
+#endif
+        const double qxe = -(kxe * OCN_TD(pc[1] - c0, dx)), qxw = -(kxw * OCN_TD(c0 - pc[-1], dx));
+        const double qyn = -(kyn * OCN_TD(pc[s2] - c0, dy)), qys = -(kys * OCN_TD(c0 - pc[-s2], dy));
+        double dzq = 0.0;
+        if (TZ != OCN_FLAT) {
+            const double kzt = pk ? 0.5 * (k0 + pk[s3]) : tf.kappa, kzb = pk ? 0.5 * (pk[-s3] + k0) : tf.kappa;
+            const double qzt = -(kzt * OCN_TD(pc[s3] - c0, M.dzF(k + 1))), qzb = -(kzb * OCN_TD(c0 - pc[-s3], M.dzF(k)));
+            dzq = az * qzt - az * qzb;
+        }
+#undef OCN_TD
+        G = G - 1 / (az * dzc) * (((ax * qxe - ax * qxw) + (ay * qyn - ay * qys)) + dzq);
+    }
+    if (TZ == OCN_BOUNDED) {  // apply_z_bcs!: k is uniform across the workgroup
+        if (k == 1 && tf.bottom.kind == OCN_BC_FLUX) G += ocn::bc_condition(tf.bottom, i, j, g.Nx, pc[0]) * az / (az * M.dzC(1));
+        if (k == g.Nz && tf.top.kind == OCN_BC_FLUX) G -= ocn::bc_condition(tf.top, i, j, g.Nx, pc[0]) * az / (az * M.dzC(g.Nz));
+    }
+    Gc[o] = G;
+    if (tf.sc.on) tf.sub.out[o] = pc[0] + (tf.sc.has_zeta ? tf.sc.dt * (tf.sc.gamma * G + tf.sc.zeta * tf.sub.Gm[o]) : (tf.sc.dt * tf.sc.gamma) * G);
 }
 
 static int tile_variant()
@@ -609,8 +645,10 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
 }
 
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
-                           double *Gc, const int32_t *range, hipStream_t stream)
+                           double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse)
 {
+    ocn::TracerFuse tf{};
+    if (fuse) tf = *fuse;
     Range r;
     int st = make_range(grid, range, r);
     if (st != OCN_SUCCESS) return st;
@@ -619,9 +657,9 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
     dim3 block(64, 4, 1);
     dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
     switch (grid->tz) {
-        case OCN_PERIODIC: hipLaunchKernelGGL(tracer_tendency_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, c, Gc, r); break;
-        case OCN_BOUNDED: hipLaunchKernelGGL(tracer_tendency_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, c, Gc, r); break;
-        case OCN_FLAT: hipLaunchKernelGGL(tracer_tendency_direct<OCN_FLAT>, nb, block, 0, stream, g, u, v, w, c, Gc, r); break;
+        case OCN_PERIODIC: hipLaunchKernelGGL(tracer_tendency_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, c, Gc, r, tf); break;
+        case OCN_BOUNDED: hipLaunchKernelGGL(tracer_tendency_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, c, Gc, r, tf); break;
+        case OCN_FLAT: hipLaunchKernelGGL(tracer_tendency_direct<OCN_FLAT>, nb, block, 0, stream, g, u, v, w, c, Gc, r, tf); break;
         default: ocn::set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;
     }
     OCN_CHECK_HIP(hipGetLastError());

@@ -273,6 +273,28 @@ class _HipDistPoisson:
         nyt, nel, r2c = C.c_int32(), C.c_int64(), C.c_int32()
         _lib.call("ocn_dist_poisson_layout", self._h, C.byref(nyt), C.byref(nel), C.byref(r2c))
         self.nyt, self.r2c = nyt.value, bool(r2c.value)  # y extent of the transposed data (padded half spectrum if r2c)
+        # every rank must use the same transposed extent: if any rank fell back to complex plans (rocFFT plan self test,
+        # csrc/poisson.hip), all ranks do
+        reduce = getattr(arch.fabric, "allreduce_max", None)
+        if reduce is not None and self.R > 1 and grid.topology[2] != Bounded:
+            flag = torch.tensor([0.0 if self.r2c else 1.0], dtype=torch.float64, device=arch.device)
+            if float(reduce(flag).item()) > 0 and self.r2c:
+                import os
+                _lib.lib().ocn_dist_poisson_destroy(self._h)
+                old_env = os.environ.get("OCN_POISSON_C2C")
+                os.environ["OCN_POISSON_C2C"] = "1"
+                try:
+                    self._h = C.c_void_p()
+                    _lib.call("ocn_dist_poisson_create", C.byref(self._h), grid.cref, arch.local_rank, self.R,
+                              C.c_double(getattr(grid, "global_Lx", grid.Lx * self.R)))
+                finally:
+                    if old_env is None:
+                        os.environ.pop("OCN_POISSON_C2C", None)
+                    else:
+                        os.environ["OCN_POISSON_C2C"] = old_env
+                _lib.call("ocn_dist_poisson_buffers", self._h, *[C.byref(p) for p in ptrs])
+                _lib.call("ocn_dist_poisson_layout", self._h, C.byref(nyt), C.byref(nel), C.byref(r2c))
+                self.nyt, self.r2c = nyt.value, bool(r2c.value)
         n = nel.value * 2
         # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
         self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)

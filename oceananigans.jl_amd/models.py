@@ -155,13 +155,18 @@ class NonhydrostaticModel:
                 s is not None and s.values is not None for b in bcs.values() for s in b.sides.values()):
             raise NotImplementedError("array boundary conditions on a Distributed architecture are not implemented")
         self._terms = self._make_terms()
-        # fused stage boundaries (tendencies + next substep in one launch) need the tiled kernel, no tracers, one rank
-        self.fuse_stage_boundaries = not self.tracers and not self.general_terms
+        # fused stage boundaries: tendencies (+ boundary fluxes) + the next substep in as few launches as possible.  Plain
+        # WENO momentum uses the tiled kernel's epilogue; tracers and the §8(f) terms use the general fused entry points
+        # (WENO advection only: the Centered(order=2) tracer kernel has no epilogue)
+        self._general_fused = self.general_terms or bool(self.tracers)
+        self.fuse_stage_boundaries = (not self._general_fused) or (isinstance(advection, WENO)
+                                                                   and os.environ.get("OCN_FUSE_GENERAL", "1") != "0")
         self._alt_velocities = None
+        self._alt_fields = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one
         self.defer_final_tendencies = self.fuse_stage_boundaries
         # fold the pressure correction of stages 1 and 2 into the loads of the fused launch (all-periodic grids)
-        self.correct_on_load = (self.fuse_stage_boundaries and all(t == "Periodic" for t in grid.topology)
+        self.correct_on_load = (self.fuse_stage_boundaries and not self._general_fused and all(t == "Periodic" for t in grid.topology)
                                 and grid.Nx >= 16 and grid.Ny >= 8 and grid.Nz >= 4
                                 and not hasattr(grid.architecture, "partition")
                                 and os.environ.get("OCN_CORRECT_ON_LOAD", "1") != "0")
@@ -194,6 +199,17 @@ class NonhydrostaticModel:
         if self.pHY is not None:
             t.pHY = self.pHY.ptr
         return t
+
+    def _refresh_term_pointers(self):
+        """the buoyancy tracers' storage may have been swapped by a fused stage boundary"""
+        t, b = self._terms, self.buoyancy
+        if isinstance(b, BuoyancyTracer):
+            t.T = self.field("b").ptr
+        elif isinstance(b, SeawaterBuoyancy):
+            if b.constant_temperature is None:
+                t.T = self.field("T").ptr
+            if b.constant_salinity is None:
+                t.S = self.field("S").ptr
 
     def prognostic_fields(self):
         return self.velocities + self.tracers
@@ -385,6 +401,8 @@ def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True, p_corr
     """update_state!(model) followed by the next stage's rk3_substep!, with compute_tendencies! and the substep fused into
     one launch (ocn_compute_momentum_tendencies_rk3).  The substep result lands in a second set of velocity arrays whose
     storage is then swapped into the model's fields."""
+    if model._general_fused:
+        return _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos)
     if model._alt_velocities is None:
         model._alt_velocities = tuple(torch.zeros_like(f.data) for f in model.velocities)
     alt = model._alt_velocities
@@ -410,6 +428,51 @@ def update_state_and_rk3_substep(model, dt, gamma, zeta, fill_halos=True, p_corr
     for f, a in zip(model.velocities, alt):
         f.data = a
     model._alt_velocities = old
+
+
+def _bcs_ref(field, grid):
+    b = getattr(field, "boundary_conditions", None)
+    return C.byref(b.c_struct(grid)) if b is not None and b.has_flux() else None
+
+
+def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=True):
+    """update_state! + the next rk3_substep! for models with tracers and / or the §8(f) terms: momentum = tiled WENO launch +
+    one finishing pass (extra terms, u / v boundary fluxes, substep), or the plain fused launch when there is nothing to add;
+    each tracer = ONE launch (WENO advection, diffusion, boundary flux, substep).  All substep results land in a second set
+    of arrays whose storage is then swapped into the fields.  Bit-identical to the unfused sequence in strict math."""
+    prog = model.prognostic_fields()
+    if model._alt_fields is None:
+        model._alt_fields = [torch.zeros_like(f.data) for f in prog]
+    alt = model._alt_fields
+    Gn, Gm = model.timestepper._Gn, model.timestepper._Gm
+    model._pending_tendencies = False
+    g, s = model.grid, stream_ptr()
+    if fill_halos:  # (Distributed: synchronous exchange; the auxiliaries need the exchanged halos)
+        fill_halo_regions(prog, fill_boundary_normal_velocities=False)
+        compute_auxiliaries(model)
+    z, hz = (0.0, 0) if zeta is None else (float(zeta), 1)
+    t = C.byref(model._terms)
+    momentum_extra = (model.coriolis is not None or model.closure is not None or model.buoyancy is not None
+                      or isinstance(model.advection, Centered) or _bcs_ref(model.u, g) is not None or _bcs_ref(model.v, g) is not None)
+    if momentum_extra:
+        _lib.call("ocn_compute_momentum_tendencies_terms_rk3", g.cref, t, _bcs_ref(model.u, g), _bcs_ref(model.v, g),
+                  model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr,
+                  alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(), float(dt), float(gamma), z, hz, None, s)
+    else:
+        _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                  Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
+                  float(dt), float(gamma), z, hz, None, 0.0, None, s)
+    for n, c in enumerate(model.tracers):
+        kappa, kappa_e = 0.0, None
+        if model.diffusivity_fields is not None:
+            kappa_e = model.diffusivity_fields["kappa_e"][n].ptr
+        elif model.closure is not None:
+            kappa = model.closure.kappa_of(model.tracer_names[n])
+        _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, kappa_e, _bcs_ref(c, g), model.u.ptr, model.v.ptr,
+                  model.w.ptr, c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[3 + n].data_ptr(), float(dt), float(gamma), z, hz, None, s)
+    for n, f in enumerate(prog):
+        f.data, alt[n] = alt[n], f.data
+    model._refresh_term_pointers()
 
 
 def _project_and_advance(model, dt, stage_dt, gamma_next, zeta_next):

@@ -432,3 +432,43 @@ def test_ocean_wind_mixing_and_convection_matches_oracle(oracle, ocn, adv, ts, m
     assert np.abs(from_dev(pm.diffusivity_fields["nu_e"]) - om.nu_e).max() <= 1e-6 * nus
     for a, d in zip(om.kappa_e, pm.diffusivity_fields["kappa_e"]):
         assert np.abs(from_dev(d) - a).max() <= 1e-6 * max(np.abs(a).max(), nus)
+
+
+@pytest.mark.parametrize("closure", ["none", "scalar", "amd"])
+def test_general_fused_stage_boundaries_equal_unfused(ocn, closure):
+    """The fused stage boundary of models with tracers / the §8(f) terms (ocn_compute_*_tendencies_terms_rk3: tendencies +
+    boundary fluxes + next substep, deferred final tendencies) gives bit-identical results to the unfused reference sequence."""
+    rng = np.random.default_rng(41)
+    N = (32, 16, 12)
+    z = stretched_faces(N[2], 32.0)
+    init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
+    init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
+
+    def build():
+        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 64), y=(0, 64), z=z, topology=("Periodic", "Periodic", "Bounded"))
+        if closure == "none":  # plain WENO model that merely carries tracers
+            return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"))
+        bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-3e-4)),
+               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+               "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-2.8e-7))}
+        cl = ocn.ScalarDiffusivity(ν=1e-3, κ={"T": 2e-3, "S": 5e-4}) if closure == "scalar" else ocn.AnisotropicMinimumDissipation()
+        return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4), closure=cl,
+                                       buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                       boundary_conditions=bcs)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    out = []
+    for fused in (True, False):
+        m = build()
+        assert m.fuse_stage_boundaries and m.defer_final_tendencies
+        if not fused:
+            m.fuse_stage_boundaries = m.defer_final_tendencies = False
+        ocn.set(m, **init)
+        for _ in range(3):
+            ocn.time_step(m, 1.5)
+        G = [f.parent() for f in m.timestepper.Gn]  # completes the deferred tendency launch
+        ocn.sync_device()
+        out.append([f.parent() for f in m.prognostic_fields()] + G + [m.pNHS.interior()])
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
