@@ -15,6 +15,9 @@
 // by reciprocal spacings and lets the compiler contract to FMA.  All kernels are one thread per cell, x fastest across
 // the 64 lanes (512-B coalesced rows); x and y are Periodic in the supported scope, so every field shares one set of
 // strides and active_weighted_ℑxy divides by exactly 1.
+#include <cstdlib>
+#include <cstring>
+
 #include "ocn_weno.h"
 
 namespace OCN_NS {
@@ -162,23 +165,15 @@ __device__ __forceinline__ double buoyancy_ccc(const TermsDev &t, long long a)
     }
 }
 
-template <int TZ>
-// `mf`: the flux boundary contributions of u, v (apply_flux_bcs.jl:107-160) and the NEXT stage's rk3 substep of u, v, w into a
-// second storage, folded into this last pass over G (same operations as apply_flux_bcs_kernel / stepper_kernel).
-__global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev t, const double *__restrict__ u,
-                                                             const double *__restrict__ v, const double *__restrict__ w,
-                                                             double *__restrict__ Gu, double *__restrict__ Gv,
-                                                             double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf)
+// One cell of the momentum finishing pass.  Uf/Vf/Wf/NEf(a, b, c) return u, v, w, νₑ at (i+a, j+b, k+c): global memory in the
+// direct kernel, LDS planes in the tiled one -- the arithmetic is the same text, so both are bit-identical to the oracle.
+template <int TZ, class FU, class FV, class FW, class FN>
+__device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const TermsDev &t, const Metrics &M, int i, int j, int k,
+                                                    long long o, long long s2, long long s3, bool has_nu, FU Uf, FV Vf, FW Wf,
+                                                    FN NEf, double *__restrict__ Gu, double *__restrict__ Gv,
+                                                    double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf)
 {
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
     constexpr bool ZF = (TZ == OCN_FLAT);
-    const Metrics M = make_metrics(g);
-    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
-    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
-    const double *pu = u + o, *pv = v + o, *pw = w + o;
     const double dx = M.dx, dy = M.dy, nu = t.nu;
     const double dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = ZF ? dzf : M.dzF(k + 1), dzcm = ZF ? dzc : M.dzC(k - 1);
 #if !OCN_STRICT
@@ -193,72 +188,70 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
     const double Axc = M.Ax(k), Ayc = M.Ay(k), Az = M.Az;
     // viscosity at the stress locations: the number ν, or the ccc array νₑ of an eddy-viscosity closure interpolated with
     // ℑxyᶠᶠᵃ / ℑxzᶠᵃᶠ / ℑyzᵃᶠᶠ (abstract_scalar_diffusivity_closure.jl:291-296)
-    const double *pn = t.nu_e ? t.nu_e + o : nullptr;
-#define NE(a, b, c) pn[(a) + (b)*s2 + (c)*s3]
-    auto nuC = [&](int a, int b, int c) { return pn ? NE(a, b, c) : nu; };
+    auto nuC = [&](int a, int b, int c) { return has_nu ? NEf(a, b, c) : nu; };
     auto nuFFC = [&](int a, int b, int c) {
-        return pn ? 0.5 * (0.5 * (NE(a - 1, b - 1, c) + NE(a, b - 1, c)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu;
+        return has_nu ? 0.5 * (0.5 * (NEf(a - 1, b - 1, c) + NEf(a, b - 1, c)) + 0.5 * (NEf(a - 1, b, c) + NEf(a, b, c))) : nu;
     };
     auto nuFCF = [&](int a, int b, int c) {
-        return pn ? 0.5 * (0.5 * (NE(a - 1, b, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu;
+        return has_nu ? 0.5 * (0.5 * (NEf(a - 1, b, c - 1) + NEf(a, b, c - 1)) + 0.5 * (NEf(a - 1, b, c) + NEf(a, b, c))) : nu;
     };
     auto nuCFF = [&](int a, int b, int c) {
-        return pn ? 0.5 * (0.5 * (NE(a, b - 1, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a, b - 1, c) + NE(a, b, c))) : nu;
+        return has_nu ? 0.5 * (0.5 * (NEf(a, b - 1, c - 1) + NEf(a, b, c - 1)) + 0.5 * (NEf(a, b - 1, c) + NEf(a, b, c))) : nu;
     };
 
     {   // ---------------- Gu at (f,c,c)
         double G = Gu[o];
         if (t.buoyancy) G = G + 0.0;  // x_dot_g_b = 0 (NegativeZDirection)
         if (t.coriolis) {             // - x_f_cross_U,  x_f_cross_U = -f * ℑxyᶠᶜᵃ(v) / 1
-            const double vi = 0.5 * (0.5 * (V_(-1, 0, 0) + V_(0, 0, 0)) + 0.5 * (V_(-1, 1, 0) + V_(0, 1, 0)));
+            const double vi = 0.5 * (0.5 * (Vf(-1, 0, 0) + Vf(0, 0, 0)) + 0.5 * (Vf(-1, 1, 0) + Vf(0, 1, 0)));
             G = G - (-t.f * vi);
         }
         if (t.pHY) G = G - DX(t.pHY[o], t.pHY[o - 1]);  // ∂xᶠᶜᶜ pHY′
         if (t.closure) {
-            const double t11e = TAU(nuC(0, 0, 0), DX(U_(1, 0, 0), U_(0, 0, 0))), t11w = TAU(nuC(-1, 0, 0), DX(U_(0, 0, 0), U_(-1, 0, 0)));
-            const double t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(U_(0, 1, 0), U_(0, 0, 0)) + DX(V_(0, 1, 0), V_(-1, 1, 0))));
-            const double t12s = TAU(nuFFC(0, 0, 0), 0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
+            const double t11e = TAU(nuC(0, 0, 0), DX(Uf(1, 0, 0), Uf(0, 0, 0))), t11w = TAU(nuC(-1, 0, 0), DX(Uf(0, 0, 0), Uf(-1, 0, 0)));
+            const double t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(Uf(0, 1, 0), Uf(0, 0, 0)) + DX(Vf(0, 1, 0), Vf(-1, 1, 0))));
+            const double t12s = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
             double dzF = 0.0;
             if (!ZF) {
-                const double t13t = TAU(nuFCF(0, 0, 1), 0.5 * (DZF1(U_(0, 0, 1), U_(0, 0, 0)) + DX(W_(0, 0, 1), W_(-1, 0, 1))));
-                const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
+                const double t13t = TAU(nuFCF(0, 0, 1), 0.5 * (DZF1(Uf(0, 0, 1), Uf(0, 0, 0)) + DX(Wf(0, 0, 1), Wf(-1, 0, 1))));
+                const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
                 dzF = Az * t13t - Az * t13b;
             }
             G = G - 1 / (Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
         }
         if (TZ == OCN_BOUNDED) {
-            if (k == 1 && mf.bottom[0].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[0], i, j, g.Nx, pu[0]) * Az / (Az * M.dzC(1));
-            if (k == g.Nz && mf.top[0].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[0], i, j, g.Nx, pu[0]) * Az / (Az * M.dzC(g.Nz));
+            if (k == 1 && mf.bottom[0].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(1));
+            if (k == g.Nz && mf.top[0].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
         Gu[o] = G;
-        if (mf.sc.on) mf.sub[0].out[o] = pu[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (mf.sc.on) mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     {   // ---------------- Gv at (c,f,c)
         double G = Gv[o];
         if (t.buoyancy) G = G + 0.0;
         if (t.coriolis) {  // - y_f_cross_U,  y_f_cross_U = f * ℑxyᶜᶠᵃ(u) / 1
-            const double ui = 0.5 * (0.5 * (U_(0, -1, 0) + U_(1, -1, 0)) + 0.5 * (U_(0, 0, 0) + U_(1, 0, 0)));
+            const double ui = 0.5 * (0.5 * (Uf(0, -1, 0) + Uf(1, -1, 0)) + 0.5 * (Uf(0, 0, 0) + Uf(1, 0, 0)));
             G = G - t.f * ui;
         }
         if (t.pHY) G = G - DY(t.pHY[o], t.pHY[o - s2]);
         if (t.closure) {
-            const double t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(U_(1, 0, 0), U_(1, -1, 0)) + DX(V_(1, 0, 0), V_(0, 0, 0))));
-            const double t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(U_(0, 0, 0), U_(0, -1, 0)) + DX(V_(0, 0, 0), V_(-1, 0, 0))));
-            const double t22n = TAU(nuC(0, 0, 0), DY(V_(0, 1, 0), V_(0, 0, 0))), t22s = TAU(nuC(0, -1, 0), DY(V_(0, 0, 0), V_(0, -1, 0)));
+            const double t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(Uf(1, 0, 0), Uf(1, -1, 0)) + DX(Vf(1, 0, 0), Vf(0, 0, 0))));
+            const double t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
+            const double t22n = TAU(nuC(0, 0, 0), DY(Vf(0, 1, 0), Vf(0, 0, 0))), t22s = TAU(nuC(0, -1, 0), DY(Vf(0, 0, 0), Vf(0, -1, 0)));
             double dzF = 0.0;
             if (!ZF) {
-                const double t23t = TAU(nuCFF(0, 0, 1), 0.5 * (DZF1(V_(0, 0, 1), V_(0, 0, 0)) + DY(W_(0, 0, 1), W_(0, -1, 1))));
-                const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+                const double t23t = TAU(nuCFF(0, 0, 1), 0.5 * (DZF1(Vf(0, 0, 1), Vf(0, 0, 0)) + DY(Wf(0, 0, 1), Wf(0, -1, 1))));
+                const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
                 dzF = Az * t23t - Az * t23b;
             }
             G = G - 1 / (Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
         }
         if (TZ == OCN_BOUNDED) {
-            if (k == 1 && mf.bottom[1].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[1], i, j, g.Nx, pv[0]) * Az / (Az * M.dzC(1));
-            if (k == g.Nz && mf.top[1].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[1], i, j, g.Nx, pv[0]) * Az / (Az * M.dzC(g.Nz));
+            if (k == 1 && mf.bottom[1].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(1));
+            if (k == g.Nz && mf.top[1].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
         Gv[o] = G;
-        if (mf.sc.on) mf.sub[1].out[o] = pv[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (mf.sc.on) mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
         double G = Gw[o];
@@ -270,25 +263,101 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
         if (t.coriolis) G = G - 0.0;  // z_f_cross_U = 0
         if (t.closure) {
             const double Axf = dy * dzf, Ayf = dx * dzf;
-            const double t13e = TAU(nuFCF(1, 0, 0), 0.5 * (DZF(U_(1, 0, 0), U_(1, 0, -1)) + DX(W_(1, 0, 0), W_(0, 0, 0))));
-            const double t13w = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(U_(0, 0, 0), U_(0, 0, -1)) + DX(W_(0, 0, 0), W_(-1, 0, 0))));
-            const double t23n = TAU(nuCFF(0, 1, 0), 0.5 * (DZF(V_(0, 1, 0), V_(0, 1, -1)) + DY(W_(0, 1, 0), W_(0, 0, 0))));
-            const double t23s = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(V_(0, 0, 0), V_(0, 0, -1)) + DY(W_(0, 0, 0), W_(0, -1, 0))));
+            const double t13e = TAU(nuFCF(1, 0, 0), 0.5 * (DZF(Uf(1, 0, 0), Uf(1, 0, -1)) + DX(Wf(1, 0, 0), Wf(0, 0, 0))));
+            const double t13w = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
+            const double t23n = TAU(nuCFF(0, 1, 0), 0.5 * (DZF(Vf(0, 1, 0), Vf(0, 1, -1)) + DY(Wf(0, 1, 0), Wf(0, 0, 0))));
+            const double t23s = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
             double dzF = 0.0;
             if (!ZF) {
-                const double t33t = TAU(nuC(0, 0, 0), OCN_DIV(W_(0, 0, 1) - W_(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
-                const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(W_(0, 0, 0) - W_(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
+                const double t33t = TAU(nuC(0, 0, 0), OCN_DIV(Wf(0, 0, 1) - Wf(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
+                const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(Wf(0, 0, 0) - Wf(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
                 dzF = Az * t33t - Az * t33b;
             }
             G = G - 1 / (Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
         }
         Gw[o] = G;
         const bool wall = (TZ == OCN_BOUNDED) && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face
-        if (mf.sc.on) mf.sub[2].out[o] = wall ? pw[0] : pw[0] + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[2].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (mf.sc.on) mf.sub[2].out[o] = wall ? Wf(0, 0, 0) : Wf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[2].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     } else if (mf.sc.on) {
-        mf.sub[2].out[o] = pw[0];  // wall face (exclude_periphery): carried over unchanged
+        mf.sub[2].out[o] = Wf(0, 0, 0);  // wall face (exclude_periphery): carried over unchanged
     }
-    if (mf.sc.on && TZ == OCN_BOUNDED && k == g.Nz) mf.sub[2].out[o + s3] = pw[s3];  // top wall face k = Nz+1
+    if (mf.sc.on && TZ == OCN_BOUNDED && k == g.Nz) mf.sub[2].out[o + s3] = Wf(0, 0, 1);  // top wall face k = Nz+1
+}
+
+// `mf`: the flux boundary contributions of u, v (apply_flux_bcs.jl:107-160) and the NEXT stage's rk3 substep of u, v, w into a
+// second storage, folded into this last pass over G (same operations as apply_flux_bcs_kernel / stepper_kernel).
+template <int TZ>
+__global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev t, const double *__restrict__ u,
+                                                             const double *__restrict__ v, const double *__restrict__ w,
+                                                             double *__restrict__ Gu, double *__restrict__ Gv,
+                                                             double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
+    const double *pu = u + o, *pv = v + o, *pw = w + o, *pn = t.nu_e ? t.nu_e + o : nullptr;
+    momentum_extra_cell<TZ>(
+        g, t, M, i, j, k, o, s2, s3, pn != nullptr, [&](int a, int b, int c) { return pu[a + b * s2 + c * s3]; },
+        [&](int a, int b, int c) { return pv[a + b * s2 + c * s3]; }, [&](int a, int b, int c) { return pw[a + b * s2 + c * s3]; },
+        [&](int a, int b, int c) { return pn[a + b * s2 + c * s3]; }, Gu, Gv, Gw, r, mf);
+}
+
+// Tiled variant of the finishing pass: a workgroup owns a 32 x 8 patch of columns and marches KZ planes upward; planes
+// k-1, k, k+1 of u, v, w (and νₑ) live in a 3-slot LDS ring with a one-cell rim, so every value enters the workgroup once per
+// plane (1.33x with the rim) instead of once per stencil tap (~60 taps per cell hit L2 in the direct kernel: the 3 planes x
+// 4 fields of a workgroup do not fit the 32 KB L1).  pHY′, G, G⁻ are touched once per cell and stay in global memory.
+template <int TZ>
+__global__ __launch_bounds__(256) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
+                                                            const double *__restrict__ v, const double *__restrict__ w,
+                                                            double *__restrict__ Gu, double *__restrict__ Gv,
+                                                            double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf, int KZ)
+{
+    constexpr int TX = 32, TY = 8, SX = TX + 2, SY = TY + 2, PL = SX * SY;
+    __shared__ double Lu[3][PL], Lv[3][PL], Lw[3][PL], Ln[3][PL];
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int i0 = r.i0 + blockIdx.x * TX, j0 = r.j0 + blockIdx.y * TY;
+    const int kb = r.k0 + blockIdx.z * KZ, ke = min(kb + KZ - 1, r.k1);
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i <= r.i1) && (j <= r.j1);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = L.s3;
+    const bool has_nu = t.nu_e != nullptr;
+    // stage plane kk (tile + rim, indices clamped to the first halo cell) into ring slot kk % 3
+    auto stage = [&](int kk) {
+        const int slot = kk % 3;
+        for (int idx = tid; idx < PL; idx += TX * TY) {
+            const int li = idx % SX, lj = idx / SX;
+            const int gi = min(i0 - 1 + li, g.Nx + 1), gj = min(j0 - 1 + lj, g.Ny + 1);
+            const long long oo = ocn::at(L, gi, gj, kk);
+            Lu[slot][idx] = u[oo];
+            Lv[slot][idx] = v[oo];
+            Lw[slot][idx] = w[oo];
+            if (has_nu) Ln[slot][idx] = t.nu_e[oo];
+        }
+    };
+    stage(kb - 1);
+    stage(kb);
+    const int c0 = (ty + 1) * SX + (tx + 1);
+    for (int k = kb; k <= ke; ++k) {
+        stage(k + 1);
+        __syncthreads();
+        if (active) {
+            const long long o = ocn::at(L, i, j, k);
+            const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
+            momentum_extra_cell<TZ>(
+                g, t, M, i, j, k, o, s2, s3, has_nu, [&](int a, int b, int c) { return Lu[(base + c) % 3][c0 + a + b * SX]; },
+                [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; },
+                [&](int a, int b, int c) { return Lw[(base + c) % 3][c0 + a + b * SX]; },
+                [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf);
+        }
+        __syncthreads();  // everyone is done with slot (k - 1) % 3 before the next iteration overwrites it
+    }
 }
 
 // Gc <- Gc - ∇_dot_qᶜ,  q = -(κ ∂c)  (closure_kernel_operators.jl:48-53)
@@ -390,6 +459,20 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;
+    static const int force_direct = (getenv("OCN_EXTRA_KERNEL") && !strcmp(getenv("OCN_EXTRA_KERNEL"), "direct"));
+    if (!force_direct && grid->tz != OCN_FLAT && wx >= 16 && wy >= 8 && wz >= 4 && grid->Hz >= 1) {
+        const int tiles = ((wx + 31) / 32) * ((wy + 7) / 8);
+        int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the two-plane prologue
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 4096) KZ = (KZ + 1) / 2;
+        dim3 nbt((wx + 31) / 32, (wy + 7) / 8, (wz + KZ - 1) / KZ);
+        if (grid->tz == OCN_PERIODIC)
+            hipLaunchKernelGGL(momentum_extra_tiled<OCN_PERIODIC>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        else
+            hipLaunchKernelGGL(momentum_extra_tiled<OCN_BOUNDED>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        OCN_CHECK_HIP(hipGetLastError());
+        return OCN_SUCCESS;
+    }
     dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r, mf);
     return OCN_SUCCESS;
