@@ -476,10 +476,47 @@ __device__ __forceinline__ double tracer_flux(double area, double ut, const doub
     return (area * ut) * cr;
 }
 
-// `tf` folds the rest of tracer_tendency and of the stage boundary into the same pass: -∇_dot_qᶜ (closure_kernel_operators.jl:48-53,
-// κ a number or the field κₑ), the bottom / top flux boundary contributions (apply_flux_bcs.jl:107-160) and the NEXT stage's
-// rk3 substep into a second storage.  Same operations in the same order as the separate kernels (physics.hip
-// tracer_diffusion_kernel, kernels.hip apply_flux_bcs_kernel, stepper_kernel): bit-identical in the strict build.
+// The rest of tracer_tendency and of the stage boundary, folded into the tracer kernels: -∇_dot_qᶜ
+// (closure_kernel_operators.jl:48-53, κ a number or the field κₑ interpolated to the faces) and the bottom / top flux boundary
+// contributions (apply_flux_bcs.jl:107-160).  Same operations in the same order as the separate kernels (physics.hip
+// tracer_diffusion_kernel, kernels.hip apply_flux_bcs_kernel): bit-identical in the strict build.
+// c0 = c[i,j,k]; cxm/cxp, cym/cyp, czm/czp its six neighbours.
+template <int TZ>
+__device__ __forceinline__ double tracer_finish(double G, const Metrics &M, const GridDev &g, const ocn::TracerFuse &tf, int i, int j,
+                                                int k, long long o, long long s2, long long s3, double c0, double cxm, double cxp,
+                                                double cym, double cyp, double czm, double czp, double ax, double ay, double az)
+{
+    if (tf.diffusion) {
+        const double dx = M.dx, dy = M.dy, dzc = M.dzC(k);
+        const double *pk = tf.kappa_e ? tf.kappa_e + o : nullptr;
+        const double k0 = pk ? pk[0] : tf.kappa;
+        const double kxe = pk ? 0.5 * (k0 + pk[1]) : tf.kappa, kxw = pk ? 0.5 * (pk[-1] + k0) : tf.kappa;
+        const double kyn = pk ? 0.5 * (k0 + pk[s2]) : tf.kappa, kys = pk ? 0.5 * (pk[-s2] + k0) : tf.kappa;
+#if OCN_STRICT
+#define OCN_TD(a, d) ((a) / (d))
+#else
+#define OCN_TD(a, d) ((a) * (1 / (d)))
+#endif
+        const double qxe = -(kxe * OCN_TD(cxp - c0, dx)), qxw = -(kxw * OCN_TD(c0 - cxm, dx));
+        const double qyn = -(kyn * OCN_TD(cyp - c0, dy)), qys = -(kys * OCN_TD(c0 - cym, dy));
+        double dzq = 0.0;
+        if (TZ != OCN_FLAT) {
+            const double kzt = pk ? 0.5 * (k0 + pk[s3]) : tf.kappa, kzb = pk ? 0.5 * (pk[-s3] + k0) : tf.kappa;
+            const double qzt = -(kzt * OCN_TD(czp - c0, M.dzF(k + 1))), qzb = -(kzb * OCN_TD(c0 - czm, M.dzF(k)));
+            dzq = az * qzt - az * qzb;
+        }
+#undef OCN_TD
+        G = G - 1 / (az * dzc) * (((ax * qxe - ax * qxw) + (ay * qyn - ay * qys)) + dzq);
+    }
+    if (TZ == OCN_BOUNDED) {  // apply_z_bcs!: k is uniform across the workgroup
+        if (k == 1 && tf.bottom.kind == OCN_BC_FLUX) G += ocn::bc_condition(tf.bottom, i, j, g.Nx, c0) * az / (az * M.dzC(1));
+        if (k == g.Nz && tf.top.kind == OCN_BC_FLUX) G -= ocn::bc_condition(tf.top, i, j, g.Nx, c0) * az / (az * M.dzC(g.Nz));
+    }
+    return G;
+}
+
+// Direct kernel: one thread per cell, all six face fluxes evaluated in place.  `tf` (see tracer_finish) additionally carries
+// the NEXT stage's rk3 substep into a second storage.
 template <int TZ>
 __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const double *__restrict__ u,
                                                               const double *__restrict__ v, const double *__restrict__ w,
@@ -508,35 +545,9 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
     }
     const double rV = 1 / (M.Az * M.dzC(k));
     double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
-    const long long o = ocn::at(Lc, i, j, k);
-    if (tf.diffusion) {
-        const long long s2 = Lc.s2, s3 = Lc.s3;
-        const double dx = M.dx, dy = M.dy, dzc = M.dzC(k);
-        const double c0 = pc[0];
-        const double *pk = tf.kappa_e ? tf.kappa_e + o : nullptr;
-        const double k0 = pk ? pk[0] : tf.kappa;
-        const double kxe = pk ? 0.5 * (k0 + pk[1]) : tf.kappa, kxw = pk ? 0.5 * (pk[-1] + k0) : tf.kappa;
-        const double kyn = pk ? 0.5 * (k0 + pk[s2]) : tf.kappa, kys = pk ? 0.5 * (pk[-s2] + k0) : tf.kappa;
-#if OCN_STRICT
-#define OCN_TD(a, d) ((a) / (d))
-#else
-#define OCN_TD(a, d) ((a) * (1 / (d)))
-#endif
-        const double qxe = -(kxe * OCN_TD(pc[1] - c0, dx)), qxw = -(kxw * OCN_TD(c0 - pc[-1], dx));
-        const double qyn = -(kyn * OCN_TD(pc[s2] - c0, dy)), qys = -(kys * OCN_TD(c0 - pc[-s2], dy));
-        double dzq = 0.0;
-        if (TZ != OCN_FLAT) {
-            const double kzt = pk ? 0.5 * (k0 + pk[s3]) : tf.kappa, kzb = pk ? 0.5 * (pk[-s3] + k0) : tf.kappa;
-            const double qzt = -(kzt * OCN_TD(pc[s3] - c0, M.dzF(k + 1))), qzb = -(kzb * OCN_TD(c0 - pc[-s3], M.dzF(k)));
-            dzq = az * qzt - az * qzb;
-        }
-#undef OCN_TD
-        G = G - 1 / (az * dzc) * (((ax * qxe - ax * qxw) + (ay * qyn - ay * qys)) + dzq);
-    }
-    if (TZ == OCN_BOUNDED) {  // apply_z_bcs!: k is uniform across the workgroup
-        if (k == 1 && tf.bottom.kind == OCN_BC_FLUX) G += ocn::bc_condition(tf.bottom, i, j, g.Nx, pc[0]) * az / (az * M.dzC(1));
-        if (k == g.Nz && tf.top.kind == OCN_BC_FLUX) G -= ocn::bc_condition(tf.top, i, j, g.Nx, pc[0]) * az / (az * M.dzC(g.Nz));
-    }
+    const long long o = ocn::at(Lc, i, j, k), s2 = Lc.s2, s3 = (TZ == OCN_FLAT) ? 0 : Lc.s3;
+    if (tf.diffusion || tf.bottom.kind || tf.top.kind)
+        G = tracer_finish<TZ>(G, M, g, tf, i, j, k, o, s2, s3, pc[0], pc[-1], pc[1], pc[-s2], pc[s2], pc[-s3], pc[s3], ax, ay, az);
     Gc[o] = G;
     if (tf.sc.on) tf.sub.out[o] = pc[0] + (tf.sc.has_zeta ? tf.sc.dt * (tf.sc.gamma * G + tf.sc.zeta * tf.sub.Gm[o]) : (tf.sc.dt * tf.sc.gamma) * G);
 }

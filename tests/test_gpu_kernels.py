@@ -190,3 +190,62 @@ def test_pressure_correct_and_divergence_bitwise(oracle, ocn, size, topo, z):
     np.testing.assert_array_equal(ddiv.cpu().numpy().T, div)
     for a, d in zip((u, v, w), (du, dv, dw)):
         np.testing.assert_array_equal(from_dev(d), a)
+
+
+MARCH_CASES = [((64, 16, 16), "PPP", (0, 2.0), None),
+               ((130, 21, 12), "PPP", (0, 1.0), None),
+               ((63, 8, 5), "PPB", "stretched", None),
+               ((96, 33, 20), "PPB", "stretched", None),
+               ((100, 24, 9), "PPB", (-1.0, 0.0), (4, 97, 3, 22, 2, 8)),
+               ((64, 16, 40), "PPP", (0, 2.0), (1, 32, 1, 16, 1, 40))]
+
+
+@pytest.mark.parametrize("size,topo,z,rng_", MARCH_CASES)
+def test_tracer_kernel_ragged_sizes_and_fused_entry(oracle, ocn, size, topo, z, rng_):
+    """Larger / ragged sizes of the tracer kernel, with and without a KernelParameters range: bit-identical to the oracle
+    where written, untouched elsewhere; then with diffusion (κₑ field), boundary fluxes and the substep folded in
+    (ocn_compute_tracer_tendency_terms_rk3).  (A flux-sharing marching variant -- wave shuffle in x, register blocking in y,
+    flux carried in z -- passed these tests too but ran at 2-3 waves/SIMD and was not faster; it was dropped.)"""
+    import ctypes as C
+    O = oracle
+    rng = np.random.default_rng(123)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng, 0.0, 1.0)
+    Gm = random_parent(og, 0, rng)
+    Gc = og.zeros(0)
+    O.tracer_tendency(og, u, v, w, c, Gc)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    dc, dGc = to_dev(ocn, pg, 0, c), ocn.Field(0, pg)
+    dGc.data.fill_(-7.0)
+    r = None if rng_ is None else ocn._lib.i32_array(list(rng_))
+    ocn._lib.call("ocn_compute_tracer_tendency", pg.cref, du.ptr, dv.ptr, dw.ptr, dc.ptr, dGc.ptr, r, 0)
+    ocn.sync_device()
+    got = from_dev(dGc)
+    mask = np.zeros(got.shape, dtype=bool)
+    i0, i1, j0, j1, k0, k1 = rng_ if rng_ is not None else (1, size[0], 1, size[1], 1, size[2])
+    mask[og.Hx + i0 - 1:og.Hx + i1, og.Hy + j0 - 1:og.Hy + j1, og.Hz + k0 - 1:og.Hz + k1] = True
+    np.testing.assert_array_equal(got[mask], Gc[mask])
+    assert np.all(got[~mask] == -7.0)
+    if rng_ is not None:
+        return
+    # everything folded in: diffusion (κ field), top / bottom flux, substep
+    kap = random_parent(og, 0, rng, 0.0, 1e-2)
+    O.tracer_diffusion(og, 0.0, c, Gc, kappa_e=kap)
+    bcs, obcs = None, {}
+    if topo == "PPB":
+        obcs = {"top": O.BC("flux", 2e-3, -1e-3), "bottom": O.FluxBoundaryCondition(-4e-3)}
+        O.apply_flux_bcs(og, 0, c, Gc, obcs)
+        fb = ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(2e-3, coeff=-1e-3), bottom=ocn.FluxBoundaryCondition(-4e-3))
+        bcs = C.byref(fb.c_struct(pg))
+    cnew = c.copy(order="F")
+    O.rk3_substep(og, 0, cnew, Gc, Gm, 0.3, 5 / 12, -17 / 60)
+    t = ocn._lib.CModelTerms()
+    dk, dGm, dout = to_dev(ocn, pg, 0, kap), to_dev(ocn, pg, 0, Gm), ocn.Field(0, pg)
+    t.closure, t.nu_e = 2, dk.ptr
+    ocn._lib.call("ocn_compute_tracer_tendency_terms_rk3", pg.cref, C.byref(t), 0.0, dk.ptr, bcs, du.ptr, dv.ptr, dw.ptr, dc.ptr,
+                  dGc.ptr, dGm.ptr, dout.ptr, 0.3, 5 / 12, -17 / 60, 1, None, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dGc)[mask], Gc[mask])
+    np.testing.assert_array_equal(from_dev(dout)[mask], cnew[mask])
