@@ -112,6 +112,12 @@ class NonhydrostaticModel:
         self.coriolis, self.closure, self.buoyancy = coriolis, closure, buoyancy
         self.clock = Clock()
         bcs = dict(boundary_conditions or {})
+        # boundary conditions of the diffusivity fields: {"νₑ": FieldBoundaryConditions, "κₑ": {tracer: FieldBoundaryConditions}}
+        # (build_diffusivity_fields, anisotropic_minimum_dissipation.jl:333-341); ASCII aliases nu_e / kappa_e
+        nu_bcs = bcs.pop("νₑ", bcs.pop("nu_e", None))
+        kappa_bcs = dict(bcs.pop("κₑ", bcs.pop("kappa_e", None)) or {})
+        if (nu_bcs is not None or kappa_bcs) and not isinstance(closure, AnisotropicMinimumDissipation):
+            raise ValueError("νₑ / κₑ boundary conditions need closure = AnisotropicMinimumDissipation()")
         for name in bcs:
             if name not in ("u", "v", "w") + tracers:
                 raise ValueError(f"boundary conditions given for unknown field {name!r}")
@@ -135,7 +141,8 @@ class NonhydrostaticModel:
         if isinstance(closure, AnisotropicMinimumDissipation):
             if grid.topology[2] == Flat:
                 raise NotImplementedError("AnisotropicMinimumDissipation needs a non-Flat z")
-            self.diffusivity_fields = {"nu_e": CenterField(grid), "kappa_e": tuple(CenterField(grid) for _ in tracers)}
+            self.diffusivity_fields = {"nu_e": CenterField(grid, nu_bcs),
+                                       "kappa_e": tuple(CenterField(grid, kappa_bcs.get(n)) for n in tracers)}
         self.pressure_solver = nonhydrostatic_pressure_solver(grid)
         prog = self.prognostic_fields()
         if timestepper in ("RungeKutta3", ":RungeKutta3"):
@@ -147,7 +154,7 @@ class NonhydrostaticModel:
         self._tuple_cache = {}
         self.copy_cached_tendencies = False
         # anything beyond plain WENO advection goes through the general (unfused) tendency entry points
-        self._has_user_bcs = any(not b.is_default() for b in bcs.values())
+        self._has_user_bcs = any(not b.is_default() for b in list(bcs.values()) + list(kappa_bcs.values()) + ([nu_bcs] if nu_bcs else []))
         self._has_flux_bcs = any(b.has_flux() for b in bcs.values())
         self.general_terms = (isinstance(advection, Centered) or coriolis is not None or closure is not None
                               or buoyancy is not None or self._has_user_bcs)

@@ -553,8 +553,11 @@ class NonhydrostaticModel:
             T, S = self._buoyancy_tracers()
             update_hydrostatic_pressure(g, self.physics, T, S, self.pHY)
         if self.amd is not None:  # fill_halo_regions!(model.diffusivity_fields; only_local_halos=true) (:48)
-            for a in [self.nu_e] + self.kappa_e:
-                fill_halo_regions(g, a, LOC_C)
+            # user boundary conditions on the diffusivity fields: boundary_conditions = {"νₑ": {...}, "κₑ": {tracer: {...}}}
+            # (build_diffusivity_fields, anisotropic_minimum_dissipation.jl:333-341)
+            fill_halo_regions(g, self.nu_e, LOC_C, bcs=self.bcs.get("νₑ"))
+            for n, a in enumerate(self.kappa_e):
+                fill_halo_regions(g, a, LOC_C, bcs=self.bcs.get("κₑ", {}).get(self.tracer_names[n]))
         if compute_tendencies:
             self.compute_tendencies()
 

@@ -472,3 +472,81 @@ def test_general_fused_stage_boundaries_equal_unfused(ocn, closure):
         out.append([f.parent() for f in m.prognostic_fields()] + G + [m.pNHS.interior()])
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+def test_constant_isotropic_diffusivity_fluxdiv_on_gpu(oracle, ocn):
+    """test_turbulence_closures.jl:36-66 through the C ABI: the reference's exact equalities at (2, 1, 3)."""
+    from test_oracle_physics import constant_isotropic_diffusivity_fields
+    O = oracle
+    nu, kappa = 0.3, 0.7
+    og, pg = make_pair(O, ocn, (3, 1, 4), "PPB", x=(0, 3), y=(0, 1), z=(-4, 0), halo=(3, 1, 3))
+    f = constant_isotropic_diffusivity_fields(O, og)
+    for mode in (ocn.MATH_STRICT, ocn.MATH_FAST):
+        ocn.set_math_mode(mode)
+        try:
+            d = {n: to_dev(ocn, pg, l, f[n]) for n, l in (("u", 1), ("v", 2), ("w", 4), ("T", 0))}
+            G = [ocn.Field(l, pg) for l in (1, 2, 4, 0)]
+            t = _terms(ocn, advection=1, nu=nu)
+            zero = [ocn.Field(l, pg) for l in (1, 2, 4)]  # velocities at rest for the advective part of the tracer call
+            ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), d["u"].ptr, d["v"].ptr, d["w"].ptr, G[0].ptr,
+                          G[1].ptr, G[2].ptr, None, 0)
+            ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), kappa, None, zero[0].ptr, zero[1].ptr, zero[2].ptr,
+                          d["T"].ptr, G[3].ptr, None, 0)
+            ocn.sync_device()
+        finally:
+            ocn.set_math_mode(ocn.MATH_STRICT)
+        # the momentum call includes Centered(order=2) advection of this non-solenoidal test field: subtract it
+        adv = [ocn.Field(l, pg) for l in (1, 2, 4)]
+        t0 = _terms(ocn, advection=1)
+        ocn.set_math_mode(mode)
+        try:
+            ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t0), d["u"].ptr, d["v"].ptr, d["w"].ptr, adv[0].ptr,
+                          adv[1].ptr, adv[2].ptr, None, 0)
+            ocn.sync_device()
+        finally:
+            ocn.set_math_mode(ocn.MATH_STRICT)
+        at = lambda fld: fld.interior()[1, 0, 2]
+        visc = [at(G[n]) - at(adv[n]) for n in range(3)]
+        if mode == ocn.MATH_STRICT:
+            assert -at(G[3]) == -2 * kappa
+        assert np.isclose(-at(G[3]), -2 * kappa, rtol=1e-14)
+        for n, fac in enumerate((2, 4, 6)):
+            assert np.isclose(-visc[n], -fac * nu, rtol=1e-13)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_fluxes_with_diffusivity_boundary_conditions_are_correct_on_gpu(ocn, mode):
+    """test_boundary_conditions_integration.jl:56-113 on the GPU (AMD closure, Value condition on κₑ, Gradient condition on b,
+    QAB2 with an Euler first step): the reference's criterion, the exact discrete budget, and the Float64 number the reference
+    quotes for its own run."""
+    from test_oracle_physics import REFERENCE_FLUX_TEST_FLOAT64_DIFFERENCE, diffusivity_bc_flux_case
+    Lz, k0, bz, b0, dt = diffusivity_bc_flux_case()
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        g = ocn.RectilinearGrid(ocn.GPU(), size=(16, 16, 16), x=(0, 1), y=(0, 1), z=(-Lz, 0), topology=("Periodic", "Periodic", "Bounded"))
+        bcs = {"b": ocn.FieldBoundaryConditions(bottom=ocn.GradientBoundaryCondition(bz)),
+               "κₑ": {"b": ocn.FieldBoundaryConditions(bottom=ocn.ValueBoundaryCondition(k0))}}
+        m = ocn.NonhydrostaticModel(g, timestepper="QuasiAdamsBashforth2", tracers="b", buoyancy=ocn.BuoyancyTracer(),
+                                    closure=ocn.AnisotropicMinimumDissipation(), boundary_conditions=bcs)
+        ocn.set(m, b=b0)
+        mean0 = np.mean(m.tracers[0].interior())
+        for n in range(10):
+            ocn.time_step(m, dt, euler=(n == 0))
+        d = np.mean(m.tracers[0].interior()) - mean0
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    flux = -k0 * bz
+    assert abs(d - flux * m.clock.time / Lz) < 1e-6
+    assert abs(d - flux * m.clock.time / Lz) < 1e-15
+    assert abs(d - REFERENCE_FLUX_TEST_FLOAT64_DIFFERENCE) < 1e-13
+
+
+@pytest.mark.parametrize("name,side", [("c", "top"), ("c", "bottom"), ("u", "top"), ("v", "bottom")])
+def test_nonhydrostatic_flux_budget_on_gpu(ocn, name, side):
+    """test_boundary_conditions_integration.jl:30-54: <ϕ> = flux t / L after one step from rest."""
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(8, 8, 8), x=(0, 1), y=(0, 2), z=(0, 0.5), topology=("Periodic", "Periodic", "Bounded"))
+    direction = 1 if side == "bottom" else -1
+    bcs = {name: ocn.FieldBoundaryConditions(**{side: ocn.FluxBoundaryCondition(np.pi * direction)})}
+    m = ocn.NonhydrostaticModel(g, tracers="c", timestepper="QuasiAdamsBashforth2", boundary_conditions=bcs)
+    ocn.time_step(m, 1.0)
+    assert np.isclose(np.mean(m.field(name).interior()[:, :, :8]), np.pi * m.clock.time / g.Lz, rtol=1e-12)

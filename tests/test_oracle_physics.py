@@ -333,3 +333,91 @@ def test_time_stepping_works_with_amd(oracle, ts):
 
 
 SEAWATER_DEFAULT = ("SeawaterBuoyancy", 9.80665, 1.67e-4, 7.80e-4)
+
+
+REFERENCE_FLUX_TEST_FLOAT64_DIFFERENCE = -3.141592656086267e-5  # test_boundary_conditions_integration.jl:106 (comment, Float64 run)
+
+
+def diffusivity_bc_flux_case():
+    """test_boundary_conditions_integration.jl:56-113: parameters and initial condition."""
+    Lz, k0, bz = 1.0, np.exp(-3), np.pi
+    zc = -Lz + (np.arange(16) + 0.5) * (Lz / 16)
+    b0 = (zc * bz)[None, None, :] * np.ones((16, 16, 1))
+    dt = 1e-6 * Lz ** 2 / k0
+    return Lz, k0, bz, b0, dt
+
+
+def test_fluxes_with_diffusivity_boundary_conditions_are_correct(oracle):
+    """test_boundary_conditions_integration.jl:56-113: AMD closure at rest (κₑ = 0 in the interior), a Value boundary condition
+    κ₀ on κₑ at the bottom and a Gradient condition on b make the bottom flux -κ₀ bz; after 10 QAB2 steps (first one Euler)
+    the mean of b moved by flux·t/Lz.  The reference accepts atol = 1e-6 and quotes its own Float64 result in a comment, which
+    carries ≈2e-14 of reduction noise (its mean(b₀) is off -π/2 by that much): matched to 1e-13."""
+    O = oracle
+    Lz, k0, bz, b0, dt = diffusivity_bc_flux_case()
+    g = O.Grid((16, 16, 16), x=(0, 1), y=(0, 1), z=(-Lz, 0), topology="PPB")
+    bcs = {"b": {"bottom": O.GradientBoundaryCondition(bz)}, "κₑ": {"b": {"bottom": O.ValueBoundaryCondition(k0)}}}
+    m = O.NonhydrostaticModel(g, advection="Centered2", timestepper=AB2, tracers=("b",), buoyancy="BuoyancyTracer",
+                              closure=("AMD",), boundary_conditions=bcs)
+    m.set(b=b0)
+    mean0 = np.mean(g.interior_N(m.tracers[0]))
+    for n in range(10):
+        m.time_step(dt, euler=(n == 0))
+    d = np.mean(g.interior_N(m.tracers[0])) - mean0
+    flux = -k0 * bz
+    assert abs(d - flux * m.time / Lz) < 1e-6            # the reference's criterion
+    assert abs(d - flux * m.time / Lz) < 1e-15           # what the discrete budget actually delivers
+    assert abs(d - REFERENCE_FLUX_TEST_FLOAT64_DIFFERENCE) < 1e-13
+    assert np.all(g.interior_N(m.kappa_e[0]) == 0) and np.all(g.interior_N(m.nu_e) == 0)
+
+
+@pytest.mark.parametrize("name,side", [("c", "top"), ("c", "bottom"), ("u", "top"), ("u", "bottom"), ("v", "top"), ("v", "bottom")])
+def test_nonhydrostatic_flux_budget(oracle, name, side):
+    """test_boundary_conditions_integration.jl:30-54: flux π through one z boundary, one step of Δt = 1 from rest:
+    <ϕ> = flux t / L (u, v to round-off because of the pressure solve)."""
+    O = oracle
+    g = O.Grid((8, 8, 8), x=(0, 1), y=(0, 2), z=(0, 0.5), topology="PPB")
+    direction = 1 if side == "bottom" else -1
+    bcs = {name: {side: O.FluxBoundaryCondition(np.pi * direction)}}
+    m = O.NonhydrostaticModel(g, advection="Centered2", tracers=("c",), timestepper=AB2, boundary_conditions=bcs)
+    m.time_step(1.0)
+    f = _field(m, name)
+    assert np.isclose(np.mean(g.interior_N(f)), np.pi * m.time / g.Lz, rtol=1e-12)
+
+
+def constant_isotropic_diffusivity_fields(O, g):
+    """test_turbulence_closures.jl:36-56: u, v, w, T = (0, -1/2, 0), (0, -2, 0), (0, -3, 0), (0, -1, 0) along x, halos filled."""
+    vals = {"u": -0.5, "v": -2.0, "w": -3.0, "T": -1.0}
+    out = {}
+    for name, loc in (("u", 1), ("v", 2), ("w", 4), ("T", 0)):
+        a = g.zeros(loc)
+        g.interior(a)[1, 0, :4] = vals[name]
+        O.fill_halo_regions(g, a, loc)
+        out[name] = a
+    return out
+
+
+def test_constant_isotropic_diffusivity_fluxdiv(oracle):
+    """test_turbulence_closures.jl:36-66 (exact equalities of the reference):  at (2, 1, 3) on a 3x1x4 unit-spaced grid
+    ∇_dot_qᶜ == -2κ, ∂ⱼ_τ₁ⱼ == -2ν, ∂ⱼ_τ₂ⱼ == -4ν, ∂ⱼ_τ₃ⱼ == -6ν."""
+    O = oracle
+    nu, kappa = 0.3, 0.7
+    g = O.Grid((3, 1, 4), x=(0, 3), y=(0, 1), z=(-4, 0), topology="PPB")
+    f = constant_isotropic_diffusivity_fields(O, g)
+    Gc = g.zeros(0)
+    O.tracer_diffusion(g, kappa, f["T"], Gc)            # Gc = 0 - ∇_dot_qᶜ
+    G = [g.zeros(l) for l in (1, 2, 4)]
+    O.momentum_extra_tendencies(g, O.Physics(nu=nu), f["u"], f["v"], f["w"], None, None, None, *G)   # G = 0 - ∂ⱼτᵢⱼ
+    at = lambda a: g.interior(a)[1, 0, 2]
+    assert -at(Gc) == -2 * kappa
+    assert -at(G[0]) == -2 * nu and -at(G[1]) == -4 * nu and -at(G[2]) == -6 * nu
+
+
+def test_fplane_constructor():
+    """test_coriolis.jl:19-27: FPlane(f=π).f ≈ π; FPlane(rotation_rate=2, latitude=30).f ≈ 2 (host-side constructor)."""
+    import oceananigans_jl_amd as ocn
+    assert ocn.FPlane(f=np.pi).f == np.pi
+    assert np.isclose(ocn.FPlane(rotation_rate=2, latitude=30).f, 2.0, rtol=1e-15)
+    with pytest.raises(ValueError):
+        ocn.FPlane(f=1.0, latitude=10)
+    with pytest.raises(ValueError):
+        ocn.FPlane()
