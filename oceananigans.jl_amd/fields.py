@@ -50,11 +50,20 @@ class Field:
         return self.data.cpu().numpy().T
 
     def set(self, value):
-        """set!(field, value): array indexed [i, j, k] over the interior, a scalar, or f(x, y, z) is NOT supported
-        (initial conditions are passed as arrays).  Halos are left untouched (src/Fields/set!.jl)."""
+        """set!(field, value): an array indexed [i, j, k] over the interior, a scalar, or a function f(x, y, z) evaluated at
+        the field's nodes (called once with broadcastable coordinate arrays; falls back to element-wise calls).
+        Halos are left untouched (src/Fields/set!.jl)."""
         iv = self.interior_view()
         if np.isscalar(value):
             iv.fill_(float(value))
+        elif callable(value):  # set!(field, f::Function): f(x, y, z) at the field's nodes (src/Fields/set!.jl:43-76)
+            x, y, z = self.grid.nodes(self.loc)
+            try:
+                a = np.asarray(value(x, y, z), dtype=np.float64)
+            except (TypeError, ValueError):
+                a = np.vectorize(value, otypes=[np.float64])(x, y, z)
+            a = np.broadcast_to(a, tuple(reversed(iv.shape)))
+            iv.copy_(on_architecture(self.grid.architecture, np.ascontiguousarray(a.T)))
         else:
             if isinstance(value, torch.Tensor):
                 t = value.to(self.data.device, dtype=torch.float64)

@@ -69,6 +69,7 @@ class RectilinearGrid:
         L, D = [1.0] * 3, [1.0] * 3
         self.z_faces = None
         self._dzc_host = self._dzf_host = None
+        self._origin = [0.0, 0.0, 0.0]  # left end of each regular dimension (for node coordinates)
         for d in range(3):
             if topo[d] == Flat:
                 continue
@@ -77,6 +78,7 @@ class RectilinearGrid:
                 raise ValueError(f"coordinate {'xyz'[d]} must be given for a non-Flat dimension")
             if np.ndim(e) == 1 and len(e) == 2:
                 c1, c2 = e
+                self._origin[d] = float(c1)
                 if not c2 > c1:
                     raise ValueError(f"{'xyz'[d]} must be an increasing interval!")
                 Lx = _exact(c2) - _exact(c1)
@@ -124,6 +126,33 @@ class RectilinearGrid:
         self._dzf_host = np.ascontiguousarray(dzf_full[1:])  # element 0 <-> k = 1-H
         assert self._dzf_host.size == N + 2 * H and self._dzc_host.size == N + 2 * H
         return float(F[N] - F[0])
+
+    # -- node coordinates (grid_generation.jl:34-135: faces F[i] = c1 + (i-1) Δ, centres F[i] + Δ/2; Julia builds them as
+    #    twice-precision ranges, reproduced here by exact rational arithmetic rounded once) ----------------------------
+    def nodes_1d(self, d, face):
+        """Interior node coordinates along dimension d (0 x, 1 y, 2 z) at Face or Center location; a Face location in a
+        Bounded dimension has N+1 nodes."""
+        N = (self.Nx, self.Ny, self.Nz)[d]
+        H = (self.Hx, self.Hy, self.Hz)[d]
+        topo = self.topology[d]
+        if topo == Flat:
+            return np.zeros(1)
+        n = N + 1 if (face and topo == Bounded) else N
+        if d == 2 and self.z_faces is not None:
+            F = np.asarray(self.z_faces)[H:H + N + 1]
+            return F[:n].copy() if face else 0.5 * (F[1:] + F[:-1])
+        from fractions import Fraction
+        c1 = Fraction(self._origin[d])
+        D = Fraction((self.dx, self.dy, self.dz)[d])
+        off = Fraction(0) if face else Fraction(1, 2)
+        return np.array([float(c1 + (i + off) * D) for i in range(n)])
+
+    def nodes(self, loc):
+        """(x, y, z) node coordinate arrays, shaped for broadcasting over [i, j, k], of a field at bitmask `loc`."""
+        x = self.nodes_1d(0, loc & 1).reshape(-1, 1, 1)
+        y = self.nodes_1d(1, loc & 2).reshape(1, -1, 1)
+        z = self.nodes_1d(2, loc & 4).reshape(1, 1, -1)
+        return x, y, z
 
     # -- sizes ------------------------------------------------------------------------------------
     def parent_shape(self, loc):

@@ -316,3 +316,21 @@ def test_checkpoint_pickup_is_exact(ocn, ts, tmp_path):
     for a, b in zip(m.prognostic_fields(), r.prognostic_fields()):
         np.testing.assert_array_equal(a.parent(), b.parent())
     assert r.clock.time == m.clock.time
+
+
+def test_set_with_functions(ocn):
+    """set!(model, u=f(x, y, z), ...) (set_nonhydrostatic_model.jl:33-60): functions are evaluated at each field's own nodes."""
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(8, 6, 5), x=(0, 2), y=(-1, 1), z=[-3.0, -2.0, -1.2, -0.5, -0.1, 0.0],
+                            topology=("Periodic", "Periodic", "Bounded"))
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers="c")
+    ocn.set(m, enforce_incompressibility=False, u=lambda x, y, z: x + 10 * y + 100 * z, w=lambda x, y, z: z, c=lambda x, y, z: 0 * x + np.cos(z))
+    xF, xC = np.arange(8) * 0.25, (np.arange(8) + 0.5) * 0.25
+    yC = -1 + (np.arange(6) + 0.5) / 3
+    zF = np.array([-3.0, -2.0, -1.2, -0.5, -0.1, 0.0])
+    zC = 0.5 * (zF[1:] + zF[:-1])
+    np.testing.assert_allclose(m.u.interior(), xF[:, None, None] + 10 * yC[None, :, None] + 100 * zC[None, None, :], rtol=0, atol=1e-13)
+    wcol = m.w.interior()[3, 2, :]                            # Face in Bounded z: Nz + 1 nodes
+    assert np.array_equal(wcol[1:-1], zF[1:-1]) and wcol[0] == 0 and wcol[-1] == 0  # walls: impenetrable fill of set!
+    assert np.array_equal(m.tracers[0].interior()[0, 0, :], np.cos(zC))
+    ocn.set(m, enforce_incompressibility=False, v=lambda x, y, z: float(1.5))                  # scalar-valued function: element-wise fallback / broadcast
+    assert np.all(m.v.interior() == 1.5)

@@ -58,3 +58,17 @@ def test_weno_scheme_arguments(pkg):
         pkg.WENO(order=4)
     with pytest.raises(NotImplementedError):
         pkg.WENO(order=7)
+
+
+def test_node_coordinates(pkg):
+    """grid_generation.jl:34-135: faces c1 + (i-1) Δ, centres half a spacing further; N+1 faces in a Bounded dimension;
+    stretched z centres are face mid-points."""
+    g = pkg.RectilinearGrid(None, size=(4, 5, 3), x=(0, 1), y=(-1, 1.5), z=[-4.0, -2.0, -0.5, 0.0],
+                            topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    assert np.array_equal(g.nodes_1d(0, 1), [0.0, 0.25, 0.5, 0.75])
+    assert np.array_equal(g.nodes_1d(0, 0), [0.125, 0.375, 0.625, 0.875])
+    assert np.allclose(g.nodes_1d(1, 0), -1 + 0.5 * (np.arange(5) + 0.5), rtol=0, atol=1e-16)
+    assert np.array_equal(g.nodes_1d(2, 4), [-4.0, -2.0, -0.5, 0.0])
+    assert np.array_equal(g.nodes_1d(2, 0), [-3.0, -1.25, -0.25])
+    x, y, z = g.nodes(1)
+    assert x.shape == (4, 1, 1) and y.shape == (1, 5, 1) and z.shape == (1, 1, 3)
