@@ -249,6 +249,12 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
  * it wants the answer.  field must be 16-byte aligned (any ocn_malloc / torch allocation is). */
 int ocn_hasnan(const double *field, int64_t n_elements, int32_t *flag_device, void *stream);
 
+/* cell_advection_timescale(grid, velocities) (src/Advection/cell_advection_timescale.jl:13-35), the quantity behind AdvectiveCFL
+ * and TimeStepWizard: min over the interior of 1 / (|u|/Δx + |v|/Δy + |w|/Δzᶜᶜᶠ).  *result_device (DEVICE double) receives the
+ * minimum (+inf for a fluid at rest); asynchronous. */
+int ocn_cell_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *result_device,
+                                 void *stream);
+
 /* ---- Time steppers ----
  * rk3_substep_field! for n fields in one launch (src/TimeSteppers/runge_kutta_3.jl:160-208).
  * has_zeta = 0 selects the first-stage method  U += (Δt*γ)*Gⁿ. */

@@ -19,7 +19,8 @@ from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, Runge
                      compute_tendencies, flush_tendencies,
                      pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_hydrostatic_pressure,
                      update_state)
-from .output import NaNChecker, hasnan, set_from_checkpoint, write_checkpoint
+from .output import (AdvectiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, hasnan, set_from_checkpoint,
+                     write_checkpoint)
 from .physics import (AnisotropicMinimumDissipation, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
                       GradientBoundaryCondition, LinearEquationOfState, ScalarDiffusivity, SeawaterBuoyancy,
                       ValueBoundaryCondition)

@@ -80,6 +80,7 @@ _SIGS = {
     "ocn_update_hydrostatic_pressure": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp],
     "ocn_fill_halo_regions_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _i32, _vp],
     "ocn_apply_flux_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _vp],
+    "ocn_cell_advection_timescale": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
     "ocn_hasnan": [_vp, C.c_int64, _vp, _vp],
     "ocn_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _i32, _vp],
     "ocn_ab2_step": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _vp],

@@ -201,6 +201,15 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
+int ocn_cell_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *result_device,
+                                 void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && result_device, "ocn_cell_advection_timescale: null pointer");
+    return launch_advection_timescale(grid, u, v, w, result_device, as_stream(stream));
+}
+
 int ocn_hasnan(const double *field, int64_t n_elements, int32_t *flag_device, void *stream)
 {
     OCN_REQUIRE(field && flag_device, "ocn_hasnan: null pointer");

@@ -204,6 +204,47 @@ int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// cell_advection_timescale(grid, velocities) (src/Advection/cell_advection_timescale.jl:13-35): the minimum over the interior of
+//   1 / (|u|/Δxᶠᶜᶜ + |v|/Δyᶜᶠᶜ + |w|/Δzᶜᶜᶠ)   (terms of Flat dimensions are 0).
+// Block reduction, then an atomic min on the bit pattern (non-negative doubles order like their bits; +inf for a fluid at
+// rest).  *out must be initialised to +inf by the caller (ocn_cell_advection_timescale does it).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void advection_timescale_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                                  const double *__restrict__ w, unsigned long long *__restrict__ out)
+{
+    const Lay L = make_lay(g, OCN_LOC_CCC);  // x, y Periodic: u, v, w share strides and offset
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    double tau = __longlong_as_double(0x7FF0000000000000LL);
+    if (i <= g.Nx && j <= g.Ny) {
+        const long long o = at(L, i, j, k);
+        const double ix = fabs(u[o]) / g.dx, iy = fabs(v[o]) / g.dy;
+        const double iz = (g.tz == OCN_FLAT) ? 0.0 : fabs(w[o]) / (g.dzf ? g.dzf[k + g.Hz - 1] : g.dz);
+        const double t = 1 / ((ix + iy) + iz);
+        if (t == t) tau = t;
+    }
+    __shared__ double red[256];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    red[tid] = tau;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red[tid] = fmin(red[tid], red[tid + s2]);
+        __syncthreads();
+    }
+    if (tid == 0) atomicMin(out, (unsigned long long)__double_as_longlong(red[0]));
+}
+
+int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const double inf = __builtin_inf();
+    OCN_CHECK_HIP(hipMemcpyAsync(out, &inf, sizeof(double), hipMemcpyHostToDevice, stream));
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(advection_timescale_kernel, nb, block, 0, stream, g, u, v, w, reinterpret_cast<unsigned long long *>(out));
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // hasnan(field) = any(isnan, parent(field)) (src/Models/nan_checker.jl:33): grid-stride scan, flag <- 1 on the first NaN.
 // 16-B loads; the flag lives in device memory so the default NaNChecker callback costs one read pass and no host sync
 // until the caller looks at the flag.

@@ -28,6 +28,7 @@ struct ZBcTuple {
 int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream,
                       const ZBcTuple *zbc = nullptr);
 int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream);
+int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream);
 int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
 int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream);
 int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);

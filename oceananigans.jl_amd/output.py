@@ -48,6 +48,42 @@ class NaNChecker:
         return None
 
 
+def cell_advection_timescale(model):
+    """cell_advection_timescale(model) (src/Advection/cell_advection_timescale.jl:13-35); all-reduced over the ranks of a
+    Distributed architecture (time_step_wizard.jl:112)."""
+    g = model.grid
+    out = torch.zeros(1, dtype=torch.float64, device=model.u.data.device)
+    _lib.call("ocn_cell_advection_timescale", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, out.data_ptr(), stream_ptr())
+    reduce = getattr(getattr(g.architecture, "fabric", None), "allreduce_max", None)
+    if reduce is not None and getattr(g.architecture, "partition", None) is not None and g.architecture.partition.x > 1:
+        out = -reduce(-out)
+    return float(out.item())
+
+
+class AdvectiveCFL:
+    """AdvectiveCFL(Δt)(model) = Δt / cell_advection_timescale(model) (src/Diagnostics/cfl.jl)"""
+
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __call__(self, model):
+        return self.dt / cell_advection_timescale(model)
+
+
+class TimeStepWizard:
+    """TimeStepWizard(; cfl=0.2, max_change=1.1, min_change=0.5, max_Δt=Inf, min_Δt=0) (src/Simulations/time_step_wizard.jl:3-115)
+    for the advective CFL: new_Δt = clamp(min(max_change Δt, max(min_change Δt, cfl τ)), min_Δt, max_Δt)."""
+
+    def __init__(self, cfl=0.2, max_change=1.1, min_change=0.5, max_dt=float("inf"), min_dt=0.0):
+        self.cfl, self.max_change, self.min_change, self.max_dt, self.min_dt = cfl, max_change, min_change, max_dt, min_dt
+
+    def __call__(self, model, old_dt):
+        new_dt = self.cfl * cell_advection_timescale(model)
+        new_dt = min(self.max_change * old_dt, new_dt)
+        new_dt = max(self.min_change * old_dt, new_dt)
+        return min(max(new_dt, self.min_dt), self.max_dt)
+
+
 def _names(model):
     return ("u", "v", "w") + tuple(model.tracer_names)
 

@@ -334,3 +334,27 @@ def test_set_with_functions(ocn):
     assert np.array_equal(m.tracers[0].interior()[0, 0, :], np.cos(zC))
     ocn.set(m, enforce_incompressibility=False, v=lambda x, y, z: float(1.5))                  # scalar-valued function: element-wise fallback / broadcast
     assert np.all(m.v.interior() == 1.5)
+
+
+@pytest.mark.parametrize("topo,z", [("PPP", (0, 1.0)), ("PPB", "stretched")])
+def test_cell_advection_timescale_and_wizard(ocn, topo, z):
+    """src/Advection/cell_advection_timescale.jl:13-35 and src/Simulations/time_step_wizard.jl:101-115: the device
+    reduction equals the numpy restatement of the formula exactly; the wizard applies cfl, max_change, min_change, max_Δt."""
+    rng = np.random.default_rng(8)
+    N = (20, 9, 7)
+    zz = stretched_faces(N[2], 1.0) if isinstance(z, str) else z
+    g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 2), y=(0, 3), z=zz, topology=tuple({"P": "Periodic", "B": "Bounded"}[t] for t in topo))
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    ocn.set(m, u=rng.uniform(-1, 1, N), v=rng.uniform(-1, 1, N))
+    u, v, w = (f.interior()[:, :, :N[2]] for f in m.velocities)
+    dzf = g._dzf_host[g.Hz:g.Hz + N[2]] if g._dzf_host is not None else np.full(N[2], g.dz)
+    ref = np.min(1 / ((np.abs(u) / g.dx + np.abs(v) / g.dy) + np.abs(w) / dzf[None, None, :]))
+    tau = ocn.cell_advection_timescale(m)
+    assert tau == ref
+    assert ocn.AdvectiveCFL(0.01)(m) == 0.01 / ref
+    wiz = ocn.TimeStepWizard(cfl=1.0, max_change=1.1, max_dt=60.0)
+    assert wiz(m, 10 * tau) == max(0.5 * 10 * tau, tau)   # shrink limited by min_change
+    assert wiz(m, 0.5 * tau) == 1.1 * 0.5 * tau           # growth limited by max_change
+    assert ocn.TimeStepWizard(cfl=1.0, max_dt=tau / 3, max_change=100)(m, tau) == tau / 3
+    rest = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    assert ocn.cell_advection_timescale(rest) == float("inf")
