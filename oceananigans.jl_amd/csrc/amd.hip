@@ -8,6 +8,7 @@
 //
 // One thread per cell, x fastest across the wave; each term is written exactly as the reference spells it (operand order,
 // left-associated sums) so the strict build is bit-identical to the CPU oracle.  x, y Periodic => one set of strides.
+// Every normalised gradient is evaluated once per thread into registers and reused by all terms and all tracers.
 #include "ocn_weno.h"
 
 namespace OCN_NS {
@@ -28,40 +29,6 @@ struct Amd {
     __device__ __forceinline__ double Fz(int d) const { return 2 * M.dzC(k + d); }
 };
 
-// normalised gradients at offset (a, b, d) from the cell
-struct DxU { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return (A.U(a + 1, b, d) - A.U(a, b, d)) / A.dx; } };
-struct DyV { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return (A.V(a, b + 1, d) - A.V(a, b, d)) / A.dy; } };
-struct DzW { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return (A.W(a, b, d + 1) - A.W(a, b, d)) / A.M.dzC(A.k + d); } };
-struct DxV { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fx / A.Fy * ((A.V(a, b, d) - A.V(a - 1, b, d)) / A.dx); } };
-struct DyU { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fy / A.Fx * ((A.U(a, b, d) - A.U(a, b - 1, d)) / A.dy); } };
-struct DxW { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fx / A.Fz(d) * ((A.W(a, b, d) - A.W(a - 1, b, d)) / A.dx); } };
-struct DzU { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fz(d) / A.Fx * ((A.U(a, b, d) - A.U(a, b, d - 1)) / A.M.dzF(A.k + d)); } };
-struct DyW { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fy / A.Fz(d) * ((A.W(a, b, d) - A.W(a, b - 1, d)) / A.dy); } };
-struct DzV { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fz(d) / A.Fy * ((A.V(a, b, d) - A.V(a, b, d - 1)) / A.M.dzF(A.k + d)); } };
-struct DxC { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fx * ((A.C(a, b, d) - A.C(a - 1, b, d)) / A.dx); } };
-struct DyC { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fy * ((A.C(a, b, d) - A.C(a, b - 1, d)) / A.dy); } };
-struct DzC { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return A.Fz(d) * ((A.C(a, b, d) - A.C(a, b, d - 1)) / A.M.dzF(A.k + d)); } };
-struct S12 { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return 0.5 * (DyU()(A, a, b, d) + DxV()(A, a, b, d)); } };
-struct S13 { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return 0.5 * (DzU()(A, a, b, d) + DxW()(A, a, b, d)); } };
-struct S23 { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return 0.5 * (DzV()(A, a, b, d) + DyW()(A, a, b, d)); } };
-template <class F>
-struct Sq { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { const double t = F()(A, a, b, d); return t * t; } };
-template <class F, class G>
-struct Pr { __device__ __forceinline__ double operator()(const Amd &A, int a, int b, int d) const { return F()(A, a, b, d) * G()(A, a, b, d); } };
-
-// ℑ of functions (interpolation_operators.jl:20-26, 44-57), evaluated at the cell
-template <class F> __device__ __forceinline__ double Ix(const Amd &A, int b = 0, int d = 0) { return 0.5 * (F()(A, 0, b, d) + F()(A, 1, b, d)); }
-template <class F> __device__ __forceinline__ double Iy(const Amd &A, int a = 0, int d = 0) { return 0.5 * (F()(A, a, 0, d) + F()(A, a, 1, d)); }
-template <class F> __device__ __forceinline__ double Iz(const Amd &A) { return 0.5 * (F()(A, 0, 0, 0) + F()(A, 0, 0, 1)); }
-template <class F> __device__ __forceinline__ double Ixy(const Amd &A) { return 0.5 * (Ix<F>(A, 0, 0) + Ix<F>(A, 1, 0)); }
-template <class F> __device__ __forceinline__ double Ixz(const Amd &A) { return 0.5 * (Ix<F>(A, 0, 0) + Ix<F>(A, 0, 1)); }
-template <class F> __device__ __forceinline__ double Iyz(const Amd &A) { return 0.5 * (Iy<F>(A, 0, 0) + Iy<F>(A, 0, 1)); }
-
-__device__ __forceinline__ double amd_delta2(const Amd &A)
-{
-    const double Fz = A.Fz(0);
-    return 3 / ((1 / (A.Fx * A.Fx) + 1 / (A.Fy * A.Fy)) + 1 / (Fz * Fz));
-}
 __device__ __forceinline__ double julia_max0(double x) { return (x > 0 || x != x) ? x : 0.0; }
 
 __device__ __forceinline__ Amd make_amd(const GridDev &g, const double *u, const double *v, const double *w, const double *c, int i,
