@@ -136,3 +136,65 @@ def test_full_size_config4_stretched(ocn):
             assert abs(float((_interior_N(f, g) * dzc).sum()) - a) < 1e-11 * scale
     finally:
         ocn.set_math_mode(ocn.MATH_STRICT)
+
+
+def test_full_size_config4_ocean_wind_mixing(ocn):
+    """configs[3] of BASELINE.json at full size (512 x 512 x 256 (P,P,B), stretched z, the example's physics incl. the AMD
+    closure), through properties that do not need the oracle: incompressibility, finiteness, νₑ/κₑ >= 0, and exact tracer
+    budgets -- the volume integral of S changes only by the evaporation flux (-rate·S at the surface, `value + coeff·c` BC)
+    and that of T only by the surface heat flux plus the diffusive flux through the bottom face (bottom Gradient BC)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import C4, config4_faces
+    N, Nz = 512, 256
+    zf = config4_faces(Nz)
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        g = ocn.RectilinearGrid(ocn.GPU(), size=(N, N, Nz), x=(0, 64), y=(0, 64), z=zf, topology=(P, P, B), halo=(3, 3, 3))
+        bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(C4["taux"])),
+               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(C4["JT"]), bottom=ocn.GradientBoundaryCondition(C4["dTdz"])),
+               "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-C4["evap"]))}
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=C4["f"]),
+                                    closure=ocn.AnisotropicMinimumDissipation(),
+                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(C4["alpha"], C4["beta"])),
+                                    boundary_conditions=bcs)
+        assert m.fuse_stage_boundaries and m.pressure_solver.info()["kind"] == 1
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(7)
+        zc = torch.from_numpy(0.5 * (zf[1:] + zf[:-1])).to("cuda")
+        T = m.field("T").interior_view()
+        T.copy_(20 + C4["dTdz"] * zc[:, None, None] + 1e-4 * torch.rand(T.shape, generator=gen, device="cuda", dtype=torch.float64))
+        S = m.field("S").interior_view()
+        S.copy_(35 + 1e-3 * torch.rand(S.shape, generator=gen, device="cuda", dtype=torch.float64))
+        for f in m.velocities:
+            iv = f.interior_view()
+            iv.copy_(1e-2 * (torch.rand(iv.shape, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1))
+        ocn.set(m)
+        dzc = torch.from_numpy(np.diff(zf)).to("cuda")[:, None, None]
+
+        def integral(name):  # per unit horizontal area
+            return float((m.field(name).interior_view() * dzc).sum()) / (N * N)
+
+        # one short RK3 step: flux-form advection and the interior diffusive fluxes cancel in the column integral, so the
+        # integrals move only by the boundary fluxes, which vary by O(1e-3) relative across the three stages
+        S0, T0 = integral("S"), integral("T")
+        dt = 1e-3
+        ocn.time_step(m, dt)
+        ocn.flush_tendencies(m)
+        ocn.sync_device()
+        assert all(bool(torch.isfinite(f.data).all()) for f in m.prognostic_fields())
+        assert _div_max(ocn, g, m) < 5e-8
+        nu = m.diffusivity_fields["nu_e"].interior_view()
+        assert float(nu.min()) >= 0 and float(nu.max()) > 0
+        assert all(float(k.interior_view().min()) >= 0 for k in m.diffusivity_fields["kappa_e"])
+        S_top = float(m.field("S").interior_view()[-1].mean())
+        # dS/dt integrated = -(top flux) = rate * <S_top>;  S_top varies by O(1e-3) relative across the step
+        dS = integral("S") - S0
+        assert abs(dS - C4["evap"] * S_top * dt) < 1e-3 * C4["evap"] * 35 * dt + 1e-13 * 35 * float(zf[-1] - zf[0])
+        # T: top flux JT leaves; the bottom Gradient condition lets -κₑ dTdz through the bottom face, κₑ >= 0 and tiny (AMD)
+        dT = integral("T") - T0
+        kb = float(m.diffusivity_fields["kappa_e"][0].interior_view()[0].mean())
+        assert abs(dT - (-C4["JT"] * dt - kb * C4["dTdz"] * dt)) < 0.05 * C4["JT"] * dt + 1e-13 * 20 * float(zf[-1] - zf[0])
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
