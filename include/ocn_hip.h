@@ -141,6 +141,7 @@ int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const dou
  * advection schemes */
 #define OCN_ADVECTION_WENO5 0     /* WENO() = WENO(order=5)             src/Advection/weno_reconstruction.jl:98-123 */
 #define OCN_ADVECTION_CENTERED2 1 /* Centered() = Centered(order=2), the reference default  centered_reconstruction.jl:39-60 */
+#define OCN_ADVECTION_UPWIND5 2   /* UpwindBiased(order=5)            upwind_biased_reconstruction.jl:41-140 */
 /* buoyancy formulations (gravity_unit_vector = NegativeZDirection()) */
 #define OCN_BUOYANCY_NONE 0
 #define OCN_BUOYANCY_TRACER 1      /* BuoyancyTracer(): b = tracer `T` slot               buoyancy_tracer.jl:12 */
@@ -237,7 +238,8 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
                                               double *Gu, double *Gv, double *Gw, const double *Gmu, const double *Gmv,
                                               const double *Gmw, double *u_out, double *v_out, double *w_out, double dt,
                                               double gamma, double zeta, int32_t has_zeta, const int32_t *range, void *stream);
-/* same for one tracer; advection must be OCN_ADVECTION_WENO5 (advection, diffusion, boundary flux and substep are ONE kernel) */
+/* same for one tracer; advection must be OCN_ADVECTION_WENO5 or OCN_ADVECTION_UPWIND5 (advection, diffusion, boundary flux
+ * and substep are ONE kernel) */
 int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
                                           const ocn_field_bcs *bcs_c, const double *u, const double *v, const double *w,
                                           const double *c, double *Gc, const double *Gmc, double *c_out, double dt, double gamma,

@@ -8,7 +8,7 @@ The directory name contains a dot, so import it through the root-level shim:
 """
 from . import _lib
 from ._lib import MATH_FAST, MATH_STRICT, OcnError
-from .advection import WENO
+from .advection import WENO, UpwindBiased
 from .architectures import CPU, GPU, on_architecture, sync_device, zeros
 from .distributed import (Distributed, DistributedFFTBasedPoissonSolver, DistributedFourierTridiagonalPoissonSolver, Partition,
                           TorchDistributedFabric)

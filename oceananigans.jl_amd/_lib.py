@@ -45,7 +45,7 @@ class CFieldBcs(C.Structure):
     _fields_ = [(n, CBc) for n in ("west", "east", "south", "north", "bottom", "top")]
 
 
-ADVECTION_WENO5, ADVECTION_CENTERED2 = 0, 1
+ADVECTION_WENO5, ADVECTION_CENTERED2, ADVECTION_UPWIND5 = 0, 1, 2
 BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_SEAWATER_TS, BUOYANCY_SEAWATER_T, BUOYANCY_SEAWATER_S = 0, 1, 2, 3, 4
 BC_DEFAULT, BC_FLUX, BC_VALUE, BC_GRADIENT = 0, 1, 2, 3
 

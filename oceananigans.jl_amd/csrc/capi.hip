@@ -222,7 +222,7 @@ int ocn_hasnan(const double *field, int64_t n_elements, int32_t *flag_device, vo
 static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
 {
     OCN_REQUIRE(t != nullptr, "terms is NULL");
-    OCN_REQUIRE(t->advection == OCN_ADVECTION_WENO5 || t->advection == OCN_ADVECTION_CENTERED2, "unknown advection scheme %d", t->advection);
+    OCN_REQUIRE(t->advection >= OCN_ADVECTION_WENO5 && t->advection <= OCN_ADVECTION_UPWIND5, "unknown advection scheme %d", t->advection);
     OCN_REQUIRE(t->coriolis == 0 || t->coriolis == 1, "unknown coriolis code %d", t->coriolis);
     OCN_REQUIRE(t->closure >= 0 && t->closure <= 2, "unknown closure code %d", t->closure);
     OCN_REQUIRE((t->closure == 2) == (t->nu_e != nullptr), "nu_e must be given exactly when closure == 2 (AnisotropicMinimumDissipation)");
@@ -233,11 +233,42 @@ static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
     if (t->buoyancy == OCN_BUOYANCY_SEAWATER_TS || t->buoyancy == OCN_BUOYANCY_SEAWATER_S)
         OCN_REQUIRE(t->S != nullptr, "buoyancy formulation %d needs the S tracer", t->buoyancy);
     OCN_REQUIRE(!t->pHY || t->buoyancy != OCN_BUOYANCY_NONE, "a hydrostatic pressure anomaly exists only with buoyancy (nonhydrostatic_model.jl:143-158)");
-    if (t->advection == OCN_ADVECTION_WENO5) return validate_weno(grid);
+    if (t->advection != OCN_ADVECTION_CENTERED2) return validate_weno(grid);  // UpwindBiased(order=5): same halo / size needs
     int st = validate_grid(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "Centered(order=2) and the closure stencils need halo >= 1");
     return OCN_SUCCESS;
+}
+
+// advective part by scheme and math mode
+static int launch_advective_momentum(int advection, const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                     double *Gv, double *Gw, const int32_t *range, hipStream_t s)
+{
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    switch (advection) {
+        case OCN_ADVECTION_WENO5:
+            return strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
+                          : ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
+        case OCN_ADVECTION_UPWIND5:
+            return strict ? ocn_strict_up::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
+                          : ocn_fast_up::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
+        default:
+            return strict ? ocn_strict::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s)
+                          : ocn_fast::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s);
+    }
+}
+static int launch_advective_tracer(int advection, const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t s, const TracerFuse *tf)
+{
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    switch (advection) {
+        case OCN_ADVECTION_WENO5:
+            return strict ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf) : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf);
+        case OCN_ADVECTION_UPWIND5:
+            return strict ? ocn_strict_up::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf) : ocn_fast_up::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf);
+        default:
+            return strict ? ocn_strict::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s) : ocn_fast::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s);
+    }
 }
 
 int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v,
@@ -250,12 +281,7 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
     OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
     hipStream_t s = as_stream(stream);
-    if (terms->advection == OCN_ADVECTION_WENO5)
-        st = strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
-                    : ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
-    else
-        st = strict ? ocn_strict::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s)
-                    : ocn_fast::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s);
+    st = launch_advective_momentum(terms->advection, grid, u, v, w, Gu, Gv, Gw, range, s);
     if (st != OCN_SUCCESS) return st;
     if (!(terms->coriolis || terms->closure || terms->buoyancy)) return OCN_SUCCESS;
     TermsDev t = to_dev(*terms);
@@ -272,12 +298,7 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
     OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency_terms: null field pointer");
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
     hipStream_t s = as_stream(stream);
-    if (terms->advection == OCN_ADVECTION_WENO5)
-        st = strict ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s)
-                    : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s);
-    else
-        st = strict ? ocn_strict::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s)
-                    : ocn_fast::launch_tracer_centered2(grid, u, v, w, c, Gc, range, s);
+    st = launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, nullptr);
     if (st != OCN_SUCCESS || !terms->closure) return st;
     OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
     return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s)
@@ -411,12 +432,7 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
     mf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
     hipStream_t s = as_stream(stream);
-    if (terms->advection == OCN_ADVECTION_WENO5)
-        st = strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
-                    : ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s);
-    else
-        st = strict ? ocn_strict::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s)
-                    : ocn_fast::launch_momentum_centered2(grid, u, v, w, Gu, Gv, Gw, range, s);
+    st = launch_advective_momentum(terms->advection, grid, u, v, w, Gu, Gv, Gw, range, s);
     if (st != OCN_SUCCESS) return st;
     TermsDev t = to_dev(*terms);
     return strict ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s, &mf)
@@ -430,7 +446,7 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(terms->advection == OCN_ADVECTION_WENO5, "ocn_compute_tracer_tendency_terms_rk3: advection must be WENO5");
+    OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
     OCN_REQUIRE(u && v && w && c && Gc && c_out, "ocn_compute_tracer_tendency_terms_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || Gmc, "ocn_compute_tracer_tendency_terms_rk3: G⁻ is required when has_zeta != 0");
     OCN_REQUIRE(c_out != c, "ocn_compute_tracer_tendency_terms_rk3: the output must not alias the input");
@@ -443,8 +459,7 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
     if (st != OCN_SUCCESS) return st;
     tf.sub = SubstepDev{Gmc, c_out};
     tf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
-    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream), &tf)
-                                          : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream), &tf);
+    return launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, as_stream(stream), &tf);
 }
 
 int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const int32_t *locs,

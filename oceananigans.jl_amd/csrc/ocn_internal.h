@@ -104,3 +104,17 @@ int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, cons
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
                            double *kappa_e, hipStream_t stream);
 }
+
+// advection = UpwindBiased(order=5): tendencies.hip compiled with OCN_UPWIND=1
+namespace ocn_strict_up {
+int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                               double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
+int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                           double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+}
+namespace ocn_fast_up {
+int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                               double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
+int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
+                           double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+}

@@ -10,8 +10,18 @@
 #error "define OCN_STRICT to 0 or 1"
 #endif
 
-#if OCN_STRICT
+// OCN_UPWIND=1 builds the same kernels for advection = UpwindBiased(order=5) (upwind_biased_reconstruction.jl:41-140): the
+// biased reconstructions become the fixed 5-point (3-point near Bounded walls, then 1-point) upwind stencils; the advecting
+// velocity scheme Centered(order=4), the halo conditions and the flux forms are those of WENO(order=5).
+#ifndef OCN_UPWIND
+#define OCN_UPWIND 0
+#endif
+#if OCN_STRICT && OCN_UPWIND
+#define OCN_NS ocn_strict_up
+#elif OCN_STRICT
 #define OCN_NS ocn_strict
+#elif OCN_UPWIND
+#define OCN_NS ocn_fast_up
 #else
 #define OCN_NS ocn_fast
 #endif
@@ -65,6 +75,24 @@ __device__ __forceinline__ double fast_rcp(double x)
 #endif
 
 // WENO5 reconstruction at a face from S = psi[n-3..n+2] (weno_interpolants.jl:341-348, 445-447, 475-511)
+#if OCN_UPWIND
+// UpwindBiased(order=5) / (order=3) stencils: calc_reconstruction_stencil(FT, buffer, :left / :right) with the coefficients of
+// stencil_coefficients evaluated as Julia does (oracle/coefficients.py); n-ary + is left-associated.
+__device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
+{
+    const double l = (((0.033333333333333326 * S0 + -0.21666666666666667 * S1) + 0.7833333333333333 * S2) + 0.45 * S3) + -0.04999999999999998 * S4;
+    const double r = (((-0.050000000000000044 * S1 + 0.45 * S2) + 0.7833333333333333 * S3) + -0.21666666666666667 * S4) + 0.03333333333333331 * S5;
+    return left ? l : r;
+}
+__device__ __forceinline__ double weno3(double S0, double S1, double S2, double S3, bool left)
+{
+    const double l = (-0.16666666666666674 * S0 + 0.8333333333333334 * S1) + 0.33333333333333337 * S2;
+    const double r = (0.3333333333333335 * S1 + 0.8333333333333333 * S2) + -0.16666666666666669 * S3;
+    return left ? l : r;
+}
+#define weno5 weno5_nonlinear_unused
+#define weno3 weno3_nonlinear_unused
+#endif
 __device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
 {
 #if OCN_STRICT
@@ -145,6 +173,11 @@ __device__ __forceinline__ double centered4(double m2, double m1, double z0, dou
 // TOPO is the topology along the line; idx the index the reference tests (i, j or k of the call);
 // CENTER selects the *ᶜ variants (the caller has already shifted the line to face idx+1).
 // ---------------------------------------------------------------------------------------------------
+#if OCN_UPWIND
+#undef weno5
+#undef weno3
+#endif
+
 template <int TOPO, bool CENTER, class V>
 __device__ __forceinline__ double sym_interp(V val, int idx, int N)
 {

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 import ctypes as C
 
-from .advection import WENO
+from .advection import WENO, UpwindBiased
 from .physics import (AnisotropicMinimumDissipation, BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity,
                       SeawaterBuoyancy)
 from .architectures import stream_ptr
@@ -86,8 +86,8 @@ class NonhydrostaticModel:
                 raise NotImplementedError(f"{name} != nothing is outside the MI355X hot-path scope (see DESIGN.md)")
         if advection is None:
             advection = Centered()  # the reference default (nonhydrostatic_model.jl:117)
-        if not isinstance(advection, (WENO, Centered)):
-            raise NotImplementedError("advection must be WENO() or Centered()")
+        if not isinstance(advection, (WENO, Centered, UpwindBiased)):
+            raise NotImplementedError("advection must be WENO(), UpwindBiased(order=5) or Centered()")
         if coriolis is not None and not isinstance(coriolis, FPlane):
             raise NotImplementedError("only coriolis = FPlane(...) is implemented")
         if closure is not None and not isinstance(closure, (ScalarDiffusivity, AnisotropicMinimumDissipation)):
@@ -156,7 +156,7 @@ class NonhydrostaticModel:
         # anything beyond plain WENO advection goes through the general (unfused) tendency entry points
         self._has_user_bcs = any(not b.is_default() for b in list(bcs.values()) + list(kappa_bcs.values()) + ([nu_bcs] if nu_bcs else []))
         self._has_flux_bcs = any(b.has_flux() for b in bcs.values())
-        self.general_terms = (isinstance(advection, Centered) or coriolis is not None or closure is not None
+        self.general_terms = (isinstance(advection, (Centered, UpwindBiased)) or coriolis is not None or closure is not None
                               or buoyancy is not None or self._has_user_bcs)
         if self._has_user_bcs and hasattr(grid.architecture, "partition") and any(
                 s is not None and s.values is not None for b in bcs.values() for s in b.sides.values()):
@@ -166,7 +166,7 @@ class NonhydrostaticModel:
         # WENO momentum uses the tiled kernel's epilogue; tracers and the §8(f) terms use the general fused entry points
         # (WENO advection only: the Centered(order=2) tracer kernel has no epilogue)
         self._general_fused = self.general_terms or bool(self.tracers)
-        self.fuse_stage_boundaries = (not self._general_fused) or (isinstance(advection, WENO)
+        self.fuse_stage_boundaries = (not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
                                                                    and os.environ.get("OCN_FUSE_GENERAL", "1") != "0")
         self._alt_velocities = None
         self._alt_fields = None
@@ -183,7 +183,8 @@ class NonhydrostaticModel:
     def _make_terms(self):
         """struct ocn_model_terms for the C ABI (pointers never change after construction)."""
         t = _lib.CModelTerms()
-        t.advection = _lib.ADVECTION_CENTERED2 if isinstance(self.advection, Centered) else _lib.ADVECTION_WENO5
+        t.advection = (_lib.ADVECTION_CENTERED2 if isinstance(self.advection, Centered)
+                       else _lib.ADVECTION_UPWIND5 if isinstance(self.advection, UpwindBiased) else _lib.ADVECTION_WENO5)
         if self.coriolis is not None:
             t.coriolis, t.f = 1, self.coriolis.f
         if isinstance(self.closure, AnisotropicMinimumDissipation):
@@ -460,7 +461,7 @@ def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=Tru
     z, hz = (0.0, 0) if zeta is None else (float(zeta), 1)
     t = C.byref(model._terms)
     momentum_extra = (model.coriolis is not None or model.closure is not None or model.buoyancy is not None
-                      or isinstance(model.advection, Centered) or _bcs_ref(model.u, g) is not None or _bcs_ref(model.v, g) is not None)
+                      or isinstance(model.advection, (Centered, UpwindBiased)) or _bcs_ref(model.u, g) is not None or _bcs_ref(model.v, g) is not None)
     if momentum_extra:
         _lib.call("ocn_compute_momentum_tendencies_terms_rk3", g.cref, t, _bcs_ref(model.u, g), _bcs_ref(model.v, g),
                   model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr,

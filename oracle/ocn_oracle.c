@@ -209,7 +209,35 @@ static inline double sym_interp(const line *L, int idx, int N, int topo, int cen
 }
 
 /* biased interpolation to face n (or centre idx = n-1 when center != 0) */
+/* UpwindBiased(order=5) / (order=3) stencils (upwind_biased_reconstruction.jl:91-117 -> calc_reconstruction_stencil,
+ * reconstruction_coefficients.jl:173-203), coefficients from oracle/coefficients.py; n-ary + is left-associated. */
+static inline double upwind5(const double S[6], int left)
+{
+    if (left) return (((0.033333333333333326 * S[0] + -0.21666666666666667 * S[1]) + 0.7833333333333333 * S[2]) + 0.45 * S[3]) + -0.04999999999999998 * S[4];
+    return (((-0.050000000000000044 * S[1] + 0.45 * S[2]) + 0.7833333333333333 * S[3]) + -0.21666666666666667 * S[4]) + 0.03333333333333331 * S[5];
+}
+static inline double upwind3(const double S[4], int left)
+{
+    if (left) return (-0.16666666666666674 * S[0] + 0.8333333333333334 * S[1]) + 0.33333333333333337 * S[2];
+    return (0.3333333333333335 * S[1] + 0.8333333333333333 * S[2]) + -0.16666666666666669 * S[3];
+}
+void ocn_oracle_upwind_coefficients(double *u5l, double *u5r, double *u3l, double *u3r)
+{
+    const double a[5] = {0.033333333333333326, -0.21666666666666667, 0.7833333333333333, 0.45, -0.04999999999999998};
+    const double b[5] = {-0.050000000000000044, 0.45, 0.7833333333333333, -0.21666666666666667, 0.03333333333333331};
+    const double c[3] = {-0.16666666666666674, 0.8333333333333334, 0.33333333333333337};
+    const double d[3] = {0.3333333333333335, 0.8333333333333333, -0.16666666666666669};
+    memcpy(u5l, a, sizeof a); memcpy(u5r, b, sizeof b); memcpy(u3l, c, sizeof c); memcpy(u3r, d, sizeof d);
+}
+
+/* scheme: 0 WENO(order=5) (fallback WENO3 -> Upwind1), 2 UpwindBiased(order=5) (fallback Upwind3 -> Upwind1); the halo
+ * conditions are the same (both have buffer 3) */
+static inline double bias_interp_scheme(const line *L, int idx, int N, int topo, int center, int left, int scheme);
 static inline double bias_interp(const line *L, int idx, int N, int topo, int center, int left)
+{
+    return bias_interp_scheme(L, idx, N, topo, center, left, 0);
+}
+static inline double bias_interp_scheme(const line *L, int idx, int N, int topo, int center, int left, int scheme)
 {
     if (topo == OCN_FLAT) return lval(L, center ? -1 : 0);
     int ok5 = 1, ok3 = 1;
@@ -225,12 +253,12 @@ static inline double bias_interp(const line *L, int idx, int N, int topo, int ce
     if (ok5) {
         double S[6];
         for (int m = 0; m < 6; ++m) S[m] = lval(L, m - 3);
-        return weno5(S, left);
+        return scheme == 2 ? upwind5(S, left) : weno5(S, left);
     }
     if (ok3) {
         double S[4];
         for (int m = 0; m < 4; ++m) S[m] = lval(L, m - 2);
-        return weno3(S, left);
+        return scheme == 2 ? upwind3(S, left) : weno3(S, left);
     }
     /* UpwindBiased(order=1): left -> psi[n-1], right -> psi[n] (reconstruction_coefficients.jl:153-157) */
     return left ? lval(L, -1) : lval(L, 0);
@@ -246,10 +274,11 @@ typedef struct {
     const ocn_grid *g;
     const double *u, *v, *w;
     lay Lu, Lv, Lw;
-    int scheme; /* 0: WENO(order=5) (the default of every entry point), 1: Centered(order=2) */
+    int scheme; /* 0: WENO(order=5) (the default of every entry point), 1: Centered(order=2), 2: UpwindBiased(order=5) */
 } vel;
 #define OCN_ADV_WENO5 0
 #define OCN_ADV_CENTERED2 1
+#define OCN_ADV_UPWIND5 2
 
 /* Centered(order=2) interpolation: FT(0.5)*psi[n-1] + FT(0.5)*psi[n]; Centered{1} is a "low order" scheme and has no
  * topology conditions (topologically_conditional_interpolation.jl:24-27 LOADV); Flat: the value itself
@@ -325,7 +354,7 @@ static double mom_flux(const vel *V, int ca, int da, int a_center, int cb, int d
         B.k0 = q[2];
     }
     int left = ut > 0; /* bias(u) = ifelse(u > 0, LeftBias(), RightBias()) :21 */
-    double pr = bias_interp(&B, ijk[db], gridN(g, db), gridT(g, db), b_center, left);
+    double pr = bias_interp_scheme(&B, ijk[db], gridN(g, db), gridT(g, db), b_center, left, V->scheme);
     return ut * pr;
 }
 
@@ -416,7 +445,7 @@ static double tracer_flux(const vel *V, const double *c, const lay *Lc, int d, i
     double area = d == 0 ? Ax_at(g, k, 0) : d == 1 ? Ay_at(g, k, 0) : Az_at(g);
     if (V->scheme == OCN_ADV_CENTERED2) /* centered_advective_fluxes.jl:23-25: Ax_q(U) * sym(c) */
         return (area * ut) * c2_interp(&B, gridT(g, d), 0);
-    double cr = bias_interp(&B, ijk[d], gridN(g, d), gridT(g, d), 0, ut > 0);
+    double cr = bias_interp_scheme(&B, ijk[d], gridN(g, d), gridT(g, d), 0, ut > 0, V->scheme);
     return (area * ut) * cr;
 }
 void ocn_oracle_tracer_tendency_scheme(const ocn_grid *g, int scheme, const double *u, const double *v, const double *w,
@@ -1162,5 +1191,7 @@ void ocn_oracle_tridiag_solve_z(int Nx, int Ny, int Nz, const double *a, const d
 
 /* 1-D reconstruction probes for unit tests (order-of-accuracy, known answers) */
 double ocn_oracle_weno5(const double *S6, int left) { return weno5(S6, left); }
+double ocn_oracle_upwind5(const double *S6, int left) { return upwind5(S6, left); }
+double ocn_oracle_upwind3(const double *S4, int left) { return upwind3(S4, left); }
 double ocn_oracle_weno3(const double *S4, int left) { return weno3(S4, left); }
 double ocn_oracle_centered4(const double *S4) { return ((C4[0] * S4[0] + C4[1] * S4[1]) + C4[2] * S4[2]) + C4[3] * S4[3]; }

@@ -54,6 +54,8 @@ def lib():
         _LIB.ocn_oracle_weno5.restype = C.c_double
         _LIB.ocn_oracle_weno3.restype = C.c_double
         _LIB.ocn_oracle_centered4.restype = C.c_double
+        _LIB.ocn_oracle_upwind5.restype = C.c_double
+        _LIB.ocn_oracle_upwind3.restype = C.c_double
     return _LIB
 
 
@@ -242,7 +244,7 @@ def fill_halo_regions(g, a, loc, fill_boundary_normal_velocities=True, bcs=None)
 # --------------------------------------------------------------------------------------
 # Kernels (thin wrappers)
 # --------------------------------------------------------------------------------------
-ADV_WENO5, ADV_CENTERED2 = 0, 1
+ADV_WENO5, ADV_CENTERED2, ADV_UPWIND5 = 0, 1, 2
 
 
 def momentum_tendencies(g, u, v, w, Gu, Gv, Gw, scheme=ADV_WENO5):
@@ -480,8 +482,8 @@ class NonhydrostaticModel:
         """advection: "WENO5" | "Centered2"; closure = (ν, {tracer: κ} or κ); buoyancy as in Physics;
         boundary_conditions = {"u": {"top": BC, ...}, ...} (§8(f) rank 1)."""
         g = self.grid = grid
-        self.scheme = {"WENO5": ADV_WENO5, "Centered2": ADV_CENTERED2}[advection]
-        need = 3 if self.scheme == ADV_WENO5 else 1
+        self.scheme = {"WENO5": ADV_WENO5, "Centered2": ADV_CENTERED2, "UpwindBiased5": ADV_UPWIND5}[advection]
+        need = 1 if self.scheme == ADV_CENTERED2 else 3
         for d, (N, H) in enumerate(((g.Nx, g.Hx), (g.Ny, g.Hy), (g.Nz, g.Hz))):
             if g.topo[d] != FLAT:
                 assert H >= need and N >= need, "WENO5 needs halo >= 3 (nonhydrostatic_model.jl:183,243-257) and N >= 3 (adapt_advection_order)"

@@ -550,3 +550,82 @@ def test_nonhydrostatic_flux_budget_on_gpu(ocn, name, side):
     m = ocn.NonhydrostaticModel(g, tracers="c", timestepper="QuasiAdamsBashforth2", boundary_conditions=bcs)
     ocn.time_step(m, 1.0)
     assert np.isclose(np.mean(m.field(name).interior()[:, :, :8]), np.pi * m.clock.time / g.Lz, rtol=1e-12)
+
+
+# ---- advection = UpwindBiased(order=5): the scheme examples/ocean_wind_mixing_and_convection.jl actually uses ----------
+UPWIND_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), (3, 3, 3)),
+                ((13, 17, 19), "PPP", (0, 1.0), (3, 3, 3)),
+                ((70, 9, 8), "PPB", (-1.0, 0.0), (3, 3, 3)),
+                ((16, 12, 10), "PPB", "stretched", (3, 3, 3)),
+                ((24, 16, 1), "PPF", None, (3, 3, 0))]
+
+
+@pytest.mark.parametrize("size,topo,z,halo", UPWIND_CASES)
+def test_upwind_biased5_advection_strict_bitwise(oracle, ocn, size, topo, z, halo):
+    O = oracle
+    rng = np.random.default_rng(51)
+    og, pg = _grid(O, ocn, size, topo, z, halo)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = random_parent(og, 0, rng)
+    G = [og.zeros(l) for l in LOCS] + [og.zeros(0)]
+    O.momentum_tendencies(og, u, v, w, *G[:3], scheme=O.ADV_UPWIND5)
+    O.tracer_tendency(og, u, v, w, c, G[3], scheme=O.ADV_UPWIND5)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dG = [ocn.Field(l, pg) for l in LOCS + (0,)]
+    t = _terms(ocn, advection=2)
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr,
+                  dG[2].ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, None, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvwc"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"G{name} differs bitwise from the oracle")
+    # and it is not the WENO result
+    Gw5 = og.zeros(1)
+    O.momentum_tendencies(og, u, v, w, Gw5, og.zeros(2), og.zeros(4))
+    assert not np.array_equal(Gw5, G[0])
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_ocean_wind_mixing_example_as_written_matches_oracle(oracle, ocn, mode):
+    """examples/ocean_wind_mixing_and_convection.jl:79-152 literally: advection = UpwindBiased(order=5), AMD, SeawaterBuoyancy,
+    FPlane, the three boundary conditions, RK3 (default time stepper): 3 steps of the product against the oracle."""
+    O = oracle
+    rng = np.random.default_rng(52)
+    size = (16, 12, 10)
+    z = stretched_faces(size[2], 32.0)
+    og, pg = make_pair(O, ocn, size, "PPB", x=(0, 64), y=(0, 64), z=z)
+    Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
+    JT, taux, evap = Q / (rho * cp), -1.225 / rho * 2.5e-3 * 10 * 10, 1e-3 / 3600
+    obcs = {"u": {"top": O.FluxBoundaryCondition(taux)},
+            "T": {"top": O.FluxBoundaryCondition(JT), "bottom": O.GradientBoundaryCondition(dTdz)},
+            "S": {"top": O.BC("flux", 0.0, -evap)}}
+    om = O.NonhydrostaticModel(og, tracers=("T", "S"), advection="UpwindBiased5", coriolis_f=1e-4, closure=("AMD",),
+                               buoyancy=SEAWATER, boundary_conditions=obcs)
+    pbcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(taux)),
+            "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(JT), bottom=ocn.GradientBoundaryCondition(dTdz)),
+            "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-evap))}
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        pm = ocn.NonhydrostaticModel(pg, advection=ocn.UpwindBiased(order=5), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
+                                     closure=ocn.AnisotropicMinimumDissipation(),
+                                     buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                     boundary_conditions=pbcs)
+        assert pm.fuse_stage_boundaries
+        zc = 0.5 * (z[1:] + z[:-1])
+        init = {n: 1e-2 * rng.uniform(-1, 1, og.interior(f).shape) for n, f in zip("uvw", (om.u, om.v, om.w))}
+        init["T"] = 20 + dTdz * zc[None, None, :] + 1e-3 * rng.uniform(-1, 1, size)
+        init["S"] = 35 + 1e-3 * rng.uniform(-1, 1, size)
+        om.set(**init)
+        ocn.set(pm, **init)
+        for _ in range(3):
+            om.time_step(2.0)
+            ocn.time_step(pm, 2.0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    vscale = max(np.abs(om.u).max(), np.abs(om.v).max(), np.abs(om.w).max())
+    for name, a, d in zip(("u", "v", "w", "T", "S"), om.fields, pm.prognostic_fields()):
+        scale = vscale if name in "uvw" else np.abs(og.interior(a)).max()
+        err = np.abs(og.interior(from_dev(d)) - og.interior(a)).max()
+        assert err <= 1e-10 * scale, f"{name}: {err} > {1e-10 * scale}"

@@ -63,3 +63,18 @@ def test_hip_header_constants_match_generator():
     for r in range(3):
         assert [defs[f"OCN_W5P_{r}{j}"] for j in range(3)] == [float(v) for v in K.weno_coeff_p(np.float64, 3, r)]
     assert defs["OCN_WENO_EPS"] == float(np.float32(1e-8))
+
+
+def test_upwind_biased_constants_match_generator(oracle):
+    """UpwindBiased(order=5) / (order=3) stencils: C oracle and HIP header literals == the Julia-faithful generator, whose
+    Float32 order-5 left stencil is the reference's jldoctest vector (test_jldoctest_float32_left_upwind5)."""
+    a, b, c, d = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_double * 3)(), (C.c_double * 3)()
+    oracle.lib().ocn_oracle_upwind_coefficients(a, b, c, d)
+    gen = lambda buf, sh: [float(v) for _, v in K.calc_reconstruction_stencil(np.float64, buf, sh)]
+    assert list(a) == gen(3, "left") and list(b) == gen(3, "right") and list(c) == gen(2, "left") and list(d) == gen(2, "right")
+    assert [o for o, _ in K.calc_reconstruction_stencil(np.float64, 3, "left")] == [-3, -2, -1, 0, 1]
+    assert [o for o, _ in K.calc_reconstruction_stencil(np.float64, 3, "right")] == [-2, -1, 0, 1, 2]
+    src = open(os.path.join(ROOT, "oceananigans.jl_amd", "csrc", "ocn_weno.h")).read()
+    blk = src[src.index("#if OCN_UPWIND\n// UpwindBiased(order=5)"):src.index("#define weno5 weno5_nonlinear_unused")]
+    lits = [float(x) for x in re.findall(r"(-?0\.\d+) \* S\d", blk)]
+    assert lits == gen(3, "left") + gen(3, "right") + gen(2, "left") + gen(2, "right")

@@ -252,3 +252,27 @@ def test_weno5_fifth_order_and_upwinding(oracle):
     assert abs(L.ocn_oracle_weno5(S.ctypes.data_as(C.c_void_p), 1) - 3.25) < 1e-14
     S4 = np.array([1.0, 2.0, 3.0, 4.0])
     assert abs(L.ocn_oracle_centered4(S4.ctypes.data_as(C.c_void_p)) - 2.5) < 1e-14  # exact for linear data
+
+
+def test_upwind_biased5_fifth_order(oracle):
+    """validation/convergence_tests/one_dimensional_advection_schemes.jl:47-63 lists UpwindBiased(order=5) next to WENO: the
+    fixed 5-point stencils converge at 5th order from cell averages, both biases; the 3-point fallback at 3rd order."""
+    L = oracle.lib()
+    e5, e3 = [], []
+    for N in (16, 32, 64):
+        h = 2 * np.pi / N
+        avg = lambda a, b: (np.cos(a) - np.cos(b)) / h
+        m5 = m3 = 0.0
+        for i in range(N):
+            xf = i * h
+            S = np.array([avg(xf + m * h, xf + (m + 1) * h) for m in range(-3, 3)])
+            S4 = np.ascontiguousarray(S[1:5])
+            for left in (1, 0):
+                m5 = max(m5, abs(L.ocn_oracle_upwind5(S.ctypes.data_as(C.c_void_p), left) - np.sin(xf)))
+                m3 = max(m3, abs(L.ocn_oracle_upwind3(S4.ctypes.data_as(C.c_void_p), left) - np.sin(xf)))
+        e5.append(m5)
+        e3.append(m3)
+    assert np.log2(e5[0] / e5[1]) > 4.7 and np.log2(e5[1] / e5[2]) > 4.9
+    assert np.log2(e3[0] / e3[1]) > 2.7 and np.log2(e3[1] / e3[2]) > 2.9
+    S = np.full(6, 3.25)
+    assert abs(L.ocn_oracle_upwind5(S.ctypes.data_as(C.c_void_p), 1) - 3.25) < 1e-14
