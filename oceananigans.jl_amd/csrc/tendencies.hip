@@ -480,18 +480,29 @@ __device__ __forceinline__ double tracer_flux(double area, double ut, const doub
 // (closure_kernel_operators.jl:48-53, κ a number or the field κₑ interpolated to the faces) and the bottom / top flux boundary
 // contributions (apply_flux_bcs.jl:107-160).  Same operations in the same order as the separate kernels (physics.hip
 // tracer_diffusion_kernel, kernels.hip apply_flux_bcs_kernel): bit-identical in the strict build.
-// c0 = c[i,j,k]; cxm/cxp, cym/cyp, czm/czp its six neighbours.
+// c0 = c[i,j,k]; cxm/cxp, cym/cyp, czm/czp its six neighbours; K[7] = κ at the cell and at the same six neighbours
+// (all equal to the number κ when there is no eddy-diffusivity field).
+struct Kappa7 {
+    double c, xm, xp, ym, yp, zm, zp;
+};
+__device__ __forceinline__ Kappa7 kappa_from_global(const ocn::TracerFuse &tf, long long o, long long s2, long long s3)
+{
+    if (!tf.kappa_e) return Kappa7{tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa};
+    const double *pk = tf.kappa_e + o;
+    return Kappa7{pk[0], pk[-1], pk[1], pk[-s2], pk[s2], pk[-s3], pk[s3]};
+}
 template <int TZ>
 __device__ __forceinline__ double tracer_finish(double G, const Metrics &M, const GridDev &g, const ocn::TracerFuse &tf, int i, int j,
-                                                int k, long long o, long long s2, long long s3, double c0, double cxm, double cxp,
-                                                double cym, double cyp, double czm, double czp, double ax, double ay, double az)
+                                                int k, const Kappa7 &K, double c0, double cxm, double cxp, double cym, double cyp,
+                                                double czm, double czp, double ax, double ay, double az)
 {
     if (tf.diffusion) {
         const double dx = M.dx, dy = M.dy, dzc = M.dzC(k);
-        const double *pk = tf.kappa_e ? tf.kappa_e + o : nullptr;
-        const double k0 = pk ? pk[0] : tf.kappa;
-        const double kxe = pk ? 0.5 * (k0 + pk[1]) : tf.kappa, kxw = pk ? 0.5 * (pk[-1] + k0) : tf.kappa;
-        const double kyn = pk ? 0.5 * (k0 + pk[s2]) : tf.kappa, kys = pk ? 0.5 * (pk[-s2] + k0) : tf.kappa;
+        const bool fld = tf.kappa_e != nullptr;
+        const double k0 = K.c;
+        // κ at the faces: ℑxᶠᵃᵃ / ℑyᵃᶠᵃ / ℑzᵃᵃᶠ of κₑ (abstract_scalar_diffusivity_closure.jl:298-300), or the number itself
+        const double kxe = fld ? 0.5 * (k0 + K.xp) : tf.kappa, kxw = fld ? 0.5 * (K.xm + k0) : tf.kappa;
+        const double kyn = fld ? 0.5 * (k0 + K.yp) : tf.kappa, kys = fld ? 0.5 * (K.ym + k0) : tf.kappa;
 #if OCN_STRICT
 #define OCN_TD(a, d) ((a) / (d))
 #else
@@ -501,7 +512,7 @@ __device__ __forceinline__ double tracer_finish(double G, const Metrics &M, cons
         const double qyn = -(kyn * OCN_TD(cyp - c0, dy)), qys = -(kys * OCN_TD(c0 - cym, dy));
         double dzq = 0.0;
         if (TZ != OCN_FLAT) {
-            const double kzt = pk ? 0.5 * (k0 + pk[s3]) : tf.kappa, kzb = pk ? 0.5 * (pk[-s3] + k0) : tf.kappa;
+            const double kzt = fld ? 0.5 * (k0 + K.zp) : tf.kappa, kzb = fld ? 0.5 * (K.zm + k0) : tf.kappa;
             const double qzt = -(kzt * OCN_TD(czp - c0, M.dzF(k + 1))), qzb = -(kzb * OCN_TD(c0 - czm, M.dzF(k)));
             dzq = az * qzt - az * qzb;
         }
@@ -547,9 +558,165 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
     double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
     const long long o = ocn::at(Lc, i, j, k), s2 = Lc.s2, s3 = (TZ == OCN_FLAT) ? 0 : Lc.s3;
     if (tf.diffusion || tf.bottom.kind || tf.top.kind)
-        G = tracer_finish<TZ>(G, M, g, tf, i, j, k, o, s2, s3, pc[0], pc[-1], pc[1], pc[-s2], pc[s2], pc[-s3], pc[s3], ax, ay, az);
+        G = tracer_finish<TZ>(G, M, g, tf, i, j, k, kappa_from_global(tf, o, s2, s3), pc[0], pc[-1], pc[1], pc[-s2], pc[s2], pc[-s3],
+                              pc[s3], ax, ay, az);
     Gc[o] = G;
     if (tf.sc.on) tf.sub.out[o] = pc[0] + (tf.sc.has_zeta ? tf.sc.dt * (tf.sc.gamma * G + tf.sc.zeta * tf.sub.Gm[o]) : (tf.sc.dt * tf.sc.gamma) * G);
+}
+
+// Tiled tracer kernel: every face flux is evaluated ONCE and shared through LDS (the direct kernel evaluates each twice), with
+// the structure of momentum_tendencies_tiled: a workgroup owns a TX x TY patch of columns, overlapping its east / north
+// neighbours by one so that (TX-1) x (TY-1) cells are written, and marches KZ planes upward;
+//  * plane k of c lives in LDS with a 3 / 2-cell ring for the x and y stencils; the z stencil c[k-2..k+3] of the own column
+//    is a register window, so each value enters the workgroup once per plane;
+//  * thread (i, j) evaluates the west-face and south-face fluxes of its cell and the top-face flux; the east / north ones come
+//    from the neighbouring threads through LDS, the bottom one is last iteration's top flux.
+// 3 flux evaluations per thread and plane instead of 6; the flux expressions are those of the direct kernel (bit-identical).
+template <int TZ, int TX, int TY>
+__global__ __launch_bounds__(TX *TY) void tracer_tendency_tiled(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                               const double *__restrict__ w, const double *__restrict__ c,
+                                                               double *__restrict__ Gc, Range r, int KZ, ocn::TracerFuse tf)
+{
+    constexpr int P = OCN_PERIODIC;
+    constexpr int LX = TX + 5, LY = TY + 5, NT = TX * TY;
+    constexpr int NRING = LX * LY - NT;
+    constexpr int RPT = (NRING + NT - 1) / NT;
+    static_assert(RPT <= 2, "tile too small for its ring");
+    __shared__ double sc[LY][LX];
+    __shared__ double sk[LY][LX];  // plane k of the eddy diffusivity κₑ (same ring geometry), when there is one
+    __shared__ double ex[2][NT];  // west-face flux (read by the west neighbour as its east flux), south-face flux
+
+    Metrics M = make_metrics(g);
+    if (TZ == OCN_PERIODIC) M.dzc = M.dzf = nullptr;
+    const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);  // x, y Periodic: one layout for u, v, w, c, G
+    const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
+    const int k_start = r.k0 + blockIdx.z * KZ, k_end = min(k_start + KZ - 1, r.k1);
+    const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
+    const int i = min(ti0 + tx, imax), j = min(tj0 + ty, jmax);
+    const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
+    const int lx = tx + 3, ly = ty + 3;
+    const long long s3 = L0.s3;
+    const long long own0 = ocn::at(L0, i, j, 1);
+    const double *pc = c + own0, *pu = u + own0, *pv = v + own0, *pw = w + own0;
+
+    // static ring assignment (as in momentum_tendencies_tiled)
+    int rcx[RPT], rcy[RPT];
+    bool ron[RPT];
+    long long roff[RPT];
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+        const int q = tid + s * NT;
+        ron[s] = q < NRING;
+        int cx, cy;
+        if (q < 3 * LX) {
+            cx = q % LX; cy = q / LX;
+        } else if (q < 5 * LX) {
+            cx = (q - 3 * LX) % LX; cy = 3 + TY + (q - 3 * LX) / LX;
+        } else {
+            const int t = q - 5 * LX, cc = t % 5;
+            cy = 3 + t / 5;
+            cx = cc < 3 ? cc : TX + cc;
+        }
+        if (!ron[s]) { cx = 0; cy = 0; }
+        rcx[s] = cx; rcy[s] = cy;
+        roff[s] = ocn::at(L0, min(ti0 - 3 + cx, imax), min(tj0 - 3 + cy, jmax), 1);
+    }
+
+    // z window: zc[m] <-> c[k-2+m]
+    double zc[6];
+    int k = k_start;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) zc[m] = pc[(long long)(k - 3 + m) * s3];
+    const double az = M.Az;
+    double fzb;
+    {   // bottom-face flux of plane k_start: stencil c[k-3 .. k+2]
+        const double cm3 = pc[(long long)(k - 4) * s3];
+        const double wf = pw[(long long)(k - 1) * s3];
+        const double S[6] = {cm3, zc[0], zc[1], zc[2], zc[3], zc[4]};
+        fzb = (az * wf) * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wf > 0);
+    }
+    // software pipeline: the global values of plane k+1 (ring cells of c, u, v at the own faces, w at the top face, the new
+    // window entry) are requested one iteration ahead so that their latency hides behind the flux arithmetic of plane k
+    const bool kfld = tf.diffusion && tf.kappa_e != nullptr;
+    const double *pke = kfld ? tf.kappa_e + own0 : nullptr;
+    double zk[3] = {0.0, 0.0, 0.0}, rk[RPT] = {};  // κₑ[k-1..k+1] of the own column; prefetched ring values of κₑ
+    if (kfld) {
+        zk[0] = pke[(long long)(k - 2) * s3];
+        zk[1] = pke[(long long)(k - 1) * s3];
+        zk[2] = pke[(long long)k * s3];
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) rk[s] = ron[s] ? tf.kappa_e[roff[s] + (long long)(k - 1) * s3] : 0.0;
+    }
+    double rv[RPT], uf, vf, wf, znew;
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) rv[s] = ron[s] ? c[roff[s] + (long long)(k - 1) * s3] : 0.0;
+    uf = pu[(long long)(k - 1) * s3];
+    vf = pv[(long long)(k - 1) * s3];
+    wf = pw[(long long)k * s3];
+    znew = (k < k_end) ? pc[(long long)(k + 3) * s3] : 0.0;
+    for (; k <= k_end; ++k) {
+        // stage plane k (the previous iteration's readers of sc are past its second barrier)
+        sc[ly][lx] = zc[2];
+#pragma unroll
+        for (int s = 0; s < RPT; ++s)
+            if (ron[s]) sc[rcy[s]][rcx[s]] = rv[s];
+        if (kfld) {
+            sk[ly][lx] = zk[1];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) sk[rcy[s]][rcx[s]] = rk[s];
+        }
+        __syncthreads();
+        const bool more = k < k_end;
+        double rk_n[RPT] = {}, zk_n = 0.0;
+        if (kfld) {
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) rk_n[s] = (more && ron[s]) ? tf.kappa_e[roff[s] + (long long)k * s3] : 0.0;
+            zk_n = more ? pke[(long long)(k + 1) * s3] : 0.0;  // κₑ[k+2]
+        }
+        const long long o = own0 + (long long)(k - 1) * s3;
+        double rv_n[RPT];
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) rv_n[s] = (more && ron[s]) ? c[roff[s] + (long long)k * s3] : 0.0;
+        const double uf_n = more ? pu[(long long)k * s3] : 0.0, vf_n = more ? pv[(long long)k * s3] : 0.0;
+        const double wf_n = more ? pw[(long long)(k + 1) * s3] : 0.0;
+        const double znew_n = (k + 1 < k_end) ? pc[(long long)(k + 4) * s3] : 0.0;
+        const double gm = (writes && tf.sc.on && tf.sc.has_zeta) ? tf.sub.Gm[o] : 0.0;
+        const double ax = M.Ax(k), ay = M.Ay(k);
+        const double fxw = (ax * uf) * bias_interp<P, false>([&](int m) { return sc[ly][lx + m]; }, i, Nx, uf > 0);
+        const double fys = (ay * vf) * bias_interp<P, false>([&](int m) { return sc[ly + m][lx]; }, j, Ny, vf > 0);
+        const double fzt = (az * wf) * bias_interp<TZ, false>([&](int m) { return zc[m + 3]; }, k + 1, Nz, wf > 0);
+        const double cxm = sc[ly][lx - 1], cxp = sc[ly][lx + 1], cym = sc[ly - 1][lx], cyp = sc[ly + 1][lx];
+        Kappa7 K{tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa};
+        if (kfld) K = Kappa7{zk[1], sk[ly][lx - 1], sk[ly][lx + 1], sk[ly - 1][lx], sk[ly + 1][lx], zk[0], zk[2]};
+        ex[0][tid] = fxw;
+        ex[1][tid] = fys;
+        __syncthreads();
+        if (writes) {
+            const double fxe = ex[0][tid + 1], fyn = ex[1][tid + TX];
+            const double rV = 1 / (M.Az * M.dzC(k));
+            double G = -(rV * (((fxe - fxw) + (fyn - fys)) + (fzt - fzb)));
+            if (tf.diffusion || tf.bottom.kind || tf.top.kind)
+                G = tracer_finish<TZ>(G, M, g, tf, i, j, k, K, zc[2], cxm, cxp, cym, cyp, zc[1], zc[3], ax, ay, az);
+            Gc[o] = G;
+            if (tf.sc.on) tf.sub.out[o] = zc[2] + (tf.sc.has_zeta ? tf.sc.dt * (tf.sc.gamma * G + tf.sc.zeta * gm) : (tf.sc.dt * tf.sc.gamma) * G);
+        }
+        fzb = fzt;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) zc[m] = zc[m + 1];
+        zc[5] = znew;
+        znew = znew_n;
+        uf = uf_n; vf = vf_n; wf = wf_n;
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) rv[s] = rv_n[s];
+        if (kfld) {
+            zk[0] = zk[1]; zk[1] = zk[2]; zk[2] = zk_n;
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) rk[s] = rk_n[s];
+        }
+    }
 }
 
 static int tile_variant()
@@ -665,6 +832,21 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;
+    static const int tracer_direct = (getenv("OCN_TRACER_KERNEL") && !strcmp(getenv("OCN_TRACER_KERNEL"), "direct"));
+    if (!tracer_direct && grid->tz != OCN_FLAT && wx >= 16 && wy >= 8 && wz >= 4) {
+        constexpr int TX = 32, TY = 8;
+        const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+        int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the bottom-flux prologue
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+        dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+        if (grid->tz == OCN_PERIODIC)
+            hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+        else
+            hipLaunchKernelGGL((tracer_tendency_tiled<OCN_BOUNDED, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+        OCN_CHECK_HIP(hipGetLastError());
+        return OCN_SUCCESS;
+    }
     dim3 block(64, 4, 1);
     dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
     switch (grid->tz) {
