@@ -328,25 +328,51 @@ __global__ __launch_bounds__(256) void momentum_extra_tiled(GridDev g, TermsDev 
     const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
     const long long s2 = L.s2, s3 = L.s3;
     const bool has_nu = t.nu_e != nullptr;
-    // stage plane kk (tile + rim, indices clamped to the first halo cell) into ring slot kk % 3
-    auto stage = [&](int kk) {
-        const int slot = kk % 3;
-        for (int idx = tid; idx < PL; idx += TX * TY) {
-            const int li = idx % SX, lj = idx / SX;
-            const int gi = min(i0 - 1 + li, g.Nx + 1), gj = min(j0 - 1 + lj, g.Ny + 1);
-            const long long oo = ocn::at(L, gi, gj, kk);
-            Lu[slot][idx] = u[oo];
-            Lv[slot][idx] = v[oo];
-            Lw[slot][idx] = w[oo];
-            if (has_nu) Ln[slot][idx] = t.nu_e[oo];
+    // Staging of plane kk (tile + rim, indices clamped to the first halo cell) into ring slot kk % 3 is split in two so that the
+    // global loads of plane k+2 are in flight while plane k is being computed: fetch() -> registers, commit() -> LDS.
+    constexpr int NS = (PL + TX * TY - 1) / (TX * TY);  // cells staged per thread (2)
+    long long soff[NS];
+    bool son[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int idx = tid + q * TX * TY;
+        son[q] = idx < PL;
+        const int li = son[q] ? idx % SX : 0, lj = son[q] ? idx / SX : 0;
+        soff[q] = ocn::at(L, min(i0 - 1 + li, g.Nx + 1), min(j0 - 1 + lj, g.Ny + 1), 0);  // plane 0: add kk * s3
+    }
+    double fu[NS], fv[NS], fw[NS], fn[NS];
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const long long oo = soff[q] + (long long)kk * s3;
+            fu[q] = son[q] ? u[oo] : 0.0;
+            fv[q] = son[q] ? v[oo] : 0.0;
+            fw[q] = son[q] ? w[oo] : 0.0;
+            fn[q] = (son[q] && has_nu) ? t.nu_e[oo] : 0.0;
         }
     };
-    stage(kb - 1);
-    stage(kb);
+    auto commit = [&](int kk) {
+        const int slot = kk % 3;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (!son[q]) continue;
+            const int idx = tid + q * TX * TY;
+            Lu[slot][idx] = fu[q];
+            Lv[slot][idx] = fv[q];
+            Lw[slot][idx] = fw[q];
+            if (has_nu) Ln[slot][idx] = fn[q];
+        }
+    };
+    fetch(kb - 1);
+    commit(kb - 1);
+    fetch(kb);
+    commit(kb);
+    fetch(kb + 1);
     const int c0 = (ty + 1) * SX + (tx + 1);
     for (int k = kb; k <= ke; ++k) {
-        stage(k + 1);
+        commit(k + 1);
         __syncthreads();
+        if (k < ke) fetch(k + 2);  // consumed by the next iteration's commit
         if (active) {
             const long long o = ocn::at(L, i, j, k);
             const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
