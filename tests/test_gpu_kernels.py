@@ -249,3 +249,59 @@ def test_tracer_kernel_ragged_sizes_and_fused_entry(oracle, ocn, size, topo, z, 
     ocn.sync_device()
     np.testing.assert_array_equal(from_dev(dGc)[mask], Gc[mask])
     np.testing.assert_array_equal(from_dev(dout)[mask], cnew[mask])
+
+
+@pytest.mark.parametrize("topo,z", [("PPP", (0, 2.0)), ("PPB", "stretched")])
+def test_fused_rk3_ranges_tile_the_full_launch(oracle, ocn, topo, z):
+    """The slab-x interior / buffer split at a production-like width (nx = 64, Hx = 3: interior 4:61 takes the tiled kernel,
+    the two 3-wide buffers the direct one), with the substep epilogue: the three ranged launches of
+    ocn_compute_momentum_tendencies_rk3 reproduce the full launch bit for bit (G and the substepped velocities), and the
+    ranged tracer launches (tiled interior, direct buffers) with everything folded in do too."""
+    import ctypes as C
+    O = oracle
+    rng = np.random.default_rng(77)
+    size = (64, 24, 20)
+    og, pg = _grid(O, ocn, size, topo, z)
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    Gm = [random_parent(og, l, rng) for l in LOCS]
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+    dGm = [to_dev(ocn, pg, l, a) for l, a in zip(LOCS, Gm)]
+    ranges = [None], [(4, 61, 1, 24, 1, 20), (1, 3, 1, 24, 1, 20), (62, 64, 1, 24, 1, 20)]
+    outs = []
+    for rs in ranges:
+        G = [ocn.Field(l, pg) for l in LOCS]
+        Uo = [ocn.Field(l, pg) for l in LOCS]
+        for r in rs:
+            ocn._lib.call("ocn_compute_momentum_tendencies_rk3", pg.cref, du.ptr, dv.ptr, dw.ptr, G[0].ptr, G[1].ptr, G[2].ptr,
+                          dGm[0].ptr, dGm[1].ptr, dGm[2].ptr, Uo[0].ptr, Uo[1].ptr, Uo[2].ptr, 0.05, 5 / 12, -17 / 60, 1, None, 0.0,
+                          None if r is None else ocn._lib.i32_array(list(r)), 0)
+        ocn.sync_device()
+        outs.append([og.interior_N(from_dev(f)) for f in G + Uo])
+    for n, (a, b) in enumerate(zip(*outs)):
+        if topo == "PPB" and n == 2:  # Gw at the wall face k = 1: written by ranged (KernelParameters) launches, excluded by :xyz
+            a, b = a[:, :, 1:], b[:, :, 1:]
+        np.testing.assert_array_equal(a, b)
+    # and against the oracle: G = advection, U_out = U + dt (γ G + ζ G⁻)
+    Gref = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *Gref)
+    for n in range(2):  # u, v (w differs at the wall face, which a ranged launch writes and the serial one excludes)
+        np.testing.assert_array_equal(outs[0][n], og.interior_N(Gref[n]))
+        unew = (u, v)[n].copy(order="F")
+        O.rk3_substep(og, LOCS[n], unew, Gref[n], Gm[n], 0.05, 5 / 12, -17 / 60)
+        np.testing.assert_array_equal(outs[0][3 + n], og.interior_N(unew))
+    # tracer: full vs ranged, with diffusion + substep
+    c, Gmc = random_parent(og, 0, rng), random_parent(og, 0, rng)
+    dc, dGmc = to_dev(ocn, pg, 0, c), to_dev(ocn, pg, 0, Gmc)
+    t = ocn._lib.CModelTerms()
+    t.closure, t.nu = 1, 1e-3
+    touts = []
+    for rs in ranges:
+        Gc, co = ocn.Field(0, pg), ocn.Field(0, pg)
+        for r in rs:
+            ocn._lib.call("ocn_compute_tracer_tendency_terms_rk3", pg.cref, C.byref(t), 2e-3, None, None, du.ptr, dv.ptr, dw.ptr, dc.ptr,
+                          Gc.ptr, dGmc.ptr, co.ptr, 0.05, 5 / 12, -17 / 60, 1, None if r is None else ocn._lib.i32_array(list(r)), 0)
+        ocn.sync_device()
+        touts.append([og.interior_N(from_dev(Gc)), og.interior_N(from_dev(co))])
+    for a, b in zip(*touts):
+        np.testing.assert_array_equal(a, b)
