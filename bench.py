@@ -250,7 +250,11 @@ def main():
                    "grid": [N, N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}", "finite": finite},
         "roofline": {"bound": "hbm", "kernel": "momentum_tendencies (fused compute_Gu/Gv/Gw, WENO5)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL},
+                     "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL,
+                     # SURVEY 8(d) books the reference's three tendency kernels at 3 x (3 r + 1 w) x 8 = 96 B/cell; against that
+                     # accounting (the one step_roofline's 1680 B uses) the same launch reaches:
+                     "frac_at_reference_accounting_96B": 96.0 * local_cells / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "note": "fp64-VALU-bound kernel (~1100 DP instr/cell, 77% VALU issue utilisation): see DESIGN.md section 4"},
         "step_roofline": {"algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
                           "achieved_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,
                           "frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world)},
