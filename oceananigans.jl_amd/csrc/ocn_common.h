@@ -152,4 +152,18 @@ int validate_grid(const ocn_grid *g);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// 256-thread block for a one-thread-per-cell launch over a range wx cells wide: the usual 64 x 4 (one wave = 64 consecutive
+// x), but for the thin x-strips of the distributed buffer tendencies (wx = halo width) 64 lanes along x would leave most of
+// every wave idle, so the block is folded towards y: (pow2 >= wx) x (256 / that).
+inline dim3 range_block(int wx)
+{
+    int bx = 64;
+    while (bx > 4 && bx / 2 >= wx) bx /= 2;
+    return dim3(bx, 256 / bx, 1);
+}
+inline dim3 range_grid(dim3 block, int wx, int wy, int wz)
+{
+    return dim3((wx + block.x - 1) / block.x, (wy + block.y - 1) / block.y, wz);
+}
+
 }  // namespace ocn

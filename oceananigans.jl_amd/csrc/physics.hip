@@ -456,7 +456,7 @@ int launch_momentum_centered2(const ocn_grid *grid, const double *u, const doubl
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(momentum_tendencies_centered2, g, u, v, w, Gu, Gv, Gw, r);
     return OCN_SUCCESS;
 }
@@ -469,7 +469,7 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(tracer_tendency_centered2, g, u, v, w, c, Gc, r);
     return OCN_SUCCESS;
 }
@@ -499,7 +499,7 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
     }
-    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r, mf);
     return OCN_SUCCESS;
 }
@@ -512,7 +512,7 @@ int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *ka
     if (st != OCN_SUCCESS) return st;
     if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(tracer_diffusion_kernel, g, kappa, kappa_e, c, Gc, r);
     return OCN_SUCCESS;
 }

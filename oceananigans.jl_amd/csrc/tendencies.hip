@@ -810,8 +810,7 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         ocn::set_error("pressure correction on load needs the tiled kernel (non-Flat z, range at least 16 x 8 x 4)");
         return OCN_ERR_UNSUPPORTED;
     }
-    dim3 block(64, 4, 1);
-    dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz);
     switch (grid->tz) {
         case OCN_PERIODIC: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r, fz); break;
         case OCN_BOUNDED: hipLaunchKernelGGL(momentum_tendencies_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, Gu, Gv, Gw, r, fz); break;
@@ -847,8 +846,7 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
     }
-    dim3 block(64, 4, 1);
-    dim3 nb((r.i1 - r.i0 + 64) / 64, (r.j1 - r.j0 + 4) / 4, r.k1 - r.k0 + 1);
+    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz);
     switch (grid->tz) {
         case OCN_PERIODIC: hipLaunchKernelGGL(tracer_tendency_direct<OCN_PERIODIC>, nb, block, 0, stream, g, u, v, w, c, Gc, r, tf); break;
         case OCN_BOUNDED: hipLaunchKernelGGL(tracer_tendency_direct<OCN_BOUNDED>, nb, block, 0, stream, g, u, v, w, c, Gc, r, tf); break;

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""What ONE rank of an R-rank slab-x run costs, measured on a single GPU: the real distributed code path (local halo fills,
+pack / unpack, interior / buffer tendency split, distributed transposes and FFTs, all kernels at the rank-local size) with a
+LOOPBACK fabric that emulates R identical ranks -- every message a rank would receive from a neighbour is the one it sends
+itself, which is exactly what R replicas of an x-periodic flow of period Lx/R exchange.  The time it prints is therefore the
+per-rank compute + host time of an R-GPU step with the communication itself replaced by device copies; compare it with
+(single-GPU step) / R to see what the decomposition costs before any link time.
+
+  tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched)
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oceananigans_jl_amd as ocn
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+workload = sys.argv[4] if len(sys.argv) > 4 else "box"
+
+
+class LoopbackFabric:
+    """R identical ranks: recv from `src` = what that rank sent to me = what I send to the mirror-image peer (-src mod R)."""
+
+    def __init__(self, R):
+        self.rank, self.size = 0, R
+
+    def start_exchange(self, sends, recvs):
+        queue = {}
+        for t, dst in sends:
+            queue.setdefault(dst % self.size, []).append(t)
+        for t, src in recvs:
+            t.copy_(queue[(-src) % self.size].pop(0))
+        return ()
+
+    @staticmethod
+    def wait(reqs):
+        pass
+
+    def all_to_all(self, recv, send):
+        n = send.numel() // self.size
+        recv.view(self.size, n).copy_(send[:n].expand(self.size, n))  # chunk m <- rank m's chunk for me = my own chunk 0
+
+    def allreduce_max(self, t):
+        return t
+
+
+ocn.set_math_mode(ocn.MATH_FAST)
+arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=LoopbackFabric(R)) if R > 1 else ocn.GPU()
+P = "Periodic"
+if workload == "config4":
+    Nz = N // 2
+    Lz, refinement, stretching = 32.0, 1.2, 12.0
+    h = lambda k: (k - 1) / Nz
+    z_faces = np.array([Lz * ((1 + (h(k) - 1) / refinement) * ((1 - np.exp(-stretching * h(k))) / (1 - np.exp(-stretching))) - 1)
+                        for k in range(1, Nz + 2)])
+    g = ocn.RectilinearGrid(arch, size=(N, N, Nz), x=(0, 64), y=(0, 64), z=z_faces, topology=(P, P, "Bounded"), halo=(3, 3, 3))
+else:
+    g = ocn.RectilinearGrid(arch, size=(N, N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+for f in m.velocities:
+    v = f.interior_view()
+    v.copy_(2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1)
+ocn.set(m)  # halos + projection
+umax = max(float(f.interior_view().abs().max()) for f in m.velocities)
+dt = 0.1 * g.dx / umax
+for _ in range(3):
+    ocn.time_step(m, dt)
+ocn.sync_device()
+t0 = time.perf_counter()
+for _ in range(steps):
+    ocn.time_step(m, dt)
+ocn.flush_tendencies(m)
+ocn.sync_device()
+ms = (time.perf_counter() - t0) / steps * 1e3
+finite = all(bool(torch.isfinite(f.interior_view()).all()) for f in m.velocities)
+print(f"{workload} N={N} R={R}: local {g.Nx}x{g.Ny}x{g.Nz}, {ms:.2f} ms/step per rank "
+      f"(ideal from one GPU = single-GPU step / {R}), finite={finite}")
