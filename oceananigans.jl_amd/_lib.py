@@ -105,6 +105,7 @@ _SIGS = {
     "ocn_dist_poisson_destroy": [_vp],
     "ocn_dist_poisson_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ocn_dist_poisson_layout": [_vp, C.POINTER(_i32), C.POINTER(C.c_int64), C.POINTER(_i32)],
+    "ocn_dist_poisson_pipeline": [_vp, C.POINTER(_i32)],
     "ocn_dist_poisson_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],
     "ocn_dist_poisson_forward_yz": [_vp, _vp],
     "ocn_dist_poisson_solve_x": [_vp, _vp],

@@ -91,6 +91,70 @@ __device__ __forceinline__ void radix_last(cplx *z)
     }
 }
 
+// Forward stage sequence of one column: x[r] = element t + (N/8) r (natural order) -> x[m] = spectrum at STORED position
+// 8 t + m (stage order, colfft_wavenumber).  A = N*CB exchange buffer [e][c], W = W_N^j table (the first barrier also makes
+// the caller's table writes visible).
+template <int N, int CB>
+__device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, int c, int t)
+{
+    constexpr int T = N / 8, T2 = N / 64;
+    const int q = t / T2, t2 = t % T2;
+    __syncthreads();  // twiddles resident
+    // ---- stage 1: radix-8 over r, twiddle W_N^(t q)
+    radix8<false>(x);
+#pragma unroll
+    for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(t * qq) % N]);
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) A[(qq * T + t) * CB + c] = x[qq];
+    __syncthreads();
+    // ---- stage 2: thread (q, t2) takes A1[q][t2 + T2 r2]
+#pragma unroll
+    for (int r = 0; r < 8; ++r) x[r] = A[(q * T + t2 + T2 * r) * CB + c];
+    radix8<false>(x);
+    if (T2 > 1) {
+#pragma unroll
+        for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(8 * t2 * qq) % N]);
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) A[((q * 8 + qq) * T2 + t2) * CB + c] = x[qq];
+        __syncthreads();
+        // ---- stage 3: thread t owns stored positions p = 8 t .. 8 t + 7 (G groups of T2)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = A[(8 * t + m) * CB + c];
+        radix_last<T2, false>(x);
+    }
+}
+
+// Inverse stage sequence: x[m] at stored position 8 t + m -> x[r] = (unnormalised) element t + (N/8) r in natural order.
+template <int N, int CB>
+__device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, int c, int t)
+{
+    constexpr int T = N / 8, T2 = N / 64;
+    const int q = t / T2, t2 = t % T2;
+    // ---- inverse: conjugate-transpose stage sequence
+    if (T2 > 1) {
+        radix_last<T2, true>(x);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) A[(8 * t + m) * CB + c] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) x[qq] = A[((q * 8 + qq) * T2 + t2) * CB + c];
+#pragma unroll
+        for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(8 * t2 * qq) % N]));
+    }
+    radix8<true>(x);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) A[(q * T + t2 + T2 * r) * CB + c] = x[r];
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) x[qq] = A[(qq * T + t) * CB + c];
+#pragma unroll
+    for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(t * qq) % N]));
+    radix8<true>(x);
+}
+
 struct ColFFTArgs {
     double *data;            // complex interleaved
     long long col_stride;    // elements between consecutive points of one column
@@ -104,6 +168,7 @@ struct ColFFTArgs {
     const double *lc;        // eigenvalue per STORED position along the column (stage order)
     double scale;
     int inner;               // number of kx per ky
+    int zero_mode;           // MODE 2: this launch holds the (0,0,0) mode (column 0 of batch 0, position 0) and zeroes it
 };
 
 // MODE 0: forward (natural -> stage order), 1: inverse (stage order -> natural), 2: forward, spectral solve, inverse
@@ -111,7 +176,6 @@ template <int N, int CB, int MODE>
 __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
 {
     constexpr int T = N / 8;    // threads per column
-    constexpr int T2 = N / 64;  // length of the last stage = R3
     extern __shared__ double lds_raw[];
     cplx *A = reinterpret_cast<cplx *>(lds_raw);          // N * CB exchange buffer, layout [e][c]
     cplx *W = reinterpret_cast<cplx *>(lds_raw) + N * CB;  // twiddle table
@@ -122,35 +186,11 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     const bool active = (col0 + c) < a.ncols;
     cplx *base = reinterpret_cast<cplx *>(a.data) + (long long)batch * a.batch_stride + (col0 + (active ? c : 0));
     cplx x[8];
-    const int q = t / T2, t2 = t % T2;  // stage-2 coordinates of this thread
 
     if (MODE == 0 || MODE == 2) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = active ? base[(long long)(t + T * r) * a.col_stride] : cplx{0, 0};
-        __syncthreads();  // twiddles resident
-        // ---- stage 1: radix-8 over r, twiddle W_N^(t q)
-        radix8<false>(x);
-#pragma unroll
-        for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(t * qq) % N]);
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) A[(qq * T + t) * CB + c] = x[qq];
-        __syncthreads();
-        // ---- stage 2: thread (q, t2) takes A1[q][t2 + T2 r2]
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = A[(q * T + t2 + T2 * r) * CB + c];
-        radix8<false>(x);
-        if (T2 > 1) {
-#pragma unroll
-            for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(8 * t2 * qq) % N]);
-            __syncthreads();
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) A[((q * 8 + qq) * T2 + t2) * CB + c] = x[qq];
-            __syncthreads();
-            // ---- stage 3: thread t owns stored positions p = 8 t .. 8 t + 7 (G groups of T2)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) x[m] = A[(8 * t + m) * CB + c];
-            radix_last<T2, false>(x);
-        }
+        fft_fwd_stages<N, CB>(x, A, W, c, t);
         // x[m] is the spectrum at stored position p = 8 t + m
     } else {
 #pragma unroll
@@ -161,7 +201,7 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     if (MODE == 2) {
         const int col = col0 + c;
         const double lxy = active ? a.lx[col % a.inner] + a.ly[col / a.inner] : 1.0;
-        const bool zero_col = (col == 0) && (batch == 0);
+        const bool zero_col = a.zero_mode && (col == 0) && (batch == 0);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int p = 8 * t + m;
@@ -174,28 +214,7 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     }
 
     if (MODE == 1 || MODE == 2) {
-        // ---- inverse: conjugate-transpose stage sequence
-        if (T2 > 1) {
-            radix_last<T2, true>(x);
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < 8; ++m) A[(8 * t + m) * CB + c] = x[m];
-            __syncthreads();
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) x[qq] = A[((q * 8 + qq) * T2 + t2) * CB + c];
-#pragma unroll
-            for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(8 * t2 * qq) % N]));
-        }
-        radix8<true>(x);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) A[(q * T + t2 + T2 * r) * CB + c] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) x[qq] = A[(qq * T + t) * CB + c];
-#pragma unroll
-        for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(t * qq) % N]));
-        radix8<true>(x);
+        fft_inv_stages<N, CB>(x, A, W, c, t);
         if (active) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) base[(long long)(t + T * r) * a.col_stride] = x[r];
@@ -249,9 +268,9 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
 
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
-                  hipStream_t stream)
+                  hipStream_t stream, int zero_mode)
 {
-    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1};
+    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode};
     switch (N) {
         case 64: return launch_n<64, 16>(mode, a, stream);
         case 128: return launch_n<128, 16>(mode, a, stream);
@@ -263,6 +282,237 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
             return launch_n<512, 8>(mode, a, stream);
         }
         default: set_error("column FFT length %d is not supported (64, 128, 256, 512)", N); return OCN_ERR_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Slab pipeline of the distributed solver (poisson.hip, ocn_dist_poisson "fast" mode): x is partitioned, so the local
+// directions y and z are transformed first -- y as a REAL transform of strided columns, z as a column FFT that writes straight
+// into the all-to-all send layout -- and x after the exchange with the fused FFT -> divide -> IFFT column kernel above.
+//
+//   rhs  real    [xl + nx (y + Ny z)]
+//   A1   complex [ky + NyH (xl + nx z)],  NyH = Ny/2 + 1            (ky fastest: the transposition happens in LDS here)
+//   send complex [d][ky + NyH (pz_l + cz xl)],  stored z position pz = d cz + pz_l, cz = Nz / R   (chunk d goes to rank d)
+//   recv complex [xg S + (ky + NyH pz_l)],  S = NyH cz, xg = r nx + xl    (x is a clean strided column after the exchange)
+// ---------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ int stage_wavenumber(int p)
+{
+    constexpr int T2 = N / 64;
+    if (T2 == 1) return (p / 8) + 8 * (p % 8);
+    const int g = p / T2, q3 = p % T2;
+    return (g / 8) + 8 * (g % 8) + 64 * q3;
+}
+
+struct RealYArgs {
+    const double *rhs;   // forward input
+    double *spec;        // A1 (forward output / inverse input)
+    double *p;           // inverse output: first interior element of the haloed pressure field
+    long long p_s2, p_s3;
+    int nx, Nz;
+    const double *twH;   // W_H^j, j < H
+    const double *twN;   // W_Ny^k, k <= H
+};
+
+// Real FFT of length Ny = 2H along y for CB adjacent x columns of one z plane: z_m = s[2m] + i s[2m+1], complex FFT of length H,
+// split step X[k] = E[k] + W_Ny^k O[k] with E = (Z[k] + conj Z[H-k]) / 2, O = (Z[k] - conj Z[H-k]) / (2i), k = 0..H; the H + 1
+// outputs of a column are written as one contiguous run (ky fastest).
+template <int H, int CB>
+__global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
+{
+    constexpr int T = H / 8, NYH = H + 1, NT = CB * T;
+    extern __shared__ double lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(lds_raw);  // H*CB exchange buffer, then Zs[c][NYH] (natural wavenumbers)
+    cplx *W = A + CB * NYH;
+    cplx *WN = W + H;
+    const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
+    const int col0 = blockIdx.x * CB, z = blockIdx.y;
+    for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
+    for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
+    const bool active = (col0 + c) < a.nx;
+    const double *src = a.rhs + (col0 + (active ? c : 0)) + (long long)a.nx * ((long long)(2 * H) * z);
+    cplx x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const long long m = t + T * r;
+        x[r] = active ? cplx{src[(2 * m) * a.nx], src[(2 * m + 1) * a.nx]} : cplx{0, 0};
+    }
+    fft_fwd_stages<H, CB>(x, A, W, c, t);
+    __syncthreads();  // the exchange buffer is free: reuse it by natural wavenumber
+#pragma unroll
+    for (int m = 0; m < 8; ++m) A[c * NYH + stage_wavenumber<H>(8 * t + m)] = x[m];
+    __syncthreads();
+    cplx *out = reinterpret_cast<cplx *>(a.spec);
+    for (int idx = tid; idx < CB * NYH; idx += NT) {
+        const int cc = idx / NYH, k = idx % NYH;
+        if (col0 + cc >= a.nx) continue;
+        const cplx Zk = A[cc * NYH + (k == H ? 0 : k)], Zc = cconj(A[cc * NYH + ((H - k) % H)]);
+        const cplx E = {0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y)};
+        const cplx D = {0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y)};
+        const cplx O = {D.y, -D.x};  // D / i
+        out[k + (long long)NYH * ((col0 + cc) + (long long)a.nx * z)] = cadd(E, cmul(WN[k], O));
+    }
+}
+
+// Inverse of the above: Hermitian half spectrum (ky fastest) -> real rows of the haloed pressure field (unnormalised: x H).
+template <int H, int CB>
+__global__ __launch_bounds__(CB *(H / 8)) void realfft_y_inv_kernel(RealYArgs a)
+{
+    constexpr int T = H / 8, NYH = H + 1, NT = CB * T;
+    extern __shared__ double lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(lds_raw);
+    cplx *W = A + CB * NYH;
+    cplx *WN = W + H;
+    const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
+    const int col0 = blockIdx.x * CB, z = blockIdx.y;
+    for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
+    for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
+    const cplx *in = reinterpret_cast<const cplx *>(a.spec);
+    for (int idx = tid; idx < CB * NYH; idx += NT) {
+        const int cc = idx / NYH, k = idx % NYH;
+        A[idx] = (col0 + cc < a.nx) ? in[k + (long long)NYH * ((col0 + cc) + (long long)a.nx * z)] : cplx{0, 0};
+    }
+    __syncthreads();
+    cplx x[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = stage_wavenumber<H>(8 * t + m);
+        const cplx Xk = A[c * NYH + k], Xc = cconj(A[c * NYH + (H - k)]);
+        const cplx E = {0.5 * (Xk.x + Xc.x), 0.5 * (Xk.y + Xc.y)};
+        const cplx WO = {0.5 * (Xk.x - Xc.x), 0.5 * (Xk.y - Xc.y)};
+        const cplx O = cmul(cconj(WN[k]), WO);
+        x[m] = cplx{E.x - O.y, E.y + O.x};  // Z[k] = E + i O
+    }
+    __syncthreads();  // A becomes the exchange buffer
+    fft_inv_stages<H, CB>(x, A, W, c, t);
+    if ((col0 + c) < a.nx) {
+        double *dst = a.p + (col0 + c) + a.p_s3 * z;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const long long m = t + T * r;
+            dst[(2 * m) * a.p_s2] = x[r].x;
+            dst[(2 * m + 1) * a.p_s2] = x[r].y;
+        }
+    }
+}
+
+// element address of (column, position along the column) in a two-level layout
+struct ColMap {
+    long long div, hi;   // column:   (col % div) + (col / div) * hi
+    long long pdiv;      // position: (e % pdiv) * s1 + (e / pdiv) * s2
+    long long s1, s2;
+    __device__ __forceinline__ long long at(long long col, long long e) const
+    {
+        return (col % div) + (col / div) * hi + (e % pdiv) * s1 + (e / pdiv) * s2;
+    }
+};
+struct ColIOArgs {
+    const double *in;
+    double *out;
+    ColMap im, om;
+    int ncols;
+    const double *tw;
+};
+
+// Out-of-place column FFT between two layouts.  MODE 0: natural -> stage order, 1: stage order -> natural.
+template <int N, int CB, int MODE>
+__global__ __launch_bounds__(CB *(N / 8)) void colfft_io_kernel(ColIOArgs a)
+{
+    constexpr int T = N / 8;
+    extern __shared__ double lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(lds_raw);
+    cplx *W = A + N * CB;
+    const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
+    const long long col = (long long)blockIdx.x * CB + c;
+    for (int j = tid; j < N; j += CB * T) W[j] = reinterpret_cast<const cplx *>(a.tw)[j];
+    const bool active = col < a.ncols;
+    const cplx *in = reinterpret_cast<const cplx *>(a.in);
+    cplx *out = reinterpret_cast<cplx *>(a.out);
+    const long long cl = active ? col : 0;
+    cplx x[8];
+    if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = active ? in[a.im.at(cl, t + T * r)] : cplx{0, 0};
+        fft_fwd_stages<N, CB>(x, A, W, c, t);
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) out[a.om.at(cl, 8 * t + m)] = x[m];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = active ? in[a.im.at(cl, 8 * t + m)] : cplx{0, 0};
+        __syncthreads();
+        fft_inv_stages<N, CB>(x, A, W, c, t);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) out[a.om.at(cl, t + T * r)] = x[r];
+        }
+    }
+}
+
+template <int H, int CB>
+static int launch_realy(int inverse, const RealYArgs &a, hipStream_t stream)
+{
+    const dim3 grid((a.nx + CB - 1) / CB, a.Nz), block(CB * (H / 8));
+    const size_t lds = (size_t)(CB * (H + 1) + H + (H + 1)) * sizeof(cplx);
+    if (!inverse) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_fwd_kernel<H, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((realfft_y_fwd_kernel<H, CB>), grid, block, lds, stream, a);
+    } else {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_inv_kernel<H, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((realfft_y_inv_kernel<H, CB>), grid, block, lds, stream, a);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+bool realfft_y_supported(int Ny) { return Ny % 2 == 0 && colfft_supported(Ny / 2); }
+
+// real y transform of the slab: forward rhs -> A1, inverse A1 -> p (first interior element, row / plane strides p_s2 / p_s3)
+int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
+                     const double *twH, const double *twN, hipStream_t stream)
+{
+    RealYArgs a{rhs, spec, p, p_s2, p_s3, nx, Nz, twH, twN};
+    switch (Ny / 2) {
+        case 64: return launch_realy<64, 16>(inverse, a, stream);
+        case 128: return launch_realy<128, 16>(inverse, a, stream);
+        case 256: return launch_realy<256, 16>(inverse, a, stream);
+        case 512: return launch_realy<512, 8>(inverse, a, stream);
+        default: set_error("real y transform of length %d is not supported (128, 256, 512, 1024)", Ny); return OCN_ERR_UNSUPPORTED;
+    }
+}
+
+template <int N, int CB>
+static int launch_io_n(int mode, const ColIOArgs &a, hipStream_t stream)
+{
+    const dim3 grid((a.ncols + CB - 1) / CB), block(CB * (N / 8));
+    const size_t lds = (size_t)(N * CB + N) * sizeof(cplx);
+    if (mode == 0) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_io_kernel<N, CB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_io_kernel<N, CB, 0>), grid, block, lds, stream, a);
+    } else {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_io_kernel<N, CB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_io_kernel<N, CB, 1>), grid, block, lds, stream, a);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// z transform of the slab between A1 and the all-to-all layout (see the layout table above); inverse = 0: A1 -> send (stage
+// order in z), 1: send -> A1 (natural z)
+int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream)
+{
+    const long long cz = Nz / R, S = (long long)NyH * cz, plane = (long long)NyH * nx;
+    const long long big = 1LL << 62;
+    const ColMap a1{big, 0, big, plane, 0};                  // col = ky + NyH xl (contiguous), z stride NyH nx
+    const ColMap snd{NyH, S, cz, NyH, S * nx};               // ky + S xl;  (pz % cz) NyH + (pz / cz) S nx
+    ColIOArgs a{in, out, inverse ? snd : a1, inverse ? a1 : snd, (int)plane, tw};
+    switch (Nz) {
+        case 64: return launch_io_n<64, 16>(inverse, a, stream);
+        case 128: return launch_io_n<128, 16>(inverse, a, stream);
+        case 256: return launch_io_n<256, 8>(inverse, a, stream);
+        case 512: return launch_io_n<512, 8>(inverse, a, stream);
+        default: set_error("column FFT length %d is not supported (64, 128, 256, 512)", Nz); return OCN_ERR_UNSUPPORTED;
     }
 }
 

@@ -51,7 +51,12 @@ int colfft_wavenumber(int N, int p);
 std::vector<double> colfft_twiddles(int N);
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
-                  hipStream_t stream);
+                  hipStream_t stream, int zero_mode = 1);
+// slab pipeline of the distributed solver (colfft.hip): real y transform and z transform into / out of the all-to-all layout
+bool realfft_y_supported(int Ny);
+int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
+                     const double *twH, const double *twN, hipStream_t stream);
+int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream);
 // row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p
 bool rowfft_supported(int Nx);
 void rowfft_twiddles(int Nx, std::vector<double> &twM, std::vector<double> &twN);

@@ -538,13 +538,19 @@ struct ocn_dist_poisson {
     double *xsol = nullptr;        // tridiagonal solution (x-local layout)
     double *diag = nullptr, *lower = nullptr, *tscr = nullptr;
     double *dzc = nullptr, *dzf = nullptr;
+    // "fast" slab pipeline (colfft.hip; periodic z): real y transform -> z column FFT writing the all-to-all layout -> exchange ->
+    // fused FFT_x / divide / IFFT_x column kernel -> exchange -> inverse z -> inverse real y into p.  No rocFFT plans, no pack /
+    // unpack passes; yfield aliases recv (the half spectrum A1 lives there between the exchanges' uses of it).
+    bool fast = false;
+    double *tw_h = nullptr, *tw_z = nullptr, *tw_x = nullptr;  // W_{Ny/2}, W_Nz, W_Nxg  (tw_y = W_Ny)
 };
 
 static void free_all(ocn_dist_poisson *s)
 {
     s->fyz.destroy(); s->byz.destroy(); s->fx.destroy(); s->bx.destroy();
+    if (s->fast) s->yfield = nullptr;  // alias of recv
     double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv,
-                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf};
+                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -688,6 +694,41 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
         *out = s;
         return OCN_SUCCESS;
     }
+    {
+        const char *ef = std::getenv("OCN_DIST_POISSON_FAST");
+        s->fast = !force_c2c && s->r2c && !(ef && ef[0] == '0') && R > 1 && ocn::realfft_y_supported(Ny) && ocn::colfft_supported(Nz) &&
+                  ocn::colfft_supported(Nxg) && Nz % R == 0;
+    }
+    if (s->fast) {
+        const int NyH = Ny / 2 + 1;
+        s->nyt = NyH;
+        s->ny = 0;  // the transposed layout is partitioned in (stored) kz, not in ky
+        const size_t n = (size_t)NyH * nx * Nz;
+        TRY_HIP(hipMalloc((void **)&s->rhs, (size_t)nx * Ny * Nz * sizeof(double)));
+        TRY_HIP(hipMemset(s->rhs, 0, (size_t)nx * Ny * Nz * sizeof(double)));
+        for (double **p : {&s->send, &s->recv}) {
+            TRY_HIP(hipMalloc((void **)p, n * 2 * sizeof(double)));
+            TRY_HIP(hipMemset(*p, 0, n * 2 * sizeof(double)));
+        }
+        s->yfield = s->recv;
+        TRY(upload(ocn::colfft_twiddles(Ny / 2), &s->tw_h));
+        TRY(upload(ocn::colfft_twiddles(Ny), &s->tw_y));
+        TRY(upload(ocn::colfft_twiddles(Nz), &s->tw_z));
+        TRY(upload(ocn::colfft_twiddles(Nxg), &s->tw_x));
+        // eigenvalues: ky natural (0..Ny/2); kz and kx by STORED position of the column kernels' stage order
+        std::vector<double> lyn = eigenvalues(Ny, lg->Ly, OCN_PERIODIC), lzn = eigenvalues(Nz, lg->Lz, OCN_PERIODIC),
+                            lxn = eigenvalues(Nxg, global_Lx, OCN_PERIODIC);
+        lyn.resize(NyH);
+        std::vector<double> lzs(Nz), lxs(Nxg);
+        for (int q = 0; q < Nz; ++q) lzs[q] = lzn[ocn::colfft_wavenumber(Nz, q)];
+        for (int q = 0; q < Nxg; ++q) lxs[q] = lxn[ocn::colfft_wavenumber(Nxg, q)];
+        TRY(upload(lyn, &s->ly));
+        TRY(upload(lzs, &s->lz));
+        TRY(upload(lxs, &s->lx));
+        TRY_HIP(hipDeviceSynchronize());
+        *out = s;
+        return OCN_SUCCESS;
+    }
     ocn::GridDev gd = ocn::to_dev(*lg);
     ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -785,6 +826,13 @@ extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int32_t *ny_transpo
     return OCN_SUCCESS;
 }
 
+extern "C" int ocn_dist_poisson_pipeline(ocn_dist_poisson_t s, int32_t *fast)
+{
+    OCN_REQUIRE(s && fast, "ocn_dist_poisson_pipeline: null argument");
+    *fast = s->fast ? 1 : 0;
+    return OCN_SUCCESS;
+}
+
 extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *u, const double *v, const double *w, double dt,
                                             void *stream)
 {
@@ -815,6 +863,12 @@ extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_forward_yz: null solver");
     if (s->tri) return dist_tri_y_transform(s, 0, ocn::as_stream(stream));
+    if (s->fast) {  // rhs -> A1 (in recv) -> send, ready for the exchange
+        const ocn_grid *g = &s->grid;
+        int st = ocn::launch_realfft_y(g->Ny, 0, s->rhs, s->recv, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y, ocn::as_stream(stream));
+        if (st != OCN_SUCCESS) return st;
+        return ocn::launch_colfft_slab_z(g->Nz, 0, s->recv, s->send, s->nx, s->nyt, s->R, s->tw_z, ocn::as_stream(stream));
+    }
     if (s->r2c) return s->fyz.exec(s->rhs, s->yfield, ocn::as_stream(stream));
     return s->fyz.exec(s->yfield, nullptr, ocn::as_stream(stream));
 }
@@ -823,6 +877,13 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_solve_x: null solver");
     hipStream_t stream = ocn::as_stream(stream_);
+    if (s->fast) {  // recv = [xg S + (ky + NyH pz_l)]: FFT_x -> -b / ((λy + λz) + λx), rank 0 zeroes the mean mode -> IFFT_x, in place
+        const int Nz = s->grid.Nz, cz = Nz / s->R, NyH = s->nyt;
+        const long long S = (long long)NyH * cz;
+        const double scale = 1.0 / ((double)(s->grid.Ny / 2) * Nz * s->Nxg);
+        return ocn::launch_colfft(s->Nxg, 2, s->recv, S, 0, (int)S, 1, s->tw_x, s->ly, s->lz + (size_t)s->rank * cz, s->lx, scale, NyH,
+                                  stream, s->rank == 0);
+    }
     int st = s->fx.exec(s->xfield, nullptr, stream);
     if (st != OCN_SUCCESS) return st;
     if (s->tri) {
@@ -851,6 +912,14 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
         int st = dist_tri_y_transform(s, 1, stream);
         if (st != OCN_SUCCESS) return st;
         return ocn::launch_copy_real(&s->grid, s->yfield, p, stream, 0);
+    }
+    if (s->fast) {  // send (after the exchange back) -> A1 (in recv) -> real rows of the local pressure interior
+        const ocn_grid *g = &s->grid;
+        ocn::GridDev gd = ocn::to_dev(*g);
+        ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+        int st = ocn::launch_colfft_slab_z(g->Nz, 1, s->send, s->recv, s->nx, s->nyt, s->R, s->tw_z, stream);
+        if (st != OCN_SUCCESS) return st;
+        return ocn::launch_realfft_y(g->Ny, 1, nullptr, s->recv, p + Lp.o, Lp.s2, Lp.s3, s->nx, g->Nz, s->tw_h, s->tw_y, stream);
     }
     if (s->r2c) {
         ocn::GridDev gd = ocn::to_dev(s->grid);

@@ -295,6 +295,9 @@ class _HipDistPoisson:
                 _lib.call("ocn_dist_poisson_buffers", self._h, *[C.byref(p) for p in ptrs])
                 _lib.call("ocn_dist_poisson_layout", self._h, C.byref(nyt), C.byref(nel), C.byref(r2c))
                 self.nyt, self.r2c = nyt.value, bool(r2c.value)
+        fast = C.c_int32()
+        _lib.call("ocn_dist_poisson_pipeline", self._h, C.byref(fast))
+        self.fast = bool(fast.value)  # slab pipeline: no pack / unpack passes (ocn_hip.h)
         n = nel.value * 2
         # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
         self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
@@ -370,6 +373,14 @@ class DistributedFFTBasedPoissonSolver:
 
     def solve(self, p):
         impl = self.impl
+        if getattr(impl, "fast", False):
+            # slab pipeline of libocn_hip: the transforms read / write the exchange layout themselves
+            impl.forward_yz()
+            self.arch.fabric.all_to_all(impl.recv, impl.send)
+            impl.solve_x()
+            self.arch.fabric.all_to_all(impl.send, impl.recv)
+            impl.backward_yz(p)
+            return p
         impl.forward_yz()
         impl.pack_y_to_x()
         impl.unpack_x_from_y(self._all_to_all())

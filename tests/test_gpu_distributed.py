@@ -137,6 +137,48 @@ def test_distributed_steps_match_single_rank(ocn, R, topo):
 
 
 @pytest.mark.parametrize("R", [2, 4])
+def test_distributed_slab_pipeline_matches_single_rank(ocn, R):
+    """Sizes the library's slab pipeline covers (real y transform, z column FFT into the exchange layout, fused x column
+    kernel; csrc/colfft.hip): the handle must select it, and two RK3 steps must match the single-rank model, whose solver is a
+    different code path (rocFFT or the row / column pipeline)."""
+    P = "Periodic"
+    N = (64, 128, 64)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 4 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(4321)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    dt = 0.005
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
+    sm = ocn.NonhydrostaticModel(sg, advection=ocn.WENO())
+    ocn.set(sm, **init)
+    for _ in range(2):
+        ocn.time_step(sm, dt)
+    ocn.sync_device()
+    ref = [f.interior() for f in sm.velocities] + [sm.pNHS.interior()]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+        assert m.pressure_solver.impl.fast
+        sl = slice(r * g.Nx, (r + 1) * g.Nx)
+        ocn.set(m, **{k: v[sl] for k, v in init.items()})
+        for _ in range(2):
+            ocn.time_step(m, dt)
+        ocn.sync_device()
+        return [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    for r, fields in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "p")):
+            tol = 1e-11 * scale if name != "p" else 1e-10 * max(1.0, np.abs(ref[3]).max())
+            assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}: {np.abs(a - b[sl]).max()}"
+
+
+@pytest.mark.parametrize("R", [2, 4])
 def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R):
     """Config 4's physics (buoyancy, Coriolis, diffusivity, flux / gradient boundary conditions; LES closure replaced by a
     constant ScalarDiffusivity) on R slab-x ranks against the single-rank model: 2 RK3 steps."""
