@@ -312,6 +312,13 @@ int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, doub
                     void *stream);
 int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const double *recv_west, const double *recv_east,
                       void *stream);
+/* The same for a tuple of fields in one launch: the strips of the fields follow one another in the buffers (field q starts at
+ * Hx * sum_{r<q} sy_r sz_r), so the exchange is one message per neighbour for the whole tuple
+ * (fill_halo_regions! of a tuple, src/DistributedComputations/halo_communication.jl:95-128). */
+int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, double *send_west,
+                           double *send_east, void *stream);
+int ocn_halo_unpack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, const double *recv_west,
+                             const double *recv_east, void *stream);
 /* Transposes between the y-local layout (nx, Ny, Nz) and the x-local layout (Nx, ny, Nz) of complex data
  * (src/DistributedComputations/distributed_transpose.jl:25-95), R = number of ranks:
  * pack_y_to_x fills the send buffer (chunk m = j in [m*ny, (m+1)*ny)), unpack_x_from_y reads the received one. */

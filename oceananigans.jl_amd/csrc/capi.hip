@@ -596,6 +596,29 @@ int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const do
     return launch_halo_pack_x(grid, field, loc, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
 }
 
+int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, double *send_west,
+                           double *send_east, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(send_west && send_east, "ocn_halo_pack_x_fields: null buffer");
+    FieldTuple ft;
+    st = make_field_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    return launch_halo_pack_x_fields(grid, ft, send_west, send_east, 0, as_stream(stream));
+}
+int ocn_halo_unpack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, const double *recv_west,
+                             const double *recv_east, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(recv_west && recv_east, "ocn_halo_unpack_x_fields: null buffer");
+    FieldTuple ft;
+    st = make_field_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    return launch_halo_pack_x_fields(grid, ft, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
+}
+
 static int check_transpose(int32_t nx, int32_t Ny, int32_t Nz, int32_t R, const void *a, const void *b)
 {
     OCN_REQUIRE(nx >= 1 && Ny >= 1 && Nz >= 1 && R >= 1, "bad transpose sizes");

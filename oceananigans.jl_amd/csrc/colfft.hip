@@ -305,7 +305,10 @@ __device__ __forceinline__ int stage_wavenumber(int p)
 }
 
 struct RealYArgs {
-    const double *rhs;   // forward input
+    const double *rhs;   // forward input (or NULL: the source term is evaluated from u, v, w)
+    GridDev g;           // fused source term: rhs = divᶜᶜᶜ(u, v, w) / dt  (solve_for_pressure.jl:21-27)
+    const double *u, *v, *w;
+    double dt;
     double *spec;        // A1 (forward output / inverse input)
     double *p;           // inverse output: first interior element of the haloed pressure field
     long long p_s2, p_s3;
@@ -317,7 +320,21 @@ struct RealYArgs {
 // Real FFT of length Ny = 2H along y for CB adjacent x columns of one z plane: z_m = s[2m] + i s[2m+1], complex FFT of length H,
 // split step X[k] = E[k] + W_Ny^k O[k] with E = (Z[k] + conj Z[H-k]) / 2, O = (Z[k] - conj Z[H-k]) / (2i), k = 0..H; the H + 1
 // outputs of a column are written as one contiguous run (ky fastest).
-template <int H, int CB>
+// same expression as kernels.hip div_ccc (x, y Periodic, z Periodic and regular in this pipeline); this file is compiled without
+// FMA contraction overrides, the value agrees with source_term_kernel to rounding
+__device__ __forceinline__ double slab_source(const RealYArgs &a, const Lay &L, int i, int j, int k)
+{
+    const GridDev &g = a.g;
+    const double dzc = g.dz;
+    const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
+    const long long o = at(L, i, j, k);
+    const double dxu = Ax * a.u[o + 1] - Ax * a.u[o];
+    const double dyv = Ay * a.v[o + L.s2] - Ay * a.v[o];
+    const double dzw = Az * a.w[o + L.s3] - Az * a.w[o];
+    return ((1 / (Az * dzc)) * ((dxu + dyv) + dzw)) / a.dt;
+}
+
+template <int H, int CB, bool SRC>
 __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
 {
     constexpr int T = H / 8, NYH = H + 1, NT = CB * T;
@@ -330,12 +347,22 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
     for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
     for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
     const bool active = (col0 + c) < a.nx;
-    const double *src = a.rhs + (col0 + (active ? c : 0)) + (long long)a.nx * ((long long)(2 * H) * z);
     cplx x[8];
+    if (SRC) {
+        const Lay L = make_lay(a.g, OCN_LOC_CCC);  // x, y, z Periodic: one layout for u, v, w
+        const int i = col0 + (active ? c : 0) + 1, k = z + 1;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const long long m = t + T * r;
-        x[r] = active ? cplx{src[(2 * m) * a.nx], src[(2 * m + 1) * a.nx]} : cplx{0, 0};
+        for (int r = 0; r < 8; ++r) {
+            const int m = t + T * r;
+            x[r] = active ? cplx{slab_source(a, L, i, 2 * m + 1, k), slab_source(a, L, i, 2 * m + 2, k)} : cplx{0, 0};
+        }
+    } else {
+        const double *src = a.rhs + (col0 + (active ? c : 0)) + (long long)a.nx * ((long long)(2 * H) * z);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const long long m = t + T * r;
+            x[r] = active ? cplx{src[(2 * m) * a.nx], src[(2 * m + 1) * a.nx]} : cplx{0, 0};
+        }
     }
     fft_fwd_stages<H, CB>(x, A, W, c, t);
     __syncthreads();  // the exchange buffer is free: reuse it by natural wavenumber
@@ -455,9 +482,12 @@ static int launch_realy(int inverse, const RealYArgs &a, hipStream_t stream)
 {
     const dim3 grid((a.nx + CB - 1) / CB, a.Nz), block(CB * (H / 8));
     const size_t lds = (size_t)(CB * (H + 1) + H + (H + 1)) * sizeof(cplx);
-    if (!inverse) {
-        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_fwd_kernel<H, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((realfft_y_fwd_kernel<H, CB>), grid, block, lds, stream, a);
+    if (!inverse && a.rhs) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_fwd_kernel<H, CB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((realfft_y_fwd_kernel<H, CB, false>), grid, block, lds, stream, a);
+    } else if (!inverse) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_fwd_kernel<H, CB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((realfft_y_fwd_kernel<H, CB, true>), grid, block, lds, stream, a);
     } else {
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)realfft_y_inv_kernel<H, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((realfft_y_inv_kernel<H, CB>), grid, block, lds, stream, a);
@@ -470,9 +500,15 @@ bool realfft_y_supported(int Ny) { return Ny % 2 == 0 && colfft_supported(Ny / 2
 
 // real y transform of the slab: forward rhs -> A1, inverse A1 -> p (first interior element, row / plane strides p_s2 / p_s3)
 int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
-                     const double *twH, const double *twN, hipStream_t stream)
+                     const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid, const double *u, const double *v,
+                     const double *w, double dt)
 {
-    RealYArgs a{rhs, spec, p, p_s2, p_s3, nx, Nz, twH, twN};
+    RealYArgs a{rhs, GridDev{}, u, v, w, dt, spec, p, p_s2, p_s3, nx, Nz, twH, twN};
+    if (grid) a.g = to_dev(*grid);
+    if (!inverse && !rhs && !(grid && u && v && w)) {
+        set_error("launch_realfft_y: the forward transform needs either rhs or (grid, u, v, w)");
+        return OCN_ERR_INVALID_ARGUMENT;
+    }
     switch (Ny / 2) {
         case 64: return launch_realy<64, 16>(inverse, a, stream);
         case 128: return launch_realy<128, 16>(inverse, a, stream);

@@ -629,6 +629,49 @@ int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, doubl
     return OCN_SUCCESS;
 }
 
+// All fields of a tuple in one launch (blockIdx.y = field); the strips of the fields follow one another in `west` / `east`, so a
+// halo exchange is ONE message per neighbour.
+struct PackTuple {
+    double *f[MAX_TUPLE];
+    int sx[MAX_TUPLE];
+    long long rows[MAX_TUPLE], off[MAX_TUPLE];
+};
+__global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *__restrict__ west, double *__restrict__ east, int unpack)
+{
+    const int fi = blockIdx.y;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.rows[fi] * Hx) return;
+    const int h = t % Hx;
+    const long long row = t / Hx;
+    double *crow = a.f[fi] + row * a.sx[fi];
+    const long long b = a.off[fi] + t;
+    if (!unpack) {
+        west[b] = crow[Hx + h];
+        east[b] = crow[nx + h];
+    } else {
+        crow[h] = west[b];
+        crow[nx + Hx + h] = east[b];
+    }
+}
+int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    PackTuple a{};
+    long long off = 0, most = 0;
+    for (int q = 0; q < ft.n; ++q) {
+        Lay L = make_lay(g, ft.loc[q]);
+        a.f[q] = ft.f[q];
+        a.sx[q] = L.sx;
+        a.rows[q] = (long long)L.sy * L.sz;
+        a.off[q] = off;
+        off += a.rows[q] * g.Hx;
+        most = a.rows[q] * g.Hx > most ? a.rows[q] * g.Hx : most;
+    }
+    hipLaunchKernelGGL(halo_pack_x_fields_kernel, dim3((unsigned)((most + 255) / 256), ft.n), dim3(256), 0, stream, g.Hx, g.Nx, a, west, east, unpack);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // y-local (nx,Ny,Nz) <-> x-local (Nx = R*nx, ny = Ny/R, Nz), complex.
 // mode 0 pack y->x : send[i + nx*(k + Nz*j)] = y[i,j,k]                          (:38-42)
 // mode 1 unpack x<-y: x[i,j,k] = recv[i' + nx*(k + Nz*j) + m*nx*ny*Nz], i = m*nx+i' (:51-60)

@@ -55,7 +55,9 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
 // slab pipeline of the distributed solver (colfft.hip): real y transform and z transform into / out of the all-to-all layout
 bool realfft_y_supported(int Ny);
 int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
-                     const double *twH, const double *twN, hipStream_t stream);
+                     const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid = nullptr,
+                     const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0);
+int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream);
 int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream);
 // row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p
 bool rowfft_supported(int Nx);

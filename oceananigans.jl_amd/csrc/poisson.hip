@@ -543,6 +543,9 @@ struct ocn_dist_poisson {
     // unpack passes; yfield aliases recv (the half spectrum A1 lives there between the exchanges' uses of it).
     bool fast = false;
     double *tw_h = nullptr, *tw_z = nullptr, *tw_x = nullptr;  // W_{Ny/2}, W_Nz, W_Nxg  (tw_y = W_Ny)
+    // the source term is evaluated inside the real y transform: ocn_dist_poisson_source_term only records its arguments
+    const double *src_u = nullptr, *src_v = nullptr, *src_w = nullptr;
+    double src_dt = 1.0;
 };
 
 static void free_all(ocn_dist_poisson *s)
@@ -838,6 +841,11 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
 {
     OCN_REQUIRE(s && u && v && w, "ocn_dist_poisson_source_term: null argument");
     const ocn_grid *g = &s->grid;
+    if (s->fast) {
+        static const bool fused = !(std::getenv("OCN_DIST_FUSED_SOURCE") && std::getenv("OCN_DIST_FUSED_SOURCE")[0] == '0');
+        s->src_u = fused ? u : nullptr; s->src_v = v; s->src_w = w; s->src_dt = dt;
+        if (fused) return OCN_SUCCESS;  // evaluated by forward_yz from the same (unchanged) velocity arrays
+    }
     // _fourier_tridiagonal_source_term! (solve_for_pressure.jl:33-38): rhs = Δzᶜ div(U) / Δt, complex
     if (s->tri) return ocn::launch_source_term(g, u, v, w, dt, 2, s->yfield, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     if (s->r2c) return ocn::launch_source_term(g, u, v, w, dt, 3, s->rhs, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
@@ -865,7 +873,9 @@ extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
     if (s->tri) return dist_tri_y_transform(s, 0, ocn::as_stream(stream));
     if (s->fast) {  // rhs -> A1 (in recv) -> send, ready for the exchange
         const ocn_grid *g = &s->grid;
-        int st = ocn::launch_realfft_y(g->Ny, 0, s->rhs, s->recv, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y, ocn::as_stream(stream));
+        int st = s->src_u ? ocn::launch_realfft_y(g->Ny, 0, nullptr, s->recv, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y,
+                                                   ocn::as_stream(stream), g, s->src_u, s->src_v, s->src_w, s->src_dt)
+                          : ocn::launch_realfft_y(g->Ny, 0, s->rhs, s->recv, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y, ocn::as_stream(stream));
         if (st != OCN_SUCCESS) return st;
         return ocn::launch_colfft_slab_z(g->Nz, 0, s->recv, s->send, s->nx, s->nyt, s->R, s->tw_z, ocn::as_stream(stream));
     }

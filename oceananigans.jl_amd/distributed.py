@@ -90,6 +90,14 @@ class HipOps:
     def unpack_x(self, grid, f, west, east):
         _lib.call("ocn_halo_unpack_x", grid.cref, f.ptr, f.loc, west.data_ptr(), east.data_ptr(), stream_ptr())
 
+    def pack_x_fields(self, grid, fields, west, east):
+        _lib.call("ocn_halo_pack_x_fields", grid.cref, _lib.ptr_array([f.ptr for f in fields]), _lib.i32_array([f.loc for f in fields]),
+                  len(fields), west.data_ptr(), east.data_ptr(), stream_ptr())
+
+    def unpack_x_fields(self, grid, fields, west, east):
+        _lib.call("ocn_halo_unpack_x_fields", grid.cref, _lib.ptr_array([f.ptr for f in fields]), _lib.i32_array([f.loc for f in fields]),
+                  len(fields), west.data_ptr(), east.data_ptr(), stream_ptr())
+
     def sync(self):
         torch.cuda.current_stream().synchronize()
 
@@ -124,14 +132,20 @@ class Distributed:
         return f"Distributed({self.child_architecture}, rank {self.local_rank} of {self.partition.x})"
 
     # ---- halo communication ------------------------------------------------------------------
-    def _halo_buffers(self, f):
-        key = (f.ptr, f.loc)
+    def _halo_buffers(self, fields):
+        """(send_w, send_e, recv_w, recv_e) for the whole tuple -- the strips of the fields follow one another, so that the exchange
+        is one message per neighbour -- and each field's (offset, length) inside them."""
+        key = tuple((f.ptr, f.loc) for f in fields)
         b = self._buffers.get(key)
         if b is None:
-            g = f.grid
-            sx, sy, sz = g.parent_shape(f.loc)
-            n = g.Hx * sy * sz  # OneDBuffers: full cross-section, corners travel with the sides (:70-75)
-            b = tuple(self.ops.new_buffer(self, n) for _ in range(4))  # send_w, send_e, recv_w, recv_e
+            g = fields[0].grid
+            spans, off = [], 0
+            for f in fields:
+                sx, sy, sz = g.parent_shape(f.loc)
+                n = g.Hx * sy * sz  # OneDBuffers: full cross-section, corners travel with the sides (:70-75)
+                spans.append((off, n))
+                off += n
+            b = (tuple(self.ops.new_buffer(self, off) for _ in range(4)), tuple(spans))
             self._buffers[key] = b
         return b
 
@@ -140,20 +154,21 @@ class Distributed:
         g = fields[0].grid
         if self.partition.x == 1:
             return None
-        sends, recvs = [], []
-        for f in fields:
-            sw, se, rw, re = self._halo_buffers(f)
-            self.ops.pack_x(g, f, sw, se)
+        fields = tuple(fields)
+        (sw, se, rw, re), spans = self._halo_buffers(fields)
+        if hasattr(self.ops, "pack_x_fields"):
+            self.ops.pack_x_fields(g, fields, sw, se)
+        else:
+            for f, (o, n) in zip(fields, spans):
+                self.ops.pack_x(g, f, sw[o:o + n], se[o:o + n])
         # (the reference calls sync_device! before posting MPI messages, halo_communication.jl:272, 303; torch.distributed
         #  collectives are ordered after the current stream's work, so no host synchronisation is needed here)
-        for f in fields:
-            sw, se, rw, re = self._halo_buffers(f)
-            # my west strip becomes the west neighbour's east halo, and vice versa.  Receives are posted in the
-            # order (from east, from west) so that with R = 2 (both neighbours the same peer) they pair up with
-            # the peer's (west, east) sends.
-            sends += [(sw, self.west_rank), (se, self.east_rank)]
-            recvs += [(rw, self.west_rank), (re, self.east_rank)] if self.partition.x > 2 else [(re, self.east_rank), (rw, self.west_rank)]
-        self._pending = (self.fabric.start_exchange(sends, recvs), tuple(fields))
+        # my west strip becomes the west neighbour's east halo, and vice versa.  With R = 2 both neighbours are the same
+        # peer: receives are then posted in the order (from east, from west) so that they pair up with the peer's
+        # (west, east) sends.
+        sends = [(sw, self.west_rank), (se, self.east_rank)]
+        recvs = [(rw, self.west_rank), (re, self.east_rank)] if self.partition.x > 2 else [(re, self.east_rank), (rw, self.west_rank)]
+        self._pending = (self.fabric.start_exchange(sends, recvs), fields)
         return self._pending
 
     def finish_halo_exchange(self):
@@ -163,9 +178,12 @@ class Distributed:
         reqs, fields = self._pending
         self.fabric.wait(reqs)
         g = fields[0].grid
-        for f in fields:
-            sw, se, rw, re = self._halo_buffers(f)
-            self.ops.unpack_x(g, f, rw, re)
+        (sw, se, rw, re), spans = self._halo_buffers(fields)
+        if hasattr(self.ops, "unpack_x_fields"):
+            self.ops.unpack_x_fields(g, fields, rw, re)
+        else:
+            for f, (o, n) in zip(fields, spans):
+                self.ops.unpack_x(g, f, rw[o:o + n], re[o:o + n])
         self._pending = None
 
     def fill_halo_regions(self, fields, fbnv=True):

@@ -72,8 +72,9 @@ t0 = time.perf_counter()
 for _ in range(steps):
     ocn.time_step(m, dt)
 ocn.flush_tendencies(m)
+host_ms = (time.perf_counter() - t0) / steps * 1e3  # time to ENQUEUE the steps: close to ms/step means launch-bound
 ocn.sync_device()
 ms = (time.perf_counter() - t0) / steps * 1e3
 finite = all(bool(torch.isfinite(f.interior_view()).all()) for f in m.velocities)
 print(f"{workload} N={N} R={R}: local {g.Nx}x{g.Ny}x{g.Nz}, {ms:.2f} ms/step per rank "
-      f"(ideal from one GPU = single-GPU step / {R}), finite={finite}")
+      f"(host enqueue {host_ms:.2f} ms; ideal from one GPU = single-GPU step / {R}), finite={finite}")
