@@ -524,35 +524,93 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int Nx, int Ny, int Nz, c
     const long long s3 = (long long)Nx * Ny;
     const long long o = i + (long long)Nx * j;
     const double tiny = 10 * 2.220446049250313e-16;
+    // The sweep is a serial recurrence, but its operands (b, f going up; t, phi going down) do not depend on it: they are
+    // requested PF planes ahead so that the memory latency is paid once per PF planes instead of once per plane (a slab of a
+    // distributed run has too few columns to hide it with occupancy).
+    constexpr int PF = 8;
     double beta = b[o];
     double2 prev = f[o];
     prev.x = prev.x / beta;
     prev.y = prev.y / beta;
     phi[o] = prev;
-    for (int k = 1; k < Nz; ++k) {
-        const double ck = c[k - 1], ak = a[k - 1], bk = b[o + k * s3];
-        const double tk = ck / beta;
-        t[o + k * s3] = tk;
-        beta = bk - ak * tk;
-        const bool dd = fabs(beta) > tiny;
-        const double2 fk = f[o + k * s3];
-        double2 star;
-        star.x = (fk.x - ak * prev.x) / beta;
-        star.y = (fk.y - ak * prev.y) / beta;
-        if (dd) {
-            phi[o + k * s3] = star;
-            prev = star;
-        } else {
-            prev = phi[o + k * s3];  // keep what storage held (batched_tridiagonal_solver.jl:224-228)
+    double bq[PF];
+    double2 fq[PF];
+#pragma unroll
+    for (int m = 0; m < PF; ++m) {
+        const int k = 1 + m;
+        bq[m] = (k < Nz) ? b[o + k * s3] : 1.0;
+        fq[m] = (k < Nz) ? f[o + k * s3] : make_double2(0.0, 0.0);
+    }
+    for (int k0 = 1; k0 < Nz; k0 += PF) {
+        double bn[PF];
+        double2 fn[PF];
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {  // next block's operands
+            const int k = k0 + PF + m;
+            bn[m] = (k < Nz) ? b[o + k * s3] : 1.0;
+            fn[m] = (k < Nz) ? f[o + k * s3] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            const int k = k0 + m;
+            if (k < Nz) {
+                const double ck = c[k - 1], ak = a[k - 1], bk = bq[m];
+                const double tk = ck / beta;
+                t[o + k * s3] = tk;
+                beta = bk - ak * tk;
+                const bool dd = fabs(beta) > tiny;
+                const double2 fk = fq[m];
+                double2 star;
+                star.x = (fk.x - ak * prev.x) / beta;
+                star.y = (fk.y - ak * prev.y) / beta;
+                if (dd) {
+                    phi[o + k * s3] = star;
+                    prev = star;
+                } else {
+                    prev = phi[o + k * s3];  // keep what storage held (batched_tridiagonal_solver.jl:224-228)
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            bq[m] = bn[m];
+            fq[m] = fn[m];
         }
     }
-    for (int k = Nz - 2; k >= 0; --k) {
-        const double tk = t[o + (k + 1) * s3];
-        double2 cur = phi[o + k * s3];
-        cur.x -= tk * prev.x;
-        cur.y -= tk * prev.y;
-        phi[o + k * s3] = cur;
-        prev = cur;
+    // back substitution, same prefetch distance (t and phi were written by this thread: visible to it in program order)
+    double tq[PF];
+    double2 pq[PF];
+#pragma unroll
+    for (int m = 0; m < PF; ++m) {
+        const int k = Nz - 2 - m;
+        tq[m] = (k >= 0) ? t[o + (k + 1) * s3] : 0.0;
+        pq[m] = (k >= 0) ? phi[o + k * s3] : make_double2(0.0, 0.0);
+    }
+    for (int k0 = Nz - 2; k0 >= 0; k0 -= PF) {
+        double tn[PF];
+        double2 pn[PF];
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            const int k = k0 - PF - m;
+            tn[m] = (k >= 0) ? t[o + (k + 1) * s3] : 0.0;
+            pn[m] = (k >= 0) ? phi[o + k * s3] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            const int k = k0 - m;
+            if (k >= 0) {
+                double2 cur = pq[m];
+                cur.x -= tq[m] * prev.x;
+                cur.y -= tq[m] * prev.y;
+                phi[o + k * s3] = cur;
+                prev = cur;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < PF; ++m) {
+            tq[m] = tn[m];
+            pq[m] = pn[m];
+        }
     }
 }
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
