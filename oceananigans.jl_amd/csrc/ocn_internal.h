@@ -63,7 +63,8 @@ int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int
 bool rowfft_supported(int Nx);
 void rowfft_twiddles(int Nx, std::vector<double> &twM, std::vector<double> &twN);
 int launch_rowfft(const ocn_grid *grid, int inverse, const double *u, const double *v, const double *w, const double *real_in,
-                  double dt, double *spec, double *p, const double *twM, const double *twN, double scale, hipStream_t stream);
+                  double dt, double *spec, double *p, const double *twM, const double *twN, double scale, hipStream_t stream,
+                  int scale_dz = 0);
 int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream);
 int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src, double *dst, hipStream_t stream);
 

@@ -130,6 +130,7 @@ struct ocn_poisson {
     double *tw = nullptr, *lz_stage = nullptr;
     bool custom_xy = false;     // x passes by rowfft.hip (fused with the source term / the write into p), y passes by colfft.hip
     double *twMx = nullptr, *twNx = nullptr, *twy = nullptr, *ly_stage = nullptr;
+    bool custom_tri = false;    // Fourier-tridiagonal flavour of custom_xy: row / column kernels for (x, y), Thomas sweep in z, no rocFFT
     bool source_in_rhs = false; // custom_xy: the source was given as a real array (set_source_term!) and still needs its x transform
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
@@ -218,7 +219,22 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
         std::vector<double> low(Nz > 1 ? Nz - 1 : 1, 0.0);
         for (int q = 2; q <= Nz; ++q) low[q - 2] = 1 / hf[q + Hz - 1];
         TRY(upload(low, &s->lower));
-        TRY(ocn::launch_main_diagonal(&s->grid, s->nxh, s->lx, s->ly, s->diag, nullptr));
+        {
+            const char *e = std::getenv("OCN_POISSON_CUSTOM_XY");
+            s->custom_tri = !s->c2c && ocn::rowfft_supported(Nx) && ocn::colfft_supported(Ny) && Nz > 1 && !(e && e[0] == '0');
+        }
+        if (s->custom_tri) {  // ky stays in the column kernel's stage order between its two passes: permuted eigenvalues
+            std::vector<double> a, b;
+            ocn::rowfft_twiddles(Nx, a, b);
+            TRY(upload(a, &s->twMx));
+            TRY(upload(b, &s->twNx));
+            TRY(upload(ocn::colfft_twiddles(Ny), &s->twy));
+            std::vector<double> lyn = eigenvalues(Ny, grid->Ly, grid->ty), lys(Ny);
+            for (int p = 0; p < Ny; ++p) lys[p] = lyn[ocn::colfft_wavenumber(Ny, p)];
+            TRY(upload(lys, &s->ly_stage));
+            s->custom_xy = true;
+        }
+        TRY(ocn::launch_main_diagonal(&s->grid, s->nxh, s->lx, s->custom_tri ? s->ly_stage : s->ly, s->diag, nullptr));
     }
 
     // Layout of the pressure field interior as an FFT output (r2c path): strides (1, sx, sx*sy)
@@ -236,9 +252,9 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
     }
     {
         const char *e = std::getenv("OCN_POISSON_CUSTOM_XY");
-        s->custom_xy = s->fused_z && ocn::rowfft_supported(Nx) && ocn::colfft_supported(Ny) && !(e && e[0] == '0');
+        s->custom_xy = s->custom_tri || (s->fused_z && ocn::rowfft_supported(Nx) && ocn::colfft_supported(Ny) && !(e && e[0] == '0'));
     }
-    if (s->custom_xy) {
+    if (s->custom_xy && !s->custom_tri) {
         std::vector<double> a, b;
         ocn::rowfft_twiddles(Nx, a, b);
         TRY(upload(a, &s->twMx));
@@ -248,6 +264,7 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
         for (int p = 0; p < Ny; ++p) lys[p] = lyn[ocn::colfft_wavenumber(Ny, p)];  // y is kept in stage order between its two passes
         TRY(upload(lys, &s->ly_stage));
     }
+    if (!s->custom_tri) {
     const int fft_dims = (s->kind == 0 && grid->tz == OCN_PERIODIC && !s->fused_z) ? 3 : 2;
     const size_t batch = (fft_dims == 3) ? 1 : (size_t)Nz;
     const size_t len[3] = {(size_t)Nx, (size_t)Ny, (size_t)Nz};
@@ -281,6 +298,7 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
             TRY(make_plan(s->bwd, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, fft_dims, len, batch,
                           rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, cstr, cdist, rstr, rdist, scale));
         }
+    }
     }
 #undef TRY
 #undef TRY_HIP
@@ -406,7 +424,8 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     const ocn_grid *g = &s->grid;
     int st;
     if (s->custom_xy) {  // K8 fused with the forward x transform: the divergence goes straight into the half spectrum
-        st = ocn::launch_rowfft(g, 0, u, v, w, nullptr, dt, s->spec, nullptr, s->twMx, s->twNx, 1.0, ocn::as_stream(stream));
+        st = ocn::launch_rowfft(g, 0, u, v, w, nullptr, dt, s->spec, nullptr, s->twMx, s->twNx, 1.0, ocn::as_stream(stream),
+                                s->custom_tri ? 1 : 0);
         s->source_in_rhs = false;
         s->source_set = (st == OCN_SUCCESS);
         return st;
@@ -460,6 +479,17 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
         // FFT_y (stage order out) -> FFT_z + solve + IFFT_z -> IFFT_y -> inverse x transform into the rows of p
         st = ocn::launch_colfft(g->Ny, 0, s->spec, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
         if (st != OCN_SUCCESS) return st;
+        if (s->custom_tri) {  // ... -> Thomas sweep in z (diagonal built with the stage-ordered λy) + zero-mean gauge -> IFFT_y -> x
+            st = ocn::launch_tridiag_z(s->nxh, g->Ny, g->Nz, s->lower, s->diag, s->lower, s->spec, s->tscr, s->spec2, stream);
+            if (st != OCN_SUCCESS) return st;
+            st = ocn::launch_remove_mean_mode(plane, g->Nz, s->spec2, stream);  // column (kx, ky position) = (0, 0) is wavenumber (0, 0)
+            if (st != OCN_SUCCESS) return st;
+            st = ocn::launch_colfft(g->Ny, 1, s->spec2, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
+            if (st != OCN_SUCCESS) return st;
+            // the packed real inverse returns (Nx/2) x; y contributes Ny
+            return ocn::launch_rowfft(g, 1, nullptr, nullptr, nullptr, nullptr, 1.0, s->spec2, p, s->twMx, s->twNx,
+                                      2.0 / ((double)g->Nx * g->Ny), stream);
+        }
         st = ocn::launch_colfft(g->Nz, 2, s->spec, plane, 0, (int)plane, 1, s->tw, s->lx, s->ly_stage, s->lz_stage,
                                 1.0 / ((double)g->Nx * g->Ny * g->Nz), s->nxh, stream);
         if (st != OCN_SUCCESS) return st;

@@ -137,6 +137,7 @@ struct RowFFTArgs {
     const double *twN;        // exp(-2 pi i k / (2M)), k <= M   (split / merge factors)
     long long nrows;          // Ny * Nz
     double scale;             // inverse: applied to the output
+    int scale_dz;             // source mode: rhs = (Δzᶜ div) / dt, the Fourier-tridiagonal form (solve_for_pressure.jl:33-38)
 };
 
 // ---- forward: rows of div(u,v,w)/dt -> half spectrum ------------------------------------------------------------------
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(RB *(M / 8)) void rowfft_source_r2c_kernel(RowFFTAr
         }
         const double d0 = rV * (((Ax * u1 - Ax * u0) + (Ay * v10 - Ay * v00)) + dw0);
         const double d1 = rV * (((Ax * u2 - Ax * u1) + (Ay * v11 - Ay * v01)) + dw1);
-        x[r] = active ? cplx{d0 / a.dt, d1 / a.dt} : cplx{0, 0};
+        x[r] = active ? (a.scale_dz ? cplx{(dzc * d0) / a.dt, (dzc * d1) / a.dt} : cplx{d0 / a.dt, d1 / a.dt}) : cplx{0, 0};
     }
     } else {
 #pragma unroll
@@ -292,9 +293,11 @@ static int launch_m(int inverse, const RowFFTArgs &a, hipStream_t stream)
 }
 
 int launch_rowfft(const ocn_grid *grid, int inverse, const double *u, const double *v, const double *w, const double *real_in,
-                  double dt, double *spec, double *p, const double *twM, const double *twN, double scale, hipStream_t stream)
+                  double dt, double *spec, double *p, const double *twM, const double *twN, double scale, hipStream_t stream,
+                  int scale_dz)
 {
     RowFFTArgs a;
+    a.scale_dz = scale_dz;
     a.g = to_dev(*grid);
     a.u = u; a.v = v; a.w = w; a.real_in = real_in; a.dt = dt; a.spec = spec; a.p = p; a.twM = twM; a.twN = twN;
     a.nrows = (long long)grid->Ny * grid->Nz;

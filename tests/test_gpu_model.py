@@ -23,6 +23,8 @@ POISSON_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi)),
                  ((16, 12, 10), "PPB", (-1.0, 0.0)),
                  ((16, 12, 9), "PPB", "stretched"),
                  ((11, 7, 9), "PPB", "stretched"),
+                 ((128, 64, 12), "PPB", "stretched"),  # row / column kernels for (x, y) + Thomas sweep, no rocFFT
+                 ((256, 128, 9), "PPB", (-2.0, 0.0)),
                  ((24, 16, 1), "PPF", None)]
 
 
@@ -52,6 +54,8 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
     if topo == "PPP":
         assert bool(solver.info()["direct_out"] & 2) == (size[2] in (64, 128, 256, 512))  # fused z kernel in use
         assert bool(solver.info()["direct_out"] & 4) == (size[0] in (128, 256) and size[1] in (64, 128))  # custom x, y passes
+    if topo == "PPB":
+        assert bool(solver.info()["direct_out"] & 4) == (size[0] in (128, 256) and size[1] in (64, 128))
     ocn.solve_for_pressure(phi, solver, 1.0, (du, dv, dw))
     ocn.fill_halo_regions(phi)
     ocn.sync_device()
