@@ -344,9 +344,12 @@ int ocn_dist_poisson_buffers(ocn_dist_poisson_t solver, double **yfield, double 
 /* y extent of the transposed complex data (Ny, or Ny/2+1 padded to a multiple of nranks when real-to-complex transforms
  * are in use), the number of complex elements of each of the four buffers, and whether r2c is active */
 int ocn_dist_poisson_layout(ocn_dist_poisson_t solver, int32_t *ny_transposed, int64_t *complex_elements, int32_t *r2c);
-/* fast != 0: the handle runs the slab pipeline (no pack / unpack passes): forward_yz leaves the all-to-all payload in `send`;
- * exchange send -> recv; solve_x works in place on `recv`; exchange recv -> send; backward_yz reads `send`.  The payload is
- * partitioned by stored kz position (Nz / nranks per rank), chunk d of `send` going to rank d. */
+/* fast != 0: the handle runs the slab pipeline (no pack / unpack passes): forward_yz leaves the all-to-all payload in `send`
+ * (chunk d goes to rank d); exchange send -> recv; then
+ *   fast == 1 (periodic z): solve_x works in place on `recv`; exchange recv -> send; backward_yz reads `send`
+ *             (payload partitioned by stored kz position, Nz / nranks per rank);
+ *   fast == 2 (Bounded z, Fourier-tridiagonal): solve_x reads `recv` and leaves the solution in `send`; exchange send -> recv
+ *             again; backward_yz reads `recv` (payload partitioned by ky, ceil((Ny/2+1) / nranks) per rank, zero padded). */
 int ocn_dist_poisson_pipeline(ocn_dist_poisson_t solver, int32_t *fast);
 int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w, double dt,
                                  void *stream);

@@ -315,23 +315,34 @@ struct RealYArgs {
     int nx, Nz;
     const double *twH;   // W_H^j, j < H
     const double *twN;   // W_Ny^k, k <= H
+    // layout of the half spectrum: kc == 0: A1[ky + NyH (xl + nx z)];  kc > 0 (tridiagonal flavour, partitioned by ky in R chunks
+    // of kc): [(ky / kc) chunk + (ky % kc) + kc (z + Nz xl)], i.e. the all-to-all layout itself
+    int kc;
+    long long chunk;
+    int scale_dz;        // source term times Δzᶜ (solve_for_pressure.jl:33-38)
+    double scale;        // inverse: applied to the real output
+    __device__ __forceinline__ long long spec_at(int k, int xl, int z, int NYH) const
+    {
+        if (kc == 0) return k + (long long)NYH * (xl + (long long)nx * z);
+        return (long long)(k / kc) * chunk + (k % kc) + (long long)kc * (z + (long long)Nz * xl);
+    }
 };
 
 // Real FFT of length Ny = 2H along y for CB adjacent x columns of one z plane: z_m = s[2m] + i s[2m+1], complex FFT of length H,
 // split step X[k] = E[k] + W_Ny^k O[k] with E = (Z[k] + conj Z[H-k]) / 2, O = (Z[k] - conj Z[H-k]) / (2i), k = 0..H; the H + 1
 // outputs of a column are written as one contiguous run (ky fastest).
-// same expression as kernels.hip div_ccc (x, y Periodic, z Periodic and regular in this pipeline); this file is compiled without
-// FMA contraction overrides, the value agrees with source_term_kernel to rounding
+// same expression as kernels.hip div_ccc / source_term_kernel (x, y Periodic; every field shares one set of strides)
 __device__ __forceinline__ double slab_source(const RealYArgs &a, const Lay &L, int i, int j, int k)
 {
     const GridDev &g = a.g;
-    const double dzc = g.dz;
+    const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
     const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
     const long long o = at(L, i, j, k);
     const double dxu = Ax * a.u[o + 1] - Ax * a.u[o];
     const double dyv = Ay * a.v[o + L.s2] - Ay * a.v[o];
     const double dzw = Az * a.w[o + L.s3] - Az * a.w[o];
-    return ((1 / (Az * dzc)) * ((dxu + dyv) + dzw)) / a.dt;
+    const double d = (1 / (Az * dzc)) * ((dxu + dyv) + dzw);
+    return a.scale_dz ? (dzc * d) / a.dt : d / a.dt;
 }
 
 template <int H, int CB, bool SRC>
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
         const cplx E = {0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y)};
         const cplx D = {0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y)};
         const cplx O = {D.y, -D.x};  // D / i
-        out[k + (long long)NYH * ((col0 + cc) + (long long)a.nx * z)] = cadd(E, cmul(WN[k], O));
+        out[a.spec_at(k, col0 + cc, z, NYH)] = cadd(E, cmul(WN[k], O));
     }
 }
 
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_inv_kernel(RealYArgs a)
     const cplx *in = reinterpret_cast<const cplx *>(a.spec);
     for (int idx = tid; idx < CB * NYH; idx += NT) {
         const int cc = idx / NYH, k = idx % NYH;
-        A[idx] = (col0 + cc < a.nx) ? in[k + (long long)NYH * ((col0 + cc) + (long long)a.nx * z)] : cplx{0, 0};
+        A[idx] = (col0 + cc < a.nx) ? in[a.spec_at(k, col0 + cc, z, NYH)] : cplx{0, 0};
     }
     __syncthreads();
     cplx x[8];
@@ -417,8 +428,8 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_inv_kernel(RealYArgs a)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const long long m = t + T * r;
-            dst[(2 * m) * a.p_s2] = x[r].x;
-            dst[(2 * m + 1) * a.p_s2] = x[r].y;
+            dst[(2 * m) * a.p_s2] = x[r].x * a.scale;
+            dst[(2 * m + 1) * a.p_s2] = x[r].y * a.scale;
         }
     }
 }
@@ -501,9 +512,9 @@ bool realfft_y_supported(int Ny) { return Ny % 2 == 0 && colfft_supported(Ny / 2
 // real y transform of the slab: forward rhs -> A1, inverse A1 -> p (first interior element, row / plane strides p_s2 / p_s3)
 int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
                      const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid, const double *u, const double *v,
-                     const double *w, double dt)
+                     const double *w, double dt, int kc, long long chunk, int scale_dz, double scale)
 {
-    RealYArgs a{rhs, GridDev{}, u, v, w, dt, spec, p, p_s2, p_s3, nx, Nz, twH, twN};
+    RealYArgs a{rhs, GridDev{}, u, v, w, dt, spec, p, p_s2, p_s3, nx, Nz, twH, twN, kc, chunk, scale_dz, scale};
     if (grid) a.g = to_dev(*grid);
     if (!inverse && !rhs && !(grid && u && v && w)) {
         set_error("launch_realfft_y: the forward transform needs either rhs or (grid, u, v, w)");

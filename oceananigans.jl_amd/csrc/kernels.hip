@@ -491,38 +491,46 @@ int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *
 // Fourier-tridiagonal pieces
 // ---------------------------------------------------------------------------------------------------
 // K15 compute_main_diagonal! ZDirection (fourier_tridiagonal_poisson_solver.jl:41-51); nxh stored x modes
-__global__ void main_diagonal_kernel(GridDev g, int nxh, const double *__restrict__ lx, const double *__restrict__ ly,
-                                     double *__restrict__ D)
+// D[i + sj j + sk (k-1)], i < ni, j < nj: the single-GPU layout is (sj, sk) = (nxh, nxh Ny); the slab pipeline of the distributed
+// solver stores (ky_local, kx, z) with (sj, sk) = (c Nz, c)
+__global__ void main_diagonal_kernel(GridDev g, int ni, int nj, long long sj, long long sk, const double *__restrict__ lx,
+                                     const double *__restrict__ ly, double *__restrict__ D)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-    if (i >= nxh) return;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)ni * nj) return;
+    const int i = (int)(q % ni), j = (int)(q / ni);
     const double lam = lx[i] + ly[j];
     const int Nz = g.Nz;
-    const long long s3 = (long long)nxh * g.Ny;
-    double *d = D + i + (long long)nxh * j;
+    double *d = D + i + sj * j;
     d[0] = -1 / dzF(g, 2) - dzC(g, 1) * lam;
-    for (int k = 2; k <= Nz - 1; ++k) d[(k - 1) * s3] = -(1 / dzF(g, k + 1) + 1 / dzF(g, k)) - dzC(g, k) * lam;
-    d[(Nz - 1) * s3] = -1 / dzF(g, Nz) - dzC(g, Nz) * lam;
+    for (int k = 2; k <= Nz - 1; ++k) d[(k - 1) * sk] = -(1 / dzF(g, k + 1) + 1 / dzF(g, k)) - dzC(g, k) * lam;
+    d[(Nz - 1) * sk] = -1 / dzF(g, Nz) - dzC(g, Nz) * lam;
+}
+int launch_main_diagonal_strided(const ocn_grid *grid, int ni, int nj, long long sj, long long sk, const double *lx, const double *ly,
+                                 double *D, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const long long n = (long long)ni * nj;
+    hipLaunchKernelGGL(main_diagonal_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, g, ni, nj, sj, sk, lx, ly, D);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
 }
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream)
 {
-    GridDev g = to_dev(*grid);
-    hipLaunchKernelGGL(main_diagonal_kernel, dim3((nxh + 63) / 64, g.Ny), dim3(64), 0, stream, g, nxh, lx, ly, D);
-    OCN_CHECK_HIP(hipGetLastError());
-    return OCN_SUCCESS;
+    return launch_main_diagonal_strided(grid, nxh, grid->Ny, nxh, (long long)nxh * grid->Ny, lx, ly, D, stream);
 }
 
 // K14 solve_batched_tridiagonal_system_z! (batched_tridiagonal_solver.jl:209-235).  One thread per (i,j) column,
 // i across lanes so every k-plane access is coalesced; serial Thomas sweep in k.
-__global__ __launch_bounds__(64) void tridiag_z_kernel(int Nx, int Ny, int Nz, const double *__restrict__ a,
-                                                       const double *__restrict__ b, const double *__restrict__ c,
-                                                       const double2 *__restrict__ f, double *__restrict__ t,
-                                                       double2 *__restrict__ phi)
+__global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long sj, long long s3, int Nz,
+                                                       const double *__restrict__ a, const double *__restrict__ b,
+                                                       const double *__restrict__ c, const double2 *__restrict__ f,
+                                                       double *__restrict__ t, double2 *__restrict__ phi)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
-    if (i >= Nx) return;
-    const long long s3 = (long long)Nx * Ny;
-    const long long o = i + (long long)Nx * j;
+    // column (i, j) at i + sj j, planes s3 apart (see main_diagonal_kernel for the two layouts in use)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)ni * nj) return;
+    const long long o = (q % ni) + sj * (q / ni);
     const double tiny = 10 * 2.220446049250313e-16;
     // The sweep is a serial recurrence, but its operands (b, f going up; t, phi going down) do not depend on it: they are
     // requested PF planes ahead so that the memory latency is paid once per PF planes instead of once per plane (a slab of a
@@ -613,13 +621,19 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int Nx, int Ny, int Nz, c
         }
     }
 }
-int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
-                     double *phi, hipStream_t stream)
+int launch_tridiag_z_strided(int ni, int nj, long long sj, long long sk, int Nz, const double *a, const double *b, const double *c,
+                             const double *f, double *t, double *phi, hipStream_t stream)
 {
-    hipLaunchKernelGGL(tridiag_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, stream, Nx, Ny, Nz, a, b, c,
+    const long long n = (long long)ni * nj;
+    hipLaunchKernelGGL(tridiag_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ni, nj, sj, sk, Nz, a, b, c,
                        reinterpret_cast<const double2 *>(f), t, reinterpret_cast<double2 *>(phi));
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
+}
+int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
+                     double *phi, hipStream_t stream)
+{
+    return launch_tridiag_z_strided(Nx, Ny, Nx, (long long)Nx * Ny, Nz, a, b, c, f, t, phi, stream);
 }
 
 // zero-mean gauge (fourier_tridiagonal_poisson_solver.jl:142) applied in spectral space: subtracting the volume

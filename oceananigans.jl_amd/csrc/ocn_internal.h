@@ -43,6 +43,10 @@ int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
                      double *phi, hipStream_t stream);
+int launch_tridiag_z_strided(int ni, int nj, long long sj, long long sk, int Nz, const double *a, const double *b, const double *c,
+                             const double *f, double *t, double *phi, hipStream_t stream);
+int launch_main_diagonal_strided(const ocn_grid *grid, int ni, int nj, long long sj, long long sk, const double *lx, const double *ly,
+                                 double *D, hipStream_t stream);
 int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream);
 // column FFTs (colfft.hip): mode 0 forward (natural -> stage order), 1 inverse (stage order -> natural),
 // 2 forward + spectral solve + inverse.  N in {64, 128, 256, 512}.
@@ -56,7 +60,8 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
 bool realfft_y_supported(int Ny);
 int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,
                      const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid = nullptr,
-                     const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0);
+                     const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0, int kc = 0,
+                     long long chunk = 0, int scale_dz = 0, double scale = 1.0);
 int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream);
 int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream);
 // row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p

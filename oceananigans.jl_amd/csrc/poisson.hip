@@ -666,6 +666,55 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
     s->r2c = !force_c2c && !(env && env[0] == '1');
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
+    const char *efast = std::getenv("OCN_DIST_POISSON_FAST");
+    if (lg->tz == OCN_BOUNDED && !(efast && efast[0] == '0') && R > 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
+        ocn::colfft_supported(Nxg)) {
+        // Slab pipeline, tridiagonal flavour: real y transform (source term x Δzᶜ evaluated on load) writing the all-to-all layout
+        // [d][ky_l + c (z + Nz xl)] (ky = d c + ky_l, c = ceil((Ny/2+1) / R), padded entries stay 0) -> exchange -> x is a strided
+        // column: FFT_x -> Thomas sweep along z (stride c) with this rank's ky range -> IFFT_x -> exchange -> inverse real y into p.
+        s->tri = true;
+        s->fast = true;
+        s->r2c = true;
+        const int NyH = Ny / 2 + 1, c = (NyH + R - 1) / R, Hz = lg->Hz;
+        s->ny = c;
+        s->nyt = c * R;
+        const size_t n = (size_t)s->nyt * Nz * nx;
+        if (lg->dzc) {
+            const size_t nf = (size_t)Nz + 2 * Hz;
+            TRY_HIP(hipMalloc((void **)&s->dzc, nf * sizeof(double)));
+            TRY_HIP(hipMalloc((void **)&s->dzf, nf * sizeof(double)));
+            TRY_HIP(hipMemcpy(s->dzc, lg->dzc, nf * sizeof(double), hipMemcpyDeviceToDevice));
+            TRY_HIP(hipMemcpy(s->dzf, lg->dzf, nf * sizeof(double), hipMemcpyDeviceToDevice));
+            s->grid.dzc = s->dzc;
+            s->grid.dzf = s->dzf;
+        }
+        for (double **p : {&s->send, &s->recv}) {
+            TRY_HIP(hipMalloc((void **)p, n * 2 * sizeof(double)));
+            TRY_HIP(hipMemset(*p, 0, n * 2 * sizeof(double)));
+        }
+        s->yfield = s->recv;
+        TRY_HIP(hipMalloc((void **)&s->diag, n * sizeof(double)));
+        TRY_HIP(hipMalloc((void **)&s->tscr, n * sizeof(double)));
+        TRY(upload(ocn::colfft_twiddles(Ny / 2), &s->tw_h));
+        TRY(upload(ocn::colfft_twiddles(Ny), &s->tw_y));
+        TRY(upload(ocn::colfft_twiddles(Nxg), &s->tw_x));
+        std::vector<double> lyn = eigenvalues(Ny, lg->Ly, OCN_PERIODIC), lxn = eigenvalues(Nxg, global_Lx, OCN_PERIODIC), lxs(Nxg);
+        lyn.resize(NyH);
+        lyn.resize(s->nyt, 1.0);  // padded ky: their data is 0, any nonzero eigenvalue keeps the sweep finite
+        for (int q = 0; q < Nxg; ++q) lxs[q] = lxn[ocn::colfft_wavenumber(Nxg, q)];
+        TRY(upload(lyn, &s->ly));
+        TRY(upload(lxs, &s->lx));
+        std::vector<double> hf(Nz + 2 * Hz, lg->dz);
+        if (lg->dzf) TRY_HIP(hipMemcpy(hf.data(), lg->dzf, hf.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<double> low(Nz - 1, 0.0);
+        for (int q = 2; q <= Nz; ++q) low[q - 2] = 1 / hf[q + Hz - 1];
+        TRY(upload(low, &s->lower));
+        // main diagonal in the exchanged layout: column (ky_l, kx position) at ky_l + c Nz kx, planes c apart
+        TRY(ocn::launch_main_diagonal_strided(&s->grid, c, Nxg, (long long)c * Nz, c, s->ly + (size_t)rank * c, s->lx, s->diag, nullptr));
+        TRY_HIP(hipDeviceSynchronize());
+        *out = s;
+        return OCN_SUCCESS;
+    }
     if (lg->tz == OCN_BOUNDED) {
         s->tri = true;
         s->r2c = false;
@@ -862,7 +911,7 @@ extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int32_t *ny_transpo
 extern "C" int ocn_dist_poisson_pipeline(ocn_dist_poisson_t s, int32_t *fast)
 {
     OCN_REQUIRE(s && fast, "ocn_dist_poisson_pipeline: null argument");
-    *fast = s->fast ? 1 : 0;
+    *fast = s->fast ? (s->tri ? 2 : 1) : 0;
     return OCN_SUCCESS;
 }
 
@@ -872,7 +921,8 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
     OCN_REQUIRE(s && u && v && w, "ocn_dist_poisson_source_term: null argument");
     const ocn_grid *g = &s->grid;
     if (s->fast) {
-        static const bool fused = !(std::getenv("OCN_DIST_FUSED_SOURCE") && std::getenv("OCN_DIST_FUSED_SOURCE")[0] == '0');
+        static const bool env_fused = !(std::getenv("OCN_DIST_FUSED_SOURCE") && std::getenv("OCN_DIST_FUSED_SOURCE")[0] == '0');
+        const bool fused = env_fused || s->tri;
         s->src_u = fused ? u : nullptr; s->src_v = v; s->src_w = w; s->src_dt = dt;
         if (fused) return OCN_SUCCESS;  // evaluated by forward_yz from the same (unchanged) velocity arrays
     }
@@ -900,6 +950,12 @@ static int dist_tri_y_transform(ocn_dist_poisson *s, int inverse, hipStream_t st
 extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_forward_yz: null solver");
+    if (s->tri && s->fast) {  // (Δzᶜ div / Δt)(u, v, w) -> half spectrum in the exchange layout
+        const ocn_grid *g = &s->grid;
+        OCN_REQUIRE(s->src_u, "ocn_dist_poisson_forward_yz: call ocn_dist_poisson_source_term first");
+        return ocn::launch_realfft_y(g->Ny, 0, nullptr, s->send, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y, ocn::as_stream(stream), g,
+                                     s->src_u, s->src_v, s->src_w, s->src_dt, s->ny, (long long)s->ny * g->Nz * s->nx, 1, 1.0);
+    }
     if (s->tri) return dist_tri_y_transform(s, 0, ocn::as_stream(stream));
     if (s->fast) {  // rhs -> A1 (in recv) -> send, ready for the exchange
         const ocn_grid *g = &s->grid;
@@ -917,6 +973,19 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
 {
     OCN_REQUIRE(s, "ocn_dist_poisson_solve_x: null solver");
     hipStream_t stream = ocn::as_stream(stream_);
+    if (s->fast && s->tri) {  // recv = [xg S + (ky_l + c z)], S = c Nz
+        const int Nz = s->grid.Nz, c = s->ny;
+        const long long S = (long long)c * Nz;
+        int st = ocn::launch_colfft(s->Nxg, 0, s->recv, S, 0, (int)S, 1, s->tw_x, nullptr, nullptr, nullptr, 1.0, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn::launch_tridiag_z_strided(c, s->Nxg, S, c, Nz, s->lower, s->diag, s->lower, s->recv, s->tscr, s->send, stream);
+        if (st != OCN_SUCCESS) return st;
+        if (s->rank == 0) {  // zero-mean gauge on the (kx, ky) = (0, 0) column: stored position 0 of both
+            st = ocn::launch_remove_mean_mode(c, Nz, s->send, stream);
+            if (st != OCN_SUCCESS) return st;
+        }
+        return ocn::launch_colfft(s->Nxg, 1, s->send, S, 0, (int)S, 1, s->tw_x, nullptr, nullptr, nullptr, 1.0, 1, stream);
+    }
     if (s->fast) {  // recv = [xg S + (ky + NyH pz_l)]: FFT_x -> -b / ((λy + λz) + λx), rank 0 zeroes the mean mode -> IFFT_x, in place
         const int Nz = s->grid.Nz, cz = Nz / s->R, NyH = s->nyt;
         const long long S = (long long)NyH * cz;
@@ -948,6 +1017,14 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
 {
     OCN_REQUIRE(s && p, "ocn_dist_poisson_backward_yz: null argument");
     hipStream_t stream = ocn::as_stream(stream_);
+    if (s->tri && s->fast) {  // recv (after the exchange back) -> real rows of p; the packed inverse carries Ny/2, FFT_x Nxg
+        const ocn_grid *g = &s->grid;
+        ocn::GridDev gd = ocn::to_dev(*g);
+        ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+        return ocn::launch_realfft_y(g->Ny, 1, nullptr, s->recv, p + Lp.o, Lp.s2, Lp.s3, s->nx, g->Nz, s->tw_h, s->tw_y, stream, nullptr,
+                                     nullptr, nullptr, nullptr, 1.0, s->ny, (long long)s->ny * g->Nz * s->nx, 0,
+                                     1.0 / ((double)(g->Ny / 2) * s->Nxg));
+    }
     if (s->tri) {
         int st = dist_tri_y_transform(s, 1, stream);
         if (st != OCN_SUCCESS) return st;

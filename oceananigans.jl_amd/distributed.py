@@ -315,7 +315,7 @@ class _HipDistPoisson:
                 self.nyt, self.r2c = nyt.value, bool(r2c.value)
         fast = C.c_int32()
         _lib.call("ocn_dist_poisson_pipeline", self._h, C.byref(fast))
-        self.fast = bool(fast.value)  # slab pipeline: no pack / unpack passes (ocn_hip.h)
+        self.fast = fast.value  # slab pipeline: no pack / unpack passes (1: periodic z, 2: tridiagonal flavour; ocn_hip.h)
         n = nel.value * 2
         # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
         self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
@@ -396,7 +396,10 @@ class DistributedFFTBasedPoissonSolver:
             impl.forward_yz()
             self.arch.fabric.all_to_all(impl.recv, impl.send)
             impl.solve_x()
-            self.arch.fabric.all_to_all(impl.send, impl.recv)
+            if impl.fast == 2:  # the tridiagonal flavour leaves its solution in `send`
+                self.arch.fabric.all_to_all(impl.recv, impl.send)
+            else:
+                self.arch.fabric.all_to_all(impl.send, impl.recv)
             impl.backward_yz(p)
             return p
         impl.forward_yz()

@@ -137,15 +137,24 @@ def test_distributed_steps_match_single_rank(ocn, R, topo):
 
 
 @pytest.mark.parametrize("R", [2, 4])
-def test_distributed_slab_pipeline_matches_single_rank(ocn, R):
+@pytest.mark.parametrize("topo", ["PPP", "PPB"])
+def test_distributed_slab_pipeline_matches_single_rank(ocn, R, topo):
     """Sizes the library's slab pipeline covers (real y transform, z column FFT into the exchange layout, fused x column
-    kernel; csrc/colfft.hip): the handle must select it, and two RK3 steps must match the single-rank model, whose solver is a
-    different code path (rocFFT or the row / column pipeline)."""
+    kernel -- or, for a Bounded stretched z, the ky-partitioned layout with FFT_x and the Thomas sweep; csrc/colfft.hip): the
+    handle must select it, and two RK3 steps must match the single-rank model, whose solver is a different code path (rocFFT
+    or the row / column pipeline).  "PPB": Ny/2 + 1 = 65 is not a multiple of R, so the zero padding of the exchange is covered."""
+    from helpers import stretched_faces
     P = "Periodic"
-    N = (64, 128, 64)
-    ext = dict(x=(0, 2 * np.pi), y=(0, 4 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    if topo == "PPP":
+        N = (64, 128, 64)
+        ext = dict(x=(0, 2 * np.pi), y=(0, 4 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    else:
+        N = (64, 128, 12)
+        ext = dict(x=(0, 2 * np.pi), y=(0, 4 * np.pi), z=stretched_faces(N[2], 2.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
     rng = np.random.default_rng(4321)
     init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    if topo == "PPB":
+        init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
     dt = 0.005
     ocn.set_math_mode(ocn.MATH_STRICT)
     sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
@@ -160,7 +169,7 @@ def test_distributed_slab_pipeline_matches_single_rank(ocn, R):
         arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
         g = ocn.RectilinearGrid(arch, size=N, **ext)
         m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
-        assert m.pressure_solver.impl.fast
+        assert m.pressure_solver.impl.fast == (1 if topo == "PPP" else 2)
         sl = slice(r * g.Nx, (r + 1) * g.Nx)
         ocn.set(m, **{k: v[sl] for k, v in init.items()})
         for _ in range(2):
