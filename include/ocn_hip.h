@@ -312,6 +312,12 @@ int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, doub
                     void *stream);
 int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const double *recv_west, const double *recv_east,
                       void *stream);
+/* One x-plane with its full (y, z) cross-section.  which = 0 (west): pack parent[1+Hx,:,:] (first interior plane), unpack into
+ * parent[Hx,:,:] (the halo plane next to it); which = 1 (east): pack parent[nx+Hx,:,:], unpack into parent[1+nx+Hx,:,:].
+ * What divᶜᶜᶜ needs of u (its east neighbour plane) and ∂xᶠᶜᶜ of the pressure (its west one): the projection's two
+ * synchronous halo fills (pressure_correction.jl:10-17) then move one plane instead of 2 Hx per field; the complete fill of
+ * the same fields follows in update_state!. */
+int ocn_halo_plane_x(const ocn_grid *grid, double *field, int32_t loc, int32_t which, double *buffer, int32_t unpack, void *stream);
 /* The same for a tuple of fields in one launch: the strips of the fields follow one another in the buffers (field q starts at
  * Hx * sum_{r<q} sy_r sz_r), so the exchange is one message per neighbour for the whole tuple
  * (fill_halo_regions! of a tuple, src/DistributedComputations/halo_communication.jl:95-128). */

@@ -97,6 +97,7 @@ _SIGS = {
     "ocn_batched_tridiagonal_solve_z": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_halo_pack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
+    "ocn_halo_plane_x": [C.POINTER(CGrid), _vp, _i32, _i32, _vp, _i32, _vp],
     "ocn_halo_pack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],
     "ocn_transpose_pack_y_to_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],

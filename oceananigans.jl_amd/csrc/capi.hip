@@ -596,6 +596,15 @@ int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const do
     return launch_halo_pack_x(grid, field, loc, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
 }
 
+int ocn_halo_plane_x(const ocn_grid *grid, double *field, int32_t loc, int32_t which, double *buffer, int32_t unpack, void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(field && buffer, "ocn_halo_plane_x: null pointer");
+    OCN_REQUIRE(which == 0 || which == 1, "ocn_halo_plane_x: which must be 0 (west) or 1 (east)");
+    OCN_REQUIRE(grid->Hx >= 1, "ocn_halo_plane_x: needs an x halo");
+    return launch_halo_plane_x(grid, field, loc, which, buffer, unpack ? 1 : 0, as_stream(stream));
+}
 int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, double *send_west,
                            double *send_east, void *stream)
 {

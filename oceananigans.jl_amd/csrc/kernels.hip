@@ -701,6 +701,30 @@ int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, doubl
     return OCN_SUCCESS;
 }
 
+// One x-plane (full cross-section) of a field: pack the first / last interior plane, unpack into the adjacent halo plane.
+// which = 0: west (pack x = 1, unpack x = 0), 1: east (pack x = nx, unpack x = nx + 1).
+__global__ void halo_plane_x_kernel(int Hx, int nx, int sx, long long rows, double *__restrict__ c, double *__restrict__ buf, int which,
+                                    int unpack)
+{
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double *crow = c + row * sx;
+    if (!unpack)
+        buf[row] = which ? crow[Hx + nx - 1] : crow[Hx];
+    else
+        crow[which ? Hx + nx : Hx - 1] = buf[row];
+}
+int launch_halo_plane_x(const ocn_grid *grid, double *field, int loc, int which, double *buf, int unpack, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    Lay L = make_lay(g, loc);
+    const long long rows = (long long)L.sy * L.sz;
+    hipLaunchKernelGGL(halo_plane_x_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, g.Hx, g.Nx, L.sx, rows, field, buf,
+                       which, unpack);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // All fields of a tuple in one launch (blockIdx.y = field); the strips of the fields follow one another in `west` / `east`, so a
 // halo exchange is ONE message per neighbour.
 struct PackTuple {

@@ -62,6 +62,7 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
                      const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid = nullptr,
                      const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0, int kc = 0,
                      long long chunk = 0, int scale_dz = 0, double scale = 1.0);
+int launch_halo_plane_x(const ocn_grid *grid, double *field, int loc, int which, double *buf, int unpack, hipStream_t stream);
 int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream);
 int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream);
 // row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p

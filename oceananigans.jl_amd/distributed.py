@@ -90,6 +90,9 @@ class HipOps:
     def unpack_x(self, grid, f, west, east):
         _lib.call("ocn_halo_unpack_x", grid.cref, f.ptr, f.loc, west.data_ptr(), east.data_ptr(), stream_ptr())
 
+    def plane_x(self, grid, f, which, buf, unpack):
+        _lib.call("ocn_halo_plane_x", grid.cref, f.ptr, f.loc, int(which), buf.data_ptr(), int(bool(unpack)), stream_ptr())
+
     def pack_x_fields(self, grid, fields, west, east):
         _lib.call("ocn_halo_pack_x_fields", grid.cref, _lib.ptr_array([f.ptr for f in fields]), _lib.i32_array([f.loc for f in fields]),
                   len(fields), west.data_ptr(), east.data_ptr(), stream_ptr())
@@ -185,6 +188,29 @@ class Distributed:
             for f, (o, n) in zip(fields, spans):
                 self.ops.unpack_x(g, f, rw[o:o + n], re[o:o + n])
         self._pending = None
+
+    def fill_neighbour_plane(self, fields, f, side):
+        """Local (y, z) fills of `fields`, then ONE x-plane of `f` from a neighbour instead of the 2 Hx strips of every field:
+        side = "east": f[nx+1, :, :] <- east neighbour's f[1, :, :] (what divᶜᶜᶜ reads of u); side = "west": f[0, :, :] <- west
+        neighbour's f[nx, :, :] (what ∂xᶠᶜᶜ reads of the pressure).  For the two synchronous fills inside the pressure projection,
+        whose fields get their complete exchange in the following update_state!."""
+        g = f.grid
+        self.ops.local_fill(g, fields, True)
+        if self.partition.x == 1 or not hasattr(self.ops, "plane_x"):
+            return self.fill_halo_regions(fields) if self.partition.x > 1 else None
+        sx, sy, sz = g.parent_shape(f.loc)
+        key = ("plane", f.loc)
+        b = self._buffers.get(key)
+        if b is None:
+            b = self._buffers[key] = (self.ops.new_buffer(self, sy * sz), self.ops.new_buffer(self, sy * sz))
+        sbuf, rbuf = b
+        east = side == "east"
+        # the plane I need from the east is my east neighbour's WEST interior plane, and vice versa
+        self.ops.plane_x(g, f, 0 if east else 1, sbuf, False)
+        reqs = self.fabric.start_exchange([(sbuf, self.west_rank if east else self.east_rank)],
+                                          [(rbuf, self.east_rank if east else self.west_rank)])
+        self.fabric.wait(reqs)
+        self.ops.plane_x(g, f, 1 if east else 0, rbuf, True)
 
     def fill_halo_regions(self, fields, fbnv=True):
         """Local (y, z) fills first, communication last (fill_halo_regions.jl:148-196); synchronous."""

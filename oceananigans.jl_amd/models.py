@@ -347,12 +347,23 @@ def compute_tendencies_(model, rng=None):
 compute_tendencies = compute_tendencies_
 
 
-def calculate_pressure_correction(model, dt, fill_pressure_halos=True):
-    """calculate_pressure_correction!(model, Δt) (pressure_correction.jl:8-20)"""
-    fill_halo_regions(model.velocities)
+def calculate_pressure_correction(model, dt, fill_pressure_halos=True, minimal_exchange=False):
+    """calculate_pressure_correction!(model, Δt) (pressure_correction.jl:8-20).
+
+    minimal_exchange (Distributed only; used between the RK3 substeps, where update_state! refills every halo right after the
+    correction): the two synchronous x exchanges move only the planes the projection reads -- u[nx+1] for the divergence and
+    p[0] for ∂x p of the first interior face -- instead of all 2 Hx planes of u, v, w and p."""
+    plane = getattr(model.architecture, "fill_neighbour_plane", None) if minimal_exchange else None
+    if plane is not None:
+        plane(tuple(model.velocities), model.u, "east")
+    else:
+        fill_halo_regions(model.velocities)
     solve_for_pressure(model.pNHS, model.pressure_solver, dt, model.velocities)
     if fill_pressure_halos:
-        fill_halo_regions(model.pNHS)
+        if plane is not None:
+            plane((model.pNHS,), model.pNHS, "west")
+        else:
+            fill_halo_regions(model.pNHS)
 
 
 def solve_for_pressure(pressure, solver, dt, U):
@@ -494,7 +505,7 @@ def _project_and_advance(model, dt, stage_dt, gamma_next, zeta_next):
         cache_previous_tendencies(model)
         update_state_and_rk3_substep(model, dt, gamma_next, zeta_next, fill_halos=False, p_correct=model.pNHS, dt_correct=stage_dt)
         return
-    calculate_pressure_correction(model, stage_dt)
+    calculate_pressure_correction(model, stage_dt, minimal_exchange=True)
     pressure_correct_velocities(model, stage_dt)
     cache_previous_tendencies(model)
     if model.fuse_stage_boundaries:

@@ -165,6 +165,13 @@ class NumpyOps:
         a[0:H] = west.numpy().reshape(shp, order="F")           # parent[1 : Hx]
         a[nx + H:nx + 2 * H] = east.numpy().reshape(shp, order="F")  # parent[1+nx+Hx : nx+2Hx]
 
+    def plane_x(self, grid, f, which, buf, unpack):
+        a, H, nx = fview(f), grid.Hx, grid.Nx
+        if not unpack:   # first / last interior plane
+            buf.numpy()[...] = a[H + nx - 1 if which else H].ravel(order="F")
+        else:            # the halo plane next to it
+            a[H + nx if which else H - 1] = buf.numpy().reshape(a.shape[1:], order="F")
+
     def sync(self):
         pass
 
