@@ -2,11 +2,12 @@
 """What ONE rank of an R-rank slab-x run costs, measured on a single GPU: the real distributed code path (local halo fills,
 pack / unpack, interior / buffer tendency split, distributed transposes and FFTs, all kernels at the rank-local size) with a
 LOOPBACK fabric that emulates R identical ranks -- every message a rank would receive from a neighbour is the one it sends
-itself, which is exactly what R replicas of an x-periodic flow of period Lx/R exchange.  The time it prints is therefore the
-per-rank compute + host time of an R-GPU step with the communication itself replaced by device copies; compare it with
+itself, which is exactly what R replicas of an x-periodic flow of period Lx/R exchange (except the return all-to-all of the
+pressure solve, see LoopbackFabric.all_to_all: TIMING ONLY, the pressure is not the true one).  The time it prints is therefore
+the per-rank compute + host time of an R-GPU step with the communication itself replaced by device copies; compare it with
 (single-GPU step) / R to see what the decomposition costs before any link time.
 
-  tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched)
+  tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched, advection only) | config4amd (its full physics)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,8 +39,15 @@ class LoopbackFabric:
         pass
 
     def all_to_all(self, recv, send):
+        # Forward exchange of a solve: chunk m <- rank m's chunk for me = my own chunk 0 (identical ranks).  The RETURN exchange
+        # cannot be emulated (the other ranks' parts of the solution are never computed here): it delivers zeros, i.e. p = 0 and
+        # no projection -- the same bytes move and the same kernels run, which is all a timing needs; the fields stay finite.
+        self.calls = getattr(self, "calls", 0) + 1
         n = send.numel() // self.size
-        recv.view(self.size, n).copy_(send[:n].expand(self.size, n))  # chunk m <- rank m's chunk for me = my own chunk 0
+        if self.calls % 2:
+            recv.view(self.size, n).copy_(send[:n].expand(self.size, n))
+        else:
+            recv.zero_()
 
     def allreduce_max(self, t):
         return t
@@ -48,7 +56,7 @@ class LoopbackFabric:
 ocn.set_math_mode(ocn.MATH_FAST)
 arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=LoopbackFabric(R)) if R > 1 else ocn.GPU()
 P = "Periodic"
-if workload == "config4":
+if workload.startswith("config4"):
     Nz = N // 2
     Lz, refinement, stretching = 32.0, 1.2, 12.0
     h = lambda k: (k - 1) / Nz
@@ -57,14 +65,30 @@ if workload == "config4":
     g = ocn.RectilinearGrid(arch, size=(N, N, Nz), x=(0, 64), y=(0, 64), z=z_faces, topology=(P, P, "Bounded"), halo=(3, 3, 3))
 else:
     g = ocn.RectilinearGrid(arch, size=(N, N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
-m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+if workload == "config4amd":  # the ocean_wind_mixing_and_convection physics as written (tools/bench_config4.py, physics = 2)
+    Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
+    bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1.225 / rho * 2.5e-3 * 10 * 10)),
+           "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(Q / (rho * cp)), bottom=ocn.GradientBoundaryCondition(dTdz)),
+           "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-1e-3 / 3600))}
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
+                                closure=ocn.AnisotropicMinimumDissipation(),
+                                buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                boundary_conditions=bcs)
+    zc = torch.from_numpy(0.5 * (z_faces[1:] + z_faces[:-1])).to("cuda")
+    T = m.field("T").interior_view()
+    T.copy_(20 + dTdz * zc[:, None, None] + 1e-6 * torch.rand(T.shape, device="cuda", dtype=torch.float64))
+    m.field("S").interior_view().fill_(35.0)
+else:
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
 for f in m.velocities:
     v = f.interior_view()
-    v.copy_(2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1)
+    v.copy_((1e-2 if workload == "config4amd" else 1.0) * (2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
 ocn.set(m)  # halos + projection
 umax = max(float(f.interior_view().abs().max()) for f in m.velocities)
-dt = 0.1 * g.dx / umax
+dt = 0.1 * (min(g.dx, float(np.diff(z_faces).min())) if workload.startswith("config4") else g.dx) / umax
+if R > 1 and workload == "config4amd":
+    dt *= 1e-3  # no projection in the loopback emulation: keep the unprojected noise from running away (timing does not depend on dt)
 for _ in range(3):
     ocn.time_step(m, dt)
 ocn.sync_device()
