@@ -193,9 +193,18 @@ int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const doub
 int ocn_compute_amd_diffusivities(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w,
                                   double *nu_e, int32_t n_tracers, const double *C_kappa, const double *const *tracers,
                                   double *const *kappa_e, void *stream);
+/* The same over the columns i_first..i_last only, which may include the halo columns 0 and Nx+1: a distributed run computes
+ * the interior while its halo exchange is in flight and the edge and halo columns afterwards, from the exchanged halos
+ * (compute_nonhydrostatic_buffer_tendencies.jl:55-68) -- the halo values equal what the neighbour computes for its own edge. */
+int ocn_compute_amd_diffusivities_range(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w,
+                                        double *nu_e, int32_t n_tracers, const double *C_kappa, const double *const *tracers,
+                                        double *const *kappa_e, int32_t i_first, int32_t i_last, void *stream);
 /* update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-53): pHY′ by downward integration of the buoyancy
  * perturbation over i in 0:Nx+1, j in 0:Ny+1 (tracer halos must be filled).  No-op on a z-Flat grid. */
 int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream);
+/* columns i_first..i_last of 0..Nx+1 only (see ocn_compute_amd_diffusivities_range) */
+int ocn_update_hydrostatic_pressure_range(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, int32_t i_first,
+                                          int32_t i_last, void *stream);
 
 /* Boundary conditions (src/BoundaryConditions/boundary_condition.jl).  The condition evaluates to
  *   values[(i-1) + Nx*(j-1)]              if values != NULL  (array boundary condition, DEVICE pointer), else

@@ -78,6 +78,8 @@ _SIGS = {
     "ocn_compute_tracer_tendency_terms_rk3": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, C.POINTER(CFieldBcs)]
                                              + [_vp] * 7 + [_dbl, _dbl, _dbl, _i32, C.POINTER(_i32), _vp],
     "ocn_update_hydrostatic_pressure": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp],
+    "ocn_update_hydrostatic_pressure_range": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _i32, _i32, _vp],
+    "ocn_compute_amd_diffusivities_range": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp, _i32, C.POINTER(_dbl), C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _vp],
     "ocn_fill_halo_regions_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _i32, _vp],
     "ocn_apply_flux_bcs": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(C.POINTER(CFieldBcs)), _i32, _vp],
     "ocn_cell_advection_timescale": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],

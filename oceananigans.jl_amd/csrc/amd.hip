@@ -67,10 +67,12 @@ struct AmdTracers {
 
 __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
                                                         const double *__restrict__ v, const double *__restrict__ w,
-                                                        double *__restrict__ nu_e, AmdTracers tr)
+                                                        double *__restrict__ nu_e, AmdTracers tr, int i0, int i1)
 {
-    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
-    if (i > g.Nx || j > g.Ny) return;
+    // i0..i1: 1..Nx, or a sub-range / the halo columns 0 and Nx+1 (the buffer recomputation of a distributed run,
+    // compute_nonhydrostatic_buffer_tendencies.jl:55-68)
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (i > i1 || j > g.Ny) return;
     const Amd A = make_amd(g, u, v, w, nullptr, i, j, k);
     const long long o = A.u - u;
     // filter-width ratios and spacings of the two z levels this cell touches (k is uniform across the workgroup)
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
 #undef I4PR
 
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
-                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream)
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream, const int32_t *irange)
 {
     if (ntr > OCN_AMD_MAX_TRACERS) {
         ocn::set_error("at most %d tracers per AMD launch, got %d", OCN_AMD_MAX_TRACERS, ntr);
@@ -184,8 +186,10 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
         tr.Ck[n] = Ck[n];
     }
     GridDev g = ocn::to_dev(*grid);
-    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
-    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr);
+    const int i0 = irange ? irange[0] : 1, i1 = irange ? irange[1] : g.Nx;
+    if (i1 < i0) return OCN_SUCCESS;
+    const dim3 block = ocn::range_block(i1 - i0 + 1), nb = ocn::range_grid(block, i1 - i0 + 1, g.Ny, g.Nz);
+    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -193,13 +197,13 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream)
 {
-    return launch_amd_fused(grid, Cnu, u, v, w, nu_e, 0, nullptr, nullptr, nullptr, stream);
+    return launch_amd_fused(grid, Cnu, u, v, w, nu_e, 0, nullptr, nullptr, nullptr, stream, nullptr);
 }
 
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
                            double *kappa_e, hipStream_t stream)
 {
-    return launch_amd_fused(grid, 0.0, u, v, w, nullptr, 1, &Ck, &c, &kappa_e, stream);
+    return launch_amd_fused(grid, 0.0, u, v, w, nullptr, 1, &Ck, &c, &kappa_e, stream, nullptr);
 }
 
 }  // namespace OCN_NS

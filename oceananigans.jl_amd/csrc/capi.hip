@@ -339,6 +339,24 @@ int ocn_compute_amd_diffusivities(const ocn_grid *grid, double C_nu, const doubl
                : ocn_fast::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream));
 }
 
+int ocn_compute_amd_diffusivities_range(const ocn_grid *grid, double C_nu, const double *u, const double *v, const double *w,
+                                        double *nu_e, int32_t n_tracers, const double *C_kappa, const double *const *tracers,
+                                        double *const *kappa_e, int32_t i_first, int32_t i_last, void *stream)
+{
+    int st = validate_amd(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && nu_e, "ocn_compute_amd_diffusivities_range: null field pointer");
+    OCN_REQUIRE(n_tracers >= 0 && n_tracers <= 4, "ocn_compute_amd_diffusivities_range: n_tracers = %d outside 0..4", n_tracers);
+    OCN_REQUIRE(n_tracers == 0 || (C_kappa && tracers && kappa_e), "ocn_compute_amd_diffusivities_range: null tracer arrays");
+    for (int n = 0; n < n_tracers; ++n) OCN_REQUIRE(tracers[n] && kappa_e[n], "ocn_compute_amd_diffusivities_range: tracer %d is NULL", n);
+    OCN_REQUIRE(i_first >= 0 && i_last <= grid->Nx + 1, "ocn_compute_amd_diffusivities_range: i range %d:%d outside 0:%d", i_first, i_last, grid->Nx + 1);
+    OCN_REQUIRE((i_first >= 1 && i_last <= grid->Nx) || grid->Hx >= 2, "the halo columns 0 and Nx+1 need Hx >= 2");
+    const int32_t ir[2] = {i_first, i_last};
+    return g_math_mode == OCN_MATH_STRICT
+               ? ocn_strict::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream), ir)
+               : ocn_fast::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream), ir);
+}
+
 int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const double *u, const double *v, const double *w,
                                 const double *c, double *kappa_e, void *stream)
 {
@@ -359,6 +377,21 @@ int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms 
     if (terms->buoyancy == OCN_BUOYANCY_SEAWATER_TS || terms->buoyancy == OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->S != nullptr, "S tracer is NULL");
     OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
     return launch_hydrostatic_pressure(grid, to_dev(*terms), pHY, as_stream(stream));
+}
+
+int ocn_update_hydrostatic_pressure_range(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, int32_t i_first, int32_t i_last,
+                                          void *stream)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(terms != nullptr && pHY != nullptr, "ocn_update_hydrostatic_pressure_range: null argument");
+    OCN_REQUIRE(terms->buoyancy != OCN_BUOYANCY_NONE, "ocn_update_hydrostatic_pressure_range: buoyancy is nothing");
+    if (terms->buoyancy != OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->T != nullptr, "T (or b) tracer is NULL");
+    if (terms->buoyancy == OCN_BUOYANCY_SEAWATER_TS || terms->buoyancy == OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->S != nullptr, "S tracer is NULL");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    OCN_REQUIRE(i_first >= 0 && i_last <= grid->Nx + 1, "ocn_update_hydrostatic_pressure_range: i range %d:%d outside 0:%d", i_first, i_last, grid->Nx + 1);
+    const int32_t ir[2] = {i_first, i_last};
+    return launch_hydrostatic_pressure(grid, to_dev(*terms), pHY, as_stream(stream), ir);
 }
 
 static int make_zbc_tuple(const ocn_grid *grid, const int32_t *locs, const ocn_field_bcs *const *bcs, int32_t n, ZBcTuple &z,

@@ -173,10 +173,10 @@ __device__ __forceinline__ double buoyancy_perturbation(const TermsDev &t, long 
     }
 }
 
-__global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, TermsDev t, double *__restrict__ pHY)
+__global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, TermsDev t, double *__restrict__ pHY, int i0, int i1)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;  // 0 .. N+1
-    if (i > g.Nx + 1 || j > g.Ny + 1) return;
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;  // 0 .. N+1 (or a sub-range in x)
+    if (i > i1 || j > g.Ny + 1) return;
     const Lay L = make_lay(g, OCN_LOC_CCC);
     const int Nz = g.Nz;
     long long o = at(L, i, j, Nz + 1);
@@ -193,12 +193,14 @@ __global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, Te
     }
 }
 
-int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream)
+int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream, const int32_t *irange)
 {
     if (grid->tz == OCN_FLAT || t.buoyancy == OCN_BUOYANCY_NONE) return OCN_SUCCESS;
     GridDev g = to_dev(*grid);
-    dim3 block(64, 4, 1), nb((g.Nx + 2 + 63) / 64, (g.Ny + 2 + 3) / 4, 1);
-    hipLaunchKernelGGL(hydrostatic_pressure_kernel, nb, block, 0, stream, g, t, pHY);
+    const int i0 = irange ? irange[0] : 0, i1 = irange ? irange[1] : g.Nx + 1;
+    if (i1 < i0) return OCN_SUCCESS;
+    const dim3 block = range_block(i1 - i0 + 1), nb = range_grid(block, i1 - i0 + 1, g.Ny + 2, 1);
+    hipLaunchKernelGGL(hydrostatic_pressure_kernel, nb, block, 0, stream, g, t, pHY, i0, i1);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

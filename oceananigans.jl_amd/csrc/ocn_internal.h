@@ -30,7 +30,7 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
 int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream);
 int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream);
 int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
-int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream);
+int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream, const int32_t *irange = nullptr);
 int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);
 int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
                        double *out, long long ld1, long long ld2, hipStream_t stream);
@@ -91,7 +91,7 @@ int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const do
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
-                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream);
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream, const int32_t *irange = nullptr);
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream);
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,
@@ -112,7 +112,7 @@ int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const do
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
-                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream);
+                     const double *Ck, const double *const *c, double *const *kappa_e, hipStream_t stream, const int32_t *irange = nullptr);
 int launch_amd_viscosity(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e,
                          hipStream_t stream);
 int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, const double *v, const double *w, const double *c,

@@ -18,6 +18,8 @@ choreography can be exercised on CPU ranks (gloo) in tests; the product ops are 
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -225,13 +227,13 @@ class Distributed:
         g = model.grid
         fields = model.prognostic_fields()
         if getattr(model, "general_terms", False):
-            # Coriolis / closure / buoyancy / boundary conditions: the hydrostatic pressure anomaly is integrated over
-            # i in 0:nx+1 and needs the exchanged tracer halos, so this path completes the exchange first and computes the
-            # tendencies of the whole slab in one go (no interior / buffer overlap yet)
-            self.fill_halo_regions(fields, False)
-            models.compute_auxiliaries(model)
+            # Coriolis / closure / buoyancy / boundary conditions
             if compute_tendencies:
-                models.compute_tendencies_(model)
+                self.update_state_general(model, lambda rng=None: models.compute_tendencies_(model, rng, boundary_contributions=False))
+                models.compute_boundary_tendency_contributions(model)
+            else:
+                self.fill_halo_regions(fields, False)
+                models.compute_auxiliaries(model)
             return
         self.ops.local_fill(g, fields, False)
         pending = self.start_halo_exchange(fields)
@@ -250,6 +252,47 @@ class Distributed:
             e0 = max(nx - Hx + 1, w1 + 1)
             if e0 <= nx:
                 models.compute_tendencies_(model, (e0, nx, 1, g.Ny, 1, g.Nz))
+
+    def update_state_general(self, model, launch):
+        """update_state! of a model with the extra terms (hydrostatic pressure anomaly, eddy diffusivities): the exchange of the
+        prognostic fields overlaps the auxiliaries and the tendencies of the columns that do not read x-halos; the edge and
+        halo columns of the auxiliaries are computed from the exchanged halos afterwards -- the buffer recomputation of
+        compute_nonhydrostatic_buffer_tendencies.jl:55-68 instead of a second exchange (the halo values of νₑ, κₑ equal what
+        the neighbour computes for its own edge column: same inputs, same arithmetic) -- followed by the two buffer strips.
+        `launch(rng)` runs the tendency kernels of the i, j, k range `rng` (None = the whole slab)."""
+        from . import models
+        g = model.grid
+        fields = model.prognostic_fields()
+        nx, Hx = g.Nx, g.Hx
+        d = model.diffusivity_fields
+        aux = (() if d is None else (d["nu_e"],) + tuple(d["kappa_e"]))
+        split = (self.partition.x > 1 and nx - 2 * Hx >= 1 and Hx >= 2 and len(model.tracers) <= 4
+                 and os.environ.get("OCN_DIST_GENERAL_OVERLAP", "1") != "0")
+        if not split:
+            self.fill_halo_regions(fields, False)
+            models.compute_auxiliaries(model)
+            launch(None)
+            return
+        self.ops.local_fill(g, fields, False)
+        self.start_halo_exchange(fields)
+        # interior: νₑ, κₑ of columns 2..nx-1 read u, v, w, c at i-1..i+1 (local); pHY′ of a column reads that column only
+        models.compute_diffusivities(model, (2, nx - 1))
+        models.update_hydrostatic_pressure(model, (1, nx))
+        if aux:
+            self.ops.local_fill(g, aux, True)  # their y / z halos (and bottom / top conditions)
+        launch((Hx + 1, nx - Hx, 1, g.Ny, 1, g.Nz))
+        self.finish_halo_exchange()
+        for rng in ((0, 1), (nx, nx + 1)):
+            models.compute_diffusivities(model, rng)
+        for rng in ((0, 0), (nx + 1, nx + 1)):
+            models.update_hydrostatic_pressure(model, rng)
+        if aux:
+            self.ops.local_fill(g, aux, True)
+        w1 = min(Hx, nx)
+        launch((1, w1, 1, g.Ny, 1, g.Nz))
+        e0 = max(nx - Hx + 1, w1 + 1)
+        if e0 <= nx:
+            launch((e0, nx, 1, g.Ny, 1, g.Nz))
 
     def update_state_fused(self, model, launch, fill_halos=True):
         """update_state! + the next rk3 substep with the fused launch: same interior / buffer split and overlap as update_state."""

@@ -286,8 +286,9 @@ def compute_auxiliaries(model):
         fill_halo_regions((d["nu_e"],) + d["kappa_e"])
 
 
-def compute_diffusivities(model):
-    """compute_diffusivities!(diffusivity_fields, closure::AnisotropicMinimumDissipation, model)"""
+def compute_diffusivities(model, irange=None):
+    """compute_diffusivities!(diffusivity_fields, closure::AnisotropicMinimumDissipation, model); irange = (i_first, i_last):
+    those columns only, 0 and Nx+1 included (Distributed: interior during the halo exchange, edges and halo columns after it)."""
     d = model.diffusivity_fields
     if d is None:
         return
@@ -295,24 +296,36 @@ def compute_diffusivities(model):
     nt = len(model.tracers)
     if nt <= 4:  # νₑ and every κₑ in one launch
         Ck = (C.c_double * max(nt, 1))(*[model.closure.Ckappa_of(n) for n in model.tracer_names])
+        if irange is not None:
+            _lib.call("ocn_compute_amd_diffusivities_range", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr,
+                      nt, Ck, _lib.ptr_array([c.ptr for c in model.tracers] or [None]),
+                      _lib.ptr_array([k.ptr for k in d["kappa_e"]] or [None]), int(irange[0]), int(irange[1]), s)
+            return
         _lib.call("ocn_compute_amd_diffusivities", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr, nt,
                   Ck, _lib.ptr_array([c.ptr for c in model.tracers] or [None]), _lib.ptr_array([k.ptr for k in d["kappa_e"]] or [None]), s)
         return
+    if irange is not None:
+        raise NotImplementedError("column ranges of the AMD diffusivities need at most 4 tracers")
     _lib.call("ocn_compute_amd_viscosity", g.cref, model.closure.Cnu, model.u.ptr, model.v.ptr, model.w.ptr, d["nu_e"].ptr, s)
     for name, c, k in zip(model.tracer_names, model.tracers, d["kappa_e"]):
         _lib.call("ocn_compute_amd_diffusivity", g.cref, model.closure.Ckappa_of(name), model.u.ptr, model.v.ptr, model.w.ptr,
                   c.ptr, k.ptr, s)
 
 
-def update_hydrostatic_pressure(model):
-    """update_hydrostatic_pressure!(model) (update_hydrostatic_pressure.jl:25-28)"""
+def update_hydrostatic_pressure(model, irange=None):
+    """update_hydrostatic_pressure!(model) (update_hydrostatic_pressure.jl:25-28); irange: columns i_first..i_last of 0..Nx+1"""
     if model.pHY is not None:
+        if irange is not None:
+            _lib.call("ocn_update_hydrostatic_pressure_range", model.grid.cref, C.byref(model._terms), model.pHY.ptr, int(irange[0]),
+                      int(irange[1]), stream_ptr())
+            return
         _lib.call("ocn_update_hydrostatic_pressure", model.grid.cref, C.byref(model._terms), model.pHY.ptr, stream_ptr())
 
 
-def compute_tendencies_(model, rng=None):
+def compute_tendencies_(model, rng=None, boundary_contributions=True):
     """compute_tendencies! -> compute_interior_tendency_contributions!: K1-K3 fused + K4 per tracer, then
-    compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:17-54)."""
+    compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:17-54).  A caller that covers the domain
+    with several ranges passes boundary_contributions=False and calls compute_boundary_tendency_contributions once at the end."""
     g = model.grid
     model._pending_tendencies = False
     Gn = model.timestepper._Gn
@@ -330,18 +343,25 @@ def compute_tendencies_(model, rng=None):
                 kappa = model.closure.kappa_of(model.tracer_names[n])
             _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, kappa_e, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr,
                       Gn[3 + n].ptr, r, s)
-        if model._has_flux_bcs:
-            prog = model.prognostic_fields()
-            arr = (C.POINTER(_lib.CFieldBcs) * len(prog))(*[
-                (C.pointer(f.boundary_conditions.c_struct(g)) if f.boundary_conditions is not None and f.boundary_conditions.has_flux()
-                 else C.POINTER(_lib.CFieldBcs)()) for f in prog])
-            _lib.call("ocn_apply_flux_bcs", g.cref, _lib.ptr_array([G.ptr for G in Gn]), _lib.ptr_array([f.ptr for f in prog]),
-                      _lib.i32_array([f.loc for f in prog]), arr, len(prog), s)
+        if boundary_contributions:
+            compute_boundary_tendency_contributions(model)
         return
     _lib.call("ocn_compute_momentum_tendencies", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
               Gn[2].ptr, r, s)
     for n, c in enumerate(model.tracers):
         _lib.call("ocn_compute_tracer_tendency", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, c.ptr, Gn[3 + n].ptr, r, s)
+
+
+def compute_boundary_tendency_contributions(model):
+    """compute_boundary_tendency_contributions! (compute_nonhydrostatic_tendencies.jl:152-195): bottom / top flux conditions"""
+    if not (model.general_terms and model._has_flux_bcs):
+        return
+    g, Gn, prog = model.grid, model.timestepper._Gn, model.prognostic_fields()
+    arr = (C.POINTER(_lib.CFieldBcs) * len(prog))(*[
+        (C.pointer(f.boundary_conditions.c_struct(g)) if f.boundary_conditions is not None and f.boundary_conditions.has_flux()
+         else C.POINTER(_lib.CFieldBcs)()) for f in prog])
+    _lib.call("ocn_apply_flux_bcs", g.cref, _lib.ptr_array([G.ptr for G in Gn]), _lib.ptr_array([f.ptr for f in prog]),
+              _lib.i32_array([f.loc for f in prog]), arr, len(prog), stream_ptr())
 
 
 compute_tendencies = compute_tendencies_
@@ -466,29 +486,38 @@ def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=Tru
     Gn, Gm = model.timestepper._Gn, model.timestepper._Gm
     model._pending_tendencies = False
     g, s = model.grid, stream_ptr()
-    if fill_halos:  # (Distributed: synchronous exchange; the auxiliaries need the exchanged halos)
-        fill_halo_regions(prog, fill_boundary_normal_velocities=False)
-        compute_auxiliaries(model)
     z, hz = (0.0, 0) if zeta is None else (float(zeta), 1)
     t = C.byref(model._terms)
     momentum_extra = (model.coriolis is not None or model.closure is not None or model.buoyancy is not None
                       or isinstance(model.advection, (Centered, UpwindBiased)) or _bcs_ref(model.u, g) is not None or _bcs_ref(model.v, g) is not None)
-    if momentum_extra:
-        _lib.call("ocn_compute_momentum_tendencies_terms_rk3", g.cref, t, _bcs_ref(model.u, g), _bcs_ref(model.v, g),
-                  model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr,
-                  alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(), float(dt), float(gamma), z, hz, None, s)
+
+    def launch(rng=None):
+        r = None if rng is None else _lib.i32_array(list(rng))
+        if momentum_extra:
+            _lib.call("ocn_compute_momentum_tendencies_terms_rk3", g.cref, t, _bcs_ref(model.u, g), _bcs_ref(model.v, g),
+                      model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr,
+                      alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(), float(dt), float(gamma), z, hz, r, s)
+        else:
+            _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                      Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
+                      float(dt), float(gamma), z, hz, None, 0.0, r, s)
+        for n, c in enumerate(model.tracers):
+            kappa, kappa_e = 0.0, None
+            if model.diffusivity_fields is not None:
+                kappa_e = model.diffusivity_fields["kappa_e"][n].ptr
+            elif model.closure is not None:
+                kappa = model.closure.kappa_of(model.tracer_names[n])
+            _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, kappa_e, _bcs_ref(c, g), model.u.ptr, model.v.ptr,
+                      model.w.ptr, c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[3 + n].data_ptr(), float(dt), float(gamma), z, hz, r, s)
+
+    hook = getattr(model.architecture, "update_state_general", None) if fill_halos else None
+    if hook is not None:  # Distributed: halo exchange overlapped with the interior auxiliaries and tendencies (distributed.py)
+        hook(model, launch)
     else:
-        _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
-                  Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
-                  float(dt), float(gamma), z, hz, None, 0.0, None, s)
-    for n, c in enumerate(model.tracers):
-        kappa, kappa_e = 0.0, None
-        if model.diffusivity_fields is not None:
-            kappa_e = model.diffusivity_fields["kappa_e"][n].ptr
-        elif model.closure is not None:
-            kappa = model.closure.kappa_of(model.tracer_names[n])
-        _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, kappa_e, _bcs_ref(c, g), model.u.ptr, model.v.ptr,
-                  model.w.ptr, c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[3 + n].data_ptr(), float(dt), float(gamma), z, hz, None, s)
+        if fill_halos:
+            fill_halo_regions(prog, fill_boundary_normal_velocities=False)
+            compute_auxiliaries(model)
+        launch()
     for n, f in enumerate(prog):
         f.data, alt[n] = alt[n], f.data
     model._refresh_term_pointers()
