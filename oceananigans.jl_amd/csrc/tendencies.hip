@@ -806,6 +806,25 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
     }
+    static const int strip_tiles = !(getenv("OCN_STRIP_TILES") && !strcmp(getenv("OCN_STRIP_TILES"), "0"));
+    if (strip_tiles && !force_direct && !fz.pc_on && grid->tz != OCN_FLAT && wx <= 3 && wy >= 64 && wz >= 4) {
+        // the halo-wide x-strips of a distributed run (buffer tendencies): the same shared-flux kernel with a 4 x 64 patch of
+        // columns (3 x 63 owned), i.e. tiled in y instead of x
+#define OCN_LAUNCH_STRIP(TZV)                                                                                                    \
+    do {                                                                                                                         \
+        constexpr int TX = 4, TY = 64;                                                                                           \
+        const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));                                                \
+        int KZ = wz;                                                                                                             \
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 1024) KZ = (KZ + 1) / 2;                                                 \
+        dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                        \
+        hipLaunchKernelGGL((momentum_tendencies_tiled<TZV, TX, TY, 3, false>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, \
+                           Gw, r, KZ, fz);                                                                                        \
+    } while (0)
+        if (grid->tz == OCN_PERIODIC) OCN_LAUNCH_STRIP(OCN_PERIODIC); else OCN_LAUNCH_STRIP(OCN_BOUNDED);
+#undef OCN_LAUNCH_STRIP
+        OCN_CHECK_HIP(hipGetLastError());
+        return OCN_SUCCESS;
+    }
     if (fz.pc_on) {
         ocn::set_error("pressure correction on load needs the tiled kernel (non-Flat z, range at least 16 x 8 x 4)");
         return OCN_ERR_UNSUPPORTED;
@@ -838,6 +857,20 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
         const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
         int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the bottom-flux prologue
         while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+        dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+        if (grid->tz == OCN_PERIODIC)
+            hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+        else
+            hipLaunchKernelGGL((tracer_tendency_tiled<OCN_BOUNDED, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+        OCN_CHECK_HIP(hipGetLastError());
+        return OCN_SUCCESS;
+    }
+    static const int strip_tiles = !(getenv("OCN_STRIP_TILES") && !strcmp(getenv("OCN_STRIP_TILES"), "0"));
+    if (strip_tiles && !tracer_direct && grid->tz != OCN_FLAT && wx <= 3 && wy >= 64 && wz >= 4) {  // halo-wide x-strips: 4 x 64 patches
+        constexpr int TX = 4, TY = 64;
+        const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+        int KZ = wz;
+        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 1024) KZ = (KZ + 1) / 2;
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
         if (grid->tz == OCN_PERIODIC)
             hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);

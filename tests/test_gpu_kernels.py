@@ -251,23 +251,24 @@ def test_tracer_kernel_ragged_sizes_and_fused_entry(oracle, ocn, size, topo, z, 
     np.testing.assert_array_equal(from_dev(dout)[mask], cnew[mask])
 
 
+@pytest.mark.parametrize("Ny", [24, 70])
 @pytest.mark.parametrize("topo,z", [("PPP", (0, 2.0)), ("PPB", "stretched")])
-def test_fused_rk3_ranges_tile_the_full_launch(oracle, ocn, topo, z):
+def test_fused_rk3_ranges_tile_the_full_launch(oracle, ocn, topo, z, Ny):
     """The slab-x interior / buffer split at a production-like width (nx = 64, Hx = 3: interior 4:61 takes the tiled kernel,
-    the two 3-wide buffers the direct one), with the substep epilogue: the three ranged launches of
-    ocn_compute_momentum_tendencies_rk3 reproduce the full launch bit for bit (G and the substepped velocities), and the
-    ranged tracer launches (tiled interior, direct buffers) with everything folded in do too."""
+    the two 3-wide buffers the direct one -- or, from Ny = 64, the shared-flux kernel with 4 x 64 patches), with the substep
+    epilogue: the three ranged launches of ocn_compute_momentum_tendencies_rk3 reproduce the full launch bit for bit (G and the
+    substepped velocities), and the ranged tracer launches with everything folded in do too."""
     import ctypes as C
     O = oracle
     rng = np.random.default_rng(77)
-    size = (64, 24, 20)
+    size = (64, Ny, 20)
     og, pg = _grid(O, ocn, size, topo, z)
     u, v, w = (random_parent(og, l, rng) for l in LOCS)
     Gm = [random_parent(og, l, rng) for l in LOCS]
     ocn.set_math_mode(ocn.MATH_STRICT)
     du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
     dGm = [to_dev(ocn, pg, l, a) for l, a in zip(LOCS, Gm)]
-    ranges = [None], [(4, 61, 1, 24, 1, 20), (1, 3, 1, 24, 1, 20), (62, 64, 1, 24, 1, 20)]
+    ranges = [None], [(4, 61, 1, Ny, 1, 20), (1, 3, 1, Ny, 1, 20), (62, 64, 1, Ny, 1, 20)]
     outs = []
     for rs in ranges:
         G = [ocn.Field(l, pg) for l in LOCS]
