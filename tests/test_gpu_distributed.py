@@ -243,6 +243,59 @@ def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, s
             assert np.abs(a - b[sl]).max() <= tol * scale, f"rank {r} field {name}: {np.abs(a - b[sl]).max()} vs {tol * scale}"
 
 
+@pytest.mark.parametrize("topo", ["PPP", "PPB"])
+def test_distributed_large_slabs_match_single_rank(ocn, topo):
+    """The slab pipelines at production-like extents (256 x 256 x 128 on R = 4 ranks: 64-wide slabs as at 512^3 / 8, column
+    counts and strides beyond 2^16 elements): one RK3 step in the default fast math against the single-rank model, plus
+    incompressibility of the distributed result."""
+    from helpers import stretched_faces
+    P = "Periodic"
+    R = 4
+    N = (256, 256, 128)
+    if topo == "PPP":
+        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    else:
+        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=stretched_faces(N[2], 2.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
+    rng = np.random.default_rng(99)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    if topo == "PPB":
+        init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
+    dt = 1e-3
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        sm = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO())
+        ocn.set(sm, **init)
+        ocn.time_step(sm, dt)
+        ocn.flush_tendencies(sm)
+        ocn.sync_device()
+        ref = [f.interior() for f in sm.velocities] + [sm.pNHS.interior()]
+        del sm
+
+        def rank_main(r, fabric):
+            arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+            g = ocn.RectilinearGrid(arch, size=N, **ext)
+            m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+            assert m.pressure_solver.impl.fast == (1 if topo == "PPP" else 2)
+            sl = slice(r * g.Nx, (r + 1) * g.Nx)
+            ocn.set(m, **{k: v[sl] for k, v in init.items()})
+            ocn.time_step(m, dt)
+            ocn.flush_tendencies(m)
+            ocn.sync_device()
+            return [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+
+        outs = _run_ranks(R, rank_main)
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    pscale = max(1.0, np.abs(ref[3]).max())
+    for r, fields in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "p")):
+            tol = 1e-10 * (pscale if name == "p" else scale)
+            assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}: {np.abs(a - b[sl]).max()} > {tol}"
+
+
 def test_distributed_halo_exchange_on_gpu(ocn):
     R = 2
     P = "Periodic"
