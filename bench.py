@@ -254,7 +254,7 @@ def main():
                      # SURVEY 8(d) books the reference's three tendency kernels at 3 x (3 r + 1 w) x 8 = 96 B/cell; against that
                      # accounting (the one step_roofline's 1680 B uses) the same launch reaches:
                      "frac_at_reference_accounting_96B": 96.0 * local_cells / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "note": "fp64-VALU-bound kernel (~1100 DP instr/cell, 77% VALU issue utilisation): see DESIGN.md section 4"},
+                     "note": "fp64-VALU-bound kernel (~690 fp64 VALU of ~1190 instructions per cell, 77% VALU issue utilisation): see DESIGN.md section 4"},
         "step_roofline": {"algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
                           "achieved_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,
                           "frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world)},
