@@ -40,6 +40,8 @@ def parse():
                     help="box: the metric's triply-periodic N^3 box (default); config4: BASELINE.json configs[3], the "
                          "ocean_wind_mixing_and_convection setup on N x N x N/2 (Periodic, Periodic, Bounded) with stretched z")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--driver", choices=("python", "c"), default="python",
+                    help="host orchestration of the step: the Python mirror of the reference's time_step!, or ocn_rk3_driver_time_step (one C call per step; box workload, one GPU)")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
@@ -184,14 +186,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.driver == "c":
+        if world > 1 or a.workload != "box":
+            raise SystemExit("--driver c: box workload on one GPU")
+        drv = ocn.RK3Driver(model)
+        step, flush = (lambda: drv.time_step(dt)), drv.flush
+    else:
+        step, flush = (lambda: ocn.time_step(model, dt)), (lambda: ocn.flush_tendencies(model))
     for _ in range(a.warmup):
-        ocn.time_step(model, dt)
-    ocn.flush_tendencies(model)
+        step()
+    flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        ocn.time_step(model, dt)
-    ocn.flush_tendencies(model)  # the deferred last compute_tendencies! belongs to the timed steps
+        step()
+    flush()  # the deferred last compute_tendencies! belongs to the timed steps
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:

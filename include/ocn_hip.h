@@ -308,6 +308,25 @@ int ocn_poisson_solve(ocn_poisson_t solver, double *p, void *stream);
 int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, const double *v, const double *w, double dt,
                            void *stream);
 
+/* ---- time_step!(model, Δt) of the RungeKutta3 NonhydrostaticModel in ONE call (src/TimeSteppers/runge_kutta_3.jl:77-151):
+ * WENO5 advection, no tracers / extra terms, (Periodic, Periodic, Periodic | Bounded | Flat), one GPU.  The handle owns a second
+ * set of velocity arrays, G^n, G^- and the pressure solver, and alternates their roles so that the stage boundaries run fused
+ * (DESIGN.md section 5); it issues the same entry points in the same order as the Python host and is bit-identical to it.
+ *   create:    u, v, w, p = the caller's parent arrays (initial velocities in the interiors); fills their halos.  `solver`: an
+ *              existing ocn_poisson_t of the same grid to borrow, or NULL.
+ *   time_step: one RK3 step; afterwards the velocities live EITHER in the caller's arrays or in the second set, and the last
+ *              compute_tendencies! is deferred into the next step.
+ *   flush:     completes the deferred tendencies and brings the velocities into the caller's arrays (one copy, if needed);
+ *              call it before reading u, v, w, G^n on the host side or handing them to other code.
+ *   fields:    where the velocities and G^n are right now (device pointers, valid until the next call). */
+typedef struct ocn_rk3_driver *ocn_rk3_driver_t;
+int ocn_rk3_driver_create(ocn_rk3_driver_t *driver, const ocn_grid *grid, double *u, double *v, double *w, double *p,
+                          ocn_poisson_t solver /* NULL: the handle creates its own */, void *stream);
+int ocn_rk3_driver_destroy(ocn_rk3_driver_t driver);
+int ocn_rk3_driver_time_step(ocn_rk3_driver_t driver, double dt, void *stream);
+int ocn_rk3_driver_flush(ocn_rk3_driver_t driver, void *stream);
+int ocn_rk3_driver_fields(ocn_rk3_driver_t driver, double **u, double **v, double **w, double **Gu, double **Gv, double **Gw);
+
 /* solve!(ϕ, ::BatchedTridiagonalSolver, rhs), z direction (src/Solvers/batched_tridiagonal_solver.jl:100-123,
  * 203-235).  a, c: real Nz-1; b: real Nx*Ny*Nz; f, phi: complex interleaved Nx*Ny*Nz; t: real scratch. */
 int ocn_batched_tridiagonal_solve_z(int32_t Nx, int32_t Ny, int32_t Nz, const double *a, const double *b, const double *c,

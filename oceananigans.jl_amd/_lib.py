@@ -99,6 +99,11 @@ _SIGS = {
     "ocn_batched_tridiagonal_solve_z": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_halo_pack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
+    "ocn_rk3_driver_create": [C.POINTER(_vp), C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_rk3_driver_destroy": [_vp],
+    "ocn_rk3_driver_time_step": [_vp, _dbl, _vp],
+    "ocn_rk3_driver_flush": [_vp, _vp],
+    "ocn_rk3_driver_fields": [_vp] + [C.POINTER(_vp)] * 6,
     "ocn_halo_plane_x": [C.POINTER(CGrid), _vp, _i32, _i32, _vp, _i32, _vp],
     "ocn_halo_pack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],

@@ -597,3 +597,41 @@ def _time_step_qab2(model, dt, euler=False):
     pressure_correct_velocities(model, dt)
     cache_previous_tendencies(model)
     update_state(model, compute_tendencies=True)
+
+
+class RK3Driver:
+    """The whole RK3 time_step! behind ONE entry point of the C ABI (ocn_rk3_driver_*, csrc/driver.hip): what a Julia host binds
+    when it wants the fused stage boundaries without managing alternating array roles itself.  Wraps the velocity and pressure
+    fields of a plain WENO model (no tracers, no extra terms, one GPU); bit-identical to `time_step(model, dt)`."""
+
+    def __init__(self, model, own_solver=False):
+        if model.tracers or model.general_terms or hasattr(model.grid.architecture, "partition"):
+            raise NotImplementedError("RK3Driver: WENO advection only (no tracers / extra terms), one GPU")
+        if not isinstance(model.timestepper, RungeKutta3TimeStepper) or not isinstance(model.advection, WENO):
+            raise NotImplementedError("RK3Driver: RungeKutta3 + WENO()")
+        flush_tendencies(model)
+        self.model = model
+        self._h = C.c_void_p()
+        _lib.call("ocn_rk3_driver_create", C.byref(self._h), model.grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, model.pNHS.ptr,
+                  None if own_solver else model.pressure_solver._h, stream_ptr())  # borrows the model's solver handle by default
+
+    def time_step(self, dt):
+        _lib.call("ocn_rk3_driver_time_step", self._h, float(dt), stream_ptr())
+
+    def flush(self):
+        """velocities back in the model's fields, deferred tendencies completed"""
+        _lib.call("ocn_rk3_driver_flush", self._h, stream_ptr())
+
+    def tendency_pointers(self):
+        ptrs = [C.c_void_p() for _ in range(6)]
+        _lib.call("ocn_rk3_driver_fields", self._h, *[C.byref(p) for p in ptrs])
+        return [p.value for p in ptrs[3:]]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ocn_rk3_driver_destroy(h)
+            except Exception:
+                pass
+            self._h = None

@@ -362,3 +362,45 @@ def test_cell_advection_timescale_and_wizard(ocn, topo, z):
     assert ocn.TimeStepWizard(cfl=1.0, max_dt=tau / 3, max_change=100)(m, tau) == tau / 3
     rest = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
     assert ocn.cell_advection_timescale(rest) == float("inf")
+
+
+@pytest.mark.parametrize("size,topo,z,own", [((32, 16, 12), "PPP", (0, 2.0), False), ((16, 12, 9), "PPB", "stretched", False),
+                                             ((12, 9, 5), "PPP", (0, 1.0), False), ((24, 16, 1), "PPF", None, False),
+                                             ((128, 64, 64), "PPP", (0, 2.0), True)])  # own solver handle: hand-written FFT pipeline
+def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own):
+    """ocn_rk3_driver_time_step (the whole RK3 step behind one C entry point, csrc/driver.hip) against the Python host's
+    time_step: same launches in the same order, so velocities, pressure and G^n agree bit for bit after 3 steps (and after an
+    intermediate flush, which brings the velocities back into the caller's arrays and breaks the deferral chain)."""
+    import ctypes as C
+    O = oracle
+    rng = np.random.default_rng(5)
+    og, pg = _grid(O, ocn, size, topo, z)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    init = {}
+    for name, l in zip("uvw", LOCS):
+        a = og.zeros(l)
+        init[name] = rng.uniform(-1, 1, og.interior(a).shape)
+    if topo == "PPF":
+        init.pop("w")
+
+    def build():
+        m = ocn.NonhydrostaticModel(pg, advection=ocn.WENO())
+        ocn.set(m, **init)
+        return m
+
+    dt = 0.01
+    ref = build()
+    for _ in range(3):
+        ocn.time_step(ref, dt)
+    ocn.flush_tendencies(ref)
+    m = build()
+    drv = ocn.RK3Driver(m, own_solver=own)
+    drv.time_step(dt)
+    drv.flush()            # exercise the copy-home path between steps
+    drv.time_step(dt)
+    drv.time_step(dt)
+    drv.flush()
+    ocn.sync_device()
+    for a, b in zip(ref.velocities + (ref.pNHS,), m.velocities + (m.pNHS,)):
+        np.testing.assert_array_equal(from_dev(a), from_dev(b))
+    del drv
