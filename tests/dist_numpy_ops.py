@@ -126,8 +126,109 @@ class _NumpyDistTridiagonal(_NumpyDistPoisson):
         fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = self.y.real
 
 
+class _NumpyDistSlab(_NumpyDistPoisson):
+    """The slab pipeline of libocn_hip's distributed FFT solver (ocn_hip.h, ocn_dist_poisson_pipeline == 1) restated with numpy:
+    real transform along y and complex along z on the slab, the half spectrum handed to the all-to-all as
+    send[d][ky + NyH (kz_l + cz xl)] (kz = d cz + kz_l), x transform + division + inverse x transform in place on
+    recv[xg][kz_l][ky], the return exchange recv -> send, inverse z and inverse real y into p.  (The library keeps kz and kx in
+    its column kernels' stage order; any consistent order works -- here the natural one.)"""
+    fast = 1
+
+    def __init__(self, grid, arch):
+        super().__init__(grid, arch)
+        nx, Ny, Nz = grid.Nx, grid.Ny, grid.Nz
+        assert Nz % self.R == 0
+        self.NyH, self.cz = Ny // 2 + 1, Nz // self.R
+        n = self.NyH * nx * Nz * 2
+        self.send, self.recv = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+
+    def forward_yz(self):
+        nx, Nz, R, cz, NyH = self.g.Nx, self.g.Nz, self.R, self.cz, self.NyH
+        A = sfft.fft(sfft.rfft(self.y.real, axis=1), axis=2)                       # (nx, NyH, Nz)
+        arr = np.transpose(A.reshape(nx, NyH, R, cz), (2, 0, 3, 1))                # (d, xl, kz_l, ky): ky fastest in C order
+        self._cbuf(self.send)[...] = np.ascontiguousarray(arr).ravel()
+
+    def solve_x(self):
+        nx, R, cz, NyH = self.g.Nx, self.R, self.cz, self.NyH
+        X = self._cbuf(self.recv).reshape(R * nx, cz, NyH)                          # (xg = r nx + xl, kz_l, ky), in place
+        xh = sfft.fft(X, axis=0)
+        lam = (self.lx[:, None, None] + self.ly[None, None, :NyH]) + self.lz[None, self.rank * cz:(self.rank + 1) * cz, None]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xh = -xh / lam
+        if self.rank == 0:
+            xh[0, 0, 0] = 0.0
+        X[...] = sfft.ifft(xh, axis=0)
+
+    def backward_yz(self, p):
+        nx, Ny, Nz, R, cz, NyH = self.g.Nx, self.g.Ny, self.g.Nz, self.R, self.cz, self.NyH
+        arr = self._cbuf(self.send).reshape(R, nx, cz, NyH)                         # (d, xl, kz_l, ky)
+        A = np.transpose(arr, (1, 3, 0, 2)).reshape(nx, NyH, Nz)
+        y = sfft.irfft(sfft.ifft(A, axis=2), n=Ny, axis=1)
+        g = self.g
+        fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = y
+
+
+class _NumpyDistSlabTridiagonal(_NumpyDistTridiagonal):
+    """The tridiagonal flavour of the slab pipeline (ocn_dist_poisson_pipeline == 2): the half spectrum is partitioned by ky in R
+    zero-padded chunks of c = ceil(NyH / R); send[d][ky_l + c (z + Nz xl)]; after the exchange recv[xg][z][ky_l]: FFT_x, Thomas
+    sweep in z with this rank's ky range, zero-mean gauge on rank 0, IFFT_x into `send`; exchanged back (send -> recv again),
+    inverse real y into p."""
+    fast = 2
+
+    def __init__(self, grid, arch):
+        self.g, self.R, self.rank = grid, arch.partition.x, arch.local_rank
+        nx, Ny, Nz = grid.Nx, grid.Ny, grid.Nz
+        self.Nxg, self.NyH = nx * self.R, Ny // 2 + 1
+        self.c = -(-self.NyH // self.R)
+        self.y = np.zeros((nx, Ny, Nz), dtype=np.complex128, order="F")
+        n = self.c * self.R * Nz * nx * 2
+        self.send, self.recv = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+        zf = getattr(grid, "z_faces", None)
+        z = (0.0, grid.Lz) if zf is None else np.asarray(zf)[grid.Hz:grid.Hz + Nz + 1]
+        halo = (grid.Hx, grid.Hy, grid.Hz)
+        self.og = O.Grid((nx, Ny, Nz), x=(0, grid.Lx), y=(0, grid.Ly), z=z, topology="PPB", halo=halo)
+        self.local = O.FourierTridiagonalPoissonSolver(self.og)
+        xg = O.Grid((self.Nxg, self.c, Nz), x=(0, grid.global_Lx), y=(0, grid.Ly), z=z, topology="PPB",
+                    halo=(min(halo[0], self.Nxg), min(halo[1], self.c), halo[2]))
+        self.xs = O.FourierTridiagonalPoissonSolver(xg)
+        lx = O.poisson_eigenvalues(self.Nxg, grid.global_Lx, O.PERIODIC)
+        lyp = np.ones(self.c * self.R)
+        lyp[:self.NyH] = O.poisson_eigenvalues(Ny, grid.Ly, O.PERIODIC)[:self.NyH]
+        ly = np.ascontiguousarray(lyp[self.rank * self.c:(self.rank + 1) * self.c])
+        O.lib().ocn_oracle_main_diagonal_z(O.C.byref(self.xs._cg), lx.ctypes.data_as(O.C.c_void_p), ly.ctypes.data_as(O.C.c_void_p),
+                                           self.xs.D.ctypes.data_as(O.C.c_void_p))
+
+    def forward_yz(self):
+        nx, Nz, R, c, NyH = self.g.Nx, self.g.Nz, self.R, self.c, self.NyH
+        A = np.zeros((nx, R * c, Nz), dtype=np.complex128)
+        A[:, :NyH] = sfft.rfft(self.y.real, axis=1)
+        arr = np.transpose(A.reshape(nx, R, c, Nz), (1, 0, 3, 2))                  # (d, xl, z, ky_l): ky_l fastest in C order
+        self._cbuf(self.send)[...] = np.ascontiguousarray(arr).ravel()
+
+    def solve_x(self):
+        nx, Nz, R, c = self.g.Nx, self.g.Nz, self.R, self.c
+        X = self._cbuf(self.recv).reshape(R * nx, Nz, c)                            # (xg, z, ky_l)
+        xh = np.asfortranarray(np.transpose(sfft.fft(X, axis=0), (0, 2, 1)))        # (kx, ky_l, z) for the oracle's sweep
+        phi = O.batched_tridiagonal_solve_z(self.xs.a, self.xs.D, self.xs.a, xh)
+        if self.rank == 0:
+            phi[0, 0, :] -= np.mean(phi[0, 0, :])
+        out = np.transpose(sfft.ifft(phi, axis=0), (0, 2, 1))                       # back to (xg, z, ky_l)
+        self._cbuf(self.send)[...] = np.ascontiguousarray(out).ravel()
+
+    def backward_yz(self, p):
+        nx, Ny, Nz, R, c, NyH = self.g.Nx, self.g.Ny, self.g.Nz, self.R, self.c, self.NyH
+        arr = self._cbuf(self.recv).reshape(R, nx, Nz, c)                           # (d, xl, z, ky_l)
+        A = np.transpose(arr, (1, 0, 3, 2)).reshape(nx, R * c, Nz)[:, :NyH]
+        y = sfft.irfft(A, n=Ny, axis=1)
+        g = self.g
+        fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = y
+
+
 class NumpyOps:
     name = "numpy"
+
+    def __init__(self, slab=False):
+        self.slab = slab  # restate the library's slab pipelines instead of the transposing reference choreography
 
     def new_buffer(self, arch, n):
         return torch.zeros(n, dtype=torch.float64)
@@ -177,5 +278,5 @@ class NumpyOps:
 
     def make_dist_poisson(self, grid, arch):
         if grid.topology[2] == "Bounded":
-            return _NumpyDistTridiagonal(grid, arch)
-        return _NumpyDistPoisson(grid, arch)
+            return (_NumpyDistSlabTridiagonal if self.slab else _NumpyDistTridiagonal)(grid, arch)
+        return (_NumpyDistSlab if self.slab and grid.Nz % arch.partition.x == 0 else _NumpyDistPoisson)(grid, arch)

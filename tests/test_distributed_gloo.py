@@ -31,7 +31,7 @@ def _worker(rank, world, port, fn, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import oceananigans_jl_amd as ocn
         from dist_numpy_ops import HostArch, NumpyOps
-        arch = ocn.Distributed(HostArch(), partition=ocn.Partition(world), ops=NumpyOps())
+        arch = ocn.Distributed(HostArch(), partition=ocn.Partition(world), ops=NumpyOps(slab=os.environ.get("OCN_TEST_SLAB") == "1"))
         fn(rank, world, ocn, arch)
         dist.barrier()
         dist.destroy_process_group()
@@ -145,6 +145,37 @@ def _poisson_matches_global(rank, world, ocn, arch):
     assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def _slab_fft_matches_global(rank, world, ocn, arch):
+    """as _poisson_matches_global with Nz a multiple of the number of ranks, so that the kz-partitioned pipeline applies"""
+    from oracle import oracle as O
+    Nx, Ny, Nz = 12, 6 * world, 2 * world * 2
+    g = _local_grid(ocn, arch, size=(Nx, Ny, Nz))
+    og = O.Grid((Nx, Ny, Nz), x=(0, 3.0), y=(0, 2.0), z=(0, 1.0), topology="PPP", halo=(3, 3, 3))
+    rng = np.random.default_rng(43)
+    hosts = []
+    for loc in (1, 2, 4):
+        a = og.zeros(loc)
+        og.interior(a)[...] = rng.random((Nx, Ny, Nz))
+        O.fill_halo_regions(og, a, loc)
+        hosts.append(a)
+    S = O.FFTBasedPoissonSolver(og)
+    p0 = og.zeros(0)
+    S.source_term(*hosts, 0.7)
+    S.solve(p0)
+    nx = g.Nx
+    U = [ocn.Field(loc, g) for loc in (1, 2, 4)]
+    for f, a in zip(U, hosts):
+        f.set(og.interior(a)[rank * nx:(rank + 1) * nx])
+    ocn.fill_halo_regions(U)
+    solver = ocn.nonhydrostatic_pressure_solver(g)
+    assert solver.impl.fast == 1
+    p = ocn.CenterField(g)
+    ocn.solve_for_pressure(p, solver, 0.7, U)
+    mine = p.interior()
+    ref = og.interior(p0)[rank * nx:(rank + 1) * nx]
+    assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def _tridiagonal_poisson_matches_global(rank, world, ocn, arch):
     """(x-partitioned, Periodic, Bounded) stretched z: the distributed Fourier-tridiagonal solve equals the single-process
     FourierTridiagonalPoissonSolver on the assembled field (test_distributed_poisson_solvers.jl:128-148 re-expressed)."""
@@ -202,3 +233,13 @@ def test_distributed_poisson_matches_global_solve(world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_tridiagonal_poisson_matches_global_solve(world):
     _run(world, _tridiagonal_poisson_matches_global)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("flavour", ["fft", "tridiagonal"])
+def test_slab_pipeline_choreography_matches_global_solve(world, flavour, monkeypatch):
+    """The exchange layouts and directions of the library's slab pipelines (send -> recv, then recv -> send for the FFT flavour,
+    send -> recv again for the tridiagonal one; chunking by kz / by zero-padded ky) restated in numpy and run through the real
+    DistributedFFTBasedPoissonSolver.solve over gloo ranks."""
+    monkeypatch.setenv("OCN_TEST_SLAB", "1")
+    _run(world, _slab_fft_matches_global if flavour == "fft" else _tridiagonal_poisson_matches_global)
