@@ -89,12 +89,12 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
     const double qdzf[2] = {dzf[0], dzf[1]};
 #else
 #define AMD_D(num, den) ((num) * (den))  /* den holds the reciprocal */
-    const double rFx = 1 / Fx, rFy = 1 / Fy, rFz[2] = {1 / Fz[0], 1 / Fz[1]};
+    const double rFx = fast_rcp(Fx), rFy = fast_rcp(Fy), rFz[2] = {fast_rcp(Fz[0]), fast_rcp(Fz[1])};
     const double rxy = Fx * rFy, ryx = Fy * rFx;
     const double rxz[2] = {Fx * rFz[0], Fx * rFz[1]}, rzx[2] = {Fz[0] * rFx, Fz[1] * rFx};
     const double ryz[2] = {Fy * rFz[0], Fy * rFz[1]}, rzy[2] = {Fz[0] * rFy, Fz[1] * rFy};
-    const double qdx = 1 / dx, qdy = 1 / dy, qdzc = 1 / dzc0;
-    const double qdzf[2] = {1 / dzf[0], 1 / dzf[1]};
+    const double qdx = fast_rcp(dx), qdy = fast_rcp(dy), qdzc = fast_rcp(dzc0);
+    const double qdzf[2] = {fast_rcp(dzf[0]), fast_rcp(dzf[1])};
 #endif
     double dyu[2][2], dxv[2][2], dzu[2][2], dxw[2][2], dzv[2][2], dyw[2][2], dywq[2][2];
 #pragma unroll
@@ -112,7 +112,13 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
     }
     const double dxu = AMD_D(A.U(1, 0, 0) - A.U(0, 0, 0), qdx), dyv = AMD_D(A.V(0, 1, 0) - A.V(0, 0, 0), qdy),
                  dzw = AMD_D(A.W(0, 0, 1) - A.W(0, 0, 0), qdzc);
+#if OCN_STRICT
     const double d2 = 3 / ((1 / (Fx * Fx) + 1 / (Fy * Fy)) + 1 / (Fz[0] * Fz[0]));
+#define AMD_Q(num, den) ((num) / (den))
+#else
+    const double d2 = 3 * fast_rcp((rFx * rFx + rFy * rFy) + rFz[0] * rFz[0]);
+#define AMD_Q(num, den) ((num) * fast_rcp(den))
+#endif
 
     if (nu_e) {
         double s12[2][2], s13[2][2], s23[2][2];
@@ -135,8 +141,12 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
             const double r3 = ((((dxu * zu2 + dyv * zv2) + dzw * (dzw * dzw)) + 2 * I4(dzu) * I4(dzv) * I4(s12)) + 2 * dzw * I4PR(dzu, s13)) +
                               2 * dzw * I4PR(dzv, s23);
             const double r = (r1 + r2) + r3;
+#if OCN_STRICT
             const double Cb_zeta = 0.0 / Fz[0];  // Cb = nothing
-            nu = -Cnu * d2 * (r - Cb_zeta) / q;
+#else
+            const double Cb_zeta = 0.0;
+#endif
+            nu = AMD_Q(-Cnu * d2 * (r - Cb_zeta), q);
         }
         nu_e[o] = julia_max0(nu);
     }
@@ -160,12 +170,13 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
                 const double cy_uy = (ixy_dyu * cy * cx + dyv * yc2) + ixz_dywq * cy * cz;  // ℑxz of norm_∂y_w, as the reference (:313)
                 const double cz_uz = (ixz_dzu * cz * cx + iyz_dzv * cz * cy) + dzw * zc2;
                 const double theta = (cx_ux + cy_uy) + cz_uz;
-                kap = -tr.Ck[n] * d2 * theta / sigma;
+                kap = AMD_Q(-tr.Ck[n] * d2 * theta, sigma);
             }
             tr.kappa_e[n][o] = julia_max0(kap);
         }
     }
 #undef AMD_D
+#undef AMD_Q
 }
 #undef I4
 #undef I4SQ

@@ -177,7 +177,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
     const double dx = M.dx, dy = M.dy, nu = t.nu;
     const double dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = ZF ? dzf : M.dzF(k + 1), dzcm = ZF ? dzc : M.dzC(k - 1);
 #if !OCN_STRICT
-    const double rdx = 1 / dx, rdy = 1 / dy, rdzc = 1 / dzc, rdzf = 1 / dzf, rdzf1 = 1 / dzf1, rdzcm = 1 / dzcm;
+    const double rdx = fast_rcp(dx), rdy = fast_rcp(dy), rdzc = fast_rcp(dzc), rdzf = fast_rcp(dzf), rdzf1 = fast_rcp(dzf1), rdzcm = fast_rcp(dzcm);
 #endif
     // strain-rate pieces (velocity_tracer_gradients.jl); δ along a Flat z is 0
 #define DX(a, b) OCN_DIV((a) - (b), dx, rdx)
@@ -217,7 +217,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
                 const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
                 dzF = Az * t13t - Az * t13b;
             }
-            G = G - 1 / (Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
+            G = G - recip_volume(Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
         }
         if (TZ == OCN_BOUNDED) {
             if (k == 1 && mf.bottom[0].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(1));
@@ -244,7 +244,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
                 const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
                 dzF = Az * t23t - Az * t23b;
             }
-            G = G - 1 / (Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
+            G = G - recip_volume(Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
         }
         if (TZ == OCN_BOUNDED) {
             if (k == 1 && mf.bottom[1].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(1));
@@ -273,7 +273,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
                 const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(Wf(0, 0, 0) - Wf(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
                 dzF = Az * t33t - Az * t33b;
             }
-            G = G - 1 / (Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
+            G = G - recip_volume(Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
         }
         Gw[o] = G;
         const bool wall = (TZ == OCN_BOUNDED) && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face

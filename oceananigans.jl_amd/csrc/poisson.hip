@@ -87,8 +87,16 @@ struct Plan {
     }
     void destroy()
     {
-        if (plan) rocfft_plan_destroy(plan);
-        if (info) rocfft_execution_info_destroy(info);
+        // rocFFT (ROCm 7.2) plans share cached state: destroying one plan has been seen to corrupt the results of another,
+        // still live, real-transform plan of a different handle (order-dependent failures of small-grid solves, see DESIGN.md
+        // "rocFFT plan self-test").  Plans are therefore retired, not destroyed: the rocfft_plan / execution_info objects (a few
+        // KB each) live until the process ends; only the work buffer is released.  OCN_ROCFFT_DESTROY_PLANS=1 restores the
+        // eager destruction.
+        static const bool eager = std::getenv("OCN_ROCFFT_DESTROY_PLANS") && std::getenv("OCN_ROCFFT_DESTROY_PLANS")[0] == '1';
+        if (eager) {
+            if (plan) rocfft_plan_destroy(plan);
+            if (info) rocfft_execution_info_destroy(info);
+        }
         if (work) (void)hipFree(work);
         plan = nullptr; info = nullptr; work = nullptr;
     }
@@ -320,7 +328,39 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
     return OCN_SUCCESS;
 }
 
-// forward then inverse transform of a pseudo-random field must reproduce it (times the plans' net scale)
+// Known-answer check of a forward transform: a few entries of the device spectrum against a direct DFT sum of the same input on
+// the host.  The round trip alone does not catch a forward / inverse pair that is wrong in a mutually consistent way (seen
+// with rocFFT real plans whose shape matches an earlier plan of different strides: the round trip reproduced the input while the
+// spectrum itself was permuted).  spec(kx, ky, kz) at kx + nxh (ky + Ny kz); dims3 = the plan transforms z as well.
+static double spectrum_sample_error(const std::vector<double> &in, const std::vector<double> &spec, int Nx, int Ny, int Nz, int nxh,
+                                    bool dims3)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const int kxs[3] = {0, 1 % nxh, (nxh - 1)}, kys[3] = {0, 2 % Ny, Ny - 1}, kzs[3] = {0, 1 % Nz, Nz - 1};
+    double worst = 0.0;
+    for (int q = 0; q < 3; ++q) {
+        const int kx = kxs[q], ky = kys[(q + 1) % 3], kz = kzs[(q + 2) % 3];
+        // 2-D plans are batched over z: the sample is the (kx, ky) entry of plane kz
+        double re = 0.0, im = 0.0;
+        const int z0 = dims3 ? 0 : kz, z1 = dims3 ? Nz : kz + 1;
+        for (int k = z0; k < z1; ++k)
+            for (int j = 0; j < Ny; ++j) {
+                const double pyz = (double)ky * j / Ny + (dims3 ? (double)kz * k / Nz : 0.0);
+                for (int i = 0; i < Nx; ++i) {
+                    const double ph = -two_pi * ((double)kx * i / Nx + pyz);
+                    const double v = in[i + (size_t)Nx * (j + (size_t)Ny * k)];
+                    re += v * std::cos(ph);
+                    im += v * std::sin(ph);
+                }
+            }
+        const size_t o = 2 * ((size_t)kx + (size_t)nxh * (ky + (size_t)Ny * kz));
+        worst = std::fmax(worst, std::fmax(std::fabs(spec[o] - re), std::fabs(spec[o + 1] - im)));
+    }
+    return worst;
+}
+
+// forward then inverse transform of a pseudo-random field must reproduce it (times the plans' net scale), and the forward
+// spectrum must be the DFT of the input
 static int poisson_plans_self_test(ocn_poisson *s)
 {
     const ocn_grid *g = &s->grid;
@@ -339,13 +379,16 @@ static int poisson_plans_self_test(ocn_poisson *s)
         z ^= z >> 31;
         in[q] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
     }
-    double err = 0.0;
+    double err = 0.0, ferr = 0.0;
     if (s->c2c) {
         std::vector<double> c(2 * n, 0.0);
         for (size_t q = 0; q < n; ++q) c[2 * q] = in[q];
         OCN_CHECK_HIP(hipMemcpy(s->spec, c.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
         int st = s->fwd.exec(s->spec, nullptr, nullptr);
         if (st != OCN_SUCCESS) return st;
+        OCN_CHECK_HIP(hipDeviceSynchronize());
+        OCN_CHECK_HIP(hipMemcpy(c.data(), s->spec, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+        ferr = spectrum_sample_error(in, c, Nx, Ny, Nz, Nx, three_d);
         st = s->bwd.exec(s->spec, nullptr, nullptr);
         if (st != OCN_SUCCESS) return st;
         OCN_CHECK_HIP(hipDeviceSynchronize());
@@ -363,6 +406,12 @@ static int poisson_plans_self_test(ocn_poisson *s)
         OCN_CHECK_HIP(hipMemcpy(s->rhs, in.data(), n * sizeof(double), hipMemcpyHostToDevice));
         int st = s->fwd.exec(s->rhs, s->spec, nullptr);
         if (st != OCN_SUCCESS) return st;
+        {
+            OCN_CHECK_HIP(hipDeviceSynchronize());
+            std::vector<double> sp((size_t)s->nxh * Ny * Nz * 2);
+            OCN_CHECK_HIP(hipMemcpy(sp.data(), s->spec, sp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            ferr = spectrum_sample_error(in, sp, Nx, Ny, Nz, s->nxh, three_d);
+        }
         if (s->direct_out) {
             OCN_CHECK_HIP(hipMalloc((void **)&tmp, np * sizeof(double)));
             OCN_CHECK_HIP(hipMemset(tmp, 0, np * sizeof(double)));
@@ -391,8 +440,9 @@ static int poisson_plans_self_test(ocn_poisson *s)
         OCN_CHECK_HIP(hipMemset(s->rhs, 0, n * sizeof(double)));
         OCN_CHECK_HIP(hipMemset(s->spec, 0, (size_t)s->nxh * Ny * Nz * 2 * sizeof(double)));
     }
-    if (!(err <= 1e-9 * net)) {
-        ocn::set_error("rocFFT %s plan pair for %dx%dx%d failed its round-trip self test (max error %.3e)", s->c2c ? "complex" : "real", Nx, Ny, Nz, err);
+    if (!(err <= 1e-9 * net) || !(ferr <= 1e-9 * count)) {
+        ocn::set_error("rocFFT %s plan pair for %dx%dx%d failed its self test (round trip: max error %.3e; forward spectrum vs direct DFT: %.3e)",
+                       s->c2c ? "complex" : "real", Nx, Ny, Nz, err, ferr);
         return OCN_ERR_ROCFFT;
     }
     return OCN_SUCCESS;

@@ -506,7 +506,7 @@ __device__ __forceinline__ double tracer_finish(double G, const Metrics &M, cons
 #if OCN_STRICT
 #define OCN_TD(a, d) ((a) / (d))
 #else
-#define OCN_TD(a, d) ((a) * (1 / (d)))
+#define OCN_TD(a, d) ((a) * fast_rcp(d))
 #endif
         const double qxe = -(kxe * OCN_TD(cxp - c0, dx)), qxw = -(kxw * OCN_TD(c0 - cxm, dx));
         const double qyn = -(kyn * OCN_TD(cyp - c0, dy)), qys = -(kys * OCN_TD(c0 - cym, dy));
@@ -517,7 +517,7 @@ __device__ __forceinline__ double tracer_finish(double G, const Metrics &M, cons
             dzq = az * qzt - az * qzb;
         }
 #undef OCN_TD
-        G = G - 1 / (az * dzc) * (((ax * qxe - ax * qxw) + (ay * qyn - ay * qys)) + dzq);
+        G = G - recip_volume(az * dzc) * (((ax * qxe - ax * qxw) + (ay * qyn - ay * qys)) + dzq);
     }
     if (TZ == OCN_BOUNDED) {  // apply_z_bcs!: k is uniform across the workgroup
         if (k == 1 && tf.bottom.kind == OCN_BC_FLUX) G += ocn::bc_condition(tf.bottom, i, j, g.Nx, c0) * az / (az * M.dzC(1));
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
         const double fz1 = tracer_flux<TZ>(az, pw[Lw.s3], pc + Lc.s3, Lc.s3, k + 1, g.Nz), fz0 = tracer_flux<TZ>(az, pw[0], pc, Lc.s3, k, g.Nz);
         dzF = fz1 - fz0;
     }
-    const double rV = 1 / (M.Az * M.dzC(k));
+    const double rV = recip_volume(M.Az * M.dzC(k));
     double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
     const long long o = ocn::at(Lc, i, j, k), s2 = Lc.s2, s3 = (TZ == OCN_FLAT) ? 0 : Lc.s3;
     if (tf.diffusion || tf.bottom.kind || tf.top.kind)
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(TX *TY) void tracer_tendency_tiled(GridDev g, const
         __syncthreads();
         if (writes) {
             const double fxe = ex[0][tid + 1], fyn = ex[1][tid + TX];
-            const double rV = 1 / (M.Az * M.dzC(k));
+            const double rV = recip_volume(M.Az * M.dzC(k));
             double G = -(rV * (((fxe - fxw) + (fyn - fys)) + (fzt - fzb)));
             if (tf.diffusion || tf.bottom.kind || tf.top.kind)
                 G = tracer_finish<TZ>(G, M, g, tf, i, j, k, K, zc[2], cxm, cxp, cym, cyp, zc[1], zc[3], ax, ay, az);
