@@ -159,6 +159,7 @@ class Distributed:
         g = fields[0].grid
         if self.partition.x == 1:
             return None
+        self.finish_halo_exchange()  # an exchange left in flight by a deferred update_state! completes first
         fields = tuple(fields)
         (sw, se, rw, re), spans = self._halo_buffers(fields)
         if hasattr(self.ops, "pack_x_fields"):
@@ -197,6 +198,7 @@ class Distributed:
         neighbour's f[nx, :, :] (what ∂xᶠᶜᶜ reads of the pressure).  For the two synchronous fills inside the pressure projection,
         whose fields get their complete exchange in the following update_state!."""
         g = f.grid
+        self.finish_halo_exchange()
         self.ops.local_fill(g, fields, True)
         if self.partition.x == 1 or not hasattr(self.ops, "plane_x"):
             return self.fill_halo_regions(fields) if self.partition.x > 1 else None
@@ -222,10 +224,18 @@ class Distributed:
             self.finish_halo_exchange()
 
     # ---- update_state! with interior / buffer overlap -------------------------------------------
-    def update_state(self, model, compute_tendencies=True):
+    def update_state(self, model, compute_tendencies=True, defer_exchange=False):
         from . import models
         g = model.grid
         fields = model.prognostic_fields()
+        if (defer_exchange and not compute_tendencies and self.partition.x > 1 and not getattr(model, "general_terms", False)
+                and os.environ.get("OCN_DIST_DEFER_EXCHANGE", "1") != "0"):
+            # end of a step whose last tendency launch is deferred: start the exchange and leave it in flight; the next step's
+            # fused launch (update_state_fused with fill_halos=False) overlaps it with its interior range, flush_tendencies and
+            # every new exchange complete it first
+            self.ops.local_fill(g, fields, False)
+            self.start_halo_exchange(fields)
+            return
         if getattr(model, "general_terms", False):
             # Coriolis / closure / buoyancy / boundary conditions
             if compute_tendencies:
@@ -298,7 +308,7 @@ class Distributed:
         """update_state! + the next rk3 substep with the fused launch: same interior / buffer split and overlap as update_state."""
         g = model.grid
         fields = model.prognostic_fields()
-        pending = None
+        pending = self._pending  # (an exchange started at the end of the previous step, when fill_halos is False)
         if fill_halos:
             self.ops.local_fill(g, fields, False)
             pending = self.start_halo_exchange(fields)

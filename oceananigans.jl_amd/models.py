@@ -247,6 +247,9 @@ def flush_tendencies(model):
     """Completes a compute_tendencies! that `time_step` deferred (model.defer_final_tendencies): the reference leaves
     Gⁿ = tendencies(state) after every time_step!; this backend may postpone that launch and fuse it with the first
     substep of the next step.  Anything that reads Gⁿ or is about to modify the state calls this first."""
+    finish = getattr(model.architecture, "finish_halo_exchange", None)
+    if finish is not None:  # Distributed: the halo exchange started at the end of the last step may still be in flight
+        finish()
     if getattr(model, "_pending_tendencies", False):
         model._pending_tendencies = False
         compute_tendencies_(model)
@@ -266,11 +269,13 @@ def set(model, enforce_incompressibility=True, **kwargs):
         update_state(model, compute_tendencies=False)
 
 
-def update_state(model, compute_tendencies=True):
-    """update_state!: tupled halo fill of velocities+tracers (fill_boundary_normal_velocities=false), then tendencies."""
+def update_state(model, compute_tendencies=True, defer_exchange=False):
+    """update_state!: tupled halo fill of velocities+tracers (fill_boundary_normal_velocities=false), then tendencies.
+    defer_exchange (Distributed, with compute_tendencies=False at the end of a step whose tendency launch is deferred): the x-halo
+    exchange is only STARTED; the next step's fused launch overlaps it with its interior range (flush_tendencies completes it)."""
     arch_hook = getattr(model.architecture, "update_state", None)
     if arch_hook is not None:  # Distributed: async exchange overlapped with interior tendencies
-        return arch_hook(model, compute_tendencies)
+        return arch_hook(model, compute_tendencies, defer_exchange) if defer_exchange else arch_hook(model, compute_tendencies)
     fill_halo_regions(model.prognostic_fields(), fill_boundary_normal_velocities=False)
     compute_auxiliaries(model)
     if compute_tendencies:
@@ -576,7 +581,7 @@ def _time_step_rk3(model, dt):
     calculate_pressure_correction(model, third_stage_dt)
     pressure_correct_velocities(model, third_stage_dt)
     if model.fuse_stage_boundaries and model.defer_final_tendencies:
-        update_state(model, compute_tendencies=False)  # halos now; the tendency launch is fused into the next step
+        update_state(model, compute_tendencies=False, defer_exchange=True)  # halos now; the tendency launch is fused into the next step
         model._pending_tendencies = True
     else:
         update_state(model, compute_tendencies=True)
