@@ -1,0 +1,86 @@
+"""CPU oracle of the first HydrostaticFreeSurfaceModel slice (oracle/hydrostatic.py): identities of the
+restated definitions and a linear free-surface wave.  PARITY UNPINNED against the reference (its tests of this model are
+time-stepping smoke tests, test_hydrostatic_free_surface_models.jl:10-30, re-expressed here as `time_step works`)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import hydrostatic as Hy
+
+
+def _grid(N=(16, 12, 6), L=(2.0e3, 1.5e3), H=50.0, stretched=False):
+    z = (-H, 0.0) if not stretched else -H * (1 - np.linspace(0, 1, N[2] + 1) ** 1.5)[::-1] * 1.0
+    if stretched:
+        z = np.sort(-H * (np.linspace(1, 0, N[2] + 1) ** 1.5))
+    return O.Grid(N, x=(0, L[0]), y=(0, L[1]), z=z, topology="PPB", halo=(3, 3, 3))
+
+
+@pytest.mark.parametrize("stretched", [False, True])
+def test_w_from_continuity_makes_the_flow_nondivergent(stretched):
+    """compute_w_from_continuity.jl:31-40: w integrates -div_xy(u, v) from w[1] = 0, so divᶜᶜᶜ(u, v, w) vanishes cell by cell."""
+    g = _grid(stretched=stretched)
+    rng = np.random.default_rng(3)
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="WENO5")
+    m.set(u=rng.uniform(-1, 1, (g.Nx, g.Ny, g.Nz)), v=rng.uniform(-1, 1, (g.Nx, g.Ny, g.Nz)))
+    assert np.all(m.w[:, :, g.Hz] == 0)
+    d = O.divergence(g, m.u, m.v, m.w)
+    scale = np.abs(m.u).max() / g.dx
+    assert np.abs(d).max() <= 1e-13 * scale
+    # the surface value is minus the divergence of the depth-integrated transport (what the free surface feels)
+    dzc = np.full(g.Nz, g.dz) if g.dzc is None else np.asarray(g.dzc[g.Hz:g.Hz + g.Nz])
+    U = (g.interior_N(m.u) * dzc).sum(axis=2)
+    V = (g.interior_N(m.v) * dzc).sum(axis=2)
+    divUV = (np.roll(U, -1, 0) - U) / g.dx + (np.roll(V, -1, 1) - V) / g.dy
+    wtop = m.w[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz + g.Nz]
+    assert np.abs(wtop + divUV).max() <= 1e-12 * np.abs(divUV).max()
+
+
+@pytest.mark.parametrize("advection", ["Centered2", "WENO5"])
+def test_time_step_works_and_conserves_volume(advection):
+    """time_step_hydrostatic_model_works (test_hydrostatic_free_surface_models.jl:10-30) + the explicit free surface conserves
+    the mean elevation on a periodic domain: sum(Gη) = sum(w_top) = -sum(div_xy(transport)) = 0."""
+    g = _grid()
+    rng = np.random.default_rng(4)
+    m = Hy.HydrostaticFreeSurfaceModel(g, tracers=("T", "S"), momentum_advection=advection, coriolis_f=1e-4, closure=(1e-2, 1e-3),
+                                       buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4))
+    m.set(u=1e-2 * rng.uniform(-1, 1, (g.Nx, g.Ny, g.Nz)), v=1e-2 * rng.uniform(-1, 1, (g.Nx, g.Ny, g.Nz)),
+          eta=1e-2 * rng.uniform(-1, 1, (g.Nx, g.Ny)), T=20 + 1e-2 * rng.uniform(-1, 1, (g.Nx, g.Ny, g.Nz)), S=35.0)
+    eta0 = m.eta[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny].sum()
+    for _ in range(5):
+        m.time_step(1.0)
+    assert all(np.isfinite(f).all() for f in m.fields) and np.isfinite(m.eta).all()
+    eta1 = m.eta[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny].sum()
+    assert abs(eta1 - eta0) <= 1e-12 * g.Nx * g.Ny * 1e-2
+    assert m.iteration == 5 and abs(m.time - 5.0) < 1e-14
+
+
+def test_linear_surface_gravity_wave_period():
+    """A small standing wave η = a cos(kx) over a flat bottom, no rotation, no stratification: the barotropic mode of the
+    hydrostatic equations oscillates at ω² = g H k_d², k_d = (2/Δx) sin(kΔx/2) the discrete wavenumber of the C-grid
+    gradient / divergence pair (continuous limit: the shallow-water speed sqrt(gH))."""
+    Nx, H, L = 32, 20.0, 4.0e3
+    g = O.Grid((Nx, 4, 4), x=(0, L), y=(0, 500.0), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2")
+    a, k = 1e-4, 2 * np.pi / L
+    x = (np.arange(Nx) + 0.5) * g.dx
+    m.set(eta=a * np.cos(k * x)[:, None] * np.ones((1, 4)))
+    kd = 2 / g.dx * np.sin(k * g.dx / 2)
+    omega = np.sqrt(Hy.g_Earth * H) * kd
+    period = 2 * np.pi / omega
+    nsteps = 800
+    dt = period / nsteps
+    amp = []
+    for n in range(nsteps):
+        m.time_step(dt)
+        e = m.eta[g.Hx:g.Hx + Nx, g.Hy]
+        amp.append(2 * np.mean(e * np.cos(k * x)))   # projection on the initial mode
+    amp = np.array(amp) / a
+    t = dt * np.arange(1, nsteps + 1)
+    # follows cos(ω t): back at +1 after one period, -1 at half a period, 0 at the quarter
+    assert abs(amp[-1] - 1.0) < 5e-3
+    assert abs(amp[nsteps // 2 - 1] + 1.0) < 5e-3
+    assert abs(amp[nsteps // 4 - 1]) < 1e-2
+    assert np.abs(amp - np.cos(omega * t)).max() < 1e-2
+    # the velocity is depth-independent (barotropic) and 90 degrees out of phase
+    u = g.interior_N(m.u)
+    assert np.abs(u - u[:, :, :1]).max() <= 1e-12 * max(np.abs(u).max(), 1e-30)
