@@ -308,6 +308,21 @@ int ocn_poisson_solve(ocn_poisson_t solver, double *p, void *stream);
 int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, const double *v, const double *w, double dt,
                            void *stream);
 
+/* ---- HydrostaticFreeSurfaceModel, first slice: explicit free surface, static (Periodic, Periodic,
+ * Bounded) grid.  u, v tendencies = ocn_compute_momentum_tendencies (flux-form advection; Gw is not used), then
+ * ocn_add_barotropic_pressure_gradient, then ocn_add_momentum_terms -- the order of the reference's sum
+ * (hydrostatic_free_surface_tendency_kernel_functions.jl:45-52).  eta / G_eta are (Nx+2Hx) x (Ny+2Hy) planes, x fastest. */
+int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v, const double *w,
+                           double *Gu, double *Gv, double *Gw, const int32_t *range, void *stream);
+/* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */
+int ocn_compute_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, void *stream);
+/* Gu -= g dx(eta), Gv -= g dy(eta) (explicit_free_surface.jl:36-40) */
+int ocn_add_barotropic_pressure_gradient(const ocn_grid *grid, double gravitational_acceleration, const double *eta, double *Gu, double *Gv,
+                                         void *stream);
+/* G_eta = w[:, :, Nz+1] (explicit_free_surface.jl:98-140), then eta += dt ((1.5 + chi) G_eta - (0.5 + chi) G_eta_previous not_euler) (:84-96) */
+int ocn_explicit_free_surface_ab2_step(const ocn_grid *grid, const double *w, double *eta, double *G_eta, const double *G_eta_previous,
+                                       double dt, double chi, void *stream);
+
 /* ---- time_step!(model, Δt) of the RungeKutta3 NonhydrostaticModel in ONE call (src/TimeSteppers/runge_kutta_3.jl:77-151):
  * WENO5 advection, no tracers / extra terms, (Periodic, Periodic, Periodic | Bounded | Flat), one GPU.  The handle owns a second
  * set of velocity arrays, G^n, G^- and the pressure solver, and alternates their roles so that the stage boundaries run fused

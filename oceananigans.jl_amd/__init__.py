@@ -28,6 +28,9 @@ from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTr
                       nonhydrostatic_pressure_solver, solve)
 
 
+from .hydrostatic import ExplicitFreeSurface, HydrostaticFreeSurfaceModel  # noqa: E402
+
+
 def set_math_mode(mode):
     """MATH_STRICT: reference evaluation order (bit-reproducible vs the CPU oracle); MATH_FAST: FMA + fused division."""
     _lib.call("ocn_set_math_mode", int(mode))

@@ -99,6 +99,10 @@ _SIGS = {
     "ocn_batched_tridiagonal_solve_z": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_halo_pack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
+    "ocn_add_momentum_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
+    "ocn_compute_w_from_continuity": [C.POINTER(CGrid), _vp, _vp, _vp, _vp],
+    "ocn_add_barotropic_pressure_gradient": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp],
+    "ocn_explicit_free_surface_ab2_step": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _dbl, _dbl, _vp],
     "ocn_rk3_driver_create": [C.POINTER(_vp), C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_rk3_driver_destroy": [_vp],
     "ocn_rk3_driver_time_step": [_vp, _dbl, _vp],

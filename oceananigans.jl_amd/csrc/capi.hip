@@ -289,6 +289,54 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
                   : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s);
 }
 
+// the extra terms alone, added to a G that already holds what precedes them in the reference's sum (used by the hydrostatic
+// tendencies, where - g ∂x η comes between the advection and the Coriolis term)
+int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v, const double *w,
+                           double *Gu, double *Gv, double *Gw, const int32_t *range, void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_add_momentum_terms: null field pointer");
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    if (!(terms->coriolis || terms->closure || terms->buoyancy)) return OCN_SUCCESS;
+    TermsDev t = to_dev(*terms);
+    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
+                                          : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
+}
+
+static int validate_hydrostatic(const ocn_grid *grid, const char *who)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC && grid->tz == OCN_BOUNDED,
+                "%s: the hydrostatic slice supports (Periodic, Periodic, Bounded) grids", who);
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1, "%s: needs x, y halos", who);
+    return OCN_SUCCESS;
+}
+int ocn_compute_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_compute_w_from_continuity");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w, "ocn_compute_w_from_continuity: null field pointer");
+    return launch_w_from_continuity(grid, u, v, w, as_stream(stream));
+}
+int ocn_add_barotropic_pressure_gradient(const ocn_grid *grid, double gravitational_acceleration, const double *eta, double *Gu, double *Gv,
+                                         void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_add_barotropic_pressure_gradient");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(eta && Gu && Gv, "ocn_add_barotropic_pressure_gradient: null pointer");
+    return launch_barotropic_gradient(grid, gravitational_acceleration, eta, Gu, Gv, as_stream(stream));
+}
+int ocn_explicit_free_surface_ab2_step(const ocn_grid *grid, const double *w, double *eta, double *G_eta, const double *G_eta_previous,
+                                       double dt, double chi, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_explicit_free_surface_ab2_step");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(w && eta && G_eta && G_eta_previous, "ocn_explicit_free_surface_ab2_step: null pointer");
+    return launch_free_surface_ab2(grid, w, eta, G_eta, G_eta_previous, dt, chi, as_stream(stream));
+}
+
 int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
                                       const double *u, const double *v, const double *w, const double *c, double *Gc,
                                       const int32_t *range, void *stream)

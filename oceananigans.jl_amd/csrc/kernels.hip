@@ -206,6 +206,91 @@ int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// HydrostaticFreeSurfaceModel, first slice: explicit free surface on a static (Periodic, Periodic, Bounded) grid
+// ---------------------------------------------------------------------------------------------------
+// _compute_w_from_continuity! (src/Models/HydrostaticFreeSurfaceModels/compute_w_from_continuity.jl:31-40): w[i,j,1] = 0,
+// w[i,j,k] = w[i,j,k-1] - (flux_div_xyᶜᶜᶜ(i,j,k-1,u,v) / Azᶜᶜᶜ + 0) for every column whose east / north neighbours exist in the
+// parent (a superset of w_kernel_parameters, :43-51).  One thread per column, i across the lanes.
+__global__ __launch_bounds__(256) void w_from_continuity_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                                double *__restrict__ w)
+{
+    const int i = 1 - g.Hx + blockIdx.x * blockDim.x + threadIdx.x, j = 1 - g.Hy + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx + g.Hx - 1 || j > g.Ny + g.Hy - 1) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);  // x, y Periodic: u, v, w share strides and offset (w only has one more plane)
+    long long o = at(L, i, j, 1);
+    const double Az = g.dx * g.dy;
+    double wk = 0.0;
+    w[o] = wk;
+    for (int k = 1; k <= g.Nz; ++k) {
+        const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        const double Ax = g.dy * dzc, Ay = g.dx * dzc;
+        const double dxu = Ax * u[o + 1] - Ax * u[o];
+        const double dyv = Ay * v[o + L.s2] - Ay * v[o];
+        const double dh = (dxu + dyv) / Az;
+        wk = wk - (dh + 0.0);
+        o += L.s3;
+        w[o] = wk;
+    }
+}
+int launch_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const int nx = g.Nx + 2 * g.Hx - 1, ny = g.Ny + 2 * g.Hy - 1;
+    dim3 block(64, 4, 1), nb((nx + 63) / 64, (ny + 3) / 4, 1);
+    hipLaunchKernelGGL(w_from_continuity_kernel, nb, block, 0, stream, g, u, v, w);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// - explicit_barotropic_pressure_x/y_gradient (explicit_free_surface.jl:36-40): Gu -= g ∂xᶠᶜᶜ η, Gv -= g ∂yᶜᶠᶜ η at every k; η is the
+// (sx, sy) plane k = Nz+1 of the reference's reduced field, halos filled.
+__global__ __launch_bounds__(256) void barotropic_gradient_kernel(GridDev g, double grav, const double *__restrict__ eta,
+                                                                  double *__restrict__ Gu, double *__restrict__ Gv)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const long long e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);
+    const long long o = at(L, i, j, k);
+    Gu[o] -= grav * ((eta[e] - eta[e - 1]) / g.dx);
+    Gv[o] -= grav * ((eta[e] - eta[e - L.sx]) / g.dy);
+}
+int launch_barotropic_gradient(const ocn_grid *grid, double grav, const double *eta, double *Gu, double *Gv, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(barotropic_gradient_kernel, nb, block, 0, stream, g, grav, eta, Gu, Gv);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// compute_hydrostatic_free_surface_Gη! (Gη = w[i,j,Nz+1], explicit_free_surface.jl:98-140) followed by
+// _explicit_ab2_step_free_surface! (:84-96): η += Δt ((1.5 + χ) Gηⁿ - (0.5 + χ) Gη⁻ not_euler); Gηⁿ is left in Gn for the caller to cache
+__global__ __launch_bounds__(256) void free_surface_ab2_kernel(GridDev g, const double *__restrict__ w, double *__restrict__ eta,
+                                                               double *__restrict__ Gn, const double *__restrict__ Gm, double dt,
+                                                               double chi, double not_euler)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const long long e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);
+    const double gn = w[at(L, i, j, g.Nz + 1)];
+    Gn[e] = gn;
+    const double G = (1.5 + chi) * gn - (0.5 + chi) * Gm[e] * not_euler;
+    eta[e] += dt * G;
+}
+int launch_free_surface_ab2(const ocn_grid *grid, const double *w, double *eta, double *Gn, const double *Gm, double dt, double chi,
+                            hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    const double not_euler = (chi != -0.5) ? 1.0 : 0.0;
+    hipLaunchKernelGGL(free_surface_ab2_kernel, nb, block, 0, stream, g, w, eta, Gn, Gm, dt, chi, not_euler);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // cell_advection_timescale(grid, velocities) (src/Advection/cell_advection_timescale.jl:13-35): the minimum over the interior of
 //   1 / (|u|/Δxᶠᶜᶜ + |v|/Δyᶜᶠᶜ + |w|/Δzᶜᶜᶠ)   (terms of Flat dimensions are 0).
 // Block reduction, then an atomic min on the bit pattern (non-negative doubles order like their bits; +inf for a fluid at

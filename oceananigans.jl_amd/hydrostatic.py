@@ -1,0 +1,147 @@
+"""First slice of the reference's HydrostaticFreeSurfaceModel on the HIP backend: ExplicitFreeSurface,
+flux-form momentum advection, QuasiAdamsBashforth2, static (Periodic, Periodic, Bounded) RectilinearGrid, one GPU.
+
+    src/Models/HydrostaticFreeSurfaceModels/hydrostatic_free_surface_model.jl (constructor), explicit_free_surface.jl,
+    compute_w_from_continuity.jl, hydrostatic_free_surface_tendency_kernel_functions.jl:29-97,
+    hydrostatic_free_surface_ab2_step.jl:9-111, update_hydrostatic_free_surface_model_state.jl:35-96
+
+The horizontal momentum and tracer tendencies are the terms of the NonhydrostaticModel path (flux-form advection, FPlane,
+∂x pHY′, ScalarDiffusivity, flux boundary conditions) plus the barotropic pressure gradient g ∇η; w is diagnosed from continuity;
+there is no pressure solve.  NOT in this slice (each raises): SplitExplicitFreeSurface / ImplicitFreeSurface, VectorInvariant
+momentum advection (the reference's default), z-star coordinates, vertically implicit diffusion, eddy-viscosity closures,
+a tracer advection scheme different from the momentum one, Distributed architectures.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .architectures import stream_ptr
+from .fields import fill_halo_regions
+from .grids import Bounded, Periodic
+from .models import NonhydrostaticModel, compute_boundary_tendency_contributions, update_hydrostatic_pressure
+from .physics import AnisotropicMinimumDissipation
+
+g_Earth = 9.80665  # Oceananigans.BuoyancyFormulations.g_Earth
+
+
+class ExplicitFreeSurface:
+    """ExplicitFreeSurface(; gravitational_acceleration = g_Earth) (explicit_free_surface.jl:9-21)"""
+
+    def __init__(self, gravitational_acceleration=g_Earth):
+        self.gravitational_acceleration = float(gravitational_acceleration)
+
+
+class HydrostaticFreeSurfaceModel:
+    def __init__(self, grid, momentum_advection=None, tracer_advection=None, tracers=(), free_surface=None, coriolis=None,
+                 closure=None, buoyancy=None, boundary_conditions=None):
+        if tuple(grid.topology) != (Periodic, Periodic, Bounded) or hasattr(grid.architecture, "partition"):
+            raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids on one GPU in this slice")
+        if free_surface is None:
+            free_surface = ExplicitFreeSurface()
+        if not isinstance(free_surface, ExplicitFreeSurface):
+            raise NotImplementedError("only free_surface = ExplicitFreeSurface(...) is implemented")
+        if momentum_advection is None:
+            raise NotImplementedError("momentum_advection = VectorInvariant() (the reference's default) is not implemented: "
+                                      "pass Centered(), WENO() or UpwindBiased(order=5) (flux form)")
+        if tracer_advection is not None and type(tracer_advection) is not type(momentum_advection):
+            raise NotImplementedError("tracer_advection must be the momentum scheme in this slice")
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            raise NotImplementedError("eddy-viscosity closures are not part of this slice")
+        # fields, physics descriptors, tendency storage and the Adams-Bashforth bookkeeping of the nonhydrostatic model are reused;
+        # its pressure solver and w tendency are simply not used
+        self._nh = NonhydrostaticModel(grid, advection=momentum_advection, tracers=tracers, timestepper="QuasiAdamsBashforth2",
+                                       closure=closure, buoyancy=buoyancy, coriolis=coriolis, boundary_conditions=boundary_conditions)
+        nh = self._nh
+        self.grid, self.architecture, self.clock = grid, grid.architecture, nh.clock
+        self.free_surface = free_surface
+        self.u, self.v, self.w = nh.u, nh.v, nh.w
+        self.velocities, self.tracers, self.tracer_names = nh.velocities, nh.tracers, nh.tracer_names
+        sx, sy = grid.Nx + 2 * grid.Hx, grid.Ny + 2 * grid.Hy
+        dev = self.u.data.device
+        self.eta = torch.zeros((sy, sx), dtype=torch.float64, device=dev)       # η[i, j, Nz+1], halos included, x fastest
+        self._Geta = torch.zeros_like(self.eta)
+        self._Geta_m = torch.zeros_like(self.eta)
+        self._adv_only = _lib.CModelTerms()                                     # the advective part alone, by scheme
+        self._adv_only.advection = nh._terms.advection
+        self.update_state(compute_tendencies=False)
+
+    # ---- helpers -------------------------------------------------------------------------------------------------------
+    def field(self, name):
+        return self._nh.field(name)
+
+    def eta_interior(self):
+        g = self.grid
+        return self.eta[g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx]
+
+    def _fill_eta_halos(self):
+        g, e = self.grid, self.eta
+        Hx, Hy, Nx, Ny = g.Hx, g.Hy, g.Nx, g.Ny
+        e[:, :Hx] = e[:, Nx:Nx + Hx]
+        e[:, Nx + Hx:] = e[:, Hx:2 * Hx]
+        e[:Hy, :] = e[Ny:Ny + Hy, :]
+        e[Ny + Hy:, :] = e[Hy:2 * Hy, :]
+
+    # ---- update_state! (update_hydrostatic_free_surface_model_state.jl:35-53, 74-96) -------------------------------------
+    def update_state(self, compute_tendencies=True):
+        nh, g = self._nh, self.grid
+        fill_halo_regions((self.u, self.v) + tuple(self.tracers), fill_boundary_normal_velocities=False)
+        self._fill_eta_halos()
+        _lib.call("ocn_compute_w_from_continuity", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, stream_ptr())
+        update_hydrostatic_pressure(nh)
+        if compute_tendencies:
+            self.compute_tendencies()
+
+    # ---- compute_tendencies! (hydrostatic_free_surface_tendency_kernel_functions.jl:45-52, 86-93, 125-131) -----------------------
+    def compute_tendencies(self):
+        nh, g, s = self._nh, self.grid, stream_ptr()
+        Gn = nh.timestepper._Gn
+        _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
+                  Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)                                         # - U_dot_∇u, - U_dot_∇v
+        _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, self.free_surface.gravitational_acceleration, self.eta.data_ptr(),
+                  Gn[0].ptr, Gn[1].ptr, s)                                                          # - g ∇η
+        _lib.call("ocn_add_momentum_terms", g.cref, C.byref(nh._terms), self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                  Gn[2].ptr, None, s)                                                               # - f x U - ∇pHY′ - ∂ⱼτᵢⱼ
+        for n, c in enumerate(self.tracers):
+            kappa = 0.0 if nh.closure is None else nh.closure.kappa_of(self.tracer_names[n])
+            _lib.call("ocn_compute_tracer_tendency_terms", g.cref, C.byref(nh._terms), kappa, None, self.u.ptr, self.v.ptr, self.w.ptr,
+                      c.ptr, Gn[3 + n].ptr, None, s)
+        compute_boundary_tendency_contributions(nh)
+
+    # ---- time_step! (quasi_adams_bashforth_2.jl:74-115 with ab2_step!(::HydrostaticFreeSurfaceModel)) -------------------------
+    def time_step(self, dt, euler=False):
+        nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
+        if clock.iteration == 0:
+            self.update_state(compute_tendencies=True)
+        euler = euler or (dt != clock.last_dt)
+        chi = -0.5 if euler else nh.timestepper.chi
+        Gn, Gm = nh.timestepper._Gn, nh.timestepper._Gm
+        # local_ab2_step!: u, v by ab2_step_field!; tracers by _ab2_step_tracer_field!, which with σ = 1 (static grid) is the same
+        # arithmetic for finite values
+        idx = [0, 1] + [3 + n for n in range(len(self.tracers))]
+        fields = [self.u, self.v] + list(self.tracers)
+        _lib.call("ocn_ab2_step", g.cref, len(idx), _lib.ptr_array([f.ptr for f in fields]), _lib.ptr_array([Gn[q].ptr for q in idx]),
+                  _lib.ptr_array([Gm[q].ptr for q in idx]), _lib.i32_array([f.loc for f in fields]), float(dt), float(chi), s)
+        # compute_free_surface_tendency! + step_free_surface!
+        _lib.call("ocn_explicit_free_surface_ab2_step", g.cref, self.w.ptr, self.eta.data_ptr(), self._Geta.data_ptr(),
+                  self._Geta_m.data_ptr(), float(dt), float(chi), s)
+        clock.time += dt
+        clock.iteration += 1
+        clock.last_dt = dt
+        clock.last_stage_dt = dt
+        # (no pressure correction with an explicit free surface) cache_previous_tendencies!: role swap
+        nh.timestepper._Gn, nh.timestepper._Gm = Gm, Gn
+        self._Geta, self._Geta_m = self._Geta_m, self._Geta
+        self.update_state(compute_tendencies=True)
+
+    def set(self, **kwargs):
+        g = self.grid
+        for name, value in kwargs.items():
+            if name in ("eta", "η"):
+                v = torch.as_tensor(value, dtype=torch.float64)
+                self.eta_interior().copy_(v.T.to(self.eta.device) if v.ndim == 2 else v)
+            elif name == "w":
+                raise ValueError("w is diagnostic in a HydrostaticFreeSurfaceModel")
+            else:
+                self.field(name).set(value)
+        self.update_state(compute_tendencies=False)
