@@ -314,6 +314,10 @@ int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, con
  * (hydrostatic_free_surface_tendency_kernel_functions.jl:45-52).  eta / G_eta are (Nx+2Hx) x (Ny+2Hy) planes, x fastest. */
 int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v, const double *w,
                            double *Gu, double *Gv, double *Gw, const int32_t *range, void *stream);
+/* Gu = -U_dot_grad(u), Gv = -U_dot_grad(v) with momentum_advection = VectorInvariant() (the model's default: EnstrophyConserving
+ * vorticity flux, EnergyConserving vertical advection and kinetic-energy gradient; Advection/vector_invariant_advection.jl:269-361) */
+int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                                     double *Gv, void *stream);
 /* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */
 int ocn_compute_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, void *stream);
 /* Gu -= g dx(eta), Gv -= g dy(eta) (explicit_free_surface.jl:36-40) */

@@ -242,6 +242,61 @@ int launch_w_from_continuity(const ocn_grid *grid, const double *u, const double
     return OCN_SUCCESS;
 }
 
+// Gu = -U_dot_∇u, Gv = -U_dot_∇v of the reference's default VectorInvariant() scheme (Advection/vector_invariant_advection.jl:
+// 269-275): EnstrophyConserving vorticity flux (:360-361, ζ₃ᶠᶠᶜ of Operators/vorticity_operators.jl:4-11), EnergyConserving
+// vertical advection (:315-319) and kinetic-energy gradient (:304-308).  ℑ = 0.5 (a + b), δ = a - b, ∂ = δ / Δ; one thread per cell.
+__global__ __launch_bounds__(256) void vector_invariant_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                               const double *__restrict__ w, double *__restrict__ Gu,
+                                                               double *__restrict__ Gv)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const long long o = at(L, i, j, k), s2 = L.s2, s3 = L.s3;
+    const double dx = g.dx, dy = g.dy, Az = dx * dy;
+    const double dzf0 = g.dzf ? g.dzf[k + g.Hz - 1] : g.dz, dzf1 = g.dzf ? g.dzf[k + g.Hz] : g.dz;  // Δzᶠ at faces k, k+1
+    const double *pu = u + o, *pv = v + o, *pw = w + o;
+#define U_(a, b, c) pu[(a) + (b)*s2 + (c)*s3]
+#define V_(a, b, c) pv[(a) + (b)*s2 + (c)*s3]
+#define W_(a, b, c) pw[(a) + (b)*s2 + (c)*s3]
+    auto zeta = [&](int a, int b) {  // ζ₃ᶠᶠᶜ at (i + a, j + b)
+        const double gam = (dy * V_(a, b, 0) - dy * V_(a - 1, b, 0)) - (dx * U_(a, b, 0) - dx * U_(a, b - 1, 0));
+        return gam / Az;
+    };
+    auto Kh = [&](int a, int b) {    // Khᶜᶜᶜ at (i + a, j + b)
+        return (0.5 * (U_(a, b, 0) * U_(a, b, 0) + U_(a + 1, b, 0) * U_(a + 1, b, 0)) +
+                0.5 * (V_(a, b, 0) * V_(a, b, 0) + V_(a, b + 1, 0) * V_(a, b + 1, 0))) / 2;
+    };
+    {   // ---- u
+        auto m = [&](int a) { return 0.5 * (dx * V_(a, 0, 0) + dx * V_(a, 1, 0)); };  // ℑyᵃᶜᵃ(Δx_qᶜᶠᶜ v) at (i + a, j)
+        const double hadv = -(0.5 * (zeta(0, 0) + zeta(0, 1))) * (0.5 * (m(-1) + m(0))) / dx;
+        auto Z = [&](int c, double dzf) { return (0.5 * (Az * W_(-1, 0, c) + Az * W_(0, 0, c))) * ((U_(0, 0, c) - U_(0, 0, c - 1)) / dzf); };
+        const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
+        const double bern = (Kh(0, 0) - Kh(-1, 0)) / dx;
+        Gu[o] = -((hadv + vadv) + bern);
+    }
+    {   // ---- v
+        auto n = [&](int b) { return 0.5 * (dy * U_(0, b, 0) + dy * U_(1, b, 0)); };  // ℑxᶜᵃᵃ(Δy_qᶠᶜᶜ u) at (i, j + b)
+        const double hadv = (0.5 * (zeta(0, 0) + zeta(1, 0))) * (0.5 * (n(-1) + n(0))) / dy;
+        auto Z = [&](int c, double dzf) { return (0.5 * (Az * W_(0, -1, c) + Az * W_(0, 0, c))) * ((V_(0, 0, c) - V_(0, 0, c - 1)) / dzf); };
+        const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
+        const double bern = (Kh(0, 0) - Kh(0, -1)) / dy;
+        Gv[o] = -((hadv + vadv) + bern);
+    }
+#undef U_
+#undef V_
+#undef W_
+}
+int launch_vector_invariant(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                            hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(vector_invariant_kernel, nb, block, 0, stream, g, u, v, w, Gu, Gv);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // - explicit_barotropic_pressure_x/y_gradient (explicit_free_surface.jl:36-40): Gu -= g ∂xᶠᶜᶜ η, Gv -= g ∂yᶜᶠᶜ η at every k; η is the
 // (sx, sy) plane k = Nz+1 of the reference's reduced field, halos filled.
 __global__ __launch_bounds__(256) void barotropic_gradient_kernel(GridDev g, double grav, const double *__restrict__ eta,

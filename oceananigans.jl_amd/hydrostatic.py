@@ -7,8 +7,9 @@ flux-form momentum advection, QuasiAdamsBashforth2, static (Periodic, Periodic, 
 
 The horizontal momentum and tracer tendencies are the terms of the NonhydrostaticModel path (flux-form advection, FPlane,
 ∂x pHY′, ScalarDiffusivity, flux boundary conditions) plus the barotropic pressure gradient g ∇η; w is diagnosed from continuity;
-there is no pressure solve.  NOT in this slice (each raises): SplitExplicitFreeSurface / ImplicitFreeSurface, VectorInvariant
-momentum advection (the reference's default), z-star coordinates, vertically implicit diffusion, eddy-viscosity closures,
+there is no pressure solve.  momentum_advection = VectorInvariant() (the reference's default: enstrophy-conserving vorticity flux,
+energy-conserving vertical advection and kinetic-energy gradient) or a flux-form scheme.  NOT in this slice (each raises):
+SplitExplicitFreeSurface / ImplicitFreeSurface, upwinding / WENO vector-invariant variants, z-star coordinates, vertically implicit diffusion, eddy-viscosity closures,
 a tracer advection scheme different from the momentum one, Distributed architectures.
 """
 import ctypes as C
@@ -20,9 +21,18 @@ from .architectures import stream_ptr
 from .fields import fill_halo_regions
 from .grids import Bounded, Periodic
 from .models import NonhydrostaticModel, compute_boundary_tendency_contributions, update_hydrostatic_pressure
-from .physics import AnisotropicMinimumDissipation
+from .physics import AnisotropicMinimumDissipation, Centered
 
 g_Earth = 9.80665  # Oceananigans.BuoyancyFormulations.g_Earth
+
+
+class VectorInvariant:
+    """VectorInvariant() with its defaults (Advection/vector_invariant_advection.jl:104-130): EnstrophyConserving vorticity scheme,
+    EnergyConserving vertical scheme and kinetic-energy gradient, second order."""
+    buffer = 1
+
+    def __repr__(self):
+        return "VectorInvariant()"
 
 
 class ExplicitFreeSurface:
@@ -42,15 +52,20 @@ class HydrostaticFreeSurfaceModel:
         if not isinstance(free_surface, ExplicitFreeSurface):
             raise NotImplementedError("only free_surface = ExplicitFreeSurface(...) is implemented")
         if momentum_advection is None:
-            raise NotImplementedError("momentum_advection = VectorInvariant() (the reference's default) is not implemented: "
-                                      "pass Centered(), WENO() or UpwindBiased(order=5) (flux form)")
-        if tracer_advection is not None and type(tracer_advection) is not type(momentum_advection):
-            raise NotImplementedError("tracer_advection must be the momentum scheme in this slice")
+            momentum_advection = VectorInvariant()  # the reference's default (hydrostatic_free_surface_model.jl)
+        self.vector_invariant = isinstance(momentum_advection, VectorInvariant)
+        if self.vector_invariant:
+            # the container model below carries the tracer scheme (reference default: Centered()); momentum goes its own way
+            container_advection = tracer_advection if tracer_advection is not None else Centered()
+        else:
+            if tracer_advection is not None and type(tracer_advection) is not type(momentum_advection):
+                raise NotImplementedError("with a flux-form momentum scheme, tracer_advection must be the same scheme in this slice")
+            container_advection = momentum_advection
         if isinstance(closure, AnisotropicMinimumDissipation):
             raise NotImplementedError("eddy-viscosity closures are not part of this slice")
         # fields, physics descriptors, tendency storage and the Adams-Bashforth bookkeeping of the nonhydrostatic model are reused;
         # its pressure solver and w tendency are simply not used
-        self._nh = NonhydrostaticModel(grid, advection=momentum_advection, tracers=tracers, timestepper="QuasiAdamsBashforth2",
+        self._nh = NonhydrostaticModel(grid, advection=container_advection, tracers=tracers, timestepper="QuasiAdamsBashforth2",
                                        closure=closure, buoyancy=buoyancy, coriolis=coriolis, boundary_conditions=boundary_conditions)
         nh = self._nh
         self.grid, self.architecture, self.clock = grid, grid.architecture, nh.clock
@@ -96,8 +111,12 @@ class HydrostaticFreeSurfaceModel:
     def compute_tendencies(self):
         nh, g, s = self._nh, self.grid, stream_ptr()
         Gn = nh.timestepper._Gn
-        _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
-                  Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)                                         # - U_dot_∇u, - U_dot_∇v
+        if self.vector_invariant:                                                                   # - U_dot_∇u, - U_dot_∇v
+            _lib.call("ocn_compute_vector_invariant_momentum_tendencies", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr,
+                      Gn[1].ptr, s)
+        else:
+            _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
+                      Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)
         _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, self.free_surface.gravitational_acceleration, self.eta.data_ptr(),
                   Gn[0].ptr, Gn[1].ptr, s)                                                          # - g ∇η
         _lib.call("ocn_add_momentum_terms", g.cref, C.byref(nh._terms), self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr, Gn[1].ptr,

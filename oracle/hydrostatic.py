@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE (CPU restatement, never imported by the product): first slice of SURVEY §8(f) rank 4, the
-HydrostaticFreeSurfaceModel of the reference with an ExplicitFreeSurface, flux-form momentum advection (Centered(order=2) /
-WENO / UpwindBiased passed as `momentum_advection`), QuasiAdamsBashforth2, on a static (Periodic, Periodic, Bounded)
+HydrostaticFreeSurfaceModel of the reference with an ExplicitFreeSurface, VectorInvariant() (its default) or flux-form momentum
+advection (Centered(order=2) / WENO / UpwindBiased passed as `momentum_advection`), QuasiAdamsBashforth2, on a static (Periodic, Periodic, Bounded)
 RectilinearGrid.  Built on the operators of oracle.py (same C kernels as the nonhydrostatic oracle), so only what is new is
 restated here:
 
@@ -12,9 +12,10 @@ restated here:
         update_hydrostatic_free_surface_model_state.jl:35-53, 74-96, TimeSteppers/quasi_adams_bashforth_2.jl:74-115
 
 PARITY UNPINNED: the reference's own tests of this model are time-stepping smoke tests (test_hydrostatic_free_surface_models.jl);
-tests/test_oracle_hydrostatic.py checks identities and a linear free-surface wave.  Not covered: split-explicit / implicit free
-surfaces, VectorInvariant momentum advection (the model's default), z-star coordinates, vertically implicit diffusion,
-immersed boundaries, forcing.  No HIP counterpart yet.
+tests/test_oracle_hydrostatic.py checks identities, a linear free-surface wave and the order of accuracy of the vector-invariant
+advection.  Not covered: split-explicit / implicit free surfaces, upwinding vector-invariant variants, z-star coordinates,
+vertically implicit diffusion, immersed boundaries, forcing.  HIP counterpart: oceananigans.jl_amd/hydrostatic.py
+(tests/test_gpu_hydrostatic.py compares the two bit for bit).
 """
 import numpy as np
 
@@ -40,7 +41,42 @@ def compute_w_from_continuity(g, u, v, w):
         dxu[:-1, :] = Ax * u[1:, :, kc] - Ax * u[:-1, :, kc]          # δxᶜᵃᵃ(Ax_qᶠᶜᶜ, u)
         dyv[:, :-1] = Ay * v[:, 1:, kc] - Ay * v[:, :-1, kc]          # δyᵃᶜᵃ(Ay_qᶜᶠᶜ, v)
         dh = (dxu + dyv) / Az
-        w[:, :, Hz + k] = w[:, :, Hz + k - 1] - (dh + 0.0)
+        w[:-1, :-1, Hz + k] = w[:-1, :-1, Hz + k - 1] - (dh[:-1, :-1] + 0.0)  # (the last parent row / column has no neighbour)
+
+
+def vector_invariant_momentum_tendencies(g, u, v, w, Gu, Gv):
+    """Gu = -U_dot_∇u, Gv = -U_dot_∇v with the reference's default VectorInvariant() scheme: EnstrophyConserving vorticity flux,
+    EnergyConserving vertical advection and kinetic-energy gradient (Advection/vector_invariant_advection.jl:269-275, 304-319,
+    360-361; Operators/vorticity_operators.jl:4-11; interpolation ℑ = 0.5 (a + b), differences a - b, derivatives δ / Δ)."""
+    Hx, Hy, Hz, Nx, Ny, Nz = g.Hx, g.Hy, g.Hz, g.Nx, g.Ny, g.Nz
+    dx, dy = g.dx, g.dy
+    Az = dx * dy
+    dzf = np.full(Nz + 2, g.dz) if g.dzf is None else np.asarray(g.dzf[Hz - 0:Hz + Nz + 2])  # Δzᶠ at faces k = 1 .. Nz+2 (1 .. Nz+1 used)
+
+    def sh(a, di=0, dj=0, dk=0):
+        return a[Hx + di:Hx + Nx + di, Hy + dj:Hy + Ny + dj, Hz + dk:Hz + Nz + dk]
+
+    def zeta(di, dj):  # ζ₃ᶠᶠᶜ at (i + di, j + dj)
+        gam = (dy * sh(v, di, dj) - dy * sh(v, di - 1, dj)) - (dx * sh(u, di, dj) - dx * sh(u, di, dj - 1))
+        return gam / Az
+
+    # ---- U
+    m = lambda di: 0.5 * (dx * sh(v, di, 0) + dx * sh(v, di, 1))                      # ℑyᵃᶜᵃ(Δx_qᶜᶠᶜ v) at (i + di, j)
+    hadv_u = -(0.5 * (zeta(0, 0) + zeta(0, 1))) * (0.5 * (m(-1) + m(0))) / dx
+    dzfk = lambda dk: dzf[dk:dk + Nz][None, None, :]                                    # Δzᶠ at face k + dk
+    Zu = lambda dk: (0.5 * (Az * sh(w, -1, 0, dk) + Az * sh(w, 0, 0, dk))) * ((sh(u, 0, 0, dk) - sh(u, 0, 0, dk - 1)) / dzfk(dk))
+    vadv_u = (0.5 * (Zu(0) + Zu(1))) / Az
+    Kh = lambda di, dj: (0.5 * (sh(u, di, dj) * sh(u, di, dj) + sh(u, di + 1, dj) * sh(u, di + 1, dj))
+                         + 0.5 * (sh(v, di, dj) * sh(v, di, dj) + sh(v, di, dj + 1) * sh(v, di, dj + 1))) / 2
+    bern_u = (Kh(0, 0) - Kh(-1, 0)) / dx
+    g.interior_N(Gu)[...] = -((hadv_u + vadv_u) + bern_u)
+    # ---- V
+    n = lambda dj: 0.5 * (dy * sh(u, 0, dj) + dy * sh(u, 1, dj))                      # ℑxᶜᵃᵃ(Δy_qᶠᶜᶜ u) at (i, j + dj)
+    hadv_v = (0.5 * (zeta(0, 0) + zeta(1, 0))) * (0.5 * (n(-1) + n(0))) / dy
+    Zv = lambda dk: (0.5 * (Az * sh(w, 0, -1, dk) + Az * sh(w, 0, 0, dk))) * ((sh(v, 0, 0, dk) - sh(v, 0, 0, dk - 1)) / dzfk(dk))
+    vadv_v = (0.5 * (Zv(0) + Zv(1))) / Az
+    bern_v = (Kh(0, 0) - Kh(0, -1)) / dy
+    g.interior_N(Gv)[...] = -((hadv_v + vadv_v) + bern_v)
 
 
 class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
@@ -57,7 +93,11 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         self.g_eta_m = np.zeros_like(self.eta)
         self.gravity = float(gravitational_acceleration)
         self.tracer_scheme = None
-        super().__init__(grid, tracers=tracers, timestepper="QuasiAdamsBashforth2", advection=momentum_advection, coriolis_f=coriolis_f,
+        self.vector_invariant = momentum_advection == "VectorInvariant"
+        if self.vector_invariant and tracer_advection is None:
+            tracer_advection = "Centered2"  # the reference's default tracer scheme
+        super().__init__(grid, tracers=tracers, timestepper="QuasiAdamsBashforth2",
+                         advection=tracer_advection if self.vector_invariant else momentum_advection, coriolis_f=coriolis_f,
                          closure=closure, buoyancy=buoyancy, boundary_conditions=boundary_conditions)
         ta = momentum_advection if tracer_advection is None else tracer_advection
         self.tracer_scheme = {"WENO5": O.ADV_WENO5, "Centered2": O.ADV_CENTERED2, "UpwindBiased5": O.ADV_UPWIND5}[ta]
@@ -93,7 +133,10 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     def compute_tendencies(self):
         g, ph = self.grid, self.physics
         Gu, Gv, Gw = self.Gn[0], self.Gn[1], self.Gn[2]
-        O.momentum_tendencies(g, self.u, self.v, self.w, Gu, Gv, Gw, self.scheme)      # -U_dot_∇u, -U_dot_∇v (flux form)
+        if getattr(self, "vector_invariant", False):
+            vector_invariant_momentum_tendencies(g, self.u, self.v, self.w, Gu, Gv)  # -U_dot_∇u, -U_dot_∇v (VectorInvariant())
+        else:
+            O.momentum_tendencies(g, self.u, self.v, self.w, Gu, Gv, Gw, self.scheme)  # ... (flux form)
         # - explicit_barotropic_pressure_x/y_gradient = g ∂xᶠᶜᶜ η, g ∂yᶜᶠᶜ η (explicit_free_surface.jl:36-40), the same for every k
         e, Hx, Hy, Hz = self.eta, g.Hx, g.Hy, g.Hz
         px = np.zeros_like(e)

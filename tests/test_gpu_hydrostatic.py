@@ -32,7 +32,7 @@ def test_w_from_continuity_bitwise(oracle, ocn, stretched):
     np.testing.assert_array_equal(got[:-1, :-1, og.Hz:og.Hz + og.Nz + 1], w[:-1, :-1, og.Hz:og.Hz + og.Nz + 1])
 
 
-@pytest.mark.parametrize("advection", ["Centered2", "WENO5"])
+@pytest.mark.parametrize("advection", ["Centered2", "WENO5", "VectorInvariant"])
 @pytest.mark.parametrize("physics", [False, True])
 def test_hydrostatic_model_steps_match_oracle(oracle, ocn, advection, physics):
     """3 QAB2 steps (the first one Euler) of the explicit-free-surface model: u, v, w, η and the tracers equal the oracle's bit
@@ -57,7 +57,7 @@ def test_hydrostatic_model_steps_match_oracle(oracle, ocn, advection, physics):
     om = Hy.HydrostaticFreeSurfaceModel(og, tracers=tracers, momentum_advection=advection, **kw_o)
     om.set(**init)
     ocn.set_math_mode(ocn.MATH_STRICT)
-    scheme = ocn.Centered() if advection == "Centered2" else ocn.WENO()
+    scheme = {"Centered2": ocn.Centered, "WENO5": ocn.WENO, "VectorInvariant": ocn.VectorInvariant}[advection]()
     pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=scheme, tracers=tracers, free_surface=ocn.ExplicitFreeSurface(), **kw_p)
     pm.set(**init)
     for dt in (2.0, 2.0, 2.0):
