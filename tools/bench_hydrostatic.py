@@ -3,7 +3,7 @@
 with what the slice has: ExplicitFreeSurface instead of the split-explicit one, flux-form WENO5 momentum and tracer advection,
 T and S, linear SeawaterBuoyancy, FPlane, ScalarDiffusivity, QuasiAdamsBashforth2.  One QAB2 step = one tendency evaluation.
 
-  tools/bench_hydrostatic.py [Nx] [Nz] [steps]
+  tools/bench_hydrostatic.py [Nx] [Nz] [steps] [WENO | VectorInvariant]     (VectorInvariant: the model's defaults, Centered tracers)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,10 +13,12 @@ import oceananigans_jl_amd as ocn
 Nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 Nz = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+scheme = sys.argv[4] if len(sys.argv) > 4 else "WENO"
 ocn.set_math_mode(ocn.MATH_FAST)
 H, L = 1000.0, 1.0e6
 g = ocn.RectilinearGrid(ocn.GPU(), size=(Nx, Nx, Nz), x=(0, L), y=(0, L), z=(-H, 0.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
-m = ocn.HydrostaticFreeSurfaceModel(g, momentum_advection=ocn.WENO(), tracers=("T", "S"), free_surface=ocn.ExplicitFreeSurface(),
+m = ocn.HydrostaticFreeSurfaceModel(g, momentum_advection=ocn.WENO() if scheme == "WENO" else ocn.VectorInvariant(), tracers=("T", "S"),
+                                    free_surface=ocn.ExplicitFreeSurface(),
                                     coriolis=ocn.FPlane(f=1e-4), closure=ocn.ScalarDiffusivity(ν=1e-2, κ=1e-3),
                                     buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)))
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
@@ -37,5 +39,5 @@ for _ in range(steps):
 ocn.sync_device()
 ms = (time.perf_counter() - t0) / steps * 1e3
 finite = bool(torch.isfinite(m.eta).all()) and all(bool(torch.isfinite(f.interior_view()).all()) for f in m.velocities)
-print(f"hydrostatic slice {Nx}x{Nx}x{Nz} PPB, explicit free surface, WENO5, T+S, QAB2: {ms:.2f} ms/step, "
+print(f"hydrostatic slice {Nx}x{Nx}x{Nz} PPB, explicit free surface, {scheme}, T+S, QAB2: {ms:.2f} ms/step, "
       f"{Nx * Nx * Nz / ms * 1e3:.3e} cell-updates/s, max|eta| = {float(m.eta.abs().max()):.2e}, finite={finite}")
