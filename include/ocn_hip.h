@@ -318,6 +318,8 @@ int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, c
  * vorticity flux, EnergyConserving vertical advection and kinetic-energy gradient; Advection/vector_invariant_advection.jl:269-361) */
 int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                                      double *Gv, void *stream);
+/* fill_halo_regions!(eta): periodic x, y halos of the free-surface plane */
+int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream);
 /* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */
 int ocn_compute_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, void *stream);
 /* Gu -= g dx(eta), Gv -= g dy(eta) (explicit_free_surface.jl:36-40) */

@@ -322,6 +322,13 @@ int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const
     OCN_REQUIRE(grid->Hz >= 1, "ocn_compute_vector_invariant_momentum_tendencies: needs a z halo");
     return launch_vector_invariant(grid, u, v, w, Gu, Gv, as_stream(stream));
 }
+int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_fill_free_surface_halos");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(eta, "ocn_fill_free_surface_halos: null pointer");
+    return launch_plane_halo(grid, eta, as_stream(stream));
+}
 int ocn_compute_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, void *stream)
 {
     int st = validate_hydrostatic(grid, "ocn_compute_w_from_continuity");

@@ -319,6 +319,26 @@ int launch_barotropic_gradient(const ocn_grid *grid, double grav, const double *
     return OCN_SUCCESS;
 }
 
+// periodic x, y halos of the free-surface plane (the fill_halo_regions! of η in update_state!): every halo cell copies from the
+// interior cell it wraps to, corners included
+__global__ void plane_halo_kernel(int Nx, int Ny, int Hx, int Hy, double *__restrict__ e)
+{
+    const int sx = Nx + 2 * Hx, sy = Ny + 2 * Hy;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)sx * sy) return;
+    const int I = (int)(t % sx), J = (int)(t / sx);
+    if (I >= Hx && I < Hx + Nx && J >= Hy && J < Hy + Ny) return;
+    const int si = Hx + ((I - Hx) % Nx + Nx) % Nx, sj = Hy + ((J - Hy) % Ny + Ny) % Ny;
+    e[t] = e[si + (long long)sx * sj];
+}
+int launch_plane_halo(const ocn_grid *grid, double *plane, hipStream_t stream)
+{
+    const long long n = (long long)(grid->Nx + 2 * grid->Hx) * (grid->Ny + 2 * grid->Hy);
+    hipLaunchKernelGGL(plane_halo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, grid->Nx, grid->Ny, grid->Hx, grid->Hy, plane);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // compute_hydrostatic_free_surface_Gη! (Gη = w[i,j,Nz+1], explicit_free_surface.jl:98-140) followed by
 // _explicit_ab2_step_free_surface! (:84-96): η += Δt ((1.5 + χ) Gηⁿ - (0.5 + χ) Gη⁻ not_euler); Gηⁿ is left in Gn for the caller to cache
 __global__ __launch_bounds__(256) void free_surface_ab2_kernel(GridDev g, const double *__restrict__ w, double *__restrict__ eta,

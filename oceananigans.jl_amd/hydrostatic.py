@@ -90,12 +90,7 @@ class HydrostaticFreeSurfaceModel:
         return self.eta[g.Hy:g.Hy + g.Ny, g.Hx:g.Hx + g.Nx]
 
     def _fill_eta_halos(self):
-        g, e = self.grid, self.eta
-        Hx, Hy, Nx, Ny = g.Hx, g.Hy, g.Nx, g.Ny
-        e[:, :Hx] = e[:, Nx:Nx + Hx]
-        e[:, Nx + Hx:] = e[:, Hx:2 * Hx]
-        e[:Hy, :] = e[Ny:Ny + Hy, :]
-        e[Ny + Hy:, :] = e[Hy:2 * Hy, :]
+        _lib.call("ocn_fill_free_surface_halos", self.grid.cref, self.eta.data_ptr(), stream_ptr())
 
     # ---- update_state! (update_hydrostatic_free_surface_model_state.jl:35-53, 74-96) -------------------------------------
     def update_state(self, compute_tendencies=True):
