@@ -315,9 +315,11 @@ int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, con
 int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, const double *u, const double *v, const double *w,
                            double *Gu, double *Gv, double *Gw, const int32_t *range, void *stream);
 /* Gu = -U_dot_grad(u), Gv = -U_dot_grad(v) with momentum_advection = VectorInvariant() (the model's default: EnstrophyConserving
- * vorticity flux, EnergyConserving vertical advection and kinetic-energy gradient; Advection/vector_invariant_advection.jl:269-361) */
+ * vorticity flux, EnergyConserving vertical advection and kinetic-energy gradient; Advection/vector_invariant_advection.jl:269-361);
+ * with eta, the barotropic pressure gradient of ocn_add_barotropic_pressure_gradient is subtracted in the same pass */
 int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
-                                                     double *Gv, void *stream);
+                                                     double *Gv, const double *eta /* or NULL: without - g grad(eta) */,
+                                                     double gravitational_acceleration, void *stream);
 /* fill_halo_regions!(eta): periodic x, y halos of the free-surface plane */
 int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream);
 /* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */

@@ -314,13 +314,13 @@ static int validate_hydrostatic(const ocn_grid *grid, const char *who)
     return OCN_SUCCESS;
 }
 int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
-                                                     double *Gv, void *stream)
+                                                     double *Gv, const double *eta, double gravitational_acceleration, void *stream)
 {
     int st = validate_hydrostatic(grid, "ocn_compute_vector_invariant_momentum_tendencies");
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && Gu && Gv, "ocn_compute_vector_invariant_momentum_tendencies: null field pointer");
     OCN_REQUIRE(grid->Hz >= 1, "ocn_compute_vector_invariant_momentum_tendencies: needs a z halo");
-    return launch_vector_invariant(grid, u, v, w, Gu, Gv, as_stream(stream));
+    return launch_vector_invariant(grid, u, v, w, Gu, Gv, as_stream(stream), eta, gravitational_acceleration);
 }
 int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream)
 {

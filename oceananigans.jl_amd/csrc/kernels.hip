@@ -245,9 +245,10 @@ int launch_w_from_continuity(const ocn_grid *grid, const double *u, const double
 // Gu = -U_dot_∇u, Gv = -U_dot_∇v of the reference's default VectorInvariant() scheme (Advection/vector_invariant_advection.jl:
 // 269-275): EnstrophyConserving vorticity flux (:360-361, ζ₃ᶠᶠᶜ of Operators/vorticity_operators.jl:4-11), EnergyConserving
 // vertical advection (:315-319) and kinetic-energy gradient (:304-308).  ℑ = 0.5 (a + b), δ = a - b, ∂ = δ / Δ; one thread per cell.
+// eta != NULL: the barotropic pressure gradient - g ∇η (barotropic_gradient_kernel below) is subtracted in the same pass.
 __global__ __launch_bounds__(256) void vector_invariant_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                                const double *__restrict__ w, double *__restrict__ Gu,
-                                                               double *__restrict__ Gv)
+                                                               double *__restrict__ Gv, const double *__restrict__ eta, double grav)
 {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny) return;
@@ -273,7 +274,12 @@ __global__ __launch_bounds__(256) void vector_invariant_kernel(GridDev g, const 
         auto Z = [&](int c, double dzf) { return (0.5 * (Az * W_(-1, 0, c) + Az * W_(0, 0, c))) * ((U_(0, 0, c) - U_(0, 0, c - 1)) / dzf); };
         const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
         const double bern = (Kh(0, 0) - Kh(-1, 0)) / dx;
-        Gu[o] = -((hadv + vadv) + bern);
+        double G = -((hadv + vadv) + bern);
+        if (eta) {
+            const long long e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);
+            G -= grav * ((eta[e] - eta[e - 1]) / g.dx);
+        }
+        Gu[o] = G;
     }
     {   // ---- v
         auto n = [&](int b) { return 0.5 * (dy * U_(0, b, 0) + dy * U_(1, b, 0)); };  // ℑxᶜᵃᵃ(Δy_qᶠᶜᶜ u) at (i, j + b)
@@ -281,18 +287,23 @@ __global__ __launch_bounds__(256) void vector_invariant_kernel(GridDev g, const 
         auto Z = [&](int c, double dzf) { return (0.5 * (Az * W_(0, -1, c) + Az * W_(0, 0, c))) * ((V_(0, 0, c) - V_(0, 0, c - 1)) / dzf); };
         const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
         const double bern = (Kh(0, 0) - Kh(0, -1)) / dy;
-        Gv[o] = -((hadv + vadv) + bern);
+        double G = -((hadv + vadv) + bern);
+        if (eta) {
+            const long long e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);
+            G -= grav * ((eta[e] - eta[e - L.sx]) / g.dy);
+        }
+        Gv[o] = G;
     }
 #undef U_
 #undef V_
 #undef W_
 }
 int launch_vector_invariant(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
-                            hipStream_t stream)
+                            hipStream_t stream, const double *eta, double grav)
 {
     GridDev g = to_dev(*grid);
     dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
-    hipLaunchKernelGGL(vector_invariant_kernel, nb, block, 0, stream, g, u, v, w, Gu, Gv);
+    hipLaunchKernelGGL(vector_invariant_kernel, nb, block, 0, stream, g, u, v, w, Gu, Gv, eta, grav);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -63,7 +63,7 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
                      const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0, int kc = 0,
                      long long chunk = 0, int scale_dz = 0, double scale = 1.0);
 int launch_vector_invariant(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
-                            hipStream_t stream);
+                            hipStream_t stream, const double *eta = nullptr, double grav = 0.0);
 int launch_plane_halo(const ocn_grid *grid, double *plane, hipStream_t stream);
 int launch_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, hipStream_t stream);
 int launch_barotropic_gradient(const ocn_grid *grid, double grav, const double *eta, double *Gu, double *Gv, hipStream_t stream);

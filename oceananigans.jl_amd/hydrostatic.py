@@ -106,14 +106,14 @@ class HydrostaticFreeSurfaceModel:
     def compute_tendencies(self):
         nh, g, s = self._nh, self.grid, stream_ptr()
         Gn = nh.timestepper._Gn
-        if self.vector_invariant:                                                                   # - U_dot_∇u, - U_dot_∇v
+        grav = self.free_surface.gravitational_acceleration
+        if self.vector_invariant:                                                         # - U_dot_∇u - g ∂x η, - U_dot_∇v - g ∂y η
             _lib.call("ocn_compute_vector_invariant_momentum_tendencies", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr,
-                      Gn[1].ptr, s)
+                      Gn[1].ptr, self.eta.data_ptr(), grav, s)
         else:
             _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
                       Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)
-        _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, self.free_surface.gravitational_acceleration, self.eta.data_ptr(),
-                  Gn[0].ptr, Gn[1].ptr, s)                                                          # - g ∇η
+            _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, grav, self.eta.data_ptr(), Gn[0].ptr, Gn[1].ptr, s)  # - g ∇η
         _lib.call("ocn_add_momentum_terms", g.cref, C.byref(nh._terms), self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr, Gn[1].ptr,
                   Gn[2].ptr, None, s)                                                               # - f x U - ∇pHY′ - ∂ⱼτᵢⱼ
         for n, c in enumerate(self.tracers):
