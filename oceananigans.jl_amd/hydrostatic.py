@@ -66,7 +66,8 @@ class HydrostaticFreeSurfaceModel:
         # fields, physics descriptors, tendency storage and the Adams-Bashforth bookkeeping of the nonhydrostatic model are reused;
         # its pressure solver and w tendency are simply not used
         self._nh = NonhydrostaticModel(grid, advection=container_advection, tracers=tracers, timestepper="QuasiAdamsBashforth2",
-                                       closure=closure, buoyancy=buoyancy, coriolis=coriolis, boundary_conditions=boundary_conditions)
+                                       closure=closure, buoyancy=buoyancy, coriolis=coriolis, boundary_conditions=boundary_conditions,
+                                       pressure_solver=None)
         nh = self._nh
         self.grid, self.architecture, self.clock = grid, grid.architecture, nh.clock
         self.free_surface = free_surface

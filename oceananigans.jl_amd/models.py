@@ -80,7 +80,7 @@ class QuasiAdamsBashforth2TimeStepper(_TendencyStore):
 class NonhydrostaticModel:
     def __init__(self, grid, advection=None, tracers=(), timestepper="RungeKutta3", closure=None, buoyancy=None,
                  coriolis=None, forcing=None, stokes_drift=None, boundary_conditions=None,
-                 hydrostatic_pressure_anomaly="default"):
+                 hydrostatic_pressure_anomaly="default", pressure_solver="default"):
         for name, val in (("forcing", forcing), ("stokes_drift", stokes_drift)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the MI355X hot-path scope (see DESIGN.md)")
@@ -143,7 +143,8 @@ class NonhydrostaticModel:
                 raise NotImplementedError("AnisotropicMinimumDissipation needs a non-Flat z")
             self.diffusivity_fields = {"nu_e": CenterField(grid, nu_bcs),
                                        "kappa_e": tuple(CenterField(grid, kappa_bcs.get(n)) for n in tracers)}
-        self.pressure_solver = nonhydrostatic_pressure_solver(grid)
+        # (pressure_solver=None: no solver is built -- the HydrostaticFreeSurfaceModel reuses this class as its field container)
+        self.pressure_solver = nonhydrostatic_pressure_solver(grid) if pressure_solver == "default" else pressure_solver
         prog = self.prognostic_fields()
         if timestepper in ("RungeKutta3", ":RungeKutta3"):
             self.timestepper = RungeKutta3TimeStepper(grid, prog, model=self)
