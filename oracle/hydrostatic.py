@@ -13,8 +13,10 @@ restated here:
 
 PARITY UNPINNED: the reference's own tests of this model are time-stepping smoke tests (test_hydrostatic_free_surface_models.jl);
 tests/test_oracle_hydrostatic.py checks identities, a linear free-surface wave and the order of accuracy of the vector-invariant
-advection.  Not covered: split-explicit / implicit free surfaces, upwinding vector-invariant variants, z-star coordinates,
-vertically implicit diffusion, immersed boundaries, forcing.  HIP counterpart: oceananigans.jl_amd/hydrostatic.py
+advection; the split-explicit free surface (ForwardBackwardScheme, `split_explicit_substeps`; SplitExplicitFreeSurfaces/*.jl) is
+pinned by the reference's own solver tests re-expressed.  Not covered: AdamsBashforth3Scheme substepping, SplitRungeKutta3,
+implicit free surfaces, upwinding vector-invariant variants, z-star coordinates, vertically implicit diffusion, immersed
+boundaries, forcing.  HIP counterpart: oceananigans.jl_amd/hydrostatic.py
 (tests/test_gpu_hydrostatic.py compares the two bit for bit).
 """
 import numpy as np
@@ -79,6 +81,51 @@ def vector_invariant_momentum_tendencies(g, u, v, w, Gu, Gv):
     g.interior_N(Gv)[...] = -((hadv_v + vadv_v) + bern_v)
 
 
+def averaging_shape_function(tau, p=2, q=4, r=0.18927):
+    """Shchepetkin & McWilliams (2005) averaging kernel (split_explicit_free_surface.jl:191-194)"""
+    tau0 = (p + 2) * (p + q + 2) / (p + 1) / (p + q + 1)
+    return (tau / tau0) ** p * (1 - (tau / tau0) ** q) - r * (tau / tau0)
+
+
+def weights_from_substeps(substeps, averaging_kernel=averaging_shape_function):
+    """weights_from_substeps (split_explicit_free_surface.jl:228-241): fractional step size Δτ and the normalised averaging
+    weights, truncated at Julia's searchsortedlast(weights, 0, rev=true)."""
+    tau = np.linspace(0.0, 2.0, substeps + 1)
+    dtau = tau[1] - tau[0]
+    w = np.array([averaging_kernel(t) for t in tau[1:]])
+    lo, hi = 0, len(w) + 1                      # Base.searchsortedlast with the Reverse ordering, on 1-based indices
+    while lo < hi - 1:
+        mid = (lo + hi) >> 1
+        if w[mid - 1] < 0:                      # lt(Reverse, 0, v[m]) = isless(v[m], 0)
+            hi = mid
+        else:
+            lo = mid
+    w = w[:lo]
+    w = w / w.sum()
+    return float(dtau), w
+
+
+def constant_averaging_kernel(tau):
+    return 1.0
+
+
+def iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau, weights, grav, H, dx, dy):
+    """iterate_split_explicit! with the ForwardBackwardScheme on a (Periodic, Periodic) static grid of column depth H
+    (step_split_explicit_free_surface.jl:3-46, 62-98): for every weight, η -= Δτ (δx(Δy U) + δy(Δx V)) / Az, then
+    U += Δτ (-g H ∂x η + Gᵁ), V likewise, and the filtered state accumulates weight x (η, U, V).  In place, interior arrays
+    [i, j]; the periodic wrap is the topology-aware δxTᶜᵃᵃ / ∂xTᶠᶜᶠ."""
+    Az = dx * dy
+    for wgt in weights:
+        eta[...] = eta - dtau * ((dy * np.roll(U, -1, 0) - dy * U) + (dx * np.roll(V, -1, 1) - dx * V)) / Az
+        Un = U + dtau * (-grav * H * ((eta - np.roll(eta, 1, 0)) / dx) + GU)
+        Vn = V + dtau * (-grav * H * ((eta - np.roll(eta, 1, 1)) / dy) + GV)
+        etab += wgt * eta
+        Ub += wgt * Un
+        Vb += wgt * Vn
+        U[...] = Un
+        V[...] = Vn
+
+
 class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     """HydrostaticFreeSurfaceModel(; grid, momentum_advection, tracer_advection, free_surface = ExplicitFreeSurface(g), coriolis,
     closure, buoyancy, tracers) with the QuasiAdamsBashforth2 time stepper.  Reuses the nonhydrostatic oracle's fields and
@@ -86,8 +133,19 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     reference's reduced field)."""
 
     def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None,
-                 buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth):
+                 buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None):
+        """split_explicit_substeps = N: free_surface = SplitExplicitFreeSurface(substeps = N) with the ForwardBackwardScheme
+        (split_explicit_free_surface.jl:60-97); None: ExplicitFreeSurface."""
         assert grid.topo[2] == O.BOUNDED and grid.topo[0] == O.PERIODIC and grid.topo[1] == O.PERIODIC
+        self.split = split_explicit_substeps
+        if self.split is not None:
+            assert grid.dzc is None or True
+            self.frac_dt, self.weights = weights_from_substeps(int(self.split))
+            shp = (grid.Nx, grid.Ny)
+            self.U, self.V = np.zeros(shp), np.zeros(shp)          # barotropic velocities (transports), interior only
+            self.Ub, self.Vb, self.etab = np.zeros(shp), np.zeros(shp), np.zeros(shp)   # filtered state
+            self.GU, self.GV = np.zeros(shp), np.zeros(shp)
+            self.initialized = False
         self.eta = np.zeros((grid.Nx + 2 * grid.Hx, grid.Ny + 2 * grid.Hy), order="F")
         self.g_eta = np.zeros_like(self.eta)
         self.g_eta_m = np.zeros_like(self.eta)
@@ -141,8 +199,9 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         e, Hx, Hy, Hz = self.eta, g.Hx, g.Hy, g.Hz
         px = np.zeros_like(e)
         py = np.zeros_like(e)
-        px[1:, :] = self.gravity * ((e[1:, :] - e[:-1, :]) / g.dx)
-        py[:, 1:] = self.gravity * ((e[:, 1:] - e[:, :-1]) / g.dy)
+        if getattr(self, "split", None) is None:  # SplitExplicitFreeSurface: explicit_barotropic_pressure_*_gradient = 0 (SplitExplicitFreeSurfaces.jl:46-47)
+            px[1:, :] = self.gravity * ((e[1:, :] - e[:-1, :]) / g.dx)
+            py[:, 1:] = self.gravity * ((e[:, 1:] - e[:, :-1]) / g.dy)
         ii, jj = slice(Hx, Hx + g.Nx), slice(Hy, Hy + g.Ny)
         Gu[ii, jj, Hz:Hz + g.Nz] -= px[ii, jj, None]
         Gv[ii, jj, Hz:Hz + g.Nz] -= py[ii, jj, None]
@@ -160,12 +219,92 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
                 O.apply_flux_bcs(g, l, f, G, self.bcs[n])
 
     # ---- time_step! (quasi_adams_bashforth_2.jl:74-115 with ab2_step!(::HydrostaticFreeSurfaceModel), :9-26) -------------------
+    # ---- SplitExplicitFreeSurface pieces ---------------------------------------------------------------------------------
+    def _dz_centres(self):
+        g = self.grid
+        return np.full(g.Nz, g.dz) if g.dzc is None else np.asarray(g.dzc[g.Hz:g.Hz + g.Nz])
+
+    def _barotropic_mode(self, f):
+        """integrate_barotropic_mode! (barotropic_split_explicit_corrector.jl:13-32) on a static grid (σ = 1): Σₖ Δz u σ, k upwards"""
+        g, dz = self.grid, self._dz_centres()
+        fi = g.interior_N(f)
+        out = dz[0] * fi[:, :, 0] * 1.0
+        for k in range(1, g.Nz):
+            out = out + dz[k] * fi[:, :, k] * 1.0
+        return out
+
+    def initialize(self):
+        """initialize_free_surface! (initialize_split_explicit_substepping.jl:15-25), once, before the first step (the reference
+        calls it from run!(simulation) / first_time_step!)"""
+        if self.split is not None:
+            self.U[...] = self._barotropic_mode(self.u)
+            self.V[...] = self._barotropic_mode(self.v)
+            self.initialized = True
+
+    def _split_explicit_step(self, dt, chi):
+        g, grav, H = self.grid, self.gravity, self.grid.Lz   # column depth of a static, flat-bottom grid
+        dx, dy, Az = g.dx, g.dy, g.dx * g.dy
+        dz = self._dz_centres()
+        # compute_free_surface_tendency!: GU = Σₖ Δz ab2_step_G (compute_slow_tendencies.jl:12-32), then the filtered state is zeroed
+        C1, C2 = 3 * 1.0 / 2 + chi, 1.0 / 2 + chi
+        not_euler = 1.0 if C2 != 0 else 0.0
+        for G, idx in ((self.GU, 0), (self.GV, 1)):
+            gn, gm = g.interior_N(self.Gn[idx]), g.interior_N(self.Gm[idx])
+            acc = dz[0] * (C1 * gn[:, :, 0] - C2 * gm[:, :, 0] * not_euler)
+            for k in range(1, g.Nz):
+                acc = acc + dz[k] * (C1 * gn[:, :, k] - C2 * gm[:, :, k] * not_euler)
+            G[...] = acc
+        self.etab[...] = 0.0
+        self.Ub[...] = 0.0
+        self.Vb[...] = 0.0
+        return dx, dy, Az, grav, H
+
+    def _substep(self, dt):
+        """iterate_split_explicit! with the ForwardBackwardScheme (step_split_explicit_free_surface.jl:3-46, 62-98) and
+        _update_split_explicit_state! (:100-108); periodic wrap = the topology-aware operators δxTᶜᵃᵃ, ∂xTᶠᶜᶠ"""
+        g, grav, H = self.grid, self.gravity, self.grid.Lz
+        dx, dy, Az = g.dx, g.dy, g.dx * g.dy
+        Hx, Hy = g.Hx, g.Hy
+        eta = self.eta[Hx:Hx + g.Nx, Hy:Hy + g.Ny].copy()
+        iterate_split_explicit(eta, self.U, self.V, self.etab, self.Ub, self.Vb, self.GU, self.GV, self.frac_dt * dt, self.weights,
+                               grav, H, dx, dy)
+        self.eta[Hx:Hx + g.Nx, Hy:Hy + g.Ny] = self.etab
+        self.U[...] = self.Ub
+        self.V[...] = self.Vb
+
+    def _barotropic_corrector(self):
+        """barotropic_split_explicit_corrector! (:44-71): U̅ <- Σ Δz u of the stepped velocities, u += (U - U̅) / H at every level"""
+        g, H = self.grid, self.grid.Lz
+        self.Ub[...] = self._barotropic_mode(self.u)
+        self.Vb[...] = self._barotropic_mode(self.v)
+        ui, vi = g.interior_N(self.u), g.interior_N(self.v)
+        ui[...] = ui + ((self.U - self.Ub) / H)[:, :, None]
+        vi[...] = vi + ((self.V - self.Vb) / H)[:, :, None]
+
     def time_step(self, dt, euler=False):
         g = self.grid
         if self.iteration == 0:
+            if self.split is not None and not self.initialized:
+                self.initialize()
             self.update_state(compute_tendencies=True)
         euler = euler or (dt != self.last_dt)
         chi = -0.5 if euler else self.chi
+        if self.split is not None:
+            self._split_explicit_step(dt, chi)                 # compute_free_surface_tendency!
+            for idx in (0, 1):                                 # local_ab2_step!
+                O.ab2_step(g, self.locs[idx], self.fields[idx], self.Gn[idx], self.Gm[idx], dt, chi)
+            alpha, beta = 1.5 + chi, 0.5 + chi
+            for n, c in enumerate(self.tracers):
+                ci, gn, gm = g.interior_N(c), g.interior_N(self.Gn[3 + n]), g.interior_N(self.Gm[3 + n])
+                ci[...] = 1.0 * ci + dt * (alpha * 1.0 * gn - beta * 1.0 * gm)
+            self._substep(dt)                                  # step_free_surface!
+            self.time += dt
+            self.iteration += 1
+            self.last_dt = dt
+            self._barotropic_corrector()                       # pressure_correct_velocities!
+            self.cache_previous_tendencies()
+            self.update_state(compute_tendencies=True)
+            return
         # compute_free_surface_tendency!: Gη = w[i, j, Nz+1] (explicit_free_surface.jl:126-140)
         self.g_eta[...] = self.w[:, :, g.Hz + g.Nz]
         # local_ab2_step!: velocities with ab2_step_field!, tracers with _ab2_step_tracer_field! (σ = 1)

@@ -125,3 +125,96 @@ def test_default_model_time_steps():
     for _ in range(4):
         m.time_step(1.0)
     assert all(np.isfinite(f).all() for f in m.fields) and np.isfinite(m.eta).all() and np.abs(m.eta).max() > 0
+
+
+# ---- SplitExplicitFreeSurface: the reference's own solver tests re-expressed (test_split_explicit_free_surface_solver.jl) ----------
+def _sefs_setup():
+    Nx, Ny = 128, 64
+    L = 2 * np.pi
+    grav = Hy.g_Earth
+    H = 1 / grav                     # Lz = 1 / g_Earth: g H = 1 (:21)
+    dx, dy = L / Nx, L / Ny
+    xc, xf = (np.arange(Nx) + 0.5) * dx, np.arange(Nx) * dx
+    z = lambda: np.zeros((Nx, Ny))
+    return Nx, Ny, dx, dy, xc, xf, grav, H, z
+
+
+def test_split_explicit_one_timestep():
+    """:36-56: η = sin x, one substep with Δτ = 1: U = -cos(x_face) within 1e-3"""
+    Nx, Ny, dx, dy, xc, xf, grav, H, z = _sefs_setup()
+    _, weights = Hy.weights_from_substeps(200, Hy.constant_averaging_kernel)
+    eta = np.sin(xc)[:, None] * np.ones((1, Ny))
+    U, V = z(), z()
+    Hy.iterate_split_explicit(eta, U, V, z(), z(), z(), z(), z(), 1.0, weights[:1], grav, H, dx, dy)
+    assert np.abs(U - (-np.cos(xf))[:, None]).max() < 1e-3
+
+
+def test_split_explicit_wave_returns_after_one_period():
+    """:58-100: g H = 1, k = 1: after T = 2π the forward-backward substepping brings η back to sin x (1e-6) and U to 0 (1e-3)"""
+    Nx, Ny, dx, dy, xc, xf, grav, H, z = _sefs_setup()
+    T = 2 * np.pi
+    dtau = 2 * np.pi / max(Nx, Ny) * 5e-2
+    Nt = int(np.floor(T / dtau))
+    dtau_end = T - Nt * dtau
+    _, weights = Hy.weights_from_substeps(Nt, Hy.constant_averaging_kernel)
+    eta0 = np.sin(xc)[:, None] * np.ones((1, Ny))
+    eta, U, V = eta0.copy(), z(), z()
+    etab, Ub, Vb, GU, GV = z(), z(), z(), z(), z()
+    for _ in range(Nt):
+        Hy.iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau, weights[:1], grav, H, dx, dy)
+    Hy.iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau_end, weights[:1], grav, H, dx, dy)
+    assert np.abs(U).max() < 1e-3
+    assert np.abs(eta - eta0).max() < 1e-6
+
+
+def test_split_explicit_averaging_does_nothing_to_a_uniform_state():
+    """:107-155: uniform η, U, V are fixed points and their constant-kernel averages reproduce them (100 eps)"""
+    Nx, Ny, dx, dy, xc, xf, grav, H, z = _sefs_setup()
+    frac, weights = Hy.weights_from_substeps(200, Hy.constant_averaging_kernel)
+    assert len(weights) == 200 and abs(frac - 0.01) < 1e-15
+    eta, U, V = z() + 1.0, z() + 2.0, z() + 3.0
+    etab, Ub, Vb = z(), z(), z()
+    dtau = 2 * np.pi / max(Nx, Ny) * 1e-2
+    for _ in range(len(weights)):
+        Hy.iterate_split_explicit(eta, U, V, etab, Ub, Vb, z(), z(), dtau, weights[:1], grav, H, dx, dy)
+    tol = 100 * np.finfo(float).eps
+    for a, v in ((eta, 1.0), (U, 2.0), (V, 3.0), (etab, 1.0), (Ub, 2.0), (Vb, 3.0)):
+        assert np.abs(a - v).max() < tol
+
+
+def test_split_explicit_weights():
+    """weights_from_substeps (split_explicit_free_surface.jl:228-241) with the default Shchepetkin-McWilliams kernel: truncated where
+    the kernel turns negative, normalised, centred on the baroclinic step (Σ aₘ m/M ≈ 1, the kernel's design condition)"""
+    frac, w = Hy.weights_from_substeps(30)
+    assert len(w) == 21 and abs(frac - 2 / 30) < 1e-15
+    assert abs(w.sum() - 1) < 1e-14 and w[-1] > 0 and w[:3].max() < 0   # the kernel starts slightly negative (its -r τ/τ₀ term)
+    tau = np.linspace(0, 2, 31)[1:]
+    assert Hy.averaging_shape_function(tau[len(w)]) < 0                   # the first dropped weight would be negative
+    assert abs((w * np.arange(1, len(w) + 1)).sum() * frac - 1) < 0.02
+
+
+def test_split_explicit_model_wave_and_barotropic_consistency():
+    """The whole QAB2 step with the split-explicit free surface (ab2_step! -> substepping -> barotropic corrector): a long
+    surface wave at a baroclinic gravity-wave CFL of 0.8 stays stable and close to cos(ω t) (the averaging damps it slightly),
+    mean(η) is conserved and Σ Δz u equals the barotropic transport after every step."""
+    Nx, H, L = 32, 20.0, 4.0e3
+    g = O.Grid((Nx, 4, 4), x=(0, L), y=(0, 500.0), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2", split_explicit_substeps=30)
+    a, k = 1e-4, 2 * np.pi / L
+    x = (np.arange(Nx) + 0.5) * g.dx
+    m.set(eta=a * np.cos(k * x)[:, None] * np.ones((1, 4)))
+    kd = 2 / g.dx * np.sin(k * g.dx / 2)
+    omega = np.sqrt(Hy.g_Earth * H) * kd
+    dt = 2 * np.pi / omega / 40
+    assert np.sqrt(Hy.g_Earth * H) * dt / g.dx > 0.75
+    amp = []
+    for n in range(80):
+        m.time_step(dt)
+        e = m.eta[g.Hx:g.Hx + Nx, g.Hy:g.Hy + 4]
+        amp.append(2 * np.mean(e[:, 0] * np.cos(k * x)) / a)
+        assert abs(e.sum()) < 1e-16 * Nx * 4
+        assert np.abs(m._barotropic_mode(m.u) - m.U).max() <= 8 * np.finfo(float).eps * max(np.abs(m.U).max(), 1e-30)
+    amp = np.array(amp)
+    t = dt * np.arange(1, 81)
+    assert np.abs(amp - np.cos(omega * t)).max() < 0.12
+    assert 0.9 < amp[79] < 1.0
