@@ -320,6 +320,21 @@ int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, c
 int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                                      double *Gv, const double *eta /* or NULL: without - g grad(eta) */,
                                                      double gravitational_acceleration, void *stream);
+/* SplitExplicitFreeSurface with the ForwardBackwardScheme (the SplitExplicitFreeSurfaces directory), (Periodic, Periodic) static grid of column
+ * depth H; every 2-D quantity is an (Nx+2Hx) x (Ny+2Hy) plane like eta, of which only the interior is used.
+ *   forcing:   compute_split_explicit_forcing! (compute_slow_tendencies.jl:12-32)
+ *   substeps:  initialize_free_surface_state! + iterate_split_explicit! + _update_split_explicit_state!
+ *              (step_split_explicit_free_surface.jl:3-108); `weights`: n averaging weights, HOST array; dtau = fractional step x dt
+ *   mode:      integrate_barotropic_mode! (initialize_free_surface!)
+ *   corrector: barotropic_split_explicit_corrector! (barotropic_split_explicit_corrector.jl:44-71) */
+int ocn_split_explicit_forcing(const ocn_grid *grid, const double *Gu, const double *Gu_previous, const double *Gv, const double *Gv_previous,
+                               double chi, double *GU, double *GV, void *stream);
+int ocn_split_explicit_substeps(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
+                                double *V_filtered, const double *GU, const double *GV, void *stream);
+int ocn_compute_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, void *stream);
+int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *U_filtered,
+                                            double *V_filtered, double column_depth, void *stream);
 /* fill_halo_regions!(eta): periodic x, y halos of the free-surface plane */
 int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream);
 /* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */

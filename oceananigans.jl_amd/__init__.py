@@ -28,7 +28,7 @@ from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTr
                       nonhydrostatic_pressure_solver, solve)
 
 
-from .hydrostatic import ExplicitFreeSurface, HydrostaticFreeSurfaceModel, VectorInvariant  # noqa: E402
+from .hydrostatic import ExplicitFreeSurface, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface, VectorInvariant  # noqa: E402
 
 
 def set_math_mode(mode):

@@ -101,6 +101,10 @@ _SIGS = {
     "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
     "ocn_add_momentum_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_vector_invariant_momentum_tendencies": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_split_explicit_forcing": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _vp],
+    "ocn_split_explicit_substeps": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_compute_barotropic_mode": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
+    "ocn_barotropic_split_explicit_corrector": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp],
     "ocn_fill_free_surface_halos": [C.POINTER(CGrid), _vp, _vp],
     "ocn_compute_w_from_continuity": [C.POINTER(CGrid), _vp, _vp, _vp, _vp],
     "ocn_add_barotropic_pressure_gradient": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp],

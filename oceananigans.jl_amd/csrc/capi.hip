@@ -322,6 +322,40 @@ int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const
     OCN_REQUIRE(grid->Hz >= 1, "ocn_compute_vector_invariant_momentum_tendencies: needs a z halo");
     return launch_vector_invariant(grid, u, v, w, Gu, Gv, as_stream(stream), eta, gravitational_acceleration);
 }
+int ocn_split_explicit_forcing(const ocn_grid *grid, const double *Gu, const double *Gu_previous, const double *Gv, const double *Gv_previous,
+                               double chi, double *GU, double *GV, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_split_explicit_forcing");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(Gu && Gu_previous && Gv && Gv_previous && GU && GV, "ocn_split_explicit_forcing: null pointer");
+    return launch_split_explicit_forcing(grid, Gu, Gu_previous, Gv, Gv_previous, chi, GU, GV, as_stream(stream));
+}
+int ocn_split_explicit_substeps(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
+                                double *V_filtered, const double *GU, const double *GV, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_split_explicit_substeps");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(n >= 1 && weights, "ocn_split_explicit_substeps: needs n >= 1 averaging weights (host array)");
+    OCN_REQUIRE(eta && U && V && eta_filtered && U_filtered && V_filtered && GU && GV, "ocn_split_explicit_substeps: null pointer");
+    return launch_split_explicit_substeps(grid, n, weights, dtau, gravitational_acceleration, column_depth, eta, U, V, eta_filtered, U_filtered,
+                                          V_filtered, GU, GV, as_stream(stream));
+}
+int ocn_compute_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_compute_barotropic_mode");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && U && V, "ocn_compute_barotropic_mode: null pointer");
+    return launch_barotropic_mode(grid, u, v, U, V, as_stream(stream));
+}
+int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *U_filtered,
+                                            double *V_filtered, double column_depth, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_barotropic_split_explicit_corrector");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && U && V && U_filtered && V_filtered, "ocn_barotropic_split_explicit_corrector: null pointer");
+    return launch_barotropic_corrector(grid, u, v, U, V, U_filtered, V_filtered, column_depth, as_stream(stream));
+}
 int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream)
 {
     int st = validate_hydrostatic(grid, "ocn_fill_free_surface_halos");

@@ -350,6 +350,143 @@ int launch_plane_halo(const ocn_grid *grid, double *plane, hipStream_t stream)
     return OCN_SUCCESS;
 }
 
+// ---- SplitExplicitFreeSurface (SplitExplicitFreeSurfaces/*.jl), ForwardBackwardScheme, (Periodic, Periodic) static grid of column
+// depth H.  All 2-D quantities are (sx, sy) planes like η; only their interiors are used (indices wrap as in δxTᶜᵃᵃ / ∂xTᶠᶜᶠ).
+__device__ __forceinline__ long long plane_at(const GridDev &g, int i, int j)  // 1-based interior (i, j)
+{
+    return (i - 1 + g.Hx) + (long long)(g.Nx + 2 * g.Hx) * (j - 1 + g.Hy);
+}
+// compute_split_explicit_forcing! (compute_slow_tendencies.jl:12-32): Gᵁ = Σₖ Δz ((3/2 + χ) Guⁿ - (1/2 + χ) Gu⁻ not_euler)
+__global__ __launch_bounds__(256) void barotropic_forcing_kernel(GridDev g, const double *__restrict__ Gun, const double *__restrict__ Gum,
+                                                                 const double *__restrict__ Gvn, const double *__restrict__ Gvm, double chi,
+                                                                 double *__restrict__ GU, double *__restrict__ GV)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const double C1 = 3 * 1.0 / 2 + chi, C2 = 1.0 / 2 + chi, ne = (C2 != 0) ? 1.0 : 0.0;
+    long long o = at(L, i, j, 1);
+    double dz = g.dzc ? g.dzc[g.Hz] : g.dz;
+    double aU = dz * (C1 * Gun[o] - C2 * Gum[o] * ne), aV = dz * (C1 * Gvn[o] - C2 * Gvm[o] * ne);
+    for (int k = 2; k <= g.Nz; ++k) {
+        o += L.s3;
+        dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        aU = aU + dz * (C1 * Gun[o] - C2 * Gum[o] * ne);
+        aV = aV + dz * (C1 * Gvn[o] - C2 * Gvm[o] * ne);
+    }
+    GU[plane_at(g, i, j)] = aU;
+    GV[plane_at(g, i, j)] = aV;
+}
+// _split_explicit_free_surface! (step_split_explicit_free_surface.jl:3-11): η -= Δτ (δx(Δy U) + δy(Δx V)) / Az
+__global__ __launch_bounds__(256) void split_explicit_eta_kernel(GridDev g, double dtau, double *__restrict__ eta, const double *__restrict__ U,
+                                                                 const double *__restrict__ V)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const int ip = i == g.Nx ? 1 : i + 1, jp = j == g.Ny ? 1 : j + 1;
+    const double dx = g.dx, dy = g.dy, Az = dx * dy;
+    const long long e = plane_at(g, i, j);
+    eta[e] = eta[e] - dtau * ((dy * U[plane_at(g, ip, j)] - dy * U[e]) + (dx * V[plane_at(g, i, jp)] - dx * V[e])) / Az;
+}
+// _split_explicit_barotropic_velocity! (:13-46): U += Δτ (-g H ∂x η + Gᵁ), V likewise; the filtered state accumulates weight x (η, U, V)
+__global__ __launch_bounds__(256) void split_explicit_velocity_kernel(GridDev g, double w, double dtau, double grav, double H,
+                                                                      const double *__restrict__ eta, double *__restrict__ U,
+                                                                      double *__restrict__ V, double *__restrict__ etab,
+                                                                      double *__restrict__ Ub, double *__restrict__ Vb,
+                                                                      const double *__restrict__ GU, const double *__restrict__ GV)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const int im = i == 1 ? g.Nx : i - 1, jm = j == 1 ? g.Ny : j - 1;
+    const long long e = plane_at(g, i, j);
+    const double et = eta[e];
+    const double Un = U[e] + dtau * (-grav * H * ((et - eta[plane_at(g, im, j)]) / g.dx) + GU[e]);
+    const double Vn = V[e] + dtau * (-grav * H * ((et - eta[plane_at(g, i, jm)]) / g.dy) + GV[e]);
+    etab[e] += w * et;
+    Ub[e] += w * Un;
+    Vb[e] += w * Vn;
+    U[e] = Un;
+    V[e] = Vn;
+}
+// integrate_barotropic_mode! on a static grid (σ = 1): Σₖ Δz u σ (barotropic_split_explicit_corrector.jl:13-32)
+__global__ __launch_bounds__(256) void barotropic_mode_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                              double *__restrict__ U, double *__restrict__ V)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    long long o = at(L, i, j, 1);
+    double dz = g.dzc ? g.dzc[g.Hz] : g.dz;
+    double aU = dz * u[o] * 1.0, aV = dz * v[o] * 1.0;
+    for (int k = 2; k <= g.Nz; ++k) {
+        o += L.s3;
+        dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        aU = aU + dz * u[o] * 1.0;
+        aV = aV + dz * v[o] * 1.0;
+    }
+    U[plane_at(g, i, j)] = aU;
+    V[plane_at(g, i, j)] = aV;
+}
+// _barotropic_split_explicit_corrector! (:57-71): u += (U - U̅) / H at every level
+__global__ __launch_bounds__(256) void barotropic_corrector_kernel(GridDev g, double *__restrict__ u, double *__restrict__ v,
+                                                                   const double *__restrict__ U, const double *__restrict__ V,
+                                                                   const double *__restrict__ Ub, const double *__restrict__ Vb, double H)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const long long o = at(L, i, j, k), e = plane_at(g, i, j);
+    u[o] = u[o] + (U[e] - Ub[e]) / H;
+    v[o] = v[o] + (V[e] - Vb[e]) / H;
+}
+int launch_split_explicit_forcing(const ocn_grid *grid, const double *Gun, const double *Gum, const double *Gvn, const double *Gvm, double chi,
+                                  double *GU, double *GV, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    hipLaunchKernelGGL(barotropic_forcing_kernel, nb, block, 0, stream, g, Gun, Gum, Gvn, Gvm, chi, GU, GV);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+int launch_split_explicit_substeps(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                   double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                   hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const size_t bytes = (size_t)(g.Nx + 2 * g.Hx) * (g.Ny + 2 * g.Hy) * sizeof(double);
+    for (double *f : {etab, Ub, Vb}) OCN_CHECK_HIP(hipMemsetAsync(f, 0, bytes, stream));  // initialize_free_surface_state!
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    for (int m = 0; m < n; ++m) {
+        hipLaunchKernelGGL(split_explicit_eta_kernel, nb, block, 0, stream, g, dtau, eta, U, V);
+        hipLaunchKernelGGL(split_explicit_velocity_kernel, nb, block, 0, stream, g, weights[m], dtau, grav, H, eta, U, V, etab, Ub, Vb, GU, GV);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    // _update_split_explicit_state!: η, U, V <- their averages (the halos of these planes are not used by the substepping)
+    OCN_CHECK_HIP(hipMemcpyAsync(eta, etab, bytes, hipMemcpyDeviceToDevice, stream));
+    OCN_CHECK_HIP(hipMemcpyAsync(U, Ub, bytes, hipMemcpyDeviceToDevice, stream));
+    OCN_CHECK_HIP(hipMemcpyAsync(V, Vb, bytes, hipMemcpyDeviceToDevice, stream));
+    return OCN_SUCCESS;
+}
+int launch_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    hipLaunchKernelGGL(barotropic_mode_kernel, nb, block, 0, stream, g, u, v, U, V);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+int launch_barotropic_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *Ub, double *Vb, double H,
+                                hipStream_t stream)
+{
+    int st = launch_barotropic_mode(grid, u, v, Ub, Vb, stream);
+    if (st != OCN_SUCCESS) return st;
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(barotropic_corrector_kernel, nb, block, 0, stream, g, u, v, U, V, Ub, Vb, H);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // compute_hydrostatic_free_surface_Gη! (Gη = w[i,j,Nz+1], explicit_free_surface.jl:98-140) followed by
 // _explicit_ab2_step_free_surface! (:84-96): η += Δt ((1.5 + χ) Gηⁿ - (0.5 + χ) Gη⁻ not_euler); Gηⁿ is left in Gn for the caller to cache
 __global__ __launch_bounds__(256) void free_surface_ab2_kernel(GridDev g, const double *__restrict__ w, double *__restrict__ eta,

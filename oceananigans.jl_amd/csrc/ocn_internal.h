@@ -64,6 +64,14 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
                      long long chunk = 0, int scale_dz = 0, double scale = 1.0);
 int launch_vector_invariant(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                             hipStream_t stream, const double *eta = nullptr, double grav = 0.0);
+int launch_split_explicit_forcing(const ocn_grid *grid, const double *Gun, const double *Gum, const double *Gvn, const double *Gvm, double chi,
+                                  double *GU, double *GV, hipStream_t stream);
+int launch_split_explicit_substeps(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                   double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                   hipStream_t stream);
+int launch_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, hipStream_t stream);
+int launch_barotropic_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *Ub, double *Vb, double H,
+                                hipStream_t stream);
 int launch_plane_halo(const ocn_grid *grid, double *plane, hipStream_t stream);
 int launch_w_from_continuity(const ocn_grid *grid, const double *u, const double *v, double *w, hipStream_t stream);
 int launch_barotropic_gradient(const ocn_grid *grid, double grav, const double *eta, double *Gu, double *Gv, hipStream_t stream);

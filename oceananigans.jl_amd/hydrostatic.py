@@ -42,6 +42,40 @@ class ExplicitFreeSurface:
         self.gravitational_acceleration = float(gravitational_acceleration)
 
 
+def averaging_shape_function(tau, p=2, q=4, r=0.18927):
+    """Shchepetkin & McWilliams (2005) averaging kernel (split_explicit_free_surface.jl:191-194)"""
+    tau0 = (p + 2) * (p + q + 2) / (p + 1) / (p + q + 1)
+    return (tau / tau0) ** p * (1 - (tau / tau0) ** q) - r * (tau / tau0)
+
+
+def weights_from_substeps(substeps, averaging_kernel=averaging_shape_function):
+    """weights_from_substeps (split_explicit_free_surface.jl:228-241): (fractional step size, normalised averaging weights truncated at
+    Julia's searchsortedlast(weights, 0, rev=true))"""
+    import numpy as np
+    tau = np.linspace(0.0, 2.0, substeps + 1)
+    w = np.array([averaging_kernel(t) for t in tau[1:]])
+    lo, hi = 0, len(w) + 1
+    while lo < hi - 1:
+        mid = (lo + hi) >> 1
+        if w[mid - 1] < 0:
+            hi = mid
+        else:
+            lo = mid
+    w = w[:lo]
+    return float(tau[1] - tau[0]), w / w.sum()
+
+
+class SplitExplicitFreeSurface:
+    """SplitExplicitFreeSurface(; substeps, gravitational_acceleration = g_Earth, timestepper = ForwardBackwardScheme())
+    (split_explicit_free_surface.jl:60-97); cfl-based substepping and the AdamsBashforth3Scheme are not implemented."""
+
+    def __init__(self, substeps=None, gravitational_acceleration=g_Earth, averaging_kernel=averaging_shape_function):
+        if substeps is None:
+            substeps = 5  # MINIMUM_SUBSTEPS (step_split_explicit_free_surface.jl:51)
+        self.gravitational_acceleration = float(gravitational_acceleration)
+        self.fractional_step_size, self.averaging_weights = weights_from_substeps(int(substeps), averaging_kernel)
+
+
 class HydrostaticFreeSurfaceModel:
     def __init__(self, grid, momentum_advection=None, tracer_advection=None, tracers=(), free_surface=None, coriolis=None,
                  closure=None, buoyancy=None, boundary_conditions=None):
@@ -49,8 +83,9 @@ class HydrostaticFreeSurfaceModel:
             raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids on one GPU in this slice")
         if free_surface is None:
             free_surface = ExplicitFreeSurface()
-        if not isinstance(free_surface, ExplicitFreeSurface):
-            raise NotImplementedError("only free_surface = ExplicitFreeSurface(...) is implemented")
+        if not isinstance(free_surface, (ExplicitFreeSurface, SplitExplicitFreeSurface)):
+            raise NotImplementedError("free_surface must be ExplicitFreeSurface(...) or SplitExplicitFreeSurface(substeps=...)")
+        self.split = isinstance(free_surface, SplitExplicitFreeSurface)
         if momentum_advection is None:
             momentum_advection = VectorInvariant()  # the reference's default (hydrostatic_free_surface_model.jl)
         self.vector_invariant = isinstance(momentum_advection, VectorInvariant)
@@ -78,6 +113,11 @@ class HydrostaticFreeSurfaceModel:
         self.eta = torch.zeros((sy, sx), dtype=torch.float64, device=dev)       # η[i, j, Nz+1], halos included, x fastest
         self._Geta = torch.zeros_like(self.eta)
         self._Geta_m = torch.zeros_like(self.eta)
+        if self.split:  # barotropic velocities, filtered state, slow forcing: planes like η (interiors used)
+            self.U, self.V, self._Ub, self._Vb, self._etab, self._GU, self._GV = (torch.zeros_like(self.eta) for _ in range(7))
+            w = free_surface.averaging_weights
+            self._weights = (C.c_double * len(w))(*[float(x) for x in w])
+            self._initialized = False
         self._adv_only = _lib.CModelTerms()                                     # the advective part alone, by scheme
         self._adv_only.advection = nh._terms.advection
         self.update_state(compute_tendencies=False)
@@ -108,13 +148,16 @@ class HydrostaticFreeSurfaceModel:
         nh, g, s = self._nh, self.grid, stream_ptr()
         Gn = nh.timestepper._Gn
         grav = self.free_surface.gravitational_acceleration
+        # explicit_barotropic_pressure_x/y_gradient: g ∇η for the ExplicitFreeSurface, zero for the split-explicit one
+        eta_ptr = None if self.split else self.eta.data_ptr()
         if self.vector_invariant:                                                         # - U_dot_∇u - g ∂x η, - U_dot_∇v - g ∂y η
             _lib.call("ocn_compute_vector_invariant_momentum_tendencies", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr,
-                      Gn[1].ptr, self.eta.data_ptr(), grav, s)
+                      Gn[1].ptr, eta_ptr, grav, s)
         else:
             _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
                       Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)
-            _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, grav, self.eta.data_ptr(), Gn[0].ptr, Gn[1].ptr, s)  # - g ∇η
+            if not self.split:
+                _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, grav, self.eta.data_ptr(), Gn[0].ptr, Gn[1].ptr, s)  # - g ∇η
         _lib.call("ocn_add_momentum_terms", g.cref, C.byref(nh._terms), self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr, Gn[1].ptr,
                   Gn[2].ptr, None, s)                                                               # - f x U - ∇pHY′ - ∂ⱼτᵢⱼ
         for n, c in enumerate(self.tracers):
@@ -127,6 +170,9 @@ class HydrostaticFreeSurfaceModel:
     def time_step(self, dt, euler=False):
         nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
         if clock.iteration == 0:
+            if self.split and not self._initialized:  # initialize_free_surface! (the reference: run!(simulation) / first_time_step!)
+                _lib.call("ocn_compute_barotropic_mode", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(), s)
+                self._initialized = True
             self.update_state(compute_tendencies=True)
         euler = euler or (dt != clock.last_dt)
         chi = -0.5 if euler else nh.timestepper.chi
@@ -137,9 +183,21 @@ class HydrostaticFreeSurfaceModel:
         fields = [self.u, self.v] + list(self.tracers)
         _lib.call("ocn_ab2_step", g.cref, len(idx), _lib.ptr_array([f.ptr for f in fields]), _lib.ptr_array([Gn[q].ptr for q in idx]),
                   _lib.ptr_array([Gm[q].ptr for q in idx]), _lib.i32_array([f.loc for f in fields]), float(dt), float(chi), s)
-        # compute_free_surface_tendency! + step_free_surface!
-        _lib.call("ocn_explicit_free_surface_ab2_step", g.cref, self.w.ptr, self.eta.data_ptr(), self._Geta.data_ptr(),
-                  self._Geta_m.data_ptr(), float(dt), float(chi), s)
+        fs = self.free_surface
+        if self.split:
+            # compute_free_surface_tendency! (slow forcing from Gⁿ, G⁻ BEFORE they are cached), then step_free_surface!
+            _lib.call("ocn_split_explicit_forcing", g.cref, Gn[0].ptr, Gm[0].ptr, Gn[1].ptr, Gm[1].ptr, float(chi), self._GU.data_ptr(),
+                      self._GV.data_ptr(), s)
+            _lib.call("ocn_split_explicit_substeps", g.cref, len(self._weights), self._weights, fs.fractional_step_size * float(dt),
+                      fs.gravitational_acceleration, float(g.Lz), self.eta.data_ptr(), self.U.data_ptr(), self.V.data_ptr(),
+                      self._etab.data_ptr(), self._Ub.data_ptr(), self._Vb.data_ptr(), self._GU.data_ptr(), self._GV.data_ptr(), s)
+            # pressure_correct_velocities!: the barotropic corrector
+            _lib.call("ocn_barotropic_split_explicit_corrector", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(),
+                      self._Ub.data_ptr(), self._Vb.data_ptr(), float(g.Lz), s)
+        else:
+            # compute_free_surface_tendency! + step_free_surface!
+            _lib.call("ocn_explicit_free_surface_ab2_step", g.cref, self.w.ptr, self.eta.data_ptr(), self._Geta.data_ptr(),
+                      self._Geta_m.data_ptr(), float(dt), float(chi), s)
         clock.time += dt
         clock.iteration += 1
         clock.last_dt = dt

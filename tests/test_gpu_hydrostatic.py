@@ -71,3 +71,41 @@ def test_hydrostatic_model_steps_match_oracle(oracle, ocn, advection, physics):
     for a, d in zip(om.tracers, pm.tracers):
         np.testing.assert_array_equal(og.interior(from_dev(d)), og.interior(a))
     assert np.abs(eta).max() > 0 and np.isfinite(eta).all()
+
+
+def test_split_explicit_free_surface_model_steps_match_oracle(oracle, ocn):
+    """SplitExplicitFreeSurface(substeps = 12), ForwardBackwardScheme: slow forcing, substepping with the averaging weights, barotropic
+    corrector -- 3 QAB2 steps of the default configuration (VectorInvariant momentum, Centered tracers) with Coriolis,
+    diffusivity, buoyancy and flux conditions equal the oracle's bit for bit, barotropic transports included."""
+    from oracle import hydrostatic as Hy
+    O = oracle
+    size = (16, 12, 7)
+    og, pg = _pair(O, ocn, size, stretched=True)
+    rng = np.random.default_rng(21)
+    init = dict(u=1e-2 * rng.uniform(-1, 1, size), v=1e-2 * rng.uniform(-1, 1, size), eta=1e-2 * rng.uniform(-1, 1, size[:2]),
+                T=20 + 1e-2 * rng.uniform(-1, 1, size), S=35 + 1e-2 * rng.uniform(-1, 1, size))
+    om = Hy.HydrostaticFreeSurfaceModel(og, tracers=("T", "S"), momentum_advection="VectorInvariant", coriolis_f=1e-4, closure=(1e-2, 2e-3),
+                                        buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4), split_explicit_substeps=12,
+                                        boundary_conditions={"u": {"top": O.FluxBoundaryCondition(-1e-4)}, "T": {"top": O.FluxBoundaryCondition(5e-5)}})
+    om.set(**init)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=ocn.VectorInvariant(), tracers=("T", "S"),
+                                         free_surface=ocn.SplitExplicitFreeSurface(substeps=12), coriolis=ocn.FPlane(f=1e-4),
+                                         closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
+                                         buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                         boundary_conditions={"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                                              "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5))})
+    pm.set(**init)
+    for dt in (20.0, 20.0, 20.0):
+        om.time_step(dt)
+        pm.time_step(dt)
+    ocn.sync_device()
+    for name, a, d in zip(("u", "v", "w"), (om.u, om.v, om.w), pm.velocities):
+        np.testing.assert_array_equal(og.interior(from_dev(d)), og.interior(a), err_msg=name)
+    ii, jj = slice(og.Hy, og.Hy + og.Ny), slice(og.Hx, og.Hx + og.Nx)
+    np.testing.assert_array_equal(pm.eta[ii, jj].cpu().numpy().T, om.eta[og.Hx:og.Hx + og.Nx, og.Hy:og.Hy + og.Ny])
+    np.testing.assert_array_equal(pm.U[ii, jj].cpu().numpy().T, om.U)
+    np.testing.assert_array_equal(pm.V[ii, jj].cpu().numpy().T, om.V)
+    for a, d in zip(om.tracers, pm.tracers):
+        np.testing.assert_array_equal(og.interior(from_dev(d)), og.interior(a))
+    assert np.abs(om.U).max() > 0
