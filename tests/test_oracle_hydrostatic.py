@@ -182,6 +182,45 @@ def test_split_explicit_averaging_does_nothing_to_a_uniform_state():
         assert np.abs(a - v).max() < tol
 
 
+def test_split_explicit_forced_two_dimensional_wave():
+    """:157-238 ("Complex Multi-Timestep"): ∂ₜη + ∇·U = 0, ∂ₜU + ∇η = G with η₀ = sin(2x) sin(3y) + 1, U₀ = V₀ = 0, constant
+    forcing G = (1, 2): mean(η) conserved to 10 eps; η, U, V and their time averages match the analytic solution within 1e-2."""
+    Nx, Ny, dx, dy, xc, xf, grav, H, z = _sefs_setup()
+    yc, yf = (np.arange(Ny) + 0.5) * dy, np.arange(Ny) * dy
+    kx, ky = 2, 3
+    om = np.sqrt(kx ** 2 + ky ** 2)
+    T = 2 * np.pi / om / 3 * 2
+    dtau = 2 * np.pi / max(Nx, Ny) * 1e-2
+    Nt = int(np.floor(T / dtau))
+    dtau_end = T - Nt * dtau
+    _, weights = Hy.weights_from_substeps(Nt + 1, Hy.constant_averaging_kernel)
+    eta0 = np.sin(kx * xc)[:, None] * np.sin(ky * yc)[None, :] + 1
+    eta, U, V = eta0.copy(), z(), z()
+    etab, Ub, Vb = z(), z(), z()
+    GU, GV = z() + 1.0, z() + 2.0
+    mean_before = eta.mean()
+    for _ in range(Nt):
+        Hy.iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau, weights[:1], grav, H, dx, dy)
+    Hy.iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau_end, weights[:1], grav, H, dx, dy)
+    assert abs(eta.mean() - mean_before) < 10 * np.finfo(float).eps
+    e0 = eta0[:, 0]
+    U0 = kx * np.cos(kx * xf) * np.sin(ky * yc[0])
+    V0 = ky * np.sin(kx * xc) * np.cos(ky * yf[0])
+    eta_exact = np.cos(om * T) * (e0 - 1) + 1
+    U_exact = -(np.sin(om * T) / om) * U0 + 1.0 * T
+    V_exact = -(np.sin(om * T) / om) * V0 + 2.0 * T
+    etab_exact = (np.sin(om * T) / om) / T * (e0 - 1) + 1
+    Ub_exact = (np.cos(om * T) / om ** 2 - 1 / om ** 2) / T * U0 + 1.0 * T / 2
+    Vb_exact = (np.cos(om * T) / om ** 2 - 1 / om ** 2) / T * V0 + 2.0 * T / 2
+    tol = 1e-2
+    assert np.abs(U[:, 0] - U_exact).max() / np.abs(U_exact).max() < tol
+    assert np.abs(V[:, 0] - V_exact).max() / np.abs(V_exact).max() < tol
+    assert np.abs(eta[:, 0] - eta_exact).max() / np.abs(eta_exact).max() < tol
+    assert np.abs(Ub[:, 0] - Ub_exact).max() < tol
+    assert np.abs(Vb[:, 0] - Vb_exact).max() < tol
+    assert np.abs(etab[:, 0] - etab_exact).max() < tol
+
+
 def test_split_explicit_weights():
     """weights_from_substeps (split_explicit_free_surface.jl:228-241) with the default Shchepetkin-McWilliams kernel: truncated where
     the kernel turns negative, normalised, centred on the baroclinic step (Σ aₘ m/M ≈ 1, the kernel's design condition)"""
