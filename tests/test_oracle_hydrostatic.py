@@ -257,3 +257,47 @@ def test_split_explicit_model_wave_and_barotropic_consistency():
     t = dt * np.arange(1, 81)
     assert np.abs(amp - np.cos(omega * t)).max() < 0.12
     assert 0.9 < amp[79] < 1.0
+
+
+# ---- test_split_explicit_vertical_integrals.jl re-expressed --------------------------------------------------------------------
+def _barotropic_kernels_model():
+    Nx, Ny, Nz = 128, 64, 32
+    L = 2 * np.pi
+    g = O.Grid((Nx, Ny, Nz), x=(0, L), y=(0, L), z=(-L, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2", split_explicit_substeps=200)
+    xc, xf = (np.arange(Nx) + 0.5) * g.dx, np.arange(Nx) * g.dx
+    yc, yf = (np.arange(Ny) + 0.5) * g.dy, np.arange(Ny) * g.dy
+    zc = -L + (np.arange(Nz) + 0.5) * g.dz
+    return g, m, L, xc, xf, yc, yf, zc
+
+
+def test_barotropic_mode_vertical_integrals():
+    """:52-111: compute_barotropic_mode! integrates cos(πz/2Lz) to 2Lz/π within 1e-3, a z-independent field exactly to Lz x field,
+    and sin(x) z cos(y) to -sin(x) Lz²/2 cos(y)"""
+    g, m, L, xc, xf, yc, yf, zc = _barotropic_kernels_model()
+    ones = np.ones((g.Nx, g.Ny, 1))
+    g.interior_N(m.u)[...] = ones * np.cos(np.pi / 2 * zc / L)[None, None, :]
+    assert np.abs(m._barotropic_mode(m.u) - 2 * L / np.pi).max() < 1e-3
+    g.interior_N(m.v)[...] = np.sin(xc[:, None, None] * yf[None, :, None]) * np.cos(np.pi / 2 * zc / L)[None, None, :]
+    assert np.abs(m._barotropic_mode(m.v) - np.sin(xc[:, None] * yf[None, :]) * 2 * L / np.pi).max() < 1e-3
+    g.interior_N(m.u)[...] = 0.0
+    assert np.all(m._barotropic_mode(m.u) == 0.0)
+    g.interior_N(m.u)[...] = 1.0
+    np.testing.assert_allclose(m._barotropic_mode(m.u), L, rtol=1e-14)
+    g.interior_N(m.u)[...] = np.sin(xf)[:, None, None] * np.ones((1, g.Ny, g.Nz))
+    np.testing.assert_allclose(m._barotropic_mode(m.u), np.sin(xf)[:, None] * L * np.ones((1, g.Ny)), rtol=1e-13, atol=1e-14)
+    g.interior_N(m.v)[...] = np.sin(xc)[:, None, None] * zc[None, None, :] * np.cos(yf)[None, :, None]
+    np.testing.assert_allclose(m._barotropic_mode(m.v), -np.sin(xc)[:, None] * L ** 2 / 2 * np.cos(yf)[None, :], rtol=1e-12, atol=1e-13)
+
+
+def test_barotropic_correction():
+    """:113-146: u = z + Lz/2 + sin x with the barotropic transport set to cos(x) Lz is corrected to z + Lz/2 + cos x (1e-14)"""
+    g, m, L, xc, xf, yc, yf, zc = _barotropic_kernels_model()
+    zz = (zc + L / 2)[None, None, :]
+    g.interior_N(m.u)[...] = zz + np.sin(xf)[:, None, None] + 0 * yc[None, :, None]
+    m.U[...] = np.cos(xf)[:, None] * L * np.ones((1, g.Ny))
+    g.interior_N(m.v)[...] = zz * np.sin(yf)[None, :, None] + np.sin(xc)[:, None, None]
+    m.V[...] = (np.cos(xc) + xc)[:, None] * L * np.ones((1, g.Ny))
+    m._barotropic_corrector()
+    assert np.abs(g.interior_N(m.u) - (zz + np.cos(xf)[:, None, None] + 0 * yc[None, :, None])).max() < 1e-14
+    assert np.abs(g.interior_N(m.v) - (zz * np.sin(yf)[None, :, None] + (np.cos(xc) + xc)[:, None, None])).max() < 1e-13
