@@ -335,6 +335,33 @@ int ocn_split_explicit_substeps(const ocn_grid *grid, int32_t n, const double *w
 int ocn_compute_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, void *stream);
 int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *U_filtered,
                                             double *V_filtered, double column_depth, void *stream);
+/* The same substep loop, temporally blocked: ceil(n / 4) launches instead of 2 n (LDS patches with a 4-cell rim run 4 substeps each);
+ * bit-identical results.  `work`: device scratch of 3 planes (3 (Nx+2Hx)(Ny+2Hy) doubles).
+ * Replaces iterate_split_explicit! + _update_split_explicit_state! (step_split_explicit_free_surface.jl:62-108). */
+int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                        double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
+                                        double *V_filtered, const double *GU, const double *GV, double *work, void *stream);
+/* One pass over the columns for the whole horizontal-momentum part of a QuasiAdamsBashforth2 step of the HydrostaticFreeSurfaceModel
+ * with momentum_advection = VectorInvariant():
+ *   compute_hydrostatic_free_surface_Gu!/Gv! (hydrostatic_free_surface_tendency_kernel_functions.jl:29-97; all terms of `terms` and the
+ *     flux conditions of bcs_u / bcs_v; - g grad(eta) when eta != NULL, i.e. with an ExplicitFreeSurface)        -> Gu, Gv
+ *   ab2_step_velocities! (hydrostatic_free_surface_ab2_step.jl:41-63): u_out = u + dt ((3/2 + chi) G - (1/2 + chi) G_previous), Euler
+ *     (chi = -1/2, G_previous not read) when euler != 0; u_out / v_out must not alias u / v
+ *   GU, GV != NULL (SplitExplicitFreeSurface): compute_split_explicit_forcing! (compute_slow_tendencies.jl:12-46) -> GU, GV and
+ *     compute_barotropic_mode! of the stepped velocities (barotropic_split_explicit_corrector.jl:13-32) -> U_star, V_star
+ * Strict math: bit-identical to the separate entry points. */
+int ocn_hydrostatic_momentum_ab2_step(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
+                                      const ocn_field_bcs *bcs_v, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                                      const double *Gu_previous, const double *Gv_previous, double *u_out, double *v_out, double dt,
+                                      double chi, int32_t euler, const double *eta, double gravitational_acceleration, double *GU,
+                                      double *GV, double *U_star, double *V_star, void *stream);
+/* barotropic_split_explicit_corrector! (barotropic_split_explicit_corrector.jl:44-71) + compute_w_from_continuity!
+ * (compute_w_from_continuity.jl:31-40) in one pass: u = u_star + (U - U_star) / H, v likewise (written to u, v, which must not alias
+ * u_star, v_star), w from the corrected velocities for the interior columns (the caller's halo fill of w supplies the halo columns).
+ * U == NULL (ExplicitFreeSurface): u = u_star, no correction. */
+int ocn_barotropic_corrector_and_w(const ocn_grid *grid, const double *u_star, const double *v_star, double *u, double *v, double *w,
+                                   const double *U, const double *V, const double *U_star, const double *V_star, double column_depth,
+                                   void *stream);
 /* fill_halo_regions!(eta): periodic x, y halos of the free-surface plane */
 int ocn_fill_free_surface_halos(const ocn_grid *grid, double *eta, void *stream);
 /* _compute_w_from_continuity! (compute_w_from_continuity.jl:31-40) for every parent column with east / north neighbours */

@@ -28,7 +28,8 @@ from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTr
                       nonhydrostatic_pressure_solver, solve)
 
 
-from .hydrostatic import ExplicitFreeSurface, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface, VectorInvariant  # noqa: E402
+from .hydrostatic import (ExplicitFreeSurface, ForwardBackwardScheme, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface,  # noqa: E402
+                          VectorInvariant)
 
 
 def set_math_mode(mode):

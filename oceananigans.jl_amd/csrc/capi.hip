@@ -593,6 +593,62 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
     return launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, as_stream(stream), &tf);
 }
 
+int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                        double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
+                                        double *V_filtered, const double *GU, const double *GV, double *work, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_split_explicit_substeps_blocked");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(n >= 1 && weights, "ocn_split_explicit_substeps_blocked: needs n >= 1 averaging weights (host array)");
+    OCN_REQUIRE(eta && U && V && eta_filtered && U_filtered && V_filtered && GU && GV && work, "ocn_split_explicit_substeps_blocked: null pointer");
+    return launch_split_explicit_substeps_blocked(grid, n, weights, dtau, gravitational_acceleration, column_depth, eta, U, V, eta_filtered,
+                                                  U_filtered, V_filtered, GU, GV, work, as_stream(stream));
+}
+
+int ocn_hydrostatic_momentum_ab2_step(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
+                                      const ocn_field_bcs *bcs_v, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                                      const double *Gu_previous, const double *Gv_previous, double *u_out, double *v_out, double dt,
+                                      double chi, int32_t euler, const double *eta, double gravitational_acceleration, double *GU,
+                                      double *GV, double *U_star, double *V_star, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_hydrostatic_momentum_ab2_step");
+    if (st != OCN_SUCCESS) return st;
+    st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->Hz >= 1, "ocn_hydrostatic_momentum_ab2_step: needs a z halo");
+    OCN_REQUIRE(terms->closure != 2, "ocn_hydrostatic_momentum_ab2_step: eddy-viscosity closures are not supported");
+    OCN_REQUIRE(u && v && w && Gu && Gv && u_out && v_out, "ocn_hydrostatic_momentum_ab2_step: null field pointer");
+    OCN_REQUIRE(euler || (Gu_previous && Gv_previous), "ocn_hydrostatic_momentum_ab2_step: G_previous is required unless euler != 0");
+    OCN_REQUIRE(u_out != u && v_out != v, "ocn_hydrostatic_momentum_ab2_step: the outputs must not alias the inputs");
+    OCN_REQUIRE((GU && GV && U_star && V_star) || (!GU && !GV && !U_star && !V_star),
+                "ocn_hydrostatic_momentum_ab2_step: GU, GV, U_star, V_star go together (all or none)");
+    MomentumFinal mf{};
+    st = flux_side(grid, bcs_u, "u", mf.bottom[0], mf.top[0]);
+    if (st != OCN_SUCCESS) return st;
+    st = flux_side(grid, bcs_v, "v", mf.bottom[1], mf.top[1]);
+    if (st != OCN_SUCCESS) return st;
+    mf.sub[0] = SubstepDev{Gu_previous, u_out};
+    mf.sub[1] = SubstepDev{Gv_previous, v_out};
+    if (euler) chi = -0.5;
+    mf.sc = SubstepCoef{dt, 1.5 + chi, -(0.5 + chi), 1, euler ? 0 : 1};
+    ocn::HydroFuse hf{eta, gravitational_acceleration, GU, GV, U_star, V_star};
+    TermsDev t = to_dev(*terms);
+    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_hydrostatic_momentum(grid, t, u, v, w, Gu, Gv, mf, hf, as_stream(stream))
+                                          : ocn_fast::launch_hydrostatic_momentum(grid, t, u, v, w, Gu, Gv, mf, hf, as_stream(stream));
+}
+
+int ocn_barotropic_corrector_and_w(const ocn_grid *grid, const double *u_star, const double *v_star, double *u, double *v, double *w,
+                                   const double *U, const double *V, const double *U_star, const double *V_star, double column_depth,
+                                   void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_barotropic_corrector_and_w");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u_star && v_star && u && v && w, "ocn_barotropic_corrector_and_w: null field pointer");
+    OCN_REQUIRE(u != u_star && v != v_star, "ocn_barotropic_corrector_and_w: the outputs must not alias the inputs");
+    OCN_REQUIRE((U && V && U_star && V_star) || (!U && !V), "ocn_barotropic_corrector_and_w: U, V, U_star, V_star go together");
+    return launch_barotropic_correct_w(grid, u_star, v_star, u, v, w, U, V, U_star, V_star, column_depth, as_stream(stream));
+}
+
 int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const int32_t *locs,
                               const ocn_field_bcs *const *bcs, int32_t n, int32_t fill_boundary_normal_velocities,
                               void *stream)

@@ -487,6 +487,191 @@ int launch_barotropic_corrector(const ocn_grid *grid, double *u, double *v, cons
     return OCN_SUCCESS;
 }
 
+// ---- the substep loop, temporally blocked ------------------------------------------------------------------------------------------
+// iterate_split_explicit! launches 2 tiny kernels per substep (the reference notes it is bound by launch latency,
+// step_split_explicit_free_surface.jl:84-88; its distributed variant already trades halo width for communication,
+// split_explicit_free_surface.jl:283-300).  Here a workgroup loads a (TXO + 2 SH) x (TYO + 2 SH) patch of η, U, V, Gᵁ, Gⱽ into LDS
+// (periodic wrap on load; Gᵁ, Gⱽ in registers) and runs up to SH substeps on it: each substep invalidates one more ring of the patch, the TXO x TYO
+// centre stays exact.  Every cell is updated with the text of split_explicit_eta_kernel / split_explicit_velocity_kernel, so the
+// result is bit-identical; the filtered state accumulates in registers for the centre cells in substep order.  Launches
+// ping-pong between (η, U, V) and a workspace because neighbouring workgroups read each other's centre cells at load time.
+template <int SH>
+struct SubstepArgs {
+    int nsub, first, write_state;
+    double w[SH];
+    double dtau, grav, H;
+    const double *eta_in, *U_in, *V_in, *GU, *GV;
+    double *eta_out, *U_out, *V_out, *etab, *Ub, *Vb;
+};
+template <int TXO, int TYO, int SH>
+__global__ __launch_bounds__(256) void split_explicit_blocked_kernel(GridDev g, SubstepArgs<SH> a)
+{
+    constexpr int W = TXO + 2 * SH, HH = TYO + 2 * SH, NC = W * HH, NQ = (NC + 255) / 256;
+    __shared__ double Le[NC], LU[NC], LV[NC];  // Gᵁ, Gⱽ of a cell are only read by the thread that updates it: registers
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * TXO, j0 = blockIdx.y * TYO;  // 0-based interior origin of the centre
+    const int sx = g.Nx + 2 * g.Hx;
+    const double dx = g.dx, dy = g.dy, Az = dx * dy;
+    long long gp[NQ];   // plane offset of each of this thread's cells
+    bool own[NQ];       // centre cell inside the domain: accumulates the filtered state and is written back
+    double ae[NQ], aU[NQ], aV[NQ], gU[NQ], gV[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = tid + 256 * q;
+        const int lx = c % W, ly = c / W;
+        const int ui = i0 + lx - SH, uj = j0 + ly - SH;                       // unwrapped 0-based interior indices
+        const int gi = ((ui % g.Nx) + g.Nx) % g.Nx, gj = ((uj % g.Ny) + g.Ny) % g.Ny;
+        gp[q] = (gi + g.Hx) + (long long)sx * (gj + g.Hy);
+        own[q] = c < NC && lx >= SH && lx < SH + TXO && ly >= SH && ly < SH + TYO && ui < g.Nx && uj < g.Ny;
+        if (c < NC) {
+            Le[c] = a.eta_in[gp[q]];
+            LU[c] = a.U_in[gp[q]];
+            LV[c] = a.V_in[gp[q]];
+        }
+        gU[q] = c < NC ? a.GU[gp[q]] : 0.0;
+        gV[q] = c < NC ? a.GV[gp[q]] : 0.0;
+        ae[q] = (own[q] && !a.first) ? a.etab[gp[q]] : 0.0;
+        aU[q] = (own[q] && !a.first) ? a.Ub[gp[q]] : 0.0;
+        aV[q] = (own[q] && !a.first) ? a.Vb[gp[q]] : 0.0;
+    }
+    __syncthreads();
+    for (int m = 0; m < a.nsub; ++m) {
+        const double wgt = a.w[m];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {  // _split_explicit_free_surface!
+            const int c = tid + 256 * q;
+            if (c < NC) {
+                const int lx = c % W, ly = c / W;
+                const int ce = ly * W + min(lx + 1, W - 1), cn = min(ly + 1, HH - 1) * W + lx;
+                Le[c] = Le[c] - a.dtau * ((dy * LU[ce] - dy * LU[c]) + (dx * LV[cn] - dx * LV[c])) / Az;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {  // _split_explicit_barotropic_velocity!
+            const int c = tid + 256 * q;
+            if (c < NC) {
+                const int lx = c % W, ly = c / W;
+                const int cw = ly * W + max(lx - 1, 0), cs = max(ly - 1, 0) * W + lx;
+                const double et = Le[c];
+                const double Un = LU[c] + a.dtau * (-a.grav * a.H * ((et - Le[cw]) / dx) + gU[q]);
+                const double Vn = LV[c] + a.dtau * (-a.grav * a.H * ((et - Le[cs]) / dy) + gV[q]);
+                if (own[q]) {
+                    ae[q] += wgt * et;
+                    aU[q] += wgt * Un;
+                    aV[q] += wgt * Vn;
+                }
+                LU[c] = Un;
+                LV[c] = Vn;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!own[q]) continue;
+        const int c = tid + 256 * q;
+        a.etab[gp[q]] = ae[q];
+        a.Ub[gp[q]] = aU[q];
+        a.Vb[gp[q]] = aV[q];
+        if (a.write_state) {
+            a.eta_out[gp[q]] = Le[c];
+            a.U_out[gp[q]] = LU[c];
+            a.V_out[gp[q]] = LV[c];
+        }
+    }
+}
+// _update_split_explicit_state! (step_split_explicit_free_surface.jl:100-108): η, U, V <- their averages, one launch
+__global__ __launch_bounds__(256) void split_explicit_update_state_kernel(GridDev g, double *__restrict__ eta, double *__restrict__ U,
+                                                                          double *__restrict__ V, const double *__restrict__ etab,
+                                                                          const double *__restrict__ Ub, const double *__restrict__ Vb)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const long long e = plane_at(g, i, j);
+    eta[e] = etab[e];
+    U[e] = Ub[e];
+    V[e] = Vb[e];
+}
+int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                           double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                           double *work, hipStream_t stream)
+{
+    constexpr int TXO = 64, TYO = 16, SH = 4;
+    GridDev g = to_dev(*grid);
+    const long long plane = (long long)(g.Nx + 2 * g.Hx) * (g.Ny + 2 * g.Hy);
+    double *set[2][3] = {{eta, U, V}, {work, work + plane, work + 2 * plane}};
+    dim3 nb((g.Nx + TXO - 1) / TXO, (g.Ny + TYO - 1) / TYO, 1);
+    int cur = 0;
+    for (int m0 = 0; m0 < n; m0 += SH) {
+        SubstepArgs<SH> a{};
+        a.nsub = n - m0 < SH ? n - m0 : SH;
+        a.first = m0 == 0;
+        a.write_state = m0 + SH < n;  // the last launch only leaves the averages
+        for (int q = 0; q < a.nsub; ++q) a.w[q] = weights[m0 + q];
+        a.dtau = dtau; a.grav = grav; a.H = H;
+        a.eta_in = set[cur][0]; a.U_in = set[cur][1]; a.V_in = set[cur][2];
+        a.eta_out = set[1 - cur][0]; a.U_out = set[1 - cur][1]; a.V_out = set[1 - cur][2];
+        a.GU = GU; a.GV = GV; a.etab = etab; a.Ub = Ub; a.Vb = Vb;
+        hipLaunchKernelGGL((split_explicit_blocked_kernel<TXO, TYO, SH>), nb, dim3(256), 0, stream, g, a);
+        cur = 1 - cur;
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    dim3 block(64, 4, 1), nb2((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    hipLaunchKernelGGL(split_explicit_update_state_kernel, nb2, block, 0, stream, g, eta, U, V, etab, Ub, Vb);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// barotropic_split_explicit_corrector! (barotropic_split_explicit_corrector.jl:44-71) + compute_w_from_continuity!
+// (compute_w_from_continuity.jl:31-40) in one pass over the columns.  us, vs: the AB2-stepped velocities (second storage of
+// hydrostatic_momentum_tiled); Us, Vs: their vertical integrals Σ Δz u* (the reference recomputes them into the filtered-state
+// arrays here).  u = u* + (U - U̅*) / H is written into the model's arrays, and w integrates the divergence of the CORRECTED
+// velocities upwards from w[k = 1] = 0; the east / north neighbours are corrected on the fly with wrapped indices (x, y Periodic),
+// so the interior of w equals what w_from_continuity_kernel computes after the halo fill, bit for bit.  40 B per cell instead of
+// 32 (corrector) + 16 (barotropic mode) + 24 (w).
+__global__ __launch_bounds__(256) void barotropic_correct_w_kernel(GridDev g, const double *__restrict__ us, const double *__restrict__ vs,
+                                                                   double *__restrict__ u, double *__restrict__ v, double *__restrict__ w,
+                                                                   const double *__restrict__ U, const double *__restrict__ V,
+                                                                   const double *__restrict__ Us, const double *__restrict__ Vs, double H)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const int ip = i == g.Nx ? 1 : i + 1, jp = j == g.Ny ? 1 : j + 1;
+    const long long e = plane_at(g, i, j), ee = plane_at(g, ip, j), en = plane_at(g, i, jp);
+    const bool corr = U != nullptr;  // ExplicitFreeSurface: no corrector, u = u*
+    const double cu = corr ? (U[e] - Us[e]) / H : 0.0, cue = corr ? (U[ee] - Us[ee]) / H : 0.0;
+    const double cv = corr ? (V[e] - Vs[e]) / H : 0.0, cvn = corr ? (V[en] - Vs[en]) / H : 0.0;
+    long long o = at(L, i, j, 1), oe = at(L, ip, j, 1), on = at(L, i, jp, 1);
+    const double Az = g.dx * g.dy;
+    double wk = 0.0;
+    w[o] = wk;
+    for (int k = 1; k <= g.Nz; ++k) {
+        const double uc = corr ? us[o] + cu : us[o], ue = corr ? us[oe] + cue : us[oe];
+        const double vc = corr ? vs[o] + cv : vs[o], vn = corr ? vs[on] + cvn : vs[on];
+        u[o] = uc;
+        v[o] = vc;
+        const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        const double Ax = g.dy * dzc, Ay = g.dx * dzc;
+        const double dxu = Ax * ue - Ax * uc;
+        const double dyv = Ay * vn - Ay * vc;
+        const double dh = (dxu + dyv) / Az;
+        wk = wk - (dh + 0.0);
+        o += L.s3; oe += L.s3; on += L.s3;
+        w[o] = wk;
+    }
+}
+int launch_barotropic_correct_w(const ocn_grid *grid, const double *us, const double *vs, double *u, double *v, double *w, const double *U,
+                                const double *V, const double *Us, const double *Vs, double H, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    hipLaunchKernelGGL(barotropic_correct_w_kernel, nb, block, 0, stream, g, us, vs, u, v, w, U, V, Us, Vs, H);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // compute_hydrostatic_free_surface_Gη! (Gη = w[i,j,Nz+1], explicit_free_surface.jl:98-140) followed by
 // _explicit_ab2_step_free_surface! (:84-96): η += Δt ((1.5 + χ) Gηⁿ - (0.5 + χ) Gη⁻ not_euler); Gηⁿ is left in Gn for the caller to cache
 __global__ __launch_bounds__(256) void free_surface_ab2_kernel(GridDev g, const double *__restrict__ w, double *__restrict__ eta,

@@ -148,6 +148,14 @@ struct MomentumFinal {
     SubstepCoef sc;
 };
 
+// what hydrostatic_momentum_tiled (physics.hip) folds in besides the tendency and the AB2 step of u, v
+struct HydroFuse {
+    const double *eta;  // ExplicitFreeSurface: η plane (sx, sy) for - g ∇η, or NULL (SplitExplicitFreeSurface: the gradient is 0)
+    double grav;
+    double *GU, *GV;    // SplitExplicitFreeSurface: barotropic forcing planes (compute_split_explicit_forcing!), or NULL
+    double *Ub, *Vb;    //                           Σ Δz u*, Σ Δz v* of the stepped velocities (for the barotropic corrector)
+};
+
 int validate_grid(const ocn_grid *g);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }

@@ -69,6 +69,11 @@ int launch_split_explicit_forcing(const ocn_grid *grid, const double *Gun, const
 int launch_split_explicit_substeps(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
                                    double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
                                    hipStream_t stream);
+int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                           double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                           double *work, hipStream_t stream);
+int launch_barotropic_correct_w(const ocn_grid *grid, const double *us, const double *vs, double *u, double *v, double *w, const double *U,
+                                const double *V, const double *Us, const double *Vs, double H, hipStream_t stream);
 int launch_barotropic_mode(const ocn_grid *grid, const double *u, const double *v, double *U, double *V, hipStream_t stream);
 int launch_barotropic_corrector(const ocn_grid *grid, double *u, double *v, const double *U, const double *V, double *Ub, double *Vb, double H,
                                 hipStream_t stream);
@@ -103,6 +108,8 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream,
                           const ocn::MomentumFinal *fin = nullptr);
+int launch_hydrostatic_momentum(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                double *Gv, const ocn::MomentumFinal &mf, const ocn::HydroFuse &hf, hipStream_t stream);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,
@@ -124,6 +131,8 @@ int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double 
 int launch_momentum_extra(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w,
                           double *Gu, double *Gv, double *Gw, const int32_t *range, hipStream_t stream,
                           const ocn::MomentumFinal *fin = nullptr);
+int launch_hydrostatic_momentum(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                double *Gv, const ocn::MomentumFinal &mf, const ocn::HydroFuse &hf, hipStream_t stream);
 int launch_tracer_diffusion(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                             const int32_t *range, hipStream_t stream);
 int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const double *v, const double *w, double *nu_e, int ntr,

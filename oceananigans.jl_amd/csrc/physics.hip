@@ -167,11 +167,15 @@ __device__ __forceinline__ double buoyancy_ccc(const TermsDev &t, long long a)
 
 // One cell of the momentum finishing pass.  Uf/Vf/Wf/NEf(a, b, c) return u, v, w, νₑ at (i+a, j+b, k+c): global memory in the
 // direct kernel, LDS planes in the tiled one -- the arithmetic is the same text, so both are bit-identical to the oracle.
-template <int TZ, class FU, class FV, class FW, class FN>
+// HYD (HydrostaticFreeSurfaceModel, hydrostatic_momentum_tiled below): the advective G of u, v arrives in G0u / G0v instead of
+// Gu[o] / Gv[o], there is no w tendency, and res[] returns {Gu, u_out, Gv, v_out} for the column sums of the split-explicit
+// free surface.
+template <int TZ, bool HYD = false, class FU, class FV, class FW, class FN>
 __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const TermsDev &t, const Metrics &M, int i, int j, int k,
                                                     long long o, long long s2, long long s3, bool has_nu, FU Uf, FV Vf, FW Wf,
                                                     FN NEf, double *__restrict__ Gu, double *__restrict__ Gv,
-                                                    double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf)
+                                                    double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf,
+                                                    double G0u = 0.0, double G0v = 0.0, double *res = nullptr)
 {
     constexpr bool ZF = (TZ == OCN_FLAT);
     const double dx = M.dx, dy = M.dy, nu = t.nu;
@@ -200,7 +204,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
     };
 
     {   // ---------------- Gu at (f,c,c)
-        double G = Gu[o];
+        double G = HYD ? G0u : Gu[o];
         if (t.buoyancy) G = G + 0.0;  // x_dot_g_b = 0 (NegativeZDirection)
         if (t.coriolis) {             // - x_f_cross_U,  x_f_cross_U = -f * ℑxyᶠᶜᵃ(v) / 1
             const double vi = 0.5 * (0.5 * (Vf(-1, 0, 0) + Vf(0, 0, 0)) + 0.5 * (Vf(-1, 1, 0) + Vf(0, 1, 0)));
@@ -224,10 +228,17 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             if (k == g.Nz && mf.top[0].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
         Gu[o] = G;
-        if (mf.sc.on) mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (HYD) {
+            const double gm = mf.sc.has_zeta ? mf.sub[0].Gm[o] : 0.0;
+            const double un = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[0].out[o] = un;
+            res[0] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;  // ab2_step_G (compute_slow_tendencies.jl:34-46)
+            res[1] = un;
+        } else if (mf.sc.on)
+            mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     {   // ---------------- Gv at (c,f,c)
-        double G = Gv[o];
+        double G = HYD ? G0v : Gv[o];
         if (t.buoyancy) G = G + 0.0;
         if (t.coriolis) {  // - y_f_cross_U,  y_f_cross_U = f * ℑxyᶜᶠᵃ(u) / 1
             const double ui = 0.5 * (0.5 * (Uf(0, -1, 0) + Uf(1, -1, 0)) + 0.5 * (Uf(0, 0, 0) + Uf(1, 0, 0)));
@@ -251,8 +262,16 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             if (k == g.Nz && mf.top[1].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
         Gv[o] = G;
-        if (mf.sc.on) mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (HYD) {
+            const double gm = mf.sc.has_zeta ? mf.sub[1].Gm[o] : 0.0;
+            const double vn = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[1].out[o] = vn;
+            res[2] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;
+            res[3] = vn;
+        } else if (mf.sc.on)
+            mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
     }
+    if (HYD) return;  // w is diagnostic in the hydrostatic model
     if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
         double G = Gw[o];
         if (t.buoyancy) {  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
@@ -386,6 +405,157 @@ __global__ __launch_bounds__(256) void momentum_extra_tiled(GridDev g, TermsDev 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// HydrostaticFreeSurfaceModel: the whole horizontal-momentum part of one QuasiAdamsBashforth2 step in ONE pass over the columns.
+//
+//   compute_hydrostatic_free_surface_Gu!/Gv!   (hydrostatic_free_surface_tendency_kernel_functions.jl:29-97):
+//       G = - U_dot_∇u [VectorInvariant(): vector_invariant_advection.jl:269-275, 304-319, 360-361] - g ∂x η (ExplicitFreeSurface
+//           only) - f x U - ∂x pHY′ - ∂ⱼτ₁ⱼ, + the flux boundary contributions (apply_flux_bcs.jl:107-160)
+//   ab2_step_velocities!                       (hydrostatic_free_surface_ab2_step.jl:41-63; TimeSteppers ab2_step_field!):
+//       u* = u + Δt ((3/2 + χ) Gⁿ - (1/2 + χ) G⁻ not_euler)            -> second storage (the neighbours still read u)
+//   compute_split_explicit_forcing!            (compute_slow_tendencies.jl:12-46):   Gᵁ = Σₖ Δz ((3/2 + χ) Gⁿ - (1/2 + χ) G⁻ not_euler)
+//   compute_barotropic_mode! of u*             (barotropic_split_explicit_corrector.jl:13-32), which the barotropic corrector needs
+//       after the substepping: U̅* = Σₖ Δz u* σ, σ = 1 on a static grid
+//
+// A workgroup owns a 32 x 8 patch of columns and marches k = 1 .. Nz; planes k-1, k, k+1 of u, v, w live in a 3-slot LDS ring with a
+// one-cell rim (every stencil of the vector-invariant form and of the stress divergence fits), pHY′, G⁻ are touched once per cell.
+// The column sums ride along in registers in the reference's order (k ascending, first term assigned), so the strict build is
+// bit-identical to the unfused kernels (vector_invariant_kernel, momentum_extra_kernel, stepper_kernel<2>,
+// barotropic_forcing_kernel, barotropic_mode_kernel).  HBM per cell: read u, v, w, pHY′, G⁻u, G⁻v; write Gu, Gv, u*, v* = 80 B
+// (the five launches it replaces: 264 B).
+// ---------------------------------------------------------------------------------------------------
+template <class FU, class FV, class FW>
+__device__ __forceinline__ void vector_invariant_cell(const Metrics &M, int k, FU uu, FV vv, FW ww, double &Gu0, double &Gv0)
+{
+    const double dx = M.dx, dy = M.dy, Az = dx * dy;
+    const double dzf0 = M.dzF(k), dzf1 = M.dzF(k + 1);  // Δzᶠ at faces k, k+1
+    auto zeta = [&](int a, int b) {  // ζ₃ᶠᶠᶜ at (i + a, j + b)  (Operators/vorticity_operators.jl:4-11)
+        const double gam = (dy * vv(a, b, 0) - dy * vv(a - 1, b, 0)) - (dx * uu(a, b, 0) - dx * uu(a, b - 1, 0));
+        return gam / Az;
+    };
+    auto Kh = [&](int a, int b) {    // Khᶜᶜᶜ at (i + a, j + b)
+        return (0.5 * (uu(a, b, 0) * uu(a, b, 0) + uu(a + 1, b, 0) * uu(a + 1, b, 0)) +
+                0.5 * (vv(a, b, 0) * vv(a, b, 0) + vv(a, b + 1, 0) * vv(a, b + 1, 0))) / 2;
+    };
+    {
+        auto m = [&](int a) { return 0.5 * (dx * vv(a, 0, 0) + dx * vv(a, 1, 0)); };  // ℑyᵃᶜᵃ(Δx_qᶜᶠᶜ v) at (i + a, j)
+        const double hadv = -(0.5 * (zeta(0, 0) + zeta(0, 1))) * (0.5 * (m(-1) + m(0))) / dx;
+        auto Z = [&](int c, double dzf) { return (0.5 * (Az * ww(-1, 0, c) + Az * ww(0, 0, c))) * ((uu(0, 0, c) - uu(0, 0, c - 1)) / dzf); };
+        const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
+        const double bern = (Kh(0, 0) - Kh(-1, 0)) / dx;
+        Gu0 = -((hadv + vadv) + bern);
+    }
+    {
+        auto n = [&](int b) { return 0.5 * (dy * uu(0, b, 0) + dy * uu(1, b, 0)); };  // ℑxᶜᵃᵃ(Δy_qᶠᶜᶜ u) at (i, j + b)
+        const double hadv = (0.5 * (zeta(0, 0) + zeta(1, 0))) * (0.5 * (n(-1) + n(0))) / dy;
+        auto Z = [&](int c, double dzf) { return (0.5 * (Az * ww(0, -1, c) + Az * ww(0, 0, c))) * ((vv(0, 0, c) - vv(0, 0, c - 1)) / dzf); };
+        const double vadv = (0.5 * (Z(0, dzf0) + Z(1, dzf1))) / Az;
+        const double bern = (Kh(0, 0) - Kh(0, -1)) / dy;
+        Gv0 = -((hadv + vadv) + bern);
+    }
+}
+
+__global__ __launch_bounds__(256) void hydrostatic_momentum_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
+                                                                  const double *__restrict__ v, const double *__restrict__ w,
+                                                                  double *__restrict__ Gu, double *__restrict__ Gv,
+                                                                  ocn::MomentumFinal mf, ocn::HydroFuse hf)
+{
+    constexpr int TZ = OCN_BOUNDED;
+    constexpr int TX = 32, TY = 8, SX = TX + 2, SY = TY + 2, PL = SX * SY;
+    __shared__ double Lu[3][PL], Lv[3][PL], Lw[3][PL];
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int i0 = 1 + blockIdx.x * TX, j0 = 1 + blockIdx.y * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool active = (i <= g.Nx) && (j <= g.Ny);
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long s2 = L.s2, s3 = L.s3;
+    PRange r{1, g.Nx, 1, g.Ny, 1, g.Nz, 1};
+    constexpr int NS = (PL + TX * TY - 1) / (TX * TY);  // cells staged per thread (2)
+    long long soff[NS];
+    bool son[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int idx = tid + q * TX * TY;
+        son[q] = idx < PL;
+        const int li = son[q] ? idx % SX : 0, lj = son[q] ? idx / SX : 0;
+        soff[q] = ocn::at(L, min(i0 - 1 + li, g.Nx + 1), min(j0 - 1 + lj, g.Ny + 1), 0);  // plane 0: add kk * s3
+    }
+    double fu[NS], fv[NS], fw[NS];
+    auto fetch = [&](int kk) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const long long oo = soff[q] + (long long)kk * s3;
+            fu[q] = son[q] ? u[oo] : 0.0;
+            fv[q] = son[q] ? v[oo] : 0.0;
+            fw[q] = son[q] ? w[oo] : 0.0;
+        }
+    };
+    auto commit = [&](int kk) {
+        const int slot = (kk + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (!son[q]) continue;
+            const int idx = tid + q * TX * TY;
+            Lu[slot][idx] = fu[q];
+            Lv[slot][idx] = fv[q];
+            Lw[slot][idx] = fw[q];
+        }
+    };
+    fetch(0);
+    commit(0);
+    fetch(1);
+    commit(1);
+    fetch(2);
+    const int c0 = (ty + 1) * SX + (tx + 1);
+    const long long e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);  // this column in the (sx, sy) planes of η, Gᵁ, U̅
+    double gxe = 0.0, gye = 0.0;
+    if (active && hf.eta) {  // explicit_barotropic_pressure_x/y_gradient (explicit_free_surface.jl:36-40), the same at every k
+        gxe = hf.grav * ((hf.eta[e] - hf.eta[e - 1]) / g.dx);
+        gye = hf.grav * ((hf.eta[e] - hf.eta[e - L.sx]) / g.dy);
+    }
+    double aGU = 0.0, aGV = 0.0, aU = 0.0, aV = 0.0;
+    for (int k = 1; k <= g.Nz; ++k) {
+        commit(k + 1);
+        __syncthreads();
+        if (k < g.Nz) fetch(k + 2);  // consumed by the next iteration's commit
+        if (active) {
+            const long long o = ocn::at(L, i, j, k);
+            const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
+            auto Uf = [&](int a, int b, int c) { return Lu[(base + c) % 3][c0 + a + b * SX]; };
+            auto Vf = [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; };
+            auto Wf = [&](int a, int b, int c) { return Lw[(base + c) % 3][c0 + a + b * SX]; };
+            double G0u, G0v, res[4];
+            vector_invariant_cell(M, k, Uf, Vf, Wf, G0u, G0v);
+            if (hf.eta) {
+                G0u -= gxe;
+                G0v -= gye;
+            }
+            momentum_extra_cell<TZ, true>(g, t, M, i, j, k, o, s2, s3, false, Uf, Vf, Wf, [&](int, int, int) { return 0.0; }, Gu, Gv,
+                                          nullptr, r, mf, G0u, G0v, res);
+            const double dz = M.dzC(k);
+            if (k == 1) {
+                aGU = dz * res[0];
+                aGV = dz * res[2];
+                aU = dz * res[1] * 1.0;
+                aV = dz * res[3] * 1.0;
+            } else {
+                aGU = aGU + dz * res[0];
+                aGV = aGV + dz * res[2];
+                aU = aU + dz * res[1] * 1.0;
+                aV = aV + dz * res[3] * 1.0;
+            }
+        }
+        __syncthreads();  // everyone is done with slot (k - 1) % 3 before the next iteration overwrites it
+    }
+    if (active && hf.GU) {
+        hf.GU[e] = aGU;
+        hf.GV[e] = aGV;
+        hf.Ub[e] = aU;
+        hf.Vb[e] = aV;
+    }
+}
+
 // Gc <- Gc - ∇_dot_qᶜ,  q = -(κ ∂c)  (closure_kernel_operators.jl:48-53)
 template <int TZ>
 __global__ __launch_bounds__(256) void tracer_diffusion_kernel(GridDev g, double kappa, const double *__restrict__ kappa_e,
@@ -501,6 +671,16 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
     }
     const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r, mf);
+    return OCN_SUCCESS;
+}
+
+int launch_hydrostatic_momentum(const ocn_grid *grid, const TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                double *Gv, const ocn::MomentumFinal &mf, const ocn::HydroFuse &hf, hipStream_t stream)
+{
+    GridDev g = ocn::to_dev(*grid);
+    dim3 nbt((g.Nx + 31) / 32, (g.Ny + 7) / 8, 1);
+    hipLaunchKernelGGL(hydrostatic_momentum_tiled, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
+    OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
 

@@ -49,10 +49,14 @@ def averaging_shape_function(tau, p=2, q=4, r=0.18927):
 
 
 def weights_from_substeps(substeps, averaging_kernel=averaging_shape_function):
-    """weights_from_substeps (split_explicit_free_surface.jl:228-241): (fractional step size, normalised averaging weights truncated at
-    Julia's searchsortedlast(weights, 0, rev=true))"""
+    """weights_from_substeps (split_explicit_free_surface.jl:250-263): (fractional step size, normalised averaging weights truncated at
+    Julia's searchsortedlast(weights, 0, rev=true)).  Julia's range(0.0, 2.0, length = N+1) is a TwicePrecision StepRangeLen whose
+    elements are the correctly rounded 2k/N, so the nodes are built from exact rationals here (np.linspace can differ in the last
+    bit).  Parity of the weights with a live Julia run is unpinned."""
+    from fractions import Fraction
+
     import numpy as np
-    tau = np.linspace(0.0, 2.0, substeps + 1)
+    tau = [float(Fraction(2 * k, substeps)) for k in range(substeps + 1)]
     w = np.array([averaging_kernel(t) for t in tau[1:]])
     lo, hi = 0, len(w) + 1
     while lo < hi - 1:
@@ -65,24 +69,71 @@ def weights_from_substeps(substeps, averaging_kernel=averaging_shape_function):
     return float(tau[1] - tau[0]), w / w.sum()
 
 
-class SplitExplicitFreeSurface:
-    """SplitExplicitFreeSurface(; substeps, gravitational_acceleration = g_Earth, timestepper = ForwardBackwardScheme())
-    (split_explicit_free_surface.jl:60-97); cfl-based substepping and the AdamsBashforth3Scheme are not implemented."""
+MINIMUM_SUBSTEPS = 5  # step_split_explicit_free_surface.jl:51
 
-    def __init__(self, substeps=None, gravitational_acceleration=g_Earth, averaging_kernel=averaging_shape_function):
-        if substeps is None:
-            substeps = 5  # MINIMUM_SUBSTEPS (step_split_explicit_free_surface.jl:51)
+
+class ForwardBackwardScheme:
+    """ForwardBackwardScheme() (split_explicit_timesteppers.jl:13-17): η = f(U) then U = f(η)"""
+
+
+class SplitExplicitFreeSurface:
+    """SplitExplicitFreeSurface(grid = nothing; substeps, cfl, fixed_Δt, gravitational_acceleration = g_Earth, averaging_kernel,
+    timestepper = ForwardBackwardScheme()) (split_explicit_free_surface.jl:120-155).
+
+      * substeps = N                      -> FixedSubstepNumber (:158-162)
+      * neither substeps nor cfl          -> MINIMUM_SUBSTEPS substeps (the reference's disambiguation method, :178-179)
+      * cfl (needs `grid`), no fixed_Δt   -> FixedTimeStepSize (:165-168, :217-235): Δt_barotropic = cfl Δs / sqrt(g Lz), the number of
+                                             substeps max(MINIMUM_SUBSTEPS, ceil(2 Δt / Δt_barotropic)) and the weights are recomputed from
+                                             the baroclinic Δt at every step (step_split_explicit_free_surface.jl:54-58)
+      * cfl and fixed_Δt (needs `grid`)   -> FixedSubstepNumber with ceil(2 fixed_Δt / Δt_barotropic) substeps (:171-176)"""
+
+    def __init__(self, grid=None, substeps=None, cfl=None, fixed_Δt=None, gravitational_acceleration=g_Earth,
+                 averaging_kernel=averaging_shape_function, timestepper=None):
+        import math
         self.gravitational_acceleration = float(gravitational_acceleration)
-        self.fractional_step_size, self.averaging_weights = weights_from_substeps(int(substeps), averaging_kernel)
+        self.averaging_kernel = averaging_kernel
+        self.timestepper = ForwardBackwardScheme() if timestepper is None else timestepper
+        self.Δt_barotropic = None
+        if cfl is not None:
+            if substeps is not None:
+                raise ValueError("SplitExplicitFreeSurface: give either substeps or cfl, not both")
+            if grid is None:
+                raise ValueError("The grid is a required positional argument to SplitExplicitFreeSurface when cfl is specified")
+            inv2 = 1.0 / grid.dx ** 2 + 1.0 / grid.dy ** 2
+            ds = math.sqrt(1.0 / inv2)
+            self.Δt_barotropic = float(cfl) * ds / math.sqrt(self.gravitational_acceleration * grid.Lz)
+            if fixed_Δt is not None:
+                substeps = math.ceil(2 * float(fixed_Δt) / self.Δt_barotropic)
+                self.Δt_barotropic = None
+        elif substeps is None:
+            substeps = MINIMUM_SUBSTEPS
+        if self.Δt_barotropic is None:
+            self.fractional_step_size, self.averaging_weights = weights_from_substeps(int(substeps), averaging_kernel)
+
+    def settings(self, dt):
+        """calculate_substeps / calculate_adaptive_settings (step_split_explicit_free_surface.jl:54-58): (fractional Δτ, weights)"""
+        if self.Δt_barotropic is None:
+            return self.fractional_step_size, self.averaging_weights
+        import math
+        n = max(MINIMUM_SUBSTEPS, math.ceil(2 * float(dt) / self.Δt_barotropic))
+        return weights_from_substeps(n, self.averaging_kernel)
 
 
 class HydrostaticFreeSurfaceModel:
     def __init__(self, grid, momentum_advection=None, tracer_advection=None, tracers=(), free_surface=None, coriolis=None,
-                 closure=None, buoyancy=None, boundary_conditions=None):
+                 closure=None, buoyancy=None, boundary_conditions=None, fused=None):
+        """fused (default: True with VectorInvariant() momentum): one QAB2 step = one pass for the horizontal momentum (tendency, AB2
+        step, barotropic forcing and mode), one launch per WENO / UpwindBiased tracer (tendency + AB2 step), the temporally blocked
+        substep loop, one pass for the barotropic corrector + w, one halo launch, the hydrostatic pressure; the tendency evaluation
+        that closes the reference's time_step! is deferred into the next step's fused launches (`flush_tendencies` completes it).
+        fused = False keeps the reference's launch sequence.  Both are bit-identical in strict math."""
         if tuple(grid.topology) != (Periodic, Periodic, Bounded) or hasattr(grid.architecture, "partition"):
             raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids on one GPU in this slice")
         if free_surface is None:
-            free_surface = ExplicitFreeSurface()
+            # default_free_surface (hydrostatic_free_surface_model.jl:51-55): ImplicitFreeSurface on an xy-regular RectilinearGrid,
+            # which this backend does not have -- refuse rather than silently pick different numerics
+            raise NotImplementedError("HydrostaticFreeSurfaceModel: the reference's default free surface on this grid is ImplicitFreeSurface, "
+                                      "which is not implemented; pass free_surface = ExplicitFreeSurface() or SplitExplicitFreeSurface(...)")
         if not isinstance(free_surface, (ExplicitFreeSurface, SplitExplicitFreeSurface)):
             raise NotImplementedError("free_surface must be ExplicitFreeSurface(...) or SplitExplicitFreeSurface(substeps=...)")
         self.split = isinstance(free_surface, SplitExplicitFreeSurface)
@@ -115,11 +166,19 @@ class HydrostaticFreeSurfaceModel:
         self._Geta_m = torch.zeros_like(self.eta)
         if self.split:  # barotropic velocities, filtered state, slow forcing: planes like η (interiors used)
             self.U, self.V, self._Ub, self._Vb, self._etab, self._GU, self._GV = (torch.zeros_like(self.eta) for _ in range(7))
-            w = free_surface.averaging_weights
-            self._weights = (C.c_double * len(w))(*[float(x) for x in w])
+            self._weights_key, self._weights, self._frac = None, None, None
             self._initialized = False
         self._adv_only = _lib.CModelTerms()                                     # the advective part alone, by scheme
         self._adv_only.advection = nh._terms.advection
+        self.fused = self.vector_invariant if fused is None else bool(fused)
+        if self.fused and not self.vector_invariant:
+            raise NotImplementedError("fused = True needs momentum_advection = VectorInvariant()")
+        self._tracer_fusable = not isinstance(container_advection, Centered)    # the tiled WENO / UpwindBiased tracer kernel has the epilogue
+        self._alt = None                                                        # second storage of u, v and the tracers
+        self._tendencies_current = False                                        # Gⁿ holds the tendencies of the current state
+        if self.split and self.fused:
+            self._Us, self._Vs = torch.zeros_like(self.eta), torch.zeros_like(self.eta)   # Σ Δz u*, Σ Δz v*
+            self._work = torch.zeros((3,) + tuple(self.eta.shape), dtype=torch.float64, device=dev)
         self.update_state(compute_tendencies=False)
 
     # ---- helpers -------------------------------------------------------------------------------------------------------
@@ -140,12 +199,20 @@ class HydrostaticFreeSurfaceModel:
         self._fill_eta_halos()
         _lib.call("ocn_compute_w_from_continuity", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, stream_ptr())
         update_hydrostatic_pressure(nh)
+        self._tendencies_current = False
         if compute_tendencies:
             self.compute_tendencies()
 
     # ---- compute_tendencies! (hydrostatic_free_surface_tendency_kernel_functions.jl:45-52, 86-93, 125-131) -----------------------
+    def flush_tendencies(self):
+        """Complete the tendency evaluation the fused time step defers (update_state!(model; compute_tendencies = true) at the end of
+        the reference's time_step!): afterwards timestepper Gⁿ holds the tendencies of the current state."""
+        if not self._tendencies_current:
+            self.compute_tendencies()
+
     def compute_tendencies(self):
         nh, g, s = self._nh, self.grid, stream_ptr()
+        self._tendencies_current = True
         Gn = nh.timestepper._Gn
         grav = self.free_surface.gravitational_acceleration
         # explicit_barotropic_pressure_x/y_gradient: g ∇η for the ExplicitFreeSurface, zero for the split-explicit one
@@ -168,7 +235,11 @@ class HydrostaticFreeSurfaceModel:
 
     # ---- time_step! (quasi_adams_bashforth_2.jl:74-115 with ab2_step!(::HydrostaticFreeSurfaceModel)) -------------------------
     def time_step(self, dt, euler=False):
+        if self.fused:
+            return self._time_step_fused(dt, euler)
         nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
+        if not self._tendencies_current and clock.iteration > 0:
+            self.compute_tendencies()
         if clock.iteration == 0:
             if self.split and not self._initialized:  # initialize_free_surface! (the reference: run!(simulation) / first_time_step!)
                 _lib.call("ocn_compute_barotropic_mode", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(), s)
@@ -188,9 +259,7 @@ class HydrostaticFreeSurfaceModel:
             # compute_free_surface_tendency! (slow forcing from Gⁿ, G⁻ BEFORE they are cached), then step_free_surface!
             _lib.call("ocn_split_explicit_forcing", g.cref, Gn[0].ptr, Gm[0].ptr, Gn[1].ptr, Gm[1].ptr, float(chi), self._GU.data_ptr(),
                       self._GV.data_ptr(), s)
-            _lib.call("ocn_split_explicit_substeps", g.cref, len(self._weights), self._weights, fs.fractional_step_size * float(dt),
-                      fs.gravitational_acceleration, float(g.Lz), self.eta.data_ptr(), self.U.data_ptr(), self.V.data_ptr(),
-                      self._etab.data_ptr(), self._Ub.data_ptr(), self._Vb.data_ptr(), self._GU.data_ptr(), self._GV.data_ptr(), s)
+            self._substep_free_surface(dt, s)
             # pressure_correct_velocities!: the barotropic corrector
             _lib.call("ocn_barotropic_split_explicit_corrector", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(),
                       self._Ub.data_ptr(), self._Vb.data_ptr(), float(g.Lz), s)
@@ -206,6 +275,98 @@ class HydrostaticFreeSurfaceModel:
         nh.timestepper._Gn, nh.timestepper._Gm = Gm, Gn
         self._Geta, self._Geta_m = self._Geta_m, self._Geta
         self.update_state(compute_tendencies=True)
+
+    # ---- the same step with fused launches -----------------------------------------------------------------------------------
+    def _substep_free_surface(self, dt, s):
+        fs, g = self.free_surface, self.grid
+        frac, w = fs.settings(dt)
+        if self._weights_key is not w:
+            self._weights_key, self._weights = w, (C.c_double * len(w))(*[float(x) for x in w])
+        args = (g.cref, len(self._weights), self._weights, frac * float(dt), fs.gravitational_acceleration, float(g.Lz), self.eta.data_ptr(),
+                self.U.data_ptr(), self.V.data_ptr(), self._etab.data_ptr(), self._Ub.data_ptr(), self._Vb.data_ptr(), self._GU.data_ptr(),
+                self._GV.data_ptr())
+        if self.fused:
+            _lib.call("ocn_split_explicit_substeps_blocked", *args, self._work.data_ptr(), s)
+        else:
+            _lib.call("ocn_split_explicit_substeps", *args, s)
+
+    def _time_step_fused(self, dt, euler=False):
+        """time_step!(model, Δt) (quasi_adams_bashforth_2.jl:74-115 with ab2_step!(::HydrostaticFreeSurfaceModel),
+        hydrostatic_free_surface_ab2_step.jl:9-26) re-cut at the launch boundaries that the data flow allows; every field ends up with
+        the bits of the reference sequence (strict math).  State on entry and exit: halos filled, w and pHY′ consistent with u, v, T, S."""
+        nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
+        if clock.iteration == 0 and self.split and not self._initialized:
+            _lib.call("ocn_compute_barotropic_mode", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(), s)
+            self._initialized = True
+        euler = bool(euler or (dt != clock.last_dt))
+        chi = -0.5 if euler else nh.timestepper.chi
+        Gn, Gm = nh.timestepper._Gn, nh.timestepper._Gm
+        prog = [self.u, self.v] + list(self.tracers)
+        if self._alt is None:
+            self._alt = [torch.zeros_like(f.data) for f in prog]
+        alt = self._alt
+        t = C.byref(nh._terms)
+        from .models import _bcs_ref
+        fs = self.free_surface
+        grav = fs.gravitational_acceleration
+        # compute_tendencies! (of the state the previous step left) + ab2_step_velocities! + compute_free_surface_tendency!
+        sp = (self._GU.data_ptr(), self._GV.data_ptr(), self._Us.data_ptr(), self._Vs.data_ptr()) if self.split else (None,) * 4
+        _lib.call("ocn_hydrostatic_momentum_ab2_step", g.cref, t, _bcs_ref(self.u, g), _bcs_ref(self.v, g), self.u.ptr, self.v.ptr, self.w.ptr,
+                  Gn[0].ptr, Gn[1].ptr, Gm[0].ptr, Gm[1].ptr, alt[0].data_ptr(), alt[1].data_ptr(), float(dt), float(chi), int(euler),
+                  None if self.split else self.eta.data_ptr(), grav, *sp, s)
+        # tracer tendencies + ab2_step_tracers!
+        gamma, zeta = 1.5 + chi, -(0.5 + chi)
+        for n, c in enumerate(self.tracers):
+            kappa = 0.0 if nh.closure is None else nh.closure.kappa_of(self.tracer_names[n])
+            if self._tracer_fusable:
+                _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, None, _bcs_ref(c, g), self.u.ptr, self.v.ptr, self.w.ptr,
+                          c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[2 + n].data_ptr(), float(dt), gamma, zeta, 0 if euler else 1, None, s)
+            else:
+                _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, None, self.u.ptr, self.v.ptr, self.w.ptr, c.ptr,
+                          Gn[3 + n].ptr, None, s)
+        if self.tracers and not self._tracer_fusable:
+            self._apply_tracer_flux_bcs()
+            idx = [3 + n for n in range(len(self.tracers))]
+            _lib.call("ocn_ab2_step", g.cref, len(idx), _lib.ptr_array([c.ptr for c in self.tracers]), _lib.ptr_array([Gn[q].ptr for q in idx]),
+                      _lib.ptr_array([Gm[q].ptr for q in idx]), _lib.i32_array([c.loc for c in self.tracers]), float(dt), float(chi), s)
+        # step_free_surface!, then pressure_correct_velocities! (the barotropic corrector) + compute_w_from_continuity!
+        if self.split:
+            self._substep_free_surface(dt, s)
+            _lib.call("ocn_barotropic_corrector_and_w", g.cref, alt[0].data_ptr(), alt[1].data_ptr(), self.u.ptr, self.v.ptr, self.w.ptr,
+                      self.U.data_ptr(), self.V.data_ptr(), self._Us.data_ptr(), self._Vs.data_ptr(), float(g.Lz), s)
+        else:
+            _lib.call("ocn_explicit_free_surface_ab2_step", g.cref, self.w.ptr, self.eta.data_ptr(), self._Geta.data_ptr(),
+                      self._Geta_m.data_ptr(), float(dt), float(chi), s)
+            _lib.call("ocn_barotropic_corrector_and_w", g.cref, alt[0].data_ptr(), alt[1].data_ptr(), self.u.ptr, self.v.ptr, self.w.ptr,
+                      None, None, None, None, float(g.Lz), s)
+            self._Geta, self._Geta_m = self._Geta_m, self._Geta
+        if self._tracer_fusable:
+            for n, c in enumerate(self.tracers):
+                c.data, alt[2 + n] = alt[2 + n], c.data
+            nh._refresh_term_pointers()
+        clock.time += dt
+        clock.iteration += 1
+        clock.last_dt = dt
+        clock.last_stage_dt = dt
+        nh.timestepper._Gn, nh.timestepper._Gm = Gm, Gn                     # cache_previous_tendencies!: role swap
+        # update_state!(model; compute_tendencies = false): halos (w's halo columns are periodic images of the interior ones computed
+        # above), η halos, hydrostatic pressure; the tendencies follow in the next step's fused launches
+        fill_halo_regions((self.u, self.v, self.w) + tuple(self.tracers), fill_boundary_normal_velocities=False)
+        self._fill_eta_halos()
+        update_hydrostatic_pressure(nh)
+        self._tendencies_current = False
+
+    def _apply_tracer_flux_bcs(self):
+        """compute_boundary_tendency_contributions! for the tracers alone (u, v get theirs inside the fused momentum launch)"""
+        nh, g = self._nh, self.grid
+        tr = [c for c in self.tracers if c.boundary_conditions is not None and c.boundary_conditions.has_flux()]
+        if not tr:
+            return
+        Gn = nh.timestepper._Gn
+        Gs = [Gn[3 + self.tracers.index(c)] for c in tr]
+        arr = (C.POINTER(_lib.CFieldBcs) * len(tr))(*[C.pointer(c.boundary_conditions.c_struct(g)) for c in tr])
+        _lib.call("ocn_apply_flux_bcs", g.cref, _lib.ptr_array([G.ptr for G in Gs]), _lib.ptr_array([c.ptr for c in tr]),
+                  _lib.i32_array([c.loc for c in tr]), arr, len(tr), stream_ptr())
 
     def set(self, **kwargs):
         g = self.grid

@@ -90,7 +90,9 @@ def averaging_shape_function(tau, p=2, q=4, r=0.18927):
 def weights_from_substeps(substeps, averaging_kernel=averaging_shape_function):
     """weights_from_substeps (split_explicit_free_surface.jl:228-241): fractional step size Δτ and the normalised averaging
     weights, truncated at Julia's searchsortedlast(weights, 0, rev=true)."""
-    tau = np.linspace(0.0, 2.0, substeps + 1)
+    from fractions import Fraction
+    # Julia's range(0.0, 2.0, length = N+1) is a TwicePrecision StepRangeLen: its elements are the correctly rounded 2k/N
+    tau = np.array([float(Fraction(2 * k, substeps)) for k in range(substeps + 1)])
     dtau = tau[1] - tau[0]
     w = np.array([averaging_kernel(t) for t in tau[1:]])
     lo, hi = 0, len(w) + 1                      # Base.searchsortedlast with the Reverse ordering, on 1-based indices

@@ -72,3 +72,42 @@ def test_node_coordinates(pkg):
     assert np.array_equal(g.nodes_1d(2, 0), [-3.0, -1.25, -0.25])
     x, y, z = g.nodes(1)
     assert x.shape == (4, 1, 1) and y.shape == (1, 5, 1) and z.shape == (1, 1, 3)
+
+
+# ---- SplitExplicitFreeSurface constructor (split_explicit_free_surface.jl:120-263) --------------------------------------------------
+def test_split_explicit_free_surface_settings(pkg):
+    """substeps = N, the MINIMUM_SUBSTEPS default of the disambiguation method (:178-179), cfl-based FixedTimeStepSize (:217-235)
+    with substeps recomputed from the baroclinic Δt (step_split_explicit_free_surface.jl:54-58), cfl + fixed_Δt (:171-176); the
+    weights equal the oracle's independent restatement, are normalised and centred (Σ aₘ m / M ≈ 1, the docstring's condition)."""
+    from oracle import hydrostatic as Hy
+    S = pkg.SplitExplicitFreeSurface
+    for n in (5, 12, 30, 51):
+        fs = S(substeps=n)
+        frac, w = fs.settings(1.0)
+        ofrac, ow = Hy.weights_from_substeps(n)
+        assert frac == ofrac == 2.0 / n and np.array_equal(w, ow)
+        assert abs(w.sum() - 1) < 1e-15 and len(w) <= n
+        if n >= 12:
+            assert abs((w * np.arange(1, len(w) + 1)).sum() * frac - 1) < 0.05
+    assert len(S().settings(1.0)[1]) == len(S(substeps=5).settings(1.0)[1])           # MINIMUM_SUBSTEPS
+    g = pkg.RectilinearGrid(None, size=(8, 8, 4), x=(0, 8e3), y=(0, 4e3), z=(-100.0, 0.0), topology=("Periodic", "Periodic", "Bounded"))
+    with pytest.raises(ValueError):
+        S(cfl=0.7)                                                                     # the grid is required with cfl
+    fs = S(g, cfl=0.7)
+    ds = np.sqrt(1 / (1 / g.dx ** 2 + 1 / g.dy ** 2))
+    dtb = 0.7 * ds / np.sqrt(fs.gravitational_acceleration * 100.0)
+    assert abs(fs.Δt_barotropic - dtb) < 1e-15 * dtb
+    for dt in (0.5 * dtb, 10 * dtb, 33.3 * dtb):
+        frac, w = fs.settings(dt)
+        n = max(5, int(np.ceil(2 * dt / dtb)))
+        assert frac == 2.0 / n and np.array_equal(w, Hy.weights_from_substeps(n)[1])
+    fs = S(g, cfl=0.7, fixed_Δt=10 * dtb)
+    assert fs.settings(123.0)[0] == 2.0 / int(np.ceil(2 * 10 * dtb / dtb))
+
+
+def test_hydrostatic_model_refuses_the_implicit_default(pkg):
+    """default_free_surface on an xy-regular RectilinearGrid is ImplicitFreeSurface (hydrostatic_free_surface_model.jl:51-52), which this
+    backend does not have: free_surface = None must raise instead of silently choosing another free surface."""
+    g = pkg.RectilinearGrid(None, size=(8, 8, 4), x=(0, 8e3), y=(0, 4e3), z=(-100.0, 0.0), topology=("Periodic", "Periodic", "Bounded"))
+    with pytest.raises(NotImplementedError):
+        pkg.HydrostaticFreeSurfaceModel(g)

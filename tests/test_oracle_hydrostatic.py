@@ -301,3 +301,37 @@ def test_barotropic_correction():
     m._barotropic_corrector()
     assert np.abs(g.interior_N(m.u) - (zz + np.cos(xf)[:, None, None] + 0 * yc[None, :, None])).max() < 1e-14
     assert np.abs(g.interior_N(m.v) - (zz * np.sin(yf)[None, :, None] + (np.cos(xc) + xc)[:, None, None])).max() < 1e-13
+
+
+# ---- BASELINE.json configs[4]: VectorInvariant momentum + WENO tracer advection + split-explicit free surface ----------------------
+def test_config5_combination_budgets():
+    """The combination BASELINE.json names (VectorInvariant() momentum, tracer_advection = WENO(), SplitExplicitFreeSurface, T / S
+    with linear SeawaterBuoyancy, FPlane, ScalarDiffusivity) steps on the oracle; mean(η) is conserved by the substepping
+    (test_split_explicit_free_surface_solver.jl: mean(η) conserved to 10 eps), Σ Δz u equals the barotropic transport after the
+    corrector, w[k = 1] = 0, and the tracer totals change only by the advective flux through the moving surface of the static
+    grid, Σ Az w[Nz+1] c_top dt (a linear free surface on z-coordinates does not conserve tracers exactly)."""
+    g = _grid(N=(20, 14, 8), stretched=False)
+    rng = np.random.default_rng(17)
+    shp = (g.Nx, g.Ny, g.Nz)
+    m = Hy.HydrostaticFreeSurfaceModel(g, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5",
+                                       coriolis_f=1e-4, closure=(1e-2, 1e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4),
+                                       split_explicit_substeps=20)
+    assert m.tracer_scheme == O.ADV_WENO5 and m.vector_invariant
+    m.set(u=1e-2 * rng.uniform(-1, 1, shp), v=1e-2 * rng.uniform(-1, 1, shp), eta=1e-3 * rng.uniform(-1, 1, shp[:2]),
+          T=20 + 1e-2 * rng.uniform(-1, 1, shp), S=35 + 1e-2 * rng.uniform(-1, 1, shp))
+    ii, jj = slice(g.Hx, g.Hx + g.Nx), slice(g.Hy, g.Hy + g.Ny)
+    eta0 = m.eta[ii, jj].mean()
+    T0, S0 = g.interior(m.tracers[0]).sum(), g.interior(m.tracers[1]).sum()
+    dt = 1.5 * g.dx / np.sqrt(Hy.g_Earth * g.Lz)
+    for _ in range(5):
+        m.time_step(dt)
+        assert abs(m.eta[ii, jj].mean() - eta0) < 10 * np.finfo(float).eps * 1e-3 * 20
+        assert np.abs(m._barotropic_mode(m.u) - m.U).max() <= 16 * np.finfo(float).eps * np.abs(m.U).max()
+        assert np.abs(m.w[ii, jj, g.Hz]).max() == 0
+    assert np.isfinite(m.eta).all() and all(np.isfinite(f).all() for f in m.fields)
+    wtop = np.abs(m.w[ii, jj, g.Hz + g.Nz]).max()
+    for c, c0 in zip(m.tracers, (T0, S0)):
+        drift = abs(g.interior(c).sum() - c0)
+        assert drift <= 5 * dt * wtop / g.dz * np.abs(g.interior(c)).max() * g.Nx * g.Ny * 2   # surface flux bound
+        assert drift < 1e-7 * abs(c0)
+    assert np.abs(m.U).max() > 0 and np.abs(g.interior(m.w)).max() > 0

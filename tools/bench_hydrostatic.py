@@ -25,7 +25,8 @@ m = ocn.HydrostaticFreeSurfaceModel(g, momentum_advection=ocn.WENO() if scheme =
                                     tracer_advection=ocn.WENO() if scheme == "config5" else None,
                                     free_surface=ocn.SplitExplicitFreeSurface(substeps=split) if split else ocn.ExplicitFreeSurface(),
                                     coriolis=ocn.FPlane(f=1e-4), closure=ocn.ScalarDiffusivity(ν=1e-2, κ=1e-3),
-                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)))
+                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                    fused=None if os.environ.get("OCN_HYDRO_FUSED", "1") != "0" else False)
 gen = torch.Generator(device="cuda"); gen.manual_seed(1)
 for f in (m.u, m.v):
     iv = f.interior_view()
@@ -44,5 +45,5 @@ for _ in range(steps):
 ocn.sync_device()
 ms = (time.perf_counter() - t0) / steps * 1e3
 finite = bool(torch.isfinite(m.eta).all()) and all(bool(torch.isfinite(f.interior_view()).all()) for f in m.velocities)
-print(f"hydrostatic slice {Nx}x{Nx}x{Nz} PPB, {'split-explicit(' + str(split) + ')' if split else 'explicit'} free surface, {scheme}, T+S, QAB2: {ms:.2f} ms/step, "
+print(f"hydrostatic slice {Nx}x{Nx}x{Nz} PPB, fused={m.fused}, {'split-explicit(' + str(split) + ')' if split else 'explicit'} free surface, {scheme}, T+S, QAB2: {ms:.2f} ms/step, "
       f"{Nx * Nx * Nz / ms * 1e3:.3e} cell-updates/s, max|eta| = {float(m.eta.abs().max()):.2e}, finite={finite}")
