@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- cell-updates/s of full RK3 time steps of the WENO5 NonhydrostaticModel (BASELINE.json metric).
+"""bench.py -- cell-updates/s of full time steps of the reference's models on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--size 512] [--math fast|strict]
+    python bench.py --gpus N --steps K --warmup W [--workload box|config4|config5] [--size 512] [--math fast|strict]
 
-Workload (config.workload): N^3 triply periodic RectilinearGrid, extent (2 pi)^3, halo 3, fp64,
-advection = WENO() (5th order), RungeKutta3, FFT-based pressure solver, no tracers/closure/buoyancy
-(BASELINE.json configs[1]/[2] at --size 256 / 512).  Inputs are synthetic: u, v, w ~ U(-1, 1) from a fixed seed,
-projected to be divergence free by set! (one dt = 1 pressure solve); dt = 0.1 dx / max|u|.
-A "step" is one full time_step!: 3 x (substep, pressure projection, tendencies).  With --gpus N > 1 the same global
-grid is x-slab partitioned over N ranks (strong scaling), one process per GPU, RCCL halo exchange + all-to-all
-transposes.  Rank 0 prints ONE JSON line.
+Workloads (config.workload):
+  box      (default; the configuration the metric is quoted on, BASELINE.json configs[1]/[2] at --size 256 / 512): N^3 triply
+           periodic RectilinearGrid, extent (2 pi)^3, halo 3, fp64, advection = WENO() (5th order), RungeKutta3, FFT-based pressure
+           solver, no tracers / closure / buoyancy.  u, v, w ~ U(-1, 1) from a fixed seed, projected to be divergence free by set!
+           (one dt = 1 pressure solve); dt = 0.1 dx / max|u|.  A "step" is one full time_step!: 3 x (substep, projection, tendencies).
+  config4  configs[3]: N x N x N/2 (Periodic, Periodic, Bounded), stretched z, ocean_wind_mixing_and_convection physics.
+  config5  configs[4]: 2N x 2N x N/4 (1024 x 1024 x 128 at --size 512) HydrostaticFreeSurfaceModel, VectorInvariant() momentum,
+           tracer_advection = WENO(), SplitExplicitFreeSurface(substeps = 30), T / S + linear SeawaterBuoyancy + FPlane +
+           ScalarDiffusivity, QuasiAdamsBashforth2.  A "step" is one time_step! (one tendency evaluation, 30 barotropic substeps).
+
+--gpus N > 1: the same global grid is x-slab partitioned over N ranks (strong scaling), one process per GPU, RCCL halo exchange
+and all-to-all transposes behind the C ABI (ocn_comm_*).  Run as `python bench.py --gpus N` the script starts its N ranks itself
+(torch.distributed.run as a CHILD process, before anything touches the GPU); run under torch.distributed.run it is one rank.
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,12 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-ALGO_BYTES_PER_CELL_STEP = 1680.0  # 560 + 584 + 536 B per cell per RK3 step (reference decomposition)
-TENDENCY_BYTES_PER_CELL = 48.0     # fused compute_Gu/Gv/Gw launch: read u, v, w once, write Gu, Gv, Gw (fp64)
+ALGO_BYTES_PER_CELL_STEP = 1680.0  # 560 + 584 + 536 B per cell per RK3 step (REFERENCE kernel decomposition)
+TENDENCY_BYTES_PLAIN = 48.0        # fused compute_Gu/Gv/Gw launch: read u, v, w once, write Gu, Gv, Gw (fp64)
+TENDENCY_BYTES_IN_STEP = 104.0     # as the step runs it: + p (correction on load) + G- read + U_out (3) write + ...
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
+# fp64 / VALU issue bound: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles (16 lanes per SIMD per cycle; the
+# 78.6 TFLOP/s fp64 vector peak is 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz), at the 2.4 GHz peak engine clock
+VALU_PEAK_GWAVEINSTR = 1024 * 2.4 / 4.0   # = 614.4 G wave-instructions / s
 
 
 def parse():
@@ -36,15 +46,43 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", dest="n", type=int, default=512, help="grid points per dimension (512 = the metric's config)")
     ap.add_argument("--math", choices=("fast", "strict"), default="fast")
-    ap.add_argument("--workload", choices=("box", "config4"), default="box",
-                    help="box: the metric's triply-periodic N^3 box (default); config4: BASELINE.json configs[3], the "
-                         "ocean_wind_mixing_and_convection setup on N x N x N/2 (Periodic, Periodic, Bounded) with stretched z")
+    ap.add_argument("--workload", choices=("box", "config4", "config5"), default="box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict_ms_per_step leg (3 steps of the bit-exact build)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the event-timed launches of the dominant kernel (profiling runs: every launch then belongs to a step)")
     ap.add_argument("--driver", choices=("python", "c"), default="python",
                     help="host orchestration of the step: the Python mirror of the reference's time_step!, or ocn_rk3_driver_time_step (one C call per step; box workload, one GPU)")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--substeps", type=int, default=30, help="config5: SplitExplicitFreeSurface(substeps = ...)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a child torch.distributed.run and relay rank 0's JSON line.
+    Nothing in this process has touched the GPU (no torch.cuda call, libocn_hip not loaded): the child is a plain subprocess, never an
+    exec of a GPU process."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0 or line is None:
+        raise SystemExit(p.returncode or 1)
+    raise SystemExit(0)
 
 
 def host_cores():
@@ -61,6 +99,7 @@ def host_cores():
 
 def config4_faces(Nz, Lz=32.0, refinement=1.2, stretching=12.0):
     """z_faces of examples/ocean_wind_mixing_and_convection.jl:38-62"""
+    import numpy as np
     k = np.arange(1, Nz + 2)
     h = (k - 1) / Nz
     zeta0 = 1 + (h - 1) / refinement
@@ -71,10 +110,13 @@ def config4_faces(Nz, Lz=32.0, refinement=1.2, stretching=12.0):
 # physical constants of examples/ocean_wind_mixing_and_convection.jl:79-110
 C4 = dict(JT=200.0 / (1026.0 * 3991.0), dTdz=0.01, taux=-1.225 / 1026.0 * 2.5e-3 * 10 * 10, evap=1e-3 / 3600, f=1e-4,
           alpha=2e-4, beta=8e-4)
+# config 5 (no script in the reference names it; the physics of tools/bench_hydrostatic.py): 1000 m deep, 1000 km wide ocean box
+C5 = dict(H=1000.0, L=1.0e6, f=1e-4, nu=1e-2, kappa=1e-3, alpha=2e-4, beta=8e-4, amp=1e-2)
 
 
 def cpu_baseline_config4(n, steps):
     """The CPU oracle with the same physics (AMD closure, SeawaterBuoyancy, FPlane, boundary conditions) on n x n x n/2."""
+    import numpy as np
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     from oracle import oracle as O
@@ -100,9 +142,36 @@ def cpu_baseline_config4(n, steps):
             "sample": f"{steps} RK3 steps of the same model at {n}x{n}x{Nz} (C oracle, OpenMP {cores} threads, scipy pocketfft), {el:.1f} s"}
 
 
+def cpu_baseline_config5(nx, nz, steps, substeps):
+    """oracle/hydrostatic.py (numpy + the C oracle's tendency kernels) with the same configuration on nx x nx x nz."""
+    import numpy as np
+    cores = host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from oracle import hydrostatic as Hy
+    from oracle import oracle as O
+    H, L = C5["H"], C5["L"] * nx / 1024.0  # same dx as the GPU workload
+    g = O.Grid((nx, nx, nz), x=(0, L), y=(0, L), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5",
+                                       coriolis_f=C5["f"], closure=(C5["nu"], C5["kappa"]),
+                                       buoyancy=("SeawaterBuoyancy", 9.80665, C5["alpha"], C5["beta"]), split_explicit_substeps=substeps)
+    rng = np.random.default_rng(1234)
+    zc = -H + (np.arange(nz) + 0.5) * H / nz
+    m.set(u=C5["amp"] * rng.uniform(-1, 1, (nx, nx, nz)), v=C5["amp"] * rng.uniform(-1, 1, (nx, nx, nz)),
+          T=20 + 0.01 * zc[None, None, :] + np.zeros((nx, nx, 1)), S=35.0)
+    dt = 2.0 * g.dx / np.sqrt(Hy.g_Earth * H)
+    m.time_step(dt)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.time_step(dt)
+    el = time.perf_counter() - t0
+    return {"value": nx * nx * nz * steps / el, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} QAB2 steps of the same model at {nx}x{nx}x{nz} (oracle/hydrostatic.py: numpy + C oracle kernels, {cores} OpenMP threads), {el:.1f} s"}
+
+
 def cpu_baseline(n, steps):
     """The CPU oracle (a port of the reference algorithm, OpenMP over k-planes + pocketfft) timed on the host cores
     on a bounded sample of the same workload."""
+    import numpy as np
     cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)  # before the OpenMP runtime of the oracle library is loaded
     from oracle import oracle as O
@@ -120,35 +189,70 @@ def cpu_baseline(n, steps):
             "sample": f"{steps} RK3 steps of the same model at {n}^3 (C oracle, OpenMP {cores} threads, scipy pocketfft), {el:.1f} s"}
 
 
+def latest_profile(pattern):
+    """The newest committed profile summary matching profiles/<pattern> (PMC numbers cannot be collected inside a timed run)."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True)
+    for path in paths:
+        try:
+            return os.path.relpath(path, ROOT), json.load(open(path))
+        except Exception:
+            continue
+    return None, None
+
+
+def event_time(fn, reps=10):
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
+    import numpy as np
+    import torch
     torch.cuda.set_device(local_rank)
     import oceananigans_jl_amd as ocn
     ocn._lib.lib()  # fail loudly if the HIP extension is missing
     ocn.set_math_mode(ocn.MATH_FAST if a.math == "fast" else ocn.MATH_STRICT)
 
     N = a.n
+    comm_info = None
     if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":  # the env var exercises the RCCL path on one rank
-        import torch.distributed as dist
+        if a.workload == "config5":
+            raise SystemExit("config5 is single-GPU in this round (the hydrostatic model is not slab-distributed yet)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(world))
+        arch = ocn.distributed.make_distributed(rank, world, local_rank)  # RCCL behind the C ABI (ocn_comm_*); gloo only bootstraps
+        comm_info = arch.fabric.info()
+        dist = arch.fabric
     else:
         dist = None
         arch = ocn.GPU()
     two_pi = 2 * np.pi
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
+
+    def rand(shape):
+        return torch.rand(shape, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+
+    hydro = a.workload == "config5"
     if a.workload == "config4":
-        Nz = N // 2
+        Nx, Nz = N, N // 2
         zf = config4_faces(Nz)
         grid = ocn.RectilinearGrid(arch, size=(N, N, Nz), x=(0, 64), y=(0, 64), z=zf,
                                    topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
@@ -164,90 +268,190 @@ def main():
         T.copy_(20 + C4["dTdz"] * zc[:, None, None] + 1e-6 * torch.rand(T.shape, generator=gen, device="cuda", dtype=torch.float64))
         model.field("S").interior_view().fill_(35.0)
         amp, dmin = 1e-2, float(np.diff(zf).min())
+    elif hydro:
+        Nx, Nz = 2 * N, N // 4
+        H, L = C5["H"], C5["L"] * Nx / 1024.0
+        grid = ocn.RectilinearGrid(arch, size=(Nx, Nx, Nz), x=(0, L), y=(0, L), z=(-H, 0.0), topology=("Periodic", "Periodic", "Bounded"),
+                                   halo=(3, 3, 3))
+        model = ocn.HydrostaticFreeSurfaceModel(grid, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
+                                                free_surface=ocn.SplitExplicitFreeSurface(substeps=a.substeps), coriolis=ocn.FPlane(f=C5["f"]),
+                                                closure=ocn.ScalarDiffusivity(ν=C5["nu"], κ=C5["kappa"]),
+                                                buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(C5["alpha"], C5["beta"])))
+        zc = torch.linspace(-H + H / (2 * Nz), -H / (2 * Nz), Nz, device="cuda", dtype=torch.float64)
+        model.field("T").interior_view().copy_((20 + 0.01 * zc)[:, None, None].expand(Nz, Nx, Nx))
+        model.field("S").interior_view().fill_(35.0)
+        amp = C5["amp"]
     else:
-        Nz = N
+        Nx, Nz = N, N
         grid = ocn.RectilinearGrid(arch, size=(N, N, N), x=(0, two_pi), y=(0, two_pi), z=(0, two_pi),
                                    topology=("Periodic", "Periodic", "Periodic"), halo=(3, 3, 3))
         model = ocn.NonhydrostaticModel(grid, advection=ocn.WENO())
         amp, dmin = 1.0, grid.dx
 
     # synthetic initial condition generated on the device (fixed seed per rank)
-    for f in model.velocities:
-        iv = f.interior_view()
-        iv.copy_(amp * (torch.rand(iv.shape, generator=gen, device=iv.device, dtype=torch.float64) * 2 - 1))
-    ocn.set(model)  # halo fills + the dt = 1 projection of set!
-    umax = torch.stack([f.interior_view().abs().max() for f in model.velocities]).max()
-    if dist is not None:
-        dist.all_reduce(umax, op=dist.ReduceOp.MAX)
-    dt = 0.1 * min(grid.dx, dmin) / float(umax)
+    if hydro:
+        for f in (model.u, model.v):
+            f.interior_view().copy_(amp * rand(f.interior_view().shape))
+        model.update_state(compute_tendencies=False)
+        dt = 2.0 * grid.dx / np.sqrt(9.80665 * C5["H"])      # baroclinic gravity-wave CFL 2, barotropic 2 x 2 / 30
+        step, flush = (lambda: model.time_step(dt)), model.flush_tendencies
+        prognostic = [model.u, model.v] + list(model.tracers)
+    else:
+        for f in model.velocities:
+            f.interior_view().copy_(amp * rand(f.interior_view().shape))
+        ocn.set(model)  # halo fills + the dt = 1 projection of set!
+        umax = torch.stack([f.interior_view().abs().max() for f in model.velocities]).max()
+        if dist is not None:
+            umax = dist.allreduce_max(umax.reshape(1))[0]
+        dt = 0.1 * min(grid.dx, dmin) / float(umax)
+        prognostic = model.prognostic_fields()
+        if a.driver == "c":
+            if world > 1 or a.workload != "box":
+                raise SystemExit("--driver c: box workload on one GPU")
+            drv = ocn.RK3Driver(model)
+            step, flush = (lambda: drv.time_step(dt)), drv.flush
+        else:
+            step, flush = (lambda: ocn.time_step(model, dt)), (lambda: ocn.flush_tendencies(model))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.driver == "c":
-        if world > 1 or a.workload != "box":
-            raise SystemExit("--driver c: box workload on one GPU")
-        drv = ocn.RK3Driver(model)
-        step, flush = (lambda: drv.time_step(dt)), drv.flush
-    else:
-        step, flush = (lambda: ocn.time_step(model, dt)), (lambda: ocn.flush_tendencies(model))
+    def timed(nsteps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        flush()  # the deferred last compute_tendencies! belongs to the timed steps
+        barrier()
+        return time.perf_counter() - t0
+
     for _ in range(a.warmup):
         step()
     flush()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    flush()  # the deferred last compute_tendencies! belongs to the timed steps
-    barrier()
-    el = time.perf_counter() - t0
+    el = timed(a.steps)
     if dist is not None:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t)
-    finite = bool(all(torch.isfinite(f.data).all() for f in model.prognostic_fields()))
+        el = float(dist.allreduce_max(torch.tensor([el], device="cuda", dtype=torch.float64))[0])
+    finite = bool(all(torch.isfinite(f.data).all() for f in prognostic))
 
-    # dominant kernel: the fused WENO5 momentum-tendency launch, timed live with events on the launching stream
+    # the bit-exact (strict IEEE, reference operand order) build of the same step, driver-visible
+    strict_ms = None
+    if a.math == "fast" and not a.no_strict and a.driver == "python":
+        ocn.set_math_mode(ocn.MATH_STRICT)
+        step()
+        flush()
+        strict_ms = timed(3) / 3 * 1e3
+        if dist is not None:
+            strict_ms = float(dist.allreduce_max(torch.tensor([strict_ms], device="cuda", dtype=torch.float64))[0])
+        ocn.set_math_mode(ocn.MATH_FAST)
+
     local_cells = grid.Nx * grid.Ny * grid.Nz
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    Gn = model.timestepper.Gn  # (completes a deferred tendency launch)
+    cells = Nx * (Nx if hydro else N) * Nz
+    value = cells * a.steps / el
+    roofline, step_roofline = None, None
+    if a.no_kernel_timing:
+        pass
+    elif not hydro:
+        # dominant kernel: the fused WENO5 momentum-tendency launch, timed live with events on the launching stream, (a) plain
+        # (compute_Gu!/Gv!/Gw! alone) and (b) as the step runs it on one rank (correction on load + next substep as epilogue)
+        Gn = model.timestepper.Gn  # (completes a deferred tendency launch)
 
-    def weno_launch():  # compute_Gu!/Gv!/Gw! of the advection term alone: the fused WENO5 kernel
-        ocn._lib.call("ocn_compute_momentum_tendencies", grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
-                      Gn[2].ptr, None, 0)
+        def plain():
+            ocn._lib.call("ocn_compute_momentum_tendencies", grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                          Gn[2].ptr, None, 0)
 
-    weno_launch()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        weno_launch()
-    e1.record()
-    torch.cuda.synchronize()
-    kern_ms = e0.elapsed_time(e1) / reps
-    achieved = TENDENCY_BYTES_PER_CELL * local_cells / (kern_ms * 1e-3) / 1e9
+        plain_ms = event_time(plain)
+        in_step_ms, in_step_bytes = None, None
+        if a.workload == "box" and world == 1 and getattr(model, "correct_on_load", False):
+            Gm = model.timestepper._Gm
+            alt = [torch.zeros_like(f.data) for f in model.velocities]
 
-    # HBM traffic of that kernel from the committed PMC profile of this workload (separate rocprofv3 --pmc passes,
-    # calibrated as MI355X_MICROARCH.md prescribes; tools/profile_gpu.sh + tools/summarize_profile.py), per launch
-    traffic = None
-    try:
-        import glob
-        for path in (sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{N}.json")), reverse=True) if a.workload == "box" else []):
-            prof = json.load(open(path))
-            k = [k for k in prof["kernels"] if "momentum_tendencies" in k["name"] and "traffic_bytes" in k]
-            if k and world == 1:
-                traffic = k[0]["traffic_bytes"]
-                break
-    except Exception:
-        traffic = None
+            def in_step():
+                ocn._lib.call("ocn_compute_momentum_tendencies_rk3", grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
+                              Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
+                              float(dt), 5.0 / 12.0, -17.0 / 60.0, 1, model.pNHS.ptr, float(dt) * 8 / 15, None, 0)
 
-    value = N * N * Nz * a.steps / el
+            in_step_ms, in_step_bytes = event_time(in_step), TENDENCY_BYTES_IN_STEP
+            del alt
+        prof_path, prof = latest_profile(f"r*_{N}.json") if a.workload == "box" else latest_profile("r*_config4.json")
+        kern = {}
+        if prof is not None and world == 1:
+            for k in prof["kernels"]:
+                if "momentum_tendencies_tiled" in k["name"]:
+                    kern["in_step" if k["name"].rstrip(">").endswith("true") else "plain"] = k
+        pk = kern.get("in_step") or kern.get("plain") or {}
+        ref_ms = in_step_ms if in_step_ms is not None else plain_ms
+        instr = pk.get("SQ_INSTS_VALU")  # VALU wave-instructions per launch of the profiled variant (committed PMC pass)
+        achieved = None if instr is None else instr * (local_cells / prof.get("cells", local_cells)) / (ref_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "valu_fp64", "kernel": "momentum_tendencies_tiled (fused compute_Gu/Gv/Gw, WENO5)",
+            "achieved": achieved, "peak": VALU_PEAK_GWAVEINSTR, "unit": "G wave-instr/s",
+            "frac": None if achieved is None else achieved / VALU_PEAK_GWAVEINSTR,
+            "traffic": pk.get("traffic_bytes"),
+            "kernel_ms": ref_ms, "variant": "in-step (correction on load + substep epilogue)" if in_step_ms is not None else "plain",
+            "valu_wave_instr_per_launch": instr, "valu_busy_frac_pmc": pk.get("valu_busy"),
+            "hbm": {"in_step": None if in_step_ms is None else {
+                        "algorithmic_bytes_per_cell": in_step_bytes, "kernel_ms": in_step_ms,
+                        "achieved_GBps": in_step_bytes * local_cells / (in_step_ms * 1e-3) / 1e9,
+                        "frac": in_step_bytes * local_cells / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "measured_bytes_per_cell": kern.get("in_step", {}).get("traffic_bytes_per_cell")},
+                    "plain": {"algorithmic_bytes_per_cell": TENDENCY_BYTES_PLAIN, "kernel_ms": plain_ms,
+                              "achieved_GBps": TENDENCY_BYTES_PLAIN * local_cells / (plain_ms * 1e-3) / 1e9,
+                              "frac": TENDENCY_BYTES_PLAIN * local_cells / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                              "measured_bytes_per_cell": kern.get("plain", {}).get("traffic_bytes_per_cell")},
+                    "peak_GBps": HBM_PEAK_GBPS},
+            "pmc_source": prof_path,
+            "note": "the kernel is bound by fp64 VALU issue, not HBM: `achieved` = VALU wave-instructions per launch (SQ_INSTS_VALU of the "
+                    "committed rocprofv3 --pmc pass named in pmc_source) / the launch time measured live here; peak = 1024 SIMDs x 2.4 GHz "
+                    "/ 4 cycles per wave64 instruction.  `hbm` gives the same launches against the 8 TB/s HBM roofline."}
+        if a.workload == "box":
+            measured = None if prof is None else prof.get("step_bytes_per_cell")
+            step_roofline = {
+                "measured_bytes_per_cell_step": measured,  # sum over the step's launches of FETCH_SIZE + WRITE_SIZE (committed PMC passes)
+                "measured_GBps": None if measured is None else measured * value / 1e9,
+                "frac_of_8TBps": None if measured is None else measured * value / 1e9 / (HBM_PEAK_GBPS * world),
+                "reference_decomposition_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
+                "reference_equivalent_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,  # what the REFERENCE's launch sequence would have to move at this step rate; not HBM traffic of this backend
+                "pmc_source": prof_path}
+    else:
+        # config 5: dominant kernel = the WENO tracer launch (tendency + diffusion + AB2 step), timed live; 56 B per cell:
+        # read c, u, v, w, G-; write G, c_out
+        nh = model._nh
+        Gn, Gm = nh.timestepper._Gn, nh.timestepper._Gm
+        alt = torch.zeros_like(model.tracers[0].data)
+        import ctypes as C
+
+        def tracer_launch():
+            ocn._lib.call("ocn_compute_tracer_tendency_terms_rk3", grid.cref, C.byref(nh._terms), C5["kappa"], None, None, model.u.ptr, model.v.ptr,
+                          model.w.ptr, model.tracers[0].ptr, Gn[3].ptr, Gm[3].ptr, alt.data_ptr(), float(dt), 1.6, -0.6, 1, None, 0)
+
+        k_ms = event_time(tracer_launch)
+        prof_path, prof = latest_profile("r*_config5.json")
+        pk = {}
+        if prof is not None:
+            for k in prof["kernels"]:
+                if "tracer_tendency_tiled" in k["name"]:
+                    pk = k
+        bytes_cell = 56.0
+        ach = bytes_cell * local_cells / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "tracer_tendency_tiled (WENO5 div_Uc + diffusion + AB2 step of one tracer)", "achieved": ach,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": pk.get("traffic_bytes"),
+                    "kernel_ms": k_ms, "algorithmic_bytes_per_cell": bytes_cell, "launches_per_step": 2,
+                    "valu_busy_frac_pmc": pk.get("valu_busy"), "pmc_source": prof_path}
+        measured = None if prof is None else prof.get("step_bytes_per_cell")
+        step_roofline = {"algorithmic_bytes_per_cell_step": 256.0,  # momentum pass 80 + 2 tracers x 56 + corrector/w 40 + pHY 24
+                         "achieved_GBps": 256.0 * value / 1e9, "frac_of_8TBps": 256.0 * value / 1e9 / HBM_PEAK_GBPS,
+                         "measured_bytes_per_cell_step": measured,
+                         "measured_GBps": None if measured is None else measured * value / 1e9, "pmc_source": prof_path}
+
     if a.workload == "config4":
         workload = (f"{N}x{N}x{Nz} (Periodic, Periodic, Bounded) stretched z, ocean_wind_mixing_and_convection setup "
                     "(WENO5, AnisotropicMinimumDissipation, SeawaterBuoyancy, FPlane, flux/gradient BCs, T and S), RK3, "
                     "FourierTridiagonalPoissonSolver, fp64")
+    elif hydro:
+        workload = (f"{Nx}x{Nx}x{Nz} (Periodic, Periodic, Bounded) HydrostaticFreeSurfaceModel, VectorInvariant momentum, WENO5 tracer advection "
+                    f"(T, S), SplitExplicitFreeSurface(substeps={a.substeps}), linear SeawaterBuoyancy, FPlane, ScalarDiffusivity, QAB2, fp64")
     else:
         workload = f"{N}^3 triply-periodic NonhydrostaticModel, WENO5, RK3, FFTBasedPoissonSolver, fp64"
     out = {
@@ -255,31 +459,26 @@ def main():
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": workload,
-                   "grid": [N, N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}", "finite": finite},
-        "roofline": {"bound": "hbm", "kernel": "momentum_tendencies (fused compute_Gu/Gv/Gw, WENO5)",
-                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_cell": TENDENCY_BYTES_PER_CELL,
-                     # SURVEY 8(d) books the reference's three tendency kernels at 3 x (3 r + 1 w) x 8 = 96 B/cell; against that
-                     # accounting (the one step_roofline's 1680 B uses) the same launch reaches:
-                     "frac_at_reference_accounting_96B": 96.0 * local_cells / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "note": "fp64-VALU-bound kernel (~690 fp64 VALU of ~1190 instructions per cell, 77% VALU issue utilisation): see DESIGN.md section 4"},
-        "step_roofline": {"algorithmic_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
-                          "achieved_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,
-                          "frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world)},
+        "config": {"workload": workload, "grid": [Nx, Nx if hydro else N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}",
+                   "finite": finite, "rccl": comm_info},
+        "strict_ms_per_step": strict_ms,
+        "roofline": roofline,
+        "step_roofline": step_roofline,
     }
-    if a.workload == "config4":
-        out["step_roofline"] = None  # SURVEY 8(d)'s 1680 B/cell/step is the accounting of the advection-only periodic box
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = (cpu_baseline(a.cpu_n, a.cpu_steps) if a.workload == "box"
-                                   else cpu_baseline_config4(min(a.cpu_n, 128), a.cpu_steps))
+            if a.workload == "box":
+                out["cpu_baseline"] = cpu_baseline(a.cpu_n, a.cpu_steps)
+            elif hydro:
+                out["cpu_baseline"] = cpu_baseline_config5(256, 32, 12, a.substeps)
+            else:
+                out["cpu_baseline"] = cpu_baseline_config4(min(a.cpu_n, 128), a.cpu_steps)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":

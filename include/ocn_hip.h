@@ -42,6 +42,7 @@ extern "C" {
 #define OCN_ERR_HIP (-3)
 #define OCN_ERR_ROCFFT (-4)
 #define OCN_ERR_ALLOC (-5)
+#define OCN_ERR_COMM (-6) /* an RCCL call failed */
 
 /* topology codes: src/Grids/Grids.jl Periodic / Bounded / Flat */
 #define OCN_PERIODIC 0
@@ -455,6 +456,37 @@ int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, con
 int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver, void *stream);
 int ocn_dist_poisson_solve_x(ocn_dist_poisson_t solver, void *stream); /* FFT_x, divide by eigenvalues, IFFT_x */
 int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *p, void *stream);
+
+/* ---- Collectives of the slab-x decomposition: RCCL (librccl, linked directly) over xGMI, one communicator per process / GPU.
+ *      Replaces the MPI.jl calls of src/DistributedComputations/: Distributed(...) set-up (distributed_architectures.jl:167-297),
+ *      fill_halo_event! / synchronize_communication! west-east (halo_communication.jl:210-229, 267-366; distributed_fields.jl:58-75;
+ *      staging buffers Fields/field_boundary_buffers.jl:276-308), Alltoallv! of the transposes (distributed_transpose.jl:185-191),
+ *      Allreduce of scalars (Simulations/simulation.jl:128-134).  A Julia host therefore needs no MPI.jl in the time-stepping
+ *      loop: only the 128-byte unique id has to reach every rank once (any channel: a file, a socket, MPI.bcast).
+ *      Ordering: exchanges run on the communicator's own stream and are ordered against the caller's `stream` with events;
+ *      no call blocks the host except ocn_comm_barrier. ---- */
+typedef void *ocn_comm_t;
+#define OCN_COMM_UNIQUE_ID_BYTES 128
+int ocn_comm_unique_id(void *id_out);                       /* rank 0: ncclGetUniqueId -> 128 bytes for every rank */
+int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *unique_id); /* on the current device; collective */
+int ocn_comm_destroy(ocn_comm_t comm);
+/* rank, the number of ranks RCCL itself reports (ncclCommCount), RCCL version code */
+int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);
+/* fill_halo_event!(...; async = true) in x for a tuple of fields (local y / z fills first, fill_halo_regions.jl:148-196): packs the
+ * 2 x Hx-wide full-cross-section strips of all fields (corners travel with the sides, OneDBuffers) on `stream` and starts one
+ * grouped send / recv per neighbour (rank -+ 1, wrapping) on the communication stream.  `stream` stays free for the interior
+ * tendency launch (interleave_communication_and_computation.jl:29-67). */
+int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
+/* synchronize_communication!: `stream` waits for the exchange (event) and unpacks the received strips into the x halos. */
+int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
+/* one x plane from a neighbour, in stream order (side 0: field[nx+1] <- east neighbour's field[1]; 1: field[0] <- west's field[nx]) */
+int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field, int32_t loc, int32_t side, void *stream);
+/* Alltoallv! with equal counts: chunk d of `send` (count doubles) goes to rank d, chunk s of `recv` comes from rank s; stream order */
+int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream);
+/* transpose_y_to_x! (direction 0) / transpose_x_to_y! (direction 1) of a distributed Poisson handle's exchange buffers */
+int ocn_dist_poisson_exchange(ocn_dist_poisson_t solver, ocn_comm_t comm, int32_t direction, void *stream);
+int ocn_comm_allreduce(ocn_comm_t comm, double *buffer, size_t count, int32_t op /* 0 sum, 1 max, 2 min */, void *stream);
+int ocn_comm_barrier(ocn_comm_t comm);                      /* MPI.Barrier; blocks the host */
 
 #ifdef __cplusplus
 }

@@ -134,6 +134,17 @@ _SIGS = {
     "ocn_dist_poisson_forward_yz": [_vp, _vp],
     "ocn_dist_poisson_solve_x": [_vp, _vp],
     "ocn_dist_poisson_backward_yz": [_vp, _vp, _vp],
+    "ocn_comm_unique_id": [_vp],
+    "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
+    "ocn_comm_destroy": [_vp],
+    "ocn_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
+    "ocn_halo_exchange_begin": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],
+    "ocn_halo_exchange_end": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],
+    "ocn_halo_exchange_plane": [_vp, C.POINTER(CGrid), _vp, _i32, _i32, _vp],
+    "ocn_comm_all_to_all": [_vp, _vp, _vp, C.c_size_t, _vp],
+    "ocn_dist_poisson_exchange": [_vp, _vp, _i32, _vp],
+    "ocn_comm_allreduce": [_vp, _vp, C.c_size_t, _i32, _vp],
+    "ocn_comm_barrier": [_vp],
 }
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ["ocn_last_error", "ocn_version", "ocn_get_math_mode"])
 

@@ -1,0 +1,320 @@
+// comm.hip -- the collectives of the slab-x decomposition behind the C ABI: RCCL (librccl, linked directly) over xGMI.
+//
+// What it replaces in the reference (all MPI.jl, src/DistributedComputations/):
+//   * Distributed(...) communicator set-up                      distributed_architectures.jl:167-297
+//   * fill_halo_event! west / east: pack -> Isend / Irecv! -> (async) -> Waitall -> unpack
+//                                                               halo_communication.jl:210-229, 267-366, distributed_fields.jl:58-75,
+//                                                               Fields/field_boundary_buffers.jl:276-308
+//   * transpose_y_to_x! / transpose_x_to_y!: Alltoallv! with equal counts       distributed_transpose.jl:185-191
+//   * MPI.Allreduce of scalars (Δt, max|u|)                      Simulations/simulation.jl:128-134
+//
+// MI355X shape: one process per GPU and one RCCL communicator per process.  Every exchange is a grouped ncclSend / ncclRecv on the
+// communicator's OWN non-blocking stream, ordered against the caller's compute stream by two events (ready: the packed buffers
+// are complete; done: the received buffers are complete) -- there is no host synchronisation anywhere (the reference calls
+// sync_device! before every post and Waitall after).  Between *_begin and *_end the caller's stream is free to run the interior
+// tendency kernels (interleave_communication_and_computation.jl:29-67).  The all-to-all of the slab transposes runs on the caller's
+// stream: it sits on the critical path of the pressure solve.  xGMI is point to point, so the R-1 peers of an all-to-all and the 2
+// neighbours of a halo exchange each use their own link; nothing here is a ring.
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "ocn_internal.h"
+
+using namespace ocn;
+
+#define OCN_CHECK_NCCL(call)                                                               \
+    do {                                                                                   \
+        ncclResult_t r_ = (call);                                                          \
+        if (r_ != ncclSuccess) {                                                           \
+            ocn::set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+            return OCN_ERR_COMM;                                                           \
+        }                                                                                  \
+    } while (0)
+
+namespace {
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, west = 0, east = 0;
+    hipStream_t stream = nullptr;            // communication stream
+    hipEvent_t ready = nullptr, done = nullptr;
+    double *buf[4] = {nullptr, nullptr, nullptr, nullptr};  // send west, send east, recv west, recv east
+    size_t cap = 0;                          // doubles per buffer
+    double *plane[2] = {nullptr, nullptr};   // one-plane exchange: send, recv
+    size_t plane_cap = 0;
+    bool pending = false;
+    size_t pending_count = 0;
+};
+
+int ensure(Comm *c, size_t n)
+{
+    if (n <= c->cap) return OCN_SUCCESS;
+    for (double *&b : c->buf) {
+        if (b) OCN_CHECK_HIP(hipFree(b));
+        b = nullptr;
+        OCN_CHECK_HIP(hipMalloc(&b, n * sizeof(double)));
+    }
+    c->cap = n;
+    return OCN_SUCCESS;
+}
+
+// the strips of all fields follow one another: doubles per side
+size_t strip_doubles(const ocn_grid *grid, const int32_t *locs, int n)
+{
+    GridDev g = to_dev(*grid);
+    size_t tot = 0;
+    for (int q = 0; q < n; ++q) {
+        Lay L = make_lay(g, locs[q]);
+        tot += (size_t)g.Hx * L.sy * L.sz;
+    }
+    return tot;
+}
+
+int make_tuple(const ocn_grid *grid, double *const *fields, const int32_t *locs, int n, FieldTuple &ft)
+{
+    OCN_REQUIRE(fields && locs && n >= 1 && n <= MAX_TUPLE, "halo exchange: 1..%d fields", MAX_TUPLE);
+    ft.n = n;
+    for (int q = 0; q < n; ++q) {
+        OCN_REQUIRE(fields[q], "halo exchange: null field pointer");
+        ft.f[q] = fields[q];
+        ft.loc[q] = locs[q];
+    }
+    (void)grid;
+    return OCN_SUCCESS;
+}
+
+// grouped exchange with the two x neighbours on the communication stream.  My west strip becomes the west neighbour's east halo
+// and vice versa.  When both neighbours are the same peer (R = 2) or myself (R = 1) the receives are posted in the order
+// (from east, from west) so that they pair up with that peer's (west, east) sends.
+int post_exchange(Comm *c, const double *sw, const double *se, double *rw, double *re, size_t count)
+{
+    OCN_CHECK_NCCL(ncclGroupStart());
+    OCN_CHECK_NCCL(ncclSend(sw, count, ncclDouble, c->west, c->comm, c->stream));
+    OCN_CHECK_NCCL(ncclSend(se, count, ncclDouble, c->east, c->comm, c->stream));
+    if (c->nranks > 2) {
+        OCN_CHECK_NCCL(ncclRecv(rw, count, ncclDouble, c->west, c->comm, c->stream));
+        OCN_CHECK_NCCL(ncclRecv(re, count, ncclDouble, c->east, c->comm, c->stream));
+    } else {
+        OCN_CHECK_NCCL(ncclRecv(re, count, ncclDouble, c->east, c->comm, c->stream));
+        OCN_CHECK_NCCL(ncclRecv(rw, count, ncclDouble, c->west, c->comm, c->stream));
+    }
+    OCN_CHECK_NCCL(ncclGroupEnd());
+    return OCN_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocn_comm_unique_id(void *id_out)
+{
+    OCN_REQUIRE(id_out, "ocn_comm_unique_id: null pointer");
+    ncclUniqueId id;
+    OCN_CHECK_NCCL(ncclGetUniqueId(&id));
+    static_assert(sizeof(id) == OCN_COMM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return OCN_SUCCESS;
+}
+
+int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *unique_id)
+{
+    OCN_REQUIRE(comm && unique_id, "ocn_comm_init: null pointer");
+    OCN_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "ocn_comm_init: rank %d of %d", rank, nranks);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    Comm *c = new Comm();
+    c->rank = rank;
+    c->nranks = nranks;
+    c->west = (rank + nranks - 1) % nranks;  // neighbours wrap around (distributed_architectures.jl:386-429)
+    c->east = (rank + 1) % nranks;
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);  // on the current device (ocn_set_device / hipSetDevice first)
+    if (r != ncclSuccess) {
+        ocn::set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, ncclGetErrorString(r));
+        delete c;
+        return OCN_ERR_COMM;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        ocn::set_error("ocn_comm_init: stream / event creation failed");
+        ncclCommDestroy(c->comm);
+        delete c;
+        return OCN_ERR_HIP;
+    }
+    *comm = c;
+    return OCN_SUCCESS;
+}
+
+int ocn_comm_destroy(ocn_comm_t comm)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) return OCN_SUCCESS;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (double *b : c->buf)
+        if (b) (void)hipFree(b);
+    for (double *b : c->plane)
+        if (b) (void)hipFree(b);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    delete c;
+    return OCN_SUCCESS;
+}
+
+int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_comm_info: null communicator");
+    int count = 0, ver = 0;
+    OCN_CHECK_NCCL(ncclCommCount(c->comm, &count));  // the number of ranks RCCL itself sees
+    OCN_CHECK_NCCL(ncclGetVersion(&ver));
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = count;
+    if (rccl_version) *rccl_version = ver;
+    return OCN_SUCCESS;
+}
+
+// fill_halo_event!(...; async = true) for the x direction of a field tuple: pack on `stream`, exchange on the communication stream.
+int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_halo_exchange_begin: null communicator");
+    OCN_REQUIRE(!c->pending, "ocn_halo_exchange_begin: an exchange is already in flight (call ocn_halo_exchange_end first)");
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    FieldTuple ft;
+    st = make_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    const size_t count = strip_doubles(grid, locs, n);
+    st = ensure(c, count);
+    if (st != OCN_SUCCESS) return st;
+    hipStream_t s = as_stream(stream);
+    st = launch_halo_pack_x_fields(grid, ft, c->buf[0], c->buf[1], 0, s);
+    if (st != OCN_SUCCESS) return st;
+    OCN_CHECK_HIP(hipEventRecord(c->ready, s));
+    OCN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    st = post_exchange(c, c->buf[0], c->buf[1], c->buf[2], c->buf[3], count);
+    if (st != OCN_SUCCESS) return st;
+    OCN_CHECK_HIP(hipEventRecord(c->done, c->stream));
+    c->pending = true;
+    c->pending_count = count;
+    return OCN_SUCCESS;
+}
+
+// synchronize_communication! (distributed_fields.jl:58-75): `stream` waits for the exchange (an event, not the host) and unpacks.
+int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_halo_exchange_end: null communicator");
+    OCN_REQUIRE(c->pending, "ocn_halo_exchange_end: no exchange in flight");
+    FieldTuple ft;
+    int st = make_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(strip_doubles(grid, locs, n) == c->pending_count, "ocn_halo_exchange_end: not the tuple the exchange was started with");
+    hipStream_t s = as_stream(stream);
+    OCN_CHECK_HIP(hipStreamWaitEvent(s, c->done, 0));
+    c->pending = false;
+    return launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], 1, s);
+}
+
+// ONE x-plane of `field` from a neighbour (the two synchronous fills inside the pressure projection, pressure_correction.jl:10-17,
+// whose fields get their complete exchange in the following update_state!): side 0 ("east"): field[nx+1] <- east neighbour's
+// field[1]; side 1 ("west"): field[0] <- west neighbour's field[nx].  In stream order on `stream`.
+int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field, int32_t loc, int32_t side, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && field, "ocn_halo_exchange_plane: null pointer");
+    OCN_REQUIRE(!c->pending, "ocn_halo_exchange_plane: a strip exchange is in flight");
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    GridDev g = to_dev(*grid);
+    Lay L = make_lay(g, loc);
+    const size_t count = (size_t)L.sy * L.sz;
+    if (count > c->plane_cap) {
+        for (double *&b : c->plane) {
+            if (b) OCN_CHECK_HIP(hipFree(b));
+            b = nullptr;
+            OCN_CHECK_HIP(hipMalloc(&b, count * sizeof(double)));
+        }
+        c->plane_cap = count;
+    }
+    hipStream_t s = as_stream(stream);
+    const bool east = side == 0;
+    // the plane I need from the east is my east neighbour's WEST interior plane, and vice versa
+    st = launch_halo_plane_x(grid, field, loc, east ? 0 : 1, c->plane[0], 0, s);
+    if (st != OCN_SUCCESS) return st;
+    OCN_CHECK_NCCL(ncclGroupStart());
+    OCN_CHECK_NCCL(ncclSend(c->plane[0], count, ncclDouble, east ? c->west : c->east, c->comm, s));
+    OCN_CHECK_NCCL(ncclRecv(c->plane[1], count, ncclDouble, east ? c->east : c->west, c->comm, s));
+    OCN_CHECK_NCCL(ncclGroupEnd());
+    return launch_halo_plane_x(grid, field, loc, east ? 1 : 0, c->plane[1], 1, s);
+}
+
+// Alltoallv! with equal counts (distributed_transpose.jl:188; transposable_field.jl:94-98): chunk d of `send` goes to rank d, chunk
+// s of `recv` comes from rank s; `count` doubles per peer.  In stream order on `stream`.
+int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && send && recv, "ocn_comm_all_to_all: null pointer");
+    OCN_REQUIRE(send != recv, "ocn_comm_all_to_all: in-place exchange is not supported");
+    hipStream_t s = as_stream(stream);
+    OCN_CHECK_NCCL(ncclGroupStart());
+    for (int d = 0; d < c->nranks; ++d) {
+        OCN_CHECK_NCCL(ncclSend(send + (size_t)d * count, count, ncclDouble, d, c->comm, s));
+        OCN_CHECK_NCCL(ncclRecv(recv + (size_t)d * count, count, ncclDouble, d, c->comm, s));
+    }
+    OCN_CHECK_NCCL(ncclGroupEnd());
+    return OCN_SUCCESS;
+}
+
+// the transposes of a distributed Poisson handle: direction 0 = y-local -> x-local (send -> recv), 1 = back
+int ocn_dist_poisson_exchange(ocn_dist_poisson_t handle, ocn_comm_t comm, int32_t direction, void *stream)
+{
+    double *yf, *xf, *snd, *rcv;
+    int st = ocn_dist_poisson_buffers(handle, &yf, &xf, &snd, &rcv);
+    if (st != OCN_SUCCESS) return st;
+    int32_t nyt, r2c, fast;
+    int64_t nel;
+    st = ocn_dist_poisson_layout(handle, &nyt, &nel, &r2c);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_pipeline(handle, &fast);
+    if (st != OCN_SUCCESS) return st;
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_dist_poisson_exchange: null communicator");
+    const size_t per_peer = (size_t)nel * 2 / c->nranks;  // complex elements -> doubles, equal chunks
+    OCN_REQUIRE((size_t)nel * 2 % c->nranks == 0, "ocn_dist_poisson_exchange: buffer not divisible by the number of ranks");
+    // the slab pipelines alternate the roles of the two buffers (csrc/colfft.hip): forward send -> recv; backward recv -> send for the
+    // periodic flavour (1) whose x pass works in place in recv, send -> recv again for the transposing paths (0) and the tridiagonal
+    // flavour (2), which leave their result in send
+    const bool swap = direction == 1 && fast == 1;
+    const double *src = swap ? rcv : snd;
+    double *dst = swap ? snd : rcv;
+    return ocn_comm_all_to_all(comm, src, dst, per_peer, stream);
+}
+
+int ocn_comm_allreduce(ocn_comm_t comm, double *buf, size_t count, int32_t op, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && buf, "ocn_comm_allreduce: null pointer");
+    OCN_REQUIRE(op >= 0 && op <= 2, "ocn_comm_allreduce: op 0 = sum, 1 = max, 2 = min");
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    OCN_CHECK_NCCL(ncclAllReduce(buf, buf, count, ncclDouble, ops[op], c->comm, as_stream(stream)));
+    return OCN_SUCCESS;
+}
+
+// MPI.Barrier: a one-element all-reduce on the communication stream, then wait for it on the host
+int ocn_comm_barrier(ocn_comm_t comm)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_comm_barrier: null communicator");
+    int st = ensure(c, 1);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(!c->pending, "ocn_comm_barrier: a halo exchange is in flight");
+    OCN_CHECK_NCCL(ncclAllReduce(c->buf[0], c->buf[0], 1, ncclDouble, ncclSum, c->comm, c->stream));
+    OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return OCN_SUCCESS;
+}
+
+}  // extern "C"

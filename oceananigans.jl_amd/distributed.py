@@ -8,12 +8,14 @@
   DistributedFFTBasedPoissonSolver                            distributed_fft_based_poisson_solver.jl:10-188
   transposes + all-to-all                                     distributed_transpose.jl:25-191, transposable_field.jl:4-104
 
-MI355X design: one process per GPU; the data path is RCCL over xGMI through torch.distributed
-(backend "nccl" is RCCL on ROCm).  Halo exchange = one batched send/recv pair per neighbour for the whole
-field tuple (6.4 MB per field-side at 512^3/8) issued asynchronously and overlapped with the interior tendency
-kernel; transposes = one all_to_all_single of equal 33.5 MB chunks (one xGMI link per peer at R = 8).
-The `fabric` (who talks to whom) and the `ops` (pack / unpack / transform kernels) are separate objects so the
-choreography can be exercised on CPU ranks (gloo) in tests; the product ops are the HIP kernels of libocn_hip.
+MI355X design: one process per GPU; the data path is RCCL over xGMI BEHIND THE C ABI (csrc/comm.hip: ocn_comm_init,
+ocn_halo_exchange_begin / _end, ocn_halo_exchange_plane, ocn_dist_poisson_exchange; `RcclFabric` below binds them through
+ctypes like every other entry point).  Halo exchange = one grouped send/recv pair per neighbour for the whole field tuple
+(6.4 MB per field-side at 512^3/8) on the communicator's own stream, ordered by events and overlapped with the interior
+tendency kernel; transposes = one grouped all-to-all of equal 33.5 MB chunks (one xGMI link per peer at R = 8).
+torch.distributed is used only (a) with the gloo backend to hand the 128-byte RCCL unique id to every rank and for host
+barriers, and (b) as `TorchDistributedFabric` so that the same choreography can be exercised on CPU ranks (gloo) in tests with
+injected CPU `ops`; the product ops are the HIP kernels of libocn_hip.
 """
 import ctypes as C
 
@@ -73,6 +75,88 @@ class TorchDistributedFabric:
         return t
 
 
+class RcclFabric:
+    """The product transport: an RCCL communicator owned by libocn_hip (include/ocn_hip.h, ocn_comm_*).  `bootstrap(obj)` must
+    broadcast a bytes object from rank 0 to every rank (make_distributed uses a gloo process group; a Julia host would use any
+    channel it likes)."""
+
+    def __init__(self, rank, size, bootstrap):
+        self.rank, self.size = int(rank), int(size)
+        uid = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.call("ocn_comm_unique_id", uid)
+        raw = bootstrap(bytes(uid))
+        uid = (C.c_ubyte * 128)(*raw)
+        self._h = C.c_void_p()
+        _lib.call("ocn_comm_init", C.byref(self._h), self.rank, self.size, uid)
+        self._scratch = None
+
+    def info(self):
+        r, n, v = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.call("ocn_comm_info", self._h, C.byref(r), C.byref(n), C.byref(v))
+        return {"rank": r.value, "ranks_seen_by_rccl": n.value, "rccl_version": v.value}
+
+    # the x halo exchange of a field tuple: pack, grouped send / recv on the communication stream, wait (event), unpack
+    def halo_exchange_begin(self, grid, fields):
+        _lib.call("ocn_halo_exchange_begin", self._h, grid.cref, _lib.ptr_array([f.ptr for f in fields]),
+                  _lib.i32_array([f.loc for f in fields]), len(fields), stream_ptr())
+
+    def halo_exchange_end(self, grid, fields):
+        _lib.call("ocn_halo_exchange_end", self._h, grid.cref, _lib.ptr_array([f.ptr for f in fields]),
+                  _lib.i32_array([f.loc for f in fields]), len(fields), stream_ptr())
+
+    def halo_exchange_plane(self, grid, f, side):
+        _lib.call("ocn_halo_exchange_plane", self._h, grid.cref, f.ptr, f.loc, 0 if side == "east" else 1, stream_ptr())
+
+    def dist_poisson_exchange(self, handle, direction):
+        _lib.call("ocn_dist_poisson_exchange", handle, self._h, int(direction), stream_ptr())
+
+    def all_to_all(self, recv, send):
+        _lib.call("ocn_comm_all_to_all", self._h, send.data_ptr(), recv.data_ptr(), send.numel() // self.size, stream_ptr())
+
+    def allreduce_max(self, t):
+        _lib.call("ocn_comm_allreduce", self._h, t.data_ptr(), t.numel(), 1, stream_ptr())
+        return t
+
+    def barrier(self):
+        torch.cuda.current_stream().synchronize()
+        _lib.call("ocn_comm_barrier", self._h)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.lib().ocn_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_distributed(rank=None, world_size=None, local_rank=None, force_communication=None):
+    """Distributed(GPU(); partition = Partition(world_size)) with the RCCL transport of libocn_hip.  One process per GPU, started by
+    torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment).  A gloo process group
+    carries the unique id (and nothing else in the time-stepping loop)."""
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+
+    def bootstrap(raw):
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    fabric = RcclFabric(rank, world_size, bootstrap)
+    return Distributed(GPU(), partition=Partition(world_size), fabric=fabric, force_communication=force_communication)
+
+
 # --------------------------------------------------------------------------------------------------
 # Ops: the device kernels the choreography calls (HIP; tests may inject CPU restatements).
 # --------------------------------------------------------------------------------------------------
@@ -113,7 +197,11 @@ class HipOps:
 class Distributed:
     """Distributed(child_architecture; partition): one rank of an x-slab decomposition."""
 
-    def __init__(self, child_architecture=None, partition=None, fabric=None, ops=None):
+    def __init__(self, child_architecture=None, partition=None, fabric=None, ops=None, force_communication=None):
+        """force_communication (default: the environment variable OCN_FORCE_DISTRIBUTED == "1"): with ONE rank, still treat x as a
+        partitioned (FullyConnected) direction and run every exchange through the transport -- a rank then sends its strips and
+        transposes to itself.  This is how the RCCL path is exercised on a one-GPU box."""
+        self.force_communication = (os.environ.get("OCN_FORCE_DISTRIBUTED") == "1") if force_communication is None else bool(force_communication)
         self.child_architecture = child_architecture if child_architecture is not None else GPU()
         self.fabric = fabric if fabric is not None else TorchDistributedFabric()
         self.ops = ops if ops is not None else HipOps()
@@ -132,6 +220,11 @@ class Distributed:
     @property
     def device(self):
         return device(self.child_architecture)
+
+    @property
+    def communicates(self):
+        """x halos come from the transport (R > 1, or one rank talking to itself when force_communication is set)"""
+        return self.partition.x > 1 or self.force_communication
 
     def __repr__(self):
         return f"Distributed({self.child_architecture}, rank {self.local_rank} of {self.partition.x})"
@@ -157,10 +250,14 @@ class Distributed:
     def start_halo_exchange(self, fields):
         """Pack + post the x exchange for a tuple of fields (fill_halo_event! with async=true)."""
         g = fields[0].grid
-        if self.partition.x == 1:
+        if not self.communicates:
             return None
         self.finish_halo_exchange()  # an exchange left in flight by a deferred update_state! completes first
         fields = tuple(fields)
+        if hasattr(self.fabric, "halo_exchange_begin"):  # RCCL behind the C ABI: pack + grouped send / recv in the library
+            self.fabric.halo_exchange_begin(g, fields)
+            self._pending = (None, fields)
+            return self._pending
         (sw, se, rw, re), spans = self._halo_buffers(fields)
         if hasattr(self.ops, "pack_x_fields"):
             self.ops.pack_x_fields(g, fields, sw, se)
@@ -182,8 +279,12 @@ class Distributed:
         if self._pending is None:
             return
         reqs, fields = self._pending
-        self.fabric.wait(reqs)
         g = fields[0].grid
+        if reqs is None:
+            self.fabric.halo_exchange_end(g, fields)
+            self._pending = None
+            return
+        self.fabric.wait(reqs)
         (sw, se, rw, re), spans = self._halo_buffers(fields)
         if hasattr(self.ops, "unpack_x_fields"):
             self.ops.unpack_x_fields(g, fields, rw, re)
@@ -200,8 +301,10 @@ class Distributed:
         g = f.grid
         self.finish_halo_exchange()
         self.ops.local_fill(g, fields, True)
-        if self.partition.x == 1 or not hasattr(self.ops, "plane_x"):
-            return self.fill_halo_regions(fields) if self.partition.x > 1 else None
+        if not self.communicates or not hasattr(self.ops, "plane_x"):
+            return self.fill_halo_regions(fields) if self.communicates else None
+        if hasattr(self.fabric, "halo_exchange_plane"):
+            return self.fabric.halo_exchange_plane(g, f, side)
         sx, sy, sz = g.parent_shape(f.loc)
         key = ("plane", f.loc)
         b = self._buffers.get(key)
@@ -228,7 +331,7 @@ class Distributed:
         from . import models
         g = model.grid
         fields = model.prognostic_fields()
-        if (defer_exchange and not compute_tendencies and self.partition.x > 1 and not getattr(model, "general_terms", False)
+        if (defer_exchange and not compute_tendencies and self.communicates and not getattr(model, "general_terms", False)
                 and os.environ.get("OCN_DIST_DEFER_EXCHANGE", "1") != "0"):
             # end of a step whose last tendency launch is deferred: start the exchange and leave it in flight; the next step's
             # fused launch (update_state_fused with fill_halos=False) overlaps it with its interior range, flush_tendencies and
@@ -276,7 +379,7 @@ class Distributed:
         nx, Hx = g.Nx, g.Hx
         d = model.diffusivity_fields
         aux = (() if d is None else (d["nu_e"],) + tuple(d["kappa_e"]))
-        split = (self.partition.x > 1 and nx - 2 * Hx >= 1 and Hx >= 2 and len(model.tracers) <= 4
+        split = (self.communicates and nx - 2 * Hx >= 1 and Hx >= 2 and len(model.tracers) <= 4
                  and os.environ.get("OCN_DIST_GENERAL_OVERLAP", "1") != "0")
         if not split:
             self.fill_halo_regions(fields, False)
@@ -340,7 +443,7 @@ def distributed_rectilinear_grid(arch, size, x=None, y=None, z=None, topology=(P
     if Nx % R:
         raise ValueError(f"Nx = {Nx} must be divisible by the number of ranks {R} (equal slabs)")
     nx = Nx // R
-    if R > 1:
+    if R > 1 or arch.communicates:
         # partition_coordinate(c::Tuple, ...) (partition_assemble.jl:63-76), same fp64 arithmetic
         dl = (float(x[1]) - float(x[0])) / Nx
         lo = float(x[0])
@@ -470,6 +573,23 @@ class DistributedFFTBasedPoissonSolver:
 
     def solve(self, p):
         impl = self.impl
+        ex = getattr(self.arch.fabric, "dist_poisson_exchange", None)
+        if ex is not None and hasattr(impl, "_h") and self.arch.communicates:
+            # the product path: both transposes are ocn_dist_poisson_exchange (grouped ncclSend / ncclRecv in the library)
+            impl.forward_yz()
+            if not getattr(impl, "fast", False):
+                impl.pack_y_to_x()
+            ex(impl._h, 0)
+            if not getattr(impl, "fast", False):
+                impl.unpack_x_from_y(impl.recv)
+            impl.solve_x()
+            if not getattr(impl, "fast", False):
+                impl.pack_x_to_y()
+            ex(impl._h, 1)
+            if not getattr(impl, "fast", False):
+                impl.unpack_y_from_x(impl.recv)
+            impl.backward_yz(p)
+            return p
         if getattr(impl, "fast", False):
             # slab pipeline of libocn_hip: the transforms read / write the exchange layout themselves
             impl.forward_yz()

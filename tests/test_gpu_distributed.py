@@ -319,3 +319,73 @@ def test_distributed_halo_exchange_on_gpu(ocn):
         J = np.arange(-3, N[1] + 3) % N[1]
         K = np.arange(-3, N[2] + 3) % N[2]
         np.testing.assert_array_equal(a, glob[np.ix_(I, J, K)])
+
+
+# ---- the product transport: RCCL behind the C ABI (csrc/comm.hip), on the one GPU of this box ------------------------------------------
+@pytest.fixture(scope="module")
+def rccl_arch(ocn):
+    """Distributed(GPU(), Partition(1)) over a real RCCL communicator of world size 1 with force_communication: x is FullyConnected and
+    every halo strip, plane and transpose goes through ocn_halo_exchange_* / ocn_dist_poisson_exchange (grouped ncclSend / ncclRecv to
+    the rank itself on the communication stream, event-ordered against the compute stream)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+    info = arch.fabric.info()
+    assert info["ranks_seen_by_rccl"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000
+    yield arch
+    arch.fabric.close()
+
+
+@pytest.mark.parametrize("N,topo", [((32, 16, 12), "PPP"), ((32, 16, 12), "PPB"), ((64, 128, 64), "PPP")])
+def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_arch, N, topo):
+    """Two RK3 steps with every exchange executed by RCCL (self send / recv): the halo strips with the overlapped interior / buffer
+    split, the one-plane exchanges of the projection, the deferred end-of-step exchange and both all-to-alls of the distributed
+    solver ((64, 128, 64) selects the slab pipeline, (32, 16, 12) the transposing rocFFT path, PPB the distributed Fourier-tridiagonal
+    solver).  Compared with the single-rank HIP model (1e-11 of max|u|) and, at the small sizes, with the CPU oracle."""
+    from helpers import stretched_faces
+    O = oracle
+    P = "Periodic"
+    z = (0, 2 * np.pi) if topo == "PPP" else stretched_faces(N[2], 2.0)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=(P, P, P if topo == "PPP" else "Bounded"), halo=(3, 3, 3))
+    rng = np.random.default_rng(4321)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    if topo == "PPB":
+        init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
+    dt = 0.01 if N[0] <= 32 else 0.002
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sm = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO())
+    ocn.set(sm, **init)
+    g = ocn.RectilinearGrid(rccl_arch, size=N, **ext)
+    assert g.topology[0] == "FullyConnected" and g.Nx == N[0]
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    assert type(m.pressure_solver).__name__.startswith("Distributed")
+    ocn.set(m, **init)
+    for _ in range(2):
+        ocn.time_step(sm, dt)
+        ocn.time_step(m, dt)
+    ocn.flush_tendencies(m)
+    ocn.sync_device()
+    scale = max(float(np.abs(f.interior()).max()) for f in sm.velocities)
+    for a, b, name in zip(m.velocities, sm.velocities, "uvw"):
+        assert np.abs(a.interior() - b.interior()).max() <= 1e-11 * scale, name
+    assert np.abs(m.pNHS.interior() - sm.pNHS.interior()).max() <= 1e-10 * max(1.0, float(np.abs(sm.pNHS.interior()).max()))
+    # the x halos of the state the step leaves behind were filled by the transport: periodic images of the interior
+    H, nx = 3, N[0]
+    u = m.u.data
+    assert torch.equal(u[:, :, :H], u[:, :, nx:nx + H]) and torch.equal(u[:, :, nx + H:nx + 2 * H], u[:, :, H:2 * H])
+    if N[0] <= 32:
+        og = O.Grid(N, x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=topo, halo=(3, 3, 3))
+        om = O.NonhydrostaticModel(og)
+        om.set(**init)
+        for _ in range(2):
+            om.time_step(dt)
+        for a, b, name in zip(m.velocities, (om.u, om.v, om.w), "uvw"):
+            assert np.abs(a.interior() - og.interior(b)).max() <= 1e-11 * scale, name

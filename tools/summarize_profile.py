@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Condenses a tools/profile_gpu.sh output directory into profiles/<tag>_<n>.{md,json}.
+"""Condenses a tools/profile_bench.sh (or profile_gpu.sh) output directory into profiles/<tag>_<name>.{md,json}.
+
+    tools/summarize_profile.py <dir> <tag> <n | name> [cells] [steps_profiled]
+
 
  - per-kernel time from rocprofv3 --kernel-trace --stats (kernel_stats.csv)
  - per-launch HBM traffic of each kernel from the two PMC passes: FETCH_SIZE and WRITE_SIZE are reported in KiB
@@ -40,24 +43,37 @@ def load_pmc(d, sub, counter):
     return acc
 
 
+SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU",
+               "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY")
+
+
 def main():
-    d, tag, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    d, tag, name = sys.argv[1], sys.argv[2], sys.argv[3]
+    n = int(name) if name.isdigit() else None
     stats = load_stats(d)
     fetch = load_pmc(d, "pmc_fetch", "FETCH_SIZE")
     write = load_pmc(d, "pmc_write", "WRITE_SIZE")
-    cells = n ** 3
+    cells = int(sys.argv[4]) if len(sys.argv) > 4 else n ** 3
+    steps_profiled = int(sys.argv[5]) if len(sys.argv) > 5 else None
+    sq = {}
+    if glob.glob(os.path.join(d, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
+        sq = {c: load_pmc(d, "pmc_sq", c) for c in SQ_COUNTERS}
     field_bytes = cells * 8.0
     # calibration kernel of known traffic in our 8 B/lane pattern:
     #   stepper_kernel<3> (cache_previous_tendencies): reads 3 fields, writes 3;  or, when the host swaps the G buffers
     #   and that kernel never runs, pressure_correct_kernel: reads p, u, v, w (4 fields), writes u, v, w (3).
     med = lambda v: sorted(v)[len(v) // 2]
     read_factor = write_factor = None
-    for cal, nr, nw in (("ocn::stepper_kernel<3>", 3, 3), ("ocn::pressure_correct_kernel", 4, 3)):
+    #   hydrostatic workloads: hydrostatic_pressure_kernel reads T, S and writes pHY' (columns 0 .. N+1: +0.4 % at 1024^2, neglected)
+    for cal, nr, nw in (("ocn::stepper_kernel<3>", 3, 3), ("ocn::pressure_correct_kernel", 4, 3), ("ocn::hydrostatic_pressure_kernel", 2, 1)):
         if cal in fetch and cal in write:
             read_factor = nr * field_bytes / (med(fetch[cal]) * 1024)
             write_factor = nw * field_bytes / (med(write[cal]) * 1024)
             break
-    out = {"tag": tag, "n": n, "read_calibration_factor": read_factor, "write_calibration_factor": write_factor, "kernels": []}
+    command = open(os.path.join(d, "command.txt")).read().strip() if os.path.exists(os.path.join(d, "command.txt")) else None
+    out = {"tag": tag, "n": n, "name": name, "cells": cells, "command": command, "steps_profiled": steps_profiled,
+           "read_calibration_factor": read_factor, "write_calibration_factor": write_factor, "kernels": []}
+    step_bytes = 0.0
     for s in stats:
         k = dict(s)
         if s["name"] in fetch and s["name"] in write and read_factor:
@@ -66,20 +82,39 @@ def main():
             k.update(read_bytes=rd, write_bytes=wr, traffic_bytes=rd + wr, traffic_bytes_per_cell=(rd + wr) / cells,
                      hbm_GBps=(rd + wr) / (s["avg_us"] * 1e-6) / 1e9,
                      raw_fetch_KiB=med(fetch[s["name"]]), raw_write_KiB=med(write[s["name"]]))
+            step_bytes += (rd + wr) * s["calls"]
+        for c in SQ_COUNTERS:
+            if c in sq and s["name"] in sq[c]:
+                k[c] = med(sq[c][s["name"]])
+        if "SQ_ACTIVE_INST_VALU" in k and k.get("GRBM_GUI_ACTIVE"):
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+            k["valu_busy"] = k["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * k["GRBM_GUI_ACTIVE"] / 8)
+            k["clock_GHz_under_pmc"] = k["GRBM_GUI_ACTIVE"] / 8 / (s["avg_us"] * 1e3)
+            k["valu_wave_instr_per_cell"] = k["SQ_INSTS_VALU"] / cells
         out["kernels"].append(k)
+    if steps_profiled:
+        # all launches of the profiled command (steps + warm-up + set!) over the steps it ran: an upper bound of one step's traffic
+        out["step_bytes_per_cell"] = step_bytes / steps_profiled / cells
     os.makedirs("profiles", exist_ok=True)
-    base = os.path.join("profiles", f"{tag}_{n}")
+    base = os.path.join("profiles", f"{tag}_{name}")
     json.dump(out, open(base + ".json", "w"), indent=1)
     with open(base + ".md", "w") as f:
-        f.write(f"# rocprofv3 summary {tag}, bench.py --size {n}\n\n")
-        f.write("Source: `rocprofv3 --kernel-trace --stats` and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE); "
-                "see tools/profile_gpu.sh / tools/summarize_profile.py.\n\n")
+        f.write(f"# rocprofv3 summary {tag}: `{command or 'bench.py --size ' + str(n)}`\n\n")
+        f.write("Source: `rocprofv3 --kernel-trace --stats` and separate `--pmc` passes (FETCH_SIZE; WRITE_SIZE; SQ counters) of the same "
+                "command; see tools/profile_bench.sh / tools/summarize_profile.py.  valu busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x "
+                "GRBM_GUI_ACTIVE / 8 XCDs); VALU instr/cell = SQ_INSTS_VALU (wave instructions) / cells.\n\n")
+        if "step_bytes_per_cell" in out:
+            f.write(f"Measured HBM traffic of the whole command / ({steps_profiled} steps x {cells} cells) = "
+                    f"**{out['step_bytes_per_cell']:.0f} B per cell per step** (includes set! and warm-up launches).\n\n")
         f.write(f"PMC calibration on `{cal}` (known fields read / written): read x{read_factor}, write x{write_factor}\n\n")
-        f.write("| kernel | calls | avg us | % GPU time | HBM traffic/launch (B/cell) | HBM GB/s |\n|---|---|---|---|---|---|\n")
+        f.write("| kernel | calls | avg us | % GPU time | HBM traffic/launch (B/cell) | HBM GB/s | VALU wave-instr/cell | valu busy | GHz under PMC |\n|---|---|---|---|---|---|---|---|---|\n")
         for k in out["kernels"][:25]:
             t = f"{k['traffic_bytes_per_cell']:.1f}" if "traffic_bytes" in k else "-"
             b = f"{k['hbm_GBps']:.0f}" if "hbm_GBps" in k else "-"
-            f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_us']:.1f} | {k['pct']:.2f} | {t} | {b} |\n")
+            vi = f"{k['valu_wave_instr_per_cell']:.2f}" if "valu_wave_instr_per_cell" in k else "-"
+            vb = f"{k['valu_busy']:.2f}" if "valu_busy" in k else "-"
+            gh = f"{k['clock_GHz_under_pmc']:.2f}" if "clock_GHz_under_pmc" in k else "-"
+            f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_us']:.1f} | {k['pct']:.2f} | {t} | {b} | {vi} | {vb} | {gh} |\n")
     print(open(base + ".md").read())
 
 
