@@ -17,6 +17,7 @@
 // neighbours of a halo exchange each use their own link; nothing here is a ring.
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ocn_internal.h"
@@ -45,6 +46,7 @@ struct Comm {
     size_t plane_cap = 0;
     bool pending = false;
     size_t pending_count = 0;
+    bool self_via_rccl = false;  // OCN_COMM_SELF_VIA_RCCL=1: a rank's transfers to itself go through ncclSend / ncclRecv too (tests)
 };
 
 int ensure(Comm *c, size_t n)
@@ -89,6 +91,13 @@ int make_tuple(const ocn_grid *grid, double *const *fields, const int32_t *locs,
 // (from east, from west) so that they pair up with that peer's (west, east) sends.
 int post_exchange(Comm *c, const double *sw, const double *se, double *rw, double *re, size_t count)
 {
+    if (c->nranks == 1 && !c->self_via_rccl) {
+        // one rank: both neighbours are this rank; a device copy moves the strips at HBM speed (RCCL's self send / recv runs on a few
+        // channels only)
+        OCN_CHECK_HIP(hipMemcpyAsync(re, sw, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        OCN_CHECK_HIP(hipMemcpyAsync(rw, se, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return OCN_SUCCESS;
+    }
     OCN_CHECK_NCCL(ncclGroupStart());
     OCN_CHECK_NCCL(ncclSend(sw, count, ncclDouble, c->west, c->comm, c->stream));
     OCN_CHECK_NCCL(ncclSend(se, count, ncclDouble, c->east, c->comm, c->stream));
@@ -126,6 +135,8 @@ int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *un
     Comm *c = new Comm();
     c->rank = rank;
     c->nranks = nranks;
+    const char *sv = getenv("OCN_COMM_SELF_VIA_RCCL");
+    c->self_via_rccl = sv && sv[0] == '1';
     c->west = (rank + nranks - 1) % nranks;  // neighbours wrap around (distributed_architectures.jl:386-429)
     c->east = (rank + 1) % nranks;
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);  // on the current device (ocn_set_device / hipSetDevice first)
@@ -245,6 +256,8 @@ int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field
     // the plane I need from the east is my east neighbour's WEST interior plane, and vice versa
     st = launch_halo_plane_x(grid, field, loc, east ? 0 : 1, c->plane[0], 0, s);
     if (st != OCN_SUCCESS) return st;
+    if (c->nranks == 1 && !c->self_via_rccl)
+        return launch_halo_plane_x(grid, field, loc, east ? 1 : 0, c->plane[0], 1, s);  // my own plane is the neighbour's
     OCN_CHECK_NCCL(ncclGroupStart());
     OCN_CHECK_NCCL(ncclSend(c->plane[0], count, ncclDouble, east ? c->west : c->east, c->comm, s));
     OCN_CHECK_NCCL(ncclRecv(c->plane[1], count, ncclDouble, east ? c->east : c->west, c->comm, s));
@@ -260,8 +273,15 @@ int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_
     OCN_REQUIRE(c && send && recv, "ocn_comm_all_to_all: null pointer");
     OCN_REQUIRE(send != recv, "ocn_comm_all_to_all: in-place exchange is not supported");
     hipStream_t s = as_stream(stream);
+    // the chunk a rank keeps for itself (1 / R of the payload) is a device copy at HBM speed; the R - 1 others are one grouped
+    // send / recv per peer, each over its own xGMI link
+    if (!c->self_via_rccl)
+        OCN_CHECK_HIP(hipMemcpyAsync(recv + (size_t)c->rank * count, send + (size_t)c->rank * count, count * sizeof(double),
+                                     hipMemcpyDeviceToDevice, s));
+    if (c->nranks == 1 && !c->self_via_rccl) return OCN_SUCCESS;
     OCN_CHECK_NCCL(ncclGroupStart());
     for (int d = 0; d < c->nranks; ++d) {
+        if (d == c->rank && !c->self_via_rccl) continue;
         OCN_CHECK_NCCL(ncclSend(send + (size_t)d * count, count, ncclDouble, d, c->comm, s));
         OCN_CHECK_NCCL(ncclRecv(recv + (size_t)d * count, count, ncclDouble, d, c->comm, s));
     }

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, Te
     long long o = at(L, i, j, Nz + 1);
     double b_up = buoyancy_perturbation(t, o);  // b[k+1]
     double p = 0.0;
-    for (int k = Nz; k >= 1; --k) {
+#pragma unroll 8
+    for (int k = Nz; k >= 1; --k) {  // (unrolled: the loads of 8 planes are in flight while the recurrence runs)
         o -= L.s3;
         const double b = buoyancy_perturbation(t, o);
         const double zb = 1 * (0.5 * (b + b_up));                       // z_dot_g_bᶜᶜᶠ(k+1)
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(256) void barotropic_correct_w_kernel(GridDev g, co
     const double Az = g.dx * g.dy;
     double wk = 0.0;
     w[o] = wk;
+#pragma unroll 8
     for (int k = 1; k <= g.Nz; ++k) {
         const double uc = corr ? us[o] + cu : us[o], ue = corr ? us[oe] + cue : us[oe];
         const double vc = corr ? vs[o] + cv : vs[o], vn = corr ? vs[on] + cvn : vs[on];

@@ -455,7 +455,8 @@ __device__ __forceinline__ void vector_invariant_cell(const Metrics &M, int k, F
     }
 }
 
-__global__ __launch_bounds__(256) void hydrostatic_momentum_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
+template <int W>
+__global__ __launch_bounds__(256, W) void hydrostatic_momentum_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
                                                                   const double *__restrict__ v, const double *__restrict__ w,
                                                                   double *__restrict__ Gu, double *__restrict__ Gv,
                                                                   ocn::MomentumFinal mf, ocn::HydroFuse hf)
@@ -679,7 +680,11 @@ int launch_hydrostatic_momentum(const ocn_grid *grid, const TermsDev &t, const d
 {
     GridDev g = ocn::to_dev(*grid);
     dim3 nbt((g.Nx + 31) / 32, (g.Ny + 7) / 8, 1);
-    hipLaunchKernelGGL(hydrostatic_momentum_tiled, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
+    static const int waves = getenv("OCN_HYDRO_WAVES") ? atoi(getenv("OCN_HYDRO_WAVES")) : 3;  // min waves / SIMD the build targets
+    if (waves >= 4)
+        hipLaunchKernelGGL(hydrostatic_momentum_tiled<4>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
+    else
+        hipLaunchKernelGGL(hydrostatic_momentum_tiled<1>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -738,7 +738,7 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
     const char *efast = std::getenv("OCN_DIST_POISSON_FAST");
-    if (lg->tz == OCN_BOUNDED && !(efast && efast[0] == '0') && R > 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
+    if (lg->tz == OCN_BOUNDED && !(efast && efast[0] == '0') && R >= 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
         ocn::colfft_supported(Nxg)) {
         // Slab pipeline, tridiagonal flavour: real y transform (source term x Δzᶜ evaluated on load) writing the all-to-all layout
         // [d][ky_l + c (z + Nz xl)] (ky = d c + ky_l, c = ceil((Ny/2+1) / R), padded entries stay 0) -> exchange -> x is a strided
@@ -849,7 +849,7 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
     }
     {
         const char *ef = std::getenv("OCN_DIST_POISSON_FAST");
-        s->fast = !force_c2c && s->r2c && !(ef && ef[0] == '0') && R > 1 && ocn::realfft_y_supported(Ny) && ocn::colfft_supported(Nz) &&
+        s->fast = !force_c2c && s->r2c && !(ef && ef[0] == '0') && R >= 1 && ocn::realfft_y_supported(Ny) && ocn::colfft_supported(Nz) &&
                   ocn::colfft_supported(Nxg) && Nz % R == 0;
     }
     if (s->fast) {

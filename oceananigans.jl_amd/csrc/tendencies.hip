@@ -572,8 +572,8 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
 //  * thread (i, j) evaluates the west-face and south-face fluxes of its cell and the top-face flux; the east / north ones come
 //    from the neighbouring threads through LDS, the bottom one is last iteration's top flux.
 // 3 flux evaluations per thread and plane instead of 6; the flux expressions are those of the direct kernel (bit-identical).
-template <int TZ, int TX, int TY>
-__global__ __launch_bounds__(TX *TY) void tracer_tendency_tiled(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+template <int TZ, int TX, int TY, int W = 1>
+__global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                                const double *__restrict__ w, const double *__restrict__ c,
                                                                double *__restrict__ Gc, Range r, int KZ, ocn::TracerFuse tf)
 {
@@ -858,7 +858,13 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
         int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the bottom-flux prologue
         while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
-        if (grid->tz == OCN_PERIODIC)
+        static const int waves = getenv("OCN_TRACER_WAVES") ? atoi(getenv("OCN_TRACER_WAVES")) : 3;  // min waves / SIMD the build targets
+        if (waves >= 4) {
+            if (grid->tz == OCN_PERIODIC)
+                hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY, 4>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+            else
+                hipLaunchKernelGGL((tracer_tendency_tiled<OCN_BOUNDED, TX, TY, 4>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+        } else if (grid->tz == OCN_PERIODIC)
             hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
         else
             hipLaunchKernelGGL((tracer_tendency_tiled<OCN_BOUNDED, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);

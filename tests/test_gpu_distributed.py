@@ -322,8 +322,8 @@ def test_distributed_halo_exchange_on_gpu(ocn):
 
 
 # ---- the product transport: RCCL behind the C ABI (csrc/comm.hip), on the one GPU of this box ------------------------------------------
-@pytest.fixture(scope="module")
-def rccl_arch(ocn):
+@pytest.fixture(scope="module", params=["self-via-rccl", "self-copy"])
+def rccl_arch(ocn, request):
     """Distributed(GPU(), Partition(1)) over a real RCCL communicator of world size 1 with force_communication: x is FullyConnected and
     every halo strip, plane and transpose goes through ocn_halo_exchange_* / ocn_dist_poisson_exchange (grouped ncclSend / ncclRecv to
     the rank itself on the communication stream, event-ordered against the compute stream)."""
@@ -337,14 +337,18 @@ def rccl_arch(ocn):
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo", rank=0, world_size=1)
+    # (read by ocn_comm_init) "1": a rank's transfers to itself go through ncclSend / ncclRecv like those to any other peer;
+    # default: device copies for the self chunk (what a production run does with its own 1 / R of every all-to-all)
+    os.environ["OCN_COMM_SELF_VIA_RCCL"] = "1" if request.param == "self-via-rccl" else "0"
     arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+    os.environ.pop("OCN_COMM_SELF_VIA_RCCL")
     info = arch.fabric.info()
     assert info["ranks_seen_by_rccl"] == 1 and info["rank"] == 0 and info["rccl_version"] > 20000
     yield arch
     arch.fabric.close()
 
 
-@pytest.mark.parametrize("N,topo", [((32, 16, 12), "PPP"), ((32, 16, 12), "PPB"), ((64, 128, 64), "PPP")])
+@pytest.mark.parametrize("N,topo", [((32, 16, 12), "PPP"), ((32, 16, 12), "PPB"), ((64, 128, 64), "PPP"), ((64, 128, 32), "PPB")])
 def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_arch, N, topo):
     """Two RK3 steps with every exchange executed by RCCL (self send / recv): the halo strips with the overlapped interior / buffer
     split, the one-plane exchanges of the projection, the deferred end-of-step exchange and both all-to-alls of the distributed
@@ -360,6 +364,7 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
     if topo == "PPB":
         init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
     dt = 0.01 if N[0] <= 32 else 0.002
+    fast_expected = {(64, 128, 64): 1, (64, 128, 32): 2}.get(N, 0)
     ocn.set_math_mode(ocn.MATH_STRICT)
     sm = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO())
     ocn.set(sm, **init)
@@ -367,6 +372,7 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
     assert g.topology[0] == "FullyConnected" and g.Nx == N[0]
     m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
     assert type(m.pressure_solver).__name__.startswith("Distributed")
+    assert m.pressure_solver.impl.fast == fast_expected  # 1 / 2: the slab pipelines (periodic / tridiagonal flavour), 0: transposing rocFFT path
     ocn.set(m, **init)
     for _ in range(2):
         ocn.time_step(sm, dt)
