@@ -87,13 +87,15 @@ struct Plan {
     }
     void destroy()
     {
-        // rocFFT (ROCm 7.2) plans share cached state: destroying one plan has been seen to corrupt the results of another,
-        // still live, real-transform plan of a different handle (order-dependent failures of small-grid solves, see DESIGN.md
-        // "rocFFT plan self-test").  Plans are therefore retired, not destroyed: the rocfft_plan / execution_info objects (a few
-        // KB each) live until the process ends; only the work buffer is released.  OCN_ROCFFT_DESTROY_PLANS=1 restores the
-        // eager destruction.
-        static const bool eager = std::getenv("OCN_ROCFFT_DESTROY_PLANS") && std::getenv("OCN_ROCFFT_DESTROY_PLANS")[0] == '1';
-        if (eager) {
+        // Plans are destroyed eagerly.  rocFFT (ROCm 7.2) real-transform plans collide with OTHER LIVE real plans: a power-of-two
+        // pair whose 2-D (x, y) kernel lengths are the transpose of an existing plan's -- (Nx/2, Ny) = (Ny', Nx'/2), e.g. 16 x 16 x k
+        // alive, then 32 x 8 x k, or 64^3 then 128 x 32 -- comes out wrong (forward spectrum, inverse, or both; the earlier plan stays
+        // correct), and destroying the first plan BEFORE creating the second cures it (tools/rocfft_repro.hip,
+        // profiles/r02_rocfft_repro.md).  Keeping dead plans alive therefore only widens the exposure; every new pair is additionally
+        // verified against known answers over its full spectrum at creation (poisson_plans_self_test) and replaced by complex plans
+        // if it fails.  OCN_ROCFFT_RETIRE_PLANS=1 restores round 1's behaviour (objects kept until the process ends).
+        static const bool retire = std::getenv("OCN_ROCFFT_RETIRE_PLANS") && std::getenv("OCN_ROCFFT_RETIRE_PLANS")[0] == '1';
+        if (!retire) {
             if (plan) rocfft_plan_destroy(plan);
             if (info) rocfft_execution_info_destroy(info);
         }
@@ -328,34 +330,115 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
     return OCN_SUCCESS;
 }
 
-// Known-answer check of a forward transform: a few entries of the device spectrum against a direct DFT sum of the same input on
-// the host.  The round trip alone does not catch a forward / inverse pair that is wrong in a mutually consistent way (seen
-// with rocFFT real plans whose shape matches an earlier plan of different strides: the round trip reproduced the input while the
-// spectrum itself was permuted).  spec(kx, ky, kz) at kx + nxh (ky + Ny kz); dims3 = the plan transforms z as well.
-static double spectrum_sample_error(const std::vector<double> &in, const std::vector<double> &spec, int Nx, int Ny, int Nz, int nxh,
-                                    bool dims3)
+// Known-answer checks of a forward transform over the FULL spectrum.  The round trip alone does not catch a forward / inverse pair
+// that is wrong in a mutually consistent way, and a sample of entries misses permuted spectra.
+//  (a) plane waves, any grid size, O(n): the input is a sum of NW real plane waves with distinct amplitudes and phases whose DFT is
+//      known in closed form (two conjugate deltas per wave, folded into the half spectrum); every entry of the device spectrum is
+//      compared with it.
+//  (b) grids of at most 2^16 points: a pseudo-random field against a separable DFT evaluated on the host.
+// spec(kx, ky, kz) at kx + nxh (ky + Ny kz); dims3 = the plan transforms z as well (otherwise z is the batch index).
+struct Wave {
+    int kx, ky, kz;
+    double amp, phase;
+};
+static std::vector<Wave> test_waves(int Nx, int Ny, int Nz, bool dims3)
+{
+    std::vector<Wave> w;
+    unsigned long long x = 0xD1B54A32D192ED03ull;
+    auto next = [&]() { x = x * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(x >> 33); };
+    for (int q = 0; q < 12; ++q)
+        w.push_back(Wave{(int)(next() % (unsigned)Nx), (int)(next() % (unsigned)Ny), dims3 ? (int)(next() % (unsigned)Nz) : 0, 0.5 + 0.125 * q,
+                         0.37 * q + 0.11});
+    w.push_back(Wave{1 % Nx, 0, 0, 1.7, 0.3});         // the axes, the Nyquist lines and the mean, each with its own amplitude
+    w.push_back(Wave{0, 1 % Ny, 0, 2.3, -0.4});
+    w.push_back(Wave{Nx / 2, Ny / 2, dims3 ? Nz / 2 : 0, 2.9, 0.0});
+    w.push_back(Wave{0, 0, 0, 3.1, 0.0});
+    if (dims3) w.push_back(Wave{0, 0, 1 % Nz, 3.7, 0.9});
+    return w;
+}
+// in[i,j,k] = sum_w amp cos(2 pi (kx i / Nx + ky j / Ny + kz k / Nz) + phase)  [2-D plans: every z plane gets (1 + k) x the field]
+static void fill_waves(std::vector<double> &in, const std::vector<Wave> &W, int Nx, int Ny, int Nz, bool dims3)
 {
     const double two_pi = 6.283185307179586476925286766559;
-    const int kxs[3] = {0, 1 % nxh, (nxh - 1)}, kys[3] = {0, 2 % Ny, Ny - 1}, kzs[3] = {0, 1 % Nz, Nz - 1};
-    double worst = 0.0;
-    for (int q = 0; q < 3; ++q) {
-        const int kx = kxs[q], ky = kys[(q + 1) % 3], kz = kzs[(q + 2) % 3];
-        // 2-D plans are batched over z: the sample is the (kx, ky) entry of plane kz
-        double re = 0.0, im = 0.0;
-        const int z0 = dims3 ? 0 : kz, z1 = dims3 ? Nz : kz + 1;
-        for (int k = z0; k < z1; ++k)
+    std::fill(in.begin(), in.end(), 0.0);
+    for (const Wave &w : W) {
+        std::vector<double> cx(Nx), sx(Nx), cy(Ny), sy(Ny), cz(Nz), sz(Nz);
+        for (int i = 0; i < Nx; ++i) { const double a = two_pi * (double)((long long)w.kx * i % Nx) / Nx; cx[i] = std::cos(a); sx[i] = std::sin(a); }
+        for (int j = 0; j < Ny; ++j) { const double a = two_pi * (double)((long long)w.ky * j % Ny) / Ny; cy[j] = std::cos(a); sy[j] = std::sin(a); }
+        for (int k = 0; k < Nz; ++k) { const double a = dims3 ? two_pi * (double)((long long)w.kz * k % Nz) / Nz : 0.0; cz[k] = std::cos(a); sz[k] = std::sin(a); }
+        const double cp = std::cos(w.phase), sp = std::sin(w.phase);
+        for (int k = 0; k < Nz; ++k) {
+            const double scale = dims3 ? 1.0 : 1.0 + k;
             for (int j = 0; j < Ny; ++j) {
-                const double pyz = (double)ky * j / Ny + (dims3 ? (double)kz * k / Nz : 0.0);
+                // cos(a + b + c + phase) with a = x angle, (b, c, phase) folded into (C, S): cos(a) C - sin(a) S
+                const double cyz = cy[j] * cz[k] - sy[j] * sz[k], syz = sy[j] * cz[k] + cy[j] * sz[k];
+                const double Cc = cyz * cp - syz * sp, Ss = syz * cp + cyz * sp;
+                double *row = &in[(size_t)Nx * (j + (size_t)Ny * k)];
+                for (int i = 0; i < Nx; ++i) row[i] += scale * w.amp * (cx[i] * Cc - sx[i] * Ss);
+            }
+        }
+    }
+}
+// max |device spectrum - closed form| over every stored entry
+static double wave_spectrum_error(const std::vector<double> &spec, const std::vector<Wave> &W, int Nx, int Ny, int Nz, int nxh, bool dims3)
+{
+    std::vector<double> ex(spec.size(), 0.0);
+    const double count = (double)Nx * Ny * (dims3 ? Nz : 1);
+    for (const Wave &w : W) {
+        // amp cos(theta + phase) = amp/2 (e^{i phase} e^{i theta} + c.c.): delta at +k with amp/2 e^{i phase}, at -k with the conjugate
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const int kx = sgn ? (Nx - w.kx) % Nx : w.kx, ky = sgn ? (Ny - w.ky) % Ny : w.ky, kz = sgn ? (Nz - w.kz) % Nz : w.kz;
+            if (kx >= nxh) continue;  // the other half of the Hermitian spectrum is not stored
+            const double re = 0.5 * w.amp * std::cos(w.phase) * count, im = (sgn ? -1.0 : 1.0) * 0.5 * w.amp * std::sin(w.phase) * count;
+            for (int k = 0; k < (dims3 ? 1 : Nz); ++k) {
+                const size_t o = 2 * ((size_t)kx + (size_t)nxh * (ky + (size_t)Ny * (dims3 ? kz : k)));
+                const double scale = dims3 ? 1.0 : 1.0 + k;
+                ex[o] += scale * re;
+                ex[o + 1] += scale * im;
+            }
+        }
+    }
+    double worst = 0.0;
+    for (size_t q = 0; q < ex.size(); ++q) worst = std::fmax(worst, std::fabs(ex[q] - spec[q]));
+    return worst;
+}
+// full separable host DFT of a small real field -> max error over every stored entry
+static double full_spectrum_error(const std::vector<double> &in, const std::vector<double> &spec, int Nx, int Ny, int Nz, int nxh, bool dims3)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    const size_t m = (size_t)nxh * Ny * Nz;
+    std::vector<double> a(2 * m), b(2 * m);
+    for (int k = 0; k < Nz; ++k)
+        for (int j = 0; j < Ny; ++j)
+            for (int kx = 0; kx < nxh; ++kx) {
+                double re = 0, im = 0;
                 for (int i = 0; i < Nx; ++i) {
-                    const double ph = -two_pi * ((double)kx * i / Nx + pyz);
-                    const double v = in[i + (size_t)Nx * (j + (size_t)Ny * k)];
+                    const double ph = -two_pi * (double)((long long)kx * i % Nx) / Nx, v = in[i + (size_t)Nx * (j + (size_t)Ny * k)];
                     re += v * std::cos(ph);
                     im += v * std::sin(ph);
                 }
+                const size_t o = 2 * (kx + (size_t)nxh * (j + (size_t)Ny * k));
+                a[o] = re; a[o + 1] = im;
             }
-        const size_t o = 2 * ((size_t)kx + (size_t)nxh * (ky + (size_t)Ny * kz));
-        worst = std::fmax(worst, std::fmax(std::fabs(spec[o] - re), std::fabs(spec[o + 1] - im)));
-    }
+    auto pass = [&](std::vector<double> &src, std::vector<double> &dst, int N, size_t stride, size_t outer_stride, size_t n_outer, size_t n_inner) {
+        for (size_t oo = 0; oo < n_outer; ++oo)
+            for (size_t ii = 0; ii < n_inner; ++ii)
+                for (int kk = 0; kk < N; ++kk) {
+                    double re = 0, im = 0;
+                    for (int q = 0; q < N; ++q) {
+                        const double ph = -two_pi * (double)((long long)kk * q % N) / N, c = std::cos(ph), sn = std::sin(ph);
+                        const size_t o = 2 * (ii + stride * q + outer_stride * oo);
+                        re += src[o] * c - src[o + 1] * sn;
+                        im += src[o] * sn + src[o + 1] * c;
+                    }
+                    const size_t o = 2 * (ii + stride * kk + outer_stride * oo);
+                    dst[o] = re; dst[o + 1] = im;
+                }
+    };
+    pass(a, b, Ny, nxh, (size_t)nxh * Ny, Nz, nxh);              // along y
+    if (dims3) { a = b; pass(a, b, Nz, (size_t)nxh * Ny, 0, 1, (size_t)nxh * Ny); }  // along z
+    double worst = 0.0;
+    for (size_t q = 0; q < 2 * m; ++q) worst = std::fmax(worst, std::fabs(b[q] - spec[q]));
     return worst;
 }
 
@@ -388,7 +471,7 @@ static int poisson_plans_self_test(ocn_poisson *s)
         if (st != OCN_SUCCESS) return st;
         OCN_CHECK_HIP(hipDeviceSynchronize());
         OCN_CHECK_HIP(hipMemcpy(c.data(), s->spec, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
-        ferr = spectrum_sample_error(in, c, Nx, Ny, Nz, Nx, three_d);
+        if (n <= (size_t)1 << 16) ferr = full_spectrum_error(in, c, Nx, Ny, Nz, Nx, three_d);
         st = s->bwd.exec(s->spec, nullptr, nullptr);
         if (st != OCN_SUCCESS) return st;
         OCN_CHECK_HIP(hipDeviceSynchronize());
@@ -396,6 +479,18 @@ static int poisson_plans_self_test(ocn_poisson *s)
         for (size_t q = 0; q < n; ++q) {
             err = std::fmax(err, std::fabs(c[2 * q] - net * in[q]));
             err = std::fmax(err, std::fabs(c[2 * q + 1]));
+        }
+        {   // plane waves: closed-form answer for every entry, any grid size
+            const std::vector<Wave> W = test_waves(Nx, Ny, Nz, three_d);
+            fill_waves(in, W, Nx, Ny, Nz, three_d);
+            std::fill(c.begin(), c.end(), 0.0);
+            for (size_t q = 0; q < n; ++q) c[2 * q] = in[q];
+            OCN_CHECK_HIP(hipMemcpy(s->spec, c.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice));
+            st = s->fwd.exec(s->spec, nullptr, nullptr);
+            if (st != OCN_SUCCESS) return st;
+            OCN_CHECK_HIP(hipDeviceSynchronize());
+            OCN_CHECK_HIP(hipMemcpy(c.data(), s->spec, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+            ferr = std::fmax(ferr, wave_spectrum_error(c, W, Nx, Ny, Nz, Nx, three_d));
         }
         OCN_CHECK_HIP(hipMemset(s->spec, 0, 2 * n * sizeof(double)));
     } else {
@@ -410,7 +505,7 @@ static int poisson_plans_self_test(ocn_poisson *s)
             OCN_CHECK_HIP(hipDeviceSynchronize());
             std::vector<double> sp((size_t)s->nxh * Ny * Nz * 2);
             OCN_CHECK_HIP(hipMemcpy(sp.data(), s->spec, sp.size() * sizeof(double), hipMemcpyDeviceToHost));
-            ferr = spectrum_sample_error(in, sp, Nx, Ny, Nz, s->nxh, three_d);
+            if (n <= (size_t)1 << 16) ferr = full_spectrum_error(in, sp, Nx, Ny, Nz, s->nxh, three_d);
         }
         if (s->direct_out) {
             OCN_CHECK_HIP(hipMalloc((void **)&tmp, np * sizeof(double)));
@@ -437,10 +532,22 @@ static int poisson_plans_self_test(ocn_poisson *s)
             OCN_CHECK_HIP(hipMemcpy(outv.data(), s->rhs, n * sizeof(double), hipMemcpyDeviceToHost));
             for (size_t q = 0; q < n; ++q) err = std::fmax(err, std::fabs(outv[q] - net * in[q]));
         }
+        {   // plane waves: closed-form answer for every entry, any grid size
+            const std::vector<Wave> W = test_waves(Nx, Ny, Nz, three_d);
+            fill_waves(in, W, Nx, Ny, Nz, three_d);
+            OCN_CHECK_HIP(hipMemcpy(s->rhs, in.data(), n * sizeof(double), hipMemcpyHostToDevice));
+            st = s->fwd.exec(s->rhs, s->spec, nullptr);
+            if (st != OCN_SUCCESS) return st;
+            OCN_CHECK_HIP(hipDeviceSynchronize());
+            std::vector<double> sp((size_t)s->nxh * Ny * Nz * 2);
+            OCN_CHECK_HIP(hipMemcpy(sp.data(), s->spec, sp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            ferr = std::fmax(ferr, wave_spectrum_error(sp, W, Nx, Ny, Nz, s->nxh, three_d));
+        }
         OCN_CHECK_HIP(hipMemset(s->rhs, 0, n * sizeof(double)));
         OCN_CHECK_HIP(hipMemset(s->spec, 0, (size_t)s->nxh * Ny * Nz * 2 * sizeof(double)));
     }
-    if (!(err <= 1e-9 * net) || !(ferr <= 1e-9 * count)) {
+    // (amplitudes of the test waves sum to < 40: the same absolute tolerance scale as the unit random field, times the wave amplitudes)
+    if (!(err <= 1e-9 * net) || !(ferr <= 4e-8 * count * (three_d ? 1 : Nz))) {
         ocn::set_error("rocFFT %s plan pair for %dx%dx%d failed its self test (round trip: max error %.3e; forward spectrum vs direct DFT: %.3e)",
                        s->c2c ? "complex" : "real", Nx, Ny, Nz, err, ferr);
         return OCN_ERR_ROCFFT;
@@ -673,7 +780,7 @@ static int dist_real_plans_self_test(ocn_dist_poisson *s)
     OCN_CHECK_HIP(hipMemcpy(s->rhs, in.data(), n * sizeof(double), hipMemcpyHostToDevice));
     int st = s->fyz.exec(s->rhs, s->yfield, nullptr);
     double ferr = 0.0;
-    if (st == OCN_SUCCESS) {  // known-answer check of the forward (y, z) transform (see spectrum_sample_error): column xl, entry (ky, kz)
+    if (st == OCN_SUCCESS) {  // known-answer check of the forward (y, z) transform (samples; the serial handles check every entry): column xl, entry (ky, kz)
         if (hipDeviceSynchronize() != hipSuccess) st = OCN_ERR_ROCFFT;
         std::vector<double> sp((size_t)nx * s->nyt * Nz * 2);
         if (st == OCN_SUCCESS && hipMemcpy(sp.data(), s->yfield, sp.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) st = OCN_ERR_ROCFFT;

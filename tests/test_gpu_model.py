@@ -72,12 +72,14 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
 
 
 def test_two_solver_handles_coexist(oracle, ocn):
-    """Regression: with a 16^3 (P,P,P) solver alive, the real-to-complex rocFFT plans of a (32, 8, 16) (P,P,B) solver returned
-    garbage (a rocFFT plan-cache interaction); every plan pair is now round-trip tested at creation and replaced by complex
-    plans if it fails.  Both handles must solve correctly, in either creation order."""
+    """Regression for the rocFFT (ROCm 7.2) real-plan collision (tools/rocfft_repro.hip, profiles/r02_rocfft_repro.md): with a
+    16^3 (P,P,P) solver alive, the real-to-complex plans of a (32, 8, k) solver come out wrong -- power-of-two pairs whose 2-D kernel
+    lengths (Nx/2, Ny) are the transpose of a live plan's; the EARLIER plan stays correct.  Every new plan pair is verified over its
+    full spectrum at creation (plane waves + a host DFT) and replaced by complex plans if it fails.  Both handles must solve
+    correctly in either creation order, and the first one must still be correct after the second has been created."""
     O = oracle
 
-    def residual(size, topo, z, keep):
+    def make(size, topo, z):
         og, pg = make_pair(O, ocn, size, topo, x=(0, 64), y=(0, 64), z=z)
         rng = np.random.default_rng(1)
         U = []
@@ -89,20 +91,27 @@ def test_two_solver_handles_coexist(oracle, ocn):
         R = O.divergence(og, *U)
         dU = [to_dev(ocn, pg, l, a) for l, a in zip((1, 2, 4), U)]
         S = ocn.nonhydrostatic_pressure_solver(pg)
-        keep.append(S)
-        p = ocn.CenterField(pg)
-        ocn.solve_for_pressure(p, S, 1.0, dU)
-        ocn.fill_halo_regions(p)
-        ocn.sync_device()
-        return np.linalg.norm(O.laplacian(og, from_dev(p)) - R) / np.linalg.norm(R)
+
+        def residual():
+            p = ocn.CenterField(pg)
+            ocn.solve_for_pressure(p, S, 1.0, dU)
+            ocn.fill_halo_regions(p)
+            ocn.sync_device()
+            return np.linalg.norm(O.laplacian(og, from_dev(p)) - R) / np.linalg.norm(R)
+
+        return S, residual
 
     A = ((16, 16, 16), "PPP", (0, 64))
     B = ((32, 8, 16), "PPB", stretched_faces(16, 32.0))
-    for order in ((A, B), (B, A)):
-        keep = []
-        for case in order:
-            assert residual(*case, keep) < 1e-12
-        del keep
+    C = ((32, 8, 8), "PPP", (0, 64))          # the exact pair of the standalone reproduction: 16^3 3-D, then 32 x 8 batched over 8
+    D = ((16, 16, 4), "PPB", (-4.0, 0.0))
+    for order in ((A, B), (B, A), (A, C), (C, A), (D, C), (A, B, C, D)):
+        handles = [make(*case) for case in order]
+        for _, residual in handles:               # every handle, after ALL of them exist
+            assert residual() < 1e-12
+        for _, residual in reversed(handles):
+            assert residual() < 1e-12
+        del handles
 
 
 def test_poisson_set_source_term(oracle, ocn):
