@@ -732,6 +732,14 @@ static int min_blocks()
     return v;
 }
 
+// the 3-wide buffer strips of a distributed run have few columns: shorter z-chunks put more workgroups in flight (they are latency
+// bound at one wave per SIMD otherwise)
+static int strip_min_kz()
+{
+    static const int v = getenv("OCN_STRIP_MIN_KZ") ? atoi(getenv("OCN_STRIP_MIN_KZ")) : 8;
+    return v;
+}
+
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 {
     if (range) {
@@ -815,7 +823,7 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
         constexpr int TX = 4, TY = 64;                                                                                           \
         const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));                                                \
         int KZ = wz;                                                                                                             \
-        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 1024) KZ = (KZ + 1) / 2;                                                 \
+        while (KZ > strip_min_kz() && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;                                     \
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);                                        \
         hipLaunchKernelGGL((momentum_tendencies_tiled<TZV, TX, TY, 3, false>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, \
                            Gw, r, KZ, fz);                                                                                        \
@@ -876,7 +884,7 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
         constexpr int TX = 4, TY = 64;
         const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
         int KZ = wz;
-        while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 1024) KZ = (KZ + 1) / 2;
+        while (KZ > strip_min_kz() && tiles * ((wz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;
         dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
         if (grid->tz == OCN_PERIODIC)
             hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);

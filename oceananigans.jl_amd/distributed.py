@@ -361,10 +361,9 @@ class Distributed:
         if compute_tendencies and pending is not None:
             # buffer_tendency_kernel_parameters (compute_nonhydrostatic_buffer_tendencies.jl:28-39)
             w1 = min(Hx, nx)
-            models.compute_tendencies_(model, (1, w1, 1, g.Ny, 1, g.Nz))
             e0 = max(nx - Hx + 1, w1 + 1)
-            if e0 <= nx:
-                models.compute_tendencies_(model, (e0, nx, 1, g.Ny, 1, g.Nz))
+            self._two_strips(lambda rng: models.compute_tendencies_(model, rng), (1, w1, 1, g.Ny, 1, g.Nz),
+                             (e0, nx, 1, g.Ny, 1, g.Nz) if e0 <= nx else None)
 
     def update_state_general(self, model, launch):
         """update_state! of a model with the extra terms (hydrostatic pressure anomaly, eddy diffusivities): the exchange of the
@@ -402,10 +401,8 @@ class Distributed:
         if aux:
             self.ops.local_fill(g, aux, True)
         w1 = min(Hx, nx)
-        launch((1, w1, 1, g.Ny, 1, g.Nz))
         e0 = max(nx - Hx + 1, w1 + 1)
-        if e0 <= nx:
-            launch((e0, nx, 1, g.Ny, 1, g.Nz))
+        self._two_strips(launch, (1, w1, 1, g.Ny, 1, g.Nz), (e0, nx, 1, g.Ny, 1, g.Nz) if e0 <= nx else None)
 
     def update_state_fused(self, model, launch, fill_halos=True):
         """update_state! + the next rk3 substep with the fused launch: same interior / buffer split and overlap as update_state."""
@@ -423,10 +420,29 @@ class Distributed:
             launch((Hx + 1, nx - Hx, 1, g.Ny, 1, g.Nz))
         self.finish_halo_exchange()
         w1 = min(Hx, nx)
-        launch((1, w1, 1, g.Ny, 1, g.Nz))
         e0 = max(nx - Hx + 1, w1 + 1)
-        if e0 <= nx:
-            launch((e0, nx, 1, g.Ny, 1, g.Nz))
+        self._two_strips(launch, (1, w1, 1, g.Ny, 1, g.Nz), (e0, nx, 1, g.Ny, 1, g.Nz) if e0 <= nx else None)
+
+    def _two_strips(self, launch, west, east):
+        """The west and east buffer strips (compute_nonhydrostatic_buffer_tendencies.jl:28-39) are independent and each too small to
+        fill the chip (3 x Ny x Nz cells): the east one runs on a side stream next to the west one.  Ordered by events against the
+        compute stream on both sides; OCN_DIST_CONCURRENT_STRIPS=0 runs them one after the other."""
+        if east is None:
+            return launch(west)
+        if not torch.cuda.is_available() or os.environ.get("OCN_DIST_CONCURRENT_STRIPS", "1") == "0" or getattr(self.ops, "name", "") != "hip":
+            launch(west)
+            return launch(east)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+            self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
+        self._fork.record(cur)
+        self._side_stream.wait_event(self._fork)
+        with torch.cuda.stream(self._side_stream):
+            launch(east)
+            self._join.record(self._side_stream)
+        launch(west)
+        cur.wait_event(self._join)
 
     def pressure_solver(self, grid):
         if grid.topology[2] == Bounded:
