@@ -232,8 +232,6 @@ def main():
     N = a.n
     comm_info = None
     if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":  # the env var exercises the RCCL path on one rank
-        if a.workload == "config5":
-            raise SystemExit("config5 is single-GPU in this round (the hydrostatic model is not slab-distributed yet)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -342,6 +342,18 @@ int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, dou
 int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
                                         double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
                                         double *V_filtered, const double *GU, const double *GV, double *work, void *stream);
+/* The substep loop on a slab-x rank: DistributedSplitExplicitFreeSurface (distributed_split_explicit_free_surface.jl: the x halos of
+ * eta, U, V, GU, GV are extended to the number of substeps and filled ONCE per baroclinic step; the substeps then run without
+ * communication over ranges that reach into the halos).  W = n (the number of substeps; needs W <= Nx of the slab).
+ *   _begin: gathers the interiors into wide work planes and packs the W-wide west / east strips of the 5 planes
+ *           (5 W Ny doubles per side) -> exchange them with the x neighbours (ocn_comm_exchange_strips, or any transport)
+ *   _run:   received strips -> wide halos, temporally blocked substeps over shrinking ranges, interior averages -> eta, U, V.
+ * work: 11 (Nx + 2 W) Ny doubles.  Interior results are bit-identical to the single-rank substepping. */
+int ocn_split_explicit_dist_begin(const ocn_grid *grid, int32_t n, const double *eta, const double *U, const double *V, const double *GU,
+                                  const double *GV, double *work, double *send_west, double *send_east, void *stream);
+int ocn_split_explicit_dist_run(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                double column_depth, double *eta, double *U, double *V, double *work, const double *recv_west,
+                                const double *recv_east, void *stream);
 /* One pass over the columns for the whole horizontal-momentum part of a QuasiAdamsBashforth2 step of the HydrostaticFreeSurfaceModel
  * with momentum_advection = VectorInvariant():
  *   compute_hydrostatic_free_surface_Gu!/Gv! (hydrostatic_free_surface_tendency_kernel_functions.jl:29-97; all terms of `terms` and the
@@ -481,6 +493,9 @@ int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const
 int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
 /* one x plane from a neighbour, in stream order (side 0: field[nx+1] <- east neighbour's field[1]; 1: field[0] <- west's field[nx]) */
 int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field, int32_t loc, int32_t side, void *stream);
+/* one contiguous strip per x neighbour, in stream order: send_west -> rank - 1 (arrives as its recv_east), send_east -> rank + 1 */
+int ocn_comm_exchange_strips(ocn_comm_t comm, const double *send_west, const double *send_east, double *recv_west, double *recv_east,
+                             size_t count, void *stream);
 /* Alltoallv! with equal counts: chunk d of `send` (count doubles) goes to rank d, chunk s of `recv` comes from rank s; stream order */
 int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream);
 /* transpose_y_to_x! (direction 0) / transpose_x_to_y! (direction 1) of a distributed Poisson handle's exchange buffers */

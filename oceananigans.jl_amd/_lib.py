@@ -142,6 +142,9 @@ _SIGS = {
     "ocn_halo_exchange_end": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],
     "ocn_halo_exchange_plane": [_vp, C.POINTER(CGrid), _vp, _i32, _i32, _vp],
     "ocn_comm_all_to_all": [_vp, _vp, _vp, C.c_size_t, _vp],
+    "ocn_comm_exchange_strips": [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp],
+    "ocn_split_explicit_dist_begin": [C.POINTER(CGrid), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_split_explicit_dist_run": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_dist_poisson_exchange": [_vp, _vp, _i32, _vp],
     "ocn_comm_allreduce": [_vp, _vp, C.c_size_t, _i32, _vp],
     "ocn_comm_barrier": [_vp],

@@ -308,11 +308,13 @@ static int validate_hydrostatic(const ocn_grid *grid, const char *who)
 {
     int st = validate_grid(grid);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC && grid->tz == OCN_BOUNDED,
+    // x may be the partitioned direction of a slab-x rank (FullyConnected: halos come from the neighbours, interior arithmetic as Periodic)
+    OCN_REQUIRE((grid->tx == OCN_PERIODIC || grid->tx == OCN_FULLY_CONNECTED) && grid->ty == OCN_PERIODIC && grid->tz == OCN_BOUNDED,
                 "%s: the hydrostatic slice supports (Periodic, Periodic, Bounded) grids", who);
     OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1, "%s: needs x, y halos", who);
     return OCN_SUCCESS;
 }
+#define OCN_REQUIRE_PERIODIC_X(who) OCN_REQUIRE(grid->tx == OCN_PERIODIC, "%s wraps x periodically: not for a partitioned (FullyConnected) x", who)
 int ocn_compute_vector_invariant_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                                      double *Gv, const double *eta, double gravitational_acceleration, void *stream)
 {
@@ -336,6 +338,7 @@ int ocn_split_explicit_substeps(const ocn_grid *grid, int32_t n, const double *w
 {
     int st = validate_hydrostatic(grid, "ocn_split_explicit_substeps");
     if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE_PERIODIC_X("ocn_split_explicit_substeps");
     OCN_REQUIRE(n >= 1 && weights, "ocn_split_explicit_substeps: needs n >= 1 averaging weights (host array)");
     OCN_REQUIRE(eta && U && V && eta_filtered && U_filtered && V_filtered && GU && GV, "ocn_split_explicit_substeps: null pointer");
     return launch_split_explicit_substeps(grid, n, weights, dtau, gravitational_acceleration, column_depth, eta, U, V, eta_filtered, U_filtered,
@@ -599,10 +602,41 @@ int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const d
 {
     int st = validate_hydrostatic(grid, "ocn_split_explicit_substeps_blocked");
     if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE_PERIODIC_X("ocn_split_explicit_substeps_blocked");
     OCN_REQUIRE(n >= 1 && weights, "ocn_split_explicit_substeps_blocked: needs n >= 1 averaging weights (host array)");
     OCN_REQUIRE(eta && U && V && eta_filtered && U_filtered && V_filtered && GU && GV && work, "ocn_split_explicit_substeps_blocked: null pointer");
     return launch_split_explicit_substeps_blocked(grid, n, weights, dtau, gravitational_acceleration, column_depth, eta, U, V, eta_filtered,
                                                   U_filtered, V_filtered, GU, GV, work, as_stream(stream));
+}
+
+static int validate_hydrostatic_slab(const ocn_grid *grid, const char *who)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE((grid->tx == OCN_PERIODIC || grid->tx == OCN_FULLY_CONNECTED) && grid->ty == OCN_PERIODIC && grid->tz == OCN_BOUNDED,
+                "%s: (Periodic | FullyConnected, Periodic, Bounded) grids", who);
+    return OCN_SUCCESS;
+}
+int ocn_split_explicit_dist_begin(const ocn_grid *grid, int32_t n, const double *eta, const double *U, const double *V, const double *GU,
+                                  const double *GV, double *work, double *send_west, double *send_east, void *stream)
+{
+    int st = validate_hydrostatic_slab(grid, "ocn_split_explicit_dist_begin");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(n >= 1 && n <= grid->Nx, "ocn_split_explicit_dist_begin: the number of substeps (%d) must not exceed the slab's Nx (%d): the extended halo "
+                "would reach past the neighbouring rank", n, grid->Nx);
+    OCN_REQUIRE(eta && U && V && GU && GV && work && send_west && send_east, "ocn_split_explicit_dist_begin: null pointer");
+    return launch_split_explicit_dist_begin(grid, n, eta, U, V, GU, GV, work, send_west, send_east, as_stream(stream));
+}
+int ocn_split_explicit_dist_run(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                double column_depth, double *eta, double *U, double *V, double *work, const double *recv_west,
+                                const double *recv_east, void *stream)
+{
+    int st = validate_hydrostatic_slab(grid, "ocn_split_explicit_dist_run");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(n >= 1 && n <= grid->Nx && weights, "ocn_split_explicit_dist_run: needs 1 <= n <= Nx averaging weights (host array)");
+    OCN_REQUIRE(eta && U && V && work && recv_west && recv_east, "ocn_split_explicit_dist_run: null pointer");
+    return launch_split_explicit_dist_run(grid, n, n, weights, dtau, gravitational_acceleration, column_depth, eta, U, V, work, recv_west,
+                                          recv_east, as_stream(stream));
 }
 
 int ocn_hydrostatic_momentum_ab2_step(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
@@ -611,7 +645,7 @@ int ocn_hydrostatic_momentum_ab2_step(const ocn_grid *grid, const ocn_model_term
                                       double chi, int32_t euler, const double *eta, double gravitational_acceleration, double *GU,
                                       double *GV, double *U_star, double *V_star, void *stream)
 {
-    int st = validate_hydrostatic(grid, "ocn_hydrostatic_momentum_ab2_step");
+    int st = validate_hydrostatic_slab(grid, "ocn_hydrostatic_momentum_ab2_step");
     if (st != OCN_SUCCESS) return st;
     st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;

@@ -265,6 +265,19 @@ int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field
     return launch_halo_plane_x(grid, field, loc, east ? 1 : 0, c->plane[1], 1, s);
 }
 
+// one strip per x neighbour in stream order (the wide halos of the split-explicit substepping, ocn_split_explicit_dist_*)
+int ocn_comm_exchange_strips(ocn_comm_t comm, const double *send_west, const double *send_east, double *recv_west, double *recv_east,
+                             size_t count, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && send_west && send_east && recv_west && recv_east, "ocn_comm_exchange_strips: null pointer");
+    hipStream_t keep = c->stream;
+    c->stream = as_stream(stream);  // post_exchange issues on c->stream
+    int st = post_exchange(c, send_west, send_east, recv_west, recv_east, count);
+    c->stream = keep;
+    return st;
+}
+
 // Alltoallv! with equal counts (distributed_transpose.jl:188; transposable_field.jl:94-98): chunk d of `send` goes to rank d, chunk
 // s of `recv` comes from rank s; `count` doubles per peer.  In stream order on `stream`.
 int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream)

@@ -496,6 +496,16 @@ int launch_barotropic_corrector(const ocn_grid *grid, double *u, double *v, cons
 // centre stays exact.  Every cell is updated with the text of split_explicit_eta_kernel / split_explicit_velocity_kernel, so the
 // result is bit-identical; the filtered state accumulates in registers for the centre cells in substep order.  Launches
 // ping-pong between (η, U, V) and a workspace because neighbouring workgroups read each other's centre cells at load time.
+// The (η, U, V, Gᵁ, Gⱽ, filtered state) planes the kernel works on: nx x ny interior cells with x / y halos hx / hy (row stride nx + 2 hx).
+// Single rank: the model's own planes (hx = grid.Hx), x wraps periodically.  Slab-x ranks (DistributedSplitExplicitFreeSurface,
+// distributed_split_explicit_free_surface.jl: halos extended to the number of substeps, no communication while substepping): wide work
+// planes with hx = W >= the number of substeps, x does NOT wrap; launch l owns the cells x0 <= i < x1 that are still exact after its
+// substeps (the owned range shrinks by the substeps of each launch and ends at the interior).
+struct PlaneLay {
+    int nx, ny, hx, hy;
+    int x0, x1;   // owned range, 0-based interior index (may extend into the x halo)
+    int wrap_x;
+};
 template <int SH>
 struct SubstepArgs {
     int nsub, first, write_state;
@@ -505,25 +515,26 @@ struct SubstepArgs {
     double *eta_out, *U_out, *V_out, *etab, *Ub, *Vb;
 };
 template <int TXO, int TYO, int SH>
-__global__ __launch_bounds__(256) void split_explicit_blocked_kernel(GridDev g, SubstepArgs<SH> a)
+__global__ __launch_bounds__(256) void split_explicit_blocked_kernel(double dx, double dy, PlaneLay P, SubstepArgs<SH> a)
 {
     constexpr int W = TXO + 2 * SH, HH = TYO + 2 * SH, NC = W * HH, NQ = (NC + 255) / 256;
     __shared__ double Le[NC], LU[NC], LV[NC];  // Gᵁ, Gⱽ of a cell are only read by the thread that updates it: registers
     const int tid = threadIdx.x;
-    const int i0 = blockIdx.x * TXO, j0 = blockIdx.y * TYO;  // 0-based interior origin of the centre
-    const int sx = g.Nx + 2 * g.Hx;
-    const double dx = g.dx, dy = g.dy, Az = dx * dy;
+    const int i0 = P.x0 + blockIdx.x * TXO, j0 = blockIdx.y * TYO;  // 0-based interior origin of the centre
+    const int sx = P.nx + 2 * P.hx;
+    const double Az = dx * dy;
     long long gp[NQ];   // plane offset of each of this thread's cells
-    bool own[NQ];       // centre cell inside the domain: accumulates the filtered state and is written back
+    bool own[NQ];       // centre cell inside the owned range: accumulates the filtered state and is written back
     double ae[NQ], aU[NQ], aV[NQ], gU[NQ], gV[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = tid + 256 * q;
         const int lx = c % W, ly = c / W;
         const int ui = i0 + lx - SH, uj = j0 + ly - SH;                       // unwrapped 0-based interior indices
-        const int gi = ((ui % g.Nx) + g.Nx) % g.Nx, gj = ((uj % g.Ny) + g.Ny) % g.Ny;
-        gp[q] = (gi + g.Hx) + (long long)sx * (gj + g.Hy);
-        own[q] = c < NC && lx >= SH && lx < SH + TXO && ly >= SH && ly < SH + TYO && ui < g.Nx && uj < g.Ny;
+        const int gi = P.wrap_x ? ((ui % P.nx) + P.nx) % P.nx : min(max(ui, -P.hx), P.nx + P.hx - 1);
+        const int gj = ((uj % P.ny) + P.ny) % P.ny;
+        gp[q] = (gi + P.hx) + (long long)sx * (gj + P.hy);
+        own[q] = c < NC && lx >= SH && lx < SH + TXO && ly >= SH && ly < SH + TYO && ui < P.x1 && uj < P.ny;
         if (c < NC) {
             Le[c] = a.eta_in[gp[q]];
             LU[c] = a.U_in[gp[q]];
@@ -594,19 +605,18 @@ __global__ __launch_bounds__(256) void split_explicit_update_state_kernel(GridDe
     U[e] = Ub[e];
     V[e] = Vb[e];
 }
-int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
-                                           double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
-                                           double *work, hipStream_t stream)
+// the launch sequence over planes of layout P0 (x0 / x1 are set per launch): set[0] holds the state on entry, set[1] is scratch
+static int run_blocked_substeps(double dx, double dy, PlaneLay P0, int halo_valid, int n, const double *weights, double dtau, double grav, double H,
+                                double *const set0[3], double *const set1[3], double *etab, double *Ub, double *Vb, const double *GU,
+                                const double *GV, hipStream_t stream)
 {
     constexpr int TXO = 64, TYO = 16, SH = 4;
-    GridDev g = to_dev(*grid);
-    const long long plane = (long long)(g.Nx + 2 * g.Hx) * (g.Ny + 2 * g.Hy);
-    double *set[2][3] = {{eta, U, V}, {work, work + plane, work + 2 * plane}};
-    dim3 nb((g.Nx + TXO - 1) / TXO, (g.Ny + TYO - 1) / TYO, 1);
-    int cur = 0;
+    double *const *set[2] = {set0, set1};
+    int cur = 0, done = 0;
     for (int m0 = 0; m0 < n; m0 += SH) {
         SubstepArgs<SH> a{};
         a.nsub = n - m0 < SH ? n - m0 : SH;
+        done += a.nsub;
         a.first = m0 == 0;
         a.write_state = m0 + SH < n;  // the last launch only leaves the averages
         for (int q = 0; q < a.nsub; ++q) a.w[q] = weights[m0 + q];
@@ -614,12 +624,98 @@ int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const do
         a.eta_in = set[cur][0]; a.U_in = set[cur][1]; a.V_in = set[cur][2];
         a.eta_out = set[1 - cur][0]; a.U_out = set[1 - cur][1]; a.V_out = set[1 - cur][2];
         a.GU = GU; a.GV = GV; a.etab = etab; a.Ub = Ub; a.Vb = Vb;
-        hipLaunchKernelGGL((split_explicit_blocked_kernel<TXO, TYO, SH>), nb, dim3(256), 0, stream, g, a);
+        PlaneLay P = P0;
+        if (!P.wrap_x) {  // the cells still exact after `done` substeps
+            P.x0 = -(halo_valid - done);
+            P.x1 = P.nx + (halo_valid - done);
+        }
+        dim3 nb((P.x1 - P.x0 + TXO - 1) / TXO, (P.ny + TYO - 1) / TYO, 1);
+        hipLaunchKernelGGL((split_explicit_blocked_kernel<TXO, TYO, SH>), nb, dim3(256), 0, stream, dx, dy, P, a);
         cur = 1 - cur;
     }
     OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                           double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                           double *work, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const long long plane = (long long)(g.Nx + 2 * g.Hx) * (g.Ny + 2 * g.Hy);
+    double *const set0[3] = {eta, U, V}, *const set1[3] = {work, work + plane, work + 2 * plane};
+    PlaneLay P{g.Nx, g.Ny, g.Hx, g.Hy, 0, g.Nx, 1};
+    int st = run_blocked_substeps(g.dx, g.dy, P, 0, n, weights, dtau, grav, H, set0, set1, etab, Ub, Vb, GU, GV, stream);
+    if (st != OCN_SUCCESS) return st;
     dim3 block(64, 4, 1), nb2((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
     hipLaunchKernelGGL(split_explicit_update_state_kernel, nb2, block, 0, stream, g, eta, U, V, etab, Ub, Vb);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// ---- slab-x ranks: DistributedSplitExplicitFreeSurface (distributed_split_explicit_free_surface.jl) ----------------------------------
+// The reference extends the x halos of η, U, V, Gᵁ, Gⱽ to the number of substeps, fills them ONCE per baroclinic step and substeps
+// without communication over kernel ranges that reach into the halos (:29-66 there; split_explicit_free_surface.jl:283-300).  Here
+// the wide planes are work buffers of (nx + 2 W) x Ny cells, W = number of substeps (no y halo: y wraps inside the kernel):
+//   begin: interiors -> wide planes; the W-wide west / east interior strips of the 5 planes -> send buffers (plane p, row j, column c at
+//          c + W (j + Ny p));  [the caller exchanges them with the x neighbours: west strip -> west neighbour's east halo]
+//   run:   received strips -> wide halos; the blocked launches over shrinking owned ranges; interior averages -> η, U, V
+// work: 11 wide planes (η, U, V twice for the ping-pong, Gᵁ, Gⱽ, filtered η, U, V).
+__global__ __launch_bounds__(256) void dist_planes_kernel(int nx, int Ny, int Hx, int Hy, int W, int mode, const double *__restrict__ e,
+                                                          const double *__restrict__ U, const double *__restrict__ V,
+                                                          const double *__restrict__ GU, const double *__restrict__ GV,
+                                                          double *__restrict__ work, double *__restrict__ west, double *__restrict__ east,
+                                                          double *__restrict__ eo, double *__restrict__ Uo, double *__restrict__ Vo)
+{
+    // mode 0: gather (model planes -> wide planes + send strips); 1: scatter received strips into the wide halos;
+    // 2: the filtered state of the interior -> η, U, V of the model
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, p = blockIdx.z;
+    const int sxw = nx + 2 * W, sxm = nx + 2 * Hx;
+    const long long wplane = (long long)sxw * Ny;
+    if (mode == 0) {
+        if (c >= nx) return;
+        const double *src = p == 0 ? e : p == 1 ? U : p == 2 ? V : p == 3 ? GU : GV;
+        const double v = src[(c + Hx) + (long long)sxm * (j + Hy)];
+        const int slot = p < 3 ? p : p + 3;  // η, U, V -> planes 0..2 (set 0); Gᵁ, Gⱽ -> planes 6, 7
+        work[slot * wplane + (c + W) + (long long)sxw * j] = v;
+        if (c < W) west[c + (long long)W * (j + (long long)Ny * p)] = v;
+        if (c >= nx - W) east[(c - (nx - W)) + (long long)W * (j + (long long)Ny * p)] = v;
+    } else if (mode == 1) {
+        if (c >= W) return;
+        const int slot = p < 3 ? p : p + 3;
+        const long long o = c + (long long)W * (j + (long long)Ny * p);
+        work[slot * wplane + c + (long long)sxw * j] = west[o];                 // west halo: columns -W .. -1
+        work[slot * wplane + (nx + W + c) + (long long)sxw * j] = east[o];      // east halo: columns nx .. nx + W - 1
+    } else {
+        if (c >= nx || p >= 3) return;
+        double *dst = p == 0 ? eo : p == 1 ? Uo : Vo;
+        dst[(c + Hx) + (long long)sxm * (j + Hy)] = work[(8 + p) * wplane + (c + W) + (long long)sxw * j];
+    }
+}
+int launch_split_explicit_dist_begin(const ocn_grid *grid, int W, const double *eta, const double *U, const double *V, const double *GU,
+                                     const double *GV, double *work, double *send_west, double *send_east, hipStream_t stream)
+{
+    dim3 nb((grid->Nx + 255) / 256, grid->Ny, 5);
+    hipLaunchKernelGGL(dist_planes_kernel, nb, dim3(256), 0, stream, grid->Nx, grid->Ny, grid->Hx, grid->Hy, W, 0, eta, U, V, GU, GV, work,
+                       send_west, send_east, nullptr, nullptr, nullptr);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+int launch_split_explicit_dist_run(const ocn_grid *grid, int W, int n, const double *weights, double dtau, double grav, double H, double *eta,
+                                   double *U, double *V, double *work, const double *recv_west, const double *recv_east, hipStream_t stream)
+{
+    const int nx = grid->Nx, Ny = grid->Ny;
+    const long long wplane = (long long)(nx + 2 * W) * Ny;
+    hipLaunchKernelGGL(dist_planes_kernel, dim3((W + 255) / 256, Ny, 5), dim3(256), 0, stream, nx, Ny, grid->Hx, grid->Hy, W, 1, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, work, const_cast<double *>(recv_west), const_cast<double *>(recv_east), nullptr, nullptr,
+                       nullptr);
+    OCN_CHECK_HIP(hipGetLastError());
+    double *const set0[3] = {work, work + wplane, work + 2 * wplane}, *const set1[3] = {work + 3 * wplane, work + 4 * wplane, work + 5 * wplane};
+    PlaneLay P{nx, Ny, W, 0, 0, nx, 0};
+    int st = run_blocked_substeps(grid->dx, grid->dy, P, W, n, weights, dtau, grav, H, set0, set1, work + 8 * wplane, work + 9 * wplane,
+                                  work + 10 * wplane, work + 6 * wplane, work + 7 * wplane, stream);
+    if (st != OCN_SUCCESS) return st;
+    hipLaunchKernelGGL(dist_planes_kernel, dim3((nx + 255) / 256, Ny, 3), dim3(256), 0, stream, nx, Ny, grid->Hx, grid->Hy, W, 2, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, work, nullptr, nullptr, eta, U, V);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

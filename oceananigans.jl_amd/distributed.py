@@ -108,6 +108,10 @@ class RcclFabric:
     def halo_exchange_plane(self, grid, f, side):
         _lib.call("ocn_halo_exchange_plane", self._h, grid.cref, f.ptr, f.loc, 0 if side == "east" else 1, stream_ptr())
 
+    def exchange_strips(self, send_west, send_east, recv_west, recv_east):
+        _lib.call("ocn_comm_exchange_strips", self._h, send_west.data_ptr(), send_east.data_ptr(), recv_west.data_ptr(), recv_east.data_ptr(),
+                  send_west.numel(), stream_ptr())
+
     def dist_poisson_exchange(self, handle, direction):
         _lib.call("ocn_dist_poisson_exchange", handle, self._h, int(direction), stream_ptr())
 
@@ -318,6 +322,17 @@ class Distributed:
                                           [(rbuf, self.east_rank if east else self.west_rank)])
         self.fabric.wait(reqs)
         self.ops.plane_x(g, f, 1 if east else 0, rbuf, True)
+
+    def exchange_strips(self, send_west, send_east, recv_west, recv_east):
+        """One contiguous strip per x neighbour, synchronous in stream order: my west strip arrives as the west neighbour's recv_east.
+        (The wide halos of the split-explicit substepping, hydrostatic.py.)"""
+        if hasattr(self.fabric, "exchange_strips"):
+            return self.fabric.exchange_strips(send_west, send_east, recv_west, recv_east)
+        self.finish_halo_exchange()
+        sends = [(send_west, self.west_rank), (send_east, self.east_rank)]
+        recvs = ([(recv_west, self.west_rank), (recv_east, self.east_rank)] if self.partition.x > 2
+                 else [(recv_east, self.east_rank), (recv_west, self.west_rank)])
+        self.fabric.wait(self.fabric.start_exchange(sends, recvs))
 
     def fill_halo_regions(self, fields, fbnv=True):
         """Local (y, z) fills first, communication last (fill_halo_regions.jl:148-196); synchronous."""

@@ -127,8 +127,11 @@ class HydrostaticFreeSurfaceModel:
         substep loop, one pass for the barotropic corrector + w, one halo launch, the hydrostatic pressure; the tendency evaluation
         that closes the reference's time_step! is deferred into the next step's fused launches (`flush_tendencies` completes it).
         fused = False keeps the reference's launch sequence.  Both are bit-identical in strict math."""
-        if tuple(grid.topology) != (Periodic, Periodic, Bounded) or hasattr(grid.architecture, "partition"):
-            raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids on one GPU in this slice")
+        from .grids import FullyConnected
+        arch = grid.architecture
+        self._dist = arch if (hasattr(arch, "partition") and arch.communicates) else None   # a slab-x rank (distributed.py)
+        if tuple(grid.topology) != (FullyConnected if self._dist is not None else Periodic, Periodic, Bounded):
+            raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids (x may be slab-partitioned)")
         if free_surface is None:
             # default_free_surface (hydrostatic_free_surface_model.jl:51-55): ImplicitFreeSurface on an xy-regular RectilinearGrid,
             # which this backend does not have -- refuse rather than silently pick different numerics
@@ -176,9 +179,13 @@ class HydrostaticFreeSurfaceModel:
         self._tracer_fusable = not isinstance(container_advection, Centered)    # the tiled WENO / UpwindBiased tracer kernel has the epilogue
         self._alt = None                                                        # second storage of u, v and the tracers
         self._tendencies_current = False                                        # Gⁿ holds the tendencies of the current state
+        if self._dist is not None and not (self.split and self.fused):
+            raise NotImplementedError("a slab-partitioned HydrostaticFreeSurfaceModel needs the fused step with a SplitExplicitFreeSurface "
+                                      "(DistributedSplitExplicitFreeSurface, distributed_split_explicit_free_surface.jl)")
         if self.split and self.fused:
             self._Us, self._Vs = torch.zeros_like(self.eta), torch.zeros_like(self.eta)   # Σ Δz u*, Σ Δz v*
             self._work = torch.zeros((3,) + tuple(self.eta.shape), dtype=torch.float64, device=dev)
+            self._dist_buffers = None
         self.update_state(compute_tendencies=False)
 
     # ---- helpers -------------------------------------------------------------------------------------------------------
@@ -285,7 +292,22 @@ class HydrostaticFreeSurfaceModel:
         args = (g.cref, len(self._weights), self._weights, frac * float(dt), fs.gravitational_acceleration, float(g.Lz), self.eta.data_ptr(),
                 self.U.data_ptr(), self.V.data_ptr(), self._etab.data_ptr(), self._Ub.data_ptr(), self._Vb.data_ptr(), self._GU.data_ptr(),
                 self._GV.data_ptr())
-        if self.fused:
+        if self._dist is not None:
+            # DistributedSplitExplicitFreeSurface: halos of η, U, V, Gᵁ, Gⱽ as wide as the number of substeps, ONE exchange per baroclinic
+            # step, no communication while substepping (distributed_split_explicit_free_surface.jl; split_explicit_free_surface.jl:283-300)
+            n = len(self._weights)
+            if self._dist_buffers is None or self._dist_buffers[0] != n:
+                dev = self.eta.device
+                strip = 5 * n * g.Ny
+                self._dist_buffers = (n, torch.zeros(11 * (g.Nx + 2 * n) * g.Ny, dtype=torch.float64, device=dev),
+                                      [torch.zeros(strip, dtype=torch.float64, device=dev) for _ in range(4)])
+            _, work, (sw, se, rw, re) = self._dist_buffers
+            _lib.call("ocn_split_explicit_dist_begin", g.cref, n, self.eta.data_ptr(), self.U.data_ptr(), self.V.data_ptr(), self._GU.data_ptr(),
+                      self._GV.data_ptr(), work.data_ptr(), sw.data_ptr(), se.data_ptr(), s)
+            self._dist.exchange_strips(sw, se, rw, re)
+            _lib.call("ocn_split_explicit_dist_run", g.cref, n, self._weights, frac * float(dt), fs.gravitational_acceleration, float(g.Lz),
+                      self.eta.data_ptr(), self.U.data_ptr(), self.V.data_ptr(), work.data_ptr(), rw.data_ptr(), re.data_ptr(), s)
+        elif self.fused:
             _lib.call("ocn_split_explicit_substeps_blocked", *args, self._work.data_ptr(), s)
         else:
             _lib.call("ocn_split_explicit_substeps", *args, s)
@@ -351,7 +373,13 @@ class HydrostaticFreeSurfaceModel:
         nh.timestepper._Gn, nh.timestepper._Gm = Gm, Gn                     # cache_previous_tendencies!: role swap
         # update_state!(model; compute_tendencies = false): halos (w's halo columns are periodic images of the interior ones computed
         # above), η halos, hydrostatic pressure; the tendencies follow in the next step's fused launches
-        fill_halo_regions((self.u, self.v, self.w) + tuple(self.tracers), fill_boundary_normal_velocities=False)
+        if self._dist is not None:
+            # slab-x rank: the x halos of u, v, T, S come from the neighbours; w (whose edge column needed the neighbour's corrected
+            # u) is then recomputed from continuity on every column, halos included, as the reference's update_state! does
+            fill_halo_regions((self.u, self.v) + tuple(self.tracers), fill_boundary_normal_velocities=False)
+            _lib.call("ocn_compute_w_from_continuity", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, s)
+        else:
+            fill_halo_regions((self.u, self.v, self.w) + tuple(self.tracers), fill_boundary_normal_velocities=False)
         self._fill_eta_halos()
         update_hydrostatic_pressure(nh)
         self._tendencies_current = False

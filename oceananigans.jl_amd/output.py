@@ -88,45 +88,119 @@ def _names(model):
     return ("u", "v", "w") + tuple(model.tracer_names)
 
 
+def _rank_path(model, filepath):
+    """Distributed architectures write one file per rank: `name_rank$r` (output_writer_utils.jl:223-224)."""
+    arch = model.grid.architecture
+    filepath = str(filepath)
+    if hasattr(arch, "partition"):
+        root, ext = (filepath[:-4], ".npz") if filepath.endswith(".npz") else (filepath, "")
+        if not root.endswith(f"_rank{arch.local_rank}"):
+            filepath = f"{root}_rank{arch.local_rank}{ext}"
+    return filepath
+
+
+def _grid_signature(g):
+    """What set!(model, filepath) compares (checkpointer.jl:241-246 compares the whole grid): sizes, halos, topology, extents, z faces."""
+    zf = g._dzc_host if getattr(g, "_dzc_host", None) is not None else np.array([g.dz])  # the cell spacings pin the z faces
+    return {"size_halo": np.array([g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz], dtype=np.int64),
+            "topology": np.array([str(t) for t in g.topology]),
+            "extent": np.array([g.dx, g.dy, g.Lx, g.Ly, g.Lz], dtype=np.float64),
+            "z_spacings": np.asarray(zf, dtype=np.float64)}
+
+
+def _check_grid(z, g, filepath):
+    sig = _grid_signature(g)
+    for k, v in sig.items():
+        key = f"{ADDR}/grid/{k}"
+        if key not in z.files:
+            if k == "size_halo":
+                raise ValueError(f"{filepath} holds no grid")
+            continue  # a checkpoint of round 1 (sizes and halos only)
+        same = (v.shape == z[key].shape) and (np.array_equal(v, z[key]) if v.dtype.kind in "iUS" else np.array_equal(v, z[key]))
+        if not same:
+            raise ValueError(f"The grid associated with {filepath} and model.grid are not the same! ({k} differs)")
+
+
+def _is_hydrostatic(model):
+    return hasattr(model, "free_surface")
+
+
 def write_checkpoint(model, filepath):
-    """write_output!(::Checkpointer, model): prognostic fields, tendencies and clock."""
-    from .models import flush_tendencies
-    flush_tendencies(model)  # Gⁿ must hold the tendencies of the current state, as after the reference's time_step!
+    """write_output!(::Checkpointer, model): the reference's checkpointed properties (checkpointer.jl:10-18, 177-201) -- prognostic
+    fields (parents, halos included), timestepper Gⁿ / G⁻, clock -- plus the grid signature.  HydrostaticFreeSurfaceModel: also η, the
+    barotropic velocities U, V and Gηⁿ / Gη⁻ (its prognostic_fields and timestepper tendencies, hydrostatic_free_surface_model.jl)."""
+    filepath = _rank_path(model, filepath)
     out = {}
-    ts = model.timestepper
-    for name, f, Gn, Gm in zip(_names(model), model.prognostic_fields(), ts._Gn, ts._Gm):
+    if _is_hydrostatic(model):
+        model.flush_tendencies()
+        nh = model._nh
+        ts, names, fields = nh.timestepper, ("u", "v") + tuple(model.tracer_names), [model.u, model.v] + list(model.tracers)
+        idx = [0, 1] + [3 + n for n in range(len(model.tracers))]
+        Gn, Gm = [ts._Gn[q] for q in idx], [ts._Gm[q] for q in idx]
+        out[f"{ADDR}/η/data"] = model.eta.cpu().numpy().T
+        out[f"{ADDR}/timestepper/Gⁿ/η/data"] = model._Geta.cpu().numpy().T
+        out[f"{ADDR}/timestepper/G⁻/η/data"] = model._Geta_m.cpu().numpy().T
+        if model.split:
+            out[f"{ADDR}/U/data"] = model.U.cpu().numpy().T
+            out[f"{ADDR}/V/data"] = model.V.cpu().numpy().T
+            out[f"{ADDR}/free_surface/initialized"] = np.int64(model._initialized)
+    else:
+        from .models import flush_tendencies
+        flush_tendencies(model)  # Gⁿ must hold the tendencies of the current state, as after the reference's time_step!
+        ts, names, fields = model.timestepper, _names(model), model.prognostic_fields()
+        Gn, Gm = ts._Gn, ts._Gm
+    for name, f, gn, gm in zip(names, fields, Gn, Gm):
         out[f"{ADDR}/{name}/data"] = f.parent()
-        out[f"{ADDR}/timestepper/Gⁿ/{name}/data"] = Gn.parent()
-        out[f"{ADDR}/timestepper/G⁻/{name}/data"] = Gm.parent()
+        out[f"{ADDR}/timestepper/Gⁿ/{name}/data"] = gn.parent()
+        out[f"{ADDR}/timestepper/G⁻/{name}/data"] = gm.parent()
     c = model.clock
     out[f"{ADDR}/clock/time"] = np.float64(c.time)
     out[f"{ADDR}/clock/iteration"] = np.int64(c.iteration)
     out[f"{ADDR}/clock/last_Δt"] = np.float64(c.last_dt)
-    g = model.grid
-    out[f"{ADDR}/grid/size_halo"] = np.array([g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz], dtype=np.int64)
+    for k, v in _grid_signature(model.grid).items():
+        out[f"{ADDR}/grid/{k}"] = v
     np.savez(filepath, **out)
     return filepath
 
 
 def set_from_checkpoint(model, filepath):
-    """set!(model, filepath): restores parents (halos included), Gⁿ/G⁻ (both steppers; RK3 ignores them in the reference
-    because it is self-starting, restoring them is harmless) and the clock, then update_state!."""
-    from .models import flush_tendencies, update_state
-    flush_tendencies(model)
+    """set!(model, filepath) (checkpointer.jl:220-288): restores parents (halos included), Gⁿ / G⁻ (both steppers; RK3 ignores them in
+    the reference because it is self-starting, restoring them is harmless) and the clock, then update_state!."""
+    filepath = _rank_path(model, filepath)
+    hyd = _is_hydrostatic(model)
+    if not hyd:
+        from .models import flush_tendencies, update_state
+        flush_tendencies(model)
     with np.load(filepath if str(filepath).endswith(".npz") else str(filepath) + ".npz") as z:
-        g = model.grid
-        sh = z[f"{ADDR}/grid/size_halo"]
-        if tuple(sh) != (g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz):
-            raise ValueError(f"The grid associated with {filepath} and model.grid are not the same!")
-        ts = model.timestepper
+        _check_grid(z, model.grid, filepath)
 
-        def put(field, key):
+        def put_tensor(t, key):
             if key in z.files:
-                field.data.copy_(torch.from_numpy(np.ascontiguousarray(z[key].T)))
+                t.copy_(torch.from_numpy(np.ascontiguousarray(z[key].T)))
                 return True
             return False
 
-        for name, f, Gn, Gm in zip(_names(model), model.prognostic_fields(), ts._Gn, ts._Gm):
+        def put(field, key):
+            return put_tensor(field.data, key)
+
+        if hyd:
+            nh = model._nh
+            ts, names, fields = nh.timestepper, ("u", "v") + tuple(model.tracer_names), [model.u, model.v] + list(model.tracers)
+            idx = [0, 1] + [3 + n for n in range(len(model.tracers))]
+            Gns, Gms = [ts._Gn[q] for q in idx], [ts._Gm[q] for q in idx]
+            if not put_tensor(model.eta, f"{ADDR}/η/data"):
+                raise KeyError("Field η does not exist in checkpoint and could not be restored.")
+            put_tensor(model._Geta, f"{ADDR}/timestepper/Gⁿ/η/data")
+            put_tensor(model._Geta_m, f"{ADDR}/timestepper/G⁻/η/data")
+            if model.split:
+                put_tensor(model.U, f"{ADDR}/U/data")
+                put_tensor(model.V, f"{ADDR}/V/data")
+                if f"{ADDR}/free_surface/initialized" in z.files:
+                    model._initialized = bool(int(z[f"{ADDR}/free_surface/initialized"]))
+        else:
+            ts, names, fields = model.timestepper, _names(model), model.prognostic_fields()
+            Gns, Gms = ts._Gn, ts._Gm
+        for name, f, Gn, Gm in zip(names, fields, Gns, Gms):
             if not put(f, f"{ADDR}/{name}/data"):
                 raise KeyError(f"Field {name} does not exist in checkpoint and could not be restored.")
             put(Gn, f"{ADDR}/timestepper/Gⁿ/{name}/data")
@@ -134,5 +208,8 @@ def set_from_checkpoint(model, filepath):
         model.clock.time = float(z[f"{ADDR}/clock/time"])
         model.clock.iteration = int(z[f"{ADDR}/clock/iteration"])
         model.clock.last_dt = float(z[f"{ADDR}/clock/last_Δt"])
-    update_state(model, compute_tendencies=False)
+    if hyd:
+        model.update_state(compute_tendencies=False)
+    else:
+        update_state(model, compute_tendencies=False)
     return model

@@ -395,3 +395,89 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
             om.time_step(dt)
         for a, b, name in zip(m.velocities, (om.u, om.v, om.w), "uvw"):
             assert np.abs(a.interior() - og.interior(b)).max() <= 1e-11 * scale, name
+
+
+# ---- HydrostaticFreeSurfaceModel on slab-x ranks (BASELINE.json configs[4] is an 8-GPU configuration) ---------------------------------------
+def _hydro_model(ocn, grid, fused=None):
+    return ocn.HydrostaticFreeSurfaceModel(grid, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
+                                           free_surface=ocn.SplitExplicitFreeSurface(substeps=12), coriolis=ocn.FPlane(f=1e-4),
+                                           closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
+                                           buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
+                                           boundary_conditions={"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                                                "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5))},
+                                           fused=fused)
+
+
+def _hydro_case():
+    from helpers import stretched_faces
+    N = (64, 12, 7)
+    ext = dict(x=(0, 8.0e3), y=(0, 1.5e3), z=stretched_faces(N[2], 40.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    rng = np.random.default_rng(77)
+    init = dict(u=1e-2 * rng.uniform(-1, 1, N), v=1e-2 * rng.uniform(-1, 1, N), eta=1e-2 * rng.uniform(-1, 1, N[:2]),
+                T=20 + 1e-2 * rng.uniform(-1, 1, N), S=35 + 1e-2 * rng.uniform(-1, 1, N))
+    return N, ext, init
+
+
+def _hydro_state(m):
+    g = m.grid
+    ii, jj = slice(g.Hy, g.Hy + g.Ny), slice(g.Hx, g.Hx + g.Nx)
+    out = {n: f.interior() for n, f in zip(("u", "v", "w"), m.velocities)}
+    out.update({f"c{n}": c.interior() for n, c in enumerate(m.tracers)})
+    out.update(eta=m.eta[ii, jj].cpu().numpy().T, U=m.U[ii, jj].cpu().numpy().T, V=m.V[ii, jj].cpu().numpy().T)
+    return out
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_distributed_hydrostatic_config5_matches_single_rank(ocn, R):
+    """configs[4]'s combination on R slab-x ranks (threads of this process, real HIP kernels): the fused QAB2 step with the
+    DistributedSplitExplicitFreeSurface scheme -- η, U, V, Gᵁ, Gⱽ halos as wide as the substep count, ONE exchange per baroclinic step,
+    no communication while substepping (distributed_split_explicit_free_surface.jl) -- equals the single-rank model BIT FOR BIT in
+    strict math after 3 steps (u, v, w, T, S, η, U, V): every rank evaluates the same expressions on the same values."""
+    N, ext, init = _hydro_case()
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sm = _hydro_model(ocn, ocn.RectilinearGrid(ocn.GPU(), size=N, **ext))
+    sm.set(**init)
+    for _ in range(3):
+        sm.time_step(20.0)
+    ocn.sync_device()
+    ref = _hydro_state(sm)
+    assert np.abs(ref["U"]).max() > 0 and np.abs(ref["w"]).max() > 0
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        assert g.Nx == N[0] // R and g.topology[0] == "FullyConnected"
+        m = _hydro_model(ocn, g)
+        sl = slice(r * g.Nx, (r + 1) * g.Nx)
+        m.set(**{k: v[sl] for k, v in init.items()})
+        for _ in range(3):
+            m.time_step(20.0)
+        ocn.sync_device()
+        return _hydro_state(m)
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    for r, got in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for name, a in got.items():
+            np.testing.assert_array_equal(a, ref[name][sl], err_msg=f"rank {r} field {name}")
+
+
+def test_rccl_world1_hydrostatic_matches_single_rank(ocn, rccl_arch):
+    """The same through the product transport (RCCL world of one rank with force_communication: the rank exchanges its strips and the
+    wide split-explicit halos with itself through ocn_halo_exchange_* / ocn_comm_exchange_strips)."""
+    N, ext, init = _hydro_case()
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sm = _hydro_model(ocn, ocn.RectilinearGrid(ocn.GPU(), size=N, **ext))
+    sm.set(**init)
+    g = ocn.RectilinearGrid(rccl_arch, size=N, **ext)
+    assert g.topology[0] == "FullyConnected"
+    m = _hydro_model(ocn, g)
+    m.set(**init)
+    for _ in range(3):
+        sm.time_step(20.0)
+        m.time_step(20.0)
+    ocn.sync_device()
+    ref, got = _hydro_state(sm), _hydro_state(m)
+    for name in ref:
+        np.testing.assert_array_equal(got[name], ref[name], err_msg=name)

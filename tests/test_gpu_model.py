@@ -331,6 +331,61 @@ def test_checkpoint_pickup_is_exact(ocn, ts, tmp_path):
     assert r.clock.time == m.clock.time
 
 
+def test_checkpoint_refuses_a_different_grid(ocn, tmp_path):
+    """set!(model, filepath) compares the grids (checkpointer.jl:241-246): a different extent, stretching or topology with the same
+    sizes must be refused (round 1 compared sizes and halos only)."""
+    P = "Periodic"
+    N = (16, 12, 10)
+    m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, P)), advection=ocn.WENO())
+    path = ocn.write_checkpoint(m, str(tmp_path / "ckpt"))
+    for kw in (dict(x=(0, 2), y=(0, 1), z=(0, 1), topology=(P, P, P)), dict(x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, "Bounded")),
+               dict(x=(0, 1), y=(0, 1), z=stretched_faces(N[2], 1.0), topology=(P, P, "Bounded"))):
+        other = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **kw), advection=ocn.WENO())
+        with pytest.raises(ValueError, match="not the same"):
+            ocn.set_from_checkpoint(other, path)
+    same = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 1), y=(0, 1), z=(0, 1), topology=(P, P, P)), advection=ocn.WENO())
+    ocn.set_from_checkpoint(same, path)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_hydrostatic_checkpoint_pickup_is_exact(ocn, fused, tmp_path):
+    """QAB2 pickup of BASELINE.json configs[4]'s model: u, v, T, S, η, the barotropic velocities and Gⁿ / G⁻ (η included) are saved;
+    a fresh model restored after 2 steps and run 2 more ends bit-identical to the uninterrupted run (the pickup step is a regular
+    AB2 step, not an Euler one, because last_Δt is restored)."""
+    rng = np.random.default_rng(9)
+    N = (32, 12, 7)
+
+    def build():
+        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 4e3), y=(0, 1.5e3), z=stretched_faces(N[2], 40.0), topology=("Periodic", "Periodic", "Bounded"),
+                                halo=(3, 3, 3))
+        return ocn.HydrostaticFreeSurfaceModel(g, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
+                                               free_surface=ocn.SplitExplicitFreeSurface(substeps=12), coriolis=ocn.FPlane(f=1e-4),
+                                               closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
+                                               buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)), fused=fused)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    m = build()
+    m.set(u=1e-2 * rng.uniform(-1, 1, N), v=1e-2 * rng.uniform(-1, 1, N), eta=1e-2 * rng.uniform(-1, 1, N[:2]),
+          T=20 + 1e-2 * rng.uniform(-1, 1, N), S=35 + 1e-2 * rng.uniform(-1, 1, N))
+    for _ in range(2):
+        m.time_step(20.0)
+    path = ocn.write_checkpoint(m, str(tmp_path / "hydrostatic_iteration2"))
+    for _ in range(2):
+        m.time_step(20.0)
+    r = build()
+    ocn.set_from_checkpoint(r, path)
+    assert r.clock.iteration == 2 and r.clock.time == 40.0
+    for _ in range(2):
+        r.time_step(20.0)
+    ocn.sync_device()
+    for a, b in zip([m.u, m.v, m.w] + list(m.tracers), [r.u, r.v, r.w] + list(r.tracers)):
+        np.testing.assert_array_equal(a.interior(), b.interior())
+    g = m.grid
+    ii, jj = slice(g.Hy, g.Hy + g.Ny), slice(g.Hx, g.Hx + g.Nx)
+    for a, b in ((m.eta, r.eta), (m.U, r.U), (m.V, r.V)):
+        np.testing.assert_array_equal(a[ii, jj].cpu().numpy(), b[ii, jj].cpu().numpy())
+
+
 def test_set_with_functions(ocn):
     """set!(model, u=f(x, y, z), ...) (set_nonhydrostatic_model.jl:33-60): functions are evaluated at each field's own nodes."""
     g = ocn.RectilinearGrid(ocn.GPU(), size=(8, 6, 5), x=(0, 2), y=(-1, 1), z=[-3.0, -2.0, -1.2, -0.5, -0.1, 0.0],
