@@ -342,6 +342,12 @@ int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, dou
 int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
                                         double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
                                         double *V_filtered, const double *GU, const double *GV, double *work, void *stream);
+/* The substep loop with timestepper = AdamsBashforth3Scheme() (split_explicit_timesteppers.jl:19-159; the reference's two launches per
+ * substep).  coefficients: HOST array {alpha, theta, beta, delta, mu, gamma, epsilon}; work: 7 planes (the scheme's history fields,
+ * re-initialised from the current state at every call as initialize_free_surface_timestepper! does). */
+int ocn_split_explicit_substeps_ab3(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                    double column_depth, const double *coefficients, double *eta, double *U, double *V, double *eta_filtered,
+                                    double *U_filtered, double *V_filtered, const double *GU, const double *GV, double *work, void *stream);
 /* The substep loop on a slab-x rank: DistributedSplitExplicitFreeSurface (distributed_split_explicit_free_surface.jl: the x halos of
  * eta, U, V, GU, GV are extended to the number of substeps and filled ONCE per baroclinic step; the substeps then run without
  * communication over ranges that reach into the halos).  W = n (the number of substeps; needs W <= Nx of the slab).

@@ -105,6 +105,7 @@ _SIGS = {
     "ocn_split_explicit_substeps": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_compute_barotropic_mode": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
     "ocn_split_explicit_substeps_blocked": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_split_explicit_substeps_ab3": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, C.POINTER(_dbl)] + [_vp] * 10,
     "ocn_hydrostatic_momentum_ab2_step": [C.POINTER(CGrid), C.POINTER(CModelTerms), C.POINTER(CFieldBcs), C.POINTER(CFieldBcs)] + [_vp] * 9
                                          + [_dbl, _dbl, _i32, _vp, _dbl, _vp, _vp, _vp, _vp, _vp],
     "ocn_barotropic_corrector_and_w": [C.POINTER(CGrid)] + [_vp] * 9 + [_dbl, _vp],

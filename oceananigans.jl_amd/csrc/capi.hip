@@ -609,6 +609,19 @@ int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const d
                                                   U_filtered, V_filtered, GU, GV, work, as_stream(stream));
 }
 
+int ocn_split_explicit_substeps_ab3(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
+                                    double column_depth, const double *coefficients, double *eta, double *U, double *V, double *eta_filtered,
+                                    double *U_filtered, double *V_filtered, const double *GU, const double *GV, double *work, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_split_explicit_substeps_ab3");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE_PERIODIC_X("ocn_split_explicit_substeps_ab3");
+    OCN_REQUIRE(n >= 1 && weights && coefficients, "ocn_split_explicit_substeps_ab3: needs n >= 1 weights and the 7 AB3 coefficients (host arrays)");
+    OCN_REQUIRE(eta && U && V && eta_filtered && U_filtered && V_filtered && GU && GV && work, "ocn_split_explicit_substeps_ab3: null pointer");
+    return launch_split_explicit_substeps_ab3(grid, n, weights, dtau, gravitational_acceleration, column_depth, coefficients, eta, U, V,
+                                              eta_filtered, U_filtered, V_filtered, GU, GV, work, as_stream(stream));
+}
+
 static int validate_hydrostatic_slab(const ocn_grid *grid, const char *who)
 {
     int st = validate_grid(grid);

@@ -409,6 +409,86 @@ __global__ __launch_bounds__(256) void split_explicit_velocity_kernel(GridDev g,
     U[e] = Un;
     V[e] = Vn;
 }
+// ---- AdamsBashforth3Scheme of the substepping (split_explicit_timesteppers.jl:19-159): the reference's two kernels per substep with the
+// AB3 extrapolations U★ = α Uᵐ + θ Uᵐ⁻¹ + β Uᵐ⁻² and η★ = δ ηᵐ⁺¹ + μ ηᵐ + γ ηᵐ⁻¹ + ϵ ηᵐ⁻² and their history updates
+// (cache_previous_free_surface! / cache_previous_velocities!).  A non-default option: kept in the reference's launch shape.
+struct AB3Coef {
+    double alpha, theta, beta, delta, mu, gamma, epsilon;
+};
+__global__ void split_explicit_update_state_kernel(GridDev g, double *__restrict__ eta, double *__restrict__ U, double *__restrict__ V,
+                                                   const double *__restrict__ etab, const double *__restrict__ Ub, const double *__restrict__ Vb);
+__global__ __launch_bounds__(256) void split_explicit_eta_ab3_kernel(GridDev g, double dtau, AB3Coef c, double *__restrict__ eta,
+                                                                     double *__restrict__ em, double *__restrict__ em1, double *__restrict__ em2,
+                                                                     const double *__restrict__ U, const double *__restrict__ Um1,
+                                                                     const double *__restrict__ Um2, const double *__restrict__ V,
+                                                                     const double *__restrict__ Vm1, const double *__restrict__ Vm2)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const int ip = i == g.Nx ? 1 : i + 1, jp = j == g.Ny ? 1 : j + 1;
+    const double dx = g.dx, dy = g.dy, Az = dx * dy;
+    const long long e = plane_at(g, i, j), ee = plane_at(g, ip, j), en = plane_at(g, i, jp);
+    em2[e] = em1[e];
+    em1[e] = em[e];
+    em[e] = eta[e];
+    auto Us = [&](long long q) { return c.alpha * U[q] + c.theta * Um1[q] + c.beta * Um2[q]; };
+    auto Vs = [&](long long q) { return c.alpha * V[q] + c.theta * Vm1[q] + c.beta * Vm2[q]; };
+    eta[e] = eta[e] - dtau * ((dy * Us(ee) - dy * Us(e)) + (dx * Vs(en) - dx * Vs(e))) / Az;
+}
+__global__ __launch_bounds__(256) void split_explicit_velocity_ab3_kernel(GridDev g, double w, double dtau, double grav, double H, AB3Coef c,
+                                                                          const double *__restrict__ eta, const double *__restrict__ em,
+                                                                          const double *__restrict__ em1, const double *__restrict__ em2,
+                                                                          double *__restrict__ U, double *__restrict__ Um1, double *__restrict__ Um2,
+                                                                          double *__restrict__ V, double *__restrict__ Vm1, double *__restrict__ Vm2,
+                                                                          double *__restrict__ etab, double *__restrict__ Ub, double *__restrict__ Vb,
+                                                                          const double *__restrict__ GU, const double *__restrict__ GV)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const int im = i == 1 ? g.Nx : i - 1, jm = j == 1 ? g.Ny : j - 1;
+    const long long e = plane_at(g, i, j), ew = plane_at(g, im, j), es = plane_at(g, i, jm);
+    Um2[e] = Um1[e];
+    Um1[e] = U[e];
+    Vm2[e] = Vm1[e];
+    Vm1[e] = V[e];
+    auto Es = [&](long long q) { return c.delta * eta[q] + c.mu * em[q] + c.gamma * em1[q] + c.epsilon * em2[q]; };
+    const double e0 = Es(e);
+    const double Un = U[e] + dtau * (-grav * H * ((e0 - Es(ew)) / g.dx) + GU[e]);
+    const double Vn = V[e] + dtau * (-grav * H * ((e0 - Es(es)) / g.dy) + GV[e]);
+    etab[e] += w * eta[e];
+    Ub[e] += w * Un;
+    Vb[e] += w * Vn;
+    U[e] = Un;
+    V[e] = Vn;
+}
+// work: 7 planes (ηᵐ, ηᵐ⁻¹, ηᵐ⁻², Uᵐ⁻¹, Uᵐ⁻², Vᵐ⁻¹, Vᵐ⁻²)
+int launch_split_explicit_substeps_ab3(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, const double *coef,
+                                       double *eta, double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                       double *work, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    const long long plane = (long long)(g.Nx + 2 * g.Hx) * (g.Ny + 2 * g.Hy);
+    const size_t bytes = (size_t)plane * sizeof(double);
+    double *em = work, *em1 = work + plane, *em2 = work + 2 * plane, *Um1 = work + 3 * plane, *Um2 = work + 4 * plane, *Vm1 = work + 5 * plane,
+           *Vm2 = work + 6 * plane;
+    // initialize_free_surface_state!: history <- current state, filtered state <- 0
+    for (double *f : {em, em1, em2}) OCN_CHECK_HIP(hipMemcpyAsync(f, eta, bytes, hipMemcpyDeviceToDevice, stream));
+    for (double *f : {Um1, Um2}) OCN_CHECK_HIP(hipMemcpyAsync(f, U, bytes, hipMemcpyDeviceToDevice, stream));
+    for (double *f : {Vm1, Vm2}) OCN_CHECK_HIP(hipMemcpyAsync(f, V, bytes, hipMemcpyDeviceToDevice, stream));
+    for (double *f : {etab, Ub, Vb}) OCN_CHECK_HIP(hipMemsetAsync(f, 0, bytes, stream));
+    const AB3Coef c{coef[0], coef[1], coef[2], coef[3], coef[4], coef[5], coef[6]};
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    for (int m = 0; m < n; ++m) {
+        hipLaunchKernelGGL(split_explicit_eta_ab3_kernel, nb, block, 0, stream, g, dtau, c, eta, em, em1, em2, U, Um1, Um2, V, Vm1, Vm2);
+        hipLaunchKernelGGL(split_explicit_velocity_ab3_kernel, nb, block, 0, stream, g, weights[m], dtau, grav, H, c, eta, em, em1, em2, U, Um1, Um2,
+                           V, Vm1, Vm2, etab, Ub, Vb, GU, GV);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(split_explicit_update_state_kernel, nb, block, 0, stream, g, eta, U, V, etab, Ub, Vb);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // integrate_barotropic_mode! on a static grid (σ = 1): Σₖ Δz u σ (barotropic_split_explicit_corrector.jl:13-32)
 __global__ __launch_bounds__(256) void barotropic_mode_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                               double *__restrict__ U, double *__restrict__ V)

@@ -72,6 +72,9 @@ int launch_split_explicit_substeps(const ocn_grid *grid, int n, const double *we
 int launch_split_explicit_substeps_blocked(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, double *eta,
                                            double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
                                            double *work, hipStream_t stream);
+int launch_split_explicit_substeps_ab3(const ocn_grid *grid, int n, const double *weights, double dtau, double grav, double H, const double *coef,
+                                       double *eta, double *U, double *V, double *etab, double *Ub, double *Vb, const double *GU, const double *GV,
+                                       double *work, hipStream_t stream);
 int launch_split_explicit_dist_begin(const ocn_grid *grid, int W, const double *eta, const double *U, const double *V, const double *GU,
                                      const double *GV, double *work, double *send_west, double *send_east, hipStream_t stream);
 int launch_split_explicit_dist_run(const ocn_grid *grid, int W, int n, const double *weights, double dtau, double grav, double H, double *eta,

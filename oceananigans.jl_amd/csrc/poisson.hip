@@ -144,13 +144,17 @@ struct ocn_poisson {
     bool source_in_rhs = false; // custom_xy: the source was given as a real array (set_source_term!) and still needs its x transform
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
+    // kind 2: FFTBasedPoissonSolver for ANY regular (Periodic | Bounded | Flat)^3 topology: separable transforms evaluated as direct sums
+    // (DFT along Periodic, REDFT10 / REDFT01 along Bounded dimensions, plan_transforms.jl:16-34) -- the reference's K11 path
+    double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per dimension: cos / sin tables
 };
 
 static void free_all(ocn_poisson *s)
 {
     s->fwd.destroy();
     s->bwd.destroy();
-    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage};
+    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage,
+                       &s->tab[0][0], &s->tab[0][1], &s->tab[1][0], &s->tab[1][1], &s->tab[2][0], &s->tab[2][1]};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -160,13 +164,152 @@ static void free_all(ocn_poisson *s)
 
 static int poisson_plans_self_test(ocn_poisson *s);
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// kind 2: FFTBasedPoissonSolver on ANY regular topology (fft_based_poisson_solver.jl:5-125 with the transforms of plan_transforms.jl:16-34,
+// 129-140: Bounded dimensions first, then Periodic ones; backward in the opposite order).  The reference's GPU path builds the cosine
+// transforms from FFTs with index permutations and twiddle factors (K11: index_permutations.jl:38-90, discrete_transforms.jl:141-176);
+// here every 1-D transform is the direct sum of its definition over a table of cos / sin values computed on the host in fp64:
+//   Periodic forward  X[k] = Σ_n x[n] e^{-2πi k n / N}                      backward x[n] = (1/N) Σ_k X[k] e^{+2πi k n / N}
+//   Bounded  forward  X[k] = 2 Σ_n x[n] cos(π (n + 1/2) k / N)  (REDFT10)    backward x[n] = (1/2N) (X[0] + 2 Σ_{k>=1} X[k] cos(π (n + 1/2) k / N))
+// O(N) work per output element: this path serves the Bounded-x / Bounded-y topologies of test_poisson_solvers.jl:58-106, which no
+// BASELINE configuration uses (their fields are not implemented by the tendency kernels either); it is exact to N eps, not tuned.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void naive_transform_kernel(int Nx, int Ny, int Nz, int dim, int topo, int inverse, const double2 *__restrict__ in,
+                                                              double2 *__restrict__ out, const double *__restrict__ ctab,
+                                                              const double *__restrict__ stab)
+{
+    const long long n = (long long)Nx * Ny * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), k = (int)(t / ((long long)Nx * Ny));
+    const int N = dim == 0 ? Nx : dim == 1 ? Ny : Nz, q = dim == 0 ? i : dim == 1 ? j : k;  // q: output index along the transformed dimension
+    const long long stride = dim == 0 ? 1 : dim == 1 ? Nx : (long long)Nx * Ny;
+    const double2 *line = in + (t - q * stride);
+    double re = 0.0, im = 0.0;
+    if (topo == OCN_PERIODIC) {
+        for (int m = 0; m < N; ++m) {
+            const int idx = (int)(((long long)q * m) % N);
+            const double c = ctab[idx], sn = inverse ? stab[idx] : -stab[idx];
+            const double2 v = line[m * stride];
+            re += v.x * c - v.y * sn;
+            im += v.x * sn + v.y * c;
+        }
+        if (inverse) { re /= N; im /= N; }
+    } else {  // Bounded: cosine transforms of the real and imaginary parts; table index (2 n + 1) k mod 4N of cos(π idx / 2N)
+        if (!inverse) {
+            for (int m = 0; m < N; ++m) {
+                const double c = ctab[(int)(((long long)(2 * m + 1) * q) % (4 * N))];
+                const double2 v = line[m * stride];
+                re += v.x * c;
+                im += v.y * c;
+            }
+            re *= 2; im *= 2;
+        } else {
+            for (int m = 1; m < N; ++m) {
+                const double c = ctab[(int)(((long long)(2 * q + 1) * m) % (4 * N))];
+                const double2 v = line[m * stride];
+                re += v.x * c;
+                im += v.y * c;
+            }
+            const double2 v0 = line[0];
+            re = (v0.x + 2 * re) / (2 * N);
+            im = (v0.y + 2 * im) / (2 * N);
+        }
+    }
+    out[t] = make_double2(re, im);
+}
+
+static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
+{
+    if (grid->dzc != nullptr) {
+        ocn::set_error("FFTBasedPoissonSolver requires regular spacings in every direction (a stretched z needs Periodic x and y)");
+        return OCN_ERR_UNSUPPORTED;
+    }
+    for (int t : {grid->tx, grid->ty, grid->tz})
+        if (t != OCN_PERIODIC && t != OCN_BOUNDED && t != OCN_FLAT) {
+            ocn::set_error("ocn_poisson_create: topology code %d is not supported by the general solver", t);
+            return OCN_ERR_UNSUPPORTED;
+        }
+    ocn_poisson *s = new ocn_poisson();
+    s->grid = *grid;
+    s->kind = 2;
+    s->c2c = true;
+    s->direct_out = false;
+    const int N[3] = {grid->Nx, grid->Ny, grid->Nz}, topo[3] = {grid->tx, grid->ty, grid->tz};
+    const double Ls[3] = {grid->Lx, grid->Ly, grid->Lz};
+    s->nxh = N[0];
+    const size_t n = (size_t)N[0] * N[1] * N[2];
+    const double pi = 3.14159265358979323846;
+    double **lam[3] = {&s->lx, &s->ly, &s->lz};
+    int st = OCN_SUCCESS;
+    for (int d = 0; d < 3 && st == OCN_SUCCESS; ++d) {
+        st = upload(eigenvalues(N[d], Ls[d], topo[d]), lam[d]);
+        if (st != OCN_SUCCESS || topo[d] == OCN_FLAT) continue;
+        const int M = topo[d] == OCN_PERIODIC ? N[d] : 4 * N[d];
+        std::vector<double> c(M), sn(M);
+        for (int m = 0; m < M; ++m) {
+            const double a = topo[d] == OCN_PERIODIC ? 2 * pi * m / N[d] : pi * m / (2.0 * N[d]);
+            c[m] = std::cos(a);
+            sn[m] = std::sin(a);
+        }
+        st = upload(c, &s->tab[d][0]);
+        if (st == OCN_SUCCESS) st = upload(sn, &s->tab[d][1]);
+    }
+    if (st == OCN_SUCCESS && (hipMalloc((void **)&s->spec, n * 2 * sizeof(double)) != hipSuccess ||
+                              hipMalloc((void **)&s->spec2, n * 2 * sizeof(double)) != hipSuccess)) {
+        ocn::set_error("ocn_poisson_create: out of device memory");
+        st = OCN_ERR_ALLOC;
+    }
+    if (st != OCN_SUCCESS) {
+        free_all(s);
+        delete s;
+        return st;
+    }
+    (void)hipMemset(s->spec, 0, n * 2 * sizeof(double));
+    *out = s;
+    return OCN_SUCCESS;
+}
+
+// forward transforms Bounded first, then Periodic (plan_transforms.jl:53-57, 129-140); backward in the opposite order
+static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
+{
+    const ocn_grid *g = &s->grid;
+    const int N[3] = {g->Nx, g->Ny, g->Nz}, topo[3] = {g->tx, g->ty, g->tz};
+    const long long n = (long long)N[0] * N[1] * N[2];
+    double *a = s->spec, *b = s->spec2;
+    int order[3], no = 0;
+    for (int d = 0; d < 3; ++d) if (topo[d] == OCN_BOUNDED) order[no++] = d;
+    for (int d = 0; d < 3; ++d) if (topo[d] == OCN_PERIODIC) order[no++] = d;
+    auto pass = [&](int d, int inverse) {
+        hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, topo[d], inverse,
+                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[d][0], s->tab[d][1]);
+        std::swap(a, b);
+    };
+    for (int q = 0; q < no; ++q) pass(order[q], 0);
+    int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream);  // -b / (λx + λy + λz), mode (1,1,1) := 0
+    if (st != OCN_SUCCESS) return st;
+    for (int q = no - 1; q >= 0; --q) pass(order[q], 1);
+    OCN_CHECK_HIP(hipGetLastError());
+    if (a != s->spec) std::swap(s->spec, s->spec2);  // the result lives in `a`; keep the handle's roles consistent
+    return ocn::launch_copy_real(g, s->spec, p, stream, 0);
+}
+
 static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool force_c2c)
 {
     OCN_REQUIRE(out && grid, "ocn_poisson_create: null argument");
+    {
+        const char *eg = std::getenv("OCN_POISSON_GENERAL");
+        const bool bounded_xy = grid->tx == OCN_BOUNDED || grid->ty == OCN_BOUNDED;
+        if (bounded_xy || (eg && eg[0] == '1' && grid->dzc == nullptr)) {
+            // (the solver only touches a Center field, whose layout does not depend on the topology: its own light validation)
+            OCN_REQUIRE(grid->Nx >= 1 && grid->Ny >= 1 && grid->Nz >= 1 && grid->Hx >= 0 && grid->Hy >= 0 && grid->Hz >= 0, "bad grid size / halo");
+            OCN_REQUIRE(grid->dx > 0 && grid->dy > 0 && grid->dz > 0 && grid->Lx > 0 && grid->Ly > 0 && grid->Lz > 0, "spacings and extents must be positive");
+            return poisson_create_general(out, grid);
+        }
+    }
     int st = ocn::validate_grid(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC,
-                "ocn_poisson_create: x and y must be Periodic (distributed grids use ocn_dist_poisson_create)");
+                "ocn_poisson_create: x and y must be Periodic or Bounded (distributed grids use ocn_dist_poisson_create)");
     ensure_rocfft();
     ocn_poisson *s = new ocn_poisson();
     s->grid = *grid;
@@ -580,6 +723,13 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     OCN_REQUIRE(s && u && v && w, "ocn_poisson_compute_source_term: null argument");
     const ocn_grid *g = &s->grid;
     int st;
+    if (s->kind == 2) {
+        OCN_REQUIRE(g->tx == OCN_PERIODIC && g->ty == OCN_PERIODIC,
+                    "ocn_poisson_compute_source_term: velocity fields on grids with a Bounded x or y are not implemented (use ocn_poisson_set_source_term)");
+        st = ocn::launch_source_term(g, u, v, w, dt, 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        s->source_set = (st == OCN_SUCCESS);
+        return st;
+    }
     if (s->custom_xy) {  // K8 fused with the forward x transform: the divergence goes straight into the half spectrum
         st = ocn::launch_rowfft(g, 0, u, v, w, nullptr, dt, s->spec, nullptr, s->twMx, s->twNx, 1.0, ocn::as_stream(stream),
                                 s->custom_tri ? 1 : 0);
@@ -626,6 +776,7 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
     hipStream_t stream = ocn::as_stream(stream_);
     const ocn_grid *g = &s->grid;
     int st;
+    if (s->kind == 2) return poisson_solve_general(s, p, stream);
     if (s->custom_xy) {
         const long long plane = (long long)s->nxh * g->Ny;
         if (s->source_in_rhs) {  // set_source_term! path: x transform of the real array

@@ -76,6 +76,21 @@ class ForwardBackwardScheme:
     """ForwardBackwardScheme() (split_explicit_timesteppers.jl:13-17): η = f(U) then U = f(η)"""
 
 
+class AdamsBashforth3Scheme:
+    """AdamsBashforth3Scheme(; β = 0.281105, α = 1.5 + β, θ = -0.5 - 2β, γ = 0.088, δ = 0.614, ϵ = 0.013, μ = 1 - δ - γ - ϵ)
+    (split_explicit_timesteppers.jl:69-70): η = f(U, Uᵐ⁻¹, Uᵐ⁻²) then U = f(η, ηᵐ, ηᵐ⁻¹, ηᵐ⁻²)."""
+
+    def __init__(self, β=0.281105, α=None, θ=None, γ=0.088, δ=0.614, ϵ=0.013, μ=None):
+        self.β = float(β)
+        self.α = 1.5 + self.β if α is None else float(α)
+        self.θ = -0.5 - 2 * self.β if θ is None else float(θ)
+        self.γ, self.δ, self.ϵ = float(γ), float(δ), float(ϵ)
+        self.μ = 1 - self.δ - self.γ - self.ϵ if μ is None else float(μ)
+
+    def c_array(self):
+        return (C.c_double * 7)(self.α, self.θ, self.β, self.δ, self.μ, self.γ, self.ϵ)
+
+
 class SplitExplicitFreeSurface:
     """SplitExplicitFreeSurface(grid = nothing; substeps, cfl, fixed_Δt, gravitational_acceleration = g_Earth, averaging_kernel,
     timestepper = ForwardBackwardScheme()) (split_explicit_free_surface.jl:120-155).
@@ -93,6 +108,8 @@ class SplitExplicitFreeSurface:
         self.gravitational_acceleration = float(gravitational_acceleration)
         self.averaging_kernel = averaging_kernel
         self.timestepper = ForwardBackwardScheme() if timestepper is None else timestepper
+        if not isinstance(self.timestepper, (ForwardBackwardScheme, AdamsBashforth3Scheme)):
+            raise TypeError("timestepper must be ForwardBackwardScheme() or AdamsBashforth3Scheme()")
         self.Δt_barotropic = None
         if cfl is not None:
             if substeps is not None:
@@ -292,7 +309,13 @@ class HydrostaticFreeSurfaceModel:
         args = (g.cref, len(self._weights), self._weights, frac * float(dt), fs.gravitational_acceleration, float(g.Lz), self.eta.data_ptr(),
                 self.U.data_ptr(), self.V.data_ptr(), self._etab.data_ptr(), self._Ub.data_ptr(), self._Vb.data_ptr(), self._GU.data_ptr(),
                 self._GV.data_ptr())
-        if self._dist is not None:
+        if isinstance(fs.timestepper, AdamsBashforth3Scheme):
+            if self._dist is not None:
+                raise NotImplementedError("AdamsBashforth3Scheme substepping on a slab-partitioned grid")
+            if getattr(self, "_ab3_work", None) is None:
+                self._ab3_work = torch.zeros((7,) + tuple(self.eta.shape), dtype=torch.float64, device=self.eta.device)
+            _lib.call("ocn_split_explicit_substeps_ab3", *args[:6], fs.timestepper.c_array(), *args[6:], self._ab3_work.data_ptr(), s)
+        elif self._dist is not None:
             # DistributedSplitExplicitFreeSurface: halos of η, U, V, Gᵁ, Gⱽ as wide as the number of substeps, ONE exchange per baroclinic
             # step, no communication while substepping (distributed_split_explicit_free_surface.jl; split_explicit_free_surface.jl:283-300)
             n = len(self._weights)

@@ -52,14 +52,30 @@ class _PoissonHandle:
 
 
 class FFTBasedPoissonSolver(_PoissonHandle):
-    """src/Solvers/fft_based_poisson_solver.jl:52-125 for topologies (Periodic, Periodic, Periodic|Flat)."""
+    """src/Solvers/fft_based_poisson_solver.jl:52-125.  (Periodic, Periodic, Periodic | Flat): the FFT pipelines of csrc/poisson.hip; any
+    topology with a Bounded x or y (regular spacings): the general solver, cosine transforms along the Bounded dimensions
+    (plan_transforms.jl:16-34; `general=True` forces it for the other regular topologies, Bounded z included)."""
 
-    def __init__(self, grid):
-        if grid.topology[2] == Bounded:
-            raise NotImplementedError("Bounded z is solved by FourierTridiagonalPoissonSolver in this backend")
+    def __init__(self, grid, general=False):
+        import os
+        bounded_xy = Bounded in grid.topology[:2]
         if grid._dzc is not None:
             raise ValueError("FFTBasedPoissonSolver requires a regular grid")
-        super().__init__(grid)
+        if grid.topology[2] == Bounded and not (bounded_xy or general):
+            raise NotImplementedError("(Periodic, Periodic, Bounded): FourierTridiagonalPoissonSolver in this backend (an exact solver of the "
+                                      "same system); FFTBasedPoissonSolver(grid, general=True) selects the cosine-transform solver")
+        if general and not bounded_xy:
+            old = os.environ.get("OCN_POISSON_GENERAL")
+            os.environ["OCN_POISSON_GENERAL"] = "1"
+            try:
+                super().__init__(grid)
+            finally:
+                if old is None:
+                    os.environ.pop("OCN_POISSON_GENERAL")
+                else:
+                    os.environ["OCN_POISSON_GENERAL"] = old
+        else:
+            super().__init__(grid)
 
 
 class FourierTridiagonalPoissonSolver(_PoissonHandle):
@@ -76,6 +92,8 @@ def nonhydrostatic_pressure_solver(grid):
     hook = getattr(grid.architecture, "pressure_solver", None)
     if hook is not None:
         return hook(grid)
+    if Bounded in grid.topology[:2]:
+        return FFTBasedPoissonSolver(grid)  # XYZRegularRG (NonhydrostaticModels.jl:25-62); a stretched z there has no solver in the reference either
     if grid.topology[2] == Bounded:
         return FourierTridiagonalPoissonSolver(grid)
     return FFTBasedPoissonSolver(grid)

@@ -128,6 +128,45 @@ def iterate_split_explicit(eta, U, V, etab, Ub, Vb, GU, GV, dtau, weights, grav,
         V[...] = Vn
 
 
+AB3_DEFAULTS = dict(beta=0.281105, gamma=0.088, delta=0.614, epsilon=0.013)  # AdamsBashforth3Scheme() (split_explicit_timesteppers.jl:69-70)
+
+
+def ab3_coefficients(beta=0.281105, alpha=None, theta=None, gamma=0.088, delta=0.614, epsilon=0.013, mu=None):
+    """AdamsBashforth3Scheme(; β, α = 1.5 + β, θ = -0.5 - 2β, γ, δ, ϵ, μ = 1 - δ - γ - ϵ) in Julia's evaluation order"""
+    alpha = 1.5 + beta if alpha is None else alpha
+    theta = -0.5 - 2 * beta if theta is None else theta
+    mu = 1 - delta - gamma - epsilon if mu is None else mu
+    return dict(beta=beta, alpha=alpha, theta=theta, gamma=gamma, delta=delta, epsilon=epsilon, mu=mu)
+
+
+def iterate_split_explicit_ab3(eta, U, V, etab, Ub, Vb, GU, GV, dtau, weights, grav, H, dx, dy, c):
+    """iterate_split_explicit! with the AdamsBashforth3Scheme (split_explicit_timesteppers.jl:19-159; step_split_explicit_free_surface.jl:
+    3-46): η -= Δτ (δx(Δy U★) + δy(Δx V★)) / Az with U★ = α Uᵐ + θ Uᵐ⁻¹ + β Uᵐ⁻²; U += Δτ (-g H ∂x η★ + Gᵁ) with
+    η★ = δ ηᵐ⁺¹ + μ ηᵐ + γ ηᵐ⁻¹ + ϵ ηᵐ⁻².  The history is re-initialised from the current state at the start of every baroclinic step
+    (initialize_free_surface_timestepper!, :116-127)."""
+    Az = dx * dy
+    Um1, Um2, Vm1, Vm2 = U.copy(), U.copy(), V.copy(), V.copy()
+    em, em1, em2 = eta.copy(), eta.copy(), eta.copy()
+    a, th, be, de, mu, ga, ep = c["alpha"], c["theta"], c["beta"], c["delta"], c["mu"], c["gamma"], c["epsilon"]
+    for wgt in weights:
+        # _split_explicit_free_surface!: cache_previous_free_surface!, then the update with U★, V★
+        em2, em1, em = em1, em, eta.copy()
+        Us = a * U + th * Um1 + be * Um2
+        Vs = a * V + th * Vm1 + be * Vm2
+        eta[...] = eta - dtau * ((dy * np.roll(Us, -1, 0) - dy * Us) + (dx * np.roll(Vs, -1, 1) - dx * Vs)) / Az
+        # _split_explicit_barotropic_velocity!: cache_previous_velocities!, then the update with η★
+        Um2, Um1 = Um1, U.copy()
+        Vm2, Vm1 = Vm1, V.copy()
+        es = de * eta + mu * em + ga * em1 + ep * em2
+        Un = U + dtau * (-grav * H * ((es - np.roll(es, 1, 0)) / dx) + GU)
+        Vn = V + dtau * (-grav * H * ((es - np.roll(es, 1, 1)) / dy) + GV)
+        etab += wgt * eta
+        Ub += wgt * Un
+        Vb += wgt * Vn
+        U[...] = Un
+        V[...] = Vn
+
+
 class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     """HydrostaticFreeSurfaceModel(; grid, momentum_advection, tracer_advection, free_surface = ExplicitFreeSurface(g), coriolis,
     closure, buoyancy, tracers) with the QuasiAdamsBashforth2 time stepper.  Reuses the nonhydrostatic oracle's fields and
@@ -135,11 +174,13 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     reference's reduced field)."""
 
     def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None,
-                 buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None):
+                 buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None,
+                 split_explicit_timestepper="ForwardBackward"):
         """split_explicit_substeps = N: free_surface = SplitExplicitFreeSurface(substeps = N) with the ForwardBackwardScheme
         (split_explicit_free_surface.jl:60-97); None: ExplicitFreeSurface."""
         assert grid.topo[2] == O.BOUNDED and grid.topo[0] == O.PERIODIC and grid.topo[1] == O.PERIODIC
         self.split = split_explicit_substeps
+        self.ab3 = ab3_coefficients() if split_explicit_timestepper in ("AdamsBashforth3", "AB3") else None
         if self.split is not None:
             assert grid.dzc is None or True
             self.frac_dt, self.weights = weights_from_substeps(int(self.split))
@@ -268,8 +309,12 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         dx, dy, Az = g.dx, g.dy, g.dx * g.dy
         Hx, Hy = g.Hx, g.Hy
         eta = self.eta[Hx:Hx + g.Nx, Hy:Hy + g.Ny].copy()
-        iterate_split_explicit(eta, self.U, self.V, self.etab, self.Ub, self.Vb, self.GU, self.GV, self.frac_dt * dt, self.weights,
-                               grav, H, dx, dy)
+        if self.ab3 is not None:
+            iterate_split_explicit_ab3(eta, self.U, self.V, self.etab, self.Ub, self.Vb, self.GU, self.GV, self.frac_dt * dt, self.weights,
+                                       grav, H, dx, dy, self.ab3)
+        else:
+            iterate_split_explicit(eta, self.U, self.V, self.etab, self.Ub, self.Vb, self.GU, self.GV, self.frac_dt * dt, self.weights,
+                                   grav, H, dx, dy)
         self.eta[Hx:Hx + g.Nx, Hy:Hy + g.Ny] = self.etab
         self.U[...] = self.Ub
         self.V[...] = self.Vb

@@ -249,3 +249,32 @@ def test_config5_full_size_properties(ocn):
             assert drift < 1e-6 * abs(c0)
     finally:
         ocn.set_math_mode(ocn.MATH_STRICT)
+
+
+def test_split_explicit_ab3_scheme_matches_oracle(oracle, ocn):
+    """SplitExplicitFreeSurface(substeps = 12, timestepper = AdamsBashforth3Scheme()): the whole model (config-5 combination), 3 steps, bit
+    for bit against the oracle in strict math -- the AB3 extrapolations U★, η★ and the history updates of
+    split_explicit_timesteppers.jl:128-159."""
+    from oracle import hydrostatic as Hy
+    O = oracle
+    size = (20, 12, 7)
+    og, pg = _pair(O, ocn, size, stretched=True)
+    rng = np.random.default_rng(41)
+    init = dict(u=1e-2 * rng.uniform(-1, 1, size), v=1e-2 * rng.uniform(-1, 1, size), eta=1e-2 * rng.uniform(-1, 1, size[:2]),
+                T=20 + 1e-2 * rng.uniform(-1, 1, size), S=35 + 1e-2 * rng.uniform(-1, 1, size))
+    om = Hy.HydrostaticFreeSurfaceModel(og, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5", coriolis_f=1e-4,
+                                        closure=(1e-2, 2e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4), split_explicit_substeps=12,
+                                        split_explicit_timestepper="AdamsBashforth3")
+    om.set(**init)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
+                                         free_surface=ocn.SplitExplicitFreeSurface(substeps=12, timestepper=ocn.AdamsBashforth3Scheme()),
+                                         coriolis=ocn.FPlane(f=1e-4), closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
+                                         buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)))
+    pm.set(**init)
+    for _ in range(3):
+        om.time_step(15.0)
+        pm.time_step(15.0)
+    ocn.sync_device()
+    _compare_hydrostatic(og, om, pm, 0)
+    assert np.abs(om.U).max() > 0 and np.abs(om.eta).max() < 1.0

@@ -71,6 +71,68 @@ def test_poisson_laplacian_equals_source(oracle, ocn, size, topo, z):
     assert err <= 1e-10 * max(1.0, np.abs(p0).max())
 
 
+ALL_TOPOS = ["PPP", "PPB", "PBP", "PBB", "BPP", "BPB", "BBP", "BBB"]
+
+
+@pytest.mark.parametrize("topo", ALL_TOPOS + ["PBF", "BBF", "BPF"])
+@pytest.mark.parametrize("size", [(7, 7, 7), (16, 16, 16), (11, 16, 7)])
+def test_fft_poisson_all_topologies(oracle, ocn, topo, size):
+    """test_poisson_solvers.jl:58-106 re-expressed on the GPU for every regular topology: the FFT-based solver with cosine transforms along
+    Bounded dimensions (the reference's K11 path; csrc/poisson.hip kind 2).  R = div(U) of a random velocity computed by the oracle (fields
+    on grids with a Bounded x or y exist only there), set as the source term; ∇²ϕ ≈ R to sqrt(eps) and ϕ equals the oracle's solution to
+    1e-10.  (Periodic, Periodic, ·) topologies run the same kernels through `general=True`."""
+    O = oracle
+    if topo[2] == "F":
+        size = size[:2]
+    rng = np.random.default_rng(1234)
+    kw = dict(x=(0, 1), y=(0, 2.5)) if topo[2] == "F" else dict(x=(0, 1), y=(0, 2.5), z=(0, 4))
+    og = O.Grid(size, topology=topo, halo=(3, 3, 3)[:len(size)], **kw)
+    names = {"P": "Periodic", "B": "Bounded", "F": "Flat"}
+    pg = ocn.RectilinearGrid(ocn.GPU(), size=size, topology=tuple(names[t] for t in topo), halo=(3, 3, 3)[:len(size)], **kw)
+    U = []
+    for loc in (1, 2, 4):
+        a = og.zeros(loc)
+        og.interior(a)[...] = rng.random(og.interior(a).shape)
+        O.fill_halo_regions(og, a, loc)
+        U.append(a)
+    if topo[2] == "F":
+        U[2][...] = 0
+    R = O.divergence(og, *U)
+    solver = ocn.FFTBasedPoissonSolver(pg, general=True)
+    assert solver.info()["kind"] == 2
+    solver.set_source_term(R)
+    phi = ocn.CenterField(pg)
+    solver.solve(phi)
+    ocn.sync_device()
+    p = np.asfortranarray(from_dev(phi))
+    O.fill_halo_regions(og, p, 0)
+    lap = O.laplacian(og, p)
+    assert np.linalg.norm(lap - R) <= np.sqrt(np.finfo(float).eps) * np.linalg.norm(R)
+    S = O.FFTBasedPoissonSolver(og)
+    p0 = og.zeros(0)
+    S.source_term(*U, 1.0)
+    S.solve(p0)
+    assert np.abs(og.interior_N(p) - og.interior_N(p0)).max() <= 1e-10 * max(1.0, np.abs(p0).max())
+
+
+def test_fft_poisson_bounded_converges_to_analytic_modes(oracle, ocn):
+    """test_poisson_solvers.jl:109-141: second-order convergence of the (Bounded, Bounded, Bounded) solve to cos(x/2) cos(y/2) cos(z/2)."""
+    errs = []
+    for N in (16, 32):
+        g = ocn.RectilinearGrid(ocn.GPU(), size=(N, N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=("Bounded",) * 3)
+        xc = (np.arange(N) + 0.5) * g.dx
+        psi = np.cos(xc / 2)
+        Psi = psi[:, None, None] * psi[None, :, None] * psi[None, None, :]
+        solver = ocn.nonhydrostatic_pressure_solver(g)
+        assert solver.info()["kind"] == 2
+        solver.set_source_term(-0.75 * Psi)
+        phi = ocn.CenterField(g)
+        solver.solve(phi)
+        ocn.sync_device()
+        errs.append(np.abs(phi.interior() - (Psi - Psi.mean())).max())
+    assert 3.5 < errs[0] / errs[1] < 4.5
+
+
 def test_two_solver_handles_coexist(oracle, ocn):
     """Regression for the rocFFT (ROCm 7.2) real-plan collision (tools/rocfft_repro.hip, profiles/r02_rocfft_repro.md): with a
     16^3 (P,P,P) solver alive, the real-to-complex plans of a (32, 8, k) solver come out wrong -- power-of-two pairs whose 2-D kernel

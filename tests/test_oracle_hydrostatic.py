@@ -335,3 +335,38 @@ def test_config5_combination_budgets():
         assert drift <= 5 * dt * wtop / g.dz * np.abs(g.interior(c)).max() * g.Nx * g.Ny * 2   # surface flux bound
         assert drift < 1e-7 * abs(c0)
     assert np.abs(m.U).max() > 0 and np.abs(g.interior(m.w)).max() > 0
+
+
+def test_split_explicit_ab3_scheme_wave():
+    """timestepper = AdamsBashforth3Scheme() (split_explicit_timesteppers.jl:19-159; the reference has no test of it): the same long surface
+    wave as the ForwardBackward test stays stable at a baroclinic gravity-wave CFL of 0.8, follows cos(ω t), conserves mean(η), and with
+    coefficients (α, θ, β) = (1, 0, 0), (δ, μ, γ, ϵ) = (1, 0, 0, 0) the scheme reduces to the ForwardBackward one bit for bit."""
+    Nx, H, L = 32, 20.0, 4.0e3
+    a, k = 1e-4, 2 * np.pi / L
+
+    def run(ts, coeffs=None, nsteps=80):
+        g = O.Grid((Nx, 4, 4), x=(0, L), y=(0, 500.0), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+        m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2", split_explicit_substeps=30, split_explicit_timestepper=ts)
+        if coeffs is not None:
+            m.ab3 = coeffs
+        x = (np.arange(Nx) + 0.5) * g.dx
+        m.set(eta=a * np.cos(k * x)[:, None] * np.ones((1, 4)))
+        kd = 2 / g.dx * np.sin(k * g.dx / 2)
+        omega = np.sqrt(Hy.g_Earth * H) * kd
+        dt = 2 * np.pi / omega / 40
+        amp = []
+        for _ in range(nsteps):
+            m.time_step(dt)
+            e = m.eta[g.Hx:g.Hx + Nx, g.Hy:g.Hy + 4]
+            amp.append(2 * np.mean(e[:, 0] * np.cos(k * x)) / a)
+            assert abs(e.sum()) < 1e-16 * Nx * 4
+        return m, np.array(amp), omega * dt * np.arange(1, nsteps + 1)
+
+    m, amp, phase = run("AdamsBashforth3")
+    assert m.ab3 is not None and abs(m.ab3["alpha"] + m.ab3["theta"] + m.ab3["beta"] - 1) < 1e-15
+    assert abs(m.ab3["delta"] + m.ab3["mu"] + m.ab3["gamma"] + m.ab3["epsilon"] - 1) < 1e-15       # both extrapolations are consistent
+    assert np.abs(amp - np.cos(phase)).max() < 0.12 and 0.9 < amp[79] < 1.01
+    fb, amp_fb, _ = run("ForwardBackward", nsteps=10)
+    deg, amp_deg, _ = run("AdamsBashforth3", coeffs=dict(alpha=1.0, theta=0.0, beta=0.0, delta=1.0, mu=0.0, gamma=0.0, epsilon=0.0), nsteps=10)
+    np.testing.assert_array_equal(deg.eta, fb.eta)
+    np.testing.assert_array_equal(deg.U, fb.U)
