@@ -72,6 +72,13 @@ __device__ __forceinline__ double fast_rcp(double x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
 }
+// the same with ONE Newton step: v_rcp_f64 is good to about 2^-26 relative, one step squares that (~2^-52); used where the
+// quotient is a convex combination of O(1) candidates (the WENO5 weights), whose value is insensitive to the last bit of 1/den
+__device__ __forceinline__ double fast_rcp1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
 #endif
 
 // WENO5 reconstruction at a face from S = psi[n-3..n+2] (weno_interpolants.jl:341-348, 445-447, 475-511)
@@ -136,12 +143,14 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double d0 = be0 + (OCN_WENO_EPS / 0.75), d1 = be1 + (OCN_WENO_EPS / 0.75), d2 = be2 + (OCN_WENO_EPS / 0.75);
     const double t2 = tau * tau;
     const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
-    const double m0 = (e0 + t2) * (e1 * e2);
-    const double m1 = (e1 + t2) * (e0 * e2);
-    const double m2 = (e2 + t2) * (e0 * e1);
+    // m_r = (e_r + t2) e_s e_t = e0 e1 e2 + t2 e_s e_t: 4 multiplies + 3 FMAs instead of 3 adds + 6 multiplies
+    const double e12 = e1 * e2, e02 = e0 * e2, e01 = e0 * e1, e012 = e0 * e12;
+    const double m0 = __builtin_fma(t2, e12, e012);
+    const double m1 = __builtin_fma(t2, e02, e012);
+    const double m2 = __builtin_fma(t2, e01, e012);
     const double num = __builtin_fma(cp2, m2, __builtin_fma(cp1, m1, cp0 * m0));
     const double den = __builtin_fma(OCN_C5_2, m2, __builtin_fma(OCN_C5_1, m1, OCN_C5_0 * m0));
-    return num * fast_rcp(den);
+    return num * fast_rcp1(den);
 #endif
 }
 

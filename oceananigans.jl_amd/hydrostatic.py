@@ -219,6 +219,8 @@ class HydrostaticFreeSurfaceModel:
     # ---- update_state! (update_hydrostatic_free_surface_model_state.jl:35-53, 74-96) -------------------------------------
     def update_state(self, compute_tendencies=True):
         nh, g = self._nh, self.grid
+        from .models import update_boundary_conditions
+        update_boundary_conditions(nh)
         fill_halo_regions((self.u, self.v) + tuple(self.tracers), fill_boundary_normal_velocities=False)
         self._fill_eta_halos()
         _lib.call("ocn_compute_w_from_continuity", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, stream_ptr())
@@ -346,6 +348,8 @@ class HydrostaticFreeSurfaceModel:
         euler = bool(euler or (dt != clock.last_dt))
         chi = -0.5 if euler else nh.timestepper.chi
         Gn, Gm = nh.timestepper._Gn, nh.timestepper._Gm
+        from .models import update_boundary_conditions
+        update_boundary_conditions(nh)   # (the deferred tendencies belong to update_state! at the current clock time)
         prog = [self.u, self.v] + list(self.tracers)
         if self._alt is None:
             self._alt = [torch.zeros_like(f.data) for f in prog]
@@ -396,6 +400,7 @@ class HydrostaticFreeSurfaceModel:
         nh.timestepper._Gn, nh.timestepper._Gm = Gm, Gn                     # cache_previous_tendencies!: role swap
         # update_state!(model; compute_tendencies = false): halos (w's halo columns are periodic images of the interior ones computed
         # above), η halos, hydrostatic pressure; the tendencies follow in the next step's fused launches
+        update_boundary_conditions(nh)   # Value / Gradient conditions of the halo fill at the new clock time
         if self._dist is not None:
             # slab-x rank: the x halos of u, v, T, S come from the neighbours; w (whose edge column needed the neighbour's corrected
             # u) is then recomputed from continuity on every column, halos included, as the reference's update_state! does

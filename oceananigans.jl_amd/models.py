@@ -160,8 +160,8 @@ class NonhydrostaticModel:
         self.general_terms = (isinstance(advection, (Centered, UpwindBiased)) or coriolis is not None or closure is not None
                               or buoyancy is not None or self._has_user_bcs)
         if self._has_user_bcs and hasattr(grid.architecture, "partition") and any(
-                s is not None and s.values is not None for b in bcs.values() for s in b.sides.values()):
-            raise NotImplementedError("array boundary conditions on a Distributed architecture are not implemented")
+                s is not None and (s.values is not None or s.func is not None) for b in bcs.values() for s in b.sides.values()):
+            raise NotImplementedError("array / function boundary conditions on a Distributed architecture are not implemented")
         self._terms = self._make_terms()
         # fused stage boundaries: tendencies (+ boundary fluxes) + the next substep in as few launches as possible.  Plain
         # WENO momentum uses the tiled kernel's epilogue; tracers and the §8(f) terms use the general fused entry points
@@ -270,10 +270,26 @@ def set(model, enforce_incompressibility=True, **kwargs):
         update_state(model, compute_tendencies=False)
 
 
+def update_boundary_conditions(model):
+    """update_boundary_condition!(fields, model) at the top of update_state! (update_nonhydrostatic_model_state.jl:29-31): function-valued
+    boundary conditions are evaluated at the current clock time (physics.py BoundaryCondition.refresh)."""
+    if not getattr(model, "_has_user_bcs", False):
+        return
+    fields = list(model.prognostic_fields())
+    d = getattr(model, "diffusivity_fields", None)
+    if d is not None:
+        fields += [d["nu_e"]] + list(d["kappa_e"])
+    for f in fields:
+        b = getattr(f, "boundary_conditions", None)
+        if b is not None:
+            b.refresh(model.grid, f.loc, model.clock.time)
+
+
 def update_state(model, compute_tendencies=True, defer_exchange=False):
     """update_state!: tupled halo fill of velocities+tracers (fill_boundary_normal_velocities=false), then tendencies.
     defer_exchange (Distributed, with compute_tendencies=False at the end of a step whose tendency launch is deferred): the x-halo
     exchange is only STARTED; the next step's fused launch overlaps it with its interior range (flush_tendencies completes it)."""
+    update_boundary_conditions(model)
     arch_hook = getattr(model.architecture, "update_state", None)
     if arch_hook is not None:  # Distributed: async exchange overlapped with interior tendencies
         return arch_hook(model, compute_tendencies, defer_exchange) if defer_exchange else arch_hook(model, compute_tendencies)
@@ -485,6 +501,7 @@ def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=Tru
     one finishing pass (extra terms, u / v boundary fluxes, substep), or the plain fused launch when there is nothing to add;
     each tracer = ONE launch (WENO advection, diffusion, boundary flux, substep).  All substep results land in a second set
     of arrays whose storage is then swapped into the fields.  Bit-identical to the unfused sequence in strict math."""
+    update_boundary_conditions(model)
     prog = model.prognostic_fields()
     if model._alt_fields is None:
         model._alt_fields = [torch.zeros_like(f.data) for f in prog]

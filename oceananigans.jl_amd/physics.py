@@ -144,21 +144,44 @@ class BoundaryCondition:
     ContinuousBoundaryFunction  f(x, y, t, c, p) = p * c  with field_dependencies = the field itself as
     condition + coeff * c[i, j, boundary-adjacent cell] (include/ocn_hip.h: struct ocn_bc)."""
 
-    def __init__(self, kind, condition=0.0, coeff=0.0):
+    def __init__(self, kind, condition=0.0, coeff=0.0, parameters=None):
+        """condition: a number, an (Nx, Ny) array, or a function f(x, y, t) [f(x, y, t, parameters) with `parameters`] of the two
+        coordinates tangential to a bottom / top boundary and time -- the reference's ContinuousBoundaryFunction without field
+        dependencies (continuous_boundary_function.jl:17-115).  The function is evaluated on the host at the field's own nodes (called
+        once with broadcastable arrays) every time the model state is updated, with the clock time of that moment, and uploaded into
+        the (Nx, Ny) device array the kernels read."""
         self.kind = kind
         self.coeff = float(coeff)
         self.values = None
         self.value = 0.0
+        self.func, self.parameters = None, parameters
         if np.isscalar(condition):
             self.value = float(condition)
         elif callable(condition):
-            raise NotImplementedError("function boundary conditions are not implemented (use a number, an array, or coeff=)")
+            self.func = condition
         else:
             self.values = np.ascontiguousarray(np.asarray(condition, dtype=np.float64).T)  # stored [j, i]: x fastest
         self._device_values = None
 
+    def refresh(self, grid, loc, time):
+        """Re-evaluate a function-valued condition at `time` (no-op otherwise)."""
+        if self.func is None:
+            return
+        x, y, _ = grid.nodes(loc)
+        x, y = x[:grid.Nx].reshape(-1, 1), y[:, :grid.Ny].reshape(1, -1)
+        args = (x, y, float(time)) if self.parameters is None else (x, y, float(time), self.parameters)
+        vals = np.broadcast_to(np.asarray(self.func(*args), dtype=np.float64), (grid.Nx, grid.Ny))
+        self.values = np.ascontiguousarray(vals.T)
+        if self._device_values is None:
+            self._device_values = on_architecture(grid.architecture, self.values)
+        else:
+            import torch
+            self._device_values.copy_(torch.from_numpy(self.values))
+
     def c_struct(self, grid):
         ptr = None
+        if self.func is not None and self._device_values is None:
+            raise RuntimeError("function-valued boundary condition used before its first evaluation (update_boundary_conditions)")
         if self.values is not None:
             if self.values.shape != (grid.Ny, grid.Nx):
                 raise ValueError(f"array boundary condition has shape {self.values.T.shape}, expected {(grid.Nx, grid.Ny)}")
@@ -168,16 +191,16 @@ class BoundaryCondition:
         return _lib.CBc(self.kind, 0, self.value, self.coeff, ptr)
 
 
-def FluxBoundaryCondition(condition=0.0, coeff=0.0):
-    return BoundaryCondition(_lib.BC_FLUX, condition, coeff)
+def FluxBoundaryCondition(condition=0.0, coeff=0.0, parameters=None):
+    return BoundaryCondition(_lib.BC_FLUX, condition, coeff, parameters)
 
 
-def ValueBoundaryCondition(condition=0.0):
-    return BoundaryCondition(_lib.BC_VALUE, condition)
+def ValueBoundaryCondition(condition=0.0, parameters=None):
+    return BoundaryCondition(_lib.BC_VALUE, condition, parameters=parameters)
 
 
-def GradientBoundaryCondition(condition=0.0):
-    return BoundaryCondition(_lib.BC_GRADIENT, condition)
+def GradientBoundaryCondition(condition=0.0, parameters=None):
+    return BoundaryCondition(_lib.BC_GRADIENT, condition, parameters=parameters)
 
 
 class FieldBoundaryConditions:
@@ -197,6 +220,12 @@ class FieldBoundaryConditions:
 
     def is_default(self):
         return all(v is None for v in self.sides.values())
+
+    def refresh(self, grid, loc, time):
+        """update_boundary_condition! for function-valued conditions: evaluate them at the clock time"""
+        for v in self.sides.values():
+            if v is not None:
+                v.refresh(grid, loc, time)
 
     def has_flux(self):
         return any(v is not None and v.kind == _lib.BC_FLUX for v in self.sides.values())

@@ -629,3 +629,54 @@ def test_ocean_wind_mixing_example_as_written_matches_oracle(oracle, ocn, mode):
         scale = vscale if name in "uvw" else np.abs(og.interior(a)).max()
         err = np.abs(og.interior(from_dev(d)) - og.interior(a)).max()
         assert err <= 1e-10 * scale, f"{name}: {err} > {1e-10 * scale}"
+
+
+def test_function_boundary_conditions(ocn):
+    """BoundaryCondition(Flux(), f) with f(x, y, t) [and `parameters`] (continuous_boundary_function.jl:17-115) at bottom / top.
+    (a) a time-independent function gives bit for bit what the array of its node values gives (tracer at Center nodes, u at x-Face
+    nodes), over 3 RK3 steps of a moving fluid; (b) the function sees the clock: after update_state! at clock time t the top-cell
+    tendency of a tracer at rest is -f(x, y, t) / Δz."""
+    P = "Periodic"
+    N = (16, 12, 8)
+    kw = dict(size=N, x=(0, 2.0), y=(-1.0, 1.0), z=(-1.0, 0.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
+    fc = lambda x, y, t: 1e-3 * (x + 2 * y)
+    fu = lambda x, y, t, p: p.amp * np.cos(np.pi * x) * (1 + y)
+
+    class Prm:
+        amp = 2e-3
+
+    def build(function):
+        g = ocn.RectilinearGrid(ocn.GPU(), **kw)
+        xc, yc, _ = g.nodes(0)
+        xf, _, _ = g.nodes(1)
+        if function:
+            bcs = {"c": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(fc)),
+                   "u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(fu, parameters=Prm))}
+        else:
+            bcs = {"c": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(fc(xc[:, :, 0], yc[:, :, 0], 0.0) + np.zeros(N[:2]))),
+                   "u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(fu(xf[:, :, 0], yc[:, :, 0], 0.0, Prm) + np.zeros(N[:2])))}
+        return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("c",), closure=ocn.ScalarDiffusivity(ν=1e-3, κ=1e-3), boundary_conditions=bcs)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    rng = np.random.default_rng(5)
+    init = dict(u=rng.uniform(-1, 1, N), v=rng.uniform(-1, 1, N), c=rng.uniform(0, 1, N))
+    a, b = build(True), build(False)
+    for m in (a, b):
+        ocn.set(m, **init)
+        for _ in range(3):
+            ocn.time_step(m, 2e-3)
+    ocn.sync_device()
+    for fa, fb in zip(a.prognostic_fields(), b.prognostic_fields()):
+        np.testing.assert_array_equal(fa.interior(), fb.interior())
+    # (b) the clock
+    g = ocn.RectilinearGrid(ocn.GPU(), **kw)
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("c",),
+                                boundary_conditions={"c": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(lambda x, y, t: (1 + t) * (1 + x * y)))})
+    xc, yc, _ = g.nodes(0)
+    for t in (0.0, 0.75):
+        m.clock.time = t
+        ocn.update_state(m, compute_tendencies=True)
+        ocn.sync_device()
+        Gc = m.timestepper.Gn[3].interior()
+        np.testing.assert_allclose(Gc[:, :, -1], -(1 + t) * (1 + xc[:, :, 0] * yc[:, :, 0]) / g.dz, rtol=1e-14)
+        assert np.abs(Gc[:, :, :-1]).max() == 0
