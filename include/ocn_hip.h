@@ -342,6 +342,15 @@ int ocn_barotropic_split_explicit_corrector(const ocn_grid *grid, double *u, dou
 int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
                                         double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
                                         double *V_filtered, const double *GU, const double *GV, double *work, void *stream);
+/* ocn_compute_tracer_tendency_terms_rk3 for TWO tracers in one launch (T and S): u, v, w at the faces, the upwind directions, the metrics
+ * and the tile staging are shared; per tracer the arithmetic is unchanged (bit-identical to two separate launches).  Every per-tracer
+ * argument is a HOST array of 2.  *launched = 0 when the range is too small for the tiled kernel (nothing was done: call the
+ * single-tracer entry twice). */
+int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, const double *kappa, const double *const *kappa_e,
+                                               const ocn_field_bcs *const *bcs_c, const double *u, const double *v, const double *w,
+                                               const double *const *c, double *const *Gc, const double *const *Gc_previous, double *const *c_out,
+                                               double dt, double gamma, double zeta, int32_t has_zeta, const int32_t *range,
+                                               int32_t *launched, void *stream);
 /* The substep loop with timestepper = AdamsBashforth3Scheme() (split_explicit_timesteppers.jl:19-159; the reference's two launches per
  * substep).  coefficients: HOST array {alpha, theta, beta, delta, mu, gamma, epsilon}; work: 7 planes (the scheme's history fields,
  * re-initialised from the current state at every call as initialize_free_surface_timestepper! does). */

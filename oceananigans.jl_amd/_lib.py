@@ -77,6 +77,9 @@ _SIGS = {
                                                  + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, C.POINTER(_i32), _vp],
     "ocn_compute_tracer_tendency_terms_rk3": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, C.POINTER(CFieldBcs)]
                                              + [_vp] * 7 + [_dbl, _dbl, _dbl, _i32, C.POINTER(_i32), _vp],
+    "ocn_compute_tracer_pair_tendency_terms_rk3": [C.POINTER(CGrid), C.POINTER(CModelTerms), C.POINTER(_dbl), C.POINTER(_vp),
+                                                   C.POINTER(C.POINTER(CFieldBcs)), _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                                   C.POINTER(_vp), _dbl, _dbl, _dbl, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp],
     "ocn_update_hydrostatic_pressure": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp],
     "ocn_update_hydrostatic_pressure_range": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _i32, _i32, _vp],
     "ocn_compute_amd_diffusivities_range": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp, _i32, C.POINTER(_dbl), C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _vp],

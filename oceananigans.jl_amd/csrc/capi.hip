@@ -596,6 +596,45 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
     return launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, as_stream(stream), &tf);
 }
 
+int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, const double *kappa, const double *const *kappa_e,
+                                               const ocn_field_bcs *const *bcs_c, const double *u, const double *v, const double *w,
+                                               const double *const *c, double *const *Gc, const double *const *Gc_previous, double *const *c_out,
+                                               double dt, double gamma, double zeta, int32_t has_zeta, const int32_t *range,
+                                               int32_t *launched, void *stream)
+{
+    int st = validate_terms(grid, terms);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(launched, "ocn_compute_tracer_pair_tendency_terms_rk3: launched is NULL");
+    *launched = 0;
+    OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_pair_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
+    OCN_REQUIRE(u && v && w && c && Gc && c_out && kappa, "ocn_compute_tracer_pair_tendency_terms_rk3: null pointer");
+    TracerFuse tf[2];
+    for (int t = 0; t < 2; ++t) {
+        OCN_REQUIRE(c[t] && Gc[t] && c_out[t] && c_out[t] != c[t], "ocn_compute_tracer_pair_tendency_terms_rk3: null or aliased field pointer");
+        OCN_REQUIRE(!has_zeta || (Gc_previous && Gc_previous[t]), "ocn_compute_tracer_pair_tendency_terms_rk3: G⁻ is required when has_zeta != 0");
+        OCN_REQUIRE(!(kappa_e && kappa_e[t]) || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
+        tf[t] = TracerFuse{};
+        tf[t].diffusion = terms->closure != 0;
+        tf[t].kappa = kappa[t];
+        tf[t].kappa_e = kappa_e ? kappa_e[t] : nullptr;
+        st = flux_side(grid, bcs_c ? bcs_c[t] : nullptr, "tracer", tf[t].bottom, tf[t].top);
+        if (st != OCN_SUCCESS) return st;
+        tf[t].sub = SubstepDev{Gc_previous ? Gc_previous[t] : nullptr, c_out[t]};
+        tf[t].sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
+    }
+    int did = 0;
+    hipStream_t s = as_stream(stream);
+    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    if (terms->advection == OCN_ADVECTION_WENO5)
+        st = strict ? ocn_strict::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did)
+                    : ocn_fast::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did);
+    else
+        st = strict ? ocn_strict_up::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did)
+                    : ocn_fast_up::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did);
+    *launched = did;
+    return st;
+}
+
 int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
                                         double column_depth, double *eta, double *U, double *V, double *eta_filtered, double *U_filtered,
                                         double *V_filtered, const double *GU, const double *GV, double *work, void *stream)

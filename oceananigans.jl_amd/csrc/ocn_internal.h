@@ -108,6 +108,8 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *const c[2],
+                                double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched);
 int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                               double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
@@ -131,6 +133,8 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *const c[2],
+                                double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched);
 int launch_momentum_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                               double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_centered2(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
@@ -156,10 +160,14 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *const c[2],
+                                double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched);
 }
 namespace ocn_fast_up {
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                            double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *const c[2],
+                                double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched);
 }

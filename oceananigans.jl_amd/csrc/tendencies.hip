@@ -719,6 +719,185 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
     }
 }
 
+// Two tracers in ONE launch (T and S of the ocean configurations): the tiled kernel above with every tracer-specific quantity doubled --
+// c plane + ring in LDS, z window, shared-flux exchange, κₑ plane, G⁻, substep output -- while u, v, w at the faces, the upwind
+// directions, the metrics, the barriers and all index arithmetic are shared.  The two single-tracer launches read u, v, w twice
+// (24 of their 56 algorithmic bytes per cell each) and are bound by HBM traffic + latency rather than VALU issue
+// (profiles/r02a_config4.md: 4.6 TB/s, VALU busy 0.55); per tracer the arithmetic is the text of tracer_tendency_tiled, so results
+// are bit-identical to two separate launches.
+struct TracerPair {
+    const double *c[2];
+    double *G[2];
+    ocn::TracerFuse tf[2];
+};
+template <int TZ, int TX, int TY>
+__global__ __launch_bounds__(TX *TY) void tracer_pair_tendency_tiled(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                                    const double *__restrict__ w, TracerPair tp, Range r, int KZ)
+{
+    constexpr int P = OCN_PERIODIC, NTR = 2;
+    constexpr int LX = TX + 5, LY = TY + 5, NT = TX * TY;
+    constexpr int NRING = LX * LY - NT;
+    constexpr int RPT = (NRING + NT - 1) / NT;
+    static_assert(RPT <= 2, "tile too small for its ring");
+    __shared__ double sc[NTR][LY][LX];
+    __shared__ double sk[NTR][LY][LX];
+    __shared__ double ex[2 * NTR][NT];
+
+    Metrics M = make_metrics(g);
+    if (TZ == OCN_PERIODIC) M.dzc = M.dzf = nullptr;
+    const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);
+    const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
+    const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
+    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
+    const int k_start = r.k0 + blockIdx.z * KZ, k_end = min(k_start + KZ - 1, r.k1);
+    const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
+    const int i = min(ti0 + tx, imax), j = min(tj0 + ty, jmax);
+    const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
+    const int lx = tx + 3, ly = ty + 3;
+    const long long s3 = L0.s3;
+    const long long own0 = ocn::at(L0, i, j, 1);
+    const double *pu = u + own0, *pv = v + own0, *pw = w + own0;
+    const double *pc[NTR] = {tp.c[0] + own0, tp.c[1] + own0};
+
+    int rcx[RPT], rcy[RPT];
+    bool ron[RPT];
+    long long roff[RPT];
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+        const int q = tid + s * NT;
+        ron[s] = q < NRING;
+        int cx, cy;
+        if (q < 3 * LX) {
+            cx = q % LX; cy = q / LX;
+        } else if (q < 5 * LX) {
+            cx = (q - 3 * LX) % LX; cy = 3 + TY + (q - 3 * LX) / LX;
+        } else {
+            const int t = q - 5 * LX, cc = t % 5;
+            cy = 3 + t / 5;
+            cx = cc < 3 ? cc : TX + cc;
+        }
+        if (!ron[s]) { cx = 0; cy = 0; }
+        rcx[s] = cx; rcy[s] = cy;
+        roff[s] = ocn::at(L0, min(ti0 - 3 + cx, imax), min(tj0 - 3 + cy, jmax), 1);
+    }
+
+    double zc[NTR][6], fzb[NTR];
+    int k = k_start;
+    const double az = M.Az;
+    double uf, vf, wf;
+    uf = pu[(long long)(k - 1) * s3];
+    vf = pv[(long long)(k - 1) * s3];
+    {
+        const double wb = pw[(long long)(k - 1) * s3];  // bottom-face flux of plane k_start: stencil c[k-3 .. k+2]
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) zc[t][m] = pc[t][(long long)(k - 3 + m) * s3];
+            const double cm3 = pc[t][(long long)(k - 4) * s3];
+            const double S[6] = {cm3, zc[t][0], zc[t][1], zc[t][2], zc[t][3], zc[t][4]};
+            fzb[t] = (az * wb) * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wb > 0);
+        }
+    }
+    wf = pw[(long long)k * s3];
+    bool kfld[NTR];
+    const double *pke[NTR];
+    double zk[NTR][3], rk[NTR][RPT], rv[NTR][RPT], znew[NTR];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+        kfld[t] = tp.tf[t].diffusion && tp.tf[t].kappa_e != nullptr;
+        pke[t] = kfld[t] ? tp.tf[t].kappa_e + own0 : nullptr;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) zk[t][m] = kfld[t] ? pke[t][(long long)(k - 2 + m) * s3] : 0.0;
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) {
+            rk[t][s] = (kfld[t] && ron[s]) ? tp.tf[t].kappa_e[roff[s] + (long long)(k - 1) * s3] : 0.0;
+            rv[t][s] = ron[s] ? tp.c[t][roff[s] + (long long)(k - 1) * s3] : 0.0;
+        }
+        znew[t] = (k < k_end) ? pc[t][(long long)(k + 3) * s3] : 0.0;
+    }
+    for (; k <= k_end; ++k) {
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            sc[t][ly][lx] = zc[t][2];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) sc[t][rcy[s]][rcx[s]] = rv[t][s];
+            if (kfld[t]) {
+                sk[t][ly][lx] = zk[t][1];
+#pragma unroll
+                for (int s = 0; s < RPT; ++s)
+                    if (ron[s]) sk[t][rcy[s]][rcx[s]] = rk[t][s];
+            }
+        }
+        __syncthreads();
+        const bool more = k < k_end;
+        const long long o = own0 + (long long)(k - 1) * s3;
+        double rk_n[NTR][RPT], zk_n[NTR], rv_n[NTR][RPT], znew_n[NTR], gm[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) {
+                rk_n[t][s] = (kfld[t] && more && ron[s]) ? tp.tf[t].kappa_e[roff[s] + (long long)k * s3] : 0.0;
+                rv_n[t][s] = (more && ron[s]) ? tp.c[t][roff[s] + (long long)k * s3] : 0.0;
+            }
+            zk_n[t] = (kfld[t] && more) ? pke[t][(long long)(k + 1) * s3] : 0.0;
+            znew_n[t] = (k + 1 < k_end) ? pc[t][(long long)(k + 4) * s3] : 0.0;
+            gm[t] = (writes && tp.tf[t].sc.on && tp.tf[t].sc.has_zeta) ? tp.tf[t].sub.Gm[o] : 0.0;
+        }
+        const double uf_n = more ? pu[(long long)k * s3] : 0.0, vf_n = more ? pv[(long long)k * s3] : 0.0;
+        const double wf_n = more ? pw[(long long)(k + 1) * s3] : 0.0;
+        const double ax = M.Ax(k), ay = M.Ay(k);
+        const bool lu = uf > 0, lv = vf > 0, lw = wf > 0;
+        double fxw[NTR], fys[NTR], fzt[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            fxw[t] = (ax * uf) * bias_interp<P, false>([&](int m) { return sc[t][ly][lx + m]; }, i, Nx, lu);
+            fys[t] = (ay * vf) * bias_interp<P, false>([&](int m) { return sc[t][ly + m][lx]; }, j, Ny, lv);
+            fzt[t] = (az * wf) * bias_interp<TZ, false>([&](int m) { return zc[t][m + 3]; }, k + 1, Nz, lw);
+            ex[2 * t][tid] = fxw[t];
+            ex[2 * t + 1][tid] = fys[t];
+        }
+        double cxm[NTR], cxp[NTR], cym[NTR], cyp[NTR];
+        Kappa7 K[NTR];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            cxm[t] = sc[t][ly][lx - 1]; cxp[t] = sc[t][ly][lx + 1]; cym[t] = sc[t][ly - 1][lx]; cyp[t] = sc[t][ly + 1][lx];
+            const double kp = tp.tf[t].kappa;
+            K[t] = Kappa7{kp, kp, kp, kp, kp, kp, kp};
+            if (kfld[t]) K[t] = Kappa7{zk[t][1], sk[t][ly][lx - 1], sk[t][ly][lx + 1], sk[t][ly - 1][lx], sk[t][ly + 1][lx], zk[t][0], zk[t][2]};
+        }
+        __syncthreads();
+        if (writes) {
+            const double rV = recip_volume(M.Az * M.dzC(k));
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) {
+                const ocn::TracerFuse &tf = tp.tf[t];
+                const double fxe = ex[2 * t][tid + 1], fyn = ex[2 * t + 1][tid + TX];
+                double G = -(rV * (((fxe - fxw[t]) + (fyn - fys[t])) + (fzt[t] - fzb[t])));
+                if (tf.diffusion || tf.bottom.kind || tf.top.kind)
+                    G = tracer_finish<TZ>(G, M, g, tf, i, j, k, K[t], zc[t][2], cxm[t], cxp[t], cym[t], cyp[t], zc[t][1], zc[t][3], ax, ay, az);
+                tp.G[t][o] = G;
+                if (tf.sc.on) tf.sub.out[o] = zc[t][2] + (tf.sc.has_zeta ? tf.sc.dt * (tf.sc.gamma * G + tf.sc.zeta * gm[t]) : (tf.sc.dt * tf.sc.gamma) * G);
+            }
+        }
+        uf = uf_n; vf = vf_n; wf = wf_n;
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            fzb[t] = fzt[t];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) zc[t][m] = zc[t][m + 1];
+            zc[t][5] = znew[t];
+            znew[t] = znew_n[t];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s) {
+                rv[t][s] = rv_n[t][s];
+                rk[t][s] = rk_n[t][s];
+            }
+            zk[t][0] = zk[t][1]; zk[t][1] = zk[t][2]; zk[t][2] = zk_n[t];
+        }
+    }
+}
+
 static int tile_variant()
 {
     const char *e = getenv("OCN_TILE");
@@ -901,6 +1080,37 @@ int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *
         default: ocn::set_error("unsupported z topology %d", grid->tz); return OCN_ERR_UNSUPPORTED;
     }
     OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// both tracers must take the tiled path (the caller falls back to two single launches otherwise): returns 1 when launched
+int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *const c[2],
+                                double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched)
+{
+    *launched = 0;
+    Range r;
+    int st = make_range(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    if (r.i1 < r.i0 || r.j1 < r.j0 || r.k1 < r.k0) { *launched = 1; return OCN_SUCCESS; }
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;
+    // Measured on MI355X (round 2): 192 VGPRs -> 2 waves / SIMD; config 5 11.7 ms / step against 11.3 with two single launches, config 4
+    // 40.7 against 40.8 -- the shared loads do not pay for the lost occupancy.  Kept as an option (OCN_TRACER_PAIR=1), off by default.
+    static const int off = !(getenv("OCN_TRACER_PAIR") && !strcmp(getenv("OCN_TRACER_PAIR"), "1"));
+    if (off || grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    TracerPair tp{};
+    for (int t = 0; t < 2; ++t) { tp.c[t] = c[t]; tp.G[t] = Gc[t]; tp.tf[t] = fuse[t]; }
+    constexpr int TX = 32, TY = 8;
+    const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+    int KZ = wz;
+    while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+    dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+    if (grid->tz == OCN_PERIODIC)
+        hipLaunchKernelGGL((tracer_pair_tendency_tiled<OCN_PERIODIC, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, tp, r, KZ);
+    else
+        hipLaunchKernelGGL((tracer_pair_tendency_tiled<OCN_BOUNDED, TX, TY>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, tp, r, KZ);
+    OCN_CHECK_HIP(hipGetLastError());
+    *launched = 1;
     return OCN_SUCCESS;
 }
 

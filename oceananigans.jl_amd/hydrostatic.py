@@ -365,13 +365,14 @@ class HydrostaticFreeSurfaceModel:
                   None if self.split else self.eta.data_ptr(), grav, *sp, s)
         # tracer tendencies + ab2_step_tracers!
         gamma, zeta = 1.5 + chi, -(0.5 + chi)
-        for n, c in enumerate(self.tracers):
-            kappa = 0.0 if nh.closure is None else nh.closure.kappa_of(self.tracer_names[n])
-            if self._tracer_fusable:
-                _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, None, _bcs_ref(c, g), self.u.ptr, self.v.ptr, self.w.ptr,
-                          c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[2 + n].data_ptr(), float(dt), gamma, zeta, 0 if euler else 1, None, s)
-            else:
-                _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappa, None, self.u.ptr, self.v.ptr, self.w.ptr, c.ptr,
+        kappas = [0.0 if nh.closure is None else nh.closure.kappa_of(name) for name in self.tracer_names]
+        if self._tracer_fusable and self.tracers:
+            from .models import fused_tracer_launches
+            fused_tracer_launches(g, t, self.u, self.v, self.w, self.tracers, kappas, [None] * len(self.tracers), Gn[3:], Gm[3:], alt[2:], dt,
+                                  gamma, zeta, 0 if euler else 1, None, s)
+        else:
+            for n, c in enumerate(self.tracers):
+                _lib.call("ocn_compute_tracer_tendency_terms", g.cref, t, kappas[n], None, self.u.ptr, self.v.ptr, self.w.ptr, c.ptr,
                           Gn[3 + n].ptr, None, s)
         if self.tracers and not self._tracer_fusable:
             self._apply_tracer_flux_bcs()

@@ -496,6 +496,33 @@ def _bcs_ref(field, grid):
     return C.byref(b.c_struct(grid)) if b is not None and b.has_flux() else None
 
 
+def fused_tracer_launches(grid, terms_ref, u, v, w, tracers, kappas, kappa_es, Gn, Gm, outs, dt, gamma, zeta, has_zeta, rng, s):
+    """tendency + boundary flux + the next substep of every tracer: pairs of tracers share ONE launch
+    (ocn_compute_tracer_pair_tendency_terms_rk3: u, v, w and the tile staging are read once for both), a remaining single tracer -- and
+    ranges too small for the tiled kernel -- take ocn_compute_tracer_tendency_terms_rk3."""
+    n, q = len(tracers), 0
+    r = None if rng is None else _lib.i32_array(list(rng))
+    while q < n:
+        if q + 1 < n:
+            pair = (q, q + 1)
+            did = C.c_int32(0)
+            bcs = (C.POINTER(_lib.CFieldBcs) * 2)(*[(C.pointer(tracers[t].boundary_conditions.c_struct(grid))
+                                                      if tracers[t].boundary_conditions is not None and tracers[t].boundary_conditions.has_flux()
+                                                      else C.POINTER(_lib.CFieldBcs)()) for t in pair])
+            _lib.call("ocn_compute_tracer_pair_tendency_terms_rk3", grid.cref, terms_ref, (C.c_double * 2)(*[float(kappas[t]) for t in pair]),
+                      _lib.ptr_array([kappa_es[t] for t in pair]), bcs, u.ptr, v.ptr, w.ptr, _lib.ptr_array([tracers[t].ptr for t in pair]),
+                      _lib.ptr_array([Gn[t].ptr for t in pair]), _lib.ptr_array([Gm[t].ptr for t in pair]),
+                      _lib.ptr_array([outs[t].data_ptr() for t in pair]), float(dt), float(gamma), float(zeta), int(has_zeta), r,
+                      C.byref(did), s)
+            if did.value:
+                q += 2
+                continue
+        c = tracers[q]
+        _lib.call("ocn_compute_tracer_tendency_terms_rk3", grid.cref, terms_ref, float(kappas[q]), kappa_es[q], _bcs_ref(c, grid), u.ptr, v.ptr,
+                  w.ptr, c.ptr, Gn[q].ptr, Gm[q].ptr, outs[q].data_ptr(), float(dt), float(gamma), float(zeta), int(has_zeta), r, s)
+        q += 1
+
+
 def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=True):
     """update_state! + the next rk3_substep! for models with tracers and / or the §8(f) terms: momentum = tiled WENO launch +
     one finishing pass (extra terms, u / v boundary fluxes, substep), or the plain fused launch when there is nothing to add;
@@ -524,14 +551,15 @@ def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=Tru
             _lib.call("ocn_compute_momentum_tendencies_rk3", g.cref, model.u.ptr, model.v.ptr, model.w.ptr, Gn[0].ptr, Gn[1].ptr,
                       Gn[2].ptr, Gm[0].ptr, Gm[1].ptr, Gm[2].ptr, alt[0].data_ptr(), alt[1].data_ptr(), alt[2].data_ptr(),
                       float(dt), float(gamma), z, hz, None, 0.0, r, s)
-        for n, c in enumerate(model.tracers):
-            kappa, kappa_e = 0.0, None
-            if model.diffusivity_fields is not None:
-                kappa_e = model.diffusivity_fields["kappa_e"][n].ptr
-            elif model.closure is not None:
-                kappa = model.closure.kappa_of(model.tracer_names[n])
-            _lib.call("ocn_compute_tracer_tendency_terms_rk3", g.cref, t, kappa, kappa_e, _bcs_ref(c, g), model.u.ptr, model.v.ptr,
-                      model.w.ptr, c.ptr, Gn[3 + n].ptr, Gm[3 + n].ptr, alt[3 + n].data_ptr(), float(dt), float(gamma), z, hz, r, s)
+        nt = len(model.tracers)
+        if nt:
+            kappas, kappa_es = [0.0] * nt, [None] * nt
+            for n in range(nt):
+                if model.diffusivity_fields is not None:
+                    kappa_es[n] = model.diffusivity_fields["kappa_e"][n].ptr
+                elif model.closure is not None:
+                    kappas[n] = model.closure.kappa_of(model.tracer_names[n])
+            fused_tracer_launches(g, t, model.u, model.v, model.w, model.tracers, kappas, kappa_es, Gn[3:], Gm[3:], alt[3:], dt, gamma, z, hz, rng, s)
 
     hook = getattr(model.architecture, "update_state_general", None) if fill_halos else None
     if hook is not None:  # Distributed: halo exchange overlapped with the interior auxiliaries and tendencies (distributed.py)

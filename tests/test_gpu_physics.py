@@ -680,3 +680,58 @@ def test_function_boundary_conditions(ocn):
         Gc = m.timestepper.Gn[3].interior()
         np.testing.assert_allclose(Gc[:, :, -1], -(1 + t) * (1 + xc[:, :, 0] * yc[:, :, 0]) / g.dz, rtol=1e-14)
         assert np.abs(Gc[:, :, :-1]).max() == 0
+
+
+def test_tracer_pair_launch_equals_two_single_launches(ocn):
+    """ocn_compute_tracer_pair_tendency_terms_rk3 (T and S in one launch, an option that is off by default: it measured no faster) against
+    two ocn_compute_tracer_tendency_terms_rk3 launches: G and the substep output of both tracers, bit for bit in strict math (1e-13 in fast math),
+    with diffusion, a top flux condition and a G⁻ term."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, torch, ctypes as C
+import oceananigans_jl_amd as ocn
+from oceananigans_jl_amd import _lib
+from oceananigans_jl_amd.models import fused_tracer_launches
+N = (40, 24, 12)
+g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 2.0), y=(0, 1.0), z=(-1.0, 0.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), closure=ocn.ScalarDiffusivity(ν=1e-3, κ=1e-3),
+                            boundary_conditions={"T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(3e-4))})
+rng = np.random.default_rng(3)
+ocn.set(m, u=rng.uniform(-1, 1, N), v=rng.uniform(-1, 1, N), T=rng.uniform(0, 1, N), S=rng.uniform(30, 31, N))
+out = {}
+for mode in (ocn.MATH_STRICT, ocn.MATH_FAST):
+    ocn.set_math_mode(mode)
+    Gm = [torch.from_numpy(rng.uniform(-1, 1, tuple(c.data.shape))).cuda() for c in m.tracers]
+    class W:  # minimal field-like wrapper for the G arrays
+        def __init__(s, t): s.t = t
+        ptr = property(lambda s: s.t.data_ptr())
+    res = []
+    for rep in range(2):
+        Gn = [torch.zeros_like(c.data) for c in m.tracers]
+        outs = [torch.zeros_like(c.data) for c in m.tracers]
+        fused_tracer_launches(g, C.byref(m._terms), m.u, m.v, m.w, m.tracers, [2e-3, 1e-3], [None, None], [W(x) for x in Gn], [W(x) for x in Gm],
+                              outs, 1e-3, 0.6, -0.3, 1, None, 0)
+        torch.cuda.synchronize()
+        res.append([x.cpu().numpy() for x in Gn + outs])
+    out[mode] = res[0]
+np.savez(OUT, **{f"{k}_{q}": a for k, v in out.items() for q, a in enumerate(v)})
+"""
+    res = {}
+    for pair in ("0", "1"):
+        path = f"/tmp/ocn_pair_{pair}_{os.getpid()}.npz"
+        env = dict(os.environ, OCN_TRACER_PAIR=pair)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {root!r}); OUT = {path!r}\n" + code], check=True, env=env, timeout=300)
+        with np.load(path) as z:
+            res[pair] = {k: z[k] for k in z.files}
+        os.remove(path)
+    assert res["0"].keys() == res["1"].keys() and len(res["0"]) == 8
+    for k in res["0"]:
+        if k.startswith("0_"):   # strict math: bit for bit
+            np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
+        else:                    # fast math: the compiler contracts the two kernels' epilogues differently (last bit)
+            np.testing.assert_allclose(res["0"][k], res["1"][k], rtol=1e-13, atol=1e-15, err_msg=k)
+        assert np.abs(res["0"][k]).max() > 0
