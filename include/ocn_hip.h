@@ -306,6 +306,8 @@ int ocn_poisson_set_source_term(ocn_poisson_t solver, const double *R, void *str
 /* solve!(ϕ, solver): writes the interior of the haloed pressure field p (fft_based_poisson_solver.jl:95-125) */
 int ocn_poisson_solve(ocn_poisson_t solver, double *p, void *stream);
 /* solve_for_pressure! = source term + solve (solve_for_pressure.jl:78-82) */
+/* solve!(phi, solver, b, m) with m != 0: (laplacian + m) phi = b, no zero-mode gauge; FFT-based handles on the plain transform path */
+int ocn_poisson_solve_shifted(ocn_poisson_t solver, double *phi, double m, void *stream);
 int ocn_solve_for_pressure(ocn_poisson_t solver, double *p, const double *u, const double *v, const double *w, double dt,
                            void *stream);
 
@@ -351,6 +353,17 @@ int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_m
                                                const double *const *c, double *const *Gc, const double *const *Gc_previous, double *const *c_out,
                                                double dt, double gamma, double zeta, int32_t has_zeta, const int32_t *range,
                                                int32_t *launched, void *stream);
+/* ImplicitFreeSurface with the FFT solver (the reference's default free surface on an xy-regular RectilinearGrid;
+ * implicit_free_surface.jl:112-145, fft_based_implicit_free_surface_solver.jl:76-115, barotropic_pressure_correction.jl:21-47):
+ *   ocn_implicit_free_surface_rhs: compute_vertically_integrated_volume_flux! (Qu = sum_k Ax u, Qv = sum_k Ay v into (sx, sy) planes) and
+ *     fft_implicit_free_surface_right_hand_side!: rhs = (dx Qu + dy Qv - Az eta / dt) / (g Lz dt Az) into a halo-free (Nx, Ny) array;
+ *   the solve is ocn_poisson_set_source_term(rhs) + ocn_poisson_solve_shifted(handle of the (TX, TY, Flat) horizontal grid, eta, m)
+ *     with m = -1 / (g Lz dt^2): solve!(phi, solver, b, m) of the screened equation (fft_based_poisson_solver.jl:95-125);
+ *   ocn_barotropic_pressure_correction: u -= g dt dx(eta), v -= g dt dy(eta) at every level (eta halos filled). */
+int ocn_implicit_free_surface_rhs(const ocn_grid *grid, const double *u, const double *v, const double *eta, double gravitational_acceleration,
+                                  double dt, double *Qu, double *Qv, double *rhs, void *stream);
+int ocn_barotropic_pressure_correction(const ocn_grid *grid, double *u, double *v, const double *eta, double gravitational_acceleration,
+                                       double dt, void *stream);
 /* The substep loop with timestepper = AdamsBashforth3Scheme() (split_explicit_timesteppers.jl:19-159; the reference's two launches per
  * substep).  coefficients: HOST array {alpha, theta, beta, delta, mu, gamma, epsilon}; work: 7 planes (the scheme's history fields,
  * re-initialised from the current state at every call as initialize_free_surface_timestepper! does). */

@@ -28,7 +28,7 @@ from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTr
                       nonhydrostatic_pressure_solver, solve)
 
 
-from .hydrostatic import (AdamsBashforth3Scheme, ExplicitFreeSurface, ForwardBackwardScheme, HydrostaticFreeSurfaceModel, SplitExplicitFreeSurface,  # noqa: E402
+from .hydrostatic import (AdamsBashforth3Scheme, ExplicitFreeSurface, ForwardBackwardScheme, HydrostaticFreeSurfaceModel, ImplicitFreeSurface, SplitExplicitFreeSurface,  # noqa: E402
                           VectorInvariant)
 
 

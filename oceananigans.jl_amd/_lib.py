@@ -99,6 +99,9 @@ _SIGS = {
     "ocn_poisson_set_source_term": [_vp, _vp, _vp],
     "ocn_poisson_solve": [_vp, _vp, _vp],
     "ocn_solve_for_pressure": [_vp, _vp, _vp, _vp, _vp, _dbl, _vp],
+    "ocn_poisson_solve_shifted": [_vp, _vp, _dbl, _vp],
+    "ocn_implicit_free_surface_rhs": [C.POINTER(CGrid), _vp, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp],
+    "ocn_barotropic_pressure_correction": [C.POINTER(CGrid), _vp, _vp, _vp, _dbl, _dbl, _vp],
     "ocn_batched_tridiagonal_solve_z": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_halo_pack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x": [C.POINTER(CGrid), _vp, _i32, _vp, _vp, _vp],

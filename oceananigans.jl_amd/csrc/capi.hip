@@ -648,6 +648,25 @@ int ocn_split_explicit_substeps_blocked(const ocn_grid *grid, int32_t n, const d
                                                   U_filtered, V_filtered, GU, GV, work, as_stream(stream));
 }
 
+int ocn_implicit_free_surface_rhs(const ocn_grid *grid, const double *u, const double *v, const double *eta, double gravitational_acceleration,
+                                  double dt, double *Qu, double *Qv, double *rhs, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_implicit_free_surface_rhs");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE_PERIODIC_X("ocn_implicit_free_surface_rhs");
+    OCN_REQUIRE(u && v && eta && Qu && Qv && rhs, "ocn_implicit_free_surface_rhs: null pointer");
+    OCN_REQUIRE(dt > 0, "ocn_implicit_free_surface_rhs: dt must be positive");
+    return launch_implicit_free_surface_rhs(grid, u, v, eta, gravitational_acceleration, dt, Qu, Qv, rhs, as_stream(stream));
+}
+int ocn_barotropic_pressure_correction(const ocn_grid *grid, double *u, double *v, const double *eta, double gravitational_acceleration,
+                                       double dt, void *stream)
+{
+    int st = validate_hydrostatic(grid, "ocn_barotropic_pressure_correction");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && eta, "ocn_barotropic_pressure_correction: null pointer");
+    return launch_barotropic_pressure_correction(grid, u, v, eta, gravitational_acceleration, dt, as_stream(stream));
+}
+
 int ocn_split_explicit_substeps_ab3(const ocn_grid *grid, int32_t n, const double *weights, double dtau, double gravitational_acceleration,
                                     double column_depth, const double *coefficients, double *eta, double *U, double *V, double *eta_filtered,
                                     double *U_filtered, double *V_filtered, const double *GU, const double *GV, double *work, void *stream)

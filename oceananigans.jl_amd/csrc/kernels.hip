@@ -409,6 +409,72 @@ __global__ __launch_bounds__(256) void split_explicit_velocity_kernel(GridDev g,
     U[e] = Un;
     V[e] = Vn;
 }
+// ---- ImplicitFreeSurface with the FFT solver (implicit_free_surface.jl:112-145, fft_based_implicit_free_surface_solver.jl:76-115,
+// barotropic_pressure_correction.jl:21-47) on a (Periodic, Periodic, Bounded) static grid of constant depth Lz.
+// compute_vertically_integrated_volume_flux! (compute_vertically_integrated_variables.jl:34-41): Qu = Σₖ Axᶠᶜᶜ u, Qv = Σₖ Ayᶜᶠᶜ v
+// (sum! accumulates k ascending from zero)
+__global__ __launch_bounds__(256) void volume_flux_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
+                                                          double *__restrict__ Qu, double *__restrict__ Qv)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    long long o = at(L, i, j, 1);
+    double aU = 0.0, aV = 0.0;
+#pragma unroll 8
+    for (int k = 1; k <= g.Nz; ++k) {
+        const double dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        aU = aU + (g.dy * dz) * u[o];
+        aV = aV + (g.dx * dz) * v[o];
+        o += L.s3;
+    }
+    Qu[plane_at(g, i, j)] = aU;
+    Qv[plane_at(g, i, j)] = aV;
+}
+// fft_implicit_free_surface_right_hand_side!: rhs = (δx Qu + δy Qv - Az η / Δt) / (g Lz Δt Az) into a halo-free (Nx, Ny) array
+__global__ __launch_bounds__(256) void implicit_rhs_kernel(GridDev g, double grav, double Lz, double dt, const double *__restrict__ Qu,
+                                                           const double *__restrict__ Qv, const double *__restrict__ eta,
+                                                           double *__restrict__ rhs)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > g.Nx || j > g.Ny) return;
+    const int ip = i == g.Nx ? 1 : i + 1, jp = j == g.Ny ? 1 : j + 1;
+    const long long e = plane_at(g, i, j);
+    const double Az = g.dx * g.dy;
+    const double dQ = (Qu[plane_at(g, ip, j)] - Qu[e]) + (Qv[plane_at(g, i, jp)] - Qv[e]);
+    rhs[(i - 1) + (long long)g.Nx * (j - 1)] = (dQ - Az * eta[e] / dt) / (grav * Lz * dt * Az);
+}
+// _barotropic_pressure_correction!: u -= g Δt ∂xᶠᶜᶠ η, v -= g Δt ∂yᶜᶠᶠ η at every level (η halos filled)
+__global__ __launch_bounds__(256) void barotropic_pressure_correction_kernel(GridDev g, double *__restrict__ u, double *__restrict__ v,
+                                                                             const double *__restrict__ eta, double grav, double dt)
+{
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny) return;
+    const Lay L = make_lay(g, OCN_LOC_CCC);
+    const long long o = at(L, i, j, k), e = (i - 1 + g.Hx) + (long long)L.sx * (j - 1 + g.Hy);
+    u[o] -= grav * dt * ((eta[e] - eta[e - 1]) / g.dx);
+    v[o] -= grav * dt * ((eta[e] - eta[e - L.sx]) / g.dy);
+}
+int launch_implicit_free_surface_rhs(const ocn_grid *grid, const double *u, const double *v, const double *eta, double grav, double dt,
+                                     double *Qu, double *Qv, double *rhs, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, 1);
+    hipLaunchKernelGGL(volume_flux_kernel, nb, block, 0, stream, g, u, v, Qu, Qv);
+    hipLaunchKernelGGL(implicit_rhs_kernel, nb, block, 0, stream, g, grav, grid->Lz, dt, Qu, Qv, eta, rhs);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+int launch_barotropic_pressure_correction(const ocn_grid *grid, double *u, double *v, const double *eta, double grav, double dt,
+                                          hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    dim3 block(64, 4, 1), nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
+    hipLaunchKernelGGL(barotropic_pressure_correction_kernel, nb, block, 0, stream, g, u, v, eta, grav, dt);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // ---- AdamsBashforth3Scheme of the substepping (split_explicit_timesteppers.jl:19-159): the reference's two kernels per substep with the
 // AB3 extrapolations U★ = α Uᵐ + θ Uᵐ⁻¹ + β Uᵐ⁻² and η★ = δ ηᵐ⁺¹ + μ ηᵐ + γ ηᵐ⁻¹ + ϵ ηᵐ⁻² and their history updates
 // (cache_previous_free_surface! / cache_previous_velocities!).  A non-default option: kept in the reference's launch shape.
@@ -1084,14 +1150,16 @@ int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc
 // nxh = number of stored x modes (Nx for C2C, Nx/2+1 for the Hermitian half spectrum).
 __global__ __launch_bounds__(256) void spectral_solve_kernel(int nxh, int Ny, int Nz, const double *__restrict__ lx,
                                                              const double *__restrict__ ly, const double *__restrict__ lz,
-                                                             double2 *__restrict__ b, int zero_mode_here, int joff, int koff)
+                                                             double2 *__restrict__ b, int zero_mode_here, int joff, int koff, double m,
+                                                             int shifted)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
     const int k = blockIdx.z;
     if (i >= nxh || j >= Ny) return;
     const long long o = i + (long long)nxh * (j + (long long)Ny * k);
-    const double lam = (lx[i] + ly[j + joff]) + lz[k + koff];
+    double lam = (lx[i] + ly[j + joff]) + lz[k + koff];
+    if (shifted) lam = lam - m;  // the screened equation (∇² + m) ϕ = b (fft_based_poisson_solver.jl:108-110)
     double2 val = b[o];
     val.x = -val.x / lam;
     val.y = -val.y / lam;
@@ -1099,10 +1167,10 @@ __global__ __launch_bounds__(256) void spectral_solve_kernel(int nxh, int Ny, in
     b[o] = val;
 }
 int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
-                          int zero_mode_here, int joff, int koff, hipStream_t stream)
+                          int zero_mode_here, int joff, int koff, hipStream_t stream, double m, int shifted)
 {
     hipLaunchKernelGGL(spectral_solve_kernel, dim3((nxh + 63) / 64, (Ny + 3) / 4, Nz), dim3(64, 4), 0, stream, nxh, Ny, Nz, lx, ly,
-                       lz, reinterpret_cast<double2 *>(b), zero_mode_here, joff, koff);
+                       lz, reinterpret_cast<double2 *>(b), zero_mode_here && !shifted, joff, koff, m, shifted);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

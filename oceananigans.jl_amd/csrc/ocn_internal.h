@@ -37,7 +37,11 @@ int launch_source_term(const ocn_grid *grid, const double *u, const double *v, c
 int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc, int Hz, double *out, int complex_out,
                       long long ld1, long long ld2, hipStream_t stream);
 int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
-                          int zero_mode_here, int joff, int koff, hipStream_t stream);
+                          int zero_mode_here, int joff, int koff, hipStream_t stream, double m = 0.0, int shifted = 0);
+int launch_implicit_free_surface_rhs(const ocn_grid *grid, const double *u, const double *v, const double *eta, double grav, double dt,
+                                     double *Qu, double *Qv, double *rhs, hipStream_t stream);
+int launch_barotropic_pressure_correction(const ocn_grid *grid, double *u, double *v, const double *eta, double grav, double dt,
+                                          hipStream_t stream);
 int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source);
 int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream);
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);

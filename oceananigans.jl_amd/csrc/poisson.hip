@@ -144,6 +144,8 @@ struct ocn_poisson {
     bool source_in_rhs = false; // custom_xy: the source was given as a real array (set_source_term!) and still needs its x transform
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
+    double shift = 0.0;         // ocn_poisson_solve_shifted: (∇² + m) ϕ = b for this solve
+    bool shifted = false;
     // kind 2: FFTBasedPoissonSolver for ANY regular (Periodic | Bounded | Flat)^3 topology: separable transforms evaluated as direct sums
     // (DFT along Periodic, REDFT10 / REDFT01 along Bounded dimensions, plan_transforms.jl:16-34) -- the reference's K11 path
     double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per dimension: cos / sin tables
@@ -285,7 +287,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         std::swap(a, b);
     };
     for (int q = 0; q < no; ++q) pass(order[q], 0);
-    int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream);  // -b / (λx + λy + λz), mode (1,1,1) := 0
+    int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
     if (st != OCN_SUCCESS) return st;
     for (int q = no - 1; q >= 0; --q) pass(order[q], 1);
     OCN_CHECK_HIP(hipGetLastError());
@@ -769,6 +771,21 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
     return st;
 }
 
+// solve!(ϕ, solver, b, m) with m != 0 (fft_based_poisson_solver.jl:95-125): the screened equation (∇² + m) ϕ = b, no zero-mode gauge
+extern "C" int ocn_poisson_solve_shifted(ocn_poisson_t s, double *p, double m, void *stream_)
+{
+    OCN_REQUIRE(s && p, "ocn_poisson_solve_shifted: null argument");
+    OCN_REQUIRE(s->kind != 1, "ocn_poisson_solve_shifted: FFT-based solvers only");
+    OCN_REQUIRE(!s->custom_xy && !s->fused_z, "ocn_poisson_solve_shifted: not available on the fused transform pipelines (a Flat or small z "
+                "uses the plain path; OCN_POISSON_CUSTOM_XY=0 OCN_POISSON_FUSED_Z=0 select it elsewhere)");
+    s->shift = m;
+    s->shifted = true;
+    const int st = ocn_poisson_solve(s, p, stream_);
+    s->shift = 0.0;
+    s->shifted = false;
+    return st;
+}
+
 extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
 {
     OCN_REQUIRE(s && p, "ocn_poisson_solve: null argument");
@@ -818,7 +835,7 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
         st = ocn::launch_colfft(g->Nz, 2, s->spec, plane, 0, (int)plane, 1, s->tw, s->lx, s->ly, s->lz_stage,
                                 1.0 / ((double)g->Nx * g->Ny * g->Nz), s->nxh, stream);
     } else if (s->kind == 0) {
-        st = ocn::launch_spectral_solve(s->nxh, g->Ny, g->Nz, s->lx, s->ly, s->lz, s->spec, 1, 0, 0, stream);
+        st = ocn::launch_spectral_solve(s->nxh, g->Ny, g->Nz, s->lx, s->ly, s->lz, s->spec, 1, 0, 0, stream, s->shift, s->shifted);
     } else {
         st = ocn::launch_tridiag_z(s->nxh, g->Ny, g->Nz, s->lower, s->diag, s->lower, s->spec, s->tscr, s->spec2, stream);
         if (st != OCN_SUCCESS) return st;

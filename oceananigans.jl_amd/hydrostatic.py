@@ -42,6 +42,18 @@ class ExplicitFreeSurface:
         self.gravitational_acceleration = float(gravitational_acceleration)
 
 
+class ImplicitFreeSurface:
+    """ImplicitFreeSurface(; solver_method = :Default, gravitational_acceleration = g_Earth) (implicit_free_surface.jl:79-80): the
+    reference's default free surface on an xy-regular RectilinearGrid (hydrostatic_free_surface_model.jl:51-52).  Only the
+    :FastFourierTransform solver (its default there, FFTImplicitFreeSurfaceSolver) is implemented:
+        (∇² - 1 / (g Lz Δt²)) ηⁿ⁺¹ = (∇ʰ·Q★ - ηⁿ / Δt) / (g Lz Δt),    u -= g Δt ∂x ηⁿ⁺¹."""
+
+    def __init__(self, solver_method="Default", gravitational_acceleration=g_Earth):
+        if str(solver_method).lstrip(":") not in ("Default", "FastFourierTransform"):
+            raise NotImplementedError("ImplicitFreeSurface: only the FastFourierTransform solver is implemented")
+        self.gravitational_acceleration = float(gravitational_acceleration)
+
+
 def averaging_shape_function(tau, p=2, q=4, r=0.18927):
     """Shchepetkin & McWilliams (2005) averaging kernel (split_explicit_free_surface.jl:191-194)"""
     tau0 = (p + 2) * (p + q + 2) / (p + 1) / (p + q + 1)
@@ -150,13 +162,11 @@ class HydrostaticFreeSurfaceModel:
         if tuple(grid.topology) != (FullyConnected if self._dist is not None else Periodic, Periodic, Bounded):
             raise NotImplementedError("HydrostaticFreeSurfaceModel: (Periodic, Periodic, Bounded) grids (x may be slab-partitioned)")
         if free_surface is None:
-            # default_free_surface (hydrostatic_free_surface_model.jl:51-55): ImplicitFreeSurface on an xy-regular RectilinearGrid,
-            # which this backend does not have -- refuse rather than silently pick different numerics
-            raise NotImplementedError("HydrostaticFreeSurfaceModel: the reference's default free surface on this grid is ImplicitFreeSurface, "
-                                      "which is not implemented; pass free_surface = ExplicitFreeSurface() or SplitExplicitFreeSurface(...)")
-        if not isinstance(free_surface, (ExplicitFreeSurface, SplitExplicitFreeSurface)):
-            raise NotImplementedError("free_surface must be ExplicitFreeSurface(...) or SplitExplicitFreeSurface(substeps=...)")
+            free_surface = ImplicitFreeSurface()  # default_free_surface(grid::XYRegularRG) (hydrostatic_free_surface_model.jl:51-52)
+        if not isinstance(free_surface, (ExplicitFreeSurface, SplitExplicitFreeSurface, ImplicitFreeSurface)):
+            raise NotImplementedError("free_surface must be ExplicitFreeSurface(...), SplitExplicitFreeSurface(...) or ImplicitFreeSurface()")
         self.split = isinstance(free_surface, SplitExplicitFreeSurface)
+        self.implicit = isinstance(free_surface, ImplicitFreeSurface)
         if momentum_advection is None:
             momentum_advection = VectorInvariant()  # the reference's default (hydrostatic_free_surface_model.jl)
         self.vector_invariant = isinstance(momentum_advection, VectorInvariant)
@@ -190,7 +200,18 @@ class HydrostaticFreeSurfaceModel:
             self._initialized = False
         self._adv_only = _lib.CModelTerms()                                     # the advective part alone, by scheme
         self._adv_only.advection = nh._terms.advection
-        self.fused = self.vector_invariant if fused is None else bool(fused)
+        self.fused = (self.vector_invariant and not self.implicit) if fused is None else bool(fused)
+        if self.implicit:
+            if self.fused or self._dist is not None:
+                raise NotImplementedError("ImplicitFreeSurface: the reference's launch sequence on one GPU (fused = False)")
+            from .grids import Flat, RectilinearGrid
+            from .solvers import FFTBasedPoissonSolver
+            # FFTImplicitFreeSurfaceSolver (fft_based_implicit_free_surface_solver.jl:39-70): a Poisson solver on the horizontal grid
+            hgrid = RectilinearGrid(grid.architecture, size=(grid.Nx, grid.Ny), x=(grid._origin[0], grid._origin[0] + grid.Lx),
+                                    y=(grid._origin[1], grid._origin[1] + grid.Ly), topology=(Periodic, Periodic, Flat), halo=(grid.Hx, grid.Hy))
+            self._fs_solver = FFTBasedPoissonSolver(hgrid)
+            self._Qu, self._Qv = torch.zeros_like(self.eta), torch.zeros_like(self.eta)
+            self._fs_rhs = torch.zeros((grid.Ny, grid.Nx), dtype=torch.float64, device=dev)
         if self.fused and not self.vector_invariant:
             raise NotImplementedError("fused = True needs momentum_advection = VectorInvariant()")
         self._tracer_fusable = not isinstance(container_advection, Centered)    # the tiled WENO / UpwindBiased tracer kernel has the epilogue
@@ -242,14 +263,14 @@ class HydrostaticFreeSurfaceModel:
         Gn = nh.timestepper._Gn
         grav = self.free_surface.gravitational_acceleration
         # explicit_barotropic_pressure_x/y_gradient: g ∇η for the ExplicitFreeSurface, zero for the split-explicit one
-        eta_ptr = None if self.split else self.eta.data_ptr()
+        eta_ptr = None if (self.split or self.implicit) else self.eta.data_ptr()
         if self.vector_invariant:                                                         # - U_dot_∇u - g ∂x η, - U_dot_∇v - g ∂y η
             _lib.call("ocn_compute_vector_invariant_momentum_tendencies", g.cref, self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr,
                       Gn[1].ptr, eta_ptr, grav, s)
         else:
             _lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(self._adv_only), self.u.ptr, self.v.ptr, self.w.ptr,
                       Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, s)
-            if not self.split:
+            if not (self.split or self.implicit):
                 _lib.call("ocn_add_barotropic_pressure_gradient", g.cref, grav, self.eta.data_ptr(), Gn[0].ptr, Gn[1].ptr, s)  # - g ∇η
         _lib.call("ocn_add_momentum_terms", g.cref, C.byref(nh._terms), self.u.ptr, self.v.ptr, self.w.ptr, Gn[0].ptr, Gn[1].ptr,
                   Gn[2].ptr, None, s)                                                               # - f x U - ∇pHY′ - ∂ⱼτᵢⱼ
@@ -289,6 +310,18 @@ class HydrostaticFreeSurfaceModel:
             # pressure_correct_velocities!: the barotropic corrector
             _lib.call("ocn_barotropic_split_explicit_corrector", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(),
                       self._Ub.data_ptr(), self._Vb.data_ptr(), float(g.Lz), s)
+        elif self.implicit:
+            # step_free_surface!(::ImplicitFreeSurface) (implicit_free_surface.jl:112-145); the halo fills of the velocities and of the
+            # volume fluxes are not needed: the kernels wrap their x / y neighbour indices
+            _lib.call("ocn_implicit_free_surface_rhs", g.cref, self.u.ptr, self.v.ptr, self.eta.data_ptr(), fs.gravitational_acceleration,
+                      float(dt), self._Qu.data_ptr(), self._Qv.data_ptr(), self._fs_rhs.data_ptr(), s)
+            h = self._fs_solver._h
+            _lib.call("ocn_poisson_set_source_term", h, self._fs_rhs.data_ptr(), s)
+            _lib.call("ocn_poisson_solve_shifted", h, self.eta.data_ptr(), -1.0 / (fs.gravitational_acceleration * float(g.Lz) * float(dt) ** 2), s)
+            self._fill_eta_halos()
+            # pressure_correct_velocities!(model, ::ImplicitFreeSurface, Δt) (barotropic_pressure_correction.jl:21-47)
+            _lib.call("ocn_barotropic_pressure_correction", g.cref, self.u.ptr, self.v.ptr, self.eta.data_ptr(), fs.gravitational_acceleration,
+                      float(dt), s)
         else:
             # compute_free_surface_tendency! + step_free_surface!
             _lib.call("ocn_explicit_free_surface_ab2_step", g.cref, self.w.ptr, self.eta.data_ptr(), self._Geta.data_ptr(),

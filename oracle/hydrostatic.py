@@ -175,10 +175,12 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
 
     def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None,
                  buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None,
-                 split_explicit_timestepper="ForwardBackward"):
+                 split_explicit_timestepper="ForwardBackward", implicit_free_surface=False):
         """split_explicit_substeps = N: free_surface = SplitExplicitFreeSurface(substeps = N) with the ForwardBackwardScheme
         (split_explicit_free_surface.jl:60-97); None: ExplicitFreeSurface."""
         assert grid.topo[2] == O.BOUNDED and grid.topo[0] == O.PERIODIC and grid.topo[1] == O.PERIODIC
+        self.implicit = bool(implicit_free_surface)   # ImplicitFreeSurface(solver_method = :FastFourierTransform)
+        assert not (self.implicit and split_explicit_substeps is not None)
         self.split = split_explicit_substeps
         self.ab3 = ab3_coefficients() if split_explicit_timestepper in ("AdamsBashforth3", "AB3") else None
         if self.split is not None:
@@ -242,7 +244,7 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         e, Hx, Hy, Hz = self.eta, g.Hx, g.Hy, g.Hz
         px = np.zeros_like(e)
         py = np.zeros_like(e)
-        if getattr(self, "split", None) is None:  # SplitExplicitFreeSurface: explicit_barotropic_pressure_*_gradient = 0 (SplitExplicitFreeSurfaces.jl:46-47)
+        if getattr(self, "split", None) is None and not getattr(self, "implicit", False):  # Split-explicit / implicit: explicit_barotropic_pressure_*_gradient = 0 (SplitExplicitFreeSurfaces.jl:46-47, implicit_free_surface.jl:106-107)
             px[1:, :] = self.gravity * ((e[1:, :] - e[:-1, :]) / g.dx)
             py[:, 1:] = self.gravity * ((e[:, 1:] - e[:, :-1]) / g.dy)
         ii, jj = slice(Hx, Hx + g.Nx), slice(Hy, Hy + g.Ny)
@@ -328,6 +330,37 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         ui[...] = ui + ((self.U - self.Ub) / H)[:, :, None]
         vi[...] = vi + ((self.V - self.Vb) / H)[:, :, None]
 
+    def _implicit_step(self, dt):
+        """step_free_surface!(::ImplicitFreeSurface) with the FFTImplicitFreeSurfaceSolver (implicit_free_surface.jl:112-145,
+        fft_based_implicit_free_surface_solver.jl:76-115): Qu = Σₖ Ax u★ (sum!: k ascending from 0), rhs = (δx Qu + δy Qv - Az η / Δt) /
+        (g Lz Δt Az), then solve!(η, solver, rhs, m = -1 / (g Lz Δt²)): η̂ = -rhŝ / (λx + λy - m) on the horizontal (TX, TY, Flat) grid
+        (fft_based_poisson_solver.jl:95-125; no zero-mode gauge when m != 0); then pressure_correct_velocities!: u -= g Δt ∂x η
+        (barotropic_pressure_correction.jl:21-47)."""
+        g, grav, Lz = self.grid, self.gravity, self.grid.Lz
+        dz = self._dz_centres()
+        ui, vi = g.interior_N(self.u), g.interior_N(self.v)
+        Qu = np.zeros((g.Nx, g.Ny))
+        Qv = np.zeros((g.Nx, g.Ny))
+        for k in range(g.Nz):
+            Qu = Qu + (g.dy * dz[k]) * ui[:, :, k]
+            Qv = Qv + (g.dx * dz[k]) * vi[:, :, k]
+        Az = g.dx * g.dy
+        ii, jj = slice(g.Hx, g.Hx + g.Nx), slice(g.Hy, g.Hy + g.Ny)
+        eta = self.eta[ii, jj]
+        dQ = (np.roll(Qu, -1, 0) - Qu) + (np.roll(Qv, -1, 1) - Qv)
+        rhs = (dQ - Az * eta / dt) / (grav * Lz * dt * Az)
+        m = -1.0 / (grav * Lz * dt ** 2)
+        lx = (2 * np.sin(np.arange(g.Nx) * np.pi / g.Nx) / (g.Lx / g.Nx)) ** 2     # poisson_eigenvalues.jl:8-31, Periodic
+        ly = (2 * np.sin(np.arange(g.Ny) * np.pi / g.Ny) / (g.Ly / g.Ny)) ** 2
+        from scipy import fft as sfft
+        hat = sfft.fft2(rhs.astype(np.complex128))
+        hat = -hat / ((lx[:, None] + ly[None, :]) + 0.0 - m)
+        self.eta[ii, jj] = np.real(sfft.ifft2(hat))
+        self._fill_eta()
+        e = self.eta
+        ui[...] = ui - (grav * dt * ((e[ii, jj] - e[g.Hx - 1:g.Hx + g.Nx - 1, jj]) / g.dx))[:, :, None]
+        vi[...] = vi - (grav * dt * ((e[ii, jj] - e[ii, g.Hy - 1:g.Hy + g.Ny - 1]) / g.dy))[:, :, None]
+
     def time_step(self, dt, euler=False):
         g = self.grid
         if self.iteration == 0:
@@ -336,6 +369,20 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
             self.update_state(compute_tendencies=True)
         euler = euler or (dt != self.last_dt)
         chi = -0.5 if euler else self.chi
+        if getattr(self, "implicit", False):
+            for idx in (0, 1):                                 # local_ab2_step!
+                O.ab2_step(g, self.locs[idx], self.fields[idx], self.Gn[idx], self.Gm[idx], dt, chi)
+            alpha, beta = 1.5 + chi, 0.5 + chi
+            for n, c in enumerate(self.tracers):
+                ci, gn, gm = g.interior_N(c), g.interior_N(self.Gn[3 + n]), g.interior_N(self.Gm[3 + n])
+                ci[...] = 1.0 * ci + dt * (alpha * 1.0 * gn - beta * 1.0 * gm)
+            self._implicit_step(dt)                            # step_free_surface! + pressure_correct_velocities!
+            self.time += dt
+            self.iteration += 1
+            self.last_dt = dt
+            self.cache_previous_tendencies()
+            self.update_state(compute_tendencies=True)
+            return
         if self.split is not None:
             self._split_explicit_step(dt, chi)                 # compute_free_surface_tendency!
             for idx in (0, 1):                                 # local_ab2_step!

@@ -278,3 +278,41 @@ def test_split_explicit_ab3_scheme_matches_oracle(oracle, ocn):
     ocn.sync_device()
     _compare_hydrostatic(og, om, pm, 0)
     assert np.abs(om.U).max() > 0 and np.abs(om.eta).max() < 1.0
+
+
+@pytest.mark.parametrize("advection", ["VectorInvariant", "WENO5"])
+def test_implicit_free_surface_model_matches_oracle(oracle, ocn, advection):
+    """ImplicitFreeSurface() with the FFT solver -- the reference's DEFAULT free surface on this grid (hydrostatic_free_surface_model.jl:
+    51-52; HydrostaticFreeSurfaceModel(grid) with no free_surface argument selects it here too): 3 QAB2 steps at a gravity-wave CFL of 5
+    with all physics against the oracle.  Everything but η's FFT solve is the same arithmetic (strict math): η to 1e-12 of its
+    maximum (rocFFT vs pocketfft round-off), the fields it feeds back into to 1e-11."""
+    from oracle import hydrostatic as Hy
+    O = oracle
+    size = (32, 16, 7)
+    og, pg = _pair(O, ocn, size, stretched=True)
+    rng = np.random.default_rng(51)
+    init = dict(u=1e-2 * rng.uniform(-1, 1, size), v=1e-2 * rng.uniform(-1, 1, size), eta=1e-2 * rng.uniform(-1, 1, size[:2]),
+                T=20 + 1e-2 * rng.uniform(-1, 1, size), S=35 + 1e-2 * rng.uniform(-1, 1, size))
+    om = Hy.HydrostaticFreeSurfaceModel(og, tracers=("T", "S"), momentum_advection=advection, coriolis_f=1e-4, closure=(1e-2, 2e-3),
+                                        buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4), implicit_free_surface=True)
+    om.set(**init)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    scheme = ocn.VectorInvariant() if advection == "VectorInvariant" else ocn.WENO()
+    pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=scheme, tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
+                                         closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
+                                         buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)))
+    assert isinstance(pm.free_surface, ocn.ImplicitFreeSurface) and not pm.fused
+    pm.set(**init)
+    dt = 5 * og.dx / np.sqrt(9.80665 * 40.0)
+    for _ in range(3):
+        om.time_step(dt)
+        pm.time_step(dt)
+    ocn.sync_device()
+    ii, jj = slice(og.Hy, og.Hy + og.Ny), slice(og.Hx, og.Hx + og.Nx)
+    eo = om.eta[og.Hx:og.Hx + og.Nx, og.Hy:og.Hy + og.Ny]
+    assert np.abs(pm.eta[ii, jj].cpu().numpy().T - eo).max() <= 1e-12 * np.abs(eo).max() and np.abs(eo).max() > 1e-4
+    for name, a, d in zip(("u", "v", "w"), (om.u, om.v, om.w), pm.velocities):
+        ref = og.interior(a)
+        assert np.abs(og.interior(from_dev(d)) - ref).max() <= 1e-11 * np.abs(ref).max(), name
+    for a, d in zip(om.tracers, pm.tracers):
+        assert np.abs(og.interior(from_dev(d)) - og.interior(a)).max() <= 1e-13 * np.abs(og.interior(a)).max()

@@ -105,9 +105,10 @@ def test_split_explicit_free_surface_settings(pkg):
     assert fs.settings(123.0)[0] == 2.0 / int(np.ceil(2 * 10 * dtb / dtb))
 
 
-def test_hydrostatic_model_refuses_the_implicit_default(pkg):
-    """default_free_surface on an xy-regular RectilinearGrid is ImplicitFreeSurface (hydrostatic_free_surface_model.jl:51-52), which this
-    backend does not have: free_surface = None must raise instead of silently choosing another free surface."""
-    g = pkg.RectilinearGrid(None, size=(8, 8, 4), x=(0, 8e3), y=(0, 4e3), z=(-100.0, 0.0), topology=("Periodic", "Periodic", "Bounded"))
+def test_implicit_free_surface_arguments(pkg):
+    """ImplicitFreeSurface(; solver_method, gravitational_acceleration) (implicit_free_surface.jl:79-80): only the FFT solver exists here"""
+    fs = pkg.ImplicitFreeSurface(gravitational_acceleration=3.0)
+    assert fs.gravitational_acceleration == 3.0
+    pkg.ImplicitFreeSurface(solver_method=":FastFourierTransform")
     with pytest.raises(NotImplementedError):
-        pkg.HydrostaticFreeSurfaceModel(g)
+        pkg.ImplicitFreeSurface(solver_method=":PreconditionedConjugateGradient")

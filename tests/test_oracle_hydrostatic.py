@@ -370,3 +370,52 @@ def test_split_explicit_ab3_scheme_wave():
     deg, amp_deg, _ = run("AdamsBashforth3", coeffs=dict(alpha=1.0, theta=0.0, beta=0.0, delta=1.0, mu=0.0, gamma=0.0, epsilon=0.0), nsteps=10)
     np.testing.assert_array_equal(deg.eta, fb.eta)
     np.testing.assert_array_equal(deg.U, fb.U)
+
+
+# ---- ImplicitFreeSurface, FFT solver (test_implicit_free_surface_solver.jl:20-97 re-expressed) ---------------------------------------------
+def test_implicit_free_surface_solver_satisfies_its_equation():
+    """run_implicit_free_surface_solver_tests: u = v = η = 0 except one surface cell carrying a transport of 1e5 m³/s; after
+    step_free_surface!(Δt = 900) the linear operator of the implicit η equation applied to the solution equals the right-hand side
+    (the reference: max |L η - rhs| < 1e-9 and std < 1e-9 in its own scaling); here in the FFT solver's scaled form
+    (∇² - 1 / (g Lz Δt²)) η = (∇ʰ·Q★ - ηⁿ / Δt) / (g Lz Δt)."""
+    Nx, Ny, Nz, H = 16, 12, 5, 50.0
+    g = O.Grid((Nx, Ny, Nz), x=(0, 2e3), y=(0, 1.5e3), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2", implicit_free_surface=True)
+    u = np.zeros((Nx, Ny, Nz))
+    u[Nx // 2, Ny // 2, Nz - 1] = 1e5 / (g.dy * g.dz)
+    m.set(u=u)
+    ustar = g.interior_N(m.u).copy()
+    dt = 900.0
+    m._implicit_step(dt)
+    e = m.eta
+    ii, jj = slice(3, 3 + Nx), slice(3, 3 + Ny)
+    lap = (e[4:4 + Nx, jj] - 2 * e[ii, jj] + e[2:2 + Nx, jj]) / g.dx ** 2 + (e[ii, 4:4 + Ny] - 2 * e[ii, jj] + e[ii, 2:2 + Ny]) / g.dy ** 2
+    lhs = lap - e[ii, jj] / (Hy.g_Earth * H * dt ** 2)
+    Qu = (g.dy * g.dz) * ustar.sum(2)
+    rhs = (np.roll(Qu, -1, 0) - Qu) / (Hy.g_Earth * H * dt * g.dx * g.dy)
+    assert np.abs(rhs).max() > 1e-6
+    assert np.abs(lhs - rhs).max() < 1e-9 * np.abs(rhs).max() and (lhs - rhs).std() < 1e-9 * np.abs(rhs).max()
+    # the pressure correction made the barotropic flow consistent with the new surface: Δη / Δt = -∇ʰ·Q / Az
+    Qn = (g.dy * g.dz) * g.interior_N(m.u).sum(2)
+    Vn = (g.dx * g.dz) * g.interior_N(m.v).sum(2)
+    div = ((np.roll(Qn, -1, 0) - Qn) + (np.roll(Vn, -1, 1) - Vn)) / (g.dx * g.dy)
+    assert np.abs(e[ii, jj] / dt + div).max() < 1e-9 * np.abs(div).max()   # (a small difference of the much larger predictor divergence)
+
+
+def test_implicit_free_surface_model_is_stable_at_large_gravity_wave_cfl():
+    """The point of the implicit free surface: the whole model steps stably at a gravity-wave CFL of 20, conserves mean(η), and damps
+    rather than amplifies the surface wave (backward Euler in η)."""
+    Nx, H, L = 32, 20.0, 4.0e3
+    g = O.Grid((Nx, 4, 4), x=(0, L), y=(0, 500.0), z=(-H, 0.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, momentum_advection="Centered2", implicit_free_surface=True)
+    a, k = 1e-3, 2 * np.pi / L
+    x = (np.arange(Nx) + 0.5) * g.dx
+    m.set(eta=a * np.cos(k * x)[:, None] * np.ones((1, 4)))
+    dt = 20 * g.dx / np.sqrt(Hy.g_Earth * H)
+    amp = []
+    for _ in range(20):
+        m.time_step(dt)
+        e = m.eta[g.Hx:g.Hx + Nx, g.Hy:g.Hy + 4]
+        amp.append(np.abs(e).max() / a)
+        assert abs(e.sum()) < 1e-14 * Nx * 4 * a
+    assert max(amp) <= 1.0 + 1e-12 and np.isfinite(m.u).all()
