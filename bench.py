@@ -403,6 +403,12 @@ def main():
             "note": "the kernel is bound by fp64 VALU issue, not HBM: `achieved` = VALU wave-instructions per launch (SQ_INSTS_VALU of the "
                     "committed rocprofv3 --pmc pass named in pmc_source) / the launch time measured live here; peak = 1024 SIMDs x 2.4 GHz "
                     "/ 4 cycles per wave64 instruction.  `hbm` gives the same launches against the 8 TB/s HBM roofline."}
+        if a.workload == "config4":
+            measured = None if prof is None else prof.get("step_bytes_per_cell")
+            step_roofline = {"measured_bytes_per_cell_step": measured,  # committed PMC passes of this workload (set! and warm-up launches included)
+                             "measured_GBps": None if measured is None else measured * value / 1e9,
+                             "frac_of_8TBps": None if measured is None else measured * value / 1e9 / (HBM_PEAK_GBPS * world),
+                             "pmc_source": prof_path}
         if a.workload == "box":
             measured = None if prof is None else prof.get("step_bytes_per_cell")
             step_roofline = {
