@@ -146,6 +146,7 @@ struct MomentumFinal {
     ZBc bottom[2], top[2];
     SubstepDev sub[3];
     SubstepCoef sc;
+    int xcd;  // XCD-aware workgroup -> tile mapping (set by the launchers)
 };
 
 // what hydrostatic_momentum_tiled (physics.hip) folds in besides the tendency and the AB2 step of u, v

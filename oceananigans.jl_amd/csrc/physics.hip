@@ -31,6 +31,25 @@ struct PRange {
     int ow;  // first k written for Gw (periphery exclusion of Face-in-Bounded)
 };
 
+// XCD-aware workgroup -> tile mapping (see block_coords in tendencies.hip): each of the 8 XCDs walks a contiguous range of tiles
+__device__ __forceinline__ void xcd_block_coords(int on, int &bx, int &by, int &bz)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!on) return;
+    const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+    const unsigned b = bx + nx * (by + ny * bz);
+    const unsigned q = b & 7u, chunk = n >> 3, rem = n & 7u;
+    const unsigned logical = q * chunk + (q < rem ? q : rem) + (b >> 3);
+    bx = logical % nx;
+    by = (logical / nx) % ny;
+    bz = logical / (nx * ny);
+}
+static int xcd_remap_on()
+{
+    static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;
+    return v;
+}
+
 static int make_prange(const ocn_grid *grid, const int32_t *range, PRange &r)
 {
     if (range) {
@@ -339,8 +358,10 @@ __global__ __launch_bounds__(256) void momentum_extra_tiled(GridDev g, TermsDev 
     constexpr int TX = 32, TY = 8, SX = TX + 2, SY = TY + 2, PL = SX * SY;
     __shared__ double Lu[3][PL], Lv[3][PL], Lw[3][PL], Ln[3][PL];
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    const int i0 = r.i0 + blockIdx.x * TX, j0 = r.j0 + blockIdx.y * TY;
-    const int kb = r.k0 + blockIdx.z * KZ, ke = min(kb + KZ - 1, r.k1);
+    int bx, by, bz;
+    xcd_block_coords(mf.xcd, bx, by, bz);
+    const int i0 = r.i0 + bx * TX, j0 = r.j0 + by * TY;
+    const int kb = r.k0 + bz * KZ, ke = min(kb + KZ - 1, r.k1);
     const int i = i0 + tx, j = j0 + ty;
     const bool active = (i <= r.i1) && (j <= r.j1);
     const Metrics M = make_metrics(g);
@@ -465,7 +486,9 @@ __global__ __launch_bounds__(256, W) void hydrostatic_momentum_tiled(GridDev g, 
     constexpr int TX = 32, TY = 8, SX = TX + 2, SY = TY + 2, PL = SX * SY;
     __shared__ double Lu[3][PL], Lv[3][PL], Lw[3][PL];
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    const int i0 = 1 + blockIdx.x * TX, j0 = 1 + blockIdx.y * TY;
+    int bx, by, bz;
+    xcd_block_coords(mf.xcd, bx, by, bz);
+    const int i0 = 1 + bx * TX, j0 = 1 + by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool active = (i <= g.Nx) && (j <= g.Ny);
     const Metrics M = make_metrics(g);
@@ -651,6 +674,7 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
 {
     ocn::MomentumFinal mf{};
     if (fin) mf = *fin;
+    mf.xcd = xcd_remap_on();
     PRange r;
     int st = make_prange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
@@ -680,11 +704,13 @@ int launch_hydrostatic_momentum(const ocn_grid *grid, const TermsDev &t, const d
 {
     GridDev g = ocn::to_dev(*grid);
     dim3 nbt((g.Nx + 31) / 32, (g.Ny + 7) / 8, 1);
+    ocn::MomentumFinal mfx = mf;
+    mfx.xcd = xcd_remap_on();
     static const int waves = getenv("OCN_HYDRO_WAVES") ? atoi(getenv("OCN_HYDRO_WAVES")) : 3;  // min waves / SIMD the build targets
     if (waves >= 4)
-        hipLaunchKernelGGL(hydrostatic_momentum_tiled<4>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
+        hipLaunchKernelGGL(hydrostatic_momentum_tiled<4>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mfx, hf);
     else
-        hipLaunchKernelGGL(hydrostatic_momentum_tiled<1>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mf, hf);
+        hipLaunchKernelGGL(hydrostatic_momentum_tiled<1>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, mfx, hf);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -22,7 +22,25 @@ using ocn::Lay;
 struct Range {
     int i0, i1, j0, j1, k0, k1;  // 1-based inclusive
     int ou, ov, ow;              // first index written for Gu (in i), Gv (in j), Gw (in k): periphery exclusion
+    int xcd;                     // remap workgroups so that each XCD owns a contiguous band of tiles (block_coords)
 };
+
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with its own L2.  Neighbouring tiles share their
+// stencil rings (a 32 x 8 patch reads 37 x 13 cells), so with the plain mapping every ring is fetched by up to 8 different L2s.
+// With r.xcd set, hardware workgroup b (XCD b % 8) takes the logical tile start_{b % 8} + b / 8: every XCD walks its own contiguous
+// range of tiles in x-fastest order and finds its neighbours' rings in its own L2.  A bijection for any grid size.
+__device__ __forceinline__ void block_coords(const Range &r, int &bx, int &by, int &bz)
+{
+    bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    if (!r.xcd) return;
+    const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+    const unsigned b = bx + nx * (by + ny * bz);
+    const unsigned q = b & 7u, chunk = n >> 3, rem = n & 7u;
+    const unsigned logical = q * chunk + (q < rem ? q : rem) + (b >> 3);
+    bx = logical % nx;
+    by = (logical / nx) % ny;
+    bz = logical / (nx * ny);
+}
 
 // One momentum flux  U~ * psi^R.
 //   advecting line: pointer pa at the face element, stride sa, metric MET (1 Ax, 2 Ay, 3 Az), AZ: line runs along z
@@ -178,8 +196,10 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #define Lw L0
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
-    const int k_start = r.k0 + blockIdx.z * KZ;
+    int bx, by, bz;
+    block_coords(r, bx, by, bz);
+    const int ti0 = r.i0 + bx * (TX - 1), tj0 = r.j0 + by * (TY - 1);
+    const int k_start = r.k0 + bz * KZ;
     const int k_end = min(k_start + KZ - 1, r.k1);
     // own column (clamped into the parent array; clamped duplicates are never written)
     const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
@@ -591,8 +611,10 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
     const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);  // x, y Periodic: one layout for u, v, w, c, G
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
-    const int k_start = r.k0 + blockIdx.z * KZ, k_end = min(k_start + KZ - 1, r.k1);
+    int bx, by, bz;
+    block_coords(r, bx, by, bz);
+    const int ti0 = r.i0 + bx * (TX - 1), tj0 = r.j0 + by * (TY - 1);
+    const int k_start = r.k0 + bz * KZ, k_end = min(k_start + KZ - 1, r.k1);
     const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
     const int i = min(ti0 + tx, imax), j = min(tj0 + ty, jmax);
     const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
@@ -748,8 +770,10 @@ __global__ __launch_bounds__(TX *TY) void tracer_pair_tendency_tiled(GridDev g, 
     const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-    const int ti0 = r.i0 + blockIdx.x * (TX - 1), tj0 = r.j0 + blockIdx.y * (TY - 1);
-    const int k_start = r.k0 + blockIdx.z * KZ, k_end = min(k_start + KZ - 1, r.k1);
+    int bx, by, bz;
+    block_coords(r, bx, by, bz);
+    const int ti0 = r.i0 + bx * (TX - 1), tj0 = r.j0 + by * (TY - 1);
+    const int k_start = r.k0 + bz * KZ, k_end = min(k_start + KZ - 1, r.k1);
     const int imax = Nx + g.Hx, jmax = Ny + g.Hy;
     const int i = min(ti0 + tx, imax), j = min(tj0 + ty, jmax);
     const bool writes = (tx < TX - 1) && (ty < TY - 1) && (ti0 + tx <= r.i1) && (tj0 + ty <= r.j1);
@@ -919,8 +943,15 @@ static int strip_min_kz()
     return v;
 }
 
+static int xcd_remap()
+{
+    static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;  // measured: 4.72 -> 4.60 ms per 512^3 launch
+    return v;
+}
+
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 {
+    r.xcd = xcd_remap();
     if (range) {
         r.i0 = range[0]; r.i1 = range[1]; r.j0 = range[2]; r.j1 = range[3]; r.k0 = range[4]; r.k1 = range[5];
         if (r.i0 < 1 || r.i1 > grid->Nx || r.j0 < 1 || r.j1 > grid->Ny || r.k0 < 1 || r.k1 > grid->Nz) {
