@@ -222,14 +222,25 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         return has_nu ? 0.5 * (0.5 * (NEf(a, b - 1, c - 1) + NEf(a, b, c - 1)) + 0.5 * (NEf(a, b - 1, c) + NEf(a, b, c))) : nu;
     };
 
+    // every global value this cell reads is requested up front: the pointers inside `t` and `mf` may alias the stores below
+    // as far as the compiler knows, so loads left in place would wait for each store in turn (three dependent round trips)
+    const bool use_gm = mf.sc.has_zeta && (HYD || mf.sc.on);
+    const double gm_u = use_gm ? mf.sub[0].Gm[o] : 0.0, gm_v = use_gm ? mf.sub[1].Gm[o] : 0.0;
+    const bool w_cell = !HYD && k >= r.ow;
+    const double gm_w = (use_gm && w_cell) ? mf.sub[2].Gm[o] : 0.0;
+    const double ph_c = t.pHY ? t.pHY[o] : 0.0, ph_w = t.pHY ? t.pHY[o - 1] : 0.0, ph_s = t.pHY ? t.pHY[o - s2] : 0.0;
+    const double Gu_in = HYD ? G0u : Gu[o], Gv_in = HYD ? G0v : Gv[o], Gw_in = w_cell ? Gw[o] : 0.0;
+    double zb_w = 0.0;  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
+    if (w_cell && t.buoyancy && !t.pHY) zb_w = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
+
     {   // ---------------- Gu at (f,c,c)
-        double G = HYD ? G0u : Gu[o];
+        double G = Gu_in;
         if (t.buoyancy) G = G + 0.0;  // x_dot_g_b = 0 (NegativeZDirection)
         if (t.coriolis) {             // - x_f_cross_U,  x_f_cross_U = -f * ℑxyᶠᶜᵃ(v) / 1
             const double vi = 0.5 * (0.5 * (Vf(-1, 0, 0) + Vf(0, 0, 0)) + 0.5 * (Vf(-1, 1, 0) + Vf(0, 1, 0)));
             G = G - (-t.f * vi);
         }
-        if (t.pHY) G = G - DX(t.pHY[o], t.pHY[o - 1]);  // ∂xᶠᶜᶜ pHY′
+        if (t.pHY) G = G - DX(ph_c, ph_w);  // ∂xᶠᶜᶜ pHY′
         if (t.closure) {
             const double t11e = TAU(nuC(0, 0, 0), DX(Uf(1, 0, 0), Uf(0, 0, 0))), t11w = TAU(nuC(-1, 0, 0), DX(Uf(0, 0, 0), Uf(-1, 0, 0)));
             const double t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(Uf(0, 1, 0), Uf(0, 0, 0)) + DX(Vf(0, 1, 0), Vf(-1, 1, 0))));
@@ -248,22 +259,22 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         }
         Gu[o] = G;
         if (HYD) {
-            const double gm = mf.sc.has_zeta ? mf.sub[0].Gm[o] : 0.0;
+            const double gm = gm_u;
             const double un = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
             mf.sub[0].out[o] = un;
             res[0] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;  // ab2_step_G (compute_slow_tendencies.jl:34-46)
             res[1] = un;
         } else if (mf.sc.on)
-            mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[0].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_u) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     {   // ---------------- Gv at (c,f,c)
-        double G = HYD ? G0v : Gv[o];
+        double G = Gv_in;
         if (t.buoyancy) G = G + 0.0;
         if (t.coriolis) {  // - y_f_cross_U,  y_f_cross_U = f * ℑxyᶜᶠᵃ(u) / 1
             const double ui = 0.5 * (0.5 * (Uf(0, -1, 0) + Uf(1, -1, 0)) + 0.5 * (Uf(0, 0, 0) + Uf(1, 0, 0)));
             G = G - t.f * ui;
         }
-        if (t.pHY) G = G - DY(t.pHY[o], t.pHY[o - s2]);
+        if (t.pHY) G = G - DY(ph_c, ph_s);
         if (t.closure) {
             const double t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(Uf(1, 0, 0), Uf(1, -1, 0)) + DX(Vf(1, 0, 0), Vf(0, 0, 0))));
             const double t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
@@ -282,22 +293,18 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         }
         Gv[o] = G;
         if (HYD) {
-            const double gm = mf.sc.has_zeta ? mf.sub[1].Gm[o] : 0.0;
+            const double gm = gm_v;
             const double vn = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
             mf.sub[1].out[o] = vn;
             res[2] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;
             res[3] = vn;
         } else if (mf.sc.on)
-            mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[1].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_v) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     if (HYD) return;  // w is diagnostic in the hydrostatic model
     if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
-        double G = Gw[o];
-        if (t.buoyancy) {  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
-            double zb = 0.0;
-            if (!t.pHY) zb = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
-            G = G + zb;
-        }
+        double G = Gw_in;
+        if (t.buoyancy) G = G + zb_w;
         if (t.coriolis) G = G - 0.0;  // z_f_cross_U = 0
         if (t.closure) {
             const double Axf = dy * dzf, Ayf = dx * dzf;
@@ -315,7 +322,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         }
         Gw[o] = G;
         const bool wall = (TZ == OCN_BOUNDED) && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face
-        if (mf.sc.on) mf.sub[2].out[o] = wall ? Wf(0, 0, 0) : Wf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * mf.sub[2].Gm[o]) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (mf.sc.on) mf.sub[2].out[o] = wall ? Wf(0, 0, 0) : Wf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_w) : (mf.sc.dt * mf.sc.gamma) * G);
     } else if (mf.sc.on) {
         mf.sub[2].out[o] = Wf(0, 0, 0);  // wall face (exclude_periphery): carried over unchanged
     }

@@ -395,6 +395,12 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                     }
             }
         }
+        // the previous stage's tendencies for the substep epilogue: loaded here so that they arrive under the arithmetic
+        double gmu = 0.0, gmv = 0.0, gmw = 0.0;
+        if (fz.on && fz.has_zeta && writes) {
+            const long long o = own0 + (long long)(k - 1) * su3;
+            gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o]; gmw = fz.Gm[2][o];
+        }
         const double(*swk)[LX] = sw[k & 1];
         const double(*swt)[LX] = sw[(k + 1) & 1];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
@@ -447,12 +453,12 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             if (i >= r.ou) {
                 const double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
                 Gu[ou_] = G;
-                if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][ou_]) : (fz.dt * fz.gamma) * G);
+                if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmu) : (fz.dt * fz.gamma) * G);
             }
             if (j >= r.ov) {
                 const double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
                 Gv[ov_] = G;
-                if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][ov_]) : (fz.dt * fz.gamma) * G);
+                if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmv) : (fz.dt * fz.gamma) * G);
             }
             if (k >= r.ow) {
                 const double rVf = recip_volume(M.Az * M.dzF(k));
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                 // rk3_substep! always excludes the wall face (runge_kutta_3.jl:171-174), even when a KernelParameters range
                 // made the tendency kernel write Gw there
                 const bool wall = (TZ == OCN_BOUNDED) && k == 1 && Nz > 1;
-                if (fz.on) fz.Uo[2][ow_] = wall ? zw[2] : zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][ow_]) : (fz.dt * fz.gamma) * G);
+                if (fz.on) fz.Uo[2][ow_] = wall ? zw[2] : zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmw) : (fz.dt * fz.gamma) * G);
             } else if (fz.on) {
                 fz.Uo[2][ow_] = zw[2];  // wall face: neither the tendency nor the substep touch it (exclude_periphery)
             }
