@@ -489,8 +489,17 @@ int ocn_dist_poisson_layout(ocn_dist_poisson_t solver, int32_t *ny_transposed, i
  *   fast == 1 (periodic z): solve_x works in place on `recv`; exchange recv -> send; backward_yz reads `send`
  *             (payload partitioned by stored kz position, Nz / nranks per rank);
  *   fast == 2 (Bounded z, Fourier-tridiagonal): solve_x reads `recv` and leaves the solution in `send`; exchange send -> recv
- *             again; backward_yz reads `recv` (payload partitioned by ky, ceil((Ny/2+1) / nranks) per rank, zero padded). */
+ *             again; backward_yz reads `recv` (payload partitioned by ky, ceil((Ny/2+1) / nranks) per rank, zero padded);
+ *   fast == 3 (periodic z, nranks > 1 by default; OCN_DIST_POISSON_XTRI=0/1): NO transposes.  forward_yz transforms y and z in
+ *             place and solves the local x blocks of the cyclic tridiagonal systems p[i-1] - (2 + dx^2 (ly + lz)) p[i] + p[i+1] =
+ *             dx^2 F[i] (the same operator the reference inverts with FFT_x and the division by lx + ly + lz,
+ *             distributed_fft_based_poisson_solver.jl:141-178, poisson_eigenvalues.jl:8-31); ONE all-gather of the gather `send`
+ *             buffer (2 complex numbers per (ky, kz) mode + the mean mode's line) into the gather `recv` buffer
+ *             (ocn_dist_poisson_gather_buffers; ocn_dist_poisson_exchange direction 0, direction 1 is a no-op); solve_x solves the
+ *             interface systems and corrects the local blocks; backward_yz inverts z and y in place.  csrc/xtri.hip. */
 int ocn_dist_poisson_pipeline(ocn_dist_poisson_t solver, int32_t *fast);
+/* fast == 3: the all-gather buffers (send: doubles_per_rank doubles; recv: nranks x doubles_per_rank, chunk s from rank s) */
+int ocn_dist_poisson_gather_buffers(ocn_dist_poisson_t solver, double **send, double **recv, int64_t *doubles_per_rank);
 int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w, double dt,
                                  void *stream);
 int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver, void *stream);
@@ -526,6 +535,8 @@ int ocn_comm_exchange_strips(ocn_comm_t comm, const double *send_west, const dou
                              size_t count, void *stream);
 /* Alltoallv! with equal counts: chunk d of `send` (count doubles) goes to rank d, chunk s of `recv` comes from rank s; stream order */
 int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream);
+/* MPI.Allgather with equal counts: chunk s of `recv` is rank s's `send` (count doubles each); in stream order on `stream` */
+int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream);
 /* transpose_y_to_x! (direction 0) / transpose_x_to_y! (direction 1) of a distributed Poisson handle's exchange buffers */
 int ocn_dist_poisson_exchange(ocn_dist_poisson_t solver, ocn_comm_t comm, int32_t direction, void *stream);
 int ocn_comm_allreduce(ocn_comm_t comm, double *buffer, size_t count, int32_t op /* 0 sum, 1 max, 2 min */, void *stream);

@@ -137,6 +137,7 @@ _SIGS = {
     "ocn_dist_poisson_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ocn_dist_poisson_layout": [_vp, C.POINTER(_i32), C.POINTER(C.c_int64), C.POINTER(_i32)],
     "ocn_dist_poisson_pipeline": [_vp, C.POINTER(_i32)],
+    "ocn_dist_poisson_gather_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64)],
     "ocn_dist_poisson_source_term": [_vp, _vp, _vp, _vp, _dbl, _vp],
     "ocn_dist_poisson_forward_yz": [_vp, _vp],
     "ocn_dist_poisson_solve_x": [_vp, _vp],
@@ -149,6 +150,7 @@ _SIGS = {
     "ocn_halo_exchange_end": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],
     "ocn_halo_exchange_plane": [_vp, C.POINTER(CGrid), _vp, _i32, _i32, _vp],
     "ocn_comm_all_to_all": [_vp, _vp, _vp, C.c_size_t, _vp],
+    "ocn_comm_all_gather": [_vp, _vp, _vp, C.c_size_t, _vp],
     "ocn_comm_exchange_strips": [_vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp],
     "ocn_split_explicit_dist_begin": [C.POINTER(CGrid), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_split_explicit_dist_run": [C.POINTER(CGrid), _i32, C.POINTER(_dbl), _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

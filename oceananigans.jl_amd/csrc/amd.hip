@@ -9,6 +9,7 @@
 // One thread per cell, x fastest across the wave; each term is written exactly as the reference spells it (operand order,
 // left-associated sums) so the strict build is bit-identical to the CPU oracle.  x, y Periodic => one set of strides.
 // Every normalised gradient is evaluated once per thread into registers and reused by all terms and all tracers.
+#include <cstdlib>
 #include "ocn_weno.h"
 
 namespace OCN_NS {
@@ -67,12 +68,27 @@ struct AmdTracers {
 
 __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
                                                         const double *__restrict__ v, const double *__restrict__ w,
-                                                        double *__restrict__ nu_e, AmdTracers tr, int i0, int i1)
+                                                        double *__restrict__ nu_e, AmdTracers tr, int i0, int i1, int KZ, int xcd)
 {
     // i0..i1: 1..Nx, or a sub-range / the halo columns 0 and Nx+1 (the buffer recomputation of a distributed run,
     // compute_nonhydrostatic_buffer_tendencies.jl:55-68)
-    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    // A workgroup marches KZ planes upward: planes k and k+1 of one iteration are planes k-1 and k of the next, so they come from
+    // the L2 of the workgroup's own XCD instead of HBM (one workgroup per plane re-read every plane three times: 120 B per cell
+    // measured against 64 compulsory, profiles/r02b_config4.md).  Each XCD walks a contiguous range of tiles (xcd).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd) {
+        const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        const unsigned b = bx + nx * (by + ny * bz);
+        const unsigned q = b & 7u, chunk = n >> 3, rem = n & 7u;
+        const unsigned logical = q * chunk + (q < rem ? q : rem) + (b >> 3);
+        bx = logical % nx;
+        by = (logical / nx) % ny;
+        bz = logical / (nx * ny);
+    }
+    const int i = i0 + bx * blockDim.x + threadIdx.x, j = 1 + by * blockDim.y + threadIdx.y;
     if (i > i1 || j > g.Ny) return;
+    const int kb = 1 + bz * KZ, ke = min(kb + KZ - 1, g.Nz);
+    for (int k = kb; k <= ke; ++k) {
     const Amd A = make_amd(g, u, v, w, nullptr, i, j, k);
     const long long o = A.u - u;
     // filter-width ratios and spacings of the two z levels this cell touches (k is uniform across the workgroup)
@@ -175,6 +191,7 @@ __global__ __launch_bounds__(256) void amd_fused_kernel(GridDev g, double Cnu, c
             tr.kappa_e[n][o] = julia_max0(kap);
         }
     }
+    }  // k
 #undef AMD_D
 #undef AMD_Q
 }
@@ -199,8 +216,16 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
     GridDev g = ocn::to_dev(*grid);
     const int i0 = irange ? irange[0] : 1, i1 = irange ? irange[1] : g.Nx;
     if (i1 < i0) return OCN_SUCCESS;
-    const dim3 block = ocn::range_block(i1 - i0 + 1), nb = ocn::range_grid(block, i1 - i0 + 1, g.Ny, g.Nz);
-    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1);
+    static const int kz_env = getenv("OCN_AMD_KZ") ? atoi(getenv("OCN_AMD_KZ")) : 16;
+    static const int xcd = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;
+    const int wx = i1 - i0 + 1;
+    dim3 block = ocn::range_block(wx);
+    if (block.x == 64) block = dim3(32, 8, 1);  // squarer tiles: fewer rim rows re-read per plane
+    int KZ = kz_env < 1 ? 1 : kz_env;
+    const long long tiles = (long long)((wx + block.x - 1) / block.x) * ((g.Ny + block.y - 1) / block.y);
+    while (KZ > 1 && tiles * ((g.Nz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;  // narrow ranges: keep the chip full
+    const dim3 nb = ocn::range_grid(block, wx, g.Ny, (g.Nz + KZ - 1) / KZ);
+    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -302,7 +302,22 @@ int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_
     return OCN_SUCCESS;
 }
 
-// the transposes of a distributed Poisson handle: direction 0 = y-local -> x-local (send -> recv), 1 = back
+// MPI.Allgather with equal counts: chunk s of `recv` is rank s's `send` (count doubles each).  In stream order on `stream`.
+int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_t count, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && send && recv, "ocn_comm_all_gather: null pointer");
+    hipStream_t s = as_stream(stream);
+    if (c->nranks == 1 && !c->self_via_rccl) {
+        OCN_CHECK_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return OCN_SUCCESS;
+    }
+    OCN_CHECK_NCCL(ncclAllGather(send, recv, count, ncclDouble, c->comm, s));
+    return OCN_SUCCESS;
+}
+
+// the exchanges of a distributed Poisson handle: direction 0 = y-local -> x-local (send -> recv), 1 = back.  The transpose-free
+// pipeline (ocn_dist_poisson_pipeline = 3) has ONE exchange: direction 0 all-gathers the interface values, direction 1 does nothing.
 int ocn_dist_poisson_exchange(ocn_dist_poisson_t handle, ocn_comm_t comm, int32_t direction, void *stream)
 {
     double *yf, *xf, *snd, *rcv;
@@ -314,6 +329,14 @@ int ocn_dist_poisson_exchange(ocn_dist_poisson_t handle, ocn_comm_t comm, int32_
     if (st != OCN_SUCCESS) return st;
     st = ocn_dist_poisson_pipeline(handle, &fast);
     if (st != OCN_SUCCESS) return st;
+    if (fast == 3) {
+        if (direction != 0) return OCN_SUCCESS;
+        double *gs, *gr;
+        int64_t per_rank;
+        st = ocn_dist_poisson_gather_buffers(handle, &gs, &gr, &per_rank);
+        if (st != OCN_SUCCESS) return st;
+        return ocn_comm_all_gather(comm, gs, gr, (size_t)per_rank, stream);
+    }
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c, "ocn_dist_poisson_exchange: null communicator");
     const size_t per_peer = (size_t)nel * 2 / c->nranks;  // complex elements -> doubles, equal chunks

@@ -66,6 +66,12 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
                      const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid = nullptr,
                      const double *u = nullptr, const double *v = nullptr, const double *w = nullptr, double dt = 1.0, int kc = 0,
                      long long chunk = 0, int scale_dz = 0, double scale = 1.0);
+// transpose-free x direction of the distributed pressure solve (xtri.hip)
+bool xtri_supported(int R, int Nxg);
+int launch_xtri_sweep(double *a1, const double *ly, const double *lz, int NyH, int nx, int Nz, double dx, double scale, double *gsend,
+                      hipStream_t stream);
+int launch_xtri_finish(double *a1, const double *ly, const double *lz, int NyH, int nx, int Nz, double dx, const double *grecv, int rank,
+                       int R, hipStream_t stream);
 int launch_vector_invariant(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv,
                             hipStream_t stream, const double *eta = nullptr, double grav = 0.0);
 int launch_split_explicit_forcing(const ocn_grid *grid, const double *Gun, const double *Gum, const double *Gvn, const double *Gvm, double chi,

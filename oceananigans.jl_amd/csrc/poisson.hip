@@ -901,6 +901,11 @@ struct ocn_dist_poisson {
     // the source term is evaluated inside the real y transform: ocn_dist_poisson_source_term only records its arguments
     const double *src_u = nullptr, *src_v = nullptr, *src_w = nullptr;
     double src_dt = 1.0;
+    // transpose-free flavour of the fast pipeline (xtri.hip): y and z transforms in place in `recv`, the x direction as a cyclic
+    // tridiagonal solve whose ranks exchange two numbers per mode (one all-gather of gsend into grecv) instead of the spectrum
+    bool xtri = false;
+    double *gsend = nullptr, *grecv = nullptr;
+    size_t gchunk = 0;  // doubles per rank in grecv
 };
 
 static void free_all(ocn_dist_poisson *s)
@@ -908,7 +913,7 @@ static void free_all(ocn_dist_poisson *s)
     s->fyz.destroy(); s->byz.destroy(); s->fx.destroy(); s->bx.destroy();
     if (s->fast) s->yfield = nullptr;  // alias of recv
     double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv,
-                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x};
+                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x, &s->gsend, &s->grecv};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -1124,8 +1129,13 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
     }
     {
         const char *ef = std::getenv("OCN_DIST_POISSON_FAST");
-        s->fast = !force_c2c && s->r2c && !(ef && ef[0] == '0') && R >= 1 && ocn::realfft_y_supported(Ny) && ocn::colfft_supported(Nz) &&
-                  ocn::colfft_supported(Nxg) && Nz % R == 0;
+        const bool local_ok = !force_c2c && s->r2c && !(ef && ef[0] == '0') && R >= 1 && ocn::realfft_y_supported(Ny) && ocn::colfft_supported(Nz);
+        // the transpose-free x solve: default for R > 1 (one rank has nothing to exchange and the fused FFT_x kernel moves fewer
+        // bytes); OCN_DIST_POISSON_XTRI=1 forces it, =0 keeps the all-to-all pipeline
+        const char *ex = std::getenv("OCN_DIST_POISSON_XTRI");
+        const bool want = ex ? ex[0] == '1' : R > 1;
+        s->xtri = local_ok && want && ocn::xtri_supported(R, Nxg);
+        s->fast = s->xtri || (local_ok && ocn::colfft_supported(Nxg) && Nz % R == 0);
     }
     if (s->fast) {
         const int NyH = Ny / 2 + 1;
@@ -1135,21 +1145,29 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
         TRY_HIP(hipMalloc((void **)&s->rhs, (size_t)nx * Ny * Nz * sizeof(double)));
         TRY_HIP(hipMemset(s->rhs, 0, (size_t)nx * Ny * Nz * sizeof(double)));
         for (double **p : {&s->send, &s->recv}) {
+            if (s->xtri && p == &s->send) continue;  // no exchange layout: the spectrum stays in `recv`
             TRY_HIP(hipMalloc((void **)p, n * 2 * sizeof(double)));
             TRY_HIP(hipMemset(*p, 0, n * 2 * sizeof(double)));
+        }
+        if (s->xtri) {
+            s->gchunk = 2 * (2 * (size_t)NyH * Nz + nx);
+            TRY_HIP(hipMalloc((void **)&s->gsend, s->gchunk * sizeof(double)));
+            TRY_HIP(hipMalloc((void **)&s->grecv, s->gchunk * R * sizeof(double)));
+            TRY_HIP(hipMemset(s->gsend, 0, s->gchunk * sizeof(double)));
+            TRY_HIP(hipMemset(s->grecv, 0, s->gchunk * R * sizeof(double)));
         }
         s->yfield = s->recv;
         TRY(upload(ocn::colfft_twiddles(Ny / 2), &s->tw_h));
         TRY(upload(ocn::colfft_twiddles(Ny), &s->tw_y));
         TRY(upload(ocn::colfft_twiddles(Nz), &s->tw_z));
-        TRY(upload(ocn::colfft_twiddles(Nxg), &s->tw_x));
+        if (!s->xtri) TRY(upload(ocn::colfft_twiddles(Nxg), &s->tw_x));
         // eigenvalues: ky natural (0..Ny/2); kz and kx by STORED position of the column kernels' stage order
         std::vector<double> lyn = eigenvalues(Ny, lg->Ly, OCN_PERIODIC), lzn = eigenvalues(Nz, lg->Lz, OCN_PERIODIC),
                             lxn = eigenvalues(Nxg, global_Lx, OCN_PERIODIC);
         lyn.resize(NyH);
         std::vector<double> lzs(Nz), lxs(Nxg);
         for (int q = 0; q < Nz; ++q) lzs[q] = lzn[ocn::colfft_wavenumber(Nz, q)];
-        for (int q = 0; q < Nxg; ++q) lxs[q] = lxn[ocn::colfft_wavenumber(Nxg, q)];
+        for (int q = 0; q < Nxg && !s->xtri; ++q) lxs[q] = lxn[ocn::colfft_wavenumber(Nxg, q)];
         TRY(upload(lyn, &s->ly));
         TRY(upload(lzs, &s->lz));
         TRY(upload(lxs, &s->lx));
@@ -1254,10 +1272,19 @@ extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int32_t *ny_transpo
     return OCN_SUCCESS;
 }
 
+extern "C" int ocn_dist_poisson_gather_buffers(ocn_dist_poisson_t s, double **send, double **recv, int64_t *doubles_per_rank)
+{
+    OCN_REQUIRE(s, "ocn_dist_poisson_gather_buffers: null solver");
+    if (send) *send = s->gsend;
+    if (recv) *recv = s->grecv;
+    if (doubles_per_rank) *doubles_per_rank = (int64_t)s->gchunk;
+    return OCN_SUCCESS;
+}
+
 extern "C" int ocn_dist_poisson_pipeline(ocn_dist_poisson_t s, int32_t *fast)
 {
     OCN_REQUIRE(s && fast, "ocn_dist_poisson_pipeline: null argument");
-    *fast = s->fast ? (s->tri ? 2 : 1) : 0;
+    *fast = s->fast ? (s->tri ? 2 : (s->xtri ? 3 : 1)) : 0;
     return OCN_SUCCESS;
 }
 
@@ -1309,6 +1336,13 @@ extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s, void *stream)
                                                    ocn::as_stream(stream), g, s->src_u, s->src_v, s->src_w, s->src_dt)
                           : ocn::launch_realfft_y(g->Ny, 0, s->rhs, s->recv, nullptr, 0, 0, s->nx, g->Nz, s->tw_h, s->tw_y, ocn::as_stream(stream));
         if (st != OCN_SUCCESS) return st;
+        if (s->xtri) {  // z in place (stage order), then the local x solves; gsend is ready for the all-gather
+            const long long cols = (long long)s->nyt * s->nx;
+            st = ocn::launch_colfft(g->Nz, 0, s->recv, cols, 0, (int)cols, 1, s->tw_z, nullptr, nullptr, nullptr, 1.0, 1, ocn::as_stream(stream));
+            if (st != OCN_SUCCESS) return st;
+            const double scale = 1.0 / ((double)(g->Ny / 2) * g->Nz);
+            return ocn::launch_xtri_sweep(s->recv, s->ly, s->lz, s->nyt, s->nx, g->Nz, g->dx, scale, s->gsend, ocn::as_stream(stream));
+        }
         return ocn::launch_colfft_slab_z(g->Nz, 0, s->recv, s->send, s->nx, s->nyt, s->R, s->tw_z, ocn::as_stream(stream));
     }
     if (s->r2c) return s->fyz.exec(s->rhs, s->yfield, ocn::as_stream(stream));
@@ -1332,6 +1366,8 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
         }
         return ocn::launch_colfft(s->Nxg, 1, s->send, S, 0, (int)S, 1, s->tw_x, nullptr, nullptr, nullptr, 1.0, 1, stream);
     }
+    if (s->xtri)  // grecv holds every rank's interface values: interface systems, spike correction, the mean mode's line
+        return ocn::launch_xtri_finish(s->recv, s->ly, s->lz, s->nyt, s->nx, s->grid.Nz, s->grid.dx, s->grecv, s->rank, s->R, stream);
     if (s->fast) {  // recv = [xg S + (ky + NyH pz_l)]: FFT_x -> -b / ((λy + λz) + λx), rank 0 zeroes the mean mode -> IFFT_x, in place
         const int Nz = s->grid.Nz, cz = Nz / s->R, NyH = s->nyt;
         const long long S = (long long)NyH * cz;
@@ -1380,7 +1416,9 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *p, voi
         const ocn_grid *g = &s->grid;
         ocn::GridDev gd = ocn::to_dev(*g);
         ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
-        int st = ocn::launch_colfft_slab_z(g->Nz, 1, s->send, s->recv, s->nx, s->nyt, s->R, s->tw_z, stream);
+        const long long cols = (long long)s->nyt * s->nx;
+        int st = s->xtri ? ocn::launch_colfft(g->Nz, 1, s->recv, cols, 0, (int)cols, 1, s->tw_z, nullptr, nullptr, nullptr, 1.0, 1, stream)
+                         : ocn::launch_colfft_slab_z(g->Nz, 1, s->send, s->recv, s->nx, s->nyt, s->R, s->tw_z, stream);
         if (st != OCN_SUCCESS) return st;
         return ocn::launch_realfft_y(g->Ny, 1, nullptr, s->recv, p + Lp.o, Lp.s2, Lp.s3, s->nx, g->Nz, s->tw_h, s->tw_y, stream);
     }

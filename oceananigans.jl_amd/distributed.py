@@ -70,6 +70,9 @@ class TorchDistributedFabric:
     def all_to_all(self, recv, send):
         self.dist.all_to_all_single(recv, send, group=self.group)
 
+    def all_gather(self, recv, send):
+        self.dist.all_gather(list(recv.view(self.size, -1).unbind(0)), send, group=self.group)
+
     def allreduce_max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return t
@@ -117,6 +120,9 @@ class RcclFabric:
 
     def all_to_all(self, recv, send):
         _lib.call("ocn_comm_all_to_all", self._h, send.data_ptr(), recv.data_ptr(), send.numel() // self.size, stream_ptr())
+
+    def all_gather(self, recv, send):
+        _lib.call("ocn_comm_all_gather", self._h, send.data_ptr(), recv.data_ptr(), send.numel(), stream_ptr())
 
     def allreduce_max(self, t):
         _lib.call("ocn_comm_allreduce", self._h, t.data_ptr(), t.numel(), 1, stream_ptr())
@@ -530,8 +536,15 @@ class _HipDistPoisson:
         _lib.call("ocn_dist_poisson_pipeline", self._h, C.byref(fast))
         self.fast = fast.value  # slab pipeline: no pack / unpack passes (1: periodic z, 2: tridiagonal flavour; ocn_hip.h)
         n = nel.value * 2
-        # wrap the library-owned transpose buffers as tensors (no copy) so torch.distributed can move them
-        self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
+        # wrap the library-owned exchange buffers as tensors (no copy) so torch.distributed can move them
+        if self.fast == 3:  # transpose-free pipeline: the only exchange is an all-gather of the interface values
+            gp, per_rank = [C.c_void_p(), C.c_void_p()], C.c_int64()
+            _lib.call("ocn_dist_poisson_gather_buffers", self._h, C.byref(gp[0]), C.byref(gp[1]), C.byref(per_rank))
+            self.gsend = _wrap_device_buffer(gp[0].value, per_rank.value, arch.device)
+            self.grecv = _wrap_device_buffer(gp[1].value, per_rank.value * self.R, arch.device)
+            self.send = None
+        else:
+            self.send = _wrap_device_buffer(ptrs[2].value, n, arch.device)
         self.recv = _wrap_device_buffer(ptrs[3].value, n, arch.device)
         self.yfield_ptr, self.xfield_ptr = ptrs[0].value, ptrs[1].value
 
@@ -602,9 +615,29 @@ class DistributedFFTBasedPoissonSolver:
         self.arch.fabric.all_to_all(self.impl.recv, self.impl.send)
         return self.impl.recv
 
+    def _all_gather(self, recv, send):
+        ag = getattr(self.arch.fabric, "all_gather", None)
+        if ag is not None:
+            return ag(recv, send)
+        # a fabric without an all-gather: every peer's chunk of an all-to-all is my whole message
+        self.arch.fabric.all_to_all(recv, send.repeat(self.R))
+
     def solve(self, p):
         impl = self.impl
         ex = getattr(self.arch.fabric, "dist_poisson_exchange", None)
+        if getattr(impl, "fast", 0) == 3:
+            # transpose-free pipeline (csrc/xtri.hip): y, z transforms and the local x blocks of the cyclic tridiagonal systems, ONE
+            # all-gather of two numbers per mode, interface systems + correction, inverse transforms
+            impl.forward_yz()
+            if ex is not None and hasattr(impl, "_h") and self.arch.communicates:
+                ex(impl._h, 0)
+            elif self.R == 1:
+                impl.grecv.copy_(impl.gsend)
+            else:
+                self._all_gather(impl.grecv, impl.gsend)
+            impl.solve_x()
+            impl.backward_yz(p)
+            return p
         if ex is not None and hasattr(impl, "_h") and self.arch.communicates:
             # the product path: both transposes are ocn_dist_poisson_exchange (grouped ncclSend / ncclRecv in the library)
             impl.forward_yz()

@@ -138,12 +138,13 @@ def test_distributed_steps_match_single_rank(ocn, R, topo):
 
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("topo", ["PPP", "PPB"])
-def test_distributed_slab_pipeline_matches_single_rank(ocn, R, topo):
+def test_distributed_slab_pipeline_matches_single_rank(ocn, R, topo, monkeypatch):
     """Sizes the library's slab pipeline covers (real y transform, z column FFT into the exchange layout, fused x column
     kernel -- or, for a Bounded stretched z, the ky-partitioned layout with FFT_x and the Thomas sweep; csrc/colfft.hip): the
     handle must select it, and two RK3 steps must match the single-rank model, whose solver is a different code path (rocFFT
     or the row / column pipeline).  "PPB": Ny/2 + 1 = 65 is not a multiple of R, so the zero padding of the exchange is covered."""
     from helpers import stretched_faces
+    monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "0")  # the all-to-all pipeline (the transpose-free one has its own test below)
     P = "Periodic"
     if topo == "PPP":
         N = (64, 128, 64)
@@ -170,6 +171,51 @@ def test_distributed_slab_pipeline_matches_single_rank(ocn, R, topo):
         g = ocn.RectilinearGrid(arch, size=N, **ext)
         m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
         assert m.pressure_solver.impl.fast == (1 if topo == "PPP" else 2)
+        sl = slice(r * g.Nx, (r + 1) * g.Nx)
+        ocn.set(m, **{k: v[sl] for k, v in init.items()})
+        for _ in range(2):
+            ocn.time_step(m, dt)
+        ocn.sync_device()
+        return [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+
+    outs = _run_ranks(R, rank_main)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    for r, fields in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "p")):
+            tol = 1e-11 * scale if name != "p" else 1e-10 * max(1.0, np.abs(ref[3]).max())
+            assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}: {np.abs(a - b[sl]).max()}"
+
+
+@pytest.mark.parametrize("R,Nx", [(1, 64), (2, 64), (4, 64), (8, 64), (2, 6), (4, 48), (8, 24)])
+def test_distributed_transpose_free_pipeline_matches_single_rank(ocn, R, Nx, monkeypatch):
+    """ocn_dist_poisson_pipeline = 3 (csrc/xtri.hip): no transposes -- the x direction is the cyclic tridiagonal system the
+    reference inverts with FFT_x and the eigenvalue division (distributed_fft_based_poisson_solver.jl:141-178), solved by local
+    Thomas sweeps, ONE all-gather of two numbers per (ky, kz) mode and a circulant interface system.  Two RK3 steps must match the
+    single-rank model (FFT in x: a different algorithm for the same operator) for 1 (a rank that is its own neighbour), 2, 4, 8
+    ranks, blocks of 3 to 64 columns and an x extent that is not a power of two."""
+    monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
+    P = "Periodic"
+    N = (Nx, 128, 64)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 4 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(977 + R)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    dt = 0.005
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
+    sm = ocn.NonhydrostaticModel(sg, advection=ocn.WENO())
+    ocn.set(sm, **init)
+    for _ in range(2):
+        ocn.time_step(sm, dt)
+    ocn.sync_device()
+    ref = [f.interior() for f in sm.velocities] + [sm.pNHS.interior()]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric, force_communication=(R == 1))
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+        assert m.pressure_solver.impl.fast == 3
         sl = slice(r * g.Nx, (r + 1) * g.Nx)
         ocn.set(m, **{k: v[sl] for k, v in init.items()})
         for _ in range(2):
@@ -275,7 +321,7 @@ def test_distributed_large_slabs_match_single_rank(ocn, topo):
             arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
             g = ocn.RectilinearGrid(arch, size=N, **ext)
             m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
-            assert m.pressure_solver.impl.fast == (1 if topo == "PPP" else 2)
+            assert m.pressure_solver.impl.fast == (3 if topo == "PPP" else 2)  # R > 1: the transpose-free pipeline by default
             sl = slice(r * g.Nx, (r + 1) * g.Nx)
             ocn.set(m, **{k: v[sl] for k, v in init.items()})
             ocn.time_step(m, dt)

@@ -49,6 +49,9 @@ class LoopbackFabric:
         else:
             recv.zero_()
 
+    def all_gather(self, recv, send):
+        recv.view(self.size, -1).copy_(send.expand(self.size, -1))  # identical ranks: everybody's message is mine
+
     def allreduce_max(self, t):
         return t
 
