@@ -394,8 +394,9 @@ def rccl_arch(ocn, request):
     arch.fabric.close()
 
 
-@pytest.mark.parametrize("N,topo", [((32, 16, 12), "PPP"), ((32, 16, 12), "PPB"), ((64, 128, 64), "PPP"), ((64, 128, 32), "PPB")])
-def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_arch, N, topo):
+@pytest.mark.parametrize("N,topo", [((32, 16, 12), "PPP"), ((32, 16, 12), "PPB"), ((64, 128, 64), "PPP"), ((64, 128, 32), "PPB"),
+                                    ((48, 128, 64), "PPP-xtri")])
+def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_arch, N, topo, monkeypatch):
     """Two RK3 steps with every exchange executed by RCCL (self send / recv): the halo strips with the overlapped interior / buffer
     split, the one-plane exchanges of the projection, the deferred end-of-step exchange and both all-to-alls of the distributed
     solver ((64, 128, 64) selects the slab pipeline, (32, 16, 12) the transposing rocFFT path, PPB the distributed Fourier-tridiagonal
@@ -403,6 +404,10 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
     from helpers import stretched_faces
     O = oracle
     P = "Periodic"
+    xtri = topo.endswith("-xtri")  # the transpose-free pipeline: its one exchange is ncclAllGather (ocn_comm_all_gather)
+    topo = topo[:3]
+    if xtri:
+        monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
     z = (0, 2 * np.pi) if topo == "PPP" else stretched_faces(N[2], 2.0)
     ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=(P, P, P if topo == "PPP" else "Bounded"), halo=(3, 3, 3))
     rng = np.random.default_rng(4321)
@@ -410,7 +415,7 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
     if topo == "PPB":
         init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
     dt = 0.01 if N[0] <= 32 else 0.002
-    fast_expected = {(64, 128, 64): 1, (64, 128, 32): 2}.get(N, 0)
+    fast_expected = 3 if xtri else {(64, 128, 64): 1, (64, 128, 32): 2}.get(N, 0)
     ocn.set_math_mode(ocn.MATH_STRICT)
     sm = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO())
     ocn.set(sm, **init)
