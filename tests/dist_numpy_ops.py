@@ -168,6 +168,94 @@ class _NumpyDistSlab(_NumpyDistPoisson):
         fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = y
 
 
+class _NumpyDistXTri(_NumpyDistPoisson):
+    """The transpose-free pipeline of libocn_hip (ocn_dist_poisson_pipeline == 3, csrc/xtri.hip) restated with numpy: real y and
+    complex z transforms on the slab; per (ky, kz) mode the cyclic tridiagonal system p[i-1] - (2 + mu) p[i] + p[i+1] = dx^2 F[i],
+    mu = dx^2 (ly + lz) -- the operator whose x-FFT eigenvalues the reference divides by (poisson_eigenvalues.jl:8-31) -- by local
+    Thomas solves, an all-gather of the blocks' first / last values (gsend -> grecv) and the circulant interface system; the
+    (0, 0) mode by prefix sums with the means removed.  Vectorised over the modes, loops over xl."""
+    fast = 3
+
+    def __init__(self, grid, arch):
+        super().__init__(grid, arch)
+        nx, Ny, Nz = grid.Nx, grid.Ny, grid.Nz
+        self.NyH = Ny // 2 + 1
+        self.M = self.NyH * Nz
+        self.send = None
+        self.A = np.zeros((nx, self.NyH, Nz), dtype=np.complex128)
+        self.gsend = torch.zeros(2 * (2 * self.M + nx), dtype=torch.float64)
+        self.grecv = torch.zeros(2 * (2 * self.M + nx) * self.R, dtype=torch.float64)
+        dx = grid.dx
+        self.dx2 = dx * dx
+        mu = self.dx2 * (self.ly[:self.NyH, None] + self.lz[None, :])     # (NyH, Nz)
+        mu[0, 0] = 1.0                                                      # singular mode: finite stand-in, its line is replaced
+        self.mu = mu
+        sq = np.sqrt(mu * (mu + 4))
+        self.r = 2 / ((2 + mu) + sq)
+
+    def forward_yz(self):
+        nx, M = self.g.Nx, self.M
+        F = self.dx2 * sfft.fft(sfft.rfft(self.y.real, axis=1), axis=2)   # (nx, NyH, Nz); the unnormalised inverse is irfft / ifft below
+        gs = self._cbuf(self.gsend)
+        gs[2 * M:] = F[:, 0, 0]
+        b = -(2 + self.mu)
+        c = np.zeros((nx,) + b.shape)
+        d = np.zeros_like(F)
+        c[0] = 1 / b
+        d[0] = F[0] / b
+        for i in range(1, nx):
+            c[i] = 1 / (b - c[i - 1])
+            d[i] = (F[i] - d[i - 1]) * c[i]
+        x = np.zeros_like(F)
+        x[nx - 1] = d[nx - 1]
+        for i in range(nx - 2, -1, -1):
+            x[i] = d[i] - c[i] * x[i + 1]
+        self.A[...] = x
+        gs[0:2 * M:2] = x[0].ravel()
+        gs[1:2 * M:2] = x[nx - 1].ravel()
+
+    def solve_x(self):
+        nx, M, R, n = self.g.Nx, self.M, self.R, self.g.Nx
+        gr = self._cbuf(self.grecv).reshape(R, 2 * M + nx)
+        shp = self.mu.shape
+        g1 = gr[:, 0:2 * M:2].reshape((R,) + shp)
+        gn = gr[:, 1:2 * M:2].reshape((R,) + shp)
+        r = self.r
+        den = 1 - r ** (2 * (n + 1))
+        v1 = -(r - r ** (2 * n + 1)) / den
+        vn = -(r ** n - r ** (n + 2)) / den
+        # a_s + v1 z_(s-1) + vn a_(s+1) = g1_s;  z_s + vn z_(s-1) + v1 a_(s+1) = gn_s  (cyclic): DFT over s
+        g1h, gnh = sfft.fft(g1, axis=0) / R, sfft.fft(gn, axis=0) / R      # xh_k = (1/R) sum_s x_s w^(-k s)
+        k = np.arange(R).reshape((R,) + (1,) * len(shp))
+        w = np.exp(2j * np.pi * k / R)
+        A11, A12, A21, A22 = 1 + vn * w, v1 / w, v1 * w, 1 + vn / w
+        det = A11 * A22 - A12 * A21
+        ah = (A22 * g1h - A12 * gnh) / det
+        zh = (A11 * gnh - A21 * g1h) / det
+        a = sfft.ifft(ah, axis=0) * R                                      # x_s = sum_k xh_k w^(k s)
+        z = sfft.ifft(zh, axis=0) * R
+        x0, xn1 = z[(self.rank - 1) % R], a[(self.rank + 1) % R]
+        i = np.arange(1, n + 1).reshape((n,) + (1,) * len(shp))
+        v = -(r ** i - r ** (2 * (n + 1) - i)) / den
+        wsp = -(r ** (n + 1 - i) - r ** (n + 1 + i)) / den
+        self.A[...] = self.A - v * x0 - wsp * xn1
+        # the (0, 0) line over the global x extent
+        F = gr[:, 2 * M:].ravel()
+        N = F.size
+        Fp = F - F.mean()
+        sc = np.cumsum(Fp)
+        dline = -sc.sum() / N + sc
+        pl = np.concatenate([[0], np.cumsum(dline)[:-1]])
+        pl = pl - pl.mean()
+        self.A[:, 0, 0] = pl[self.rank * n:(self.rank + 1) * n]
+
+    def backward_yz(self, p):
+        Ny = self.g.Ny
+        y = sfft.irfft(sfft.ifft(self.A, axis=2), n=Ny, axis=1)
+        g = self.g
+        fview(p)[g.Hx:g.Hx + g.Nx, g.Hy:g.Hy + g.Ny, g.Hz:g.Hz + g.Nz] = y
+
+
 class _NumpyDistSlabTridiagonal(_NumpyDistTridiagonal):
     """The tridiagonal flavour of the slab pipeline (ocn_dist_poisson_pipeline == 2): the half spectrum is partitioned by ky in R
     zero-padded chunks of c = ceil(NyH / R); send[d][ky_l + c (z + Nz xl)]; after the exchange recv[xg][z][ky_l]: FFT_x, Thomas
@@ -227,8 +315,9 @@ class _NumpyDistSlabTridiagonal(_NumpyDistTridiagonal):
 class NumpyOps:
     name = "numpy"
 
-    def __init__(self, slab=False):
+    def __init__(self, slab=False, xtri=False):
         self.slab = slab  # restate the library's slab pipelines instead of the transposing reference choreography
+        self.xtri = xtri  # restate the transpose-free pipeline (periodic z)
 
     def new_buffer(self, arch, n):
         return torch.zeros(n, dtype=torch.float64)
@@ -279,4 +368,6 @@ class NumpyOps:
     def make_dist_poisson(self, grid, arch):
         if grid.topology[2] == "Bounded":
             return (_NumpyDistSlabTridiagonal if self.slab else _NumpyDistTridiagonal)(grid, arch)
+        if self.xtri:
+            return _NumpyDistXTri(grid, arch)
         return (_NumpyDistSlab if self.slab and grid.Nz % arch.partition.x == 0 else _NumpyDistPoisson)(grid, arch)

@@ -31,7 +31,8 @@ def _worker(rank, world, port, fn, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import oceananigans_jl_amd as ocn
         from dist_numpy_ops import HostArch, NumpyOps
-        arch = ocn.Distributed(HostArch(), partition=ocn.Partition(world), ops=NumpyOps(slab=os.environ.get("OCN_TEST_SLAB") == "1"))
+        arch = ocn.Distributed(HostArch(), partition=ocn.Partition(world), ops=NumpyOps(slab=os.environ.get("OCN_TEST_SLAB") == "1",
+                                                                                               xtri=os.environ.get("OCN_TEST_XTRI") == "1"))
         fn(rank, world, ocn, arch)
         dist.barrier()
         dist.destroy_process_group()
@@ -176,6 +177,38 @@ def _slab_fft_matches_global(rank, world, ocn, arch):
     assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def _xtri_matches_global(rank, world, ocn, arch):
+    """The transpose-free pipeline (one all-gather per solve, dist.all_gather over gloo) against the oracle's global FFT solve:
+    Ny needs no relation to the number of ranks beyond the reference's Ny % R == 0, Nz none at all."""
+    from oracle import oracle as O
+    Nx, Ny, Nz = 6 * world, 2 * world, 5
+    g = _local_grid(ocn, arch, size=(Nx, Ny, Nz))
+    og = O.Grid((Nx, Ny, Nz), x=(0, 3.0), y=(0, 2.0), z=(0, 1.0), topology="PPP", halo=(3, 3, 3))
+    rng = np.random.default_rng(47)
+    hosts = []
+    for loc in (1, 2, 4):
+        a = og.zeros(loc)
+        og.interior(a)[...] = rng.random((Nx, Ny, Nz))
+        O.fill_halo_regions(og, a, loc)
+        hosts.append(a)
+    S = O.FFTBasedPoissonSolver(og)
+    p0 = og.zeros(0)
+    S.source_term(*hosts, 0.7)
+    S.solve(p0)
+    nx = g.Nx
+    U = [ocn.Field(loc, g) for loc in (1, 2, 4)]
+    for f, a in zip(U, hosts):
+        f.set(og.interior(a)[rank * nx:(rank + 1) * nx])
+    ocn.fill_halo_regions(U)
+    solver = ocn.nonhydrostatic_pressure_solver(g)
+    assert solver.impl.fast == 3
+    p = ocn.CenterField(g)
+    ocn.solve_for_pressure(p, solver, 0.7, U)
+    mine = p.interior()
+    ref = og.interior(p0)[rank * nx:(rank + 1) * nx]
+    assert np.abs(mine - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 def _tridiagonal_poisson_matches_global(rank, world, ocn, arch):
     """(x-partitioned, Periodic, Bounded) stretched z: the distributed Fourier-tridiagonal solve equals the single-process
     FourierTridiagonalPoissonSolver on the assembled field (test_distributed_poisson_solvers.jl:128-148 re-expressed)."""
@@ -243,3 +276,13 @@ def test_slab_pipeline_choreography_matches_global_solve(world, flavour, monkeyp
     DistributedFFTBasedPoissonSolver.solve over gloo ranks."""
     monkeypatch.setenv("OCN_TEST_SLAB", "1")
     _run(world, _slab_fft_matches_global if flavour == "fft" else _tridiagonal_poisson_matches_global)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_transpose_free_pipeline_matches_global_solve(world, monkeypatch):
+    """csrc/xtri.hip's algorithm (cyclic tridiagonal x solve by the partition method: local Thomas sweeps, ONE all-gather of two
+    numbers per mode, circulant interface systems, the singular mode by prefix sums) restated in numpy
+    (dist_numpy_ops._NumpyDistXTri) and run through the real DistributedFFTBasedPoissonSolver.solve over gloo ranks, against the
+    oracle's FFT solve of the assembled field (test_distributed_poisson_solvers.jl:70-89 re-expressed)."""
+    monkeypatch.setenv("OCN_TEST_XTRI", "1")
+    _run(world, _xtri_matches_global)
