@@ -14,7 +14,8 @@ Workloads (config.workload):
            ScalarDiffusivity, QuasiAdamsBashforth2.  A "step" is one time_step! (one tendency evaluation, 30 barotropic substeps).
 
 --gpus N > 1: the same global grid is x-slab partitioned over N ranks (strong scaling), one process per GPU, RCCL halo exchange
-and all-to-all transposes behind the C ABI (ocn_comm_*).  Run as `python bench.py --gpus N` the script starts its N ranks itself
+and the pressure solve's exchange (one all-gather per solve with the transpose-free pipeline, csrc/xtri.hip) behind the C ABI
+(ocn_comm_*).  Run as `python bench.py --gpus N` the script starts its N ranks itself
 (torch.distributed.run as a CHILD process, before anything touches the GPU); run under torch.distributed.run it is one rank.
 Rank 0 prints ONE JSON line.
 """
@@ -29,6 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC for RCCL / cross-process device memory: must be in the environment BEFORE the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_CELL_STEP = 1680.0  # 560 + 584 + 536 B per cell per RK3 step (REFERENCE kernel decomposition)
 TENDENCY_BYTES_PLAIN = 48.0        # fused compute_Gu/Gv/Gw launch: read u, v, w once, write Gu, Gv, Gw (fp64)

@@ -67,6 +67,32 @@ def test_momentum_tendencies_fast_tolerance(oracle, ocn, size, topo, z):
         assert np.abs(from_dev(b) - a).max() <= 1e-12 * scale
 
 
+@pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1.0, 1e6, 1e12, 1e20])
+def test_momentum_tendencies_fast_dynamic_range(oracle, ocn, scale):
+    """The fast build's single-reciprocal WENO weights form products of three smoothness indicators (m_r ~ psi^12,
+    csrc/ocn_weno.h), which overflow for |psi| >~ 4e25 where the reference's ratios tau / (beta + eps) do not: the supported range
+    of the fast build is stated here and in DESIGN.md -- velocities from 1e-12 to 1e20 in the grid's units agree with the oracle
+    (= strict build) to 1e-12 of max|G|, as at unit scale; fields beyond ~1e25 need the strict build (ocn_set_math_mode)."""
+    O = oracle
+    rng = np.random.default_rng(99)
+    og, pg = make_pair(O, ocn, (16, 12, 10), "PPB", z=stretched_faces(10))
+    u, v, w = (scale * random_parent(og, l, rng) for l in LOCS)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G)
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+        dG = [ocn.Field(l, pg) for l in LOCS]
+        ocn._lib.call("ocn_compute_momentum_tendencies", pg.cref, du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    for a, b in zip(G, dG):
+        got = from_dev(b)
+        assert np.isfinite(got).all()
+        assert np.abs(got - a).max() <= 1e-12 * np.abs(a).max()
+
+
 @pytest.mark.parametrize("size,topo,z", CASES)
 def test_tracer_tendency_strict_bitwise(oracle, ocn, size, topo, z):
     O = oracle
