@@ -223,6 +223,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line (the JSON of rank 0): RCCL and gloo print banners to the C-level stdout on initialisation, so
+    # file descriptor 1 points at stderr until the result is ready
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
     import numpy as np
@@ -482,7 +487,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_config4(min(a.cpu_n, 128), a.cpu_steps)
         else:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)  # anything the teardown prints goes to stderr again
     if dist is not None:
         dist.barrier()
         dist.close()

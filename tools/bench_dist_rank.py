@@ -16,7 +16,7 @@ import oceananigans_jl_amd as ocn
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 60  # the timed region carries ~30 ms of one-off cost (final flush, first-use allocations): 20 steps overstate by 1 ms
 workload = sys.argv[4] if len(sys.argv) > 4 else "box"
 
 
@@ -92,8 +92,9 @@ umax = max(float(f.interior_view().abs().max()) for f in m.velocities)
 dt = 0.1 * (min(g.dx, float(np.diff(z_faces).min())) if workload.startswith("config4") else g.dx) / umax
 if R > 1 and workload == "config4amd":
     dt *= 1e-3  # no projection in the loopback emulation: keep the unprojected noise from running away (timing does not depend on dt)
-for _ in range(3):
+for _ in range(5):
     ocn.time_step(m, dt)
+ocn.flush_tendencies(m)
 ocn.sync_device()
 t0 = time.perf_counter()
 for _ in range(steps):
