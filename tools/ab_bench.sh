@@ -15,7 +15,7 @@ for L in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab/$n.$rep.json"))
-r=d["roofline"]
+r=d.get("roofline") or {}
 print("$n rep$rep ms/step %.3f kernel_ms %s plain %s" % (d["ms_per_step"], r.get("kernel_ms"), r.get("hbm",{}).get("plain",{}).get("kernel_ms")))
 PY
 done
