@@ -150,13 +150,24 @@ class SplitExplicitFreeSurface:
 
 class HydrostaticFreeSurfaceModel:
     def __init__(self, grid, momentum_advection=None, tracer_advection=None, tracers=(), free_surface=None, coriolis=None,
-                 closure=None, buoyancy=None, boundary_conditions=None, fused=None):
+                 closure=None, buoyancy=None, boundary_conditions=None, fused=None, timestepper="QuasiAdamsBashforth2"):
         """fused (default: True with VectorInvariant() momentum): one QAB2 step = one pass for the horizontal momentum (tendency, AB2
         step, barotropic forcing and mode), one launch per WENO / UpwindBiased tracer (tendency + AB2 step), the temporally blocked
         substep loop, one pass for the barotropic corrector + w, one halo launch, the hydrostatic pressure; the tendency evaluation
         that closes the reference's time_step! is deferred into the next step's fused launches (`flush_tendencies` completes it).
         fused = False keeps the reference's launch sequence.  Both are bit-identical in strict math."""
         from .grids import FullyConnected
+        timestepper = str(timestepper).lstrip(":")
+        if timestepper not in ("QuasiAdamsBashforth2", "SplitRungeKutta3"):
+            raise ValueError(f"timestepper must be :QuasiAdamsBashforth2 or :SplitRungeKutta3, got {timestepper!r}")
+        self.split_rk3 = timestepper == "SplitRungeKutta3"
+        if self.split_rk3:
+            # (the reference itself warns that this time stepper is experimental, split_hydrostatic_runge_kutta_3.jl:57-58)
+            if not isinstance(free_surface, SplitExplicitFreeSurface):
+                raise NotImplementedError("SplitRungeKutta3: with a SplitExplicitFreeSurface")
+            if fused:
+                raise NotImplementedError("SplitRungeKutta3 runs the reference's launch sequence (fused = False)")
+            fused = False
         arch = grid.architecture
         self._dist = arch if (hasattr(arch, "partition") and arch.communicates) else None   # a slab-x rank (distributed.py)
         if tuple(grid.topology) != (FullyConnected if self._dist is not None else Periodic, Periodic, Bounded):
@@ -281,7 +292,65 @@ class HydrostaticFreeSurfaceModel:
         compute_boundary_tendency_contributions(nh)
 
     # ---- time_step! (quasi_adams_bashforth_2.jl:74-115 with ab2_step!(::HydrostaticFreeSurfaceModel)) -------------------------
+    def _time_step_split_rk3(self, dt):
+        """time_step!(model::AbstractModel{<:SplitRungeKutta3TimeStepper}, Δt) (split_hydrostatic_runge_kutta_3.jl:76-133) with
+        split_rk3_substep!(::HydrostaticFreeSurfaceModel) (hydrostatic_free_surface_rk3_step.jl:7-28): see oracle/hydrostatic.py
+        `_time_step_split_rk3` for the sequence.  The 3-D tendencies, the vertical integrals, the substepping, the corrector and
+        update_state! are the library's kernels; the stage combinations are elementwise IEEE operations in the reference's order."""
+        nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
+        if clock.iteration == 0:
+            if not self._initialized:
+                _lib.call("ocn_compute_barotropic_mode", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(), s)
+                self._initialized = True
+            self.update_state(compute_tendencies=True)
+        elif not self._tendencies_current:
+            self.compute_tendencies()
+        stepped = [self.u, self.v] + list(self.tracers)
+        gidx = [0, 1] + [3 + n for n in range(len(self.tracers))]
+        psi = [f.data.clone() for f in stepped]                                    # cache_previous_fields! (halos included)
+        psi_eta, psi_U, psi_V = self.eta.clone(), self.U.clone(), self.V.clone()
+        ii, jj = slice(g.Hy, g.Hy + g.Ny), slice(g.Hx, g.Hx + g.Nx)               # planes are [y, x]
+        kk = slice(g.Hz, g.Hz + g.Nz)
+        GUi, GVi, GUm, GVm = (torch.zeros_like(self.eta) for _ in range(4))
+        # (a / python_number multiplies by the rounded reciprocal on the device; a 0-dim device tensor divides)
+        three, six = (torch.tensor(x, dtype=torch.float64, device=self.eta.device) for x in (3.0, 6.0))
+        for stage, (gam, zet) in enumerate(((None, None), (1.0 / 4, 3.0 / 4), (2.0 / 3, 1.0 / 3)), 1):
+            clock.stage = stage
+            Gn = nh.timestepper._Gn
+            # G_vertical_integral: the slow-forcing kernel with χ = -1/2 returns Σ Δz (1 Gⁿ - 0 G⁻)
+            _lib.call("ocn_split_explicit_forcing", g.cref, Gn[0].ptr, Gn[0].ptr, Gn[1].ptr, Gn[1].ptr, -0.5, GUi.data_ptr(), GVi.data_ptr(), s)
+            if stage == 1:
+                self._GU.copy_(GUi); self._GV.copy_(GVi)
+                GUm.copy_(GUi); GVm.copy_(GVi)
+            elif stage == 2:
+                self._GU.copy_(GUi); self._GV.copy_(GVi)
+                GUm.copy_((GUi + GUm) / six); GVm.copy_((GVi + GVm) / six)
+            else:
+                self._GU.copy_(2 * GUi / three + GUm); self._GV.copy_(2 * GVi / three + GVm)
+                self.U.copy_(psi_U); self.V.copy_(psi_V); self.eta.copy_(psi_eta)
+            for q, (f, P) in enumerate(zip(stepped, psi)):
+                fi, Pi, Gi = f.data[kk, ii, jj], P[kk, ii, jj], Gn[gidx[q]].data[kk, ii, jj]
+                if stage == 1:
+                    fi.copy_((fi + dt * Gi) if q < 2 else (Pi + dt * Gi * 1.0))
+                else:
+                    fi.copy_(zet * Pi + gam * (fi + dt * Gi))
+            self._substep_free_surface(dt, s)                                      # the complete substepping over Δt
+            if stage == 2:
+                self.U[ii, jj] = zet * psi_U[ii, jj] + gam * self.U[ii, jj]
+                self.V[ii, jj] = zet * psi_V[ii, jj] + gam * self.V[ii, jj]
+                self.eta[ii, jj] = zet * psi_eta[ii, jj] + gam * self.eta[ii, jj]
+            _lib.call("ocn_barotropic_split_explicit_corrector", g.cref, self.u.ptr, self.v.ptr, self.U.data_ptr(), self.V.data_ptr(),
+                      self._Ub.data_ptr(), self._Vb.data_ptr(), float(g.Lz), s)
+            self.update_state(compute_tendencies=True)
+        clock.stage = 1
+        clock.time += dt
+        clock.iteration += 1
+        clock.last_dt = dt
+        clock.last_stage_dt = dt
+
     def time_step(self, dt, euler=False):
+        if self.split_rk3:
+            return self._time_step_split_rk3(dt)
         if self.fused:
             return self._time_step_fused(dt, euler)
         nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()

@@ -175,9 +175,14 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
 
     def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None,
                  buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None,
-                 split_explicit_timestepper="ForwardBackward", implicit_free_surface=False):
+                 split_explicit_timestepper="ForwardBackward", implicit_free_surface=False, timestepper="QuasiAdamsBashforth2"):
         """split_explicit_substeps = N: free_surface = SplitExplicitFreeSurface(substeps = N) with the ForwardBackwardScheme
-        (split_explicit_free_surface.jl:60-97); None: ExplicitFreeSurface."""
+        (split_explicit_free_surface.jl:60-97); None: ExplicitFreeSurface.  timestepper = "SplitRungeKutta3":
+        SplitRungeKutta3TimeStepper (split_hydrostatic_runge_kutta_3.jl, hydrostatic_free_surface_rk3_step.jl) with the split-explicit
+        free surface."""
+        assert timestepper in ("QuasiAdamsBashforth2", "SplitRungeKutta3")
+        self.split_rk3 = timestepper == "SplitRungeKutta3"
+        assert not self.split_rk3 or split_explicit_substeps is not None, "SplitRungeKutta3 here: SplitExplicitFreeSurface only"
         assert grid.topo[2] == O.BOUNDED and grid.topo[0] == O.PERIODIC and grid.topo[1] == O.PERIODIC
         self.implicit = bool(implicit_free_surface)   # ImplicitFreeSurface(solver_method = :FastFourierTransform)
         assert not (self.implicit and split_explicit_substeps is not None)
@@ -361,8 +366,68 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         ui[...] = ui - (grav * dt * ((e[ii, jj] - e[g.Hx - 1:g.Hx + g.Nx - 1, jj]) / g.dx))[:, :, None]
         vi[...] = vi - (grav * dt * ((e[ii, jj] - e[ii, g.Hy - 1:g.Hy + g.Ny - 1]) / g.dy))[:, :, None]
 
+    def _time_step_split_rk3(self, dt):
+        """time_step!(model::AbstractModel{<:SplitRungeKutta3TimeStepper}, Δt) (split_hydrostatic_runge_kutta_3.jl:76-133) with
+        split_rk3_substep!(::HydrostaticFreeSurfaceModel) (hydrostatic_free_surface_rk3_step.jl:7-28): per stage the integrated RK3
+        tendencies (compute_slow_tendencies.jl:85-108), u, v, tracers by Uᵐ⁺¹ = ζ Uⁿ + γ (Uᵐ + Δt Gᵐ) (γ², γ³ = 1/4, 2/3; ζ², ζ³ = 3/4,
+        1/3; stage 1: U + Δt G), the COMPLETE barotropic substepping over Δt (stage 3 restarts from the state at step n,
+        initialize_split_explicit_substepping.jl:44-63), the stage-2 average of η, U, V (rk3_average_free_surface!), the barotropic
+        corrector and update_state!(compute_tendencies = true); one tick of Δt at the end.  Static grid: σ = 1."""
+        g = self.grid
+        if self.iteration == 0:
+            if not self.initialized:
+                self.initialize()
+            self.update_state(compute_tendencies=True)
+        dz = self._dz_centres()
+        stepped = [self.u, self.v] + list(self.tracers)
+        gidx = [0, 1] + [3 + n for n in range(len(self.tracers))]
+        psi = [f.copy() for f in stepped]                                         # cache_previous_fields!
+        psi_eta, psi_U, psi_V = self.eta.copy(), self.U.copy(), self.V.copy()
+        ii, jj = slice(g.Hx, g.Hx + g.Nx), slice(g.Hy, g.Hy + g.Ny)
+        GUm, GVm = np.zeros_like(self.GU), np.zeros_like(self.GV)                   # timestepper.G⁻.U, G⁻.V
+        for stage, (gam, zet) in enumerate(((None, None), (1.0 / 4, 3.0 / 4), (2.0 / 3, 1.0 / 3)), 1):
+            # compute_free_surface_tendency!: G_vertical_integral, then the stage's combination; initialize_free_surface_state!
+            integ = []
+            for idx in (0, 1):
+                gn = g.interior_N(self.Gn[idx])
+                acc = dz[0] * gn[:, :, 0]
+                for k in range(1, g.Nz):
+                    acc = acc + dz[k] * gn[:, :, k]
+                integ.append(acc)
+            if stage == 1:
+                self.GU[...], self.GV[...] = integ[0], integ[1]
+                GUm[...], GVm[...] = self.GU, self.GV
+            elif stage == 2:
+                self.GU[...], self.GV[...] = integ[0], integ[1]
+                GUm[...], GVm[...] = (self.GU + GUm) / 6, (self.GV + GVm) / 6
+            else:
+                self.GU[...], self.GV[...] = 2 * integ[0] / 3 + GUm, 2 * integ[1] / 3 + GVm
+                self.U[...], self.V[...], self.eta[...] = psi_U, psi_V, psi_eta
+            self.etab[...] = 0.0
+            self.Ub[...] = 0.0
+            self.Vb[...] = 0.0
+            # rk3_substep_velocities!, rk3_substep_tracers!
+            for q, (f, P) in enumerate(zip(stepped, psi)):
+                fi, Pi, G = g.interior_N(f), g.interior_N(P), g.interior_N(self.Gn[gidx[q]])
+                if stage == 1:
+                    fi[...] = (fi + dt * G) if q < 2 else (Pi + dt * G * 1.0)
+                else:
+                    fi[...] = zet * Pi + (gam if q < 2 else gam * 1.0) * (fi + dt * G)
+            self._substep(dt)                                                      # step_free_surface! over the whole Δt
+            if stage == 2:                                                         # rk3_average_free_surface!
+                self.U[...] = zet * psi_U + gam * self.U
+                self.V[...] = zet * psi_V + gam * self.V
+                self.eta[ii, jj] = zet * psi_eta[ii, jj] + gam * self.eta[ii, jj]
+            self._barotropic_corrector()                                           # pressure_correct_velocities!
+            self.update_state(compute_tendencies=True)
+        self.time += dt
+        self.iteration += 1
+        self.last_dt = dt
+
     def time_step(self, dt, euler=False):
         g = self.grid
+        if getattr(self, "split_rk3", False):
+            return self._time_step_split_rk3(dt)
         if self.iteration == 0:
             if self.split is not None and not self.initialized:
                 self.initialize()

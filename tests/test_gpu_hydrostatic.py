@@ -118,7 +118,7 @@ def test_split_explicit_free_surface_model_steps_match_oracle(oracle, ocn, fused
 
 
 # ---- BASELINE.json configs[4]: VectorInvariant momentum + WENO tracer advection + SplitExplicitFreeSurface -----------------------------
-def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None):
+def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None, timestepper="QuasiAdamsBashforth2"):
     from oracle import hydrostatic as Hy
     O = oracle
     og, pg = _pair(O, ocn, size, stretched=stretched)
@@ -127,7 +127,7 @@ def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None):
                 T=20 + 1e-2 * rng.uniform(-1, 1, size), S=35 + 1e-2 * rng.uniform(-1, 1, size))
     om = Hy.HydrostaticFreeSurfaceModel(og, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5",
                                         coriolis_f=1e-4, closure=(1e-2, 2e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4),
-                                        split_explicit_substeps=substeps,
+                                        split_explicit_substeps=substeps, timestepper=timestepper,
                                         boundary_conditions={"u": {"top": O.FluxBoundaryCondition(-1e-4)}, "T": {"top": O.FluxBoundaryCondition(5e-5)}})
     om.set(**init)
     pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
@@ -136,7 +136,7 @@ def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None):
                                          buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
                                          boundary_conditions={"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1e-4)),
                                                               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5))},
-                                         fused=fused)
+                                         fused=fused, timestepper=timestepper)
     pm.set(**init)
     return og, om, pm
 
@@ -180,6 +180,29 @@ def test_config5_combination_matches_oracle(oracle, ocn, size, substeps, stretch
         _compare_hydrostatic(og, om, pm, 0 if math == "strict" else 1e-10)
         assert np.abs(om.U).max() > 0 and np.abs(og.interior(om.w)).max() > 0
         assert np.abs(og.interior(om.u)).max() < 1.0 and np.abs(om.eta).max() < 1.0      # a stable run, not a common blow-up
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+
+
+@pytest.mark.parametrize("size,substeps,stretched,dt", [((16, 12, 7), 12, True, 20.0), ((67, 9, 12), 8, True, 3.0)])
+@pytest.mark.parametrize("math", ["strict", "fast"])
+def test_split_runge_kutta_3_matches_oracle(oracle, ocn, size, substeps, stretched, dt, math):
+    """HydrostaticFreeSurfaceModel(timestepper = :SplitRungeKutta3) with the split-explicit free surface
+    (split_hydrostatic_runge_kutta_3.jl:76-133, hydrostatic_free_surface_rk3_step.jl:7-60, compute_slow_tendencies.jl:85-108,
+    initialize_split_explicit_substepping.jl:44-63): three stages per step, each with the complete barotropic substepping, the
+    stage-2 average and the stage-3 restart from step n.  The reference holds no test of this (experimental) time stepper, so the
+    oracle is its only pin: 2 steps, bit for bit in strict math, 1e-10 in fast math."""
+    ocn.set_math_mode(ocn.MATH_STRICT if math == "strict" else ocn.MATH_FAST)
+    try:
+        og, om, pm = _config5_pair(oracle, ocn, size, substeps, stretched, timestepper="SplitRungeKutta3")
+        assert pm.split_rk3 and not pm.fused
+        for _ in range(2):
+            om.time_step(dt)
+            pm.time_step(dt)
+        ocn.sync_device()
+        _compare_hydrostatic(og, om, pm, 0 if math == "strict" else 1e-10)
+        assert pm.clock.iteration == 2 and abs(pm.clock.time - 2 * dt) < 1e-12
+        assert np.abs(og.interior(om.u)).max() < 1.0 and np.abs(om.eta).max() < 1.0
     finally:
         ocn.set_math_mode(ocn.MATH_STRICT)
 

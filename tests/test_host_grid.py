@@ -112,3 +112,11 @@ def test_implicit_free_surface_arguments(pkg):
     pkg.ImplicitFreeSurface(solver_method=":FastFourierTransform")
     with pytest.raises(NotImplementedError):
         pkg.ImplicitFreeSurface(solver_method=":PreconditionedConjugateGradient")
+
+
+def test_hydrostatic_timestepper_argument(pkg):
+    """HydrostaticFreeSurfaceModel(; timestepper = :QuasiAdamsBashforth2 | :SplitRungeKutta3) (hydrostatic_free_surface_model.jl): the
+    name is validated before anything touches a device"""
+    import inspect
+    sig = inspect.signature(pkg.HydrostaticFreeSurfaceModel.__init__)
+    assert sig.parameters["timestepper"].default == "QuasiAdamsBashforth2"

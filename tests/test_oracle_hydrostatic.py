@@ -419,3 +419,40 @@ def test_implicit_free_surface_model_is_stable_at_large_gravity_wave_cfl():
         amp.append(np.abs(e).max() / a)
         assert abs(e.sum()) < 1e-14 * Nx * 4 * a
     assert max(amp) <= 1.0 + 1e-12 and np.isfinite(m.u).all()
+
+
+# ---- SplitRungeKutta3 (split_hydrostatic_runge_kutta_3.jl; the reference ships no test of it and calls it experimental) -----------------------
+def _rk3_case(ts, n, T=160.0, N=(16, 12, 6)):
+    from helpers import stretched_faces
+    g = O.Grid(N, x=(0, 4.0e3), y=(0, 3.0e3), z=stretched_faces(N[2], 40.0), topology="PPB", halo=(3, 3, 3))
+    m = Hy.HydrostaticFreeSurfaceModel(g, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5", coriolis_f=1e-4,
+                                       closure=(1e-2, 2e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4), split_explicit_substeps=12,
+                                       timestepper=ts)
+    x, y = (np.arange(N[0]) + 0.5) / N[0], (np.arange(N[1]) + 0.5) / N[1]
+    one = np.ones(N)
+    m.set(u=0.05 * np.sin(2 * np.pi * x)[:, None, None] * np.cos(2 * np.pi * y)[None, :, None] * one,
+          v=-0.05 * np.cos(2 * np.pi * x)[:, None, None] * np.sin(2 * np.pi * y)[None, :, None] * one,
+          eta=0.02 * np.cos(2 * np.pi * x)[:, None] * np.ones(N[:2]), T=20 + 0.1 * np.sin(2 * np.pi * x)[:, None, None] * one, S=35.0 * one)
+    for _ in range(n):
+        m.time_step(T / n)
+    return g.interior_N(m.u).copy(), m.eta[3:-3, 3:-3].copy(), m
+
+
+def test_split_runge_kutta_3_is_consistent_with_qab2_and_converges():
+    """Both time steppers integrate the same equations with the same split-explicit free surface: at the same Δt their solutions agree
+    far better than either agrees with a finer step, and halving Δt halves the distance to a 4x finer run (the barotropic averaging over
+    a Δt-wide window makes both first order in Δt for the fast surface wave).  Volume is conserved and the barotropic corrector leaves
+    Σ Δz u = U at the end of every stage."""
+    u_ref, e_ref, _ = _rk3_case("SplitRungeKutta3", 64)
+    u8, e8, _ = _rk3_case("SplitRungeKutta3", 8)
+    u16, e16, m = _rk3_case("SplitRungeKutta3", 16)
+    uq, eq, _ = _rk3_case("QuasiAdamsBashforth2", 16)
+    su, se = np.abs(u_ref).max(), np.abs(e_ref).max()
+    err8, err16 = np.abs(u8 - u_ref).max() / su, np.abs(u16 - u_ref).max() / su
+    assert err16 < 0.01 and 1.6 < err8 / err16 < 2.6, (err8, err16)
+    assert np.abs(e16 - e_ref).max() / se < 0.12
+    assert np.abs(u16 - uq).max() / su < 0.1 * err16 and np.abs(e16 - eq).max() / se < 0.01   # same Δt: the two schemes nearly coincide
+    g = m.grid
+    assert abs(m.eta[3:-3, 3:-3].mean() - 0.0) < 1e-15 + 1e-13 * se                          # mean(η) of the cosine initial condition is 0
+    assert np.abs(m._barotropic_mode(m.u) - m.U).max() <= 1e-12 * np.abs(m.U).max()
+    assert m.iteration == 16 and abs(m.time - 160.0) < 1e-9
