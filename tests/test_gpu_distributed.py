@@ -80,9 +80,9 @@ def _run_ranks(R, fn):
 
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("topo", ["PPP", "PPB"])
-def test_distributed_steps_match_single_rank(ocn, R, topo):
-    """Two RK3 steps on R slab-x ranks against the single-rank model; "PPB" = stretched Bounded z, i.e. the distributed
-    Fourier-tridiagonal solver (config 4's solver at 1 -> 8 GPUs)."""
+def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
+    """Two RK3 steps on R slab-x ranks against the single-rank model AND, directly, against the CPU oracle; "PPB" = stretched Bounded
+    z, i.e. the distributed Fourier-tridiagonal solver (config 4's solver at 1 -> 8 GPUs)."""
     from helpers import stretched_faces
     P = "Periodic"
     N = (32, 16, 12)
@@ -134,6 +134,17 @@ def test_distributed_steps_match_single_rank(ocn, R, topo):
                 # writes it (kernel_launching.jl:236-240); no kernel ever reads it
                 a, b = a[:, :, 1:], b[:, :, 1:]
             assert np.abs(a - b[sl]).max() <= 1e-9 * max(1.0, np.abs(b).max())
+    # the same two steps on the CPU oracle: the distributed result is compared with it directly, not only through the single-rank model
+    O = oracle
+    og = O.Grid(N, x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi) if topo == "PPP" else ext["z"], topology=topo, halo=(3, 3, 3))
+    om = O.NonhydrostaticModel(og)
+    om.set(**init)
+    for _ in range(2):
+        om.time_step(dt)
+    for r, (fields, _) in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, name in zip(fields[:3], (om.u, om.v, om.w), "uvw"):
+            assert np.abs(a - og.interior(b)[sl]).max() <= 1e-11 * scale, f"rank {r} field {name} vs the oracle"
 
 
 @pytest.mark.parametrize("R", [2, 4])
