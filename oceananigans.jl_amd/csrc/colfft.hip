@@ -283,8 +283,12 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
             // 16 columns per workgroup = 256-B runs per row (one workgroup of 1024 threads per CU): 2.87 ms per 512^3 solve against
             // 2.96 ms with 8 columns (128-B runs, 2 workgroups per CU)
             static const int cb = getenv("OCN_COLFFT_CB") ? atoi(getenv("OCN_COLFFT_CB")) : 16;
-            if (cb == 4) return launch_n<512, 4>(mode, a, stream);
-            if (cb == 8) return launch_n<512, 8>(mode, a, stream);
+            // the fused FFT-solve-IFFT pass holds 94 VGPRs and works twice as long per byte: two 8-column workgroups per CU overlap one's
+            // loads / stores with the other's arithmetic (512^3 step 27.15 vs 27.35 ms, same box)
+            static const int cb2 = getenv("OCN_COLFFT_CB2") ? atoi(getenv("OCN_COLFFT_CB2")) : (getenv("OCN_COLFFT_CB") ? cb : 8);
+            const int c = mode == 2 ? cb2 : cb;
+            if (c == 4) return launch_n<512, 4>(mode, a, stream);
+            if (c == 8) return launch_n<512, 8>(mode, a, stream);
             return launch_n<512, 16>(mode, a, stream);
         }
         default: set_error("column FFT length %d is not supported (64, 128, 256, 512)", N); return OCN_ERR_UNSUPPORTED;
