@@ -244,6 +244,60 @@ def test_distributed_transpose_free_pipeline_matches_single_rank(ocn, R, Nx, mon
             assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}: {np.abs(a - b[sl]).max()}"
 
 
+@pytest.mark.parametrize("Lx,Ly,Lz", [(2.0e3, 0.5, 3.0), (2.0e-2, 50.0, 7.0), (1.0, 1.0, 1.0e-3)])
+def test_transpose_free_poisson_extreme_aspect_ratios(ocn, Lx, Ly, Lz, monkeypatch):
+    """The cyclic tridiagonal x solve over the whole range of mu = dx^2 (ly + lz): mu ~ 1e7 (r^n underflows, the blocks decouple),
+    mu ~ 1e-9 for the gravest modes (r -> 1, the closed forms go through expm1 / log1p), and a thin z.  solve_for_pressure! on 4 ranks
+    against the single-rank FFT solver on the same velocities: relative 20 eps x (largest / smallest eigenvalue) of max|p| (the
+    conditioning of the eigenvalue division itself), and the discrete Laplacian of the distributed p reproduces the source term."""
+    monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
+    P, R, N = "Periodic", 4, (48, 128, 64)
+    ext = dict(x=(0, Lx), y=(0, Ly), z=(0, Lz), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(2024)
+    init = [rng.uniform(-1, 1, N) for _ in range(3)]
+    sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
+    U = [ocn.Field(loc, sg) for loc in (1, 2, 4)]
+    for f, a in zip(U, init):
+        f.set(a)
+    ocn.fill_halo_regions(U)
+    ps = ocn.CenterField(sg)
+    ocn.solve_for_pressure(ps, ocn.nonhydrostatic_pressure_solver(sg), 0.7, U)
+    ocn.sync_device()
+    ref = ps.interior()
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        sl = slice(r * g.Nx, (r + 1) * g.Nx)
+        Ul = [ocn.Field(loc, g) for loc in (1, 2, 4)]
+        for f, a in zip(Ul, init):
+            f.set(a[sl])
+        ocn.fill_halo_regions(Ul)
+        solver = ocn.nonhydrostatic_pressure_solver(g)
+        assert solver.impl.fast == 3
+        p = ocn.CenterField(g)
+        ocn.solve_for_pressure(p, solver, 0.7, Ul)
+        ocn.sync_device()
+        return p.interior()
+
+    outs = _run_ranks(R, rank_main)
+    got = np.concatenate(outs, axis=0)
+    assert np.isfinite(got).all()
+    # both solvers divide by the same eigenvalues: what they may differ by is eps x the condition number of the operator
+    dx, dy, dz = Lx / N[0], Ly / N[1], Lz / N[2]
+    lam_max = 4 / dx ** 2 + 4 / dy ** 2 + 4 / dz ** 2
+    lam_min = min((2 * np.sin(np.pi / n) / d) ** 2 for n, d in zip(N, (dx, dy, dz)))
+    tol = max(1e-10, 20 * np.finfo(float).eps * lam_max / lam_min)
+    assert tol < 1e-3
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), (np.abs(got - ref).max() / np.abs(ref).max(), tol)
+    # residual: the periodic 7-point Laplacian of p equals div(U) / dt
+    lap = ((np.roll(got, -1, 0) - 2 * got + np.roll(got, 1, 0)) / dx ** 2 + (np.roll(got, -1, 1) - 2 * got + np.roll(got, 1, 1)) / dy ** 2
+           + (np.roll(got, -1, 2) - 2 * got + np.roll(got, 1, 2)) / dz ** 2)
+    u, v, w = init
+    div = ((np.roll(u, -1, 0) - u) / dx + (np.roll(v, -1, 1) - v) / dy + (np.roll(w, -1, 2) - w) / dz) / 0.7
+    assert np.abs(lap - div).max() <= tol * np.abs(div).max(), (np.abs(lap - div).max() / np.abs(div).max(), tol)
+
+
 @pytest.mark.parametrize("R", [2, 4])
 @pytest.mark.parametrize("closure,stepper", [("constant", "RungeKutta3"), ("AMD", "RungeKutta3"), ("AMD", "QuasiAdamsBashforth2")])
 def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, stepper):
