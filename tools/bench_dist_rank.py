@@ -7,7 +7,8 @@ pressure solve, see LoopbackFabric.all_to_all: TIMING ONLY, the pressure is not 
 the per-rank compute + host time of an R-GPU step with the communication itself replaced by device copies; compare it with
 (single-GPU step) / R to see what the decomposition costs before any link time.
 
-  tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched, advection only) | config4amd (its full physics)
+  tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched, advection only) | config4amd (its full physics) |
+                                                          config5 (2N x 2N x N/4 HydrostaticFreeSurfaceModel as bench.py --workload config5)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,6 +58,38 @@ class LoopbackFabric:
 
 
 ocn.set_math_mode(ocn.MATH_FAST)
+if workload == "config5":
+    # BASELINE.json configs[4] (an 8-GPU configuration): what one of R slab-x ranks costs
+    arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=LoopbackFabric(R)) if R > 1 else ocn.GPU()
+    Nx, Nz, H, L = 2 * N, N // 4, 1000.0, 1.0e6 * 2 * N / 1024.0
+    g = ocn.RectilinearGrid(arch, size=(Nx, Nx, Nz), x=(0, L), y=(0, L), z=(-H, 0.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    m = ocn.HydrostaticFreeSurfaceModel(g, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
+                                        free_surface=ocn.SplitExplicitFreeSurface(substeps=30), coriolis=ocn.FPlane(f=1e-4),
+                                        closure=ocn.ScalarDiffusivity(ν=1e-2, κ=1e-3),
+                                        buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)))
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    for f in (m.u, m.v):
+        v = f.interior_view()
+        v.copy_(1e-2 * (2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
+    zc = torch.linspace(-H + H / (2 * Nz), -H / (2 * Nz), Nz, device="cuda", dtype=torch.float64)
+    m.field("T").interior_view().copy_((20 + 0.01 * zc)[:, None, None].expand(Nz, Nx, g.Nx))
+    m.field("S").interior_view().fill_(35.0)
+    m.update_state(compute_tendencies=False)
+    dt = 2.0 * g.dx / np.sqrt(9.80665 * H)
+    for _ in range(5):
+        m.time_step(dt)
+    m.flush_tendencies()
+    ocn.sync_device()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.time_step(dt)
+    m.flush_tendencies()
+    host_ms = (time.perf_counter() - t0) / steps * 1e3
+    ocn.sync_device()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    finite = all(bool(torch.isfinite(f.interior_view()).all()) for f in (m.u, m.v))
+    print(f"config5 N={Nx}x{Nx}x{Nz} R={R}: local {g.Nx}x{g.Ny}x{g.Nz}, {ms:.2f} ms/step per rank (host enqueue {host_ms:.2f} ms), finite={finite}")
+    sys.exit(0)
 arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=LoopbackFabric(R)) if R > 1 else ocn.GPU()
 P = "Periodic"
 if workload.startswith("config4"):
