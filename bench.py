@@ -466,13 +466,15 @@ def main():
                     f"(T, S), SplitExplicitFreeSurface(substeps={a.substeps}), linear SeawaterBuoyancy, FPlane, ScalarDiffusivity, QAB2, fp64")
     else:
         workload = f"{N}^3 triply-periodic NonhydrostaticModel, WENO5, RK3, FFTBasedPoissonSolver, fp64"
+    # which exchange pattern the pressure solve of a partitioned run uses (ocn_dist_poisson_pipeline): 3 = no transposes, one all-gather
+    pipeline = getattr(getattr(getattr(model, "pressure_solver", None), "impl", None), "fast", None)
     out = {
         "metric": "cell-updates/sec (whole node), 512^3 NonhydrostaticModel WENO5, 1/2/4/8 GPU",
         "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "grid": [Nx, Nx if hydro else N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}",
-                   "finite": finite, "rccl": comm_info},
+                   "finite": finite, "rccl": comm_info, "dist_pressure_pipeline": pipeline},
         "strict_ms_per_step": strict_ms,
         "roofline": roofline,
         "step_roofline": step_roofline,
