@@ -530,3 +530,38 @@ def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own):
     for a, b in zip(ref.velocities + (ref.pNHS,), m.velocities + (m.pNHS,)):
         np.testing.assert_array_equal(from_dev(a), from_dev(b))
     del drv
+
+
+def test_plain_c_host_of_the_c_abi_matches_the_python_host(ocn, tmp_path):
+    """examples/c_abi_rk3.c (built by __graft_entry__.build()): a C99 program with no Python and no torch allocates through
+    ocn_malloc, runs set! and three RK3 time_step!s through ocn_rk3_driver_* and writes u, v, w.  The Python host driving the same
+    library from the same initial condition must agree bit for bit (strict math): the C ABI is self-sufficient."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "c_abi_rk3")
+    if not os.path.exists(exe):
+        pytest.fail("examples/bin/c_abi_rk3 is missing: run __graft_entry__.build()")
+    N, steps, dt = 24, 3, 2e-3
+    out = tmp_path / "uvw.bin"
+    r = subprocess.run([exe, str(N), str(steps), repr(dt), "strict", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, dtype=np.float64).reshape(3, N, N, N)           # [field][k][j][i]
+    # the same 64-bit LCG as the C program, i fastest, for u, v, w
+    state, vals = 0x9E3779B97F4A7C15, np.empty(3 * N ** 3)
+    for q in range(vals.size):
+        state = (state * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        vals[q] = (state >> 11) / 9007199254740992.0 * 2.0 - 1.0
+    init = vals.reshape(3, N, N, N)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(N, N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi),
+                            topology=("Periodic", "Periodic", "Periodic"), halo=(3, 3, 3))
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    ocn.set(m, u=init[0].T, v=init[1].T, w=init[2].T)                      # set takes [i, j, k]
+    for _ in range(steps):
+        ocn.time_step(m, dt)
+    ocn.flush_tendencies(m)
+    ocn.sync_device()
+    for f, a, name in zip(m.velocities, got, "uvw"):
+        np.testing.assert_array_equal(f.interior().T, a, err_msg=name)      # interior() is [i, j, k]
+    assert "max|div u|" in r.stdout
