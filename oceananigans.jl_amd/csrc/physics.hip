@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
 // plane (1.33x with the rim) instead of once per stencil tap (~60 taps per cell hit L2 in the direct kernel: the 3 planes x
 // 4 fields of a workgroup do not fit the 32 KB L1).  pHY′, G, G⁻ are touched once per cell and stay in global memory.
 template <int TZ>
-__global__ __launch_bounds__(256) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
+__global__ __launch_bounds__(256, 4) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
                                                             const double *__restrict__ v, const double *__restrict__ w,
                                                             double *__restrict__ Gu, double *__restrict__ Gv,
                                                             double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf, int KZ)
