@@ -490,6 +490,15 @@ def test_cell_advection_timescale_and_wizard(ocn, topo, z):
     assert ocn.cell_advection_timescale(rest) == float("inf")
 
 
+def test_advective_cfl_reference_doctest_value(ocn):
+    """A known answer the reference itself holds (jldoctest in src/Diagnostics/cfl.jl:36-49): RectilinearGrid(size = (16, 16, 16),
+    extent = (8, 8, 8)) (default topology (Periodic, Periodic, Bounded)), u .= pi, AdvectiveCFL(1.0)(model) == 6.283185307179586."""
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(16, 16, 16), x=(0, 8), y=(0, 8), z=(-8, 0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    m.u.data.fill_(np.pi)
+    assert ocn.AdvectiveCFL(1.0)(m) == 6.283185307179586
+
+
 @pytest.mark.parametrize("size,topo,z,own", [((32, 16, 12), "PPP", (0, 2.0), False), ((16, 12, 9), "PPB", "stretched", False),
                                              ((12, 9, 5), "PPP", (0, 1.0), False), ((24, 16, 1), "PPF", None, False),
                                              ((128, 64, 64), "PPP", (0, 2.0), True)])  # own solver handle: hand-written FFT pipeline
