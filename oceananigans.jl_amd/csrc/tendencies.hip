@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
 //    Patches therefore overlap by one column/row: (TX-1) x (TY-1) outputs per TX x TY threads.
 // All flux expressions are the same as in the direct kernel, so strict mode stays bit-identical to the oracle.
 // ---------------------------------------------------------------------------------------------------
-template <int TZ, int TX, int TY, int W, bool PC>
+template <int TZ, int TX, int TY, int W, bool PC, bool OB = false>
 __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
                                                                        const double *__restrict__ v,
                                                                        const double *__restrict__ w, double *__restrict__ Gu,
@@ -183,8 +183,13 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     constexpr int NRING = LX * LY - NT;         // ring cells of one tile
     constexpr int RPT = (NRING + NT - 1) / NT;  // ring cells per thread (1 or 2)
     static_assert(RPT <= 2, "tile too small for its ring");
-    __shared__ double su[LY][LX], sv[LY][LX], sw[2][LY][LX];
-    __shared__ double ex[6][NT];  // Fuu_w, Fuv, Fuw (read by the west neighbour), Fvv_s, Fvu, Fvw (by the south one)
+    // OB ("one barrier"): planes k and k+1 of u, v and k, k+1, k+2 of w are resident and the flux exchange is double-buffered, so the
+    // staging of the NEXT plane moves behind this plane's flux evaluation and shares its barrier with the flux exchange.
+    constexpr int NUV = OB ? 2 : 1, NW_ = OB ? 3 : 2, NEX = OB ? 2 : 1;
+    __shared__ double su_[NUV][LY][LX], sv_[NUV][LY][LX], sw[NW_][LY][LX];
+    __shared__ double ex_[NEX][6][NT];  // Fuu_w, Fuv, Fuw (read by the west neighbour), Fvv_s, Fvu, Fvw (by the south one)
+    auto uvslot = [](int kk) { return OB ? (kk & 1) : 0; };
+    auto wslot = [](int kk) { return OB ? (kk % 3) : (kk & 1); };
 
     Metrics M = make_metrics(g);
     if (TZ == OCN_PERIODIC) M.dzc = M.dzf = nullptr;  // a Periodic z is never stretched: lets the compiler fold the metric loads
@@ -311,16 +316,28 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     double nu[RPT], nv[RPT], nw[RPT];  // prefetched ring values: u(k), v(k), w(k+1)
     double pc_prev = 0.0, rp_prev[RPT] = {};  // PC: pressure of the previous plane at the own column / ring cells
     {
-        sw[k & 1][ly][lx] = zw[2];
+        sw[wslot(k)][ly][lx] = zw[2];
 #pragma unroll
         for (int s = 0; s < RPT; ++s)
-            if (ron[s]) sw[k & 1][rcy[s]][rcx[s]] = ring_w(s, k);
+            if (ron[s]) sw[wslot(k)][rcy[s]][rcx[s]] = ring_w(s, k);
+        if (OB) {  // plane k of u, v and plane k+1 of w as well: the loop only ever stages the NEXT plane
+            su_[uvslot(k)][ly][lx] = zu[2];
+            sv_[uvslot(k)][ly][lx] = zv[2];
+            sw[wslot(k + 1)][ly][lx] = zw[3];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) {
+                    su_[uvslot(k)][rcy[s]][rcx[s]] = ring_u(s, k);
+                    sv_[uvslot(k)][rcy[s]][rcx[s]] = ring_v(s, k);
+                    sw[wslot(k + 1)][rcy[s]][rcx[s]] = ring_w(s, k + 1);
+                }
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < RPT; ++s) {
-            nu[s] = ron[s] ? ring_u(s, k) : 0.0;
-            nv[s] = ron[s] ? ring_v(s, k) : 0.0;
-            nw[s] = ron[s] ? ring_w(s, k + 1) : 0.0;
+            nu[s] = (!OB && ron[s]) ? ring_u(s, k) : 0.0;
+            nv[s] = (!OB && ron[s]) ? ring_v(s, k) : 0.0;
+            nw[s] = (!OB && ron[s]) ? ring_w(s, k + 1) : 0.0;
         }
         if (PC) {
             pc_prev = pC[zz(k + 3)];
@@ -328,7 +345,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             for (int s = 0; s < RPT; ++s) rp_prev[s] = ron[s] ? rpc[s][zz(k + 1)] : 0.0;
         }
         const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
-        const double(*swk)[LX] = sw[k & 1];
+        const double(*swk)[LX] = sw[wslot(k)];
         {   // Fwu(k): sym x-face of Az*w at plane k ; biased z-face of u
             const double a = M.Az;
             const double wt = sym_interp_scaled<P, false>([&](int m) { return swk[ly][lx + m]; }, a, i, Nx);
@@ -350,18 +367,23 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     }
 
     for (; k <= k_end; ++k) {
-        // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident) from registers
-        su[ly][lx] = zu[2];
-        sv[ly][lx] = zv[2];
-        sw[(k + 1) & 1][ly][lx] = zw[3];
+        double(*su)[LX] = su_[uvslot(k)];
+        double(*sv)[LX] = sv_[uvslot(k)];
+        double(*ex)[NT] = ex_[uvslot(k)];
+        if (!OB) {
+            // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident) from registers
+            su[ly][lx] = zu[2];
+            sv[ly][lx] = zv[2];
+            sw[(k + 1) & 1][ly][lx] = zw[3];
 #pragma unroll
-        for (int s = 0; s < RPT; ++s)
-            if (ron[s]) {
-                su[rcy[s]][rcx[s]] = nu[s];
-                sv[rcy[s]][rcx[s]] = nv[s];
-                sw[(k + 1) & 1][rcy[s]][rcx[s]] = nw[s];
-            }
-        __syncthreads();
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) {
+                    su[rcy[s]][rcx[s]] = nu[s];
+                    sv[rcy[s]][rcx[s]] = nv[s];
+                    sw[(k + 1) & 1][rcy[s]][rcx[s]] = nw[s];
+                }
+            __syncthreads();
+        }
         // ---- prefetch what the NEXT plane needs; the loads fly under this plane's arithmetic
         double zu_n = 0, zv_n = 0, zw_n = 0;
         if (k < k_end) {
@@ -401,8 +423,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             const long long o = own0 + (long long)(k - 1) * su3;
             gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o]; gmw = fz.Gm[2][o];
         }
-        const double(*swk)[LX] = sw[k & 1];
-        const double(*swt)[LX] = sw[(k + 1) & 1];
+        const double(*swk)[LX] = sw[wslot(k)];
+        const double(*swt)[LX] = sw[wslot(k + 1)];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
 
         // ---- x-fluxes (consumed by this cell and its WEST neighbour)
@@ -444,6 +466,18 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         {   // Fww(k): line shifted to face k+1: w[k-2..k+3]
             const double wt = sym_interp_scaled<TZ, true>([&](int m) { return zw[3 + m]; }, az, k, Nz);
             fww = wt * bias_interp<TZ, true>([&](int m) { return zw[3 + m]; }, k, Nz, wt > 0);
+        }
+        if (OB && k < k_end) {  // stage plane k+1 of u, v and plane k+2 of w: their slots were last read before the previous barrier
+            su_[uvslot(k + 1)][ly][lx] = zu[3];
+            sv_[uvslot(k + 1)][ly][lx] = zv[3];
+            sw[wslot(k + 2)][ly][lx] = zw[4];
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) {
+                    su_[uvslot(k + 1)][rcy[s]][rcx[s]] = nu[s];
+                    sv_[uvslot(k + 1)][rcy[s]][rcx[s]] = nv[s];
+                    sw[wslot(k + 2)][rcy[s]][rcx[s]] = nw[s];
+                }
         }
         __syncthreads();
         if (writes) {
@@ -949,6 +983,15 @@ static int strip_min_kz()
     return v;
 }
 
+// One barrier per plane (template parameter OB of momentum_tendencies_tiled): bit 0 = the correction-on-load variant, bit 1 = the plain
+// Periodic-z one, bit 2 = Bounded z.  Measured on one box, 512^3 step: 27.21 ms without, 27.06 with bit 0, 27.33 with bit 1, 27.09 with
+// both; config 4 (bit 2) +0.45 ms.  The variant that waits for the most loads per plane is the one that gains from the missing barrier.
+static int one_barrier()
+{
+    static const int v = getenv("OCN_TEND_ONE_BARRIER") ? atoi(getenv("OCN_TEND_ONE_BARRIER")) : 1;
+    return v;
+}
+
 static int xcd_remap()
 {
     static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;  // measured: 4.72 -> 4.60 ms per 512^3 launch
@@ -1012,8 +1055,27 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
             int KZ = wz;
             while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
             dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
-            hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu,
-                               Gv, Gw, r, KZ, fz);
+            if (one_barrier() & 1)
+                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w,
+                                   Gu, Gv, Gw, r, KZ, fz);
+            else
+                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu,
+                                   Gv, Gw, r, KZ, fz);
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+        if (variant == 0 && (one_barrier() & (grid->tz == OCN_PERIODIC ? 2 : 4))) {  // the default 32 x 8 tile with one barrier per plane (see the kernel)
+            constexpr int TX = 32, TY = 8;
+            const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+            int KZ = wz;
+            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+            dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+            if (grid->tz == OCN_PERIODIC)
+                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v,
+                                   w, Gu, Gv, Gw, r, KZ, fz);
+            else
+                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, 3, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v,
+                                   w, Gu, Gv, Gw, r, KZ, fz);
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }
