@@ -385,7 +385,9 @@ def main():
         if prof is not None and world == 1:
             for k in prof["kernels"]:
                 if "momentum_tendencies_tiled" in k["name"]:
-                    kern["in_step" if k["name"].rstrip(">").endswith("true") else "plain"] = k
+                    # template arguments <TZ, TX, TY, W, PC[, OB]>: PC = pressure correction on load = the in-step variant
+                    targs = [x.strip() for x in k["name"].split("<", 1)[1].rstrip(">").split(",")] if "<" in k["name"] else []
+                    kern["in_step" if len(targs) > 4 and targs[4] == "true" else "plain"] = k
         pk = kern.get("in_step") or kern.get("plain") or {}
         ref_ms = in_step_ms if in_step_ms is not None else plain_ms
         instr = pk.get("SQ_INSTS_VALU")  # VALU wave-instructions per launch of the profiled variant (committed PMC pass)
