@@ -2,6 +2,8 @@
 for x, y regular and z regular or stretched; topologies (Periodic, Periodic, Periodic|Bounded|Flat).
 """
 import ctypes as C
+import math
+import struct
 from fractions import Fraction
 
 import numpy as np
@@ -26,6 +28,76 @@ def _exact(x):
     return Fraction(float(x))
 
 
+class _JuliaRange:
+    """range(start, stop, length = n) of Julia's Base for Float64 -- the object the reference stores as a regular coordinate
+    (`F = range(FT(F₋), FT(F₊), length = TF)`, src/Grids/grid_generation.jl:117-121): a StepRangeLen whose reference value and step are
+    double-double numbers (base/twiceprecision.jl, `_linspace`).  Its elements are what xnodes / ynodes / znodes return, and they
+    are NOT c₁ + (i - 1) Δ rounded once: the reference's own doctest prints `x ∈ [3.60072e-17, 6.28319)` for x = (0, 2π)
+    (src/Grids/rectilinear_grid.jl:176-182), which this class reproduces (tests/test_reference_fixtures.py)."""
+
+    def __init__(self, start, stop, n):
+        self.n = n
+        self.rational = None
+        if n < 2 or start == stop:
+            self.rational = [Fraction(start)] * n
+            return
+        p, q = self._rat(start), self._rat(stop)
+        if p[1] and q[1]:
+            den = p[1] * q[1] // math.gcd(p[1], q[1])
+            if abs(den * start) <= 2.0 ** 53 and abs(den * stop) <= 2.0 ** 53:
+                a, b = round(den * start), round(den * stop)
+                if a / den == start and b / den == stop:  # endpoints are exact ratios: interpolate exactly, round once
+                    self.rational = [Fraction(a * (n - i) + b * (i - 1), (n - 1) * den) for i in range(1, n + 1)]
+                    return
+        span = stop - start
+        k = round(-(start / span) * (n - 1) + 1)  # index of the element of smallest magnitude
+        if 1 < k < n:
+            t = (k - 1) / (n - 1)
+            ref = (1 - t) * start + t * stop
+            step = (ref - start) / (k - 1) if k - 1 < n - k else (stop - ref) / (n - k)
+        else:
+            k = 1 if k <= 1 else n
+            ref, step = (start, span / (n - 1)) if k == 1 else (stop, span / (n - 1))
+        bits = min(27, math.ceil(math.log2(max(k - 1, n - k))) + 1)
+        hi = struct.unpack("<d", struct.pack("<Q", struct.unpack("<Q", struct.pack("<d", step))[0] >> bits << bits))[0]
+        lo_end, hi_end = self._two_sum((1 - k) * hi, ref), self._two_sum((n - k) * hi, ref)
+        ea, eb = (start - lo_end[0]) - lo_end[1], (stop - hi_end[0]) - hi_end[1]
+        self.k, self.ref, self.step_hi = k, ref, hi
+        self.step_lo = (eb - ea) / (n - 1)
+        self.ref_lo = ea - (1 - k) * self.step_lo
+
+    @staticmethod
+    def _two_sum(x, y):
+        if abs(y) > abs(x):
+            x, y = y, x
+        h = x + y
+        return h, (x - h) + y
+
+    @staticmethod
+    def _rat(x, limit=1 << 24):
+        """Base.rat: the continued-fraction convergent of x with terms up to maxintfloat(Float32)"""
+        y, a, b, c, d = x, 1, 0, 0, 1
+        while abs(y) <= limit:
+            f = math.trunc(y)
+            y -= f
+            a, c = f * a + c, a
+            b, d = f * b + d, b
+            if max(abs(a), abs(b)) > limit:
+                return c, d
+            if y == 0 or a / b == x:
+                break
+            y = 1.0 / y
+        return a, b
+
+    def __getitem__(self, i):
+        """element i, 1-based like the reference's indices"""
+        if self.rational is not None:
+            return float(self.rational[i - 1])
+        u = i - self.k
+        hi, lo = self._two_sum(self.ref, u * self.step_hi)
+        return hi + (lo + (u * self.step_lo + self.ref_lo))
+
+
 class RectilinearGrid:
     """RectilinearGrid(arch; size, x, y, z, topology, halo).
 
@@ -33,13 +105,29 @@ class RectilinearGrid:
     2-tuple (regular) or an array of Nz+1 increasing face positions (stretched, needs Bounded z)."""
 
     def __init__(self, architecture, size, x=None, y=None, z=None, topology=(Periodic, Periodic, Bounded), halo=None,
-                 _local=False):
+                 extent=None, _local=False):
+        if extent is not None:
+            # validate_rectilinear_domain (input_validation.jl:106-131): an "oceanic" default domain x = (0, Lx), y = (0, Ly), z = (-Lz, 0)
+            if x is not None or y is not None or z is not None:
+                raise ValueError("Cannot specify both 'extent' and 'x, y, z' keyword arguments.")
+            ext_t = tuple(extent) if np.ndim(extent) else (extent,)
+            if len(ext_t) != sum(t != Flat for t in topology):
+                raise ValueError(f"extent {ext_t} must have one entry per non-Flat dimension of {tuple(topology)}")
+            it = iter(ext_t)
+            Ls = [None if t == Flat else float(next(it)) for t in topology]
+            x = None if Ls[0] is None else (0.0, Ls[0])
+            y = None if Ls[1] is None else (0.0, Ls[1])
+            z = None if Ls[2] is None else (-Ls[2], 0.0)
         if hasattr(architecture, "partition") and not _local:
             # RectilinearGrid(arch::Distributed, ...) returns the rank-local grid (distributed_grids.jl:75-118)
             from .distributed import distributed_rectilinear_grid
             g = distributed_rectilinear_grid(architecture, tuple(size), x=x, y=y, z=z, topology=tuple(topology), halo=halo)
             self.__dict__.update(g.__dict__)
+            self._ctor = dict(size=tuple(size), x=x, y=y, z=z, topology=tuple(topology))  # the GLOBAL description (with_halo)
+            self._ctor_local = False
             return
+        self._ctor = dict(size=tuple(size) if np.ndim(size) else (size,), x=x, y=y, z=z, topology=tuple(topology))
+        self._ctor_local = _local
         self.architecture = architecture
         topo = tuple(topology)
         for t in topo:
@@ -69,16 +157,19 @@ class RectilinearGrid:
         L, D = [1.0] * 3, [1.0] * 3
         self.z_faces = None
         self._dzc_host = self._dzf_host = None
-        self._origin = [0.0, 0.0, 0.0]  # left end of each regular dimension (for node coordinates)
+        self._interval = [(0.0, 1.0)] * 3  # end points of each regular dimension (for node coordinates)
+        self._ranges = {}
         for d in range(3):
             if topo[d] == Flat:
                 continue
             e = ext[d]
             if e is None:
                 raise ValueError(f"coordinate {'xyz'[d]} must be given for a non-Flat dimension")
+            if callable(e):  # a function of the face index k = 1 .. N+1 (grid_generation.jl:34-50)
+                e = np.array([float(e(k)) for k in range(1, N[d] + 2)])
             if np.ndim(e) == 1 and len(e) == 2:
                 c1, c2 = e
-                self._origin[d] = float(c1)
+                self._interval[d] = (float(c1), float(c2))
                 if not c2 > c1:
                     raise ValueError(f"{'xyz'[d]} must be an increasing interval!")
                 Lx = _exact(c2) - _exact(c1)
@@ -127,11 +218,31 @@ class RectilinearGrid:
         assert self._dzf_host.size == N + 2 * H and self._dzc_host.size == N + 2 * H
         return float(F[N] - F[0])
 
-    # -- node coordinates (grid_generation.jl:34-135: faces F[i] = c1 + (i-1) Δ, centres F[i] + Δ/2; Julia builds them as
-    #    twice-precision ranges, reproduced here by exact rational arithmetic rounded once) ----------------------------
-    def nodes_1d(self, d, face):
-        """Interior node coordinates along dimension d (0 x, 1 y, 2 z) at Face or Center location; a Face location in a
-        Bounded dimension has N+1 nodes."""
+    # -- node coordinates: the elements of the reference's coordinate ranges (grid_generation.jl:98-135) --------------------------
+    def _coordinate_range(self, d, face):
+        """F = range(FT(F₋), FT(F₊), length = TF) or C = range(FT(C₋), FT(C₊), length = TC) of a regular dimension; element
+        i + H of the range is the reference's ξ[i] (OffsetArray(F, -H))."""
+        key = (d, bool(face))
+        r = self._ranges.get(key)
+        if r is None:
+            N = (self.Nx, self.Ny, self.Nz)[d]
+            H = (self.Hx, self.Hy, self.Hz)[d]
+            bounded = self.topology[d] == Bounded
+            c1, c2 = (Fraction(v) for v in self._interval[d])
+            L = c2 - c1
+            D = L / N                                                # BigFloat arithmetic of the reference, here exact
+            Fm = c1 - H * D
+            if face:
+                lo, hi, n = Fm, Fm + (L + 2 * H * D if bounded else L + (2 * H - 1) * D), N + 2 * H + (1 if bounded else 0)
+            else:
+                lo = Fm + D / 2
+                hi, n = lo + L + D * (2 * H - 1), N + 2 * H
+            r = self._ranges[key] = _JuliaRange(float(lo), float(hi), n)
+        return r
+
+    def nodes_1d(self, d, face, with_halos=False):
+        """xnodes / ynodes / znodes(grid, ℓ; with_halos): node coordinates along dimension d (0 x, 1 y, 2 z) at Face or Center
+        location; a Face location in a Bounded dimension has N+1 interior nodes."""
         N = (self.Nx, self.Ny, self.Nz)[d]
         H = (self.Hx, self.Hy, self.Hz)[d]
         topo = self.topology[d]
@@ -139,13 +250,33 @@ class RectilinearGrid:
             return np.zeros(1)
         n = N + 1 if (face and topo == Bounded) else N
         if d == 2 and self.z_faces is not None:
-            F = np.asarray(self.z_faces)[H:H + N + 1]
+            Fall = np.asarray(self.z_faces)
+            if with_halos:
+                return Fall.copy() if face else 0.5 * (Fall[1:] + Fall[:-1])
+            F = Fall[H:H + N + 1]
             return F[:n].copy() if face else 0.5 * (F[1:] + F[:-1])
-        from fractions import Fraction
-        c1 = Fraction(self._origin[d])
-        D = Fraction((self.dx, self.dy, self.dz)[d])
-        off = Fraction(0) if face else Fraction(1, 2)
-        return np.array([float(c1 + (i + off) * D) for i in range(n)])
+        r = self._coordinate_range(d, face)
+        if with_halos:
+            return np.array([r[i] for i in range(1, r.n + 1)])
+        return np.array([r[i + H] for i in range(1, n + 1)])
+
+    def domain(self, d):
+        """x_domain / y_domain / z_domain: (ξ[1], ξ[N+1]) of the Face coordinate (grid_utils.jl:120), what `show(grid)` prints"""
+        N = (self.Nx, self.Ny, self.Nz)[d]
+        H = (self.Hx, self.Hy, self.Hz)[d]
+        if d == 2 and self.z_faces is not None:
+            F = np.asarray(self.z_faces)
+            return float(F[H]), float(F[H + N])
+        r = self._coordinate_range(d, True)
+        return r[1 + H], r[N + 1 + H]
+
+    def spacing_extrema(self, d, face=False):
+        """(min, max) of the interior cell spacings along d: `min(Δz)=…, max(Δz)=…` of the reference's `show` (Center spacings)"""
+        if d == 2 and self._dzc_host is not None:
+            a = (self._dzf_host if face else self._dzc_host)[self.Hz:self.Hz + self.Nz + (1 if face else 0)]
+            return float(a.min()), float(a.max())
+        D = (self.dx, self.dy, self.dz)[d]
+        return D, D
 
     def nodes(self, loc):
         """(x, y, z) node coordinate arrays, shaped for broadcasting over [i, j, k], of a field at bitmask `loc`."""
@@ -153,6 +284,14 @@ class RectilinearGrid:
         y = self.nodes_1d(1, loc & 2).reshape(1, -1, 1)
         z = self.nodes_1d(2, loc & 4).reshape(1, 1, -1)
         return x, y, z
+
+    def with_halo(self, new_halo):
+        """with_halo(new_halo, grid) (rectilinear_grid.jl:367-383): the same grid rebuilt with another halo; new_halo has one entry per
+        dimension (entries of Flat dimensions are ignored, like the reference's pop_flat_elements)."""
+        if self._ctor_local:
+            raise NotImplementedError("with_halo of a rank-local grid: rebuild it from the global description")
+        halo = tuple(int(h) for h, t in zip(new_halo, self.topology) if t != Flat)
+        return RectilinearGrid(self.architecture, halo=halo, **self._ctor)
 
     # -- sizes ------------------------------------------------------------------------------------
     def parent_shape(self, loc):

@@ -218,8 +218,8 @@ class HydrostaticFreeSurfaceModel:
             from .grids import Flat, RectilinearGrid
             from .solvers import FFTBasedPoissonSolver
             # FFTImplicitFreeSurfaceSolver (fft_based_implicit_free_surface_solver.jl:39-70): a Poisson solver on the horizontal grid
-            hgrid = RectilinearGrid(grid.architecture, size=(grid.Nx, grid.Ny), x=(grid._origin[0], grid._origin[0] + grid.Lx),
-                                    y=(grid._origin[1], grid._origin[1] + grid.Ly), topology=(Periodic, Periodic, Flat), halo=(grid.Hx, grid.Hy))
+            hgrid = RectilinearGrid(grid.architecture, size=(grid.Nx, grid.Ny), x=grid._interval[0],
+                                    y=grid._interval[1], topology=(Periodic, Periodic, Flat), halo=(grid.Hx, grid.Hy))
             self._fs_solver = FFTBasedPoissonSolver(hgrid)
             self._Qu, self._Qv = torch.zeros_like(self.eta), torch.zeros_like(self.eta)
             self._fs_rhs = torch.zeros((grid.Ny, grid.Nx), dtype=torch.float64, device=dev)

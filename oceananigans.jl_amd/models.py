@@ -101,11 +101,17 @@ class NonhydrostaticModel:
             for req in buoyancy.required_tracers:
                 if req not in tracers:
                     raise ValueError(f"{type(buoyancy).__name__} requires tracers {buoyancy.required_tracers}, got {tracers}")
-        # inflate_grid_halo_size (nonhydrostatic_model.jl:183, 243-257): the reference rebuilds the grid with the halo the
-        # advection scheme / closure need.  Here the user must build it so; adapt_advection_order is not supported.
-        for d, (N, H, t) in enumerate(zip(grid.size, (grid.Hx, grid.Hy, grid.Hz), grid.topology)):
-            if t != Flat and (H < advection.buffer or N < advection.buffer):
-                raise ValueError(f"{advection!r} needs halo >= {advection.buffer} and size >= {advection.buffer} in dimension {d + 1} (got N={N}, H={H})")
+        # inflate_grid_halo_size (nonhydrostatic_model.jl:183, 243-257; test_nonhydrostatic_models.jl:34-66): the model rebuilds the
+        # grid with the halo its advection scheme and closure need, never with a smaller one than the user gave.
+        # adapt_advection_order (a lower-order scheme in a direction with too few cells) is not supported: that raises.
+        required = max(advection.buffer, 1 if closure is not None else 0, 1)
+        H = (grid.Hx, grid.Hy, grid.Hz)
+        for d, (N, t) in enumerate(zip(grid.size, grid.topology)):
+            if t != Flat and N < advection.buffer:
+                raise NotImplementedError(f"{advection!r} needs size >= {advection.buffer} in dimension {d + 1} (got N={N}); "
+                                          "adapt_advection_order is not implemented")
+        if any(t != Flat and h < required for h, t in zip(H, grid.topology)):
+            grid = grid.with_halo(tuple(max(h, required) for h in H))
         self.grid = grid
         self.architecture = grid.architecture
         self.advection = advection

@@ -18,6 +18,36 @@ from . import _lib
 from .architectures import on_architecture
 
 
+def sind(x):
+    """Julia's sind (base/special/trig.jl): the argument is reduced mod 360 exactly and the result is the correctly rounded
+    sin(x π / 180) -- exactly 0, ±0.5, ±1 where they occur, which math.sin(math.radians(x)) misses (sind(30) == 0.5).
+    Used by FPlane(latitude = φ), f = 2 Ω sind(φ) (f_plane.jl:38-40; test/test_coriolis.jl:24-27 expects f = 2 from Ω = 2, φ = 30)."""
+    from decimal import Decimal, localcontext
+    from fractions import Fraction
+    r = Fraction(x) % 360
+    sign = 1.0
+    if r >= 180:
+        r, sign = r - 180, -1.0
+    if r > 90:
+        r = 180 - r
+    if r == 0:
+        return 0.0
+    if r == 30:
+        return sign * 0.5
+    if r == 90:
+        return sign
+    with localcontext() as ctx:
+        ctx.prec = 60
+        pi = Decimal("3.14159265358979323846264338327950288419716939937510582097494459230781640628620899")
+        t = Decimal(r.numerator) / Decimal(r.denominator) * pi / 180
+        term, total, n = t, t, 1
+        while abs(term) > Decimal(10) ** -58:
+            term = -term * t * t / ((2 * n) * (2 * n + 1))
+            total += term
+            n += 1
+        return sign * float(total)
+
+
 class Centered:
     """Centered(order=2)"""
 
@@ -46,7 +76,7 @@ class FPlane:
             raise ValueError("Either both keywords rotation_rate and latitude must be specified, or only f must be specified.")
         if f is None:
             rotation_rate = self.OMEGA_EARTH if rotation_rate is None else rotation_rate
-            f = 2 * rotation_rate * math.sin(math.radians(latitude))
+            f = 2 * rotation_rate * sind(latitude)
         self.f = float(f)
 
 

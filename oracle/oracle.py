@@ -99,6 +99,7 @@ class Grid:
         self.dzc = None
         self.dzf = None
         self.zf = None
+        self._interval = [None, None, None]
         for d in range(3):
             if topo[d] == FLAT:
                 continue  # Δ = L = 1 (grid_generation.jl:138-155)
@@ -110,6 +111,7 @@ class Grid:
                 raise ValueError("only z may be stretched in this restatement")
             self.L[d] = float(Fraction(float(e[1])) - Fraction(float(e[0])))
             self.d[d] = _regular_spacing(e[0], e[1], N[d])
+            self._interval[d] = (float(e[0]), float(e[1]))
         self.Lx, self.Ly, self.Lz = self.L
         self.dx, self.dy, self.dz = self.d
         self.c = _CGrid(self.Nx, self.Ny, self.Nz, self.Hx, self.Hy, self.Hz, self.tx, self.ty, self.tz,
@@ -150,6 +152,34 @@ class Grid:
             self.dzc = np.concatenate([self.dzc, self.dzc[-1:]])
         self.zf = Fall
         self.d[2] = float("nan")
+
+    def coordinate(self, d, face):
+        """The reference's coordinate array of dimension d (0 x, 1 y, 2 z) including halos, first element <-> index 1 - H:
+        F = range(FT(F₋), FT(F₊), length = TF) / C = range(FT(C₋), FT(C₊), length = TC) for a regular dimension
+        (grid_generation.jl:98-135, elements by Julia's TwicePrecision range: oracle/julia_base.py), the explicit arrays for a
+        stretched z (:34-95)."""
+        from . import julia_base
+        N, H, t = (self.Nx, self.Ny, self.Nz)[d], (self.Hx, self.Hy, self.Hz)[d], self.topo[d]
+        if d == 2 and self.zf is not None:
+            F = np.asarray(self.zf)
+            return F.copy() if face else np.array([(F[i + 1] + F[i]) / 2 for i in range(N + 2 * H)])
+        c1, c2 = (Fraction(v) for v in self._interval[d])
+        L = c2 - c1
+        D = L / N
+        Fm = c1 - H * D
+        bounded = t == BOUNDED
+        if face:
+            lo, hi, n = Fm, Fm + (L + 2 * H * D if bounded else L + (2 * H - 1) * D), N + 2 * H + (1 if bounded else 0)
+        else:
+            lo = Fm + D / 2
+            hi, n = lo + L + D * (2 * H - 1), N + 2 * H
+        return np.array(julia_base.julia_range(float(lo), float(hi), n))
+
+    def nodes(self, d, face, with_halos=False):
+        """xnodes / ynodes / znodes (nodes_and_spacings.jl)"""
+        N, H, t = (self.Nx, self.Ny, self.Nz)[d], (self.Hx, self.Hy, self.Hz)[d], self.topo[d]
+        a = self.coordinate(d, face)
+        return a if with_halos else a[H:H + N + (1 if face and t == BOUNDED else 0)]
 
     # parent extents of a field at `loc`
     def shape(self, loc):
