@@ -59,6 +59,12 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--substeps", type=int, default=30, help="config5: SplitExplicitFreeSurface(substeps = ...)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="start the --gpus N ranks, rendezvous, hand the RCCL unique id to every rank, check environment and library, "
+                         "print one JSON line and exit BEFORE any GPU call (runs on a machine without GPUs)")
+    ap.add_argument("--dist-poisson", choices=("xtri", "alltoall"), default=None,
+                    help="pressure solve of a partitioned run: xtri = transpose-free cyclic tridiagonal x solve + one all-gather (default), "
+                         "alltoall = the slab FFT pipeline with two RCCL all-to-alls per solve (north_star's pencil transpose)")
     return ap.parse_args()
 
 
@@ -77,7 +83,7 @@ def self_launch(a):
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in p.stdout.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
+        if ln.startswith("{") and ('"metric"' in ln or '"preflight"' in ln):
             line = ln
         else:
             print(ln, file=sys.stderr)
@@ -216,6 +222,75 @@ def event_time(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def preflight(a, rank, world, local_rank, stdout_fd):
+    """Everything a multi-GPU launch needs BEFORE the first GPU call, so that plumbing cannot be what fails on the 8-GPU node: the ranks
+    exist and agree on the world, the gloo rendezvous on MASTER_ADDR:MASTER_PORT works, rank 0's RCCL unique id (ncclGetUniqueId needs
+    no device) reaches every rank intact, the HIP library loads and exports the distributed entry points, the environment carries the
+    dmabuf IPC switch, LOCAL_RANK is a valid device index when devices are visible.  Touches no GPU (torch.cuda.device_count() does not
+    initialise one on this image)."""
+    import ctypes as C
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import oceananigans_jl_amd as ocn
+    checks = {}
+    lib = ocn._lib.lib()
+    need = ["ocn_comm_unique_id", "ocn_comm_init", "ocn_halo_exchange_begin", "ocn_halo_exchange_end", "ocn_halo_exchange_plane",
+            "ocn_halo_exchange_pressure", "ocn_comm_all_gather", "ocn_comm_all_to_all", "ocn_dist_poisson_create", "ocn_comm_schedule"]
+    checks["library_symbols"] = all(hasattr(lib, n) for n in need)
+    checks["ipc_mode_env"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    checks["master_addr_is_loopback_or_set"] = bool(os.environ["MASTER_ADDR"])
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    checks["world_size"] = dist.get_world_size() == world == a.gpus
+    uid = (C.c_ubyte * 128)()
+    if rank == 0:
+        ocn._lib.call("ocn_comm_unique_id", uid)
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=0)
+    digest = hashlib.sha256(box[0]).digest()
+    t = torch.tensor(list(digest), dtype=torch.int64)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    checks["unique_id_identical_on_all_ranks"] = len(box[0]) == 128 and any(box[0]) and all(bool((g == gathered[0]).all()) for g in gathered)
+    ranks = torch.zeros(world, dtype=torch.int64)
+    ranks[rank] = local_rank + 1
+    dist.all_reduce(ranks)
+    ndev = torch.cuda.device_count()
+    checks["local_rank_is_a_device"] = ndev == 0 or local_rank < ndev
+    # the neighbour schedule every rank will issue (pure host function): its sends must meet the peers' receives
+    ops = (ocn._lib.CCommOp * 8)()
+    n = C.c_int32()
+    ocn._lib.call("ocn_comm_schedule", ocn._lib.SCHED_STRIPS, rank, world, 0, ops, 8, C.byref(n))
+    mine = torch.tensor([[ops[q].is_recv, ops[q].peer, ops[q].slot] for q in range(n.value)] or [[0, 0, 0]] * 4, dtype=torch.int64)
+    allops = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allops, mine)
+    ok = True
+    if world > 1:
+        for r in range(world):
+            for is_recv, peer, slot in allops[r].tolist():
+                if not is_recv:  # my send_west (0) must be received by my west neighbour as recv_east (3), send_east (1) as recv_west (2)
+                    want = 3 if slot == 0 else 2
+                    ok &= any(ir and pr == r and sl == want for ir, pr, sl in allops[peer].tolist())
+    checks["neighbour_schedule_pairs_up"] = ok
+    all_ok = all(checks.values())
+    flag = torch.tensor([1 if all_ok else 0], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    out = {"preflight": "ok" if int(flag[0]) == 1 else "FAILED", "ranks": world, "local_ranks_seen": [int(v) - 1 for v in ranks],
+           "visible_devices": ndev, "checks_rank0": checks, "master": f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
+           "gpu_touched": False}
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    raise SystemExit(0 if int(flag[0]) == 1 else 1)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -223,11 +298,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dist_poisson is not None:
+        os.environ["OCN_DIST_POISSON_XTRI"] = "1" if a.dist_poisson == "xtri" else "0"
     # stdout carries exactly ONE line (the JSON of rank 0): RCCL and gloo print banners to the C-level stdout on initialisation, so
     # file descriptor 1 points at stderr until the result is ready
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
+    if a.preflight:
+        preflight(a, rank, world, local_rank, stdout_fd)
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
     import numpy as np
@@ -251,10 +330,19 @@ def main():
         arch = ocn.GPU()
     two_pi = 2 * np.pi
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
+    field_counter = [0]
 
     def rand(shape):
-        return torch.rand(shape, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        """U(-1, 1) values of this rank's slab of a GLOBAL synthetic field that does not depend on the number of ranks (the n-th field
+        of a run is seeded 1234 + n and generated at its global extent, every rank keeps its x range): the checksum the line reports
+        is then comparable between --gpus 1 and --gpus N."""
+        gen.manual_seed(1234 + field_counter[0])
+        field_counter[0] += 1
+        nz_, ny_, nx_ = shape
+        full = torch.rand((nz_, ny_, nx_ * world), generator=gen, device="cuda", dtype=torch.float64)
+        out = (full[:, :, rank * nx_:(rank + 1) * nx_] * 2 - 1).contiguous()
+        del full
+        return out
 
     hydro = a.workload == "config5"
     if a.workload == "config4":
@@ -271,7 +359,7 @@ def main():
                                         boundary_conditions=bcs)
         zc = torch.from_numpy(0.5 * (zf[1:] + zf[:-1])).to("cuda")
         T = model.field("T").interior_view()
-        T.copy_(20 + C4["dTdz"] * zc[:, None, None] + 1e-6 * torch.rand(T.shape, generator=gen, device="cuda", dtype=torch.float64))
+        T.copy_(20 + C4["dTdz"] * zc[:, None, None] + 0.5e-6 * (rand(T.shape) + 1))
         model.field("S").interior_view().fill_(35.0)
         amp, dmin = 1e-2, float(np.diff(zf).min())
     elif hydro:
@@ -340,6 +428,13 @@ def main():
     if dist is not None:
         el = float(dist.allreduce_max(torch.tensor([el], device="cuda", dtype=torch.float64))[0])
     finite = bool(all(torch.isfinite(f.data).all() for f in prognostic))
+    # state checksum after warm-up + timed steps: sum of squares of every prognostic field over the global interior.  The synthetic
+    # initial fields do not depend on the number of ranks, so a --gpus N line can be checked against the --gpus 1 line of the same
+    # command (agreement to ~1e-9 relative: the pressure solvers of the two paths differ in rounding).
+    sums = torch.stack([(f.interior_view() ** 2).sum() for f in prognostic])
+    if dist is not None:
+        sums = dist.allreduce_sum(sums) if hasattr(dist, "allreduce_sum") else sums
+    checksum = [float(v) for v in sums]
 
     # the bit-exact (strict IEEE, reference operand order) build of the same step, driver-visible
     strict_ms = None
@@ -476,7 +571,10 @@ def main():
         "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "grid": [Nx, Nx if hydro else N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}",
-                   "finite": finite, "rccl": comm_info, "dist_pressure_pipeline": pipeline},
+                   "finite": finite, "rccl": comm_info, "dist_pressure_pipeline": pipeline,
+                   "state_checksum": {"sum_of_squares": checksum, "fields": "prognostic fields in model order, global interior",
+                                      "after_steps": a.warmup + a.steps,
+                                      "comparable_across_n_gpus": True}},
         "strict_ms_per_step": strict_ms,
         "roofline": roofline,
         "step_roofline": step_roofline,

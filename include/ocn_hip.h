@@ -127,8 +127,9 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
  * p_correct != NULL additionally folds the PREVIOUS stage's _pressure_correct_velocities! (pressure_correction.jl:31-37)
  * into the loads: every velocity value is read as  u - ((p[i]-p[i-1])/dx)*dt_correct  (v, w alike) with periodically
  * wrapped indices, so (u, v, w) are the *uncorrected* fields with valid halos and p needs no halos.
- * (Periodic, Periodic, Periodic) single-rank grids with an interior of at least 16 x 8 x 4 and range = NULL only;
- * otherwise OCN_ERR_UNSUPPORTED. */
+ * (Periodic, Periodic, Periodic) grids with an interior of at least 16 x 8 x 4 and range = NULL only; otherwise
+ * OCN_ERR_UNSUPPORTED.  On a (FullyConnected, Periodic, Periodic) local grid of a slab-x run the x indices are not wrapped: p must
+ * hold the neighbours' planes in its x halos and u[1 - Hx] must already be corrected (ocn_halo_exchange_pressure). */
 int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                         double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
@@ -452,6 +453,18 @@ int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const do
  * synchronous halo fills (pressure_correction.jl:10-17) then move one plane instead of 2 Hx per field; the complete fill of
  * the same fields follows in update_state!. */
 int ocn_halo_plane_x(const ocn_grid *grid, double *field, int32_t loc, int32_t which, double *buffer, int32_t unpack, void *stream);
+/* x-halo payload of the correction-on-load stage of a slab-x rank (no reference counterpart; results identical to
+ * fill_halo_regions!(pNHS) + pressure_correct_velocities! + fill_halo_regions!(velocities), pressure_correction.jl:8-50 and
+ * update_nonhydrostatic_model_state.jl:33-37).  After solve_for_pressure! the rank sends, per x neighbour, ONE message of
+ * (Hx + 1) values per row of the (y, z) cross-section: the Hx pressure planes next to the interface and -- eastwards only -- the u plane
+ * i = nx - Hx + 1 with the pressure correction of this stage already applied (the receiver's westmost halo column of u, whose
+ * correction would need p[-Hx]).  ocn_compute_momentum_tendencies_rk3 with p_correct on a FullyConnected x then corrects everything
+ * else on load.  pack: send buffers of (Hx + 1) * sy * sz doubles each; unpack: the neighbour's send_east arrives as recv_west and
+ * vice versa.  (Periodic y, z; nx >= Hx + 1.)  u is the UNCORRECTED u* of this stage with its x halos already exchanged. */
+int ocn_halo_pack_pressure(const ocn_grid *grid, const double *p, const double *u, double dt_correct, double *send_west,
+                           double *send_east, void *stream);
+int ocn_halo_unpack_pressure(const ocn_grid *grid, double *p, double *u, const double *recv_west, const double *recv_east,
+                             void *stream);
 /* The same for a tuple of fields in one launch: the strips of the fields follow one another in the buffers (field q starts at
  * Hx * sum_{r<q} sy_r sz_r), so the exchange is one message per neighbour for the whole tuple
  * (fill_halo_regions! of a tuple, src/DistributedComputations/halo_communication.jl:95-128). */
@@ -516,6 +529,24 @@ int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *p, void *str
  *      no call blocks the host except ocn_comm_barrier. ---- */
 typedef void *ocn_comm_t;
 #define OCN_COMM_UNIQUE_ID_BYTES 128
+#define OCN_COMM_MAX_RANKS 64
+/* The point-to-point schedule a rank issues inside ONE RCCL group, as a pure host function (no device, no communicator): what
+ * ocn_halo_exchange_begin / ocn_comm_exchange_strips (OCN_SCHED_STRIPS: slots 0 send_west, 1 send_east, 2 recv_west, 3 recv_east),
+ * ocn_halo_exchange_plane (OCN_SCHED_PLANE_EAST / _WEST: slot 0 send, 1 recv) and ocn_comm_all_to_all (OCN_SCHED_ALL_TO_ALL: slot =
+ * chunk index) execute, in issue order.  RCCL pairs the k-th send of rank a to rank b with the k-th receive of b from a; the test
+ * suite replays the schedules of all ranks for R = 1, 2, 3, 8 and checks every pairing (the MPI tags of
+ * halo_communication.jl:100-150 do this job in the reference).  self_via_rccl: a rank's transfers to itself are sends too. */
+#define OCN_SCHED_STRIPS 0
+#define OCN_SCHED_PLANE_EAST 1
+#define OCN_SCHED_PLANE_WEST 2
+#define OCN_SCHED_ALL_TO_ALL 3
+typedef struct ocn_comm_op {
+    int32_t is_recv; /* 0 send, 1 receive */
+    int32_t peer;    /* rank */
+    int32_t slot;    /* which buffer (see above) */
+} ocn_comm_op;
+int ocn_comm_schedule(int32_t kind, int32_t rank, int32_t nranks, int32_t self_via_rccl, ocn_comm_op *ops, int32_t capacity,
+                      int32_t *n_ops);
 int ocn_comm_unique_id(void *id_out);                       /* rank 0: ncclGetUniqueId -> 128 bytes for every rank */
 int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *unique_id); /* on the current device; collective */
 int ocn_comm_destroy(ocn_comm_t comm);
@@ -530,6 +561,9 @@ int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const
 int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
 /* one x plane from a neighbour, in stream order (side 0: field[nx+1] <- east neighbour's field[1]; 1: field[0] <- west's field[nx]) */
 int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field, int32_t loc, int32_t side, void *stream);
+/* ocn_halo_pack_pressure -> one grouped send / recv per neighbour -> ocn_halo_unpack_pressure, in stream order on `stream` (it sits
+ * on the critical path between the pressure solve and the tendency launch that corrects on load) */
+int ocn_halo_exchange_pressure(ocn_comm_t comm, const ocn_grid *grid, double *p, double *u, double dt_correct, void *stream);
 /* one contiguous strip per x neighbour, in stream order: send_west -> rank - 1 (arrives as its recv_east), send_east -> rank + 1 */
 int ocn_comm_exchange_strips(ocn_comm_t comm, const double *send_west, const double *send_east, double *recv_west, double *recv_east,
                              size_t count, void *stream);

@@ -45,6 +45,12 @@ class CFieldBcs(C.Structure):
     _fields_ = [(n, CBc) for n in ("west", "east", "south", "north", "bottom", "top")]
 
 
+class CCommOp(C.Structure):
+    """struct ocn_comm_op"""
+    _fields_ = [("is_recv", C.c_int32), ("peer", C.c_int32), ("slot", C.c_int32)]
+
+
+SCHED_STRIPS, SCHED_PLANE_EAST, SCHED_PLANE_WEST, SCHED_ALL_TO_ALL = 0, 1, 2, 3
 ADVECTION_WENO5, ADVECTION_CENTERED2, ADVECTION_UPWIND5 = 0, 1, 2
 BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_SEAWATER_TS, BUOYANCY_SEAWATER_T, BUOYANCY_SEAWATER_S = 0, 1, 2, 3, 4
 BC_DEFAULT, BC_FLUX, BC_VALUE, BC_GRADIENT = 0, 1, 2, 3
@@ -126,6 +132,9 @@ _SIGS = {
     "ocn_rk3_driver_flush": [_vp, _vp],
     "ocn_rk3_driver_fields": [_vp] + [C.POINTER(_vp)] * 6,
     "ocn_halo_plane_x": [C.POINTER(CGrid), _vp, _i32, _i32, _vp, _i32, _vp],
+    "ocn_halo_pack_pressure": [C.POINTER(CGrid), _vp, _vp, _dbl, _vp, _vp, _vp],
+    "ocn_halo_unpack_pressure": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
+    "ocn_halo_exchange_pressure": [_vp, C.POINTER(CGrid), _vp, _vp, _dbl, _vp],
     "ocn_halo_pack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],
     "ocn_halo_unpack_x_fields": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp, _vp, _vp],
     "ocn_transpose_pack_y_to_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
@@ -142,6 +151,7 @@ _SIGS = {
     "ocn_dist_poisson_forward_yz": [_vp, _vp],
     "ocn_dist_poisson_solve_x": [_vp, _vp],
     "ocn_dist_poisson_backward_yz": [_vp, _vp, _vp],
+    "ocn_comm_schedule": [_i32, _i32, _i32, _i32, C.POINTER(CCommOp), _i32, C.POINTER(_i32)],
     "ocn_comm_unique_id": [_vp],
     "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
     "ocn_comm_destroy": [_vp],

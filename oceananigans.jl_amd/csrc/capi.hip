@@ -897,6 +897,31 @@ int ocn_halo_plane_x(const ocn_grid *grid, double *field, int32_t loc, int32_t w
     OCN_REQUIRE(grid->Hx >= 1, "ocn_halo_plane_x: needs an x halo");
     return launch_halo_plane_x(grid, field, loc, which, buffer, unpack ? 1 : 0, as_stream(stream));
 }
+static int validate_pressure_planes(const ocn_grid *grid, const char *who)
+{
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC, "%s: y and z must be Periodic", who);
+    OCN_REQUIRE(grid->Hx >= 1 && grid->Nx >= grid->Hx + 1, "%s: needs nx >= Hx + 1 (got nx = %d, Hx = %d)", who, grid->Nx, grid->Hx);
+    return OCN_SUCCESS;
+}
+int ocn_halo_pack_pressure(const ocn_grid *grid, const double *p, const double *u, double dt_correct, double *send_west,
+                           double *send_east, void *stream)
+{
+    int st = validate_pressure_planes(grid, "ocn_halo_pack_pressure");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(p && u && send_west && send_east, "ocn_halo_pack_pressure: null pointer");
+    if (g_math_mode == OCN_MATH_STRICT)
+        return ocn_strict::launch_pressure_planes(grid, const_cast<double *>(p), const_cast<double *>(u), dt_correct, send_west, send_east, 0, as_stream(stream));
+    return ocn_fast::launch_pressure_planes(grid, const_cast<double *>(p), const_cast<double *>(u), dt_correct, send_west, send_east, 0, as_stream(stream));
+}
+int ocn_halo_unpack_pressure(const ocn_grid *grid, double *p, double *u, const double *recv_west, const double *recv_east, void *stream)
+{
+    int st = validate_pressure_planes(grid, "ocn_halo_unpack_pressure");
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(p && u && recv_west && recv_east, "ocn_halo_unpack_pressure: null pointer");
+    return ocn_strict::launch_pressure_planes(grid, p, u, 0.0, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
+}
 int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, double *send_west,
                            double *send_east, void *stream)
 {

@@ -35,6 +35,15 @@ using namespace ocn;
 
 namespace {
 
+// An open ncclGroupStart() must be closed on EVERY path: an early return from inside the group would leave it open, every later NCCL
+// call of the thread would be queued into it and never launched, and the caller would hang instead of seeing OCN_ERR_COMM.
+struct NcclGroup {
+    bool open = false;
+    ncclResult_t start() { ncclResult_t r = ncclGroupStart(); open = (r == ncclSuccess); return r; }
+    ncclResult_t end() { open = false; return ncclGroupEnd(); }
+    ~NcclGroup() { if (open) (void)ncclGroupEnd(); }
+};
+
 struct Comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, west = 0, east = 0;
@@ -44,6 +53,8 @@ struct Comm {
     size_t cap = 0;                          // doubles per buffer
     double *plane[2] = {nullptr, nullptr};   // one-plane exchange: send, recv
     size_t plane_cap = 0;
+    double *pbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // pressure-plane exchange: send west, send east, recv west, recv east
+    size_t pcap = 0;
     bool pending = false;
     size_t pending_count = 0;
     bool self_via_rccl = false;  // OCN_COMM_SELF_VIA_RCCL=1: a rank's transfers to itself go through ncclSend / ncclRecv too (tests)
@@ -86,6 +97,60 @@ int make_tuple(const ocn_grid *grid, double *const *fields, const int32_t *locs,
     return OCN_SUCCESS;
 }
 
+// ---- the send / recv schedules as PURE HOST FUNCTIONS (ocn_comm_schedule exports them; tests/test_comm_schedule.py simulates every
+// rank of R = 1, 2, 3, 8 and checks that the k-th send of rank a to rank b meets the k-th receive of b from a, with the buffers the
+// choreography means).  RCCL matches point-to-point operations of one group per (sender, receiver) pair in issue order.
+//   kind OCN_SCHED_STRIPS: slots 0 send_west, 1 send_east, 2 recv_west, 3 recv_east.  My west strip becomes the west neighbour's east
+//     halo and vice versa.  When both neighbours are the same peer (R = 2) or myself (R = 1) the receives are posted in the order
+//     (from east, from west) so that they pair up with that peer's (west, east) sends.
+//   kind OCN_SCHED_PLANE_EAST / _WEST: slot 0 send, 1 recv.  The plane I need from the east is my east neighbour's WEST interior plane.
+//   kind OCN_SCHED_ALL_TO_ALL: slot = chunk index d (send chunk d to rank d, receive chunk d from rank d).
+int build_schedule(int kind, int rank, int nranks, bool self_via_rccl, ocn_comm_op *ops, int cap, int *n)
+{
+    const int west = (rank + nranks - 1) % nranks, east = (rank + 1) % nranks;
+    int m = 0;
+    auto push = [&](int is_recv, int peer, int slot) {
+        if (m < cap) ops[m] = ocn_comm_op{is_recv, peer, slot};
+        ++m;
+    };
+    switch (kind) {
+        case OCN_SCHED_STRIPS:
+            if (nranks == 1 && !self_via_rccl) break;  // device copies
+            push(0, west, 0);
+            push(0, east, 1);
+            if (nranks > 2) { push(1, west, 2); push(1, east, 3); }
+            else            { push(1, east, 3); push(1, west, 2); }
+            break;
+        case OCN_SCHED_PLANE_EAST:
+        case OCN_SCHED_PLANE_WEST: {
+            if (nranks == 1 && !self_via_rccl) break;
+            const bool e = kind == OCN_SCHED_PLANE_EAST;
+            push(0, e ? west : east, 0);
+            push(1, e ? east : west, 1);
+            break;
+        }
+        case OCN_SCHED_ALL_TO_ALL:
+            for (int d = 0; d < nranks; ++d) {
+                if (d == rank && !self_via_rccl) continue;  // own chunk: a device copy
+                push(0, d, d);
+                push(1, d, d);
+            }
+            break;
+        default:
+            ocn::set_error("ocn_comm_schedule: unknown kind %d", kind);
+            return OCN_ERR_INVALID_ARGUMENT;
+    }
+    *n = m;
+    if (m > cap) {
+        ocn::set_error("ocn_comm_schedule: %d operations do not fit the capacity %d", m, cap);
+        return OCN_ERR_INVALID_ARGUMENT;
+    }
+    return OCN_SUCCESS;
+}
+
+// issue a schedule inside ONE group on `stream`; send[slot] / recv[slot] give the buffer of a slot, `count` doubles each
+int run_schedule(Comm *c, int kind, const double *const *send, double *const *recv, size_t count, hipStream_t stream);
+
 // grouped exchange with the two x neighbours on the communication stream.  My west strip becomes the west neighbour's east halo
 // and vice versa.  When both neighbours are the same peer (R = 2) or myself (R = 1) the receives are posted in the order
 // (from east, from west) so that they pair up with that peer's (west, east) sends.
@@ -98,23 +163,44 @@ int post_exchange(Comm *c, const double *sw, const double *se, double *rw, doubl
         OCN_CHECK_HIP(hipMemcpyAsync(rw, se, count * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return OCN_SUCCESS;
     }
-    OCN_CHECK_NCCL(ncclGroupStart());
-    OCN_CHECK_NCCL(ncclSend(sw, count, ncclDouble, c->west, c->comm, c->stream));
-    OCN_CHECK_NCCL(ncclSend(se, count, ncclDouble, c->east, c->comm, c->stream));
-    if (c->nranks > 2) {
-        OCN_CHECK_NCCL(ncclRecv(rw, count, ncclDouble, c->west, c->comm, c->stream));
-        OCN_CHECK_NCCL(ncclRecv(re, count, ncclDouble, c->east, c->comm, c->stream));
-    } else {
-        OCN_CHECK_NCCL(ncclRecv(re, count, ncclDouble, c->east, c->comm, c->stream));
-        OCN_CHECK_NCCL(ncclRecv(rw, count, ncclDouble, c->west, c->comm, c->stream));
+    const double *snd[4] = {sw, se, nullptr, nullptr};
+    double *rcv[4] = {nullptr, nullptr, rw, re};
+    return run_schedule(c, OCN_SCHED_STRIPS, snd, rcv, count, c->stream);
+}
+
+int run_schedule(Comm *c, int kind, const double *const *send, double *const *recv, size_t count, hipStream_t stream)
+{
+    ocn_comm_op ops[2 * OCN_COMM_MAX_RANKS];
+    int n = 0;
+    int st = build_schedule(kind, c->rank, c->nranks, c->self_via_rccl, ops, 2 * OCN_COMM_MAX_RANKS, &n);
+    if (st != OCN_SUCCESS) return st;
+    if (n == 0) return OCN_SUCCESS;
+    NcclGroup group;
+    OCN_CHECK_NCCL(group.start());
+    for (int q = 0; q < n; ++q) {
+        if (ops[q].is_recv)
+            OCN_CHECK_NCCL(ncclRecv(recv[ops[q].slot], count, ncclDouble, ops[q].peer, c->comm, stream));
+        else
+            OCN_CHECK_NCCL(ncclSend(send[ops[q].slot], count, ncclDouble, ops[q].peer, c->comm, stream));
     }
-    OCN_CHECK_NCCL(ncclGroupEnd());
+    OCN_CHECK_NCCL(group.end());
     return OCN_SUCCESS;
 }
 
 }  // namespace
 
 extern "C" {
+
+int ocn_comm_schedule(int32_t kind, int32_t rank, int32_t nranks, int32_t self_via_rccl, ocn_comm_op *ops, int32_t capacity, int32_t *n_ops)
+{
+    OCN_REQUIRE(ops && n_ops && capacity >= 0, "ocn_comm_schedule: null pointer");
+    OCN_REQUIRE(nranks >= 1 && nranks <= OCN_COMM_MAX_RANKS && rank >= 0 && rank < nranks, "ocn_comm_schedule: rank %d of %d (at most %d ranks)",
+                rank, nranks, OCN_COMM_MAX_RANKS);
+    int n = 0;
+    int st = build_schedule(kind, rank, nranks, self_via_rccl != 0, ops, capacity, &n);
+    *n_ops = n;
+    return st;
+}
 
 int ocn_comm_unique_id(void *id_out)
 {
@@ -165,6 +251,8 @@ int ocn_comm_destroy(ocn_comm_t comm)
     for (double *b : c->buf)
         if (b) (void)hipFree(b);
     for (double *b : c->plane)
+        if (b) (void)hipFree(b);
+    for (double *b : c->pbuf)
         if (b) (void)hipFree(b);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
@@ -226,8 +314,9 @@ int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *
     OCN_REQUIRE(strip_doubles(grid, locs, n) == c->pending_count, "ocn_halo_exchange_end: not the tuple the exchange was started with");
     hipStream_t s = as_stream(stream);
     OCN_CHECK_HIP(hipStreamWaitEvent(s, c->done, 0));
-    c->pending = false;
-    return launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], 1, s);
+    st = launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], 1, s);
+    if (st == OCN_SUCCESS) c->pending = false;  // a failed unpack leaves the exchange pending: the caller may call _end again
+    return st;
 }
 
 // ONE x-plane of `field` from a neighbour (the two synchronous fills inside the pressure projection, pressure_correction.jl:10-17,
@@ -258,11 +347,39 @@ int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field
     if (st != OCN_SUCCESS) return st;
     if (c->nranks == 1 && !c->self_via_rccl)
         return launch_halo_plane_x(grid, field, loc, east ? 1 : 0, c->plane[0], 1, s);  // my own plane is the neighbour's
-    OCN_CHECK_NCCL(ncclGroupStart());
-    OCN_CHECK_NCCL(ncclSend(c->plane[0], count, ncclDouble, east ? c->west : c->east, c->comm, s));
-    OCN_CHECK_NCCL(ncclRecv(c->plane[1], count, ncclDouble, east ? c->east : c->west, c->comm, s));
-    OCN_CHECK_NCCL(ncclGroupEnd());
+    {
+        const double *snd[2] = {c->plane[0], nullptr};
+        double *rcv[2] = {nullptr, c->plane[1]};
+        st = run_schedule(c, east ? OCN_SCHED_PLANE_EAST : OCN_SCHED_PLANE_WEST, snd, rcv, count, s);
+        if (st != OCN_SUCCESS) return st;
+    }
     return launch_halo_plane_x(grid, field, loc, east ? 1 : 0, c->plane[1], 1, s);
+}
+
+// The x-halo payload of the correction-on-load stage (ocn_halo_pack_pressure / _unpack_pressure, capi.hip): in stream order on
+// `stream`, own buffers (a strip exchange of the velocities may have been received into buf[] just before).
+int ocn_halo_exchange_pressure(ocn_comm_t comm, const ocn_grid *grid, double *p, double *u, double dt_correct, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && p && u, "ocn_halo_exchange_pressure: null pointer");
+    OCN_REQUIRE(!c->pending, "ocn_halo_exchange_pressure: a strip exchange is in flight (its unpack would overwrite the corrected u plane)");
+    OCN_REQUIRE(grid != nullptr, "ocn_halo_exchange_pressure: null grid");
+    GridDev g = to_dev(*grid);
+    Lay L = make_lay(g, OCN_LOC_CCC);
+    const size_t count = (size_t)L.sy * L.sz * (g.Hx + 1);
+    if (count > c->pcap) {
+        for (double *&b : c->pbuf) {
+            if (b) OCN_CHECK_HIP(hipFree(b));
+            b = nullptr;
+            OCN_CHECK_HIP(hipMalloc(&b, count * sizeof(double)));
+        }
+        c->pcap = count;
+    }
+    int st = ocn_halo_pack_pressure(grid, p, u, dt_correct, c->pbuf[0], c->pbuf[1], stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_comm_exchange_strips(comm, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], count, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_halo_unpack_pressure(grid, p, u, c->pbuf[2], c->pbuf[3], stream);
 }
 
 // one strip per x neighbour in stream order (the wide halos of the split-explicit substepping, ocn_split_explicit_dist_*)
@@ -292,14 +409,14 @@ int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_
         OCN_CHECK_HIP(hipMemcpyAsync(recv + (size_t)c->rank * count, send + (size_t)c->rank * count, count * sizeof(double),
                                      hipMemcpyDeviceToDevice, s));
     if (c->nranks == 1 && !c->self_via_rccl) return OCN_SUCCESS;
-    OCN_CHECK_NCCL(ncclGroupStart());
+    OCN_REQUIRE(c->nranks <= OCN_COMM_MAX_RANKS, "ocn_comm_all_to_all: at most %d ranks", OCN_COMM_MAX_RANKS);
+    const double *snd[OCN_COMM_MAX_RANKS];
+    double *rcv[OCN_COMM_MAX_RANKS];
     for (int d = 0; d < c->nranks; ++d) {
-        if (d == c->rank && !c->self_via_rccl) continue;
-        OCN_CHECK_NCCL(ncclSend(send + (size_t)d * count, count, ncclDouble, d, c->comm, s));
-        OCN_CHECK_NCCL(ncclRecv(recv + (size_t)d * count, count, ncclDouble, d, c->comm, s));
+        snd[d] = send + (size_t)d * count;
+        rcv[d] = recv + (size_t)d * count;
     }
-    OCN_CHECK_NCCL(ncclGroupEnd());
-    return OCN_SUCCESS;
+    return run_schedule(c, OCN_SCHED_ALL_TO_ALL, snd, rcv, count, s);
 }
 
 // MPI.Allgather with equal counts: chunk s of `recv` is rank s's `send` (count doubles each).  In stream order on `stream`.

@@ -91,6 +91,9 @@ struct FuseArgs {
     const double *pc_p;
     double pc_dt;
     int pc_on;
+    // x-partitioned (FullyConnected) local grid: the x indices of p are NOT wrapped -- the x halos of p hold the neighbours' planes
+    // (ocn_halo_exchange_pressure) and the westmost halo column of u, whose correction would need p[-Hx], arrives corrected
+    int pc_xhalo;
 };
 
 // device-side copy of ocn_model_terms (physics.hip)

@@ -114,6 +114,7 @@ int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src,
 }  // namespace ocn
 
 namespace ocn_strict {
+int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
@@ -139,6 +140,7 @@ int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, con
                            double *kappa_e, hipStream_t stream);
 }
 namespace ocn_fast {
+int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,

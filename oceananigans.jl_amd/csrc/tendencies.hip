@@ -221,12 +221,15 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     // PC: the previous stage's pressure correction is applied on load (indices wrap periodically, so neither the
     // pressure halos nor re-filled velocity halos are needed): same expression as pressure_correct_kernel.
     auto wrp = [](int q, int N) { return q < 1 ? q + N : (q > N ? q - N : q); };
+    // x of a rank-local slab (fz.pc_xhalo): p has its neighbours' planes in its x halos, nothing wraps
+    const bool xhalo = PC && fz.pc_xhalo;
+    auto wrx = [&](int q) { return xhalo ? q : (q < 1 ? q + Nx : (q > Nx ? q - Nx : q)); };
     const double *pC = nullptr, *pWn = nullptr, *pSn = nullptr;  // p columns at (i,j), (i-1,j), (i,j-1)
     if (PC) {
         const Lay &Lp = L0;
-        pC = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j, Ny), 1);
-        pWn = fz.pc_p + ocn::at(Lp, wrp(i - 1, Nx), wrp(j, Ny), 1);
-        pSn = fz.pc_p + ocn::at(Lp, wrp(i, Nx), wrp(j - 1, Ny), 1);
+        pC = fz.pc_p + ocn::at(Lp, wrx(i), wrp(j, Ny), 1);
+        pWn = fz.pc_p + ocn::at(Lp, wrx(i - 1), wrp(j, Ny), 1);
+        pSn = fz.pc_p + ocn::at(Lp, wrx(i), wrp(j - 1, Ny), 1);
     }
     const double pcdt = fz.pc_dt;
 #if OCN_STRICT
@@ -281,9 +284,10 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         roff[s] = ocn::at(L0, gi, gj, 1);
         if (PC) {
             const Lay &Lp = L0;
-            rpc[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj, Ny), 1);
-            rpw[s] = fz.pc_p + ocn::at(Lp, wrp(gi - 1, Nx), wrp(gj, Ny), 1);
-            rps[s] = fz.pc_p + ocn::at(Lp, wrp(gi, Nx), wrp(gj - 1, Ny), 1);
+            rpc[s] = fz.pc_p + ocn::at(Lp, wrx(gi), wrp(gj, Ny), 1);
+            // the westmost halo column of u on a slab (gi = 1 - Hx) was corrected by its owner (p[-Hx] is not here): zero gradient
+            rpw[s] = (xhalo && gi - 1 < 1 - g.Hx) ? rpc[s] : fz.pc_p + ocn::at(Lp, wrx(gi - 1), wrp(gj, Ny), 1);
+            rps[s] = fz.pc_p + ocn::at(Lp, wrx(gi), wrp(gj - 1, Ny), 1);
         }
     }
     auto ring_u = [&](int s, int kk) {
@@ -962,6 +966,65 @@ __global__ __launch_bounds__(TX *TY) void tracer_pair_tendency_tiled(GridDev g, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// x-halo payload of the correction-on-load stage of a slab-x rank (distributed runs; momentum_tendencies_tiled with fz.pc_xhalo).
+// After the pressure solve a rank needs, besides its own p[1..nx], the neighbours' pressure planes in p's x halos, and -- because
+// the correction of u at the westmost halo column i = 1 - Hx would read p[-Hx], which no array holds -- that ONE u plane already
+// corrected by its owner:   u[1-Hx] <- west neighbour's  u[nx-Hx+1] - ((p[nx-Hx+1] - p[nx-Hx]) / dx) dt,
+// the expression of _pressure_correct_velocities! (pressure_correction.jl:31-37) in this build's arithmetic (same macro as the
+// on-load correction), evaluated at every row of the cross-section with periodically wrapped (j, k): a halo row of u* is the copy of
+// an interior row, so its corrected value is that row's.
+//   buffers: (Hx + 1) values per row;  pack:  west[h] = p[1 + h],  east[h] = p[nx - Hx + 1 + h]  (h < Hx),  east[Hx] = corrected u
+//   unpack:  p[1 - Hx + h] = west[h], u[1 - Hx] = west[Hx]  (from the west neighbour's `east`);  p[nx + 1 + h] = east[h]
+__global__ void pressure_planes_kernel(GridDev g, double *__restrict__ p, double *__restrict__ u, double pcdt, double *__restrict__ west,
+                                       double *__restrict__ east, int unpack)
+{
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const int Hx = g.Hx, nx = g.Nx, W = Hx + 1;
+    const long long rows = (long long)L.sy * L.sz;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * W) return;
+    const int h = t % W;
+    const long long row = t / W;
+    double *prow = p + row * L.sx, *urow = u + row * L.sx;
+    if (unpack) {
+        if (h < Hx) {
+            prow[h] = west[t];
+            prow[nx + Hx + h] = east[t];
+        } else {
+            urow[0] = west[t];
+        }
+        return;
+    }
+    if (h < Hx) {
+        west[t] = prow[Hx + h];
+        east[t] = prow[nx + h];
+        return;
+    }
+    // the corrected u plane, p taken at the periodically wrapped interior row
+    const int jp = row % L.sy, kp = row / L.sy;
+    int j = jp - g.Hy + 1, k = kp - g.Hz + 1;
+    j = j < 1 ? j + g.Ny : (j > g.Ny ? j - g.Ny : j);
+    k = k < 1 ? k + g.Nz : (k > g.Nz ? k - g.Nz : k);
+    const double *pw = p + ocn::at(L, nx - Hx + 1, j, k);
+#if OCN_STRICT
+    const double grad = (pw[0] - pw[-1]) / g.dx;
+#else
+    const double grad = (pw[0] - pw[-1]) * (1.0 / g.dx);
+#endif
+    west[t] = 0.0;
+    east[t] = urow[nx] - grad * pcdt;
+}
+int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream)
+{
+    GridDev g = ocn::to_dev(*grid);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const long long n = (long long)L.sy * L.sz * (g.Hx + 1);
+    hipLaunchKernelGGL(pressure_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, p, u, dt, west, east, unpack);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 static int tile_variant()
 {
     const char *e = getenv("OCN_TILE");
@@ -996,6 +1059,33 @@ static int xcd_remap()
 {
     static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;  // measured: 4.72 -> 4.60 ms per 512^3 launch
     return v;
+}
+
+// lanes a tiling spends per owned column: (TX x TY threads per patch) x patches / columns
+static double lanes_per_column(int TX, int TY, int wx, int wy)
+{
+    const double patches = (double)((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+    return patches * (double)(((TX * TY + 63) / 64) * 64) / ((double)wx * wy);
+}
+// 17 x 15 instead of 32 x 8 patches when they waste clearly fewer lanes (their 136-byte rows coalesce worse: measured 2.5 % slower
+// than 32 x 8 at equal useful-lane count with 16 x 16 patches).  OCN_NARROW_TILE = 0 / 1 forces the choice.
+static bool narrow_tile(int wx, int wy)
+{
+    static const int force = getenv("OCN_NARROW_TILE") ? atoi(getenv("OCN_NARROW_TILE")) : -1;
+    if (wx < 16 || wy < 14) return false;
+    if (force >= 0) return force != 0;
+    return lanes_per_column(17, 15, wx, wy) * 1.08 < lanes_per_column(32, 8, wx, wy);
+}
+
+template <int TZ, int TX, int TY, bool PC, bool OB>
+static void launch_tiled(const GridDev &g, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw, const Range &r,
+                         const ocn::FuseArgs &fz, int wx, int wy, int wz, hipStream_t stream)
+{
+    const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+    int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the 3-flux prologue
+    while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+    dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+    hipLaunchKernelGGL((momentum_tendencies_tiled<TZ, TX, TY, 3, PC, OB>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, Gw, r, KZ, fz);
 }
 
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
@@ -1045,37 +1135,37 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
             hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, W, false>), nbt, dim3(TX * TY), 0, stream, g,  \
                                u, v, w, Gu, Gv, Gw, r, KZ, fz);                                                             \
     } while (0)
-        if (fz.pc_on) {  // pressure correction on load: all-periodic, single rank, default tile only
-            if (grid->tx != OCN_PERIODIC || grid->tz != OCN_PERIODIC || range != nullptr) {
-                ocn::set_error("pressure correction on load needs a (Periodic, Periodic, Periodic) single-rank grid and the full range");
+        // narrow ranges (the 64-wide slab of one rank of eight): 32 x 8 patches own 31 columns each, so 64 columns take 3 patches (69 %
+        // of the lanes useful in x); 17 x 15 patches own 16 x 14 and fit 64 = 4 x 16 exactly
+        const bool narrow = variant == 0 && narrow_tile(wx, wy);
+        if (fz.pc_on) {  // pressure correction on load: periodic z; x Periodic (wrapped) or FullyConnected (p halos exchanged), full range
+            if ((grid->tx != OCN_PERIODIC && grid->tx != OCN_FULLY_CONNECTED) || grid->tz != OCN_PERIODIC || range != nullptr) {
+                ocn::set_error("pressure correction on load needs a (Periodic | FullyConnected, Periodic, Periodic) grid and the full range");
                 return OCN_ERR_UNSUPPORTED;
             }
-            constexpr int TX = 32, TY = 8;
-            const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
-            int KZ = wz;
-            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
-            dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
-            if (one_barrier() & 1)
-                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w,
-                                   Gu, Gv, Gw, r, KZ, fz);
+            fz.pc_xhalo = grid->tx == OCN_FULLY_CONNECTED;
+            if (narrow)
+                launch_tiled<OCN_PERIODIC, 17, 15, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+            else if (one_barrier() & 1)
+                launch_tiled<OCN_PERIODIC, 32, 8, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
-                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu,
-                                   Gv, Gw, r, KZ, fz);
+                launch_tiled<OCN_PERIODIC, 32, 8, true, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+        if (narrow) {
+            if (grid->tz == OCN_PERIODIC)
+                launch_tiled<OCN_PERIODIC, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+            else
+                launch_tiled<OCN_BOUNDED, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }
         if (variant == 0 && (one_barrier() & (grid->tz == OCN_PERIODIC ? 2 : 4))) {  // the default 32 x 8 tile with one barrier per plane (see the kernel)
-            constexpr int TX = 32, TY = 8;
-            const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
-            int KZ = wz;
-            while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
-            dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
             if (grid->tz == OCN_PERIODIC)
-                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v,
-                                   w, Gu, Gv, Gw, r, KZ, fz);
+                launch_tiled<OCN_PERIODIC, 32, 8, false, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
-                hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, 3, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v,
-                                   w, Gu, Gv, Gw, r, KZ, fz);
+                launch_tiled<OCN_BOUNDED, 32, 8, false, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }

@@ -231,6 +231,15 @@ class HydrostaticFreeSurfaceModel:
         if self._dist is not None and not (self.split and self.fused):
             raise NotImplementedError("a slab-partitioned HydrostaticFreeSurfaceModel needs the fused step with a SplitExplicitFreeSurface "
                                       "(DistributedSplitExplicitFreeSurface, distributed_split_explicit_free_surface.jl)")
+        if self._dist is not None and self.split and free_surface.Δt_barotropic is not None:
+            # materialize_free_surface (split_explicit_free_surface.jl:166-173): FixedTimeStepSize on a connected topology is an error
+            # (every rank would derive its own substep count, and with it the width of the exchanged barotropic halos)
+            raise ValueError("A variable substepping through a CFL condition is not supported for the `SplitExplicitFreeSurface` on a "
+                             "partitioned grid. Provide a fixed number of substeps through the `substeps` keyword argument as: "
+                             "`free_surface = SplitExplicitFreeSurface(grid; substeps = N)` where `N::Int`")
+        if self._dist is not None and self.split and len(free_surface.averaging_weights) > grid.Nx:
+            raise ValueError(f"SplitExplicitFreeSurface on a partitioned grid: the {len(free_surface.averaging_weights)} barotropic substeps "
+                             f"need halos wider than the local x extent {grid.Nx} (use fewer ranks or fewer substeps)")
         if self.split and self.fused:
             self._Us, self._Vs = torch.zeros_like(self.eta), torch.zeros_like(self.eta)   # Σ Δz u*, Σ Δz v*
             self._work = torch.zeros((3,) + tuple(self.eta.shape), dtype=torch.float64, device=dev)

@@ -185,6 +185,9 @@ class NonhydrostaticModel:
                                 and not hasattr(grid.architecture, "partition")
                                 and os.environ.get("OCN_CORRECT_ON_LOAD", "1") != "0")
         self._pending_tendencies = False
+        # slab-x ranks: the same folding with the pressure planes of the neighbours exchanged after the solve (distributed.py)
+        sup = getattr(grid.architecture, "correct_on_load_supported", None)
+        self.dist_correct_on_load = bool(sup is not None and sup(self))
         update_state(self, compute_tendencies=False)
 
     def _make_terms(self):
@@ -541,13 +544,14 @@ def _update_state_and_rk3_substep_general(model, dt, gamma, zeta, fill_halos=Tru
     alt = model._alt_fields
     Gn, Gm = model.timestepper._Gn, model.timestepper._Gm
     model._pending_tendencies = False
-    g, s = model.grid, stream_ptr()
+    g = model.grid
     z, hz = (0.0, 0) if zeta is None else (float(zeta), 1)
     t = C.byref(model._terms)
     momentum_extra = (model.coriolis is not None or model.closure is not None or model.buoyancy is not None
                       or isinstance(model.advection, (Centered, UpwindBiased)) or _bcs_ref(model.u, g) is not None or _bcs_ref(model.v, g) is not None)
 
     def launch(rng=None):
+        s = stream_ptr()  # read HERE: the Distributed hook runs the east buffer strip under torch.cuda.stream(side stream)
         r = None if rng is None else _lib.i32_array(list(rng))
         if momentum_extra:
             _lib.call("ocn_compute_momentum_tendencies_terms_rk3", g.cref, t, _bcs_ref(model.u, g), _bcs_ref(model.v, g),
@@ -591,6 +595,8 @@ def _project_and_advance(model, dt, stage_dt, gamma_next, zeta_next):
         cache_previous_tendencies(model)
         update_state_and_rk3_substep(model, dt, gamma_next, zeta_next, fill_halos=False, p_correct=model.pNHS, dt_correct=stage_dt)
         return
+    if getattr(model, "dist_correct_on_load", False):
+        return model.architecture.project_and_advance(model, dt, stage_dt, gamma_next, zeta_next)
     calculate_pressure_correction(model, stage_dt, minimal_exchange=True)
     pressure_correct_velocities(model, stage_dt)
     cache_previous_tendencies(model)

@@ -286,3 +286,24 @@ def test_transpose_free_pipeline_matches_global_solve(world, monkeypatch):
     oracle's FFT solve of the assembled field (test_distributed_poisson_solvers.jl:70-89 re-expressed)."""
     monkeypatch.setenv("OCN_TEST_XTRI", "1")
     _run(world, _xtri_matches_global)
+
+
+def test_bench_preflight_two_ranks():
+    """`python bench.py --gpus 2 --preflight`: the launcher starts its ranks, they rendezvous over gloo, rank 0's RCCL unique id reaches
+    every rank, the neighbour schedule pairs up, the library exports the distributed entry points -- and no GPU is touched (this test runs
+    on the CPU-only container).  What fails first on a multi-GPU node must not be plumbing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--preflight"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # exactly one stdout line, like the bench contract
+    out = json.loads(lines[0])
+    assert out["preflight"] == "ok" and out["ranks"] == 2 and out["local_ranks_seen"] == [0, 1] and out["gpu_touched"] is False
+    assert all(out["checks_rank0"].values()), out["checks_rank0"]
