@@ -400,8 +400,8 @@ def main():
         dt = 0.1 * min(grid.dx, dmin) / float(umax)
         prognostic = model.prognostic_fields()
         if a.driver == "c":
-            if world > 1 or a.workload != "box":
-                raise SystemExit("--driver c: box workload on one GPU")
+            if a.workload != "box":
+                raise SystemExit("--driver c: box workload (one GPU, or one C call per rank-step with --gpus N)")
             drv = ocn.RK3Driver(model)
             step, flush = (lambda: drv.time_step(dt)), drv.flush
         else:

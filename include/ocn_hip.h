@@ -433,6 +433,12 @@ int ocn_rk3_driver_destroy(ocn_rk3_driver_t driver);
 int ocn_rk3_driver_time_step(ocn_rk3_driver_t driver, double dt, void *stream);
 int ocn_rk3_driver_flush(ocn_rk3_driver_t driver, void *stream);
 int ocn_rk3_driver_fields(ocn_rk3_driver_t driver, double **u, double **v, double **w, double **Gu, double **Gv, double **Gw);
+/* defer_correction != 0 (the default on all-periodic grids; OCN_DRIVER_DEFER_CORRECTION=0 in the environment changes the default):
+ * pressure_correct_velocities! of the THIRD stage is not launched either -- the next step's first fused launch applies it on load
+ * like stages 1 and 2 (three identical stage boundaries per step, no pressure-correction pass, no halo fill after it).  Between
+ * time_step and flush the velocity arrays then hold the uncorrected u*, v*, w*; ocn_rk3_driver_flush applies the correction, fills
+ * the halos and completes the tendencies -- the state it leaves is the reference's, bit for bit in strict math. */
+int ocn_rk3_driver_configure(ocn_rk3_driver_t driver, int32_t defer_correction);
 
 /* solve!(ϕ, ::BatchedTridiagonalSolver, rhs), z direction (src/Solvers/batched_tridiagonal_solver.jl:100-123,
  * 203-235).  a, c: real Nz-1; b: real Nx*Ny*Nz; f, phi: complex interleaved Nx*Ny*Nz; t: real scratch. */
@@ -574,7 +580,18 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
 /* transpose_y_to_x! (direction 0) / transpose_x_to_y! (direction 1) of a distributed Poisson handle's exchange buffers */
 int ocn_dist_poisson_exchange(ocn_dist_poisson_t solver, ocn_comm_t comm, int32_t direction, void *stream);
 int ocn_comm_allreduce(ocn_comm_t comm, double *buffer, size_t count, int32_t op /* 0 sum, 1 max, 2 min */, void *stream);
-int ocn_comm_barrier(ocn_comm_t comm);                      /* MPI.Barrier; blocks the host */
+int ocn_comm_barrier(ocn_comm_t comm);
+
+/* The same one-call RK3 time_step! for ONE RANK of a slab-x run (Distributed(GPU(); partition = Partition(R)),
+ * distributed_architectures.jl:167-297): local (FullyConnected, Periodic, Periodic) grid, the rank's ocn_dist_poisson_t (slab
+ * pipelines: ocn_dist_poisson_pipeline 1 or 3) and its communicator, both borrowed.  Per stage: local y / z halo fills -> the u plane
+ * the divergence reads -> the strips of u*, v*, w* posted on the communication stream (they fly under the pressure solve) ->
+ * distributed solve -> strips unpacked -> ocn_halo_exchange_pressure -> ONE launch over the whole slab that corrects on load, computes
+ * the tendencies and takes the next substep.  No host synchronisation, no Python between the launches; collectives included.
+ * Bit-identical to the per-call sequence of oceananigans.jl_amd/distributed.py (tests/test_gpu_distributed.py).  The third stage's
+ * correction is always deferred (see ocn_rk3_driver_configure); flush / fields / destroy as above. */
+int ocn_rk3_driver_create_distributed(ocn_rk3_driver_t *driver, const ocn_grid *local_grid, double *u, double *v, double *w, double *p,
+                                      ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream);                      /* MPI.Barrier; blocks the host */
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,8 @@ _SIGS = {
     "ocn_add_barotropic_pressure_gradient": [C.POINTER(CGrid), _dbl, _vp, _vp, _vp, _vp],
     "ocn_explicit_free_surface_ab2_step": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _dbl, _dbl, _vp],
     "ocn_rk3_driver_create": [C.POINTER(_vp), C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_rk3_driver_create_distributed": [C.POINTER(_vp), C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_rk3_driver_configure": [_vp, _i32],
     "ocn_rk3_driver_destroy": [_vp],
     "ocn_rk3_driver_time_step": [_vp, _dbl, _vp],
     "ocn_rk3_driver_flush": [_vp, _vp],

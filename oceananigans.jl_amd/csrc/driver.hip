@@ -32,14 +32,56 @@ struct ocn_rk3_driver {
     bool started = false;         // iteration 0 done
     bool correct_on_load = false;
     long long iteration = 0;
+    // the third stage's pressure correction is left to the next step's first fused launch (applied on load like stages 1 and 2): the
+    // velocities in U are then the UNCORRECTED u*, v*, w* with valid halos, p holds the pressure, ocn_rk3_driver_flush applies it
+    bool defer_correction = false;
+    bool correction_pending = false;
+    double correction_dt = 0.0;
+    // slab-x rank (ocn_rk3_driver_create_distributed): RCCL communicator + distributed Poisson handle, both borrowed
+    ocn_comm_t comm = nullptr;
+    ocn_dist_poisson_t dsolver = nullptr;
 };
 
 namespace {
 const int32_t LOCS[3] = {OCN_LOC_FCC, OCN_LOC_CFC, OCN_LOC_CCF};
 
+// fill_halo_regions!(velocities): local periodic / wall fills, then -- on a slab -- the x exchange with the neighbours (synchronous)
 int fill_velocities(ocn_rk3_driver *d, int fbnv, void *stream)
 {
-    return ocn_fill_halo_regions(&d->grid, d->U, LOCS, 3, fbnv, stream);
+    int st = ocn_fill_halo_regions(&d->grid, d->U, LOCS, 3, fbnv, stream);
+    if (st != OCN_SUCCESS || !d->comm) return st;
+    st = ocn_halo_exchange_begin(d->comm, &d->grid, d->U, LOCS, 3, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_halo_exchange_end(d->comm, &d->grid, d->U, LOCS, 3, stream);
+}
+
+int fill_pressure(ocn_rk3_driver *d, void *stream)
+{
+    const int32_t ploc = OCN_LOC_CCC;
+    double *pf[1] = {d->p};
+    int st = ocn_fill_halo_regions(&d->grid, pf, &ploc, 1, 1, stream);
+    if (st != OCN_SUCCESS || !d->comm) return st;
+    st = ocn_halo_exchange_begin(d->comm, &d->grid, pf, &ploc, 1, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_halo_exchange_end(d->comm, &d->grid, pf, &ploc, 1, stream);
+}
+
+// solve_for_pressure!(pNHS, solver, Δt, U) (solve_for_pressure.jl:78-82) on one GPU or on a slab (the slab pipelines of the handle:
+// distributed_fft_based_poisson_solver.jl:141-178 without pack / unpack passes)
+int solve(ocn_rk3_driver *d, double stage_dt, void *stream)
+{
+    if (!d->dsolver) return ocn_solve_for_pressure(d->solver, d->p, d->U[0], d->U[1], d->U[2], stage_dt, stream);
+    int st = ocn_dist_poisson_source_term(d->dsolver, d->U[0], d->U[1], d->U[2], stage_dt, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_forward_yz(d->dsolver, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_exchange(d->dsolver, d->comm, 0, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_solve_x(d->dsolver, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_exchange(d->dsolver, d->comm, 1, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_dist_poisson_backward_yz(d->dsolver, d->p, stream);
 }
 
 // update_state! + the next rk3_substep! in one launch, then the two velocity sets trade places
@@ -60,26 +102,60 @@ void swap_tendencies(ocn_rk3_driver *d)  // cache_previous_tendencies! (store_te
     for (int f = 0; f < 3; ++f) std::swap(d->Gn[f], d->Gm[f]);
 }
 
-// everything between two substeps (runge_kutta_3.jl:103-118)
-int project_and_advance(ocn_rk3_driver *d, double dt, double stage_dt, double gamma_next, double zeta_next, void *stream)
+// The projection of a stage up to (not including) the correction, for a launch that corrects on load: halos of the uncorrected
+// velocities, pressure solve and -- on a slab -- the pressure planes of the neighbours.  On a slab the exchange of u*, v*, w* is posted
+// BEFORE the solve (only the plane the divergence reads is waited for) and flies under it on the communication stream.
+int project_for_load(ocn_rk3_driver *d, double stage_dt, void *stream)
 {
-    int st = fill_velocities(d, 1, stream);
+    int st = ocn_fill_halo_regions(&d->grid, d->U, LOCS, 3, 1, stream);
     if (st != OCN_SUCCESS) return st;
-    st = ocn_solve_for_pressure(d->solver, d->p, d->U[0], d->U[1], d->U[2], stage_dt, stream);
-    if (st != OCN_SUCCESS) return st;
-    if (d->correct_on_load) {
-        swap_tendencies(d);
-        return fused_launch(d, dt, gamma_next, zeta_next, 1, d->p, stage_dt, stream);
+    if (d->comm) {
+        st = ocn_halo_exchange_plane(d->comm, &d->grid, d->U[0], OCN_LOC_FCC, 0, stream);  // u[nx+1] <- east neighbour's u[1]
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_halo_exchange_begin(d->comm, &d->grid, d->U, LOCS, 3, stream);
+        if (st != OCN_SUCCESS) return st;
     }
-    const int32_t ploc = OCN_LOC_CCC;
-    double *pf[1] = {d->p};
-    st = ocn_fill_halo_regions(&d->grid, pf, &ploc, 1, 1, stream);
+    st = solve(d, stage_dt, stream);
+    if (st != OCN_SUCCESS) return st;
+    if (d->comm) {
+        st = ocn_halo_exchange_end(d->comm, &d->grid, d->U, LOCS, 3, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_halo_exchange_pressure(d->comm, &d->grid, d->p, d->U[0], stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
+    return OCN_SUCCESS;
+}
+
+// calculate_pressure_correction! + pressure_correct_velocities! + the halo fill of update_state! (pressure_correction.jl:8-50)
+int project_and_correct(ocn_rk3_driver *d, double stage_dt, bool solve_too, void *stream)
+{
+    int st;
+    if (solve_too) {
+        st = fill_velocities(d, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = solve(d, stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
+    st = fill_pressure(d, stream);
     if (st != OCN_SUCCESS) return st;
     st = ocn_pressure_correct_velocities(&d->grid, d->U[0], d->U[1], d->U[2], d->p, stage_dt, stream);
     if (st != OCN_SUCCESS) return st;
-    swap_tendencies(d);
-    st = fill_velocities(d, 0, stream);
+    return fill_velocities(d, 0, stream);
+}
+
+// everything between two substeps (runge_kutta_3.jl:103-118)
+int project_and_advance(ocn_rk3_driver *d, double dt, double stage_dt, double gamma_next, double zeta_next, void *stream)
+{
+    int st;
+    if (d->correct_on_load) {
+        st = project_for_load(d, stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+        swap_tendencies(d);
+        return fused_launch(d, dt, gamma_next, zeta_next, 1, d->p, stage_dt, stream);
+    }
+    st = project_and_correct(d, stage_dt, true, stream);
     if (st != OCN_SUCCESS) return st;
+    swap_tendencies(d);
     return fused_launch(d, dt, gamma_next, zeta_next, 1, nullptr, 0.0, stream);
 }
 }  // namespace
@@ -97,15 +173,32 @@ extern "C" int ocn_rk3_driver_destroy(ocn_rk3_driver_t d)
     return OCN_SUCCESS;
 }
 
-extern "C" int ocn_rk3_driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u, double *v, double *w, double *p,
-                                     ocn_poisson_t solver, void *stream)
+static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u, double *v, double *w, double *p, ocn_poisson_t solver,
+                         ocn_dist_poisson_t dsolver, ocn_comm_t comm, void *stream)
 {
     OCN_REQUIRE(out && grid && u && v && w && p, "ocn_rk3_driver_create: null argument");
     int st = ocn::validate_grid(grid);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_rk3_driver_create: x and y must be Periodic (one GPU)");
+    if (comm) {
+        OCN_REQUIRE(grid->tx == OCN_FULLY_CONNECTED && grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC && dsolver,
+                    "ocn_rk3_driver_create_distributed: a (FullyConnected, Periodic, Periodic) local grid and its distributed Poisson handle");
+        int32_t fast = 0;
+        st = ocn_dist_poisson_pipeline(dsolver, &fast);
+        if (st != OCN_SUCCESS) return st;
+        if (fast != 1 && fast != 3) {
+            ocn::set_error("ocn_rk3_driver_create_distributed: the Poisson handle runs the transposing path (sizes outside the slab "
+                           "pipelines): drive it through the per-call entry points");
+            return OCN_ERR_UNSUPPORTED;
+        }
+        OCN_REQUIRE(grid->Nx >= 16 && grid->Nx >= grid->Hx + 1 && grid->Ny >= 8 && grid->Nz >= 4,
+                    "ocn_rk3_driver_create_distributed: the local slab must be at least 16 x 8 x 4");
+    } else {
+        OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_rk3_driver_create: x and y must be Periodic (one GPU)");
+    }
     ocn_rk3_driver *d = new ocn_rk3_driver();
     d->grid = *grid;
+    d->comm = comm;
+    d->dsolver = dsolver;
     d->user[0] = u; d->user[1] = v; d->user[2] = w;
     d->p = p;
     GridDev g = ocn::to_dev(*grid);
@@ -122,7 +215,9 @@ extern "C" int ocn_rk3_driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid
         d->U[f] = d->user[f];
         d->A[f] = d->own[f];
     }
-    if (solver) {  // the caller's pressure solver for this grid (borrowed)
+    if (comm) {
+        d->owns_solver = false;
+    } else if (solver) {  // the caller's pressure solver for this grid (borrowed)
         d->solver = solver;
         d->owns_solver = false;
     } else {
@@ -132,15 +227,40 @@ extern "C" int ocn_rk3_driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid
             return st;
         }
     }
-    // fold the pressure correction of stages 1 and 2 into the loads of the fused launch: all-periodic grids the tiled kernel covers
+    // fold the pressure correction into the loads of the fused launch: all-periodic grids the tiled kernel covers; always on a slab
     const char *e = std::getenv("OCN_CORRECT_ON_LOAD");
-    d->correct_on_load = grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4 && !(e && e[0] == '0');
+    d->correct_on_load = comm || (grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4 && !(e && e[0] == '0'));
+    const char *dc = std::getenv("OCN_DRIVER_DEFER_CORRECTION");
+    d->defer_correction = d->correct_on_load && !(dc && dc[0] == '0');
     st = fill_velocities(d, 0, stream);  // update_state!(model; compute_tendencies = false) of the constructor
     if (st != OCN_SUCCESS) {
         ocn_rk3_driver_destroy(d);
         return st;
     }
     *out = d;
+    return OCN_SUCCESS;
+}
+
+extern "C" int ocn_rk3_driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u, double *v, double *w, double *p,
+                                     ocn_poisson_t solver, void *stream)
+{
+    return driver_create(out, grid, u, v, w, p, solver, nullptr, nullptr, stream);
+}
+
+extern "C" int ocn_rk3_driver_create_distributed(ocn_rk3_driver_t *out, const ocn_grid *local_grid, double *u, double *v, double *w,
+                                                 double *p, ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream)
+{
+    OCN_REQUIRE(solver && comm, "ocn_rk3_driver_create_distributed: null solver / communicator");
+    return driver_create(out, local_grid, u, v, w, p, nullptr, solver, comm, stream);
+}
+
+extern "C" int ocn_rk3_driver_configure(ocn_rk3_driver_t d, int32_t defer_correction)
+{
+    OCN_REQUIRE(d, "ocn_rk3_driver_configure: null driver");
+    OCN_REQUIRE(!d->correction_pending, "ocn_rk3_driver_configure: flush first (a deferred pressure correction is pending)");
+    OCN_REQUIRE(!defer_correction || d->correct_on_load, "ocn_rk3_driver_configure: deferring the correction needs correction on load (all-periodic grid)");
+    OCN_REQUIRE(defer_correction || !d->comm, "ocn_rk3_driver_configure: a distributed driver always defers the third stage's correction");
+    d->defer_correction = defer_correction != 0;
     return OCN_SUCCESS;
 }
 
@@ -160,7 +280,9 @@ extern "C" int ocn_rk3_driver_time_step(ocn_rk3_driver_t d, double dt, void *str
     const double first_stage_dt = g1 * dt, second_stage_dt = (g2 + z2) * dt, third_stage_dt = (g3 + z3) * dt;
     // ---- first stage
     if (d->pending) {
-        st = fused_launch(d, dt, g1, 0.0, 0, nullptr, 0.0, stream);
+        const bool pc = d->correction_pending;  // the previous step's third-stage correction rides on this launch's loads
+        st = fused_launch(d, dt, g1, 0.0, 0, pc ? d->p : nullptr, pc ? d->correction_dt : 0.0, stream);
+        d->correction_pending = false;
     } else {
         st = ocn_rk3_substep(&d->grid, 3, d->U, d->Gn, d->Gm, LOCS, dt, g1, 0.0, 0, stream);
     }
@@ -169,19 +291,17 @@ extern "C" int ocn_rk3_driver_time_step(ocn_rk3_driver_t d, double dt, void *str
     if (st != OCN_SUCCESS) return st;
     st = project_and_advance(d, dt, second_stage_dt, g3, z3, stream);  // ... ends with the third substep
     if (st != OCN_SUCCESS) return st;
-    // ---- third stage: projection, then the halos; its compute_tendencies! is fused into the next step's first substep
-    st = fill_velocities(d, 1, stream);
-    if (st != OCN_SUCCESS) return st;
-    st = ocn_solve_for_pressure(d->solver, d->p, d->U[0], d->U[1], d->U[2], third_stage_dt, stream);
-    if (st != OCN_SUCCESS) return st;
-    const int32_t ploc = OCN_LOC_CCC;
-    double *pf[1] = {d->p};
-    st = ocn_fill_halo_regions(&d->grid, pf, &ploc, 1, 1, stream);
-    if (st != OCN_SUCCESS) return st;
-    st = ocn_pressure_correct_velocities(&d->grid, d->U[0], d->U[1], d->U[2], d->p, third_stage_dt, stream);
-    if (st != OCN_SUCCESS) return st;
-    st = fill_velocities(d, 0, stream);
-    if (st != OCN_SUCCESS) return st;
+    // ---- third stage: projection; its compute_tendencies! is fused into the next step's first substep, and so is -- when the
+    //      correction is deferred -- pressure_correct_velocities! itself
+    if (d->defer_correction) {
+        st = project_for_load(d, third_stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+        d->correction_pending = true;
+        d->correction_dt = third_stage_dt;
+    } else {
+        st = project_and_correct(d, third_stage_dt, true, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
     d->pending = true;
     d->iteration += 1;
     return OCN_SUCCESS;
@@ -190,6 +310,11 @@ extern "C" int ocn_rk3_driver_time_step(ocn_rk3_driver_t d, double dt, void *str
 extern "C" int ocn_rk3_driver_flush(ocn_rk3_driver_t d, void *stream)
 {
     OCN_REQUIRE(d, "ocn_rk3_driver_flush: null driver");
+    if (d->correction_pending) {  // the deferred third-stage correction: p halos, pressure_correct_velocities!, velocity halos
+        int st = project_and_correct(d, d->correction_dt, false, stream);
+        if (st != OCN_SUCCESS) return st;
+        d->correction_pending = false;
+    }
     if (d->pending) {  // complete the deferred compute_tendencies!: G^n of the current state
         int st = ocn_compute_momentum_tendencies(&d->grid, d->U[0], d->U[1], d->U[2], d->Gn[0], d->Gn[1], d->Gn[2], nullptr, stream);
         if (st != OCN_SUCCESS) return st;

@@ -665,18 +665,34 @@ def _time_step_qab2(model, dt, euler=False):
 class RK3Driver:
     """The whole RK3 time_step! behind ONE entry point of the C ABI (ocn_rk3_driver_*, csrc/driver.hip): what a Julia host binds
     when it wants the fused stage boundaries without managing alternating array roles itself.  Wraps the velocity and pressure
-    fields of a plain WENO model (no tracers, no extra terms, one GPU); bit-identical to `time_step(model, dt)`."""
+    fields of a plain WENO model (no tracers, no extra terms) on one GPU or on ONE RANK of a slab-x run with the RCCL transport
+    (ocn_rk3_driver_create_distributed: the collectives are issued by the library too, no Python between the launches);
+    after flush() the state is bit-identical to `time_step(model, dt)` + flush_tendencies.
+    defer_correction (default: the library's, on for all-periodic grids): the third stage's pressure correction rides on the next
+    step's first fused launch; between time_step() and flush() the model's velocity fields are then NOT the corrected ones."""
 
-    def __init__(self, model, own_solver=False):
-        if model.tracers or model.general_terms or hasattr(model.grid.architecture, "partition"):
-            raise NotImplementedError("RK3Driver: WENO advection only (no tracers / extra terms), one GPU")
+    def __init__(self, model, own_solver=False, defer_correction=None):
+        if model.tracers or model.general_terms:
+            raise NotImplementedError("RK3Driver: WENO advection only (no tracers / extra terms)")
         if not isinstance(model.timestepper, RungeKutta3TimeStepper) or not isinstance(model.advection, WENO):
             raise NotImplementedError("RK3Driver: RungeKutta3 + WENO()")
         flush_tendencies(model)
         self.model = model
         self._h = C.c_void_p()
-        _lib.call("ocn_rk3_driver_create", C.byref(self._h), model.grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, model.pNHS.ptr,
-                  None if own_solver else model.pressure_solver._h, stream_ptr())  # borrows the model's solver handle by default
+        arch = model.grid.architecture
+        if hasattr(arch, "partition"):
+            comm = getattr(arch.fabric, "_h", None)
+            impl = getattr(model.pressure_solver, "impl", None)
+            if comm is None or getattr(impl, "_h", None) is None:
+                raise NotImplementedError("RK3Driver on a Distributed architecture needs the RCCL transport (make_distributed) and the library's "
+                                          "distributed Poisson handle")
+            _lib.call("ocn_rk3_driver_create_distributed", C.byref(self._h), model.grid.cref, model.u.ptr, model.v.ptr, model.w.ptr,
+                      model.pNHS.ptr, impl._h, comm, stream_ptr())
+        else:
+            _lib.call("ocn_rk3_driver_create", C.byref(self._h), model.grid.cref, model.u.ptr, model.v.ptr, model.w.ptr, model.pNHS.ptr,
+                      None if own_solver else model.pressure_solver._h, stream_ptr())  # borrows the model's solver handle by default
+        if defer_correction is not None:
+            _lib.call("ocn_rk3_driver_configure", self._h, int(bool(defer_correction)))
 
     def time_step(self, dt):
         _lib.call("ocn_rk3_driver_time_step", self._h, float(dt), stream_ptr())

@@ -502,10 +502,13 @@ def test_advective_cfl_reference_doctest_value(ocn):
 @pytest.mark.parametrize("size,topo,z,own", [((32, 16, 12), "PPP", (0, 2.0), False), ((16, 12, 9), "PPB", "stretched", False),
                                              ((12, 9, 5), "PPP", (0, 1.0), False), ((24, 16, 1), "PPF", None, False),
                                              ((128, 64, 64), "PPP", (0, 2.0), True)])  # own solver handle: hand-written FFT pipeline
-def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own):
+@pytest.mark.parametrize("defer", [None, False])
+def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own, defer):
     """ocn_rk3_driver_time_step (the whole RK3 step behind one C entry point, csrc/driver.hip) against the Python host's
     time_step: same launches in the same order, so velocities, pressure and G^n agree bit for bit after 3 steps (and after an
-    intermediate flush, which brings the velocities back into the caller's arrays and breaks the deferral chain)."""
+    intermediate flush, which brings the velocities back into the caller's arrays and breaks the deferral chain).  defer = None: the
+    library's default, which on all-periodic grids also defers the THIRD stage's pressure correction into the next step's first
+    launch (ocn_rk3_driver_configure); flush restores the reference's state bit for bit either way."""
     import ctypes as C
     O = oracle
     rng = np.random.default_rng(5)
@@ -529,7 +532,7 @@ def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own):
         ocn.time_step(ref, dt)
     ocn.flush_tendencies(ref)
     m = build()
-    drv = ocn.RK3Driver(m, own_solver=own)
+    drv = ocn.RK3Driver(m, own_solver=own, defer_correction=defer)
     drv.time_step(dt)
     drv.flush()            # exercise the copy-home path between steps
     drv.time_step(dt)
@@ -538,6 +541,11 @@ def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own):
     ocn.sync_device()
     for a, b in zip(ref.velocities + (ref.pNHS,), m.velocities + (m.pNHS,)):
         np.testing.assert_array_equal(from_dev(a), from_dev(b))
+    Gd = drv.tendency_pointers()
+    for G, ptr in zip(ref.timestepper.Gn, Gd):
+        import torch
+        got = torch.as_tensor(ocn.distributed._DevBuf(ptr, G.data.numel()), device="cuda").reshape(G.data.shape).cpu().numpy().T
+        np.testing.assert_array_equal(og.interior_N(from_dev(G)), og.interior_N(got))
     del drv
 
 

@@ -58,6 +58,45 @@ class LoopbackFabric:
 
 
 ocn.set_math_mode(ocn.MATH_FAST)
+if workload == "driver":
+    # ONE C call per step (ocn_rk3_driver_create_distributed): a slab of the R-rank size as a one-rank RCCL world that exchanges with itself
+    # (force_communication) -- the same kernels at the same local size as one rank of R (the interface systems of the x solve are those
+    # of one rank instead of R), every collective issued by the library.  What it shows: the host enqueue time per rank-step.
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+    nx = N // R
+    g = ocn.RectilinearGrid(arch, size=(nx, N, N), x=(0, 2 * np.pi / R), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=("Periodic",) * 3, halo=(3, 3, 3))
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    for f in m.velocities:
+        v = f.interior_view()
+        v.copy_(2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1)
+    ocn.set(m)
+    dt = 0.1 * g.dx / max(float(f.interior_view().abs().max()) for f in m.velocities)
+    for name, stepper, flush in (("python host", lambda: ocn.time_step(m, dt), lambda: ocn.flush_tendencies(m)), ("C driver", None, None)):
+        if stepper is None:
+            drv = ocn.RK3Driver(m)
+            stepper, flush = (lambda: drv.time_step(dt)), drv.flush
+        for _ in range(5):
+            stepper()
+        flush()
+        ocn.sync_device()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper()
+        flush()
+        host_ms = (time.perf_counter() - t0) / steps * 1e3
+        ocn.sync_device()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        finite = all(bool(torch.isfinite(f.interior_view()).all()) for f in m.velocities)
+        print(f"driver N={N} R={R} [{name}]: local {g.Nx}x{g.Ny}x{g.Nz}, {ms:.2f} ms/step per rank (host enqueue {host_ms:.2f} ms), finite={finite}")
+    sys.exit(0)
 if workload == "config5":
     # BASELINE.json configs[4] (an 8-GPU configuration): what one of R slab-x ranks costs
     arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=LoopbackFabric(R)) if R > 1 else ocn.GPU()

@@ -47,6 +47,12 @@ SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_G
                "SQ_INSTS_LDS", "SQ_WAIT_INST_ANY")
 
 
+STALL_COUNTERS = ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS",
+                  "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")
+OCC_COUNTERS = ("SQ_WAVES", "SQ_LEVEL_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VMEM",
+                "SQ_ACTIVE_INST_LDS")
+
+
 def main():
     d, tag, name = sys.argv[1], sys.argv[2], sys.argv[3]
     n = int(name) if name.isdigit() else None
@@ -58,6 +64,11 @@ def main():
     sq = {}
     if glob.glob(os.path.join(d, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
         sq = {c: load_pmc(d, "pmc_sq", c) for c in SQ_COUNTERS}
+    stall, occ = {}, {}
+    if glob.glob(os.path.join(d, "pmc_stall", "**", "*counter_collection.csv"), recursive=True):
+        stall = {c: load_pmc(d, "pmc_stall", c) for c in STALL_COUNTERS}
+    if glob.glob(os.path.join(d, "pmc_occ", "**", "*counter_collection.csv"), recursive=True):
+        occ = {c: load_pmc(d, "pmc_occ", c) for c in OCC_COUNTERS}
     field_bytes = cells * 8.0
     # calibration kernel of known traffic in our 8 B/lane pattern:
     #   stepper_kernel<3> (cache_previous_tendencies): reads 3 fields, writes 3;  or, when the host swaps the G buffers
@@ -86,6 +97,21 @@ def main():
         for c in SQ_COUNTERS:
             if c in sq and s["name"] in sq[c]:
                 k[c] = med(sq[c][s["name"]])
+        for group, prefix in ((stall, "stall_"), (occ, "occ_")):
+            for c, per_kernel in group.items():
+                if s["name"] in per_kernel:
+                    k[prefix + c] = med(per_kernel[s["name"]])
+        wc = k.get("stall_SQ_WAVE_CYCLES")
+        if wc:
+            # fractions of the wave cycles: issuing, stalled at issue (of which LDS), parked at s_waitcnt / barrier
+            k["frac_active"] = k.get("stall_SQ_ACTIVE_INST_ANY", 0.0) / wc
+            k["frac_issue_stall"] = k.get("stall_SQ_WAIT_INST_ANY", 0.0) / wc
+            k["frac_issue_stall_lds"] = k.get("stall_SQ_WAIT_INST_LDS", 0.0) / wc
+            k["frac_parked"] = k.get("stall_SQ_WAIT_ANY", 0.0) / wc
+            if k.get("stall_SQ_LDS_IDX_ACTIVE"):
+                k["lds_conflict_frac"] = k.get("stall_SQ_LDS_BANK_CONFLICT", 0.0) / k["stall_SQ_LDS_IDX_ACTIVE"]
+        if k.get("occ_SQ_LEVEL_WAVES") and k.get("occ_SQ_BUSY_CYCLES"):
+            k["mean_waves_in_flight_per_SE_unit"] = k["occ_SQ_LEVEL_WAVES"] / k["occ_SQ_BUSY_CYCLES"]
         if "SQ_ACTIVE_INST_VALU" in k and k.get("GRBM_GUI_ACTIVE"):
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
             k["valu_busy"] = k["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * k["GRBM_GUI_ACTIVE"] / 8)
@@ -115,6 +141,15 @@ def main():
             vb = f"{k['valu_busy']:.2f}" if "valu_busy" in k else "-"
             gh = f"{k['clock_GHz_under_pmc']:.2f}" if "clock_GHz_under_pmc" in k else "-"
             f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_us']:.1f} | {k['pct']:.2f} | {t} | {b} | {vi} | {vb} | {gh} |\n")
+        if any("frac_parked" in k for k in out["kernels"]):
+            f.write("\n## Where the wave cycles go (SQ_WAVE_CYCLES = issuing + stalled at issue + parked at s_waitcnt / barrier)\n\n"
+                    "| kernel | issuing | issue stall (LDS part) | parked (s_waitcnt, barrier) | LDS bank-conflict cycles / LDS cycles | LDS instr / VMEM rd instr per launch |\n|---|---|---|---|---|---|\n")
+            for k in out["kernels"][:14]:
+                if "frac_parked" not in k:
+                    continue
+                lc = f"{k['lds_conflict_frac']:.3f}" if "lds_conflict_frac" in k else "-"
+                f.write(f"| `{k['name']}` | {k['frac_active']:.2f} | {k['frac_issue_stall']:.2f} ({k['frac_issue_stall_lds']:.2f}) | {k['frac_parked']:.2f} | {lc} | "
+                        f"{k.get('stall_SQ_INSTS_LDS', 0):.3g} / {k.get('occ_SQ_INSTS_VMEM_RD', 0):.3g} |\n")
     print(open(base + ".md").read())
 
 
