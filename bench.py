@@ -491,6 +491,10 @@ def main():
             "bound": "valu_fp64", "kernel": "momentum_tendencies_tiled (fused compute_Gu/Gv/Gw, WENO5)",
             "achieved": achieved, "peak": VALU_PEAK_GWAVEINSTR, "unit": "G wave-instr/s",
             "frac": None if achieved is None else achieved / VALU_PEAK_GWAVEINSTR,
+            # SURVEY 8(d)'s definition of the same launch: algorithmic HBM bytes / launch time / 8 TB/s (the kernel is VALU-bound, so this is low by construction)
+            "frac_hbm": (in_step_bytes * local_cells / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if in_step_ms is not None
+                        else TENDENCY_BYTES_PLAIN * local_cells / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "sustained_GHz": pk.get("clock_GHz_under_pmc"),  # GRBM_GUI_ACTIVE / 8 XCDs / launch time of the committed PMC pass
             "traffic": pk.get("traffic_bytes"),
             "kernel_ms": ref_ms, "variant": "in-step (correction on load + substep epilogue)" if in_step_ms is not None else "plain",
             "valu_wave_instr_per_launch": instr, "valu_busy_frac_pmc": pk.get("valu_busy"),
@@ -578,7 +582,21 @@ def main():
         "strict_ms_per_step": strict_ms,
         "roofline": roofline,
         "step_roofline": step_roofline,
+        "driver": a.driver,
     }
+    if a.workload == "box" and step_roofline is not None:
+        # north_star's unit, "the WENO5 tendency + pressure-correction step" = one RK3 substage (substep + projection + tendencies):
+        # a third of the step; bytes from the committed PMC passes, against the 8 TB/s HBM roofline (north_star asks >= 0.40)
+        mb = step_roofline.get("measured_bytes_per_cell_step")
+        sub_ms = el / a.steps * 1e3 / 3
+        out["substage"] = {"what": "one RK3 substage: rk3_substep + pressure projection (FFT solve) + WENO5 tendencies, i.e. north_star's "
+                                   "'WENO5 tendency + pressure-correction step'",
+                           "ms": sub_ms, "measured_bytes_per_cell": None if mb is None else mb / 3,
+                           "measured_GBps": None if mb is None else mb / 3 * cells / (sub_ms * 1e-3) / 1e9,
+                           "frac_of_8TBps": None if mb is None else mb / 3 * cells / (sub_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                           "reference_decomposition_bytes_per_cell": ALGO_BYTES_PER_CELL_STEP / 3,
+                           "reference_decomposition_frac_of_8TBps": ALGO_BYTES_PER_CELL_STEP / 3 * cells / (sub_ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                           "pmc_source": step_roofline.get("pmc_source")}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             if a.workload == "box":

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a
             const ZBc &bc = (k == 0) ? zbc.bottom[f] : zbc.top[f];
             if (bc.kind >= OCN_BC_VALUE) {
                 const int kb = (k == 0) ? 1 : g.Nz + 1;  // boundary face index kᴮ
-                const double D = g.dzf ? g.dzf[kb + g.Hz - 1] : g.dz;
+                const double D = g.dzf ? uniform_load(g.dzf, kb + g.Hz - 1) : g.dz;
                 const double bv = bc_condition(bc, si, sj, g.Nx, val);
                 double grad;
                 if (bc.kind == OCN_BC_GRADIENT) grad = bv;
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(256) void apply_flux_bcs_kernel(GridDev g, FieldTup
     const ZBc &bb = zbc.bottom[f], &bt = zbc.top[f];
     if (bb.kind == OCN_BC_FLUX) {
         const long long o = at(L, i, j, 1);
-        const double V = Az * (g.dzc ? g.dzc[1 + g.Hz - 1] : g.dz);
+        const double V = Az * (g.dzc ? uniform_load(g.dzc, 1 + g.Hz - 1) : g.dz);
         G.f[f][o] += bc_condition(bb, i, j, g.Nx, c.f[f][o]) * Az / V;
     }
     if (bt.kind == OCN_BC_FLUX) {
         const long long o = at(L, i, j, g.Nz);
-        const double V = Az * (g.dzc ? g.dzc[g.Nz + g.Hz - 1] : g.dz);
+        const double V = Az * (g.dzc ? uniform_load(g.dzc, g.Nz + g.Hz - 1) : g.dz);
         G.f[f][o] -= bc_condition(bt, i, j, g.Nx, c.f[f][o]) * Az / V;
     }
 }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, Te
         o -= L.s3;
         const double b = buoyancy_perturbation(t, o);
         const double zb = 1 * (0.5 * (b + b_up));                       // z_dot_g_bᶜᶜᶠ(k+1)
-        const double dz = g.dzf ? g.dzf[k + 1 + g.Hz - 1] : g.dz;       // Δzᶜᶜᶠ(k+1)
+        const double dz = g.dzf ? uniform_load(g.dzf, k + 1 + g.Hz - 1) : g.dz;       // Δzᶜᶜᶠ(k+1)
         p = (k == Nz) ? -zb * dz : p - zb * dz;
         pHY[o] = p;
         b_up = b;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void w_from_continuity_kernel(GridDev g, const
     double wk = 0.0;
     w[o] = wk;
     for (int k = 1; k <= g.Nz; ++k) {
-        const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         const double Ax = g.dy * dzc, Ay = g.dx * dzc;
         const double dxu = Ax * u[o + 1] - Ax * u[o];
         const double dyv = Ay * v[o + L.s2] - Ay * v[o];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void vector_invariant_kernel(GridDev g, const 
     const Lay L = make_lay(g, OCN_LOC_CCC);
     const long long o = at(L, i, j, k), s2 = L.s2, s3 = L.s3;
     const double dx = g.dx, dy = g.dy, Az = dx * dy;
-    const double dzf0 = g.dzf ? g.dzf[k + g.Hz - 1] : g.dz, dzf1 = g.dzf ? g.dzf[k + g.Hz] : g.dz;  // Δzᶠ at faces k, k+1
+    const double dzf0 = g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz, dzf1 = g.dzf ? uniform_load(g.dzf, k + g.Hz) : g.dz;  // Δzᶠ at faces k, k+1
     const double *pu = u + o, *pv = v + o, *pw = w + o;
 #define U_(a, b, c) pu[(a) + (b)*s2 + (c)*s3]
 #define V_(a, b, c) pv[(a) + (b)*s2 + (c)*s3]
@@ -367,11 +367,11 @@ __global__ __launch_bounds__(256) void barotropic_forcing_kernel(GridDev g, cons
     const Lay L = make_lay(g, OCN_LOC_CCC);
     const double C1 = 3 * 1.0 / 2 + chi, C2 = 1.0 / 2 + chi, ne = (C2 != 0) ? 1.0 : 0.0;
     long long o = at(L, i, j, 1);
-    double dz = g.dzc ? g.dzc[g.Hz] : g.dz;
+    double dz = g.dzc ? uniform_load(g.dzc, g.Hz) : g.dz;
     double aU = dz * (C1 * Gun[o] - C2 * Gum[o] * ne), aV = dz * (C1 * Gvn[o] - C2 * Gvm[o] * ne);
     for (int k = 2; k <= g.Nz; ++k) {
         o += L.s3;
-        dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        dz = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         aU = aU + dz * (C1 * Gun[o] - C2 * Gum[o] * ne);
         aV = aV + dz * (C1 * Gvn[o] - C2 * Gvm[o] * ne);
     }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void volume_flux_kernel(GridDev g, const doubl
     double aU = 0.0, aV = 0.0;
 #pragma unroll 8
     for (int k = 1; k <= g.Nz; ++k) {
-        const double dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        const double dz = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         aU = aU + (g.dy * dz) * u[o];
         aV = aV + (g.dx * dz) * v[o];
         o += L.s3;
@@ -563,11 +563,11 @@ __global__ __launch_bounds__(256) void barotropic_mode_kernel(GridDev g, const d
     if (i > g.Nx || j > g.Ny) return;
     const Lay L = make_lay(g, OCN_LOC_CCC);
     long long o = at(L, i, j, 1);
-    double dz = g.dzc ? g.dzc[g.Hz] : g.dz;
+    double dz = g.dzc ? uniform_load(g.dzc, g.Hz) : g.dz;
     double aU = dz * u[o] * 1.0, aV = dz * v[o] * 1.0;
     for (int k = 2; k <= g.Nz; ++k) {
         o += L.s3;
-        dz = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        dz = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         aU = aU + dz * u[o] * 1.0;
         aV = aV + dz * v[o] * 1.0;
     }
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256) void barotropic_correct_w_kernel(GridDev g, co
         const double vc = corr ? vs[o] + cv : vs[o], vn = corr ? vs[on] + cvn : vs[on];
         u[o] = uc;
         v[o] = vc;
-        const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+        const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         const double Ax = g.dy * dzc, Ay = g.dx * dzc;
         const double dxu = Ax * ue - Ax * uc;
         const double dyv = Ay * vn - Ay * vc;
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void advection_timescale_kernel(GridDev g, con
     if (i <= g.Nx && j <= g.Ny) {
         const long long o = at(L, i, j, k);
         const double ix = fabs(u[o]) / g.dx, iy = fabs(v[o]) / g.dy;
-        const double iz = (g.tz == OCN_FLAT) ? 0.0 : fabs(w[o]) / (g.dzf ? g.dzf[k + g.Hz - 1] : g.dz);
+        const double iz = (g.tz == OCN_FLAT) ? 0.0 : fabs(w[o]) / (g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz);
         const double t = 1 / ((ix + iy) + iz);
         if (t == t) tau = t;
     }
@@ -1067,8 +1067,8 @@ int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double d
 // ---------------------------------------------------------------------------------------------------
 // Pressure kernels
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dzC(const GridDev &g, int k) { return g.dzc ? g.dzc[k + g.Hz - 1] : g.dz; }
-__device__ __forceinline__ double dzF(const GridDev &g, int k) { return g.dzf ? g.dzf[k + g.Hz - 1] : g.dz; }
+__device__ __forceinline__ double dzC(const GridDev &g, int k) { return g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz; }
+__device__ __forceinline__ double dzF(const GridDev &g, int k) { return g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz; }
 
 // divᶜᶜᶜ (divergence_operators.jl:16-19): 1/V * (δx(Ax u) + δy(Ay v) + δz(Az w)); δ along Flat is 0
 __device__ __forceinline__ double div_ccc(const GridDev &g, const double *__restrict__ u, const double *__restrict__ v,

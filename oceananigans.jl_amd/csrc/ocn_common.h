@@ -49,6 +49,18 @@ inline GridDev to_dev(const ocn_grid &g)
     return d;
 }
 
+// Read-only vectors indexed by a wave-uniform index (the stretched-z metrics Δzᵃᵃᶜ[k], Δzᵃᵃᶠ[k]): a pointer that reaches a kernel inside a
+// by-value struct is not known to be invariant, so the compiler loads through it with VECTOR memory instructions -- and every
+// `s_waitcnt vmcnt(0)` in front of such a value also waits for all the prefetches issued before it, which serialised the software
+// pipelines of the Bounded-z kernels (profiles/r03a_config4.md: 45-53 % of the wave cycles parked).  Reading through the CONSTANT address
+// space makes them scalar loads (s_load, lgkmcnt): no vector-memory ordering, no VGPRs.  The vectors are never written by a kernel.
+typedef const double __attribute__((address_space(4))) *ocn_const_ptr;
+__device__ __forceinline__ double uniform_load(const double *p, int idx) { return ((ocn_const_ptr)p)[idx]; }
+
+// Compiler-level fence for software pipelines: memory operations written above it are issued above it (the loads of the NEXT plane must
+// leave at the top of an iteration, not where the scheduler finds their first use).  No instruction is emitted.
+#define OCN_ISSUE_LOADS_HERE() asm volatile("" ::: "memory")
+
 // Parent-array layout of a field at location `loc` (bit0 x-face, bit1 y-face, bit2 z-face).
 struct Lay {
     int sx, sy, sz;       // parent extents

@@ -246,8 +246,8 @@ struct Metrics {
     double dx, dy, dz, Az;
     const double *dzc, *dzf;
     int Hz;
-    __device__ __forceinline__ double dzC(int k) const { return dzc ? dzc[k + Hz - 1] : dz; }
-    __device__ __forceinline__ double dzF(int k) const { return dzf ? dzf[k + Hz - 1] : dz; }
+    __device__ __forceinline__ double dzC(int k) const { return dzc ? ocn::uniform_load(dzc, k + Hz - 1) : dz; }
+    __device__ __forceinline__ double dzF(int k) const { return dzf ? ocn::uniform_load(dzf, k + Hz - 1) : dz; }
     __device__ __forceinline__ double Ax(int k) const { return dy * dzC(k); }  // Axᶠᶜᶜ = Δy*Δz
     __device__ __forceinline__ double Ay(int k) const { return dx * dzC(k); }  // Ayᶜᶠᶜ = Δx*Δz
 };

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(RB *(M / 8)) void rowfft_source_r2c_kernel(RowFFTAr
     const int j = active ? (int)(row % g.Ny) + 1 : 1, k = active ? (int)(row / g.Ny) + 1 : 1;
     const Lay L = make_lay(g, OCN_LOC_CCC);  // x, y periodic: same strides for every location
     // div at cells i, i+1 for i = 2 (t + T r) + 1 (1-based): divᶜᶜᶜ (divergence_operators.jl:16-19), then / dt
-    const double dzc = g.dzc ? g.dzc[k + g.Hz - 1] : g.dz;
+    const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
     const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy, rV = 1 / (Az * dzc);
     const bool flatz = g.tz == OCN_FLAT;
     cplx x[8];

@@ -750,6 +750,10 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
         const double wf_n = more ? pw[(long long)(k + 1) * s3] : 0.0;
         const double znew_n = (k + 1 < k_end) ? pc[(long long)(k + 4) * s3] : 0.0;
         const double gm = (writes && tf.sc.on && tf.sc.has_zeta) ? tf.sub.Gm[o] : 0.0;
+        // Everything above must be REQUESTED here: left alone, the scheduler sinks these loads to their first use -- behind the second
+        // barrier, a few hundred cycles before the next iteration waits for them -- and, vector-memory returns being in order, a late G⁻
+        // load in the epilogue then waits for the whole prefetch group (profiles/r03a_config4.md: 45 % of the wave cycles parked).
+        OCN_ISSUE_LOADS_HERE();
         const double ax = M.Ax(k), ay = M.Ay(k);
         const double fxw = (ax * uf) * bias_interp<P, false>([&](int m) { return sc[ly][lx + m]; }, i, Nx, uf > 0);
         const double fys = (ay * vf) * bias_interp<P, false>([&](int m) { return sc[ly + m][lx]; }, j, Ny, vf > 0);
