@@ -203,9 +203,11 @@ def latest_profile(pattern):
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True)
     for path in paths:
         try:
-            return os.path.relpath(path, ROOT), json.load(open(path))
+            d = json.load(open(path))
         except Exception:
             continue
+        if isinstance(d, dict) and "kernels" in d:  # (bench lines kept under profiles/ match the same patterns)
+            return os.path.relpath(path, ROOT), d
     return None, None
 
 

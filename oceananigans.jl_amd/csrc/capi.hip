@@ -19,7 +19,10 @@ void set_error(const char *fmt, ...)
     g_last_error = buf;
 }
 
-int validate_grid(const ocn_grid *g)
+// any_xy: the entry point has a direction-generic path (csrc/general.hip, fill_halos_general_kernel, the per-location layouts of the
+// steppers and pressure kernels) and accepts Bounded / Flat x and y; the others keep the Periodic (or partitioned) x, Periodic y
+// their kernels are written for
+static int validate_grid_impl(const ocn_grid *g, bool any_xy)
 {
     OCN_REQUIRE(g != nullptr, "grid is NULL");
     OCN_REQUIRE(g->Nx >= 1 && g->Ny >= 1 && g->Nz >= 1, "grid size must be positive, got (%d, %d, %d)", g->Nx, g->Ny, g->Nz);
@@ -33,8 +36,16 @@ int validate_grid(const ocn_grid *g)
         // halo must not exceed the interior (Grids/input_validation.jl: halo <= size)
         if (t[d] != OCN_FLAT) OCN_REQUIRE(H[d] <= N[d], "halo %d larger than size %d in dimension %d", H[d], N[d], d);
     }
-    if (!(g->tx == OCN_PERIODIC || g->tx == OCN_FULLY_CONNECTED) || g->ty != OCN_PERIODIC) {
+    if (!any_xy && (!(g->tx == OCN_PERIODIC || g->tx == OCN_FULLY_CONNECTED) || g->ty != OCN_PERIODIC)) {
         set_error("unsupported topology (%d, %d, %d): x must be Periodic (or FullyConnected), y Periodic", g->tx, g->ty, g->tz);
+        return OCN_ERR_UNSUPPORTED;
+    }
+    if (g->ty == OCN_FULLY_CONNECTED) {
+        set_error("only x is ever partitioned (slab decomposition)");
+        return OCN_ERR_UNSUPPORTED;
+    }
+    if (any_xy && (g->tx == OCN_BOUNDED || g->ty == OCN_BOUNDED || g->tx == OCN_FLAT || g->ty == OCN_FLAT) && g->tx == OCN_FULLY_CONNECTED) {
+        set_error("a partitioned x needs a Periodic y");
         return OCN_ERR_UNSUPPORTED;
     }
     if (g->tz == OCN_FULLY_CONNECTED) {
@@ -45,14 +56,19 @@ int validate_grid(const ocn_grid *g)
     OCN_REQUIRE(g->dx > 0 && g->dy > 0 && (g->dzc || g->dz > 0), "spacings must be positive");
     return OCN_SUCCESS;
 }
+int validate_grid(const ocn_grid *g) { return validate_grid_impl(g, false); }
+int validate_grid_any(const ocn_grid *g) { return validate_grid_impl(g, true); }
+// x and y Periodic (x possibly partitioned): the tiled / shared-layout kernels apply; otherwise the direction-generic ones
+static bool xy_periodic(const ocn_grid *g) { return (g->tx == OCN_PERIODIC || g->tx == OCN_FULLY_CONNECTED) && g->ty == OCN_PERIODIC; }
 
 // WENO5 reads 3 halo cells (nonhydrostatic_model.jl:183, 243-257 inflates the halo to >= 3)
 static int validate_weno(const ocn_grid *g)
 {
-    int st = validate_grid(g);
+    int st = validate_grid_any(g);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(g->Hx >= 3 && g->Hy >= 3 && (g->tz == OCN_FLAT || g->Hz >= 3), "WENO(order=5) needs halo >= 3, got (%d, %d, %d)", g->Hx, g->Hy, g->Hz);
-    OCN_REQUIRE(g->Nx >= 3 && g->Ny >= 3 && (g->tz == OCN_FLAT || g->Nz >= 3),
+    OCN_REQUIRE((g->tx == OCN_FLAT || g->Hx >= 3) && (g->ty == OCN_FLAT || g->Hy >= 3) && (g->tz == OCN_FLAT || g->Hz >= 3),
+                "WENO(order=5) needs halo >= 3, got (%d, %d, %d)", g->Hx, g->Hy, g->Hz);
+    OCN_REQUIRE((g->tx == OCN_FLAT || g->Nx >= 3) && (g->ty == OCN_FLAT || g->Ny >= 3) && (g->tz == OCN_FLAT || g->Nz >= 3),
                 "grid too small for WENO(order=5): adapt_advection_order would lower the order (adapt_advection_order.jl:101-108)");
     return OCN_SUCCESS;
 }
@@ -150,11 +166,12 @@ static int make_field_tuple(const ocn_grid *grid, double *const *fields, const i
 int ocn_fill_halo_regions(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n,
                           int32_t fill_boundary_normal_velocities, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     FieldTuple ft;
     st = make_field_tuple(grid, fields, locs, n, ft);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) return launch_fill_halos_general(grid, ft, fill_boundary_normal_velocities, as_stream(stream));
     return launch_fill_halos(grid, ft, fill_boundary_normal_velocities, -1, as_stream(stream));
 }
 
@@ -177,6 +194,9 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
     int st = validate_weno(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies: null field pointer");
+    if (!xy_periodic(grid))
+        return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
+                                              : ocn_fast::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
     if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, as_stream(stream));
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, as_stream(stream));
 }
@@ -192,6 +212,10 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw && u_out && v_out && w_out, "ocn_compute_momentum_tendencies_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_rk3: G⁻ pointers are required when has_zeta != 0");
     OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_rk3: outputs must not alias the inputs");
+    if (!xy_periodic(grid)) {
+        set_error("the fused stage boundaries need Periodic x and y: use ocn_compute_momentum_tendencies + ocn_rk3_substep on this grid");
+        return OCN_ERR_UNSUPPORTED;
+    }
     FuseArgs fz;
     fz.Gm[0] = Gmu; fz.Gm[1] = Gmv; fz.Gm[2] = Gmw;
     fz.Uo[0] = u_out; fz.Uo[1] = v_out; fz.Uo[2] = w_out;
@@ -234,9 +258,10 @@ static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
         OCN_REQUIRE(t->S != nullptr, "buoyancy formulation %d needs the S tracer", t->buoyancy);
     OCN_REQUIRE(!t->pHY || t->buoyancy != OCN_BUOYANCY_NONE, "a hydrostatic pressure anomaly exists only with buoyancy (nonhydrostatic_model.jl:143-158)");
     if (t->advection != OCN_ADVECTION_CENTERED2) return validate_weno(grid);  // UpwindBiased(order=5): same halo / size needs
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "Centered(order=2) and the closure stencils need halo >= 1");
+    OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && (grid->tz == OCN_FLAT || grid->Hz >= 1),
+                "Centered(order=2) and the closure stencils need halo >= 1");
     return OCN_SUCCESS;
 }
 
@@ -245,6 +270,14 @@ static int launch_advective_momentum(int advection, const ocn_grid *grid, const 
                                      double *Gv, double *Gw, const int32_t *range, hipStream_t s)
 {
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    if (!xy_periodic(grid)) {  // direction-generic kernels (csrc/general.hip)
+        const int c2 = advection == OCN_ADVECTION_CENTERED2;
+        if (advection == OCN_ADVECTION_UPWIND5)
+            return strict ? ocn_strict_up::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, s)
+                          : ocn_fast_up::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, s);
+        return strict ? ocn_strict::launch_momentum_tendencies_general(grid, c2, u, v, w, Gu, Gv, Gw, range, s)
+                      : ocn_fast::launch_momentum_tendencies_general(grid, c2, u, v, w, Gu, Gv, Gw, range, s);
+    }
     switch (advection) {
         case OCN_ADVECTION_WENO5:
             return strict ? ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, s)
@@ -261,6 +294,18 @@ static int launch_advective_tracer(int advection, const ocn_grid *grid, const do
                                    double *Gc, const int32_t *range, hipStream_t s, const TracerFuse *tf)
 {
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    if (!xy_periodic(grid)) {
+        if (tf) {
+            set_error("the fused tracer stage boundary needs Periodic x and y");
+            return OCN_ERR_UNSUPPORTED;
+        }
+        const int c2 = advection == OCN_ADVECTION_CENTERED2;
+        if (advection == OCN_ADVECTION_UPWIND5)
+            return strict ? ocn_strict_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s)
+                          : ocn_fast_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s);
+        return strict ? ocn_strict::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s)
+                      : ocn_fast::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s);
+    }
     switch (advection) {
         case OCN_ADVECTION_WENO5:
             return strict ? ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf) : ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, s, tf);
@@ -278,13 +323,16 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies_terms: null field pointer");
-    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
     const bool strict = (g_math_mode == OCN_MATH_STRICT);
     hipStream_t s = as_stream(stream);
     st = launch_advective_momentum(terms->advection, grid, u, v, w, Gu, Gv, Gw, range, s);
     if (st != OCN_SUCCESS) return st;
     if (!(terms->coriolis || terms->closure || terms->buoyancy)) return OCN_SUCCESS;
     TermsDev t = to_dev(*terms);
+    if (!xy_periodic(grid))
+        return strict ? ocn_strict::launch_momentum_extra_general(grid, t, u, v, w, Gu, Gv, Gw, range, s)
+                      : ocn_fast::launch_momentum_extra_general(grid, t, u, v, w, Gu, Gv, Gw, range, s);
     return strict ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s)
                   : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, s);
 }
@@ -402,6 +450,9 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
     st = launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, nullptr);
     if (st != OCN_SUCCESS || !terms->closure) return st;
     OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
+    if (!xy_periodic(grid))
+        return strict ? ocn_strict::launch_tracer_diffusion_general(grid, kappa, kappa_e, c, Gc, range, s)
+                      : ocn_fast::launch_tracer_diffusion_general(grid, kappa, kappa_e, c, Gc, range, s);
     return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s)
                   : ocn_fast::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s);
 }
@@ -552,6 +603,10 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) {
+        set_error("ocn_compute_momentum_tendencies_terms_rk3: the fused stage boundaries need Periodic x and y");
+        return OCN_ERR_UNSUPPORTED;
+    }
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw && u_out && v_out && w_out, "ocn_compute_momentum_tendencies_terms_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_terms_rk3: G⁻ pointers are required when has_zeta != 0");
     OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_terms_rk3: outputs must not alias the inputs");
@@ -580,6 +635,10 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) {
+        set_error("ocn_compute_tracer_tendency_terms_rk3: the fused stage boundaries need Periodic x and y");
+        return OCN_ERR_UNSUPPORTED;
+    }
     OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
     OCN_REQUIRE(u && v && w && c && Gc && c_out, "ocn_compute_tracer_tendency_terms_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || Gmc, "ocn_compute_tracer_tendency_terms_rk3: G⁻ is required when has_zeta != 0");
@@ -604,6 +663,10 @@ int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_m
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) {
+        set_error("ocn_compute_tracer_pair_tendency_terms_rk3: the fused stage boundaries need Periodic x and y");
+        return OCN_ERR_UNSUPPORTED;
+    }
     OCN_REQUIRE(launched, "ocn_compute_tracer_pair_tendency_terms_rk3: launched is NULL");
     *launched = 0;
     OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_pair_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
@@ -758,11 +821,30 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
                               const ocn_field_bcs *const *bcs, int32_t n, int32_t fill_boundary_normal_velocities,
                               void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     FieldTuple ft;
     st = make_field_tuple(grid, fields, locs, n, ft);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) {  // every side may carry a condition (fill_halo_regions_value_gradient.jl for west / east / south / north too)
+        SideBcTuple sb{};
+        bool any = false;
+        const int T[3] = {grid->tx, grid->ty, grid->tz};
+        for (int f = 0; f < n; ++f) {
+            if (!bcs || !bcs[f]) continue;
+            const ocn_bc *side[6] = {&bcs[f]->west, &bcs[f]->east, &bcs[f]->south, &bcs[f]->north, &bcs[f]->bottom, &bcs[f]->top};
+            for (int q = 0; q < 6; ++q) {
+                const ocn_bc &c = *side[q];
+                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+                if (c.kind == OCN_BC_DEFAULT) continue;
+                OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
+                OCN_REQUIRE(!((locs[f] >> (q / 2)) & 1), "field %d: the wall-normal velocity keeps its impenetrable condition", f);
+                sb.side[q][f] = ZBc{c.kind, c.value, c.coeff, c.values};
+                any = true;
+            }
+        }
+        return launch_fill_halos_general(grid, ft, fill_boundary_normal_velocities, as_stream(stream), any ? &sb : nullptr);
+    }
     ZBcTuple z;
     bool any;
     st = make_zbc_tuple(grid, locs, bcs, n, z, false, any);
@@ -794,6 +876,9 @@ int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const dou
     int st = validate_weno(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency: null field pointer");
+    if (!xy_periodic(grid))
+        return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, as_stream(stream))
+                                              : ocn_fast::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, as_stream(stream));
     if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
     return ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
 }
@@ -817,7 +902,7 @@ static int make_step_tuple(int32_t n, double *const *U, const double *const *Gn,
 int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
                     const int32_t *locs, double dt, double gamma, double zeta, int32_t has_zeta, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     StepTuple t;
     st = make_step_tuple(n, U, Gn, const_cast<double *const *>(reinterpret_cast<const double *const *>(Gm)), locs, true, t);
@@ -828,7 +913,7 @@ int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const dou
 int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
                  const int32_t *locs, double dt, double chi, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     StepTuple t;
     st = make_step_tuple(n, U, Gn, const_cast<double *const *>(reinterpret_cast<const double *const *>(Gm)), locs, true, t);
@@ -840,7 +925,7 @@ int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double
 int ocn_cache_previous_tendencies(const ocn_grid *grid, int32_t n, double *const *Gm, const double *const *Gn,
                                   const int32_t *locs, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     StepTuple t;
     st = make_step_tuple(n, nullptr, Gn, Gm, locs, false, t);
@@ -850,16 +935,17 @@ int ocn_cache_previous_tendencies(const ocn_grid *grid, int32_t n, double *const
 
 int ocn_pressure_correct_velocities(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && p, "ocn_pressure_correct_velocities: null field pointer");
-    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "pressure correction needs halo >= 1");
+    OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && (grid->tz == OCN_FLAT || grid->Hz >= 1),
+                "pressure correction needs halo >= 1");
     return launch_pressure_correct(grid, u, v, w, p, dt, as_stream(stream));
 }
 
 int ocn_divergence(const ocn_grid *grid, const double *u, const double *v, const double *w, double *div, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && div, "ocn_divergence: null pointer");
     return launch_source_term(grid, u, v, w, 1.0, 0, div, grid->Nx, (long long)grid->Nx * grid->Ny, as_stream(stream));

@@ -225,61 +225,6 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     }
 }
 
-// The fused pass (MODE 2) as a PERSISTENT kernel: a workgroup walks over column sets  blockIdx.x, blockIdx.x + gridDim.x, ...  and
-// requests the 8 values per thread of its NEXT set before it starts the two transforms of the current one, so the HBM reads of a set
-// fly under ~8 barrier phases of LDS / VALU work of the previous set instead of being waited for at the top of each workgroup
-// (the one-shot kernel reaches 3.1 TB/s where the single-transform passes reach 4.6, profiles/r02e_512.md).  Same arithmetic in the
-// same order: bit-identical results.
-template <int N, int CB, int MINW>
-__global__ __launch_bounds__(CB *(N / 8), MINW) void colfft_fused_persistent_kernel(ColFFTArgs a, int nsets)
-{
-    constexpr int T = N / 8;
-    extern __shared__ double lds_raw[];
-    cplx *A = reinterpret_cast<cplx *>(lds_raw);
-    cplx *W = reinterpret_cast<cplx *>(lds_raw) + N * CB;
-    const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
-    const int batch = blockIdx.y;
-    for (int j = tid; j < N; j += CB * T) W[j] = reinterpret_cast<const cplx *>(a.tw)[j];
-    cplx *const base0 = reinterpret_cast<cplx *>(a.data) + (long long)batch * a.batch_stride;
-    auto load = [&](int set, cplx *x) {
-        const int col = set * CB + c;
-        const bool act = col < a.ncols;
-        const cplx *b = base0 + (act ? col : 0);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = act ? b[(long long)(t + T * r) * a.col_stride] : cplx{0, 0};
-    };
-    cplx x[8], xn[8];
-    int set = blockIdx.x;
-    if (set < nsets) load(set, x);
-    for (; set < nsets; set += gridDim.x) {
-        const int next = set + gridDim.x;
-        if (next < nsets) load(next, xn);  // in flight during this set's transforms
-        fft_fwd_stages<N, CB>(x, A, W, c, t);
-        const int col = set * CB + c;
-        const bool active = col < a.ncols;
-        const double lxy = active ? a.lx[col % a.inner] + a.ly[col / a.inner] : 1.0;
-        const bool zero_col = a.zero_mode && (col == 0) && (batch == 0);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int p = 8 * t + m;
-            const double lam = lxy + a.lc[p];
-            double sc = -a.scale / lam;
-            if (zero_col && p == 0) sc = 0.0;
-            x[m].x *= sc;
-            x[m].y *= sc;
-        }
-        fft_inv_stages<N, CB>(x, A, W, c, t);
-        if (active) {
-            cplx *b = base0 + col;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) b[(long long)(t + T * r) * a.col_stride] = x[r];
-        }
-        __syncthreads();  // the exchange buffer is free again
-#pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = xn[r];
-    }
-}
-
 bool colfft_supported(int N) { return N == 64 || N == 128 || N == 256 || N == 512; }
 
 // stored position p -> true wavenumber k for the stage order produced by the forward kernel
@@ -314,34 +259,10 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((colfft_kernel<N, CB, 1>), grid, block, lds, stream, a);
     } else {
-        // OCN_COLFFT_PERSIST = k > 0: the persistent variant with k workgroups per CU-slot (see colfft_fused_persistent_kernel)
-        static const int persist = getenv("OCN_COLFFT_PERSIST") ? atoi(getenv("OCN_COLFFT_PERSIST")) : 0;
-        const int nsets = (a.ncols + CB - 1) / CB;
-        if (persist > 0 && N >= 256) {
-            // MINW (waves per SIMD the build targets): 2 = all registers (prefetch costs 32 VGPRs on top of ~100), one 512-thread workgroup per CU;
-            // 4 = two workgroups per CU with spills.  OCN_COLFFT_PERSIST_MINW selects.
-            static const int minw = getenv("OCN_COLFFT_PERSIST_MINW") ? atoi(getenv("OCN_COLFFT_PERSIST_MINW")) : 2;
-            const int waves = CB * (N / 8) / 64;
-            int per_cu = (int)((160 * 1024) / lds);
-            if (per_cu * waves > 4 * minw) per_cu = 4 * minw / waves;
-            if (per_cu < 1) per_cu = 1;
-            int wgs = 256 * per_cu * persist / (a.nbatch > 0 ? a.nbatch : 1);
-            if (wgs < 1) wgs = 1;
-            if (wgs > nsets) wgs = nsets;
-#define OCN_PERSIST_LAUNCH(MW)                                                                                                       \
-    do {                                                                                                                             \
-        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_fused_persistent_kernel<N, CB, MW>,                                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
-        hipLaunchKernelGGL((colfft_fused_persistent_kernel<N, CB, MW>), dim3(wgs, a.nbatch), block, lds, stream, a, nsets);           \
-    } while (0)
-            if (minw >= 4) OCN_PERSIST_LAUNCH(4);
-            else if (minw == 3) OCN_PERSIST_LAUNCH(3);
-            else OCN_PERSIST_LAUNCH(2);
-#undef OCN_PERSIST_LAUNCH
-        } else {
-            OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((colfft_kernel<N, CB, 2>), grid, block, lds, stream, a);
-        }
+        // (measured and rejected, round 3: a persistent variant that requests the next column set's values before transforming the current
+        //  one -- 2.93 ms per 512^3 solve at 166 VGPRs / one workgroup per CU, 3.17 ms with the registers capped for two, against 2.85 ms)
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_kernel<N, CB, 2>), grid, block, lds, stream, a);
     }
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;

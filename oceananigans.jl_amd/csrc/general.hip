@@ -1,0 +1,453 @@
+// general.hip -- the tendency kernels on grids with a Bounded or Flat x / y direction.
+//
+// The production kernels (tendencies.hip, physics.hip) assume Periodic x, y: every staggered location then shares ONE parent layout and
+// no x / y stencil ever meets a wall.  On (Periodic, Bounded, Bounded), (Bounded, Bounded, Bounded), (Periodic, Flat, Bounded) ... grids
+//   * Face-located fields have N + 1 + 2H points along a Bounded direction (grid_utils.jl:66-72): u, v, w, c have different strides;
+//   * reconstructions lose order near the walls (topologically_conditional_interpolation.jl:37-128) in x and y too;
+//   * interpolation along a Flat direction is the identity and differences / fluxes through it vanish
+//     (flat_advective_fluxes.jl:8-44, difference_operators.jl:33-49, interpolation_operators.jl:103-110);
+//   * Face-located fields skip their first index in a Bounded direction (launch!(...; exclude_periphery = true),
+//     kernel_launching.jl:113-161);
+//   * the Coriolis term averages over ACTIVE nodes only (active_weighted_ℑxy, interpolation_operators.jl:121-131).
+// These kernels are direction-generic, one thread per cell, topologies read at run time (they are uniform over a launch): correctness and
+// coverage first (every reference example on a closed box or an x-z slice runs), not the roofline -- the BASELINE configurations are
+// all (Periodic, Periodic, .) and keep the tiled kernels.  Strict build: the operand order of the reference's kernel functions
+// (nonhydrostatic_tendency_kernel_functions.jl:47-259, momentum_advection_operators.jl:46-83, closure_kernel_operators.jl:27-53),
+// bit-identical to the CPU oracle.
+//
+// Compiled twice like tendencies.hip (namespaces via ocn_weno.h): strict / fast, WENO5 or UpwindBiased(order = 5).
+#include "ocn_weno.h"
+
+namespace OCN_NS {
+
+using ocn::GridDev;
+using ocn::Lay;
+
+namespace gen {
+
+// topologically conditional interpolation with the topology as a run-time value (ocn_weno.h: sym_interp / bias_interp)
+template <bool CENTER, class V>
+__device__ __forceinline__ double sym_rt(int topo, V val, int idx, int N)
+{
+    if (topo == OCN_FLAT) return val(CENTER ? -1 : 0);
+    if (topo == OCN_BOUNDED) {
+        const bool hi = CENTER ? (idx >= 3 && idx <= N + 1 - 3) : (idx >= 4 && idx <= N + 1 - 3);
+        if (!hi) return 0.5 * val(-1) + 0.5 * val(0);
+    }
+    return centered4(val(-2), val(-1), val(0), val(1));
+}
+
+template <bool CENTER, class V>
+__device__ __forceinline__ double bias_rt(int topo, V val, int idx, int N, bool left)
+{
+    if (topo == OCN_FLAT) return val(CENTER ? -1 : 0);
+    if (topo == OCN_BOUNDED) {
+        bool ok5, ok3;
+        if (CENTER) {
+            ok5 = (idx >= 3) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 2) && (idx <= N + 1 - 2);
+        } else {
+            ok5 = (idx >= 4) && (idx <= N + 1 - 3);
+            ok3 = (idx >= 3) && (idx <= N + 1 - 2);
+        }
+        if (!ok5) {
+            if (ok3) return weno3(val(-2), val(-1), val(0), val(1), left);
+            return left ? val(-1) : val(0);
+        }
+    }
+    return weno5(val(-3), val(-2), val(-1), val(0), val(1), val(2), left);
+}
+
+// Centered(order = 2): no topology conditions (a "low order" scheme); the value itself along a Flat direction
+template <bool CENTER, class V>
+__device__ __forceinline__ double c2_rt(int topo, V val)
+{
+    if (topo == OCN_FLAT) return val(CENTER ? -1 : 0);
+    return 0.5 * val(-1) + 0.5 * val(0);
+}
+
+struct Fields {
+    GridDev g;
+    const double *u, *v, *w;
+    Lay Lu, Lv, Lw, Lc;
+    int centered2;  // advection = Centered(order = 2) instead of the build's upwind scheme
+};
+
+__device__ __forceinline__ int topo_of(const GridDev &g, int d) { return d == 0 ? g.tx : d == 1 ? g.ty : g.tz; }
+__device__ __forceinline__ int size_of(const GridDev &g, int d) { return d == 0 ? g.Nx : d == 1 ? g.Ny : g.Nz; }
+__device__ __forceinline__ long long stride_of(const Lay &L, int d) { return d == 0 ? 1 : d == 1 ? L.s2 : L.s3; }
+
+// One momentum flux  U~ * psi^R  (upwind_biased_advective_fluxes.jl:23-93; centered_advective_fluxes.jl:7-17):
+//   advecting component CA interpolated along DA (to the centre when ACEN), advected component CB interpolated along DB.
+template <int CA, int DA, bool ACEN, int CB, int DB, bool BCEN>
+__device__ __forceinline__ double mom_flux(const Fields &F, const Metrics &M, int i, int j, int k)
+{
+    const GridDev &g = F.g;
+    if (topo_of(g, CA) == OCN_FLAT) return 0.0;  // the flux THROUGH a Flat direction is zero (flat_advective_fluxes.jl:8-22)
+    const double *fa = CA == 0 ? F.u : CA == 1 ? F.v : F.w;
+    const double *fb = CB == 0 ? F.u : CB == 1 ? F.v : F.w;
+    const Lay &La = CA == 0 ? F.Lu : CA == 1 ? F.Lv : F.Lw;
+    const Lay &Lb = CB == 0 ? F.Lu : CB == 1 ? F.Lv : F.Lw;
+    const int ijk[3] = {i, j, k};
+    int qa[3] = {i, j, k}, qb[3] = {i, j, k};
+    if (ACEN) qa[DA] += 1;  // symmetric_interpolate_*ᶜ: the line shifted to face idx + 1
+    if (BCEN) qb[DB] += 1;
+    const double *pa = fa + ocn::at(La, qa[0], qa[1], qa[2]);
+    const double *pb = fb + ocn::at(Lb, qb[0], qb[1], qb[2]);
+    const long long sa = stride_of(La, DA), sb = stride_of(Lb, DB);
+    const int ka = qa[2];
+    if (F.centered2) {
+        // A(flux location) * sym(U) * sym(u), left-associated; the area is NOT inside the interpolation
+        const double ua = c2_rt<ACEN>(topo_of(g, DA), [&](int m) { return pa[m * sa]; });
+        const double ub = c2_rt<BCEN>(topo_of(g, DB), [&](int m) { return pb[m * sb]; });
+        const bool zf = (CB == 2 && CA != 2);  // z-location of the flux: Face for Uw, Vw
+        const double dzk = zf ? M.dzF(k) : M.dzC(k);
+        const double area = CA == 0 ? M.dy * dzk : CA == 1 ? M.dx * dzk : M.Az;
+        return (area * ua) * ub;
+    }
+    double ut;
+    if (CA == 2) {
+        const double a = M.Az;
+        ut = sym_rt<ACEN>(topo_of(g, DA), [&](int m) { return a * pa[m * sa]; }, ijk[DA], size_of(g, DA));
+    } else if (DA == 2) {  // the line runs along z: the area changes along it
+        ut = sym_rt<ACEN>(topo_of(g, DA), [&](int m) { return (CA == 0 ? M.Ax(ka + m) : M.Ay(ka + m)) * pa[m * sa]; }, ijk[DA], size_of(g, DA));
+    } else {
+        const double a = CA == 0 ? M.Ax(ka) : M.Ay(ka);
+#if OCN_STRICT
+        ut = sym_rt<ACEN>(topo_of(g, DA), [&](int m) { return a * pa[m * sa]; }, ijk[DA], size_of(g, DA));
+#else
+        ut = a * sym_rt<ACEN>(topo_of(g, DA), [&](int m) { return pa[m * sa]; }, ijk[DA], size_of(g, DA));
+#endif
+    }
+    const double pr = bias_rt<BCEN>(topo_of(g, DB), [&](int m) { return pb[m * sb]; }, ijk[DB], size_of(g, DB), ut > 0);
+    return ut * pr;
+}
+
+// tracer flux through face (i, j, k) of direction D:  (A * U) * cR  (upwind_biased_advective_fluxes.jl:99-121)
+template <int D>
+__device__ __forceinline__ double tracer_flux(const Fields &F, const Metrics &M, const double *__restrict__ c, int i, int j, int k)
+{
+    const GridDev &g = F.g;
+    if (topo_of(g, D) == OCN_FLAT) return 0.0;
+    const double *fa = D == 0 ? F.u : D == 1 ? F.v : F.w;
+    const Lay &La = D == 0 ? F.Lu : D == 1 ? F.Lv : F.Lw;
+    const double ut = fa[ocn::at(La, i, j, k)];
+    const double *pc = c + ocn::at(F.Lc, i, j, k);
+    const long long sc = stride_of(F.Lc, D);
+    const int ijk[3] = {i, j, k};
+    const double area = D == 0 ? M.Ax(k) : D == 1 ? M.Ay(k) : M.Az;
+    if (F.centered2) return (area * ut) * c2_rt<false>(topo_of(g, D), [&](int m) { return pc[m * sc]; });
+    const double cr = bias_rt<false>(topo_of(g, D), [&](int m) { return pc[m * sc]; }, ijk[D], size_of(g, D), ut > 0);
+    return (area * ut) * cr;
+}
+
+struct GRange {
+    int i0, i1, j0, j1, k0, k1;
+    int ou, ov, ow;  // first index written for Gu (in i), Gv (in j), Gw (in k)
+};
+
+}  // namespace gen
+
+// compute_Gu! / Gv! / Gw!: G = -div_𝐯u etc. (momentum_advection_operators.jl:46-83)
+__global__ __launch_bounds__(256) void momentum_tendencies_general(gen::Fields F, double *__restrict__ Gu, double *__restrict__ Gv,
+                                                                   double *__restrict__ Gw, gen::GRange r)
+{
+    using namespace gen;
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const GridDev &g = F.g;
+    const Metrics M = make_metrics(g);
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT, fz = g.tz == OCN_FLAT;
+    if (i >= r.ou) {  // Gu at (f,c,c)
+        const double dxF = fx ? 0.0 : mom_flux<0, 0, true, 0, 0, true>(F, M, i, j, k) - mom_flux<0, 0, true, 0, 0, true>(F, M, i - 1, j, k);
+        const double dyF = fy ? 0.0 : mom_flux<1, 0, false, 0, 1, false>(F, M, i, j + 1, k) - mom_flux<1, 0, false, 0, 1, false>(F, M, i, j, k);
+        const double dzF = fz ? 0.0 : mom_flux<2, 0, false, 0, 2, false>(F, M, i, j, k + 1) - mom_flux<2, 0, false, 0, 2, false>(F, M, i, j, k);
+        const double rV = 1 / (M.Az * M.dzC(k));
+        Gu[ocn::at(F.Lu, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+    }
+    if (j >= r.ov) {  // Gv at (c,f,c)
+        const double dxF = fx ? 0.0 : mom_flux<0, 1, false, 1, 0, false>(F, M, i + 1, j, k) - mom_flux<0, 1, false, 1, 0, false>(F, M, i, j, k);
+        const double dyF = fy ? 0.0 : mom_flux<1, 1, true, 1, 1, true>(F, M, i, j, k) - mom_flux<1, 1, true, 1, 1, true>(F, M, i, j - 1, k);
+        const double dzF = fz ? 0.0 : mom_flux<2, 1, false, 1, 2, false>(F, M, i, j, k + 1) - mom_flux<2, 1, false, 1, 2, false>(F, M, i, j, k);
+        const double rV = 1 / (M.Az * M.dzC(k));
+        Gv[ocn::at(F.Lv, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+    }
+    if (k >= r.ow) {  // Gw at (c,c,f)
+        const double dxF = fx ? 0.0 : mom_flux<0, 2, false, 2, 0, false>(F, M, i + 1, j, k) - mom_flux<0, 2, false, 2, 0, false>(F, M, i, j, k);
+        const double dyF = fy ? 0.0 : mom_flux<1, 2, false, 2, 1, false>(F, M, i, j + 1, k) - mom_flux<1, 2, false, 2, 1, false>(F, M, i, j, k);
+        const double dzF = fz ? 0.0 : mom_flux<2, 2, true, 2, 2, true>(F, M, i, j, k) - mom_flux<2, 2, true, 2, 2, true>(F, M, i, j, k - 1);
+        const double rV = 1 / (M.Az * M.dzF(k));
+        Gw[ocn::at(F.Lw, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+    }
+}
+
+// compute_Gc!: Gc = -div_Uc (tracer_advection_operators.jl:30-34)
+__global__ __launch_bounds__(256) void tracer_tendency_general(gen::Fields F, const double *__restrict__ c, double *__restrict__ Gc, gen::GRange r)
+{
+    using namespace gen;
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const GridDev &g = F.g;
+    const Metrics M = make_metrics(g);
+    const double dxF = g.tx == OCN_FLAT ? 0.0 : tracer_flux<0>(F, M, c, i + 1, j, k) - tracer_flux<0>(F, M, c, i, j, k);
+    const double dyF = g.ty == OCN_FLAT ? 0.0 : tracer_flux<1>(F, M, c, i, j + 1, k) - tracer_flux<1>(F, M, c, i, j, k);
+    const double dzF = g.tz == OCN_FLAT ? 0.0 : tracer_flux<2>(F, M, c, i, j, k + 1) - tracer_flux<2>(F, M, c, i, j, k);
+    const double rV = 1 / (M.Az * M.dzC(k));
+    Gc[ocn::at(F.Lc, i, j, k)] = -(rV * ((dxF + dyF) + dzF));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The non-advective terms, ADDED to G in the reference's order  ((((-div𝐯u) + gb) - f×U) - ∇pHY′) - ∂ⱼτᵢⱼ
+// (nonhydrostatic_tendency_kernel_functions.jl:47-200): FPlane Coriolis with active-node weighting, the hydrostatic pressure gradient,
+// z_dot_g_b without a separate pHY′, the isotropic viscous stress divergence with ν a number or the eddy viscosity νₑ.
+// ---------------------------------------------------------------------------------------------------
+struct ExtraArgs {
+    ocn::TermsDev t;
+    const double *nu_e;
+};
+
+__device__ __forceinline__ double gen_buoyancy(const ocn::TermsDev &t, long long a)
+{
+    switch (t.buoyancy) {
+        case OCN_BUOYANCY_TRACER: return t.T[a];
+        case OCN_BUOYANCY_SEAWATER_TS: return t.g * (t.alpha * t.T[a] - t.beta * t.S[a]);
+        case OCN_BUOYANCY_SEAWATER_T: return t.g * t.alpha * t.T[a];
+        case OCN_BUOYANCY_SEAWATER_S: return -t.g * t.beta * t.S[a];
+        default: return 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn::TermsDev t, double *__restrict__ Gu, double *__restrict__ Gv,
+                                                              double *__restrict__ Gw, gen::GRange r)
+{
+    using namespace gen;
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const GridDev &g = F.g;
+    const Metrics M = make_metrics(g);
+    const Lay &Lu = F.Lu, &Lv = F.Lv, &Lw = F.Lw, &Lc = F.Lc;
+    const double *u = F.u, *v = F.v, *w = F.w, *nu_e = t.nu_e;
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT, fz = g.tz == OCN_FLAT;
+    const double dx = M.dx, dy = M.dy, nu = t.nu;
+#define U_(a, b, c) u[ocn::at(Lu, a, b, c)]
+#define V_(a, b, c) v[ocn::at(Lv, a, b, c)]
+#define W_(a, b, c) w[ocn::at(Lw, a, b, c)]
+#define NE(a, b, c) nu_e[ocn::at(Lc, a, b, c)]
+    // derivative operators (derivative_operators.jl:20-30); a difference along a Flat direction is 0
+    auto DXU_C = [&](int a, int b, int c) { return fx ? 0.0 : (U_(a + 1, b, c) - U_(a, b, c)) / dx; };
+    auto DYV_C = [&](int a, int b, int c) { return fy ? 0.0 : (V_(a, b + 1, c) - V_(a, b, c)) / dy; };
+    auto DZW_C = [&](int a, int b, int c) { return fz ? 0.0 : (W_(a, b, c + 1) - W_(a, b, c)) / M.dzC(c); };
+    auto DYU_FF = [&](int a, int b, int c) { return fy ? 0.0 : (U_(a, b, c) - U_(a, b - 1, c)) / dy; };
+    auto DXV_FF = [&](int a, int b, int c) { return fx ? 0.0 : (V_(a, b, c) - V_(a - 1, b, c)) / dx; };
+    auto DZU_FF = [&](int a, int b, int c) { return fz ? 0.0 : (U_(a, b, c) - U_(a, b, c - 1)) / M.dzF(c); };
+    auto DXW_FF = [&](int a, int b, int c) { return fx ? 0.0 : (W_(a, b, c) - W_(a - 1, b, c)) / dx; };
+    auto DZV_FF = [&](int a, int b, int c) { return fz ? 0.0 : (V_(a, b, c) - V_(a, b, c - 1)) / M.dzF(c); };
+    auto DYW_FF = [&](int a, int b, int c) { return fy ? 0.0 : (W_(a, b, c) - W_(a, b - 1, c)) / dy; };
+    // viscosity at the stress locations (abstract_scalar_diffusivity_closure.jl:291-296)
+    auto NU_C = [&](int a, int b, int c) { return nu_e ? NE(a, b, c) : nu; };
+    auto NU_FFC = [&](int a, int b, int c) { return nu_e ? 0.5 * (0.5 * (NE(a - 1, b - 1, c) + NE(a, b - 1, c)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu; };
+    auto NU_FCF = [&](int a, int b, int c) { return nu_e ? 0.5 * (0.5 * (NE(a - 1, b, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a - 1, b, c) + NE(a, b, c))) : nu; };
+    auto NU_CFF = [&](int a, int b, int c) { return nu_e ? 0.5 * (0.5 * (NE(a, b - 1, c - 1) + NE(a, b, c - 1)) + 0.5 * (NE(a, b - 1, c) + NE(a, b, c))) : nu; };
+    auto T11 = [&](int a, int b, int c) { return -2 * (NU_C(a, b, c) * DXU_C(a, b, c)); };
+    auto T22 = [&](int a, int b, int c) { return -2 * (NU_C(a, b, c) * DYV_C(a, b, c)); };
+    auto T33 = [&](int a, int b, int c) { return -2 * (NU_C(a, b, c) * DZW_C(a, b, c)); };
+    auto T12 = [&](int a, int b, int c) { return -2 * (NU_FFC(a, b, c) * (0.5 * (DYU_FF(a, b, c) + DXV_FF(a, b, c)))); };
+    auto T13 = [&](int a, int b, int c) { return -2 * (NU_FCF(a, b, c) * (0.5 * (DZU_FF(a, b, c) + DXW_FF(a, b, c)))); };
+    auto T23 = [&](int a, int b, int c) { return -2 * (NU_CFF(a, b, c) * (0.5 * (DZV_FF(a, b, c) + DYW_FF(a, b, c)))); };
+    // inactive_cell (Grids/inactive_node.jl:35-95) and the peripheral-node tests of the Coriolis average
+    auto inactive = [&](int a, int b, int c) {
+        bool q = false;
+        if (g.tx == OCN_BOUNDED) q |= (a < 1) | (a > g.Nx);
+        if (g.ty == OCN_BOUNDED) q |= (b < 1) | (b > g.Ny);
+        if (g.tz == OCN_BOUNDED) q |= (c < 1) | (c > g.Nz);
+        return q;
+    };
+    auto act_cfc = [&](int a, int b, int c) { return (inactive(a, b, c) || inactive(a, b - 1, c)) ? 0.0 : 1.0; };
+    auto act_fcc = [&](int a, int b, int c) { return (inactive(a, b, c) || inactive(a - 1, b, c)) ? 0.0 : 1.0; };
+    const double Axc = M.Ax(k), Ayc = M.Ay(k), Az = M.Az;
+    if (i >= r.ou) {
+        const long long o = ocn::at(Lu, i, j, k);
+        double G = Gu[o];
+        if (t.buoyancy) G = G + 0.0;
+        if (t.coriolis) {  // x_f_cross_U = -f * active_weighted_ℑxyᶠᶜᶜ(v)
+            auto IXF = [&](int jj) { return fx ? V_(i, jj, k) : 0.5 * (V_(i - 1, jj, k) + V_(i, jj, k)); };
+            auto IXFa = [&](int jj) { return fx ? act_cfc(i, jj, k) : 0.5 * (act_cfc(i - 1, jj, k) + act_cfc(i, jj, k)); };
+            const double an = fy ? IXFa(j) : 0.5 * (IXFa(j) + IXFa(j + 1));
+            const double vi = (an == 0) ? 0.0 : (fy ? IXF(j) : 0.5 * (IXF(j) + IXF(j + 1))) / an;
+            G = G - (-t.f * vi);
+        }
+        if (t.pHY) G = G - (fx ? 0.0 : (t.pHY[ocn::at(Lc, i, j, k)] - t.pHY[ocn::at(Lc, i - 1, j, k)]) / dx);
+        if (t.closure) {
+            const double dxF = fx ? 0.0 : Axc * T11(i, j, k) - Axc * T11(i - 1, j, k);
+            const double dyF = fy ? 0.0 : Ayc * T12(i, j + 1, k) - Ayc * T12(i, j, k);
+            const double dzF = fz ? 0.0 : Az * T13(i, j, k + 1) - Az * T13(i, j, k);
+            G = G - 1 / (Az * M.dzC(k)) * ((dxF + dyF) + dzF);
+        }
+        Gu[o] = G;
+    }
+    if (j >= r.ov) {
+        const long long o = ocn::at(Lv, i, j, k);
+        double G = Gv[o];
+        if (t.buoyancy) G = G + 0.0;
+        if (t.coriolis) {  // y_f_cross_U = f * active_weighted_ℑxyᶜᶠᶜ(u)
+            auto IXC = [&](int jj) { return fx ? U_(i, jj, k) : 0.5 * (U_(i, jj, k) + U_(i + 1, jj, k)); };
+            auto IXCa = [&](int jj) { return fx ? act_fcc(i, jj, k) : 0.5 * (act_fcc(i, jj, k) + act_fcc(i + 1, jj, k)); };
+            const double an = fy ? IXCa(j) : 0.5 * (IXCa(j - 1) + IXCa(j));
+            const double ui = (an == 0) ? 0.0 : (fy ? IXC(j) : 0.5 * (IXC(j - 1) + IXC(j))) / an;
+            G = G - t.f * ui;
+        }
+        if (t.pHY) G = G - (fy ? 0.0 : (t.pHY[ocn::at(Lc, i, j, k)] - t.pHY[ocn::at(Lc, i, j - 1, k)]) / dy);
+        if (t.closure) {
+            const double dxF = fx ? 0.0 : Axc * T12(i + 1, j, k) - Axc * T12(i, j, k);
+            const double dyF = fy ? 0.0 : Ayc * T22(i, j, k) - Ayc * T22(i, j - 1, k);
+            const double dzF = fz ? 0.0 : Az * T23(i, j, k + 1) - Az * T23(i, j, k);
+            G = G - 1 / (Az * M.dzC(k)) * ((dxF + dyF) + dzF);
+        }
+        Gv[o] = G;
+    }
+    if (k >= r.ow) {
+        const long long o = ocn::at(Lw, i, j, k);
+        double G = Gw[o];
+        if (t.buoyancy) {
+            double zb = 0.0;
+            if (!t.pHY) zb = fz ? gen_buoyancy(t, ocn::at(Lc, i, j, k))
+                                : 1 * (0.5 * (gen_buoyancy(t, ocn::at(Lc, i, j, k - 1)) + gen_buoyancy(t, ocn::at(Lc, i, j, k))));
+            G = G + zb;
+        }
+        if (t.coriolis) G = G - 0.0;
+        if (t.closure) {
+            const double Axf = dy * M.dzF(k), Ayf = dx * M.dzF(k);
+            const double dxF = fx ? 0.0 : Axf * T13(i + 1, j, k) - Axf * T13(i, j, k);
+            const double dyF = fy ? 0.0 : Ayf * T23(i, j + 1, k) - Ayf * T23(i, j, k);
+            const double dzF = fz ? 0.0 : Az * T33(i, j, k) - Az * T33(i, j, k - 1);
+            G = G - 1 / (Az * M.dzF(k)) * ((dxF + dyF) + dzF);
+        }
+        Gw[o] = G;
+    }
+#undef U_
+#undef V_
+#undef W_
+#undef NE
+}
+
+// Gc <- Gc - ∇_dot_qᶜ (closure_kernel_operators.jl:48-53), κ a number or the eddy diffusivity field interpolated to the faces
+__global__ __launch_bounds__(256) void tracer_diffusion_general(GridDev g, double kappa, const double *__restrict__ kappa_e,
+                                                                const double *__restrict__ c, double *__restrict__ Gc, gen::GRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const Metrics M = make_metrics(g);
+    const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT, fz = g.tz == OCN_FLAT;
+#define C_(a, b, cc) c[ocn::at(L, a, b, cc)]
+#define KE(a, b, cc) kappa_e[ocn::at(L, a, b, cc)]
+    auto QX = [&](int a, int b, int cc) { return -((kappa_e ? 0.5 * (KE(a - 1, b, cc) + KE(a, b, cc)) : kappa) * ((C_(a, b, cc) - C_(a - 1, b, cc)) / M.dx)); };
+    auto QY = [&](int a, int b, int cc) { return -((kappa_e ? 0.5 * (KE(a, b - 1, cc) + KE(a, b, cc)) : kappa) * ((C_(a, b, cc) - C_(a, b - 1, cc)) / M.dy)); };
+    auto QZ = [&](int a, int b, int cc) { return -((kappa_e ? 0.5 * (KE(a, b, cc - 1) + KE(a, b, cc)) : kappa) * ((C_(a, b, cc) - C_(a, b, cc - 1)) / M.dzF(cc))); };
+    const double Ax = M.Ax(k), Ay = M.Ay(k), Az = M.Az;
+    const double dxF = fx ? 0.0 : Ax * QX(i + 1, j, k) - Ax * QX(i, j, k);
+    const double dyF = fy ? 0.0 : Ay * QY(i, j + 1, k) - Ay * QY(i, j, k);
+    const double dzF = fz ? 0.0 : Az * QZ(i, j, k + 1) - Az * QZ(i, j, k);
+    const long long o = ocn::at(L, i, j, k);
+    Gc[o] = Gc[o] - 1 / (Az * M.dzC(k)) * ((dxF + dyF) + dzF);
+#undef C_
+#undef KE
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static int make_grange(const ocn_grid *grid, const int32_t *range, gen::GRange &r)
+{
+    if (range) {
+        r.i0 = range[0]; r.i1 = range[1]; r.j0 = range[2]; r.j1 = range[3]; r.k0 = range[4]; r.k1 = range[5];
+        if (r.i0 < 1 || r.i1 > grid->Nx || r.j0 < 1 || r.j1 > grid->Ny || r.k0 < 1 || r.k1 > grid->Nz) {
+            ocn::set_error("tendency range {%d:%d,%d:%d,%d:%d} outside the interior %dx%dx%d", r.i0, r.i1, r.j0, r.j1, r.k0, r.k1, grid->Nx,
+                           grid->Ny, grid->Nz);
+            return OCN_ERR_INVALID_ARGUMENT;
+        }
+        r.ou = r.ov = r.ow = 1;  // KernelParameters: periphery not excluded
+    } else {
+        r.i0 = 1; r.i1 = grid->Nx; r.j0 = 1; r.j1 = grid->Ny; r.k0 = 1; r.k1 = grid->Nz;
+        r.ou = (grid->tx == OCN_BOUNDED && grid->Nx > 1) ? 2 : 1;  // periphery_offset(Face, Bounded, N) (kernel_launching.jl:113-114)
+        r.ov = (grid->ty == OCN_BOUNDED && grid->Ny > 1) ? 2 : 1;
+        r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    }
+    return OCN_SUCCESS;
+}
+
+static gen::Fields make_fields(const ocn_grid *grid, const double *u, const double *v, const double *w, int centered2)
+{
+    gen::Fields F;
+    F.g = ocn::to_dev(*grid);
+    F.u = u; F.v = v; F.w = w;
+    F.Lu = ocn::make_lay(F.g, OCN_LOC_FCC);
+    F.Lv = ocn::make_lay(F.g, OCN_LOC_CFC);
+    F.Lw = ocn::make_lay(F.g, OCN_LOC_CCF);
+    F.Lc = ocn::make_lay(F.g, OCN_LOC_CCC);
+    F.centered2 = centered2;
+    return F;
+}
+
+#define OCN_GEN_DIMS(r)                                                                               \
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;                       \
+    if (wx < 1 || wy < 1 || wz < 1) return OCN_SUCCESS;                                                \
+    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz)
+
+int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+{
+    gen::GRange r;
+    int st = make_grange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    OCN_GEN_DIMS(r);
+    hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), Gu, Gv, Gw, r);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t stream)
+{
+    gen::GRange r;
+    int st = make_grange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    OCN_GEN_DIMS(r);
+    hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), c, Gc, r);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+{
+    gen::GRange r;
+    int st = make_grange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    OCN_GEN_DIMS(r);
+    hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, make_fields(grid, u, v, w, 0), t, Gu, Gv, Gw, r);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                                    const int32_t *range, hipStream_t stream)
+{
+    gen::GRange r;
+    int st = make_grange(grid, range, r);
+    if (st != OCN_SUCCESS) return st;
+    OCN_GEN_DIMS(r);
+    hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, ocn::to_dev(*grid), kappa, kappa_e, c, Gc, r);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+}  // namespace OCN_NS

@@ -126,6 +126,145 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
     return OCN_SUCCESS;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// General topologies: any of x, y, z Periodic, Bounded or Flat (fill_halo_regions.jl:50-196).  The reference fills in this order:
+// impenetrable walls (wall-normal velocity <- 0 on both boundary faces), then the non-periodic sides -- each over the INTERIOR
+// cross-section 1:N of the two other directions (fill_halo_size = :yz / :xz / :xy) and only the FIRST halo cell (no-flux mirror,
+// or the Value / Gradient extrapolation) -- then the periodic directions over the whole parent cross-section.  One launch reproduces
+// the composition: a halo cell copies from the cell that sequence propagates into it,
+//   periodic direction  : wrapped index;
+//   Bounded direction   : the mirror cell iff it is the first halo cell of a Center-located field AND every OTHER Bounded direction
+//                         sits inside 1:N (so corners of two walls, deeper halo cells and halos behind a Face-located wall keep
+//                         their values, exactly as the reference leaves them); otherwise its own index.
+// Source cells are never written by the same launch.
+__global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, FieldTuple a, SideBcTuple bcs, int has_bc)
+{
+    const int f = blockIdx.y;
+    double *__restrict__ c = a.f[f];
+    const int loc = a.loc[f];
+    const Lay L = make_lay(g, loc);
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
+    const int S[3] = {L.sx, L.sy, L.sz};
+    const long long nzi = S[2] - 2 * H[2], nyi = S[1] - 2 * H[1];
+    const long long A = (long long)S[0] * S[1] * 2 * H[2];
+    const long long B = (long long)S[0] * 2 * H[1] * nzi;
+    const long long Cn = (long long)2 * H[0] * nyi * nzi;
+    const long long total = A + B + Cn;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        int P[3];  // 0-based parent coordinates
+        if (t < A) {
+            P[0] = t % S[0];
+            const long long q = t / S[0];
+            P[1] = q % S[1];
+            const int kk = q / S[1];
+            P[2] = kk < H[2] ? kk : kk - H[2] + (S[2] - H[2]);
+        } else if (t < A + B) {
+            const long long s = t - A;
+            P[0] = s % S[0];
+            const long long q = s / S[0];
+            const int jj = q % (2 * H[1]);
+            P[2] = H[2] + q / (2 * H[1]);
+            P[1] = jj < H[1] ? jj : jj - H[1] + (S[1] - H[1]);
+        } else {
+            const long long s = t - A - B;
+            const int ii = s % (2 * H[0]);
+            const long long q = s / (2 * H[0]);
+            P[1] = H[1] + q % nyi;
+            P[2] = H[2] + q / nyi;
+            P[0] = ii < H[0] ? ii : ii - H[0] + (S[0] - H[0]);
+        }
+        int idx[3], src[3];
+        int mirror_dir = -1;
+        bool mirror_ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            idx[d] = P[d] - H[d] + 1;
+            src[d] = idx[d];
+            if (T[d] == OCN_PERIODIC) {
+                src[d] = wrap1(idx[d], N[d]);
+            } else if (T[d] == OCN_BOUNDED) {
+                const bool face = (loc >> d) & 1;
+                if (!face && (idx[d] == 0 || idx[d] == N[d] + 1)) mirror_dir = (mirror_dir < 0) ? d : 3;  // 3: two walls meet
+                if (idx[d] < 1 || idx[d] > N[d]) mirror_ok = mirror_ok && (mirror_dir == d);            // another Bounded direction outside 1:N
+            }
+        }
+        // (the test above accepts the mirror direction itself; re-check the OTHER Bounded directions)
+        if (mirror_dir >= 0 && mirror_dir < 3) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+                if (d != mirror_dir && T[d] == OCN_BOUNDED && (idx[d] < 1 || idx[d] > N[d])) mirror_dir = 3;
+        }
+        const bool mirror = mirror_dir >= 0 && mirror_dir < 3;
+        if (mirror) src[mirror_dir] = (idx[mirror_dir] == 0) ? 1 : N[mirror_dir];
+        if (src[0] == idx[0] && src[1] == idx[1] && src[2] == idx[2]) continue;
+        double val = c[at(L, src[0], src[1], src[2])];
+        if (mirror && has_bc) {
+            const int d = mirror_dir, lo = idx[d] == 0;
+            const ZBc &bc = bcs.side[2 * d + (lo ? 0 : 1)][f];
+            if (bc.kind >= OCN_BC_VALUE) {  // fill_halo_regions_value_gradient.jl:5-103
+                const int ib = lo ? 1 : N[d] + 1;  // boundary face index
+                const double D = d == 0 ? g.dx : d == 1 ? g.dy : (g.dzf ? uniform_load(g.dzf, ib + g.Hz - 1) : g.dz);
+                const int a1 = d == 0 ? src[1] : src[0], a2 = d == 2 ? src[1] : src[2];
+                const int n1 = d == 0 ? N[1] : N[0];
+                const double bv = bc_condition(bc, a1, a2, n1, val);
+                double grad;
+                if (bc.kind == OCN_BC_GRADIENT) grad = bv;
+                else grad = lo ? (val - bv) / (D / 2) : (bv - val) / (D / 2);
+                val = lo ? val + grad * (-D) : val + grad * D;
+            }
+        }
+        c[at(L, idx[0], idx[1], idx[2])] = val;
+    }
+}
+
+// Impenetrable walls in direction d for the field whose wall-normal direction it is (fill_halo_regions_open.jl:65-70)
+__global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int loc, int d)
+{
+    const Lay L = make_lay(g, loc);
+    const int N[3] = {g.Nx, g.Ny, g.Nz};
+    const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
+    const int a = 1 + blockIdx.x * blockDim.x + threadIdx.x, b = 1 + blockIdx.y;
+    if (a > N[d1]) return;
+    int lo[3], hi[3];
+    lo[d1] = hi[d1] = a;
+    lo[d2] = hi[d2] = b;
+    lo[d] = 1;
+    hi[d] = N[d] + 1;
+    c[at(L, lo[0], lo[1], lo[2])] = 0.0;
+    c[at(L, hi[0], hi[1], hi[2])] = 0.0;
+}
+
+int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int open_fill, hipStream_t stream, const SideBcTuple *bcs_in)
+{
+    SideBcTuple bcs{};
+    const int has_bc = bcs_in != nullptr;
+    if (bcs_in) bcs = *bcs_in;
+    GridDev g = to_dev(*grid);
+    const int T[3] = {grid->tx, grid->ty, grid->tz}, N[3] = {g.Nx, g.Ny, g.Nz};
+    if (open_fill) {
+        for (int f = 0; f < ft.n; ++f)
+            for (int d = 0; d < 3; ++d)
+                if (T[d] == OCN_BOUNDED && ft.loc[f] == (1 << d)) {
+                    const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
+                    hipLaunchKernelGGL(open_fill_general_kernel, dim3((N[d1] + 63) / 64, N[d2]), dim3(64), 0, stream, g, ft.f[f], ft.loc[f], d);
+                }
+    }
+    long long maxcells = 0;
+    for (int f = 0; f < ft.n; ++f) {
+        Lay L = make_lay(g, ft.loc[f]);
+        const long long nzi = L.sz - 2 * g.Hz, nyi = L.sy - 2 * g.Hy;
+        const long long tot = (long long)L.sx * L.sy * 2 * g.Hz + (long long)L.sx * 2 * g.Hy * nzi + (long long)2 * g.Hx * nyi * nzi;
+        if (tot > maxcells) maxcells = tot;
+    }
+    if (maxcells == 0) return OCN_SUCCESS;
+    long long nb = (maxcells + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(fill_halos_general_kernel, dim3((unsigned)nb, ft.n), dim3(256), 0, stream, g, ft, bcs, has_bc);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // apply_z_bcs! for a tuple of fields (apply_flux_bcs.jl:107-160):
 //   bottom: G[i,j,1]  += flux * Az / V(i,j,1)      top: G[i,j,Nz] -= flux * Az(Nz+1) / V(i,j,Nz)
@@ -1033,6 +1172,8 @@ __global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, do
         const int loc = a.loc[f];
         // launch!(..., :xyz; exclude_periphery=true): Face in a Bounded dim starts at 2 (kernel_launching.jl:113-161)
         if (MODE != 3 && (loc & 4) && g.tz == OCN_BOUNDED && g.Nz > 1 && k < 2) continue;
+        if (MODE != 3 && (loc & 1) && g.tx == OCN_BOUNDED && g.Nx > 1 && i < 2) continue;
+        if (MODE != 3 && (loc & 2) && g.ty == OCN_BOUNDED && g.Ny > 1 && j < 2) continue;
         const Lay L = make_lay(g, loc);
         const long long o = at(L, i, j, k);
         if (MODE == 0) {
@@ -1077,8 +1218,8 @@ __device__ __forceinline__ double div_ccc(const GridDev &g, const double *__rest
 {
     const double dzc = dzC(g, k);
     const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
-    const double dxu = Ax * u[at(Lu, i + 1, j, k)] - Ax * u[at(Lu, i, j, k)];
-    const double dyv = Ay * v[at(Lv, i, j + 1, k)] - Ay * v[at(Lv, i, j, k)];
+    const double dxu = (g.tx == OCN_FLAT) ? 0.0 : Ax * u[at(Lu, i + 1, j, k)] - Ax * u[at(Lu, i, j, k)];
+    const double dyv = (g.ty == OCN_FLAT) ? 0.0 : Ay * v[at(Lv, i, j + 1, k)] - Ay * v[at(Lv, i, j, k)];
     const double dzw = (g.tz == OCN_FLAT) ? 0.0 : Az * w[at(Lw, i, j, k + 1)] - Az * w[at(Lw, i, j, k)];
     return (1 / (Az * dzc)) * ((dxu + dyv) + dzw);
 }
@@ -1209,8 +1350,8 @@ __global__ __launch_bounds__(256) void pressure_correct_kernel(GridDev g, double
     const Lay Lu = make_lay(g, OCN_LOC_FCC), Lv = make_lay(g, OCN_LOC_CFC), Lw = make_lay(g, OCN_LOC_CCF),
               Lp = make_lay(g, OCN_LOC_CCC);
     const double pc = p[at(Lp, i, j, k)];
-    const double px = (pc - p[at(Lp, i - 1, j, k)]) / g.dx;
-    const double py = (pc - p[at(Lp, i, j - 1, k)]) / g.dy;
+    const double px = (g.tx == OCN_FLAT) ? 0.0 : (pc - p[at(Lp, i - 1, j, k)]) / g.dx;
+    const double py = (g.ty == OCN_FLAT) ? 0.0 : (pc - p[at(Lp, i, j - 1, k)]) / g.dy;
     u[at(Lu, i, j, k)] -= px * dt;
     v[at(Lv, i, j, k)] -= py * dt;
     if (g.tz == OCN_FLAT) {

@@ -172,7 +172,8 @@ struct HydroFuse {
     double *Ub, *Vb;    //                           Σ Δz u*, Σ Δz v* of the stepped velocities (for the barotropic corrector)
 };
 
-int validate_grid(const ocn_grid *g);
+int validate_grid(const ocn_grid *g);      // Periodic (or partitioned) x, Periodic y
+int validate_grid_any(const ocn_grid *g);  // any of Periodic / Bounded / Flat in x and y
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

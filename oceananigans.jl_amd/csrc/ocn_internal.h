@@ -27,6 +27,10 @@ struct ZBcTuple {
 };
 int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream,
                       const ZBcTuple *zbc = nullptr);
+struct SideBcTuple {
+    ZBc side[6][MAX_TUPLE];  // west, east, south, north, bottom, top of every field of a tuple
+};
+int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int open_fill, hipStream_t stream, const SideBcTuple *bcs = nullptr);
 int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream);
 int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream);
 int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
@@ -114,6 +118,14 @@ int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src,
 }  // namespace ocn
 
 namespace ocn_strict {
+int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                                    const int32_t *range, hipStream_t stream);
 int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
@@ -140,6 +152,14 @@ int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, con
                            double *kappa_e, hipStream_t stream);
 }
 namespace ocn_fast {
+int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                                    const int32_t *range, hipStream_t stream);
 int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
@@ -168,6 +188,14 @@ int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, con
 
 // advection = UpwindBiased(order=5): tendencies.hip compiled with OCN_UPWIND=1
 namespace ocn_strict_up {
+int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                                    const int32_t *range, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
@@ -176,6 +204,14 @@ int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const dou
                                 double *const Gc[2], const int32_t *range, hipStream_t stream, const ocn::TracerFuse fuse[2], int *launched);
 }
 namespace ocn_fast_up {
+int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
+                                   double *Gc, const int32_t *range, hipStream_t stream);
+int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
+                                    const int32_t *range, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                double *Gv, double *Gw, const int32_t *range, const ocn::FuseArgs *fuse, hipStream_t stream);
 int launch_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,

@@ -189,12 +189,44 @@ __device__ __forceinline__ double buoyancy_ccc(const TermsDev &t, long long a)
 // HYD (HydrostaticFreeSurfaceModel, hydrostatic_momentum_tiled below): the advective G of u, v arrives in G0u / G0v instead of
 // Gu[o] / Gv[o], there is no w tendency, and res[] returns {Gu, u_out, Gv, v_out} for the column sums of the split-explicit
 // free surface.
+// The global values one cell of the finishing pass reads besides the LDS-staged velocities: G⁻ of the substep, pHY′ and its west / south
+// neighbours, the incoming advective G, the buoyancy at the two cells around the w face.  Requested by momentum_extra_loads, consumed
+// by momentum_extra_cell: the tiled kernels issue them BEFORE the plane-ahead prefetch of the next staging step -- vector-memory
+// returns are in order, so a wait for these values would otherwise drain the whole prefetch group in the same iteration
+// (profiles/r03b_config4.md: 52 % of the wave cycles parked).
+struct ExtraLoads {
+    double gm_u, gm_v, gm_w, ph_c, ph_w, ph_s, Gu_in, Gv_in, Gw_in, zb_w;
+    bool w_cell;
+};
+template <int TZ, bool HYD = false>
+__device__ __forceinline__ ExtraLoads momentum_extra_loads(const TermsDev &t, const ocn::MomentumFinal &mf, const PRange &r, int k, long long o,
+                                                           long long s2, long long s3, const double *__restrict__ Gu,
+                                                           const double *__restrict__ Gv, const double *__restrict__ Gw)
+{
+    constexpr bool ZF = (TZ == OCN_FLAT);
+    ExtraLoads ld;
+    const bool use_gm = mf.sc.has_zeta && (HYD || mf.sc.on);
+    ld.gm_u = use_gm ? mf.sub[0].Gm[o] : 0.0;
+    ld.gm_v = use_gm ? mf.sub[1].Gm[o] : 0.0;
+    ld.w_cell = !HYD && k >= r.ow;
+    ld.gm_w = (use_gm && ld.w_cell) ? mf.sub[2].Gm[o] : 0.0;
+    ld.ph_c = t.pHY ? t.pHY[o] : 0.0;
+    ld.ph_w = t.pHY ? t.pHY[o - 1] : 0.0;
+    ld.ph_s = t.pHY ? t.pHY[o - s2] : 0.0;
+    ld.Gu_in = HYD ? 0.0 : Gu[o];
+    ld.Gv_in = HYD ? 0.0 : Gv[o];
+    ld.Gw_in = ld.w_cell ? Gw[o] : 0.0;
+    ld.zb_w = 0.0;  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
+    if (ld.w_cell && t.buoyancy && !t.pHY) ld.zb_w = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
+    return ld;
+}
+
 template <int TZ, bool HYD = false, class FU, class FV, class FW, class FN>
 __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const TermsDev &t, const Metrics &M, int i, int j, int k,
                                                     long long o, long long s2, long long s3, bool has_nu, FU Uf, FV Vf, FW Wf,
                                                     FN NEf, double *__restrict__ Gu, double *__restrict__ Gv,
                                                     double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf,
-                                                    double G0u = 0.0, double G0v = 0.0, double *res = nullptr)
+                                                    const ExtraLoads &ld, double G0u = 0.0, double G0v = 0.0, double *res = nullptr)
 {
     constexpr bool ZF = (TZ == OCN_FLAT);
     const double dx = M.dx, dy = M.dy, nu = t.nu;
@@ -222,16 +254,8 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         return has_nu ? 0.5 * (0.5 * (NEf(a, b - 1, c - 1) + NEf(a, b, c - 1)) + 0.5 * (NEf(a, b - 1, c) + NEf(a, b, c))) : nu;
     };
 
-    // every global value this cell reads is requested up front: the pointers inside `t` and `mf` may alias the stores below
-    // as far as the compiler knows, so loads left in place would wait for each store in turn (three dependent round trips)
-    const bool use_gm = mf.sc.has_zeta && (HYD || mf.sc.on);
-    const double gm_u = use_gm ? mf.sub[0].Gm[o] : 0.0, gm_v = use_gm ? mf.sub[1].Gm[o] : 0.0;
-    const bool w_cell = !HYD && k >= r.ow;
-    const double gm_w = (use_gm && w_cell) ? mf.sub[2].Gm[o] : 0.0;
-    const double ph_c = t.pHY ? t.pHY[o] : 0.0, ph_w = t.pHY ? t.pHY[o - 1] : 0.0, ph_s = t.pHY ? t.pHY[o - s2] : 0.0;
-    const double Gu_in = HYD ? G0u : Gu[o], Gv_in = HYD ? G0v : Gv[o], Gw_in = w_cell ? Gw[o] : 0.0;
-    double zb_w = 0.0;  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
-    if (w_cell && t.buoyancy && !t.pHY) zb_w = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
+    const double gm_u = ld.gm_u, gm_v = ld.gm_v, gm_w = ld.gm_w, ph_c = ld.ph_c, ph_w = ld.ph_w, ph_s = ld.ph_s;
+    const double Gu_in = HYD ? G0u : ld.Gu_in, Gv_in = HYD ? G0v : ld.Gv_in, Gw_in = ld.Gw_in, zb_w = ld.zb_w;
 
     {   // ---------------- Gu at (f,c,c)
         double G = Gu_in;
@@ -346,10 +370,11 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
     const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
     const long long s2 = L.s2, s3 = ZF ? 0 : L.s3, o = ocn::at(L, i, j, k);
     const double *pu = u + o, *pv = v + o, *pw = w + o, *pn = t.nu_e ? t.nu_e + o : nullptr;
+    const ExtraLoads ld = momentum_extra_loads<TZ>(t, mf, r, k, o, s2, s3, Gu, Gv, Gw);
     momentum_extra_cell<TZ>(
         g, t, M, i, j, k, o, s2, s3, pn != nullptr, [&](int a, int b, int c) { return pu[a + b * s2 + c * s3]; },
         [&](int a, int b, int c) { return pv[a + b * s2 + c * s3]; }, [&](int a, int b, int c) { return pw[a + b * s2 + c * s3]; },
-        [&](int a, int b, int c) { return pn[a + b * s2 + c * s3]; }, Gu, Gv, Gw, r, mf);
+        [&](int a, int b, int c) { return pn[a + b * s2 + c * s3]; }, Gu, Gv, Gw, r, mf, ld);
 }
 
 // Tiled variant of the finishing pass: a workgroup owns a 32 x 8 patch of columns and marches KZ planes upward; planes
@@ -419,15 +444,19 @@ __global__ __launch_bounds__(256, 4) void momentum_extra_tiled(GridDev g, TermsD
     for (int k = kb; k <= ke; ++k) {
         commit(k + 1);
         __syncthreads();
-        if (k < ke) fetch(k + 2);  // consumed by the next iteration's commit
+        const long long o = ocn::at(L, active ? i : r.i1, active ? j : r.j1, k);
+        ExtraLoads ld{};
+        if (active) ld = momentum_extra_loads<TZ>(t, mf, r, k, o, s2, s3, Gu, Gv, Gw);  // this plane's own values first ...
+        OCN_ISSUE_LOADS_HERE();
+        if (k < ke) fetch(k + 2);  // ... then the staging values of plane k + 2, consumed by the next iteration's commit
+        OCN_ISSUE_LOADS_HERE();
         if (active) {
-            const long long o = ocn::at(L, i, j, k);
             const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
             momentum_extra_cell<TZ>(
                 g, t, M, i, j, k, o, s2, s3, has_nu, [&](int a, int b, int c) { return Lu[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Lw[(base + c) % 3][c0 + a + b * SX]; },
-                [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf);
+                [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf, ld);
         }
         __syncthreads();  // everyone is done with slot (k - 1) % 3 before the next iteration overwrites it
     }
@@ -549,9 +578,13 @@ __global__ __launch_bounds__(256, W) void hydrostatic_momentum_tiled(GridDev g, 
     for (int k = 1; k <= g.Nz; ++k) {
         commit(k + 1);
         __syncthreads();
-        if (k < g.Nz) fetch(k + 2);  // consumed by the next iteration's commit
+        const long long o = ocn::at(L, active ? i : g.Nx, active ? j : g.Ny, k);
+        ExtraLoads ld{};
+        if (active) ld = momentum_extra_loads<TZ, true>(t, mf, r, k, o, s2, s3, Gu, Gv, nullptr);  // this plane's own values first ...
+        OCN_ISSUE_LOADS_HERE();
+        if (k < g.Nz) fetch(k + 2);  // ... then the staging values of plane k + 2, consumed by the next iteration's commit
+        OCN_ISSUE_LOADS_HERE();
         if (active) {
-            const long long o = ocn::at(L, i, j, k);
             const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
             auto Uf = [&](int a, int b, int c) { return Lu[(base + c) % 3][c0 + a + b * SX]; };
             auto Vf = [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; };
@@ -563,7 +596,7 @@ __global__ __launch_bounds__(256, W) void hydrostatic_momentum_tiled(GridDev g, 
                 G0v -= gye;
             }
             momentum_extra_cell<TZ, true>(g, t, M, i, j, k, o, s2, s3, false, Uf, Vf, Wf, [&](int, int, int) { return 0.0; }, Gu, Gv,
-                                          nullptr, r, mf, G0u, G0v, res);
+                                          nullptr, r, mf, ld, G0u, G0v, res);
             const double dz = M.dzC(k);
             if (k == 1) {
                 aGU = dz * res[0];

@@ -300,7 +300,7 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
     OCN_REQUIRE(out && grid, "ocn_poisson_create: null argument");
     {
         const char *eg = std::getenv("OCN_POISSON_GENERAL");
-        const bool bounded_xy = grid->tx == OCN_BOUNDED || grid->ty == OCN_BOUNDED;
+        const bool bounded_xy = grid->tx == OCN_BOUNDED || grid->ty == OCN_BOUNDED || grid->tx == OCN_FLAT || grid->ty == OCN_FLAT;
         if (bounded_xy || (eg && eg[0] == '1' && grid->dzc == nullptr)) {
             // (the solver only touches a Center field, whose layout does not depend on the topology: its own light validation)
             OCN_REQUIRE(grid->Nx >= 1 && grid->Ny >= 1 && grid->Nz >= 1 && grid->Hx >= 0 && grid->Hy >= 0 && grid->Hz >= 0, "bad grid size / halo");

@@ -58,8 +58,12 @@ def _grid(pkg, **kw):
 def test_argument_validation_needs_no_gpu(pkg):
     call, pa, ia = pkg._lib.call, pkg._lib.ptr_array, pkg._lib.i32_array
     fake = pa([0x1000])
-    with pytest.raises(pkg.OcnError, match="unsupported topology"):
-        call("ocn_fill_halo_regions", C.byref(_grid(pkg, tx=1)), fake, ia([0]), 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="unsupported topology"):   # an entry point without a direction-generic path: Periodic x, y only
+        call("ocn_compute_w_from_continuity", C.byref(_grid(pkg, tx=1)), 1, 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="only x is ever partitioned"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg, ty=3)), fake, ia([0]), 1, 1, None)
+    with pytest.raises(pkg.OcnError, match="fused stage boundaries need Periodic x and y"):
+        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, ty=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, None, 0.0, None, None)
     with pytest.raises(pkg.OcnError, match="Flat dimension"):
         call("ocn_fill_halo_regions", C.byref(_grid(pkg, tz=2)), fake, ia([0]), 1, 1, None)
     with pytest.raises(pkg.OcnError, match="number of fields"):
