@@ -855,13 +855,42 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
 int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *const *fields, const int32_t *locs,
                        const ocn_field_bcs *const *bcs, int32_t n, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     FieldTuple gt, ft;
     st = make_field_tuple(grid, G, locs, n, gt);
     if (st != OCN_SUCCESS) return st;
     st = make_field_tuple(grid, const_cast<double *const *>(fields), locs, n, ft);
     if (st != OCN_SUCCESS) return st;
+    if (!xy_periodic(grid)) {  // apply_x_bcs!, apply_y_bcs!, then apply_z_bcs! (compute_nonhydrostatic_tendencies.jl:204-213)
+        SideBcTuple sb{};
+        ZBcTuple z{};
+        bool any_xy = false, any_z = false;
+        const int T[3] = {grid->tx, grid->ty, grid->tz};
+        for (int f = 0; f < n; ++f) {
+            if (!bcs || !bcs[f]) continue;
+            const ocn_bc *side[6] = {&bcs[f]->west, &bcs[f]->east, &bcs[f]->south, &bcs[f]->north, &bcs[f]->bottom, &bcs[f]->top};
+            for (int q = 0; q < 6; ++q) {
+                const ocn_bc &c = *side[q];
+                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+                if (c.kind != OCN_BC_FLUX) continue;
+                OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
+                OCN_REQUIRE(!((locs[f] >> (q / 2)) & 1), "field %d: the wall-normal velocity keeps its impenetrable condition", f);
+                if (q < 4) {
+                    sb.side[q][f] = ZBc{c.kind, c.value, c.coeff, c.values};
+                    any_xy = true;
+                } else {
+                    (q == 4 ? z.bottom[f] : z.top[f]) = ZBc{c.kind, c.value, c.coeff, c.values};
+                    any_z = true;
+                }
+            }
+        }
+        if (any_xy) {
+            st = launch_apply_flux_bcs_lateral(grid, gt, ft, sb, as_stream(stream));
+            if (st != OCN_SUCCESS) return st;
+        }
+        return any_z ? launch_apply_flux_bcs(grid, gt, ft, z, as_stream(stream)) : OCN_SUCCESS;
+    }
     ZBcTuple z;
     bool any;
     st = make_zbc_tuple(grid, locs, bcs, n, z, true, any);

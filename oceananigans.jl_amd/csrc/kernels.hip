@@ -289,6 +289,52 @@ __global__ __launch_bounds__(256) void apply_flux_bcs_kernel(GridDev g, FieldTup
     }
 }
 
+// apply_x_bcs! / apply_y_bcs! (apply_flux_bcs.jl:38-46, 117-146) of a tuple of fields on a grid with a Bounded x / y: one thread per
+// boundary-face cell (a, b) adds the left flux to G[1] and subtracts the right one from G[N], in that order (N = 1: the same cell).
+//   area = the cell's face area across `dir` (location flipped along dir), V = the cell volume at the field's location.
+__global__ __launch_bounds__(256) void apply_flux_bcs_lateral_kernel(GridDev g, FieldTuple G, FieldTuple c, SideBcTuple bcs, int dir)
+{
+    const int f = blockIdx.z;
+    const int N[3] = {g.Nx, g.Ny, g.Nz};
+    const int d1 = dir == 0 ? 1 : 0;
+    const int a = 1 + blockIdx.x * blockDim.x + threadIdx.x, k = 1 + blockIdx.y;
+    if (a > N[d1]) return;
+    const ZBc &lo = bcs.side[2 * dir][f], &hi = bcs.side[2 * dir + 1][f];
+    if (lo.kind != OCN_BC_FLUX && hi.kind != OCN_BC_FLUX) return;
+    const Lay L = make_lay(g, G.loc[f]);
+    const int zf = (G.loc[f] >> 2) & 1;
+    const double dz = zf ? (g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz) : (g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz);
+    const double area = (dir == 0 ? g.dy : g.dx) * dz;
+    const double V = g.dx * g.dy * dz;
+    int q[3];
+    q[d1] = a;
+    q[2] = k;
+    if (lo.kind == OCN_BC_FLUX) {
+        q[dir] = 1;
+        const long long o = at(L, q[0], q[1], q[2]);
+        G.f[f][o] += bc_condition(lo, a, k, N[d1], c.f[f][o]) * area / V;
+    }
+    if (hi.kind == OCN_BC_FLUX) {
+        q[dir] = N[dir];
+        const long long o = at(L, q[0], q[1], q[2]);
+        G.f[f][o] -= bc_condition(hi, a, k, N[d1], c.f[f][o]) * area / V;
+    }
+}
+
+int launch_apply_flux_bcs_lateral(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const SideBcTuple &bcs, hipStream_t stream)
+{
+    GridDev g = to_dev(*grid);
+    for (int dir = 0; dir < 2; ++dir) {
+        bool any = false;
+        for (int f = 0; f < G.n; ++f) any = any || bcs.side[2 * dir][f].kind == OCN_BC_FLUX || bcs.side[2 * dir + 1][f].kind == OCN_BC_FLUX;
+        if (!any) continue;
+        const int n1 = dir == 0 ? g.Ny : g.Nx;
+        hipLaunchKernelGGL(apply_flux_bcs_lateral_kernel, dim3((n1 + 63) / 64, g.Nz, G.n), dim3(64), 0, stream, g, G, fields, bcs, dir);
+        OCN_CHECK_HIP(hipGetLastError());
+    }
+    return OCN_SUCCESS;
+}
+
 int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream)
 {
     GridDev g = to_dev(*grid);

@@ -32,6 +32,7 @@ struct SideBcTuple {
 };
 int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int open_fill, hipStream_t stream, const SideBcTuple *bcs = nullptr);
 int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const ZBcTuple &zbc, hipStream_t stream);
+int launch_apply_flux_bcs_lateral(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const SideBcTuple &bcs, hipStream_t stream);
 int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream);
 int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
 int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream, const int32_t *irange = nullptr);

@@ -149,12 +149,23 @@ struct ocn_poisson {
     // kind 2: FFTBasedPoissonSolver for ANY regular (Periodic | Bounded | Flat)^3 topology: separable transforms evaluated as direct sums
     // (DFT along Periodic, REDFT10 / REDFT01 along Bounded dimensions, plan_transforms.jl:16-34) -- the reference's K11 path
     double *tab[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // per dimension: cos / sin tables
+    // ... or, by default, from complex FFTs of the same length with index permutations and twiddle factors (the reference's K11,
+    // index_permutations.jl:38-90, discrete_transforms.jl:141-176): O(N log N) per line
+    Plan gfwd[3], gbwd[3];
+    double *gtw[3] = {nullptr, nullptr, nullptr};  // w_k = exp(-i π k / 2N), k < N, of the Bounded dimensions
+    bool fft_dct = false;
 };
 
 static void free_all(ocn_poisson *s)
 {
     s->fwd.destroy();
     s->bwd.destroy();
+    for (int d = 0; d < 3; ++d) {
+        s->gfwd[d].destroy();
+        s->gbwd[d].destroy();
+        if (s->gtw[d]) (void)hipFree(s->gtw[d]);
+        s->gtw[d] = nullptr;
+    }
     double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage,
                        &s->tab[0][0], &s->tab[0][1], &s->tab[1][0], &s->tab[1][1], &s->tab[2][0], &s->tab[2][1]};
     for (auto p : ptrs)
@@ -220,6 +231,67 @@ __global__ __launch_bounds__(256) void naive_transform_kernel(int Nx, int Ny, in
     out[t] = make_double2(re, im);
 }
 
+// ---- the same transforms from FFTs (Makhoul 1980; the reference's GPU path K11) ------------------------------------------------
+// REDFT10 of a line x[0..N):  v[n] = x[2n] (n < ceil(N/2)),  v[N-1-n] = x[2n+1];  V = FFT_N(v);  X[k] = 2 Re(w_k V[k]), w_k = e^{-iπk/2N}.
+// The lines here are complex (earlier dimensions are already in spectral space): the real and imaginary parts are two real lines
+// transformed by ONE complex FFT and separated through the Hermitian symmetry of their spectra,
+//     X[k] = Re(w_k (V[k] + conj V[N-k]))  +  i Im(w_k (V[k] - conj V[N-k])).
+// REDFT01 / 2N (the inverse):  V[k] = (1/2) conj(w_k) (X[k] - i X[N-k]),  X[N] := 0;  v = IFFT_N(V) / N;  x[2n] = v[n], x[2n+1] = v[N-1-n].
+// mode 0: gather (x -> v), 1: forward post-twiddle (V -> X), 2: inverse pre-twiddle (X -> V), 3: scatter (v -> x); out of place.
+__global__ __launch_bounds__(256) void dct_shuffle_kernel(int Nx, int Ny, int Nz, int dim, int mode, const double2 *__restrict__ in,
+                                                          double2 *__restrict__ out, const double2 *__restrict__ w)
+{
+    const long long n = (long long)Nx * Ny * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), k = (int)(t / ((long long)Nx * Ny));
+    const int N = dim == 0 ? Nx : dim == 1 ? Ny : Nz, q = dim == 0 ? i : dim == 1 ? j : k;
+    const long long stride = dim == 0 ? 1 : dim == 1 ? Nx : (long long)Nx * Ny;
+    const double2 *line = in + (t - q * stride);
+    const int half = (N + 1) / 2;
+    if (mode == 0) {         // v[q]
+        out[t] = q < half ? line[(long long)(2 * q) * stride] : line[(long long)(2 * (N - 1 - q) + 1) * stride];
+    } else if (mode == 3) {  // x[q]
+        out[t] = (q & 1) ? line[(long long)(N - 1 - (q - 1) / 2) * stride] : line[(long long)(q / 2) * stride];
+    } else if (mode == 1) {
+        const double2 a = line[(long long)q * stride], b = line[(long long)((N - q) % N) * stride], wk = w[q];
+        const double sr = a.x + b.x, si = a.y - b.y;  // V[k] + conj V[N-k]
+        const double dr = a.x - b.x, di = a.y + b.y;  // V[k] - conj V[N-k]
+        out[t] = make_double2(wk.x * sr - wk.y * si, wk.x * di + wk.y * dr);
+    } else {
+        const double2 a = line[(long long)q * stride];
+        const double2 b = q == 0 ? make_double2(0.0, 0.0) : line[(long long)(N - q) * stride];
+        const double2 wk = w[q];
+        const double zr = a.x + b.y, zi = a.y - b.x;  // X[k] - i X[N-k]
+        out[t] = make_double2(0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr));  // (1/2) conj(w_k) z
+    }
+}
+
+// batched complex FFT plans along dimension d of a contiguous Nx x Ny x Nz array (x fastest), in place; d = 1 is planned per z plane
+static int make_line_plans(ocn_poisson *s, int d, const int N[3])
+{
+    const size_t len[1] = {(size_t)N[d]};
+    size_t stride[1], dist, batch;
+    if (d == 0) { stride[0] = 1; dist = (size_t)N[0]; batch = (size_t)N[1] * N[2]; }
+    else if (d == 1) { stride[0] = (size_t)N[0]; dist = 1; batch = (size_t)N[0]; }
+    else { stride[0] = (size_t)N[0] * N[1]; dist = 1; batch = (size_t)N[0] * N[1]; }
+    int st = make_plan(s->gfwd[d], rocfft_placement_inplace, rocfft_transform_type_complex_forward, 1, len, batch,
+                       rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, stride, dist, stride, dist, 1.0);
+    if (st != OCN_SUCCESS) return st;
+    return make_plan(s->gbwd[d], rocfft_placement_inplace, rocfft_transform_type_complex_inverse, 1, len, batch,
+                     rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, stride, dist, stride, dist, 1.0 / N[d]);
+}
+
+static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const int N[3], hipStream_t stream)
+{
+    Plan &P = inverse ? s->gbwd[d] : s->gfwd[d];
+    if (d != 1) return P.exec(a, nullptr, stream);
+    for (int k = 0; k < N[2]; ++k) {
+        int st = P.exec(a + (size_t)2 * N[0] * N[1] * k, nullptr, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
+    return OCN_SUCCESS;
+}
+
 static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
 {
     if (grid->dzc != nullptr) {
@@ -256,6 +328,25 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         st = upload(c, &s->tab[d][0]);
         if (st == OCN_SUCCESS) st = upload(sn, &s->tab[d][1]);
     }
+    {   // FFT-based transforms (default); OCN_POISSON_NAIVE_DCT=1 keeps the direct sums of the definitions (the checker of the tests)
+        const char *nv = std::getenv("OCN_POISSON_NAIVE_DCT");
+        s->fft_dct = !(nv && nv[0] == '1');
+        if (s->fft_dct && st == OCN_SUCCESS) {
+            ensure_rocfft();
+            for (int d = 0; d < 3 && st == OCN_SUCCESS; ++d) {
+                if (topo[d] == OCN_FLAT) continue;
+                st = make_line_plans(s, d, N);
+                if (st != OCN_SUCCESS || topo[d] != OCN_BOUNDED) continue;
+                std::vector<double> w(2 * (size_t)N[d]);
+                for (int k = 0; k < N[d]; ++k) {
+                    const long double a = 3.14159265358979323846264338327950288L * k / (2.0L * N[d]);
+                    w[2 * k] = (double)cosl(a);
+                    w[2 * k + 1] = (double)(-sinl(a));
+                }
+                st = upload(w, &s->gtw[d]);
+            }
+        }
+    }
     if (st == OCN_SUCCESS && (hipMalloc((void **)&s->spec, n * 2 * sizeof(double)) != hipSuccess ||
                               hipMalloc((void **)&s->spec2, n * 2 * sizeof(double)) != hipSuccess)) {
         ocn::set_error("ocn_poisson_create: out of device memory");
@@ -281,15 +372,36 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     int order[3], no = 0;
     for (int d = 0; d < 3; ++d) if (topo[d] == OCN_BOUNDED) order[no++] = d;
     for (int d = 0; d < 3; ++d) if (topo[d] == OCN_PERIODIC) order[no++] = d;
-    auto pass = [&](int d, int inverse) {
-        hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, topo[d], inverse,
-                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[d][0], s->tab[d][1]);
+    int pst = OCN_SUCCESS;
+    auto shuffle = [&](int d, int mode) {
+        hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, mode,
+                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[d]));
         std::swap(a, b);
     };
+    auto pass = [&](int d, int inverse) {
+        if (pst != OCN_SUCCESS) return;
+        if (!s->fft_dct) {
+            hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, topo[d], inverse,
+                               reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[d][0], s->tab[d][1]);
+            std::swap(a, b);
+        } else if (topo[d] == OCN_PERIODIC) {
+            pst = exec_line_plan(s, d, inverse, a, N, stream);
+        } else if (!inverse) {  // REDFT10: gather, FFT, twiddle
+            shuffle(d, 0);
+            pst = exec_line_plan(s, d, 0, a, N, stream);
+            shuffle(d, 1);
+        } else {                // REDFT01 / 2N: twiddle, inverse FFT (scaled 1 / N), scatter
+            shuffle(d, 2);
+            pst = exec_line_plan(s, d, 1, a, N, stream);
+            shuffle(d, 3);
+        }
+    };
     for (int q = 0; q < no; ++q) pass(order[q], 0);
+    if (pst != OCN_SUCCESS) return pst;
     int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
     if (st != OCN_SUCCESS) return st;
     for (int q = no - 1; q >= 0; --q) pass(order[q], 1);
+    if (pst != OCN_SUCCESS) return pst;
     OCN_CHECK_HIP(hipGetLastError());
     if (a != s->spec) std::swap(s->spec, s->spec2);  // the result lives in `a`; keep the handle's roles consistent
     return ocn::launch_copy_real(g, s->spec, p, stream, 0);
@@ -726,8 +838,7 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     const ocn_grid *g = &s->grid;
     int st;
     if (s->kind == 2) {
-        OCN_REQUIRE(g->tx == OCN_PERIODIC && g->ty == OCN_PERIODIC,
-                    "ocn_poisson_compute_source_term: velocity fields on grids with a Bounded x or y are not implemented (use ocn_poisson_set_source_term)");
+        // (divᶜᶜᶜ reads u, v, w through their own parent layouts and treats Flat directions: any topology)
         st = ocn::launch_source_term(g, u, v, w, dt, 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
         s->source_set = (st == OCN_SUCCESS);
         return st;

@@ -173,8 +173,18 @@ class NonhydrostaticModel:
         # WENO momentum uses the tiled kernel's epilogue; tracers and the §8(f) terms use the general fused entry points
         # (WENO advection only: the Centered(order=2) tracer kernel has no epilogue)
         self._general_fused = self.general_terms or bool(self.tracers)
-        self.fuse_stage_boundaries = (not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
-                                                                   and os.environ.get("OCN_FUSE_GENERAL", "1") != "0")
+        # grids with a Bounded or Flat x / y run the direction-generic kernels (csrc/general.hip) with the reference's launch sequence
+        xy_periodic = grid.topology[0] in ("Periodic", "FullyConnected") and grid.topology[1] == "Periodic"
+        self.fuse_stage_boundaries = xy_periodic and ((not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
+                                                                                   and os.environ.get("OCN_FUSE_GENERAL", "1") != "0"))
+        if not xy_periodic:
+            if isinstance(closure, AnisotropicMinimumDissipation):
+                raise NotImplementedError("AnisotropicMinimumDissipation needs Periodic x and y in this backend")
+            if buoyancy is not None and self.pHY is not None:
+                raise NotImplementedError("a separate hydrostatic pressure anomaly needs Periodic x and y in this backend "
+                                          "(pass hydrostatic_pressure_anomaly=None: the buoyancy then acts on w directly)")
+            if hasattr(grid.architecture, "partition"):
+                raise NotImplementedError("a partitioned x needs Periodic y")
         self._alt_velocities = None
         self._alt_fields = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one

@@ -235,7 +235,8 @@ def GradientBoundaryCondition(condition=0.0, parameters=None):
 
 class FieldBoundaryConditions:
     """FieldBoundaryConditions(; west, east, south, north, bottom, top); unspecified sides keep the topology defaults
-    (field_boundary_conditions.jl:15-33).  The backend supports user conditions at bottom / top only."""
+    (field_boundary_conditions.jl:15-33).  Bottom / top: Flux, Value, Gradient; west / east / south / north (Bounded x / y grids):
+    Value, Gradient."""
     SIDES = ("west", "east", "south", "north", "bottom", "top")
 
     def __init__(self, **sides):
@@ -243,8 +244,9 @@ class FieldBoundaryConditions:
             if k not in self.SIDES:
                 raise TypeError(f"unknown boundary {k!r}")
         for k in ("west", "east", "south", "north"):
-            if sides.get(k) is not None:
-                raise NotImplementedError("only bottom / top boundary conditions are implemented (x, y are Periodic)")
+            if sides.get(k) is not None and sides[k].kind == _lib.BC_FLUX:
+                raise NotImplementedError("Flux boundary conditions on west / east / south / north are not implemented (apply_x_bcs!, apply_y_bcs!); "
+                                          "Value and Gradient conditions are (Bounded x / y grids)")
         self.sides = {k: sides.get(k) for k in self.SIDES}
         self._c = None
 

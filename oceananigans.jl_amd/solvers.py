@@ -58,7 +58,7 @@ class FFTBasedPoissonSolver(_PoissonHandle):
 
     def __init__(self, grid, general=False):
         import os
-        bounded_xy = Bounded in grid.topology[:2]
+        bounded_xy = Bounded in grid.topology[:2] or Flat in grid.topology[:2]  # (the library routes every non-Periodic x / y to the general solver)
         if grid._dzc is not None:
             raise ValueError("FFTBasedPoissonSolver requires a regular grid")
         if grid.topology[2] == Bounded and not (bounded_xy or general):
@@ -92,7 +92,7 @@ def nonhydrostatic_pressure_solver(grid):
     hook = getattr(grid.architecture, "pressure_solver", None)
     if hook is not None:
         return hook(grid)
-    if Bounded in grid.topology[:2]:
+    if Bounded in grid.topology[:2] or Flat in grid.topology[:2]:
         return FFTBasedPoissonSolver(grid)  # XYZRegularRG (NonhydrostaticModels.jl:25-62); a stretched z there has no solver in the reference either
     if grid.topology[2] == Bounded:
         return FourierTridiagonalPoissonSolver(grid)
