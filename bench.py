@@ -403,12 +403,12 @@ def main():
             umax = dist.allreduce_max(umax.reshape(1))[0]
         dt = 0.1 * min(grid.dx, dmin) / float(umax)
         prognostic = model.prognostic_fields()
-        if a.driver == "c" and a.workload != "box":
-            raise SystemExit("--driver c: box workload (one GPU, or one C call per rank-step with --gpus N)")
+        if a.driver == "c" and a.workload != "box" and world > 1:
+            raise SystemExit("--driver c: box workload (one GPU, or one C call per rank-step with --gpus N), or config4 on one GPU")
         drv = None
-        if a.driver in ("c", "auto") and a.workload == "box":
+        if a.driver in ("c", "auto") and (a.workload == "box" or world == 1):
             try:
-                drv = ocn.RK3Driver(model)
+                drv = ocn.RK3Driver(model) if a.workload == "box" else ocn.ModelRK3Driver(model)
             except (NotImplementedError, ocn.OcnError) as e:  # e.g. a slab size outside the library's slab pipelines
                 if a.driver == "c":
                     raise

@@ -274,6 +274,11 @@ int ocn_cell_advection_timescale(const ocn_grid *grid, const double *u, const do
 int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn,
                     const double *const *Gm, const int32_t *locs, double dt, double gamma, double zeta, int32_t has_zeta,
                     void *stream);
+/* split_rk3_substep_field! of the HydrostaticFreeSurfaceModel's SplitRungeKutta3 stepper, stages 2 and 3
+ * (hydrostatic_free_surface_rk3_step.jl:30-60):  U = zeta * Psi + gamma * (U + dt * G)  over the interior of every field of the tuple,
+ * Psi = the field cached at the start of the step (cache_previous_fields!); stage 1 is ocn_rk3_substep with gamma = 1, has_zeta = 0. */
+int ocn_split_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *G, const double *const *Psi,
+                          const int32_t *locs, double dt, double gamma, double zeta, void *stream);
 /* ab2_step_field! (src/TimeSteppers/quasi_adams_bashforth_2.jl:128-175) */
 int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
                  const int32_t *locs, double dt, double chi, void *stream);
@@ -439,6 +444,38 @@ int ocn_rk3_driver_fields(ocn_rk3_driver_t driver, double **u, double **v, doubl
  * time_step and flush the velocity arrays then hold the uncorrected u*, v*, w*; ocn_rk3_driver_flush applies the correction, fills
  * the halos and completes the tendencies -- the state it leaves is the reference's, bit for bit in strict math. */
 int ocn_rk3_driver_configure(ocn_rk3_driver_t driver, int32_t defer_correction);
+
+/* ---- the same for a model with tracers and the SURVEY 8(f) terms (config 4's term set: WENO5 / UpwindBiased5 advection, FPlane,
+ * ScalarDiffusivity or AnisotropicMinimumDissipation, BuoyancyTracer / SeawaterBuoyancy with or without a separate pHY', bottom / top
+ * boundary conditions), (Periodic, Periodic, Bounded | Periodic | Flat), one GPU: time_step!(model, dt) of
+ * runge_kutta_3.jl:77-151 with update_state! (update_nonhydrostatic_model_state.jl:20-70: halo fills, compute_auxiliaries!, the diffusivity
+ * halo fill), compute_tendencies! (+ boundary contributions) and the pressure projection issued by the library -- the launch sequence of
+ * the Python host (models.py::_time_step_rk3 on the general fused path), bit-identical to it.  The handle owns a second set of every
+ * prognostic array, G^n and G^-; nu_e, kappa_e, pHY and p stay the caller's.  Number-valued and array-valued conditions are supported
+ * (the arrays are the caller's device arrays, read at every stage); conditions that are functions of time must be refreshed by the
+ * caller between steps (they are then piecewise constant over a step, unlike the reference, which evaluates them per stage). */
+#define OCN_MODEL_MAX_TRACERS 4
+typedef struct ocn_model_driver_desc {
+    ocn_model_terms terms;    /* terms.T / terms.S are ignored: tracer_T / tracer_S below name the tracers the buoyancy reads */
+    int32_t n_tracers;        /* 0 .. OCN_MODEL_MAX_TRACERS */
+    int32_t tracer_T, tracer_S; /* index into tracers[] of the temperature (or buoyancy tracer) and of the salinity; -1 = unused */
+    int32_t _pad;
+    double kappa[OCN_MODEL_MAX_TRACERS];   /* ScalarDiffusivity kappa of every tracer (closure == 1) */
+    double C_nu, C_kappa[OCN_MODEL_MAX_TRACERS]; /* AnisotropicMinimumDissipation Cnu and per-tracer Ckappa (closure == 2) */
+    double *tracers[OCN_MODEL_MAX_TRACERS];      /* DEVICE: the caller's tracer parents */
+    double *nu_e, *kappa_e[OCN_MODEL_MAX_TRACERS]; /* DEVICE: diffusivity fields (closure == 2), default boundary conditions */
+    double *pHY;              /* DEVICE: hydrostatic pressure anomaly or NULL (must equal terms.pHY) */
+    const ocn_field_bcs *bcs[3 + OCN_MODEL_MAX_TRACERS]; /* u, v, w, tracers...; NULL = defaults.  Copied at creation. */
+} ocn_model_driver_desc;
+typedef struct ocn_model_driver *ocn_model_driver_t;
+int ocn_model_driver_create(ocn_model_driver_t *driver, const ocn_grid *grid, const ocn_model_driver_desc *desc, double *u, double *v,
+                            double *w, double *p, ocn_poisson_t solver /* NULL: the handle creates its own */, void *stream);
+int ocn_model_driver_destroy(ocn_model_driver_t driver);
+int ocn_model_driver_time_step(ocn_model_driver_t driver, double dt, void *stream);
+/* completes the deferred compute_tendencies! and brings every prognostic field into the caller's arrays */
+int ocn_model_driver_flush(ocn_model_driver_t driver, void *stream);
+/* where field f (0, 1, 2 = u, v, w; 3 + n = tracer n) and its G^n are right now */
+int ocn_model_driver_field(ocn_model_driver_t driver, int32_t f, double **field, double **G);
 
 /* solve!(ϕ, ::BatchedTridiagonalSolver, rhs), z direction (src/Solvers/batched_tridiagonal_solver.jl:100-123,
  * 203-235).  a, c: real Nz-1; b: real Nx*Ny*Nz; f, phi: complex interleaved Nx*Ny*Nz; t: real scratch. */

@@ -358,4 +358,67 @@ function solve_for_pressure!(p, s::HIPDistributedPoissonSolver, Δt, U)
     end
 end
 
+# ---- the distributed step behind one call per rank (csrc/driver.hip: exchanges and collectives are issued by the library too) ----------
+"ONE RANK of a slab-x run: u*, v*, w* strips fly under the Poisson solve, only pressure planes cross after it, one full-slab launch"
+function HIPRK3Driver(model::HIPModel, s::HIPDistributedPoissonSolver)
+    h = Ref{Ptr{Cvoid}}(C_NULL); U = model.velocities
+    GC.@preserve model check(ccall((:ocn_rk3_driver_create_distributed, lib), Cint,
+        (Ptr{Ptr{Cvoid}}, Ref{OcnGrid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        h, Ref(OcnGrid(model.grid)), dptr(U.u), dptr(U.v), dptr(U.w), dptr(model.pressures.pNHS), s.handle, s.comm.handle, C_NULL))
+    d = HIPRK3Driver(h[])
+    finalizer(x -> ccall((:ocn_rk3_driver_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), d)
+    return d
+end
+"defer = false: pressure_correct_velocities! of the third stage runs inside time_step! (one GPU only)"
+defer_correction!(d::HIPRK3Driver, defer::Bool) = check(ccall((:ocn_rk3_driver_configure, lib), Cint, (Ptr{Cvoid}, Int32), d.handle, defer))
+"where u, v, w and Gⁿ are right now (device pointers; valid until the next call)"
+function driver_fields(d::HIPRK3Driver)
+    r = [Ref{Ptr{Float64}}(C_NULL) for _ in 1:6]
+    check(ccall((:ocn_rk3_driver_fields, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}},
+                Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), d.handle, r[1], r[2], r[3], r[4], r[5], r[6]))
+    return map(x -> x[], r)
+end
+
+# ---- config 4's term set behind one call (csrc/model_driver.hip): struct ocn_bc, ocn_field_bcs, ocn_model_driver_desc -------------------
+struct OcnBc
+    kind::Int32; _pad::Int32
+    value::Float64; coeff::Float64
+    values::Ptr{Float64}
+end
+OcnBc() = OcnBc(0, 0, 0.0, 0.0, C_NULL)
+struct OcnFieldBcs
+    west::OcnBc; east::OcnBc; south::OcnBc; north::OcnBc; bottom::OcnBc; top::OcnBc
+end
+struct OcnModelDriverDesc
+    terms::OcnModelTerms
+    n_tracers::Int32; tracer_T::Int32; tracer_S::Int32; _pad::Int32
+    kappa::NTuple{4, Float64}
+    C_nu::Float64; C_kappa::NTuple{4, Float64}
+    tracers::NTuple{4, Ptr{Float64}}
+    nu_e::Ptr{Float64}; kappa_e::NTuple{4, Ptr{Float64}}
+    pHY::Ptr{Float64}
+    bcs::NTuple{7, Ptr{OcnFieldBcs}}
+end
+mutable struct HIPModelDriver
+    handle :: Ptr{Cvoid}
+    keep   :: Any                                     # the boundary-condition structs, alive while create runs
+end
+function HIPModelDriver(model::HIPModel, desc::OcnModelDriverDesc; keep = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL); U = model.velocities
+    GC.@preserve model keep check(ccall((:ocn_model_driver_create, lib), Cint,
+        (Ptr{Ptr{Cvoid}}, Ref{OcnGrid}, Ref{OcnModelDriverDesc}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
+        h, Ref(OcnGrid(model.grid)), Ref(desc), dptr(U.u), dptr(U.v), dptr(U.w), dptr(model.pressures.pNHS), model.pressure_solver.handle, C_NULL))
+    d = HIPModelDriver(h[], nothing)
+    finalizer(x -> ccall((:ocn_model_driver_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), d)
+    return d
+end
+"time_step!(model, Δt) with tracers, closures, buoyancy and boundary fluxes: halo fills, compute_auxiliaries!, tendencies, projection"
+time_step!(d::HIPModelDriver, Δt) = check(ccall((:ocn_model_driver_time_step, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), d.handle, Δt, C_NULL))
+flush!(d::HIPModelDriver) = check(ccall((:ocn_model_driver_flush, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d.handle, C_NULL))
+function driver_field(d::HIPModelDriver, n::Integer)              # 0, 1, 2 = u, v, w; 3 + n = tracer n
+    f = Ref{Ptr{Float64}}(C_NULL); G = Ref{Ptr{Float64}}(C_NULL)
+    check(ccall((:ocn_model_driver_field, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), d.handle, n, f, G))
+    return (field = f[], G = G[])
+end
+
 end # module

@@ -16,7 +16,7 @@ from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,
                      cache_previous_tendencies, calculate_pressure_correction, compute_auxiliaries, compute_diffusivities,
-                     compute_tendencies, flush_tendencies, RK3Driver,
+                     compute_tendencies, flush_tendencies, RK3Driver, ModelRK3Driver,
                      pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_hydrostatic_pressure,
                      update_state)
 from .output import (AdvectiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, hasnan, set_from_checkpoint,

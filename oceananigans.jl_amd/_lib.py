@@ -45,6 +45,17 @@ class CFieldBcs(C.Structure):
     _fields_ = [(n, CBc) for n in ("west", "east", "south", "north", "bottom", "top")]
 
 
+MODEL_MAX_TRACERS = 4
+
+
+class CModelDriverDesc(C.Structure):
+    """struct ocn_model_driver_desc"""
+    _fields_ = [("terms", CModelTerms), ("n_tracers", C.c_int32), ("tracer_T", C.c_int32), ("tracer_S", C.c_int32), ("_pad", C.c_int32),
+                ("kappa", C.c_double * MODEL_MAX_TRACERS), ("C_nu", C.c_double), ("C_kappa", C.c_double * MODEL_MAX_TRACERS),
+                ("tracers", C.c_void_p * MODEL_MAX_TRACERS), ("nu_e", C.c_void_p), ("kappa_e", C.c_void_p * MODEL_MAX_TRACERS),
+                ("pHY", C.c_void_p), ("bcs", C.POINTER(CFieldBcs) * (3 + MODEL_MAX_TRACERS))]
+
+
 class CCommOp(C.Structure):
     """struct ocn_comm_op"""
     _fields_ = [("is_recv", C.c_int32), ("peer", C.c_int32), ("slot", C.c_int32)]
@@ -94,6 +105,7 @@ _SIGS = {
     "ocn_cell_advection_timescale": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],
     "ocn_hasnan": [_vp, C.c_int64, _vp, _vp],
     "ocn_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _i32, _vp],
+    "ocn_split_rk3_substep": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _dbl, _vp],
     "ocn_ab2_step": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _dbl, _dbl, _vp],
     "ocn_cache_previous_tendencies": [C.POINTER(CGrid), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), _vp],
     "ocn_pressure_correct_velocities": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _dbl, _vp],
@@ -133,6 +145,11 @@ _SIGS = {
     "ocn_rk3_driver_time_step": [_vp, _dbl, _vp],
     "ocn_rk3_driver_flush": [_vp, _vp],
     "ocn_rk3_driver_fields": [_vp] + [C.POINTER(_vp)] * 6,
+    "ocn_model_driver_create": [C.POINTER(_vp), C.POINTER(CGrid), C.POINTER(CModelDriverDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_model_driver_destroy": [_vp],
+    "ocn_model_driver_time_step": [_vp, _dbl, _vp],
+    "ocn_model_driver_flush": [_vp, _vp],
+    "ocn_model_driver_field": [_vp, _i32, C.POINTER(_vp), C.POINTER(_vp)],
     "ocn_halo_plane_x": [C.POINTER(CGrid), _vp, _i32, _i32, _vp, _i32, _vp],
     "ocn_halo_pack_pressure": [C.POINTER(CGrid), _vp, _vp, _dbl, _vp, _vp, _vp],
     "ocn_halo_unpack_pressure": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp],

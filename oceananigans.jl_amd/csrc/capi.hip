@@ -939,6 +939,18 @@ int ocn_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const dou
     return launch_stepper(grid, t, has_zeta ? 1 : 0, dt, gamma, zeta, as_stream(stream));
 }
 
+int ocn_split_rk3_substep(const ocn_grid *grid, int32_t n, double *const *U, const double *const *G, const double *const *Psi,
+                          const int32_t *locs, double dt, double gamma, double zeta, void *stream)
+{
+    int st = validate_grid_any(grid);
+    if (st != OCN_SUCCESS) return st;
+    StepTuple t;
+    st = make_step_tuple(n, U, G, const_cast<double *const *>(reinterpret_cast<const double *const *>(Psi)), locs, true, t);
+    if (st != OCN_SUCCESS) return st;
+    for (int f = 0; f < n; ++f) OCN_REQUIRE(Psi[f] != U[f], "ocn_split_rk3_substep: field %d: Psi must not alias U", f);
+    return launch_stepper(grid, t, 4, dt, gamma, zeta, as_stream(stream));
+}
+
 int ocn_ab2_step(const ocn_grid *grid, int32_t n, double *const *U, const double *const *Gn, const double *const *Gm,
                  const int32_t *locs, double dt, double chi, void *stream)
 {

@@ -1204,6 +1204,7 @@ int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream)
 // mode 1: rk3             U += dt*(gamma*Gn + zeta*Gm)
 // mode 2: ab2             U += dt*((1.5+chi)*Gn - (0.5+chi)*Gm*not_euler)   (c2 = not_euler)
 // mode 3: cache           Gm <- Gn   (U unused)
+// mode 4: split RK3       U = c2 * Psi + c1 * (U + dt * Gn)   (Psi = the field at the start of the step, in the Gm slot)
 // ---------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, double dt, double c1, double c2)
@@ -1230,6 +1231,9 @@ __global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, do
             // `* not_euler` with a Julia Bool is a strong zero: 0.0 even when G⁻ holds NaN (quasi_adams_bashforth_2.jl:169)
             const double G = (1.5 + c1) * a.Gn[f][o] - ((c2 != 0.0) ? (0.5 + c1) * a.Gm[f][o] : 0.0);
             a.U[f][o] += dt * G;
+        } else if (MODE == 4) {
+            // split_rk3_substep_field! (hydrostatic_free_surface_rk3_step.jl:30-60): Uᵐ⁺¹ = ζ Ψⁿ + γ (Uᵐ + Δt Gᵐ), Ψⁿ in the Gm slot
+            a.U[f][o] = c2 * a.Gm[f][o] + c1 * (a.U[f][o] + dt * a.Gn[f][o]);
         } else {
             a.Gm[f][o] = a.Gn[f][o];
         }
@@ -1245,6 +1249,7 @@ int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double d
         case 0: hipLaunchKernelGGL(stepper_kernel<0>, nb, block, 0, stream, g, st, dt, c1, c2); break;
         case 1: hipLaunchKernelGGL(stepper_kernel<1>, nb, block, 0, stream, g, st, dt, c1, c2); break;
         case 2: hipLaunchKernelGGL(stepper_kernel<2>, nb, block, 0, stream, g, st, dt, c1, c2); break;
+        case 4: hipLaunchKernelGGL(stepper_kernel<4>, nb, block, 0, stream, g, st, dt, c1, c2); break;
         default: hipLaunchKernelGGL(stepper_kernel<3>, nb, block, 0, stream, g, st, dt, c1, c2); break;
     }
     OCN_CHECK_HIP(hipGetLastError());

@@ -305,7 +305,8 @@ class HydrostaticFreeSurfaceModel:
         """time_step!(model::AbstractModel{<:SplitRungeKutta3TimeStepper}, Δt) (split_hydrostatic_runge_kutta_3.jl:76-133) with
         split_rk3_substep!(::HydrostaticFreeSurfaceModel) (hydrostatic_free_surface_rk3_step.jl:7-28): see oracle/hydrostatic.py
         `_time_step_split_rk3` for the sequence.  The 3-D tendencies, the vertical integrals, the substepping, the corrector and
-        update_state! are the library's kernels; the stage combinations are elementwise IEEE operations in the reference's order."""
+        update_state! are the library's kernels, and so are the stage combinations of the 3-D fields (ocn_split_rk3_substep); the combinations of
+        the 2-D barotropic planes (η, U, V, the integrated tendencies) are elementwise IEEE operations in the reference's order."""
         nh, g, clock, s = self._nh, self.grid, self.clock, stream_ptr()
         if clock.iteration == 0:
             if not self._initialized:
@@ -337,12 +338,16 @@ class HydrostaticFreeSurfaceModel:
             else:
                 self._GU.copy_(2 * GUi / three + GUm); self._GV.copy_(2 * GVi / three + GVm)
                 self.U.copy_(psi_U); self.V.copy_(psi_V); self.eta.copy_(psi_eta)
-            for q, (f, P) in enumerate(zip(stepped, psi)):
-                fi, Pi, Gi = f.data[kk, ii, jj], P[kk, ii, jj], Gn[gidx[q]].data[kk, ii, jj]
-                if stage == 1:
-                    fi.copy_((fi + dt * Gi) if q < 2 else (Pi + dt * Gi * 1.0))
-                else:
-                    fi.copy_(zet * Pi + gam * (fi + dt * Gi))
+            # split_rk3_substep_field! of u, v and the tracers in ONE launch: stage 1 is Uⁿ + Δt G (for the tracers Ψⁿ + Δt G·1: the same
+            # bits), stages 2 and 3 ζ Ψⁿ + γ (Uᵐ + Δt Gᵐ)
+            pa = _lib.ptr_array
+            locs = _lib.i32_array([f.loc for f in stepped])
+            Gs = pa([Gn[q].ptr for q in gidx])
+            if stage == 1:
+                _lib.call("ocn_rk3_substep", g.cref, len(stepped), pa([f.ptr for f in stepped]), Gs, Gs, locs, float(dt), 1.0, 0.0, 0, s)
+            else:
+                _lib.call("ocn_split_rk3_substep", g.cref, len(stepped), pa([f.ptr for f in stepped]), Gs, pa([P.data_ptr() for P in psi]), locs,
+                          float(dt), float(gam), float(zet), s)
             self._substep_free_surface(dt, s)                                      # the complete substepping over Δt
             if stage == 2:
                 self.U[ii, jj] = zet * psi_U[ii, jj] + gam * self.U[ii, jj]

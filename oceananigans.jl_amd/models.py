@@ -129,9 +129,18 @@ class NonhydrostaticModel:
                 raise ValueError(f"boundary conditions given for unknown field {name!r}")
             if not isinstance(bcs[name], FieldBoundaryConditions):
                 raise TypeError("boundary_conditions values must be FieldBoundaryConditions")
-        if "w" in bcs and not bcs["w"].is_default():
-            raise NotImplementedError("w keeps its impenetrable bottom / top boundary condition")
-        self.u, self.v, self.w = XFaceField(grid, bcs.get("u")), YFaceField(grid, bcs.get("v")), ZFaceField(grid)
+        # validate_boundary_condition_topology (boundary_condition.jl:128-136) + the impenetrable wall-normal component
+        normal = {"u": ("west", "east"), "v": ("south", "north"), "w": ("bottom", "top")}
+        for name, b in bcs.items():
+            for d, pair in enumerate((("west", "east"), ("south", "north"), ("bottom", "top"))):
+                for side in pair:
+                    if b.sides[side] is None:
+                        continue
+                    if grid.topology[d] != "Bounded":
+                        raise ValueError(f"Cannot set {side} boundary condition of {name} in a `{grid.topology[d]}` direction!")
+                    if side in normal.get(name, ()):
+                        raise NotImplementedError(f"{name} keeps its impenetrable {side} boundary condition (open boundaries are not implemented)")
+        self.u, self.v, self.w = XFaceField(grid, bcs.get("u")), YFaceField(grid, bcs.get("v")), ZFaceField(grid, bcs.get("w"))
         self.velocities = (self.u, self.v, self.w)
         self.tracer_names = tracers
         self.tracers = tuple(CenterField(grid, bcs.get(n)) for n in self.tracer_names)
@@ -721,6 +730,99 @@ class RK3Driver:
         if h is not None and h.value:
             try:
                 _lib.lib().ocn_rk3_driver_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class ModelRK3Driver:
+    """time_step!(model, Δt) of a model WITH tracers and the §8(f) terms (config 4's term set) behind ONE entry point of the C ABI
+    (ocn_model_driver_*, csrc/model_driver.hip): halo fills, compute_auxiliaries!, the fused tendency / substep launches and the pressure
+    projection are issued by the library in the order `time_step(model, dt)` issues them on the general fused path, so after flush() the
+    state is bit-identical to the Python host's -- without an interpreter between the ~20 launches of a stage.  One GPU, Periodic x / y,
+    WENO or UpwindBiased advection, RungeKutta3; number- or array-valued boundary conditions (functions of time are refused)."""
+
+    def __init__(self, model, own_solver=False):
+        if not isinstance(model.timestepper, RungeKutta3TimeStepper):
+            raise NotImplementedError("ModelRK3Driver: RungeKutta3")
+        if not (model.fuse_stage_boundaries and model._general_fused):
+            raise NotImplementedError("ModelRK3Driver: a model on the general fused path (tracers and / or extra terms, WENO / UpwindBiased "
+                                      "advection, Periodic x and y); plain WENO models take RK3Driver")
+        if hasattr(model.grid.architecture, "partition"):
+            raise NotImplementedError("ModelRK3Driver: one GPU")
+        nt = len(model.tracers)
+        if nt > _lib.MODEL_MAX_TRACERS:
+            raise NotImplementedError(f"ModelRK3Driver: at most {_lib.MODEL_MAX_TRACERS} tracers")
+        prog = model.prognostic_fields()
+        for f in prog:
+            b = getattr(f, "boundary_conditions", None)
+            if b is not None and any(s is not None and s.func is not None for s in b.sides.values()):
+                raise NotImplementedError("ModelRK3Driver: boundary conditions that are functions of time need the Python host")
+        d = model.diffusivity_fields
+        if d is not None:
+            for f in (d["nu_e"],) + tuple(d["kappa_e"]):
+                b = getattr(f, "boundary_conditions", None)
+                if b is not None and not b.is_default():
+                    raise NotImplementedError("ModelRK3Driver: boundary conditions on the diffusivity fields need the Python host")
+        flush_tendencies(model)
+        self.model = model
+        desc = _lib.CModelDriverDesc()
+        model._refresh_term_pointers()
+        C.memmove(C.byref(desc.terms), C.byref(model._terms), C.sizeof(_lib.CModelTerms))
+        desc.n_tracers = nt
+        desc.tracer_T = desc.tracer_S = -1
+        b = model.buoyancy
+        names = list(model.tracer_names)
+        if isinstance(b, BuoyancyTracer):
+            desc.tracer_T = names.index("b")
+        elif isinstance(b, SeawaterBuoyancy):
+            if b.constant_temperature is None:
+                desc.tracer_T = names.index("T")
+            if b.constant_salinity is None:
+                desc.tracer_S = names.index("S")
+        amd = isinstance(model.closure, AnisotropicMinimumDissipation)
+        if amd:
+            desc.C_nu = model.closure.Cnu
+            desc.nu_e = d["nu_e"].ptr
+        for n, name in enumerate(names):
+            desc.tracers[n] = model.tracers[n].ptr
+            if amd:
+                desc.C_kappa[n] = model.closure.Ckappa_of(name)
+                desc.kappa_e[n] = d["kappa_e"][n].ptr
+            elif model.closure is not None:
+                desc.kappa[n] = model.closure.kappa_of(name)
+        desc.pHY = None if model.pHY is None else model.pHY.ptr
+        self._bcs = []  # keep the structs alive until the library has copied them
+        for n, f in enumerate(prog):
+            bc = getattr(f, "boundary_conditions", None)
+            if bc is not None and not bc.is_default():
+                self._bcs.append(bc.c_struct(model.grid))
+                desc.bcs[n] = C.pointer(self._bcs[-1])
+        self._h = C.c_void_p()
+        _lib.call("ocn_model_driver_create", C.byref(self._h), model.grid.cref, C.byref(desc), model.u.ptr, model.v.ptr, model.w.ptr,
+                  model.pNHS.ptr, None if own_solver else model.pressure_solver._h, stream_ptr())
+
+    def time_step(self, dt):
+        _lib.call("ocn_model_driver_time_step", self._h, float(dt), stream_ptr())
+        clock = self.model.clock
+        clock.time += dt
+        clock.iteration += 1
+        clock.last_dt = dt
+
+    def flush(self):
+        """every prognostic field back in the model's arrays, deferred tendencies completed"""
+        _lib.call("ocn_model_driver_flush", self._h, stream_ptr())
+
+    def tendency_pointer(self, n):
+        f, G = C.c_void_p(), C.c_void_p()
+        _lib.call("ocn_model_driver_field", self._h, int(n), C.byref(f), C.byref(G))
+        return G.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _lib.lib().ocn_model_driver_destroy(h)
             except Exception:
                 pass
             self._h = None

@@ -235,8 +235,8 @@ def GradientBoundaryCondition(condition=0.0, parameters=None):
 
 class FieldBoundaryConditions:
     """FieldBoundaryConditions(; west, east, south, north, bottom, top); unspecified sides keep the topology defaults
-    (field_boundary_conditions.jl:15-33).  Bottom / top: Flux, Value, Gradient; west / east / south / north (Bounded x / y grids):
-    Value, Gradient."""
+    (field_boundary_conditions.jl:15-33).  Flux, Value, Gradient on every side of a Bounded direction (west / east / south / north:
+    numbers only; the fluxes enter through apply_x_bcs! / apply_y_bcs!, apply_flux_bcs.jl:38-146)."""
     SIDES = ("west", "east", "south", "north", "bottom", "top")
 
     def __init__(self, **sides):
@@ -244,9 +244,10 @@ class FieldBoundaryConditions:
             if k not in self.SIDES:
                 raise TypeError(f"unknown boundary {k!r}")
         for k in ("west", "east", "south", "north"):
-            if sides.get(k) is not None and sides[k].kind == _lib.BC_FLUX:
-                raise NotImplementedError("Flux boundary conditions on west / east / south / north are not implemented (apply_x_bcs!, apply_y_bcs!); "
-                                          "Value and Gradient conditions are (Bounded x / y grids)")
+            b = sides.get(k)
+            if b is not None and (b.values is not None or b.func is not None):
+                raise NotImplementedError("array / function boundary conditions on west / east / south / north are not implemented "
+                                          "(numbers and condition + coeff * c are)")
         self.sides = {k: sides.get(k) for k in self.SIDES}
         self._c = None
 

@@ -310,3 +310,65 @@ def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, monkeypa
                 lap += (a[sl(1)] - 2 * c + a[sl(-1)]) / D[d] ** 2
             assert np.abs(lap - R).max() <= np.sqrt(np.finfo(float).eps) * np.abs(R).max()
     assert np.abs(sols[0] - sols[1]).max() <= 1e-12 * np.abs(sols[1]).max()
+
+
+@pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((1, 9, 8), "FBB")])
+def test_flux_conditions_on_x_y_walls_bitwise(oracle, ocn, size, topo):
+    """apply_x_bcs! / apply_y_bcs! / apply_z_bcs! (apply_flux_bcs.jl:38-160): fluxes through west / east / south / north / bottom / top of a
+    tracer, through south / north / top of u and through west / east of w (a Face-in-z field: the face spacing enters area and volume) are
+    added to G in the reference's order x, y, z -- corner cells take up to three contributions -- bit for bit, on a stretched z"""
+    O = oracle
+    rng = np.random.default_rng(21)
+    zf = -0.7 * np.linspace(1, 0, size[2] + 1) ** 1.3
+    og, pg = make_pair(O, ocn, size, topo, x=(0, 1.3), y=(0, 0.9), z=zf)
+    assert og.zf is not None
+    xb = topo[0] == "B"
+    sides = {
+        0: dict(south=(0.3, 0.0), north=(-1.1, 0.2), bottom=(0.7, 0.0), top=(2.0, -0.4), **({"west": (0.9, 0.0), "east": (-0.6, 0.5)} if xb else {})),
+        1: dict(south=(1.3, 0.0), north=(0.0, 0.7), top=(-0.2, 0.0)),
+        4: ({"west": (0.4, 0.3), "east": (1.9, 0.0)} if xb else {}) | dict(south=(-0.8, 0.0)),
+    }
+    locs = [0, 1, 4]
+    c = [random_parent(og, l, rng) for l in locs]
+    G = [random_parent(og, l, rng) for l in locs]
+    dc = [to_dev(ocn, pg, l, a) for l, a in zip(locs, c)]
+    dG = [to_dev(ocn, pg, l, a) for l, a in zip(locs, G)]
+    pb = []
+    for l, a, g in zip(locs, c, G):
+        O.apply_flux_bcs(og, l, a, g, {k: O.BC("flux", v, coeff) for k, (v, coeff) in sides[l].items()})
+        pb.append(ocn.FieldBoundaryConditions(**{k: ocn.FluxBoundaryCondition(v, coeff) for k, (v, coeff) in sides[l].items()}))
+    arr = (C.POINTER(ocn._lib.CFieldBcs) * 3)(*[C.pointer(b.c_struct(pg)) for b in pb])
+    ocn._lib.call("ocn_apply_flux_bcs", pg.cref, ocn._lib.ptr_array([f.ptr for f in dG]), ocn._lib.ptr_array([f.ptr for f in dc]),
+                  ocn._lib.i32_array(locs), arr, 3, 0)
+    ocn.sync_device()
+    for l, a, b in zip(locs, G, dG):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} loc {l}")
+
+
+def test_channel_model_with_wall_fluxes_matches_oracle(oracle, ocn):
+    """(Periodic, Bounded, Bounded) channel with ScalarDiffusivity, a tracer heated through the south wall and cooled through the north
+    one, u dragged at the north wall (condition + coeff * u): 3 RK3 steps against the oracle's model, 1e-11 (cosine-transform rounding)"""
+    O = oracle
+    og, pg = _pair(O, ocn, (16, 12, 10), "PBB")
+    rng = np.random.default_rng(22)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    ob = {"c": {"south": O.BC("flux", 0.8), "north": O.BC("flux", 0.8), "top": O.BC("flux", -0.3)}, "u": {"north": O.BC("flux", 0.0, 0.6)}}
+    pbc = {"c": ocn.FieldBoundaryConditions(south=ocn.FluxBoundaryCondition(0.8), north=ocn.FluxBoundaryCondition(0.8), top=ocn.FluxBoundaryCondition(-0.3)),
+           "u": ocn.FieldBoundaryConditions(north=ocn.FluxBoundaryCondition(0.0, 0.6))}
+    om = O.NonhydrostaticModel(og, tracers=("c",), closure=(0.02, {"c": 0.03}), boundary_conditions=ob)
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("c",), closure=ocn.ScalarDiffusivity(ν=0.02, κ=0.03), boundary_conditions=pbc)
+    init = {n: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for n, l in zip("uvw", LOCS)}
+    init["c"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
+    om.set(**init)
+    ocn.set(pm, **init)
+    c0 = og.interior(om.tracers[0]).mean()
+    for _ in range(3):
+        om.time_step(2e-3)
+        ocn.time_step(pm, 2e-3)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    scale = max(np.abs(a).max() for a in (om.u, om.v, om.w))
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "c")):
+        assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-11 * max(scale, 1.0), name
+    # the south flux enters, the north and top fluxes leave: d<c>/dt = 0.8/Ly - 0.8/Ly + 0.3/Lz
+    assert abs((og.interior(from_dev(pm.tracers[0])).mean() - c0) / (3 * 2e-3) - 0.3 / 0.7) < 1e-9

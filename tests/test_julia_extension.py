@@ -17,6 +17,7 @@ REQUIRED = {
     "ocn_fill_halo_regions", "ocn_compute_momentum_tendencies", "ocn_compute_tracer_tendency", "ocn_rk3_substep", "ocn_ab2_step",
     "ocn_cache_previous_tendencies", "ocn_poisson_create", "ocn_poisson_destroy", "ocn_solve_for_pressure",
     "ocn_pressure_correct_velocities", "ocn_rk3_driver_create", "ocn_rk3_driver_time_step", "ocn_rk3_driver_flush",
+    "ocn_rk3_driver_create_distributed", "ocn_rk3_driver_configure", "ocn_model_driver_create", "ocn_model_driver_time_step", "ocn_model_driver_flush",
     "ocn_comm_unique_id", "ocn_comm_init", "ocn_halo_exchange_begin", "ocn_halo_exchange_end", "ocn_dist_poisson_create",
     "ocn_dist_poisson_exchange", "ocn_compute_momentum_tendencies_terms", "ocn_compute_tracer_tendency_terms",
 }
@@ -144,18 +145,46 @@ def _c_struct_fields(name):
         for nm in names.split(","):
             nm = nm.strip()
             ptr = "*" in ctype or nm.startswith("*")
-            fields.append((nm.lstrip("* "), "ptr" if ptr else c_kind(ctype)))
+            nm = nm.lstrip("* ")
+            count = None
+            am = re.match(r"([A-Za-z0-9_]+)\[(.*)\]$", nm)  # fixed arrays: name[expr] with the header's #define constants
+            if am:
+                nm = am.group(1)
+                expr = am.group(2)
+                for k, v in re.findall(r"#define\s+([A-Z0-9_]+)\s+(\d+)", src):
+                    expr = re.sub(r"\b" + k + r"\b", v, expr)
+                count = int(eval(expr, {"__builtins__": {}}))
+            base = ctype.replace("const ", "").replace("*", "").strip()
+            kind = "ptr" if ptr else ("struct:" + base if base.startswith("ocn_") and not base.endswith("_t") else c_kind(ctype))
+            fields.append((nm, kind if count is None else f"{count}x{kind}"))
     return fields
 
 
 def _julia_struct_fields(name):
     src = strip_julia_comments(open(EXT).read())
     body = re.search(r"\bstruct " + name + r"\b(.*?)\bend\b", src, flags=re.S).group(1)
-    return [(n, julia_kind(t)) for n, t in re.findall(r"([A-Za-z_][A-Za-z0-9_]*)::([A-Za-z0-9_{}]+)", body)]
+    out = []
+    for n, t in re.findall(r"([A-Za-z_][A-Za-z0-9_]*)::([A-Za-z0-9_{}, ]+?)(?=;|\n|$)", body):
+        t = t.strip()
+        m = re.match(r"NTuple\{(\d+), *(.*)\}$", t)
+        if m:
+            out.append((n, f"{m.group(1)}x{_julia_field_kind(m.group(2))}"))
+        else:
+            out.append((n, _julia_field_kind(t)))
+    return out
 
 
-@pytest.mark.parametrize("cname,jname", [("ocn_grid", "OcnGrid"), ("ocn_model_terms", "OcnModelTerms")])
+JULIA_STRUCTS = {"OcnGrid": "ocn_grid", "OcnModelTerms": "ocn_model_terms", "OcnBc": "ocn_bc", "OcnFieldBcs": "ocn_field_bcs",
+                 "OcnModelDriverDesc": "ocn_model_driver_desc"}
+
+
+def _julia_field_kind(t):
+    return "struct:" + JULIA_STRUCTS[t] if t in JULIA_STRUCTS else julia_kind(t)
+
+
+@pytest.mark.parametrize("jname,cname", sorted(JULIA_STRUCTS.items()))
 def test_julia_mirror_structs_match_the_c_structs(cname, jname):
+    """field names, order, scalar / pointer kinds, nested structs and fixed-array lengths (NTuple{N, T} <-> T name[N])"""
     assert _julia_struct_fields(jname) == _c_struct_fields(cname)
 
 
