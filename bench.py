@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--driver", choices=("auto", "python", "c"), default="auto",
                     help="host orchestration of the step: the Python mirror of the reference's time_step! (per-kernel entry points), or "
                          "ocn_rk3_driver_time_step -- ONE C call per (rank-)step, collectives included, the third stage's pressure correction "
-                         "deferred onto the next step's first launch (box workload); auto = c where it applies")
+                         "deferred onto the next step's first launch (box), ocn_model_driver_time_step for config 4's term set; auto = c where it applies")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--substeps", type=int, default=30, help="config5: SplitExplicitFreeSurface(substeps = ...)")
@@ -403,10 +403,8 @@ def main():
             umax = dist.allreduce_max(umax.reshape(1))[0]
         dt = 0.1 * min(grid.dx, dmin) / float(umax)
         prognostic = model.prognostic_fields()
-        if a.driver == "c" and a.workload != "box" and world > 1:
-            raise SystemExit("--driver c: box workload (one GPU, or one C call per rank-step with --gpus N), or config4 on one GPU")
         drv = None
-        if a.driver in ("c", "auto") and (a.workload == "box" or world == 1):
+        if a.driver in ("c", "auto"):
             try:
                 drv = ocn.RK3Driver(model) if a.workload == "box" else ocn.ModelRK3Driver(model)
             except (NotImplementedError, ocn.OcnError) as e:  # e.g. a slab size outside the library's slab pipelines

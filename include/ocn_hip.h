@@ -628,7 +628,13 @@ int ocn_comm_barrier(ocn_comm_t comm);
  * Bit-identical to the per-call sequence of oceananigans.jl_amd/distributed.py (tests/test_gpu_distributed.py).  The third stage's
  * correction is always deferred (see ocn_rk3_driver_configure); flush / fields / destroy as above. */
 int ocn_rk3_driver_create_distributed(ocn_rk3_driver_t *driver, const ocn_grid *local_grid, double *u, double *v, double *w, double *p,
-                                      ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream);                      /* MPI.Barrier; blocks the host */
+                                      ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream);
+/* ONE RANK of a slab-x run (local grid (FullyConnected, Periodic, *), RCCL communicator, the rank's distributed Poisson handle on one of
+ * its slab pipelines): every x exchange -- the strips of the prognostic fields and of nu_e / kappa_e in update_state!, the single planes
+ * of u and p inside the projection of stages 1 and 2, the solver's transposes or all-gather -- is issued by the library.  The exchange is
+ * synchronous here (no interior / buffer split: distributed.py::update_state_general overlaps it); results are identical. */
+int ocn_model_driver_create_distributed(ocn_model_driver_t *driver, const ocn_grid *local_grid, const ocn_model_driver_desc *desc, double *u,
+                                        double *v, double *w, double *p, ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream);                      /* MPI.Barrier; blocks the host */
 
 #ifdef __cplusplus
 }

@@ -412,6 +412,16 @@ function HIPModelDriver(model::HIPModel, desc::OcnModelDriverDesc; keep = nothin
     finalizer(x -> ccall((:ocn_model_driver_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), d)
     return d
 end
+"ONE RANK of a slab-x run of the same term set: every exchange (strips, planes, the solver's transposes) is issued by the library"
+function HIPModelDriver(model::HIPModel, desc::OcnModelDriverDesc, s::HIPDistributedPoissonSolver; keep = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL); U = model.velocities
+    GC.@preserve model keep check(ccall((:ocn_model_driver_create_distributed, lib), Cint,
+        (Ptr{Ptr{Cvoid}}, Ref{OcnGrid}, Ref{OcnModelDriverDesc}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+        h, Ref(OcnGrid(model.grid)), Ref(desc), dptr(U.u), dptr(U.v), dptr(U.w), dptr(model.pressures.pNHS), s.handle, s.comm.handle, C_NULL))
+    d = HIPModelDriver(h[], nothing)
+    finalizer(x -> ccall((:ocn_model_driver_destroy, lib), Cint, (Ptr{Cvoid},), x.handle), d)
+    return d
+end
 "time_step!(model, Δt) with tracers, closures, buoyancy and boundary fluxes: halo fills, compute_auxiliaries!, tendencies, projection"
 time_step!(d::HIPModelDriver, Δt) = check(ccall((:ocn_model_driver_time_step, lib), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}), d.handle, Δt, C_NULL))
 flush!(d::HIPModelDriver) = check(ccall((:ocn_model_driver_flush, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), d.handle, C_NULL))

@@ -146,6 +146,7 @@ _SIGS = {
     "ocn_rk3_driver_flush": [_vp, _vp],
     "ocn_rk3_driver_fields": [_vp] + [C.POINTER(_vp)] * 6,
     "ocn_model_driver_create": [C.POINTER(_vp), C.POINTER(CGrid), C.POINTER(CModelDriverDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    "ocn_model_driver_create_distributed": [C.POINTER(_vp), C.POINTER(CGrid), C.POINTER(CModelDriverDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ocn_model_driver_destroy": [_vp],
     "ocn_model_driver_time_step": [_vp, _dbl, _vp],
     "ocn_model_driver_flush": [_vp, _vp],

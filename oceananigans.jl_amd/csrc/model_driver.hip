@@ -1,5 +1,5 @@
 // model_driver.hip -- time_step!(model::NonhydrostaticModel{<:RungeKutta3TimeStepper}, Δt) as ONE call of the C ABI for a model with
-// tracers and the SURVEY §8(f) terms (config 4's term set), one GPU, Periodic x and y:
+// tracers and the SURVEY §8(f) terms (config 4's term set), one GPU with Periodic x and y, or ONE RANK of a slab-x run:
 //   runge_kutta_3.jl:77-151, update_nonhydrostatic_model_state.jl:20-70, compute_nonhydrostatic_tendencies.jl:17-54, 204-213,
 //   pressure_correction.jl:8-50, store_tendencies.jl:12-22.
 // Host code only: every device operation is one of the public entry points, issued in the order the Python host issues them on its
@@ -38,6 +38,9 @@ struct ocn_model_driver {
     bool any_bcs = false, any_flux = false, momentum_extra = false;
     bool pending = false, started = false;
     long long iteration = 0;
+    // slab-x rank (ocn_model_driver_create_distributed): RCCL communicator + distributed Poisson handle, both borrowed
+    ocn_comm_t comm = nullptr;
+    ocn_dist_poisson_t dsolver = nullptr;
 };
 
 namespace {
@@ -69,8 +72,29 @@ int fill(ocn_model_driver *d, double *const *fields, const int32_t *locs, const 
 {
     bool any = false;
     for (int f = 0; f < n && bcs; ++f) any = any || bcs[f];
-    if (any) return ocn_fill_halo_regions_bcs(&d->grid, fields, locs, bcs, n, fbnv, stream);
-    return ocn_fill_halo_regions(&d->grid, fields, locs, n, fbnv, stream);
+    int st = any ? ocn_fill_halo_regions_bcs(&d->grid, fields, locs, bcs, n, fbnv, stream) : ocn_fill_halo_regions(&d->grid, fields, locs, n, fbnv, stream);
+    if (st != OCN_SUCCESS || !d->comm) return st;
+    // a slab: local (y, z) fills first, the x exchange with the neighbours last (fill_halo_regions.jl:148-196); synchronous
+    st = ocn_halo_exchange_begin(d->comm, &d->grid, fields, locs, n, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_halo_exchange_end(d->comm, &d->grid, fields, locs, n, stream);
+}
+
+// solve_for_pressure! on one GPU or on a slab (the slab pipelines of the handle, csrc/poisson.hip)
+int solve(ocn_model_driver *d, double stage_dt, void *stream)
+{
+    if (!d->dsolver) return ocn_solve_for_pressure(d->solver, d->p, d->U[0], d->U[1], d->U[2], stage_dt, stream);
+    int st = ocn_dist_poisson_source_term(d->dsolver, d->U[0], d->U[1], d->U[2], stage_dt, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_forward_yz(d->dsolver, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_exchange(d->dsolver, d->comm, 0, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_solve_x(d->dsolver, stream);
+    if (st != OCN_SUCCESS) return st;
+    st = ocn_dist_poisson_exchange(d->dsolver, d->comm, 1, stream);
+    if (st != OCN_SUCCESS) return st;
+    return ocn_dist_poisson_backward_yz(d->dsolver, d->p, stream);
 }
 
 // compute_auxiliaries! (update_nonhydrostatic_model_state.jl:59-70) + the diffusivity halo fill (:48)
@@ -94,7 +118,7 @@ int compute_auxiliaries(ocn_model_driver *d, void *stream)
             f[1 + t] = d->kappa_e[t];
             l[1 + t] = OCN_LOC_CCC;
         }
-        st = ocn_fill_halo_regions(&d->grid, f, l, 1 + d->nt, 1, stream);
+        st = fill(d, f, l, nullptr, 1 + d->nt, 1, stream);
         if (st != OCN_SUCCESS) return st;
     }
     return OCN_SUCCESS;
@@ -172,24 +196,41 @@ int fused_launch(ocn_model_driver *d, double dt, double gamma, double zeta, int 
     return OCN_SUCCESS;
 }
 
-// calculate_pressure_correction! + pressure_correct_velocities! (pressure_correction.jl:8-50)
-int project(ocn_model_driver *d, double stage_dt, void *stream)
+// calculate_pressure_correction! + pressure_correct_velocities! (pressure_correction.jl:8-50).  minimal (a slab, stages 1 and 2, whose
+// update_state! refills every halo right afterwards): the two synchronous x exchanges move only the planes the projection reads --
+// u[nx+1] for the divergence and p[0] for the pressure gradient at the first face -- instead of all 2 Hx planes of u, v, w and p
+int project(ocn_model_driver *d, double stage_dt, bool minimal, void *stream)
 {
-    int st = fill(d, d->U, d->locs, d->bcs, 3, 1, stream);
-    if (st != OCN_SUCCESS) return st;
-    st = ocn_solve_for_pressure(d->solver, d->p, d->U[0], d->U[1], d->U[2], stage_dt, stream);
-    if (st != OCN_SUCCESS) return st;
     const int32_t ploc = OCN_LOC_CCC;
     double *pf[1] = {d->p};
-    st = ocn_fill_halo_regions(&d->grid, pf, &ploc, 1, 1, stream);
-    if (st != OCN_SUCCESS) return st;
+    int st;
+    if (d->comm && minimal) {
+        const bool any = d->bcs[0] || d->bcs[1] || d->bcs[2];
+        st = any ? ocn_fill_halo_regions_bcs(&d->grid, d->U, d->locs, d->bcs, 3, 1, stream) : ocn_fill_halo_regions(&d->grid, d->U, d->locs, 3, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_halo_exchange_plane(d->comm, &d->grid, d->U[0], OCN_LOC_FCC, 0, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = solve(d, stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_fill_halo_regions(&d->grid, pf, &ploc, 1, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_halo_exchange_plane(d->comm, &d->grid, d->p, OCN_LOC_CCC, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+    } else {
+        st = fill(d, d->U, d->locs, d->bcs, 3, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = solve(d, stage_dt, stream);
+        if (st != OCN_SUCCESS) return st;
+        st = fill(d, pf, &ploc, nullptr, 1, 1, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
     return ocn_pressure_correct_velocities(&d->grid, d->U[0], d->U[1], d->U[2], d->p, stage_dt, stream);
 }
 
 // everything between two substeps (runge_kutta_3.jl:103-118)
 int project_and_advance(ocn_model_driver *d, double dt, double stage_dt, double gamma_next, double zeta_next, void *stream)
 {
-    int st = project(d, stage_dt, stream);
+    int st = project(d, stage_dt, true, stream);
     if (st != OCN_SUCCESS) return st;
     for (int f = 0; f < d->n; ++f) std::swap(d->Gn[f], d->Gm[f]);  // cache_previous_tendencies! as a role swap
     st = update_state(d, stream);
@@ -211,13 +252,27 @@ extern "C" int ocn_model_driver_destroy(ocn_model_driver_t d)
     return OCN_SUCCESS;
 }
 
-extern "C" int ocn_model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, const ocn_model_driver_desc *desc, double *u, double *v,
-                                       double *w, double *p, ocn_poisson_t solver, void *stream)
+static int model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, const ocn_model_driver_desc *desc, double *u, double *v, double *w,
+                               double *p, ocn_poisson_t solver, ocn_dist_poisson_t dsolver, ocn_comm_t comm, void *stream)
 {
     OCN_REQUIRE(out && grid && desc && u && v && w && p, "ocn_model_driver_create: null argument");
     int st = ocn::validate_grid(grid);
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_model_driver_create: x and y must be Periodic (one GPU)");
+    if (comm) {
+        OCN_REQUIRE(grid->tx == OCN_FULLY_CONNECTED && grid->ty == OCN_PERIODIC && dsolver,
+                    "ocn_model_driver_create_distributed: a (FullyConnected, Periodic, *) local grid and its distributed Poisson handle");
+        int32_t fast = 0;
+        st = ocn_dist_poisson_pipeline(dsolver, &fast);
+        if (st != OCN_SUCCESS) return st;
+        if (fast < 1 || fast > 3) {
+            ocn::set_error("ocn_model_driver_create_distributed: the Poisson handle runs the transposing path (sizes outside the slab "
+                           "pipelines): drive it through the per-call entry points");
+            return OCN_ERR_UNSUPPORTED;
+        }
+        OCN_REQUIRE(grid->Nx >= grid->Hx, "ocn_model_driver_create_distributed: the local slab must be at least a halo wide");
+    } else {
+        OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_model_driver_create: x and y must be Periodic (one GPU)");
+    }
     OCN_REQUIRE(desc->n_tracers >= 0 && desc->n_tracers <= OCN_MODEL_MAX_TRACERS, "ocn_model_driver_create: n_tracers %d outside 0..%d",
                 desc->n_tracers, OCN_MODEL_MAX_TRACERS);
     const ocn_model_terms &t = desc->terms;
@@ -241,6 +296,8 @@ extern "C" int ocn_model_driver_create(ocn_model_driver_t *out, const ocn_grid *
     d->tT = needT ? desc->tracer_T : -1;
     d->tS = needS ? desc->tracer_S : -1;
     d->p = p;
+    d->comm = comm;
+    d->dsolver = dsolver;
     d->pHY = desc->pHY;
     d->nu_e = desc->nu_e;
     d->Cnu = desc->C_nu;
@@ -283,7 +340,9 @@ extern "C" int ocn_model_driver_create(ocn_model_driver_t *out, const ocn_grid *
         d->A[f] = d->own[f];
     }
     refresh_terms(d);
-    if (solver) {
+    if (comm) {
+        d->owns_solver = false;
+    } else if (solver) {
         d->solver = solver;
         d->owns_solver = false;
     } else {
@@ -300,6 +359,19 @@ extern "C" int ocn_model_driver_create(ocn_model_driver_t *out, const ocn_grid *
     }
     *out = d;
     return OCN_SUCCESS;
+}
+
+extern "C" int ocn_model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, const ocn_model_driver_desc *desc, double *u, double *v,
+                                       double *w, double *p, ocn_poisson_t solver, void *stream)
+{
+    return model_driver_create(out, grid, desc, u, v, w, p, solver, nullptr, nullptr, stream);
+}
+
+extern "C" int ocn_model_driver_create_distributed(ocn_model_driver_t *out, const ocn_grid *local_grid, const ocn_model_driver_desc *desc, double *u,
+                                                   double *v, double *w, double *p, ocn_dist_poisson_t solver, ocn_comm_t comm, void *stream)
+{
+    OCN_REQUIRE(solver && comm, "ocn_model_driver_create_distributed: null solver / communicator");
+    return model_driver_create(out, local_grid, desc, u, v, w, p, nullptr, solver, comm, stream);
 }
 
 extern "C" int ocn_model_driver_time_step(ocn_model_driver_t d, double dt, void *stream)
@@ -326,7 +398,7 @@ extern "C" int ocn_model_driver_time_step(ocn_model_driver_t d, double dt, void 
     st = project_and_advance(d, dt, second_stage_dt, g3, z3, stream);  // ... ends with the third substep
     if (st != OCN_SUCCESS) return st;
     // ---- third stage: projection, update_state!; its compute_tendencies! is fused into the next step's first substep
-    st = project(d, third_stage_dt, stream);
+    st = project(d, third_stage_dt, false, stream);
     if (st != OCN_SUCCESS) return st;
     st = update_state(d, stream);
     if (st != OCN_SUCCESS) return st;

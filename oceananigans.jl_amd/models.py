@@ -739,8 +739,10 @@ class ModelRK3Driver:
     """time_step!(model, Δt) of a model WITH tracers and the §8(f) terms (config 4's term set) behind ONE entry point of the C ABI
     (ocn_model_driver_*, csrc/model_driver.hip): halo fills, compute_auxiliaries!, the fused tendency / substep launches and the pressure
     projection are issued by the library in the order `time_step(model, dt)` issues them on the general fused path, so after flush() the
-    state is bit-identical to the Python host's -- without an interpreter between the ~20 launches of a stage.  One GPU, Periodic x / y,
-    WENO or UpwindBiased advection, RungeKutta3; number- or array-valued boundary conditions (functions of time are refused)."""
+    state is bit-identical to the Python host's -- without an interpreter between the ~20 launches of a stage.  One GPU with Periodic x / y,
+    or ONE RANK of a slab-x run over the RCCL transport (ocn_model_driver_create_distributed: every exchange is issued by the library too;
+    synchronous, without the interior / buffer split of distributed.py); WENO or UpwindBiased advection, RungeKutta3; number- or
+    array-valued boundary conditions (functions of time are refused)."""
 
     def __init__(self, model, own_solver=False):
         if not isinstance(model.timestepper, RungeKutta3TimeStepper):
@@ -748,8 +750,14 @@ class ModelRK3Driver:
         if not (model.fuse_stage_boundaries and model._general_fused):
             raise NotImplementedError("ModelRK3Driver: a model on the general fused path (tracers and / or extra terms, WENO / UpwindBiased "
                                       "advection, Periodic x and y); plain WENO models take RK3Driver")
-        if hasattr(model.grid.architecture, "partition"):
-            raise NotImplementedError("ModelRK3Driver: one GPU")
+        arch = model.grid.architecture
+        comm = impl = None
+        if hasattr(arch, "partition"):
+            comm = getattr(arch.fabric, "_h", None)
+            impl = getattr(model.pressure_solver, "impl", None)
+            if comm is None or getattr(impl, "_h", None) is None:
+                raise NotImplementedError("ModelRK3Driver on a Distributed architecture needs the RCCL transport (make_distributed) and the "
+                                          "library's distributed Poisson handle")
         nt = len(model.tracers)
         if nt > _lib.MODEL_MAX_TRACERS:
             raise NotImplementedError(f"ModelRK3Driver: at most {_lib.MODEL_MAX_TRACERS} tracers")
@@ -799,8 +807,15 @@ class ModelRK3Driver:
                 self._bcs.append(bc.c_struct(model.grid))
                 desc.bcs[n] = C.pointer(self._bcs[-1])
         self._h = C.c_void_p()
-        _lib.call("ocn_model_driver_create", C.byref(self._h), model.grid.cref, C.byref(desc), model.u.ptr, model.v.ptr, model.w.ptr,
-                  model.pNHS.ptr, None if own_solver else model.pressure_solver._h, stream_ptr())
+        if comm is not None:
+            finish = getattr(arch, "finish_halo_exchange", None)
+            if finish is not None:
+                finish()
+            _lib.call("ocn_model_driver_create_distributed", C.byref(self._h), model.grid.cref, C.byref(desc), model.u.ptr, model.v.ptr,
+                      model.w.ptr, model.pNHS.ptr, impl._h, comm, stream_ptr())
+        else:
+            _lib.call("ocn_model_driver_create", C.byref(self._h), model.grid.cref, C.byref(desc), model.u.ptr, model.v.ptr, model.w.ptr,
+                      model.pNHS.ptr, None if own_solver else model.pressure_solver._h, stream_ptr())
 
     def time_step(self, dt):
         _lib.call("ocn_model_driver_time_step", self._h, float(dt), stream_ptr())

@@ -8,7 +8,8 @@ the per-rank compute + host time of an R-GPU step with the communication itself 
 (single-GPU step) / R to see what the decomposition costs before any link time.
 
   tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched, advection only) | config4amd (its full physics) |
-                                                          config5 (2N x 2N x N/4 HydrostaticFreeSurfaceModel as bench.py --workload config5)
+                                                          config5 (2N x 2N x N/4 HydrostaticFreeSurfaceModel as bench.py --workload config5) |
+                                                          driver / driver4 (one C call per rank-step over a one-rank RCCL world: box / config 4's term set)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,6 +59,65 @@ class LoopbackFabric:
 
 
 ocn.set_math_mode(ocn.MATH_FAST)
+if workload == "driver4":
+    # the same for config 4's term set (ocn_model_driver_create_distributed): a (N / R) x N x (N / 2) slab, stretched Bounded z, AMD, T, S
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+    nx, Nz = N // R, N // 2
+    Lz, refinement, stretching = 32.0, 1.2, 12.0
+    h = lambda k: (k - 1) / Nz
+    z_faces = np.array([Lz * ((1 + (h(k) - 1) / refinement) * ((1 - np.exp(-stretching * h(k))) / (1 - np.exp(-stretching))) - 1)
+                        for k in range(1, Nz + 2)])
+
+    def build():
+        g = ocn.RectilinearGrid(arch, size=(nx, N, Nz), x=(0, 64 / R), y=(0, 64), z=z_faces, topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+        Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
+        bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1.225 / rho * 2.5e-3 * 10 * 10)),
+               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(Q / (rho * cp)), bottom=ocn.GradientBoundaryCondition(dTdz)),
+               "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-1e-3 / 3600))}
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4), closure=ocn.AnisotropicMinimumDissipation(),
+                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)), boundary_conditions=bcs)
+        zc = torch.from_numpy(0.5 * (z_faces[1:] + z_faces[:-1])).to("cuda")
+        T = m.field("T").interior_view()
+        T.copy_(20 + dTdz * zc[:, None, None] + 1e-6 * torch.rand(T.shape, device="cuda", dtype=torch.float64))
+        m.field("S").interior_view().fill_(35.0)
+        gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+        for f in m.velocities:
+            v = f.interior_view()
+            v.copy_(1e-2 * (2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1))
+        ocn.set(m)
+        return m
+
+    for name in ("python host", "C driver"):
+        m = build()
+        g = m.grid
+        dt = 0.1 * min(g.dx, float(np.diff(z_faces).min())) / max(float(f.interior_view().abs().max()) for f in m.velocities)
+        if name == "C driver":
+            drv = ocn.ModelRK3Driver(m)
+            stepper, flush = (lambda: drv.time_step(dt)), drv.flush
+        else:
+            stepper, flush = (lambda: ocn.time_step(m, dt)), (lambda: ocn.flush_tendencies(m))
+        for _ in range(3):
+            stepper()
+        flush()
+        ocn.sync_device()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper()
+        flush()
+        host_ms = (time.perf_counter() - t0) / steps * 1e3
+        ocn.sync_device()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        finite = all(bool(torch.isfinite(f.interior_view()).all()) for f in m.prognostic_fields())
+        print(f"driver4 N={N} R={R} [{name}]: local {g.Nx}x{g.Ny}x{g.Nz}, {ms:.2f} ms/step per rank (host enqueue {host_ms:.2f} ms), finite={finite}")
+        del m
+    sys.exit(0)
 if workload == "driver":
     # ONE C call per step (ocn_rk3_driver_create_distributed): a slab of the R-rank size as a one-rank RCCL world that exchanges with itself
     # (force_communication) -- the same kernels at the same local size as one rank of R (the interface systems of the x solve are those
