@@ -521,13 +521,14 @@ int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const doub
 
 int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(terms != nullptr && pHY != nullptr, "ocn_update_hydrostatic_pressure: null argument");
     OCN_REQUIRE(terms->buoyancy != OCN_BUOYANCY_NONE, "ocn_update_hydrostatic_pressure: buoyancy is nothing");
     if (terms->buoyancy != OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->T != nullptr, "T (or b) tracer is NULL");
     if (terms->buoyancy == OCN_BUOYANCY_SEAWATER_TS || terms->buoyancy == OCN_BUOYANCY_SEAWATER_S) OCN_REQUIRE(terms->S != nullptr, "S tracer is NULL");
-    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
+    OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && (grid->tz == OCN_FLAT || grid->Hz >= 1),
+                "halo >= 1 required");
     return launch_hydrostatic_pressure(grid, to_dev(*terms), pHY, as_stream(stream));
 }
 

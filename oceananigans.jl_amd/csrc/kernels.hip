@@ -358,10 +358,11 @@ __device__ __forceinline__ double buoyancy_perturbation(const TermsDev &t, long 
     }
 }
 
-__global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, TermsDev t, double *__restrict__ pHY, int i0, int i1)
+__global__ __launch_bounds__(256) void hydrostatic_pressure_kernel(GridDev g, TermsDev t, double *__restrict__ pHY, int i0, int i1, int j0, int j1)
 {
-    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;  // 0 .. N+1 (or a sub-range in x)
-    if (i > i1 || j > g.Ny + 1) return;
+    // p_kernel_parameters (update_hydrostatic_pressure.jl:48-56): 0 .. N+1 (1 .. N along a Flat direction), or a sub-range in x
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x, j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > i1 || j > j1) return;
     const Lay L = make_lay(g, OCN_LOC_CCC);
     const int Nz = g.Nz;
     long long o = at(L, i, j, Nz + 1);
@@ -383,10 +384,12 @@ int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double 
 {
     if (grid->tz == OCN_FLAT || t.buoyancy == OCN_BUOYANCY_NONE) return OCN_SUCCESS;
     GridDev g = to_dev(*grid);
-    const int i0 = irange ? irange[0] : 0, i1 = irange ? irange[1] : g.Nx + 1;
+    const bool fx = grid->tx == OCN_FLAT, fy = grid->ty == OCN_FLAT;
+    const int i0 = irange ? irange[0] : (fx ? 1 : 0), i1 = irange ? irange[1] : (fx ? g.Nx : g.Nx + 1);
+    const int j0 = fy ? 1 : 0, j1 = fy ? g.Ny : g.Ny + 1;
     if (i1 < i0) return OCN_SUCCESS;
-    const dim3 block = range_block(i1 - i0 + 1), nb = range_grid(block, i1 - i0 + 1, g.Ny + 2, 1);
-    hipLaunchKernelGGL(hydrostatic_pressure_kernel, nb, block, 0, stream, g, t, pHY, i0, i1);
+    const dim3 block = range_block(i1 - i0 + 1), nb = range_grid(block, i1 - i0 + 1, j1 - j0 + 1, 1);
+    hipLaunchKernelGGL(hydrostatic_pressure_kernel, nb, block, 0, stream, g, t, pHY, i0, i1, j0, j1);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

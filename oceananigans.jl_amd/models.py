@@ -189,9 +189,6 @@ class NonhydrostaticModel:
         if not xy_periodic:
             if isinstance(closure, AnisotropicMinimumDissipation):
                 raise NotImplementedError("AnisotropicMinimumDissipation needs Periodic x and y in this backend")
-            if buoyancy is not None and self.pHY is not None:
-                raise NotImplementedError("a separate hydrostatic pressure anomaly needs Periodic x and y in this backend "
-                                          "(pass hydrostatic_pressure_anomaly=None: the buoyancy then acts on w directly)")
             if hasattr(grid.architecture, "partition"):
                 raise NotImplementedError("a partitioned x needs Periodic y")
         self._alt_velocities = None

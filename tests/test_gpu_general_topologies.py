@@ -372,3 +372,61 @@ def test_channel_model_with_wall_fluxes_matches_oracle(oracle, ocn):
         assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-11 * max(scale, 1.0), name
     # the south flux enters, the north and top fluxes leave: d<c>/dt = 0.8/Ly - 0.8/Ly + 0.3/Lz
     assert abs((og.interior(from_dev(pm.tracers[0])).mean() - c0) / (3 * 2e-3) - 0.3 / 0.7) < 1e-9
+
+
+@pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((16, 1, 10), "PFB"), ((1, 10, 9), "FBB")])
+def test_hydrostatic_pressure_anomaly_on_closed_and_sliced_grids(oracle, ocn, size, topo):
+    """_update_hydrostatic_pressure! over p_kernel_parameters = 0:N+1 (1:N along a Flat direction, update_hydrostatic_pressure.jl:48-56)
+    from mirrored tracer halos, and the tendencies with -∂x pHY', -∂y pHY' on the faces that are not walls: bit-identical to the oracle"""
+    O = oracle
+    rng = np.random.default_rng(31)
+    zf = -0.7 * np.linspace(1, 0, size[2] + 1) ** 1.3
+    og, pg = make_pair(O, ocn, size, topo, x=(0, 1.3), y=(0, 0.9), z=zf)
+    u, v, w, c = _filled(O, og, rng)
+    ph = O.Physics(f=0.7, nu=0.013, kappa=0.021, buoyancy="BuoyancyTracer")
+    pHY = og.zeros(0)
+    O.update_hydrostatic_pressure(og, ph, c, None, pHY)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G)
+    O.momentum_extra_tendencies(og, ph, u, v, w, c, None, pHY, *G)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dp = ocn.Field(0, pg)
+    dG = [ocn.Field(l, pg) for l in LOCS]
+    t = ocn._lib.CModelTerms()
+    t.advection, t.coriolis, t.f, t.closure, t.nu = ocn._lib.ADVECTION_WENO5, 1, 0.7, 1, 0.013
+    t.buoyancy, t.T, t.pHY = ocn._lib.BUOYANCY_TRACER, dc.ptr, dp.ptr
+    ocn._lib.call("ocn_update_hydrostatic_pressure", pg.cref, C.byref(t), dp.ptr, 0)
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dp), pHY, err_msg=f"{topo} pHY")
+    assert np.abs(pHY).max() > 0
+    for a, b, name in zip(G, dG, ("Gu", "Gv", "Gw")):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} {name}")
+
+
+@pytest.mark.parametrize("topo", ["PBB", "BBB"])
+def test_stratified_channel_with_separate_hydrostatic_pressure_matches_oracle(oracle, ocn, topo):
+    """BuoyancyTracer with the model's default separate pHY' (nonhydrostatic_model.jl:143-158) on a channel and a closed box, FPlane and
+    ScalarDiffusivity: 3 RK3 steps against the oracle's model (1e-11: cosine-transform rounding), walls impenetrable"""
+    O = oracle
+    og, pg = _pair(O, ocn, (16, 12, 10), topo)
+    rng = np.random.default_rng(33)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    om = O.NonhydrostaticModel(og, tracers=("b",), coriolis_f=0.3, closure=(0.02, {"b": 0.03}), buoyancy="BuoyancyTracer")
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("b",), coriolis=ocn.FPlane(f=0.3), closure=ocn.ScalarDiffusivity(ν=0.02, κ=0.03),
+                                 buoyancy=ocn.BuoyancyTracer())
+    assert pm.pHY is not None and not pm.fuse_stage_boundaries
+    init = {n: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for n, l in zip("uvw", LOCS)}
+    init["b"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
+    om.set(**init)
+    ocn.set(pm, **init)
+    for _ in range(3):
+        om.time_step(2e-3)
+        ocn.time_step(pm, 2e-3)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    scale = max(np.abs(a).max() for a in (om.u, om.v, om.w))
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "b")):
+        assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-11 * max(scale, 1.0), name
+    np.testing.assert_allclose(og.interior(from_dev(pm.pHY)), og.interior(om.pHY), rtol=0, atol=1e-12)
