@@ -106,6 +106,9 @@ struct FuseArgs {
     // x-partitioned (FullyConnected) local grid: the x indices of p are NOT wrapped -- the x halos of p hold the neighbours' planes
     // (ocn_halo_exchange_pressure) and the westmost halo column of u, whose correction would need p[-Hx], arrives corrected
     int pc_xhalo;
+    // G already holds the terms that do not come from advection (momentum_extra_* in `pre` mode ran first): G <- advection + G before it is
+    // stored and used by the substep.  Fast math only: the sum is the reference's with the advective term added last instead of first.
+    int acc;
 };
 
 // device-side copy of ocn_model_terms (physics.hip)
@@ -162,6 +165,7 @@ struct MomentumFinal {
     SubstepDev sub[3];
     SubstepCoef sc;
     int xcd;  // XCD-aware workgroup -> tile mapping (set by the launchers)
+    int pre;  // the pass runs BEFORE the advective launch: G does not hold anything yet (taken as 0), no substep (FuseArgs::acc follows)
 };
 
 // what hydrostatic_momentum_tiled (physics.hip) folds in besides the tendency and the AB2 step of u, v

@@ -213,20 +213,27 @@ __device__ __forceinline__ ExtraLoads momentum_extra_loads(const TermsDev &t, co
     ld.ph_c = t.pHY ? t.pHY[o] : 0.0;
     ld.ph_w = t.pHY ? t.pHY[o - 1] : 0.0;
     ld.ph_s = t.pHY ? t.pHY[o - s2] : 0.0;
-    ld.Gu_in = HYD ? 0.0 : Gu[o];
-    ld.Gv_in = HYD ? 0.0 : Gv[o];
-    ld.Gw_in = ld.w_cell ? Gw[o] : 0.0;
+    ld.Gu_in = (HYD || mf.pre) ? 0.0 : Gu[o];
+    ld.Gv_in = (HYD || mf.pre) ? 0.0 : Gv[o];
+    ld.Gw_in = (ld.w_cell && !mf.pre) ? Gw[o] : 0.0;
     ld.zb_w = 0.0;  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
     if (ld.w_cell && t.buoyancy && !t.pHY) ld.zb_w = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
     return ld;
 }
+
+// The 15 stress values the three components of a cell read, when the caller has evaluated every stress ONCE per face / centre and shares
+// them between the cells that read them (momentum_extra_tiled): T11, T22, T33 at centres, T12 at (f,f,c), T13 at (f,c,f), T23 at (c,f,f).
+struct Stresses {
+    double t11e, t11w, t12n, t12c, t12e, t13t, t13c, t13e, t22n, t22s, t23t, t23c, t23n, t33t, t33b;
+};
 
 template <int TZ, bool HYD = false, class FU, class FV, class FW, class FN>
 __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const TermsDev &t, const Metrics &M, int i, int j, int k,
                                                     long long o, long long s2, long long s3, bool has_nu, FU Uf, FV Vf, FW Wf,
                                                     FN NEf, double *__restrict__ Gu, double *__restrict__ Gv,
                                                     double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf,
-                                                    const ExtraLoads &ld, double G0u = 0.0, double G0v = 0.0, double *res = nullptr)
+                                                    const ExtraLoads &ld, double G0u = 0.0, double G0v = 0.0, double *res = nullptr,
+                                                    const Stresses *sh = nullptr)
 {
     constexpr bool ZF = (TZ == OCN_FLAT);
     const double dx = M.dx, dy = M.dy, nu = t.nu;
@@ -266,14 +273,20 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         }
         if (t.pHY) G = G - DX(ph_c, ph_w);  // ∂xᶠᶜᶜ pHY′
         if (t.closure) {
-            const double t11e = TAU(nuC(0, 0, 0), DX(Uf(1, 0, 0), Uf(0, 0, 0))), t11w = TAU(nuC(-1, 0, 0), DX(Uf(0, 0, 0), Uf(-1, 0, 0)));
-            const double t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(Uf(0, 1, 0), Uf(0, 0, 0)) + DX(Vf(0, 1, 0), Vf(-1, 1, 0))));
-            const double t12s = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
-            double dzF = 0.0;
-            if (!ZF) {
-                const double t13t = TAU(nuFCF(0, 0, 1), 0.5 * (DZF1(Uf(0, 0, 1), Uf(0, 0, 0)) + DX(Wf(0, 0, 1), Wf(-1, 0, 1))));
-                const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
-                dzF = Az * t13t - Az * t13b;
+            double t11e, t11w, t12n, t12s, dzF = 0.0;
+            if (sh) {  // evaluated once by the owner of each face / centre: the same expressions, hence the same bits
+                t11e = sh->t11e; t11w = sh->t11w; t12n = sh->t12n; t12s = sh->t12c;
+                if (!ZF) dzF = Az * sh->t13t - Az * sh->t13c;
+            } else {
+                t11e = TAU(nuC(0, 0, 0), DX(Uf(1, 0, 0), Uf(0, 0, 0)));
+                t11w = TAU(nuC(-1, 0, 0), DX(Uf(0, 0, 0), Uf(-1, 0, 0)));
+                t12n = TAU(nuFFC(0, 1, 0), 0.5 * (DY(Uf(0, 1, 0), Uf(0, 0, 0)) + DX(Vf(0, 1, 0), Vf(-1, 1, 0))));
+                t12s = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
+                if (!ZF) {
+                    const double t13t = TAU(nuFCF(0, 0, 1), 0.5 * (DZF1(Uf(0, 0, 1), Uf(0, 0, 0)) + DX(Wf(0, 0, 1), Wf(-1, 0, 1))));
+                    const double t13b = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
+                    dzF = Az * t13t - Az * t13b;
+                }
             }
             G = G - recip_volume(Az * dzc) * (((Axc * t11e - Axc * t11w) + (Ayc * t12n - Ayc * t12s)) + dzF);
         }
@@ -300,14 +313,20 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         }
         if (t.pHY) G = G - DY(ph_c, ph_s);
         if (t.closure) {
-            const double t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(Uf(1, 0, 0), Uf(1, -1, 0)) + DX(Vf(1, 0, 0), Vf(0, 0, 0))));
-            const double t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
-            const double t22n = TAU(nuC(0, 0, 0), DY(Vf(0, 1, 0), Vf(0, 0, 0))), t22s = TAU(nuC(0, -1, 0), DY(Vf(0, 0, 0), Vf(0, -1, 0)));
-            double dzF = 0.0;
-            if (!ZF) {
-                const double t23t = TAU(nuCFF(0, 0, 1), 0.5 * (DZF1(Vf(0, 0, 1), Vf(0, 0, 0)) + DY(Wf(0, 0, 1), Wf(0, -1, 1))));
-                const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
-                dzF = Az * t23t - Az * t23b;
+            double t12e, t12w, t22n, t22s, dzF = 0.0;
+            if (sh) {
+                t12e = sh->t12e; t12w = sh->t12c; t22n = sh->t22n; t22s = sh->t22s;
+                if (!ZF) dzF = Az * sh->t23t - Az * sh->t23c;
+            } else {
+                t12e = TAU(nuFFC(1, 0, 0), 0.5 * (DY(Uf(1, 0, 0), Uf(1, -1, 0)) + DX(Vf(1, 0, 0), Vf(0, 0, 0))));
+                t12w = TAU(nuFFC(0, 0, 0), 0.5 * (DY(Uf(0, 0, 0), Uf(0, -1, 0)) + DX(Vf(0, 0, 0), Vf(-1, 0, 0))));
+                t22n = TAU(nuC(0, 0, 0), DY(Vf(0, 1, 0), Vf(0, 0, 0)));
+                t22s = TAU(nuC(0, -1, 0), DY(Vf(0, 0, 0), Vf(0, -1, 0)));
+                if (!ZF) {
+                    const double t23t = TAU(nuCFF(0, 0, 1), 0.5 * (DZF1(Vf(0, 0, 1), Vf(0, 0, 0)) + DY(Wf(0, 0, 1), Wf(0, -1, 1))));
+                    const double t23b = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
+                    dzF = Az * t23t - Az * t23b;
+                }
             }
             G = G - recip_volume(Az * dzc) * (((Axc * t12e - Axc * t12w) + (Ayc * t22n - Ayc * t22s)) + dzF);
         }
@@ -332,15 +351,20 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         if (t.coriolis) G = G - 0.0;  // z_f_cross_U = 0
         if (t.closure) {
             const double Axf = dy * dzf, Ayf = dx * dzf;
-            const double t13e = TAU(nuFCF(1, 0, 0), 0.5 * (DZF(Uf(1, 0, 0), Uf(1, 0, -1)) + DX(Wf(1, 0, 0), Wf(0, 0, 0))));
-            const double t13w = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
-            const double t23n = TAU(nuCFF(0, 1, 0), 0.5 * (DZF(Vf(0, 1, 0), Vf(0, 1, -1)) + DY(Wf(0, 1, 0), Wf(0, 0, 0))));
-            const double t23s = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
-            double dzF = 0.0;
-            if (!ZF) {
-                const double t33t = TAU(nuC(0, 0, 0), OCN_DIV(Wf(0, 0, 1) - Wf(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
-                const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(Wf(0, 0, 0) - Wf(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
-                dzF = Az * t33t - Az * t33b;
+            double t13e, t13w, t23n, t23s, dzF = 0.0;
+            if (sh) {
+                t13e = sh->t13e; t13w = sh->t13c; t23n = sh->t23n; t23s = sh->t23c;
+                if (!ZF) dzF = Az * sh->t33t - Az * sh->t33b;
+            } else {
+                t13e = TAU(nuFCF(1, 0, 0), 0.5 * (DZF(Uf(1, 0, 0), Uf(1, 0, -1)) + DX(Wf(1, 0, 0), Wf(0, 0, 0))));
+                t13w = TAU(nuFCF(0, 0, 0), 0.5 * (DZF(Uf(0, 0, 0), Uf(0, 0, -1)) + DX(Wf(0, 0, 0), Wf(-1, 0, 0))));
+                t23n = TAU(nuCFF(0, 1, 0), 0.5 * (DZF(Vf(0, 1, 0), Vf(0, 1, -1)) + DY(Wf(0, 1, 0), Wf(0, 0, 0))));
+                t23s = TAU(nuCFF(0, 0, 0), 0.5 * (DZF(Vf(0, 0, 0), Vf(0, 0, -1)) + DY(Wf(0, 0, 0), Wf(0, -1, 0))));
+                if (!ZF) {
+                    const double t33t = TAU(nuC(0, 0, 0), OCN_DIV(Wf(0, 0, 1) - Wf(0, 0, 0), dzc, rdzc));    // Σ₃₃ at centre k
+                    const double t33b = TAU(nuC(0, 0, -1), OCN_DIV(Wf(0, 0, 0) - Wf(0, 0, -1), dzcm, rdzcm));  // Σ₃₃ at centre k-1
+                    dzF = Az * t33t - Az * t33b;
+                }
             }
             G = G - recip_volume(Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
         }
@@ -381,14 +405,20 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
 // k-1, k, k+1 of u, v, w (and νₑ) live in a 3-slot LDS ring with a one-cell rim, so every value enters the workgroup once per
 // plane (1.33x with the rim) instead of once per stencil tap (~60 taps per cell hit L2 in the direct kernel: the 3 planes x
 // 4 fields of a workgroup do not fit the 32 KB L1).  pHY′, G, G⁻ are touched once per cell and stay in global memory.
-template <int TZ>
-__global__ __launch_bounds__(256, 4) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
+template <int TZ, bool SH>
+__global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
                                                             const double *__restrict__ v, const double *__restrict__ w,
                                                             double *__restrict__ Gu, double *__restrict__ Gv,
                                                             double *__restrict__ Gw, PRange r, ocn::MomentumFinal mf, int KZ)
 {
     constexpr int TX = 32, TY = 8, SX = TX + 2, SY = TY + 2, PL = SX * SY;
     __shared__ double Lu[3][PL], Lv[3][PL], Lw[3][PL], Ln[3][PL];
+    // Stresses shared between the cells that read them (closure != 0): every cell evaluates the six stresses it OWNS -- T11, T22, T33 at
+    // its centre, T12 at its south-west edge, T13, T23 at its lower west / south edges -- once per plane instead of the 18 values its three
+    // components read (each stress is read by 2 to 4 cells); T33 stays in registers (same column), T13 / T23 of plane k + 1 become plane k
+    // of the next iteration.  Same expressions, same operands: bit-identical to the unshared evaluation.
+    constexpr int SPL = SH ? PL : 1;
+    __shared__ double S11[SPL], S22[SPL], S12[SPL], S13[2][SPL], S23[2][SPL];
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     int bx, by, bz;
     xcd_block_coords(mf.xcd, bx, by, bz);
@@ -441,6 +471,18 @@ __global__ __launch_bounds__(256, 4) void momentum_extra_tiled(GridDev g, TermsD
     commit(kb);
     fetch(kb + 1);
     const int c0 = (ty + 1) * SX + (tx + 1);
+    // rim positions whose stresses the tile's cells read: one per lane of the first 32 / 32 / 8 / 8 lanes of waves 0 .. 3
+    //   wave 0: south row (T22 of row j0 - 1), wave 1: north row (T12, T23 of row j0 + TY), wave 2: west column (T11 of column i0 - 1),
+    //   wave 3: east column (T12, T13 of column i0 + TX)
+    const int wv = tid >> 6, ln = tid & 63;
+    const int rim = (wv == 0 && ln < TX) ? 1 : (wv == 1 && ln < TX) ? 2 : (wv == 2 && ln < TY) ? 3 : (wv == 3 && ln < TY) ? 4 : 0;
+    const int cr = rim == 1 ? (ln + 1) : rim == 2 ? (TY + 1) * SX + (ln + 1) : rim == 3 ? (ln + 1) * SX : rim == 4 ? (ln + 1) * SX + (TX + 1) : c0;
+    constexpr bool shared = SH;
+    const double dx = M.dx, dy = M.dy, nu = t.nu;
+#if !OCN_STRICT
+    const double rdx = fast_rcp(dx), rdy = fast_rcp(dy);
+#endif
+    double t33_prev = 0.0;
     for (int k = kb; k <= ke; ++k) {
         commit(k + 1);
         __syncthreads();
@@ -450,15 +492,88 @@ __global__ __launch_bounds__(256, 4) void momentum_extra_tiled(GridDev g, TermsD
         OCN_ISSUE_LOADS_HERE();
         if (k < ke) fetch(k + 2);  // ... then the staging values of plane k + 2, consumed by the next iteration's commit
         OCN_ISSUE_LOADS_HERE();
+        const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
+        Stresses sh{};
+        if (shared) {
+            const double dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = M.dzF(k + 1), dzcm = M.dzC(k - 1);
+#if !OCN_STRICT
+            const double rdzc = fast_rcp(dzc), rdzf = fast_rcp(dzf), rdzf1 = fast_rcp(dzf1), rdzcm = fast_rcp(dzcm);
+#endif
+            auto sU = [&](int c, int a, int b, int d) { return Lu[(base + d) % 3][c + a + b * SX]; };
+            auto sV = [&](int c, int a, int b, int d) { return Lv[(base + d) % 3][c + a + b * SX]; };
+            auto sW = [&](int c, int a, int b, int d) { return Lw[(base + d) % 3][c + a + b * SX]; };
+            auto sN = [&](int c, int a, int b, int d) { return Ln[(base + d) % 3][c + a + b * SX]; };
+            auto nuC = [&](int c, int d) { return has_nu ? sN(c, 0, 0, d) : nu; };
+            auto nuFFC = [&](int c) {
+                return has_nu ? 0.5 * (0.5 * (sN(c, -1, -1, 0) + sN(c, 0, -1, 0)) + 0.5 * (sN(c, -1, 0, 0) + sN(c, 0, 0, 0))) : nu;
+            };
+            auto nuFCF = [&](int c, int d) {
+                return has_nu ? 0.5 * (0.5 * (sN(c, -1, 0, d - 1) + sN(c, 0, 0, d - 1)) + 0.5 * (sN(c, -1, 0, d) + sN(c, 0, 0, d))) : nu;
+            };
+            auto nuCFF = [&](int c, int d) {
+                return has_nu ? 0.5 * (0.5 * (sN(c, 0, -1, d - 1) + sN(c, 0, 0, d - 1)) + 0.5 * (sN(c, 0, -1, d) + sN(c, 0, 0, d))) : nu;
+            };
+            // the expressions of momentum_extra_cell, with the centre of evaluation as an argument (d: z-face k + d)
+            auto T11 = [&](int c) { return TAU(nuC(c, 0), DX(sU(c, 1, 0, 0), sU(c, 0, 0, 0))); };
+            auto T22 = [&](int c) { return TAU(nuC(c, 0), DY(sV(c, 0, 1, 0), sV(c, 0, 0, 0))); };
+            auto T12 = [&](int c) { return TAU(nuFFC(c), 0.5 * (DY(sU(c, 0, 0, 0), sU(c, 0, -1, 0)) + DX(sV(c, 0, 0, 0), sV(c, -1, 0, 0)))); };
+            auto T13 = [&](int c, int d) {
+                const double dzu = d ? OCN_DIV(sU(c, 0, 0, 1) - sU(c, 0, 0, 0), dzf1, rdzf1) : OCN_DIV(sU(c, 0, 0, 0) - sU(c, 0, 0, -1), dzf, rdzf);
+                return TAU(nuFCF(c, d), 0.5 * (dzu + DX(sW(c, 0, 0, d), sW(c, -1, 0, d))));
+            };
+            auto T23 = [&](int c, int d) {
+                const double dzv = d ? OCN_DIV(sV(c, 0, 0, 1) - sV(c, 0, 0, 0), dzf1, rdzf1) : OCN_DIV(sV(c, 0, 0, 0) - sV(c, 0, 0, -1), dzf, rdzf);
+                return TAU(nuCFF(c, d), 0.5 * (dzv + DY(sW(c, 0, 0, d), sW(c, 0, -1, d))));
+            };
+            const int cur = k & 1, nxt = cur ^ 1;
+            const bool first = (k == kb);
+            // own position (every thread, active or not: the neighbours of the last active column / row read these)
+            const double o11 = T11(c0), o22 = T22(c0), o12 = T12(c0), o13n = T13(c0, 1), o23n = T23(c0, 1);
+            double o13c, o23c;
+            if (first) {
+                o13c = T13(c0, 0);
+                o23c = T23(c0, 0);
+                S13[cur][c0] = o13c;
+                S23[cur][c0] = o23c;
+                t33_prev = TAU(nuC(c0, -1), OCN_DIV(sW(c0, 0, 0, 0) - sW(c0, 0, 0, -1), dzcm, rdzcm));
+            } else {
+                o13c = S13[cur][c0];  // (written by this thread in the previous iteration)
+                o23c = S23[cur][c0];
+            }
+            S11[c0] = o11; S22[c0] = o22; S12[c0] = o12; S13[nxt][c0] = o13n; S23[nxt][c0] = o23n;
+            const double o33 = TAU(nuC(c0, 0), OCN_DIV(sW(c0, 0, 0, 1) - sW(c0, 0, 0, 0), dzc, rdzc));
+            // rim positions
+            if (rim == 1) {
+                S22[cr] = T22(cr);
+            } else if (rim == 2) {
+                S12[cr] = T12(cr);
+                S23[nxt][cr] = T23(cr, 1);
+                if (first) S23[cur][cr] = T23(cr, 0);
+            } else if (rim == 3) {
+                S11[cr] = T11(cr);
+            } else if (rim == 4) {
+                S12[cr] = T12(cr);
+                S13[nxt][cr] = T13(cr, 1);
+                if (first) S13[cur][cr] = T13(cr, 0);
+            }
+            __syncthreads();
+            sh.t11e = o11; sh.t11w = S11[c0 - 1];
+            sh.t12c = o12; sh.t12n = S12[c0 + SX]; sh.t12e = S12[c0 + 1];
+            sh.t13t = o13n; sh.t13c = o13c; sh.t13e = S13[cur][c0 + 1];
+            sh.t22n = o22; sh.t22s = S22[c0 - SX];
+            sh.t23t = o23n; sh.t23c = o23c; sh.t23n = S23[cur][c0 + SX];
+            sh.t33t = o33; sh.t33b = t33_prev;
+            t33_prev = o33;
+        }
         if (active) {
-            const int base = k + 3;  // (k + c) % 3 for c in {-1, 0, 1} without negative operands
             momentum_extra_cell<TZ>(
                 g, t, M, i, j, k, o, s2, s3, has_nu, [&](int a, int b, int c) { return Lu[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Lw[(base + c) % 3][c0 + a + b * SX]; },
-                [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf, ld);
+                [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf, ld, 0.0, 0.0, nullptr,
+                SH ? &sh : nullptr);
         }
-        __syncthreads();  // everyone is done with slot (k - 1) % 3 before the next iteration overwrites it
+        __syncthreads();  // everyone is done with slot (k - 1) % 3 (and with the plane-k stresses) before the next iteration overwrites them
     }
 }
 
@@ -715,6 +830,8 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
     ocn::MomentumFinal mf{};
     if (fin) mf = *fin;
     mf.xcd = xcd_remap_on();
+    static const bool share_env = !(getenv("OCN_SHARE_STRESSES") && getenv("OCN_SHARE_STRESSES")[0] == '0');
+    const bool share = share_env && t.closure != 0;  // every stress evaluated once per face / centre and shared through LDS
     PRange r;
     int st = make_prange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
@@ -727,10 +844,17 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
         int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the two-plane prologue
         while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 4096) KZ = (KZ + 1) / 2;
         dim3 nbt((wx + 31) / 32, (wy + 7) / 8, (wz + KZ - 1) / KZ);
-        if (grid->tz == OCN_PERIODIC)
-            hipLaunchKernelGGL(momentum_extra_tiled<OCN_PERIODIC>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
-        else
-            hipLaunchKernelGGL(momentum_extra_tiled<OCN_BOUNDED>, nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        if (grid->tz == OCN_PERIODIC) {
+            if (share)
+                hipLaunchKernelGGL((momentum_extra_tiled<OCN_PERIODIC, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+            else
+                hipLaunchKernelGGL((momentum_extra_tiled<OCN_PERIODIC, false>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        } else {
+            if (share)
+                hipLaunchKernelGGL((momentum_extra_tiled<OCN_BOUNDED, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+            else
+                hipLaunchKernelGGL((momentum_extra_tiled<OCN_BOUNDED, false>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        }
         OCN_CHECK_HIP(hipGetLastError());
         return OCN_SUCCESS;
     }

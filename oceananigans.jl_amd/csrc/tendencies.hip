@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzC(k));
-        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
         const long long o = ocn::at(Lu, i, j, k);
+        double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        if (fz.acc) G = G + Gu[o];
         Gu[o] = G;
         if (fz.on) fz.Uo[0][o] = pu[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[0][o]) : (fz.dt * fz.gamma) * G);
     }
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzC(k));
-        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
         const long long o = ocn::at(Lv, i, j, k);
+        double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        if (fz.acc) G = G + Gv[o];
         Gv[o] = G;
         if (fz.on) fz.Uo[1][o] = pv[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[1][o]) : (fz.dt * fz.gamma) * G);
     }
@@ -144,8 +146,9 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
             dzF = fz1 - fz0;
         }
         const double rV = 1 / (M.Az * M.dzF(k));
-        const double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
         const long long o = ocn::at(Lw, i, j, k);
+        double G = -(rV * (((fx1 - fx0) + (fy1 - fy0)) + dzF));
+        if (fz.acc) G = G + Gw[o];
         Gw[o] = G;
         const bool wall = (TZ == OCN_BOUNDED) && k == 1 && Nz > 1;  // rk3_substep! never steps the wall face
         if (fz.on) fz.Uo[2][o] = wall ? pw[0] : pw[0] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * fz.Gm[2][o]) : (fz.dt * fz.gamma) * G);
@@ -427,6 +430,14 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             const long long o = own0 + (long long)(k - 1) * su3;
             gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o]; gmw = fz.Gm[2][o];
         }
+        // ... and the terms the finishing pass has already left in G (fz.acc)
+        double eu = 0.0, ev = 0.0, ew = 0.0;
+        if (fz.acc && writes) {
+            const long long o = own0 + (long long)(k - 1) * su3;
+            if (i >= r.ou) eu = Gu[o];
+            if (j >= r.ov) ev = Gv[o];
+            if (k >= r.ow) ew = Gw[o];
+        }
         const double(*swk)[LX] = sw[wslot(k)];
         const double(*swt)[LX] = sw[wslot(k + 1)];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
@@ -489,18 +500,21 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             const double rVc = recip_volume(M.Az * M.dzC(k));
             const long long ou_ = ocn::at(Lu, i, j, k), ov_ = ocn::at(Lv, i, j, k), ow_ = ocn::at(Lw, i, j, k);
             if (i >= r.ou) {
-                const double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
+                double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
+                if (fz.acc) G = G + eu;
                 Gu[ou_] = G;
                 if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmu) : (fz.dt * fz.gamma) * G);
             }
             if (j >= r.ov) {
-                const double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
+                double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
+                if (fz.acc) G = G + ev;
                 Gv[ov_] = G;
                 if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmv) : (fz.dt * fz.gamma) * G);
             }
             if (k >= r.ow) {
                 const double rVf = recip_volume(M.Az * M.dzF(k));
-                const double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
+                double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
+                if (fz.acc) G = G + ew;
                 Gw[ow_] = G;
                 // rk3_substep! always excludes the wall face (runge_kutta_3.jl:171-174), even when a KernelParameters range
                 // made the tendency kernel write Gw there
