@@ -573,7 +573,11 @@ __global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev 
                 [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf, ld, 0.0, 0.0, nullptr,
                 SH ? &sh : nullptr);
         }
-        __syncthreads();  // everyone is done with slot (k - 1) % 3 (and with the plane-k stresses) before the next iteration overwrites them
+        // Unshared: everyone must be done with slot (k - 1) % 3 before the next iteration's commit overwrites it.  Shared: nothing reads plane
+        // k - 1 after the first iteration's stress phase (T13, T23 of plane k and T33 of k - 1 are carried), which the barrier above already
+        // closed; the plane-k stress arrays are next written after the NEXT iteration's first barrier, which every wave reaches only after its
+        // cell phase -- so two barriers per plane suffice.
+        if (!SH) __syncthreads();
     }
 }
 
