@@ -592,6 +592,12 @@ int ocn_comm_schedule(int32_t kind, int32_t rank, int32_t nranks, int32_t self_v
                       int32_t *n_ops);
 int ocn_comm_unique_id(void *id_out);                       /* rank 0: ncclGetUniqueId -> 128 bytes for every rank */
 int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *unique_id); /* on the current device; collective */
+/* An in-process transport instead of RCCL, for ranks that are THREADS of one process sharing ONE GPU (RCCL refuses two ranks on one
+ * device): every entry point below then runs unchanged with R = 2, 4, 8 on a one-GPU box -- the send / recv schedules, pack / unpack,
+ * event ordering, the pressure-plane exchange, the distributed drivers.  Staging copies through per-pair mailboxes with RCCL's pairing
+ * rule (the k-th send a -> b meets the k-th receive of b from a); host-blocking; not a product path.  All ranks pass the same group_key;
+ * the call returns when all have joined.  ocn_comm_info reports rccl_version 0. */
+int ocn_comm_init_local(ocn_comm_t *comm, int32_t rank, int32_t nranks, int64_t group_key);
 int ocn_comm_destroy(ocn_comm_t comm);
 /* rank, the number of ranks RCCL itself reports (ncclCommCount), RCCL version code */
 int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);

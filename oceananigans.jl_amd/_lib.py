@@ -174,6 +174,7 @@ _SIGS = {
     "ocn_comm_schedule": [_i32, _i32, _i32, _i32, C.POINTER(CCommOp), _i32, C.POINTER(_i32)],
     "ocn_comm_unique_id": [_vp],
     "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
+    "ocn_comm_init_local": [C.POINTER(_vp), _i32, _i32, C.c_int64],
     "ocn_comm_destroy": [_vp],
     "ocn_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "ocn_halo_exchange_begin": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],

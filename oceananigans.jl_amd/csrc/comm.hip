@@ -17,8 +17,14 @@
 // neighbours of a halo exchange each use their own link; nothing here is a ring.
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "ocn_internal.h"
 
@@ -58,7 +64,169 @@ struct Comm {
     bool pending = false;
     size_t pending_count = 0;
     bool self_via_rccl = false;  // OCN_COMM_SELF_VIA_RCCL=1: a rank's transfers to itself go through ncclSend / ncclRecv too (tests)
+    struct LocalGroup *local = nullptr;  // != NULL: the in-process transport below instead of RCCL (ocn_comm_init_local)
 };
+
+// ---- in-process transport (ocn_comm_init_local): the ranks are THREADS of one process sharing ONE GPU.  RCCL refuses two ranks on one
+// device, so on a one-GPU box everything above the transport -- the send / recv schedules, the pack / unpack launches, the event ordering
+// between the compute and the communication stream, the pressure-plane exchange, the C drivers -- could only run with one rank; with this
+// transport it runs with R = 2, 4, 8 (tests/test_gpu_distributed.py).  A send copies into a staging buffer on the sender's stream and
+// posts (buffer, event) into the mailbox of the (source, destination) pair; the matching receive -- the k-th of that pair, the same
+// pairing rule as RCCL's -- takes it, makes its stream wait for the event and copies out.  Within a group all sends are posted before the
+// first receive blocks, so ranks that issue the same sequence of groups cannot deadlock.  Not a product path: one GPU, host-blocking.
+struct LocalMsg {
+    double *stage;
+    size_t count;
+    hipEvent_t ready;
+};
+struct LocalGroup {
+    int nranks = 0, joined = 0, left = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    std::map<std::pair<int, int>, std::deque<LocalMsg>> box;  // (source, destination) -> messages in issue order
+    std::vector<std::pair<double *, size_t>> free_stage;      // staging buffers whose last reader has been enqueued on the null-ordered streams
+    std::vector<hipEvent_t> free_events;
+    // host barrier + all-reduce scratch
+    int arrived = 0, generation = 0;
+    std::vector<double> red;
+    int red_count = 0;
+};
+std::mutex g_local_mutex;
+std::map<long long, LocalGroup *> g_local_groups;
+
+int local_send(Comm *c, const double *buf, size_t count, int dst, hipStream_t stream)
+{
+    LocalGroup *G = c->local;
+    LocalMsg msg{nullptr, count, nullptr};
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        for (size_t q = 0; q < G->free_stage.size(); ++q)
+            if (G->free_stage[q].second >= count) {
+                msg.stage = G->free_stage[q].first;
+                msg.count = G->free_stage[q].second;
+                G->free_stage.erase(G->free_stage.begin() + q);
+                break;
+            }
+        if (!G->free_events.empty()) {
+            msg.ready = G->free_events.back();
+            G->free_events.pop_back();
+        }
+    }
+    if (!msg.stage) {
+        OCN_CHECK_HIP(hipMalloc(&msg.stage, (count ? count : 1) * sizeof(double)));
+        msg.count = count;
+    }
+    if (!msg.ready) OCN_CHECK_HIP(hipEventCreateWithFlags(&msg.ready, hipEventDisableTiming));
+    // (a recycled staging buffer re-entered the free list only after the copy that read it had completed: local_recv synchronises)
+    OCN_CHECK_HIP(hipMemcpyAsync(msg.stage, buf, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    OCN_CHECK_HIP(hipEventRecord(msg.ready, stream));
+    msg.count = count;  // (a recycled buffer may be larger; it re-enters the free list with this size)
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->box[{c->rank, dst}].push_back(msg);
+    }
+    G->cv.notify_all();
+    return OCN_SUCCESS;
+}
+
+int local_recv(Comm *c, double *buf, size_t count, int src, hipStream_t stream)
+{
+    LocalGroup *G = c->local;
+    LocalMsg msg;
+    {
+        std::unique_lock<std::mutex> lk(G->m);
+        auto &q = G->box[{src, c->rank}];
+        if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty(); })) {
+            ocn::set_error("in-process transport: rank %d waited 120 s for a message from rank %d (mismatched schedules?)", c->rank, src);
+            return OCN_ERR_COMM;
+        }
+        msg = q.front();
+        q.pop_front();
+    }
+    if (msg.count != count) {
+        ocn::set_error("in-process transport: rank %d expected %zu doubles from rank %d, the matching send has %zu", c->rank, count, src, msg.count);
+        return OCN_ERR_COMM;
+    }
+    OCN_CHECK_HIP(hipStreamWaitEvent(stream, msg.ready, 0));
+    OCN_CHECK_HIP(hipMemcpyAsync(buf, msg.stage, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    // the staging buffer may be reused once this copy has run: wait for it here (a test transport: simplicity over overlap)
+    OCN_CHECK_HIP(hipStreamSynchronize(stream));
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->free_stage.push_back({msg.stage, count});
+        G->free_events.push_back(msg.ready);
+    }
+    return OCN_SUCCESS;
+}
+
+// all sends of the group first, then the receives (see above)
+int local_run_ops(Comm *c, const ocn_comm_op *ops, int n, const double *const *send, double *const *recv, size_t count, hipStream_t stream)
+{
+    for (int q = 0; q < n; ++q)
+        if (!ops[q].is_recv) {
+            int st = local_send(c, send[ops[q].slot], count, ops[q].peer, stream);
+            if (st != OCN_SUCCESS) return st;
+        }
+    for (int q = 0; q < n; ++q)
+        if (ops[q].is_recv) {
+            int st = local_recv(c, recv[ops[q].slot], count, ops[q].peer, stream);
+            if (st != OCN_SUCCESS) return st;
+        }
+    return OCN_SUCCESS;
+}
+
+int local_barrier(Comm *c)
+{
+    LocalGroup *G = c->local;
+    std::unique_lock<std::mutex> lk(G->m);
+    const int gen = G->generation;
+    if (++G->arrived == G->nranks) {
+        G->arrived = 0;
+        ++G->generation;
+        G->cv.notify_all();
+        return OCN_SUCCESS;
+    }
+    if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return G->generation != gen; })) {
+        ocn::set_error("in-process transport: rank %d waited 120 s at a barrier", c->rank);
+        return OCN_ERR_COMM;
+    }
+    return OCN_SUCCESS;
+}
+
+// all-reduce of a small device buffer through the host (Δt, max|u|, checksums): every rank adds its values, the last one publishes
+int local_allreduce(Comm *c, double *buf, size_t count, int op, hipStream_t stream)
+{
+    LocalGroup *G = c->local;
+    std::vector<double> mine(count);
+    OCN_CHECK_HIP(hipMemcpyAsync(mine.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    OCN_CHECK_HIP(hipStreamSynchronize(stream));
+    int st = local_barrier(c);  // the previous reduction's result has been read by everybody
+    if (st != OCN_SUCCESS) return st;
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        if (G->red_count == 0) G->red = mine;
+        else
+            for (size_t q = 0; q < count; ++q)
+                G->red[q] = op == 0 ? G->red[q] + mine[q] : op == 1 ? (mine[q] > G->red[q] ? mine[q] : G->red[q]) : (mine[q] < G->red[q] ? mine[q] : G->red[q]);
+        ++G->red_count;
+    }
+    st = local_barrier(c);  // everybody has contributed
+    if (st != OCN_SUCCESS) return st;
+    std::vector<double> res;
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        res = G->red;
+    }
+    st = local_barrier(c);  // everybody has read
+    if (st != OCN_SUCCESS) return st;
+    {
+        std::lock_guard<std::mutex> lk(G->m);
+        G->red_count = 0;
+    }
+    OCN_CHECK_HIP(hipMemcpyAsync(buf, res.data(), count * sizeof(double), hipMemcpyHostToDevice, stream));
+    OCN_CHECK_HIP(hipStreamSynchronize(stream));  // `res` lives on this stack frame
+    return OCN_SUCCESS;
+}
 
 int ensure(Comm *c, size_t n)
 {
@@ -175,6 +343,7 @@ int run_schedule(Comm *c, int kind, const double *const *send, double *const *re
     int st = build_schedule(kind, c->rank, c->nranks, c->self_via_rccl, ops, 2 * OCN_COMM_MAX_RANKS, &n);
     if (st != OCN_SUCCESS) return st;
     if (n == 0) return OCN_SUCCESS;
+    if (c->local) return local_run_ops(c, ops, n, send, recv, count, stream);
     NcclGroup group;
     OCN_CHECK_NCCL(group.start());
     for (int q = 0; q < n; ++q) {
@@ -258,7 +427,75 @@ int ocn_comm_destroy(ocn_comm_t comm)
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    if (c->local) {  // the last rank to leave frees the group
+        LocalGroup *G = c->local;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(G->m);
+            last = (++G->left == G->nranks);
+        }
+        if (last) {
+            std::lock_guard<std::mutex> lk(g_local_mutex);
+            for (auto it = g_local_groups.begin(); it != g_local_groups.end(); ++it)
+                if (it->second == G) {
+                    g_local_groups.erase(it);
+                    break;
+                }
+            (void)hipDeviceSynchronize();
+            for (auto &b : G->free_stage) (void)hipFree(b.first);
+            for (auto &kv : G->box)
+                for (auto &msg : kv.second) (void)hipFree(msg.stage);
+            for (hipEvent_t e : G->free_events) (void)hipEventDestroy(e);
+            delete G;
+        }
+    }
     delete c;
+    return OCN_SUCCESS;
+}
+
+// The in-process transport (see LocalGroup above): rank `rank` of `nranks` THREADS of this process that share the current device.  Every
+// rank of a group passes the same `group_key` (any number the ranks agree on); the call returns when all ranks have joined.
+int ocn_comm_init_local(ocn_comm_t *comm, int32_t rank, int32_t nranks, int64_t group_key)
+{
+    OCN_REQUIRE(comm, "ocn_comm_init_local: null pointer");
+    OCN_REQUIRE(nranks >= 1 && nranks <= OCN_COMM_MAX_RANKS && rank >= 0 && rank < nranks, "ocn_comm_init_local: rank %d of %d", rank, nranks);
+    LocalGroup *G;
+    {
+        std::lock_guard<std::mutex> lk(g_local_mutex);
+        auto it = g_local_groups.find(group_key);
+        if (it == g_local_groups.end()) {
+            G = new LocalGroup();
+            G->nranks = nranks;
+            g_local_groups[group_key] = G;
+        } else {
+            G = it->second;
+        }
+    }
+    OCN_REQUIRE(G->nranks == nranks, "ocn_comm_init_local: group %lld has %d ranks, not %d", (long long)group_key, G->nranks, nranks);
+    Comm *c = new Comm();
+    c->rank = rank;
+    c->nranks = nranks;
+    c->west = (rank + nranks - 1) % nranks;
+    c->east = (rank + 1) % nranks;
+    c->local = G;
+    c->self_via_rccl = true;  // a rank's transfers to itself take the mailboxes too: the same code path as any other peer
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        ocn::set_error("ocn_comm_init_local: stream / event creation failed");
+        delete c;
+        return OCN_ERR_HIP;
+    }
+    {
+        std::unique_lock<std::mutex> lk(G->m);
+        ++G->joined;
+        G->cv.notify_all();
+        if (!G->cv.wait_for(lk, std::chrono::seconds(120), [&] { return G->joined >= G->nranks; })) {
+            ocn::set_error("ocn_comm_init_local: only %d of %d ranks joined group %lld within 120 s", G->joined, G->nranks, (long long)group_key);
+            return OCN_ERR_COMM;
+        }
+    }
+    *comm = c;
     return OCN_SUCCESS;
 }
 
@@ -267,8 +504,12 @@ int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c, "ocn_comm_info: null communicator");
     int count = 0, ver = 0;
-    OCN_CHECK_NCCL(ncclCommCount(c->comm, &count));  // the number of ranks RCCL itself sees
-    OCN_CHECK_NCCL(ncclGetVersion(&ver));
+    if (c->local) {
+        count = c->nranks;  // rccl_version 0: the in-process transport
+    } else {
+        OCN_CHECK_NCCL(ncclCommCount(c->comm, &count));  // the number of ranks RCCL itself sees
+        OCN_CHECK_NCCL(ncclGetVersion(&ver));
+    }
     if (rank) *rank = c->rank;
     if (nranks) *nranks = count;
     if (rccl_version) *rccl_version = ver;
@@ -429,6 +670,17 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
         OCN_CHECK_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return OCN_SUCCESS;
     }
+    if (c->local) {  // every rank's chunk to every rank (its own included), through the mailboxes
+        for (int d = 0; d < c->nranks; ++d) {
+            int st = local_send(c, send, count, d, s);
+            if (st != OCN_SUCCESS) return st;
+        }
+        for (int r = 0; r < c->nranks; ++r) {
+            int st = local_recv(c, recv + (size_t)r * count, count, r, s);
+            if (st != OCN_SUCCESS) return st;
+        }
+        return OCN_SUCCESS;
+    }
     OCN_CHECK_NCCL(ncclAllGather(send, recv, count, ncclDouble, c->comm, s));
     return OCN_SUCCESS;
 }
@@ -472,6 +724,7 @@ int ocn_comm_allreduce(ocn_comm_t comm, double *buf, size_t count, int32_t op, v
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c && buf, "ocn_comm_allreduce: null pointer");
     OCN_REQUIRE(op >= 0 && op <= 2, "ocn_comm_allreduce: op 0 = sum, 1 = max, 2 = min");
+    if (c->local) return local_allreduce(c, buf, count, op, as_stream(stream));
     const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
     OCN_CHECK_NCCL(ncclAllReduce(buf, buf, count, ncclDouble, ops[op], c->comm, as_stream(stream)));
     return OCN_SUCCESS;
@@ -485,6 +738,10 @@ int ocn_comm_barrier(ocn_comm_t comm)
     int st = ensure(c, 1);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(!c->pending, "ocn_comm_barrier: a halo exchange is in flight");
+    if (c->local) {
+        OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
+        return local_barrier(c);
+    }
     OCN_CHECK_NCCL(ncclAllReduce(c->buf[0], c->buf[0], 1, ncclDouble, ncclSum, c->comm, c->stream));
     OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
     return OCN_SUCCESS;

@@ -151,6 +151,18 @@ class RcclFabric:
             pass
 
 
+class LocalFabric(RcclFabric):
+    """The library's in-process transport (ocn_comm_init_local): the ranks are THREADS of this process sharing one GPU.  Same entry
+    points, schedules, pack / unpack launches and stream ordering as the RCCL transport -- what a one-GPU box can exercise of an R-rank
+    run besides RCCL itself (RCCL refuses two ranks on one device).  Test transport: host-blocking staging copies."""
+
+    def __init__(self, rank, size, group_key):
+        self.rank, self.size = int(rank), int(size)
+        self._h = C.c_void_p()
+        _lib.call("ocn_comm_init_local", C.byref(self._h), self.rank, self.size, int(group_key))
+        self._scratch = None
+
+
 def make_distributed(rank=None, world_size=None, local_rank=None, force_communication=None):
     """Distributed(GPU(); partition = Partition(world_size)) with the RCCL transport of libocn_hip.  One process per GPU, started by
     torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment).  A gloo process group

@@ -612,6 +612,165 @@ def test_c_distributed_model_driver_equals_python_host_and_single_rank(ocn, rccl
     del drv
 
 
+# ---- R > 1 through the LIBRARY's transport code (in-process mailboxes instead of RCCL: csrc/comm.hip, ocn_comm_init_local) -------------------
+_LOCAL_KEY = [1000]
+
+
+def _run_ranks_local(ocn, R, fn):
+    """R threads, each with an ocn_comm_init_local communicator of the same group: every exchange goes through the C entry points the RCCL
+    transport uses (schedules, pack / unpack, events), with R distinct peers."""
+    _LOCAL_KEY[0] += 1
+    key = _LOCAL_KEY[0]
+    out, errs = [None] * R, []
+
+    def target(r):
+        try:
+            torch.cuda.set_device(0)
+            fabric = ocn.distributed.LocalFabric(r, R, key)
+            try:
+                out[r] = fn(r, fabric)
+            finally:
+                ocn.sync_device()
+        except Exception:  # noqa
+            import traceback
+            errs.append(f"rank {r}: {traceback.format_exc()}")
+
+    threads = [threading.Thread(target=target, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errs, "\n".join(errs)
+    return out
+
+
+@pytest.mark.parametrize("R,N,pipeline", [(2, (64, 128, 64), "xtri"), (4, (64, 128, 64), "xtri"), (2, (128, 128, 64), "alltoall"),
+                                          (4, (128, 128, 64), "alltoall"), (8, (128, 128, 64), "xtri")])
+def test_library_transport_ranks_match_single_rank(ocn, R, N, pipeline, monkeypatch):
+    """R ranks as threads over the library's in-process transport: the correction-on-load stage (u plane, strips of u*, v*, w* begun under
+    the distributed solve, pressure planes + the owner-corrected u plane after it, one full-slab launch) with every send / recv issued by
+    csrc/comm.hip's schedule code between R DISTINCT peers -- Python host and C driver (ocn_rk3_driver_create_distributed): the C driver is
+    bit-identical to the Python host rank by rank, both within 1e-11 / 1e-10 of the single-rank model."""
+    P = "Periodic"
+    monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1" if pipeline == "xtri" else "0")
+    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(24)
+    init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
+    dt = 0.1 * (2 * np.pi / max(N))
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    single = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO())
+    ocn.set(single, **init)
+    for _ in range(3):
+        ocn.time_step(single, dt)
+    ocn.flush_tendencies(single)
+    ocn.sync_device()
+    ref = [f.interior() for f in single.velocities] + [single.pNHS.interior()]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        info = fabric.info()
+        assert info["ranks_seen_by_rccl"] == R and info["rccl_version"] == 0 and info["rank"] == r
+        out = []
+        for use_driver in (False, True):
+            g = ocn.RectilinearGrid(arch, size=N, **ext)
+            m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+            assert m.dist_correct_on_load
+            sl = slice(r * g.Nx, (r + 1) * g.Nx)
+            ocn.set(m, **{k: v[sl] for k, v in init.items()})
+            if use_driver:
+                drv = ocn.RK3Driver(m)
+                drv.time_step(dt)
+                drv.flush()
+                drv.time_step(dt)
+                drv.time_step(dt)
+                drv.flush()
+                del drv
+            else:
+                for _ in range(3):
+                    ocn.time_step(m, dt)
+                ocn.flush_tendencies(m)
+            ocn.sync_device()
+            out.append([f.interior() for f in m.velocities] + [m.pNHS.interior()])
+        fabric.barrier()
+        return out
+
+    outs = _run_ranks_local(ocn, R, rank_main)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    for r, (host, drv) in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, c, name in zip(host, drv, ref, ("u", "v", "w", "p")):
+            np.testing.assert_array_equal(a, b, err_msg=f"rank {r} {name}: C driver vs Python host")
+            tol = 1e-11 * scale if name != "p" else 1e-10 * max(1.0, np.abs(ref[3]).max())
+            assert np.abs(a - c[sl]).max() <= tol, f"rank {r} field {name} vs the single-rank model"
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_library_transport_config4_terms_match_single_rank(ocn, R):
+    """Config 4's term set (T, S, SeawaterBuoyancy + pHY', FPlane, AMD, flux / gradient conditions, stretched Bounded z, the distributed
+    Fourier-tridiagonal solver) on R ranks over the library's transport: Python host (interior / buffer split, diffusivities recomputed in
+    the edge and halo columns) and the C model driver (ocn_model_driver_create_distributed), rank by rank bit-identical to each other and
+    within 1e-10 of the single-rank model."""
+    from helpers import stretched_faces
+    N = (64 * R // 2, 128, 32)
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    rng = np.random.default_rng(25)
+    init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
+    init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+
+    def build(arch, sl=slice(None)):
+        bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-3e-4)),
+               "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+               "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-2.8e-7))}
+        m = ocn.NonhydrostaticModel(ocn.RectilinearGrid(arch, size=N, **ext), advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4),
+                                    closure=ocn.AnisotropicMinimumDissipation(),
+                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)), boundary_conditions=bcs)
+        ocn.set(m, **{k: v[sl] for k, v in init.items()})
+        return m
+
+    single = build(ocn.GPU())
+    for _ in range(3):
+        ocn.time_step(single, 1.5)
+    ocn.flush_tendencies(single)
+    ocn.sync_device()
+    ref = [f.interior() for f in single.prognostic_fields()] + [single.pNHS.interior()]
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        nx = N[0] // R
+        out = []
+        for use_driver in (False, True):
+            m = build(arch, slice(r * nx, (r + 1) * nx))
+            if use_driver:
+                drv = ocn.ModelRK3Driver(m)
+                for _ in range(3):
+                    drv.time_step(1.5)
+                drv.flush()
+                del drv
+            else:
+                for _ in range(3):
+                    ocn.time_step(m, 1.5)
+                ocn.flush_tendencies(m)
+            ocn.sync_device()
+            out.append([f.interior() for f in m.prognostic_fields()] + [m.pNHS.interior()])
+        fabric.barrier()
+        return out
+
+    outs = _run_ranks_local(ocn, R, rank_main)
+    nx = N[0] // R
+    scale = max(np.abs(a).max() for a in ref[:3])
+    names = ("u", "v", "w", "T", "S", "p")
+    for r, (host, drv) in enumerate(outs):
+        sl = slice(r * nx, (r + 1) * nx)
+        for a, b, c, name in zip(host, drv, ref, names):
+            np.testing.assert_array_equal(a, b, err_msg=f"rank {r} {name}: C model driver vs Python host")
+            refmax = np.abs(c).max()
+            tol = 1e-10 * max(1.0, refmax) if name == "p" else 1e-10 * (scale if name in "uvw" else refmax)
+            assert np.abs(a - c[sl]).max() <= tol, f"rank {r} field {name} vs the single-rank model"
+
+
 # ---- HydrostaticFreeSurfaceModel on slab-x ranks (BASELINE.json configs[4] is an 8-GPU configuration) ---------------------------------------
 def _hydro_model(ocn, grid, fused=None):
     return ocn.HydrostaticFreeSurfaceModel(grid, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_gpu_distributed import _run_ranks
+from test_gpu_distributed import _run_ranks, _run_ranks_local
 
 pytestmark = pytest.mark.gpu
 P = "Periodic"
@@ -27,10 +27,14 @@ def _release():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("pipeline", ["xtri", "alltoall"])
+@pytest.mark.parametrize("pipeline", ["xtri", "alltoall", "xtri-library-transport-c-driver"])
 def test_config3_box_512_on_8_ranks_matches_single_rank(ocn, pipeline, monkeypatch):
     """512^3 periodic box, WENO5, RK3: two steps on 8 ranks (64 x 512 x 512 each) against the single-rank model, strict math:
-    u, v, w within 1e-11 max|u| and the pressure within 1e-10 (north_star's tolerance), with either distributed pressure pipeline."""
+    u, v, w within 1e-11 max|u| and the pressure within 1e-10 (north_star's tolerance), with either distributed pressure pipeline.
+    Third flavour: what `bench.py --gpus 8` runs apart from RCCL itself -- ocn_rk3_driver_create_distributed (one C call per rank-step)
+    over the library's own transport code (csrc/comm.hip with in-process mailboxes between 8 distinct peers)."""
+    library = pipeline.endswith("c-driver")
+    pipeline = pipeline.split("-")[0]
     monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1" if pipeline == "xtri" else "0")
     N = (512, 512, 512)
     two_pi = 2 * np.pi
@@ -57,13 +61,24 @@ def test_config3_box_512_on_8_ranks_matches_single_rank(ocn, pipeline, monkeypat
         assert m.pressure_solver.impl.fast == (3 if pipeline == "xtri" else 1)
         sl = slice(r * g.Nx, (r + 1) * g.Nx)
         ocn.set(m, **{k: v[sl] for k, v in init.items()})
-        for _ in range(2):
-            ocn.time_step(m, dt)
-        ocn.flush_tendencies(m)
+        if library:
+            assert m.dist_correct_on_load
+            drv = ocn.RK3Driver(m)
+            for _ in range(2):
+                drv.time_step(dt)
+            drv.flush()
+            del drv
+        else:
+            for _ in range(2):
+                ocn.time_step(m, dt)
+            ocn.flush_tendencies(m)
         ocn.sync_device()
-        return [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+        out = [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+        if library:
+            fabric.barrier()
+        return out
 
-    outs = _run_ranks(R, rank_main)
+    outs = _run_ranks_local(ocn, R, rank_main) if library else _run_ranks(R, rank_main)
     _release()
     scale = max(np.abs(a).max() for a in ref[:3])
     pscale = max(1.0, np.abs(ref[3]).max())
