@@ -801,8 +801,8 @@ def _hydro_state(m):
     return out
 
 
-@pytest.mark.parametrize("R", [2, 4])
-def test_distributed_hydrostatic_config5_matches_single_rank(ocn, R):
+@pytest.mark.parametrize("R,transport", [(2, "python"), (4, "python"), (2, "library"), (4, "library")])
+def test_distributed_hydrostatic_config5_matches_single_rank(ocn, R, transport):
     """configs[4]'s combination on R slab-x ranks (threads of this process, real HIP kernels): the fused QAB2 step with the
     DistributedSplitExplicitFreeSurface scheme -- η, U, V, Gᵁ, Gⱽ halos as wide as the substep count, ONE exchange per baroclinic step,
     no communication while substepping (distributed_split_explicit_free_surface.jl) -- equals the single-rank model BIT FOR BIT in
@@ -827,9 +827,14 @@ def test_distributed_hydrostatic_config5_matches_single_rank(ocn, R):
         for _ in range(3):
             m.time_step(20.0)
         ocn.sync_device()
-        return _hydro_state(m)
+        out = _hydro_state(m)
+        if transport == "library":
+            fabric.barrier()
+        return out
 
-    outs = _run_ranks(R, rank_main)
+    # "library": the strips and the wide barotropic halos travel through csrc/comm.hip's entry points between R distinct peers
+    # (ocn_halo_exchange_*, ocn_comm_exchange_strips over the in-process transport) instead of the tests' Python fabric
+    outs = _run_ranks_local(ocn, R, rank_main) if transport == "library" else _run_ranks(R, rank_main)
     nx = N[0] // R
     for r, got in enumerate(outs):
         sl = slice(r * nx, (r + 1) * nx)
