@@ -155,13 +155,13 @@ int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const dou
  * that change the tendency kernels, plus the device fields those terms read. */
 typedef struct ocn_model_terms {
     int32_t advection; /* OCN_ADVECTION_* */
-    int32_t coriolis;  /* 0 nothing, 1 FPlane(f)                                            src/Coriolis/f_plane.jl:44-46 */
+    int32_t coriolis;  /* 0 nothing, 1 FPlane(f), 2 BetaPlane(f, coriolis_beta)      src/Coriolis/f_plane.jl:44-46, beta_plane.jl:43-57 */
     int32_t closure;   /* 0 nothing, 1 ScalarDiffusivity(ν, κ): ThreeDimensionalFormulation, ExplicitTimeDiscretization,
                           constant coefficients                    abstract_scalar_diffusivity_closure.jl:158-223;
                           2 AnisotropicMinimumDissipation: the same isotropic stress with the eddy viscosity field nu_e
                           (anisotropic_minimum_dissipation.jl:20-21) */
     int32_t buoyancy;  /* OCN_BUOYANCY_* */
-    double f;          /* FPlane.f */
+    double f;          /* FPlane.f or BetaPlane.f₀ */
     double nu;         /* ScalarDiffusivity.ν */
     double g, alpha, beta; /* gravitational_acceleration, thermal_expansion, haline_contraction */
     const double *T;   /* DEVICE: temperature (or the buoyancy tracer b); NULL if unused */
@@ -169,6 +169,11 @@ typedef struct ocn_model_terms {
     const double *pHY; /* DEVICE: hydrostatic pressure anomaly pHY′ (model.pressures.pHY′) or NULL = `nothing`
                           (then w receives z_dot_g_b directly, nonhydrostatic_tendency_kernel_functions.jl:141-143) */
     const double *nu_e; /* DEVICE: closure == 2: diffusivity_fields.νₑ (Center field, halos filled); else NULL */
+    /* coriolis == 2: BetaPlane(f₀ = f, β = coriolis_beta), f = f₀ + β ynode (src/Coriolis/beta_plane.jl:43-57): yc / yf are DEVICE vectors
+     * of the grid's y nodes at Centers / Faces WITH halos (element 0 <-> j = 1 - Hy: yᵃᶜᵃ, yᵃᶠᵃ of the reference); x_f_cross_U reads
+     * y at (Face, Center, Center), y_f_cross_U at (Center, Face, Center).  Unused otherwise. */
+    double coriolis_beta;
+    const double *yc, *yf;
 } ocn_model_terms;
 
 /* compute_Gu!/Gv!/Gw! with every supported term:

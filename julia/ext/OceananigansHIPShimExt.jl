@@ -251,6 +251,7 @@ struct OcnModelTerms
     advection::Int32; coriolis::Int32; closure::Int32; buoyancy::Int32
     f::Float64; nu::Float64; g::Float64; alpha::Float64; beta::Float64
     T::Ptr{Float64}; S::Ptr{Float64}; pHY::Ptr{Float64}; nu_e::Ptr{Float64}
+    coriolis_beta::Float64; yc::Ptr{Float64}; yf::Ptr{Float64}          # BetaPlane: f = f + coriolis_beta * ynode (parent(grid.yᵃᶜᵃ), parent(grid.yᵃᶠᵃ))
 end
 function compute_tendencies_with_terms!(model::HIPModel, t::OcnModelTerms, κ::Vector{Float64}, κₑ::Vector{Ptr{Float64}}, kernel_parameters)
     g = Ref(OcnGrid(model.grid)); U = model.velocities; G = model.timestepper.Gⁿ; r = range6(kernel_parameters); tr = Ref(t)

@@ -21,7 +21,7 @@ from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, Runge
                      update_state)
 from .output import (AdvectiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, hasnan, set_from_checkpoint,
                      write_checkpoint)
-from .physics import (AnisotropicMinimumDissipation, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
+from .physics import (AnisotropicMinimumDissipation, BetaPlane, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
                       GradientBoundaryCondition, LinearEquationOfState, ScalarDiffusivity, SeawaterBuoyancy,
                       ValueBoundaryCondition)
 from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver,

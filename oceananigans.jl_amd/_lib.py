@@ -32,7 +32,8 @@ class CModelTerms(C.Structure):
     """struct ocn_model_terms"""
     _fields_ = [("advection", C.c_int32), ("coriolis", C.c_int32), ("closure", C.c_int32), ("buoyancy", C.c_int32),
                 ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
-                ("T", C.c_void_p), ("S", C.c_void_p), ("pHY", C.c_void_p), ("nu_e", C.c_void_p)]
+                ("T", C.c_void_p), ("S", C.c_void_p), ("pHY", C.c_void_p), ("nu_e", C.c_void_p),
+                ("coriolis_beta", C.c_double), ("yc", C.c_void_p), ("yf", C.c_void_p)]
 
 
 class CBc(C.Structure):

@@ -247,7 +247,8 @@ static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
 {
     OCN_REQUIRE(t != nullptr, "terms is NULL");
     OCN_REQUIRE(t->advection >= OCN_ADVECTION_WENO5 && t->advection <= OCN_ADVECTION_UPWIND5, "unknown advection scheme %d", t->advection);
-    OCN_REQUIRE(t->coriolis == 0 || t->coriolis == 1, "unknown coriolis code %d", t->coriolis);
+    OCN_REQUIRE(t->coriolis >= 0 && t->coriolis <= 2, "unknown coriolis code %d", t->coriolis);
+    OCN_REQUIRE(t->coriolis != 2 || (t->yc && t->yf && grid->ty != OCN_FLAT), "BetaPlane needs the y node vectors yc, yf (and a non-Flat y)");
     OCN_REQUIRE(t->closure >= 0 && t->closure <= 2, "unknown closure code %d", t->closure);
     OCN_REQUIRE((t->closure == 2) == (t->nu_e != nullptr), "nu_e must be given exactly when closure == 2 (AnisotropicMinimumDissipation)");
     OCN_REQUIRE(t->closure != 2 || grid->tz != OCN_FLAT, "AnisotropicMinimumDissipation needs a non-Flat z");

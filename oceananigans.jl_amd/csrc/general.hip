@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn
             auto IXFa = [&](int jj) { return fx ? act_cfc(i, jj, k) : 0.5 * (act_cfc(i - 1, jj, k) + act_cfc(i, jj, k)); };
             const double an = fy ? IXFa(j) : 0.5 * (IXFa(j) + IXFa(j + 1));
             const double vi = (an == 0) ? 0.0 : (fy ? IXF(j) : 0.5 * (IXF(j) + IXF(j + 1))) / an;
-            G = G - (-t.f * vi);
+            G = G - (-ocn::coriolis_f_at(t, g.Hy, j, 0) * vi);
         }
         if (t.pHY) G = G - (fx ? 0.0 : (t.pHY[ocn::at(Lc, i, j, k)] - t.pHY[ocn::at(Lc, i - 1, j, k)]) / dx);
         if (t.closure) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn
             auto IXCa = [&](int jj) { return fx ? act_fcc(i, jj, k) : 0.5 * (act_fcc(i, jj, k) + act_fcc(i + 1, jj, k)); };
             const double an = fy ? IXCa(j) : 0.5 * (IXCa(j - 1) + IXCa(j));
             const double ui = (an == 0) ? 0.0 : (fy ? IXC(j) : 0.5 * (IXC(j - 1) + IXC(j))) / an;
-            G = G - t.f * ui;
+            G = G - ocn::coriolis_f_at(t, g.Hy, j, 1) * ui;
         }
         if (t.pHY) G = G - (fy ? 0.0 : (t.pHY[ocn::at(Lc, i, j, k)] - t.pHY[ocn::at(Lc, i, j - 1, k)]) / dy);
         if (t.closure) {

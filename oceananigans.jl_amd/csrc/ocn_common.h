@@ -117,7 +117,15 @@ struct TermsDev {
     double f, nu, g, alpha, beta;
     const double *T, *S, *pHY;
     const double *nu_e;  // eddy viscosity νₑ (ccc, halos filled) of an LES closure, or NULL: the number `nu`
+    double cbeta;        // coriolis == 2 (BetaPlane): f = f + cbeta * y, y = yc[j + Hy - 1] at u points, yf[j + Hy - 1] at v points
+    const double *yc, *yf;
 };
+// the Coriolis parameter at row j of a u point (face = 0) or a v point (face = 1)   (f_plane.jl:44-46, beta_plane.jl:43-57)
+__device__ __forceinline__ double coriolis_f_at(const TermsDev &t, int Hy, int j, int face)
+{
+    if (t.coriolis != 2) return t.f;
+    return t.f + t.cbeta * (face ? t.yf : t.yc)[j + Hy - 1];
+}
 inline TermsDev to_dev(const ocn_model_terms &m)
 {
     TermsDev t;
@@ -125,6 +133,7 @@ inline TermsDev to_dev(const ocn_model_terms &m)
     t.f = m.f; t.nu = m.nu; t.g = m.g; t.alpha = m.alpha; t.beta = m.beta;
     t.T = m.T; t.S = m.S; t.pHY = m.pHY;
     t.nu_e = m.nu_e;
+    t.cbeta = m.coriolis_beta; t.yc = m.yc; t.yf = m.yf;
     return t;
 }
 

@@ -269,7 +269,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         if (t.buoyancy) G = G + 0.0;  // x_dot_g_b = 0 (NegativeZDirection)
         if (t.coriolis) {             // - x_f_cross_U,  x_f_cross_U = -f * ℑxyᶠᶜᵃ(v) / 1
             const double vi = 0.5 * (0.5 * (Vf(-1, 0, 0) + Vf(0, 0, 0)) + 0.5 * (Vf(-1, 1, 0) + Vf(0, 1, 0)));
-            G = G - (-t.f * vi);
+            G = G - (-ocn::coriolis_f_at(t, g.Hy, j, 0) * vi);
         }
         if (t.pHY) G = G - DX(ph_c, ph_w);  // ∂xᶠᶜᶜ pHY′
         if (t.closure) {
@@ -309,7 +309,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
         if (t.buoyancy) G = G + 0.0;
         if (t.coriolis) {  // - y_f_cross_U,  y_f_cross_U = f * ℑxyᶜᶠᵃ(u) / 1
             const double ui = 0.5 * (0.5 * (Uf(0, -1, 0) + Uf(1, -1, 0)) + 0.5 * (Uf(0, 0, 0) + Uf(1, 0, 0)));
-            G = G - t.f * ui;
+            G = G - ocn::coriolis_f_at(t, g.Hy, j, 1) * ui;
         }
         if (t.pHY) G = G - DY(ph_c, ph_s);
         if (t.closure) {

@@ -14,6 +14,8 @@ or Centered(); coriolis = FPlane, closure = ScalarDiffusivity, buoyancy = Buoyan
 top Flux / Value / Gradient boundary conditions are the SURVEY §8(f) rank-1 terms (physics.py); anything else raises.
 """
 import math
+
+import numpy as np
 import os
 
 import torch
@@ -22,7 +24,7 @@ from . import _lib
 import ctypes as C
 
 from .advection import WENO, UpwindBiased
-from .physics import (AnisotropicMinimumDissipation, BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity,
+from .physics import (AnisotropicMinimumDissipation, BetaPlane, BuoyancyTracer, Centered, FieldBoundaryConditions, FPlane, ScalarDiffusivity,
                       SeawaterBuoyancy)
 from .architectures import stream_ptr
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
@@ -88,8 +90,10 @@ class NonhydrostaticModel:
             advection = Centered()  # the reference default (nonhydrostatic_model.jl:117)
         if not isinstance(advection, (WENO, Centered, UpwindBiased)):
             raise NotImplementedError("advection must be WENO(), UpwindBiased(order=5) or Centered()")
-        if coriolis is not None and not isinstance(coriolis, FPlane):
-            raise NotImplementedError("only coriolis = FPlane(...) is implemented")
+        if coriolis is not None and not isinstance(coriolis, (FPlane, BetaPlane)):
+            raise NotImplementedError("only coriolis = FPlane(...) or BetaPlane(...) is implemented")
+        if isinstance(coriolis, BetaPlane) and grid.topology[1] == Flat:
+            raise NotImplementedError("BetaPlane needs a non-Flat y")
         if closure is not None and not isinstance(closure, (ScalarDiffusivity, AnisotropicMinimumDissipation)):
             raise NotImplementedError("only closure = ScalarDiffusivity(...) or AnisotropicMinimumDissipation(...) is implemented")
         if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
@@ -212,7 +216,16 @@ class NonhydrostaticModel:
         t.advection = (_lib.ADVECTION_CENTERED2 if isinstance(self.advection, Centered)
                        else _lib.ADVECTION_UPWIND5 if isinstance(self.advection, UpwindBiased) else _lib.ADVECTION_WENO5)
         if self.coriolis is not None:
-            t.coriolis, t.f = 1, self.coriolis.f
+            if isinstance(self.coriolis, BetaPlane):
+                # f = f₀ + β ynode (beta_plane.jl:43-57): the y nodes of Centers / Faces with halos, element 0 <-> j = 1 - Hy
+                from .architectures import on_architecture
+                g = self.grid
+                self._ynodes = tuple(on_architecture(g.architecture, np.ascontiguousarray(g.nodes_1d(1, face, with_halos=True)))
+                                     for face in (False, True))
+                t.coriolis, t.f, t.coriolis_beta = 2, self.coriolis.f0, self.coriolis.beta
+                t.yc, t.yf = self._ynodes[0].data_ptr(), self._ynodes[1].data_ptr()
+            else:
+                t.coriolis, t.f = 1, self.coriolis.f
         if isinstance(self.closure, AnisotropicMinimumDissipation):
             t.closure, t.nu_e = 2, self.diffusivity_fields["nu_e"].ptr
         elif self.closure is not None:

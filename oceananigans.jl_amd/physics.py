@@ -5,7 +5,7 @@
   ScalarDiffusivity(ν=..., κ=...)                 src/TurbulenceClosures/turbulence_closure_implementations/scalar_diffusivity.jl
   BuoyancyTracer(), SeawaterBuoyancy(...), LinearEquationOfState(...)
                                                   src/BuoyancyFormulations/{buoyancy_tracer,seawater_buoyancy,linear_equation_of_state}.jl
-  FluxBoundaryCondition, ValueBoundaryCondition, GradientBoundaryCondition, FieldBoundaryConditions
+  FluxBoundaryCondition, ValueBoundaryCondition, GradientBoundaryCondition, FieldBoundaryConditions, BetaPlane
                                                   src/BoundaryConditions/{boundary_condition,field_boundary_conditions}.jl
 
 Only what the HIP kernels implement is accepted; everything else raises NotImplementedError.
@@ -48,6 +48,13 @@ def sind(x):
         return sign * float(total)
 
 
+def cosd(x):
+    """Julia's cosd: cos(x π / 180) correctly rounded, exact at the multiples of 30 / 90 where the cosine is 0, ±0.5, ±1
+    (cosd(x) = sind(90 - x) holds exactly for the reduced argument)."""
+    from fractions import Fraction
+    return sind(Fraction(90) - Fraction(x))
+
+
 class Centered:
     """Centered(order=2)"""
 
@@ -78,6 +85,29 @@ class FPlane:
             rotation_rate = self.OMEGA_EARTH if rotation_rate is None else rotation_rate
             f = 2 * rotation_rate * sind(latitude)
         self.f = float(f)
+
+
+class BetaPlane:
+    """BetaPlane(; f₀, β) or BetaPlane(; rotation_rate=Ω_Earth, latitude, radius=R_Earth) (beta_plane.jl:6-41): f = f₀ + β y, evaluated at
+    the y node of each velocity point (:43-57)."""
+    OMEGA_EARTH = 7.292115e-5  # src/Coriolis/Coriolis.jl:19
+    R_EARTH = 6371.0e3         # src/Grids/Grids.jl:40
+
+    def __init__(self, f0=None, beta=None, rotation_rate=None, latitude=None, radius=None, **kw):
+        f0 = kw.pop("f₀", f0)
+        beta = kw.pop("β", beta)
+        if kw:
+            raise TypeError(f"unknown keyword(s) {sorted(kw)}")
+        use_f_and_beta = f0 is not None and beta is not None
+        use_planet = latitude is not None
+        if use_f_and_beta == use_planet:
+            raise ValueError("Either both keywords f₀ and β must be specified, *or* all of rotation_rate, latitude, and radius.")
+        if use_planet:
+            rotation_rate = self.OMEGA_EARTH if rotation_rate is None else rotation_rate
+            radius = self.R_EARTH if radius is None else radius
+            f0 = 2 * rotation_rate * sind(latitude)
+            beta = 2 * rotation_rate * cosd(latitude) / radius
+        self.f0, self.beta = float(f0), float(beta)
 
 
 class ScalarDiffusivity:

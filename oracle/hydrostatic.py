@@ -173,7 +173,7 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
     operators; w is diagnostic, η is the extra prognostic field (stored as a (sx, sy) array, the plane k = Nz+1 of the
     reference's reduced field)."""
 
-    def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None,
+    def __init__(self, grid, tracers=(), momentum_advection="Centered2", tracer_advection=None, coriolis_f=None, closure=None, coriolis_beta=None,
                  buoyancy=None, boundary_conditions=None, gravitational_acceleration=g_Earth, split_explicit_substeps=None,
                  split_explicit_timestepper="ForwardBackward", implicit_free_surface=False, timestepper="QuasiAdamsBashforth2"):
         """split_explicit_substeps = N: free_surface = SplitExplicitFreeSurface(substeps = N) with the ForwardBackwardScheme
@@ -205,7 +205,7 @@ class HydrostaticFreeSurfaceModel(O.NonhydrostaticModel):
         if self.vector_invariant and tracer_advection is None:
             tracer_advection = "Centered2"  # the reference's default tracer scheme
         super().__init__(grid, tracers=tracers, timestepper="QuasiAdamsBashforth2",
-                         advection=tracer_advection if self.vector_invariant else momentum_advection, coriolis_f=coriolis_f,
+                         advection=tracer_advection if self.vector_invariant else momentum_advection, coriolis_f=coriolis_f, coriolis_beta=coriolis_beta,
                          closure=closure, buoyancy=buoyancy, boundary_conditions=boundary_conditions)
         ta = momentum_advection if tracer_advection is None else tracer_advection
         self.tracer_scheme = {"WENO5": O.ADV_WENO5, "Centered2": O.ADV_CENTERED2, "UpwindBiased5": O.ADV_UPWIND5}[ta]

@@ -485,15 +485,25 @@ void ocn_oracle_tracer_tendency(const ocn_grid *g, const double *u, const double
  * value / gradient boundary conditions.
  * ===================================================================================== */
 typedef struct {
-    int32_t coriolis; /* 0 nothing, 1 FPlane (Coriolis/f_plane.jl:44-46) */
+    int32_t coriolis; /* 0 nothing, 1 FPlane (Coriolis/f_plane.jl:44-46), 2 BetaPlane (beta_plane.jl:43-57) */
     int32_t closure;  /* 0 nothing, 1 ScalarDiffusivity(ν, κ): ThreeDimensionalFormulation, ExplicitTimeDiscretization, constants */
     int32_t buoyancy; /* 0 nothing, 1 BuoyancyTracer, 2 SeawaterBuoyancy(LinearEquationOfState) with T and S,
                          3 ... with T only (constant_salinity), 4 ... with S only (constant_temperature) */
     int32_t _pad;
-    double f;            /* FPlane.f */
+    double f;            /* FPlane.f, or BetaPlane.f₀ */
     double nu;           /* ScalarDiffusivity.ν */
     double g, alpha, beta; /* gravitational_acceleration, thermal_expansion, haline_contraction */
+    /* coriolis == 2: BetaPlane(f₀, β) (Coriolis/beta_plane.jl:43-57): f = f₀ + β y with y = ynode at the velocity point, i.e.
+     * yᵃᶜᵃ[j] for x_f_cross_U and yᵃᶠᵃ[j] for y_f_cross_U; the node vectors include the halos (element 0 <-> j = 1 - Hy) */
+    double coriolis_beta;
+    const double *yc, *yf;
 } ocn_physics;
+static inline double coriolis_f_at(const ocn_grid *g, const ocn_physics *ph, int j, int face)
+{
+    if (ph->coriolis != 2) return ph->f;
+    const double y = (face ? ph->yf : ph->yc)[j + g->Hy - 1];
+    return ph->f + ph->coriolis_beta * y;
+}
 
 /* inactive_cell (Grids/inactive_node.jl:35-95): outside the domain in a Bounded direction */
 static inline int inactive_cell(const ocn_grid *g, int i, int j, int k)
@@ -625,7 +635,7 @@ void ocn_oracle_momentum_extra_tendencies_nu(const ocn_grid *g, const ocn_physic
                     if (ph->coriolis) { /* x_f_cross_U = -f * active_weighted_ℑxyᶠᶜᶜ(v) (interpolation_operators.jl:127-131) */
                         double an = ixy_fc_active(g, i, j, k);
                         double vi = (an == 0) ? 0.0 : ixy_fc(g, v, &Lv, i, j, k) / an;
-                        G = G - (-ph->f * vi);
+                        G = G - (-coriolis_f_at(g, ph, j, 0) * vi);
                     }
                     if (pHY) G = G - (fx ? 0.0 : (pHY[AT(Lc, i, j, k)] - pHY[AT(Lc, i - 1, j, k)]) / dx); /* ∂xᶠᶜᶜ pHY′ */
                     if (ph->closure) { /* ∂ⱼ_τ₁ⱼ (closure_kernel_operators.jl:27-32) */
@@ -642,7 +652,7 @@ void ocn_oracle_momentum_extra_tendencies_nu(const ocn_grid *g, const ocn_physic
                     if (ph->coriolis) { /* y_f_cross_U = f * active_weighted_ℑxyᶜᶠᶜ(u) */
                         double an = ixy_cf_active(g, i, j, k);
                         double ui = (an == 0) ? 0.0 : ixy_cf(g, u, &Lu, i, j, k) / an;
-                        G = G - ph->f * ui;
+                        G = G - coriolis_f_at(g, ph, j, 1) * ui;
                     }
                     if (pHY) G = G - (fy ? 0.0 : (pHY[AT(Lc, i, j, k)] - pHY[AT(Lc, i, j - 1, k)]) / dy);
                     if (ph->closure) { /* ∂ⱼ_τ₂ⱼ (:34-39) */

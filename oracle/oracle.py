@@ -287,14 +287,16 @@ def tracer_tendency(g, u, v, w, c, Gc, scheme=ADV_WENO5):
 
 class _CPhysics(C.Structure):
     _fields_ = [("coriolis", C.c_int32), ("closure", C.c_int32), ("buoyancy", C.c_int32), ("_pad", C.c_int32),
-                ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double)]
+                ("f", C.c_double), ("nu", C.c_double), ("g", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
+                ("coriolis_beta", C.c_double), ("yc", C.c_void_p), ("yf", C.c_void_p)]
 
 
 class Physics:
     """coriolis = FPlane(f); closure = ScalarDiffusivity(ν, κ); buoyancy = "BuoyancyTracer" or
     ("SeawaterBuoyancy", g, α, β[, "T" | "S"]) with a LinearEquationOfState."""
 
-    def __init__(self, f=None, nu=None, kappa=None, buoyancy=None):
+    def __init__(self, f=None, nu=None, kappa=None, buoyancy=None, coriolis_beta=None, grid=None):
+        """coriolis_beta (with `grid`): BetaPlane(f₀ = f, β = coriolis_beta), f = f₀ + β ynode (beta_plane.jl:43-57)"""
         self.f, self.nu, self.kappa = f, nu, kappa
         self.buoyancy = buoyancy
         kind, gg, al, be = 0, 0.0, 0.0, 0.0
@@ -304,7 +306,14 @@ class Physics:
             _, gg, al, be = buoyancy[:4]
             kind = {None: 2, "T": 3, "S": 4}[buoyancy[4] if len(buoyancy) > 4 else None]
         self.c = _CPhysics(0 if f is None else 1, 0 if nu is None else 1, kind, 0, 0.0 if f is None else float(f),
-                           0.0 if nu is None else float(nu), float(gg), float(al), float(be))
+                           0.0 if nu is None else float(nu), float(gg), float(al), float(be), 0.0, None, None)
+        if coriolis_beta is not None:
+            assert f is not None and grid is not None
+            # ynode = yᵃᶜᵃ[j], yᵃᶠᵃ[j] of the grid, halos included (element 0 <-> j = 1 - Hy)
+            self._yc = np.ascontiguousarray(grid.nodes(1, face=False, with_halos=True), dtype=np.float64)
+            self._yf = np.ascontiguousarray(grid.nodes(1, face=True, with_halos=True), dtype=np.float64)
+            self.c.coriolis, self.c.coriolis_beta = 2, float(coriolis_beta)
+            self.c.yc, self.c.yf = self._yc.ctypes.data, self._yf.ctypes.data
 
     @property
     def ref(self):
@@ -507,7 +516,7 @@ class NonhydrostaticModel:
     (set_nonhydrostatic_model.jl:33-60), RK3 `time_step!` (runge_kutta_3.jl:77-151) and
     QAB2 `time_step!` (quasi_adams_bashforth_2.jl:74-115)."""
 
-    def __init__(self, grid, tracers=(), timestepper="RungeKutta3", workers=1, advection="WENO5", coriolis_f=None,
+    def __init__(self, grid, tracers=(), timestepper="RungeKutta3", workers=1, advection="WENO5", coriolis_f=None, coriolis_beta=None,
                  closure=None, buoyancy=None, boundary_conditions=None, hydrostatic_pressure_anomaly="default"):
         """advection: "WENO5" | "Centered2"; closure = (ν, {tracer: κ} or κ); buoyancy as in Physics;
         boundary_conditions = {"u": {"top": BC, ...}, ...} (§8(f) rank 1)."""
@@ -531,7 +540,7 @@ class NonhydrostaticModel:
             if not isinstance(kappa, dict):
                 kappa = {n: kappa for n in tracers}
         self.kappa = kappa
-        self.physics = Physics(f=coriolis_f, nu=nu, kappa=kappa, buoyancy=buoyancy)
+        self.physics = Physics(f=coriolis_f, nu=nu, kappa=kappa, buoyancy=buoyancy, coriolis_beta=coriolis_beta, grid=grid)
         self.bcs = boundary_conditions or {}
         # nonhydrostatic_model.jl:143-158: a separate hydrostatic pressure anomaly exists iff buoyancy is not nothing
         self.pHY = g.zeros(LOC_C) if (buoyancy is not None and hydrostatic_pressure_anomaly == "default") else None

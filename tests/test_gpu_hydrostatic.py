@@ -118,7 +118,7 @@ def test_split_explicit_free_surface_model_steps_match_oracle(oracle, ocn, fused
 
 
 # ---- BASELINE.json configs[4]: VectorInvariant momentum + WENO tracer advection + SplitExplicitFreeSurface -----------------------------
-def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None, timestepper="QuasiAdamsBashforth2"):
+def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None, timestepper="QuasiAdamsBashforth2", beta=None):
     from oracle import hydrostatic as Hy
     O = oracle
     og, pg = _pair(O, ocn, size, stretched=stretched)
@@ -126,12 +126,13 @@ def _config5_pair(oracle, ocn, size, substeps, stretched, seed=31, fused=None, t
     init = dict(u=1e-2 * rng.uniform(-1, 1, size), v=1e-2 * rng.uniform(-1, 1, size), eta=1e-2 * rng.uniform(-1, 1, size[:2]),
                 T=20 + 1e-2 * rng.uniform(-1, 1, size), S=35 + 1e-2 * rng.uniform(-1, 1, size))
     om = Hy.HydrostaticFreeSurfaceModel(og, tracers=("T", "S"), momentum_advection="VectorInvariant", tracer_advection="WENO5",
-                                        coriolis_f=1e-4, closure=(1e-2, 2e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4),
+                                        coriolis_f=1e-4, coriolis_beta=beta, closure=(1e-2, 2e-3), buoyancy=("SeawaterBuoyancy", 9.80665, 2e-4, 8e-4),
                                         split_explicit_substeps=substeps, timestepper=timestepper,
                                         boundary_conditions={"u": {"top": O.FluxBoundaryCondition(-1e-4)}, "T": {"top": O.FluxBoundaryCondition(5e-5)}})
     om.set(**init)
     pm = ocn.HydrostaticFreeSurfaceModel(pg, momentum_advection=ocn.VectorInvariant(), tracer_advection=ocn.WENO(), tracers=("T", "S"),
-                                         free_surface=ocn.SplitExplicitFreeSurface(substeps=substeps), coriolis=ocn.FPlane(f=1e-4),
+                                         free_surface=ocn.SplitExplicitFreeSurface(substeps=substeps),
+                                         coriolis=ocn.FPlane(f=1e-4) if beta is None else ocn.BetaPlane(f0=1e-4, beta=beta),
                                          closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-3),
                                          buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
                                          boundary_conditions={"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1e-4)),
@@ -182,6 +183,24 @@ def test_config5_combination_matches_oracle(oracle, ocn, size, substeps, stretch
         assert np.abs(og.interior(om.u)).max() < 1.0 and np.abs(om.eta).max() < 1.0      # a stable run, not a common blow-up
     finally:
         ocn.set_math_mode(ocn.MATH_STRICT)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_config5_combination_on_a_beta_plane_matches_oracle(oracle, ocn, fused):
+    """The same combination with coriolis = BetaPlane(f₀, β) (beta_plane.jl:43-57; the hydrostatic model's usual Coriolis term): 3 QAB2
+    steps bit for bit against the oracle, fused and reference launch sequences."""
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    og, om, pm = _config5_pair(oracle, ocn, (16, 12, 7), 12, True, fused=fused, beta=2e-8)
+    assert pm.fused == fused
+    for _ in range(3):
+        om.time_step(20.0)
+        pm.time_step(20.0)
+    ocn.sync_device()
+    _compare_hydrostatic(og, om, pm, 0)
+    og2, om2, _ = _config5_pair(oracle, ocn, (16, 12, 7), 12, True, fused=fused)
+    for _ in range(3):
+        om2.time_step(20.0)
+    assert np.abs(og.interior(om.u) - og2.interior(om2.u)).max() > 0  # β matters
 
 
 @pytest.mark.parametrize("size,substeps,stretched,dt", [((16, 12, 7), 12, True, 20.0), ((67, 9, 12), 8, True, 3.0)])

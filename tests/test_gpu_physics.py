@@ -65,6 +65,74 @@ def test_centered2_advection_strict_bitwise(oracle, ocn, size, topo, z, halo):
     assert np.abs(G[0]).max() > 0 and np.abs(G[3]).max() > 0
 
 
+@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PPB"), ((70, 9, 8), "PPB"), ((5, 6, 4), "PPP"), ((12, 10, 9), "PBB"), ((11, 9, 8), "BBB")])
+def test_beta_plane_coriolis_strict_bitwise(oracle, ocn, size, topo):
+    """BetaPlane(f₀, β) (Coriolis/beta_plane.jl:43-57): f = f₀ + β ynode, with y at (Face, Center, Center) in x_f_cross_U and at (Center,
+    Face, Center) in y_f_cross_U, the node vectors being the reference's TwicePrecision ranges -- tiled, direct and direction-generic
+    kernels against the oracle, bit for bit, on grids whose y interval does not start at 0"""
+    O = oracle
+    rng = np.random.default_rng(26)
+    og, pg = make_pair(O, ocn, size, topo, x=(0, 1.3), y=(-0.45, 0.75), z=(-0.7, 0))
+    u, v, w = [], [], []
+    fields = []
+    for loc in LOCS:
+        a = random_parent(og, loc, rng)
+        O.fill_halo_regions(og, a, loc)
+        fields.append(a)
+    u, v, w = fields
+    ph = O.Physics(f=0.7, nu=0.013, coriolis_beta=1.9, grid=og)
+    G = [og.zeros(l) for l in LOCS]
+    O.momentum_tendencies(og, u, v, w, *G)
+    O.momentum_extra_tendencies(og, ph, u, v, w, None, None, None, *G)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, fields))
+    import torch
+    yc = torch.from_numpy(np.ascontiguousarray(pg.nodes_1d(1, False, with_halos=True))).cuda()
+    yf = torch.from_numpy(np.ascontiguousarray(pg.nodes_1d(1, True, with_halos=True))).cuda()
+    np.testing.assert_array_equal(yc.cpu().numpy(), og.nodes(1, False, with_halos=True))   # the two restatements of Julia's range agree
+    np.testing.assert_array_equal(yf.cpu().numpy(), og.nodes(1, True, with_halos=True))
+    t = _terms(ocn, advection=0, f=0.7, nu=0.013)
+    t.coriolis, t.coriolis_beta, t.yc, t.yf = 2, 1.9, yc.data_ptr(), yf.data_ptr()
+    dG = [ocn.Field(l, pg) for l in LOCS]
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, "uvw"):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} G{name}")
+    t.yc = None
+    with pytest.raises(ocn.OcnError, match="BetaPlane needs the y node vectors"):
+        ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_beta_plane_model_matches_oracle(oracle, ocn, mode):
+    """NonhydrostaticModel(coriolis = BetaPlane(f₀, β)) with a buoyancy tracer and diffusivity on the fused path: 3 RK3 steps against the
+    oracle's model (strict 1e-11, fast 1e-10)"""
+    O = oracle
+    og, pg = make_pair(O, ocn, (32, 16, 12), "PPB", x=(0, 2.0), y=(-1.0, 1.0), z=(-1.0, 0))
+    rng = np.random.default_rng(27)
+    ocn.set_math_mode(ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    try:
+        om = O.NonhydrostaticModel(og, tracers=("b",), coriolis_f=0.4, coriolis_beta=1.5, closure=(0.01, {"b": 0.02}), buoyancy="BuoyancyTracer")
+        pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("b",), coriolis=ocn.BetaPlane(f0=0.4, beta=1.5),
+                                     closure=ocn.ScalarDiffusivity(ν=0.01, κ=0.02), buoyancy=ocn.BuoyancyTracer())
+        assert pm.fuse_stage_boundaries
+        init = {n: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for n, l in zip("uvw", LOCS)}
+        init["b"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
+        om.set(**init)
+        ocn.set(pm, **init)
+        for _ in range(3):
+            om.time_step(2e-3)
+            ocn.time_step(pm, 2e-3)
+        ocn.flush_tendencies(pm)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    scale = max(np.abs(a).max() for a in (om.u, om.v, om.w))
+    tol = 1e-11 if mode == "strict" else 1e-10
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "b")):
+        assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= tol * max(scale, 1.0), name
+
+
 @pytest.mark.parametrize("size,topo,z,halo", CASES)
 @pytest.mark.parametrize("separate_pHY", [True, False])
 def test_all_momentum_terms_strict_bitwise(oracle, ocn, size, topo, z, halo, separate_pHY):

@@ -421,3 +421,32 @@ def test_fplane_constructor():
         ocn.FPlane(f=1.0, latitude=10)
     with pytest.raises(ValueError):
         ocn.FPlane()
+
+
+def test_beta_plane_is_f_plane_row_by_row(oracle):
+    """BetaPlane (beta_plane.jl:43-57) on the oracle: with β = 0 it IS the FPlane; with β != 0 row j of G_u equals the FPlane result with
+    f = f₀ + β yᶜ[j] and row j of G_v the one with f = f₀ + β yᶠ[j], bit for bit"""
+    O = oracle
+    og = O.Grid((8, 6, 5), x=(0, 1), y=(-0.5, 0.7), z=(-1, 0), topology="PPB", halo=(3, 3, 3))
+    rng = np.random.default_rng(0)
+    U = []
+    for loc in (1, 2, 4):
+        a = og.zeros(loc)
+        a[...] = rng.uniform(-1, 1, a.shape)
+        O.fill_halo_regions(og, a, loc)
+        U.append(a)
+
+    def extra(ph):
+        G = [og.zeros(l) for l in (1, 2, 4)]
+        O.momentum_extra_tendencies(og, ph, *U, None, None, None, *G)
+        return G
+
+    for a, b in zip(extra(O.Physics(f=0.7, coriolis_beta=0.0, grid=og)), extra(O.Physics(f=0.7))):
+        np.testing.assert_array_equal(a, b)
+    G = extra(O.Physics(f=0.7, coriolis_beta=2.0, grid=og))
+    yc, yf = og.nodes(1, False), og.nodes(1, True)
+    assert abs(yc[0] + 0.4) < 1e-15 and abs(yf[0] + 0.5) < 1e-15  # (Julia's range arithmetic: yᶠ[1] = -0.5000000000000001 here)
+    for j in range(og.Ny):
+        np.testing.assert_array_equal(og.interior(G[0])[:, j, :], og.interior(extra(O.Physics(f=0.7 + 2.0 * yc[j]))[0])[:, j, :])
+        np.testing.assert_array_equal(og.interior(G[1])[:, j, :], og.interior(extra(O.Physics(f=0.7 + 2.0 * yf[j]))[1])[:, j, :])
+

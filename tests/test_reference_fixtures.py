@@ -295,3 +295,24 @@ def test_julia_range_restatements_agree():
         assert got == julia_base.julia_range(a, b, n)
         assert got[0] == a and got[-1] == b
         assert np.allclose(got, np.linspace(a, b, n), rtol=1e-14, atol=1e-15 * max(abs(a), abs(b)))
+
+
+def test_beta_plane_constructor_known_answers():
+    """test/test_coriolis.jl:40-53, 112-120: BetaPlane(f₀ = π, β = 2π) keeps its arguments; BetaPlane(latitude = 70, radius = 2π, rotation_rate = 3π)
+    gives f₀ = 6π sind(70), β = 6π cosd(70) / 2π; neither / both argument sets is an ArgumentError; and cosd has Julia's exact values"""
+    import math
+    import oceananigans_jl_amd as ocn
+    from oceananigans_jl_amd import physics
+    c = ocn.BetaPlane(f0=math.pi, beta=2 * math.pi)
+    assert c.f0 == math.pi and c.beta == 2 * math.pi
+    c = ocn.BetaPlane(latitude=70, radius=2 * math.pi, rotation_rate=3 * math.pi)
+    assert c.f0 == 6 * math.pi * physics.sind(70)
+    assert c.beta == 6 * math.pi * physics.cosd(70) / (2 * math.pi)
+    assert abs(physics.cosd(70) - math.cos(math.radians(70))) <= 1e-15
+    assert physics.cosd(60) == 0.5 and physics.cosd(90) == 0.0 and physics.cosd(0) == 1.0 and physics.cosd(180) == -1.0 and physics.cosd(120) == -0.5
+    for kw in ({}, dict(f0=1.0), dict(f0=1.0, beta=2.0, latitude=10)):
+        with pytest.raises(ValueError):
+            ocn.BetaPlane(**kw)
+    earth = ocn.BetaPlane(latitude=45)
+    assert earth.f0 == 2 * 7.292115e-5 * physics.sind(45) and earth.beta == 2 * 7.292115e-5 * physics.cosd(45) / 6371.0e3
+
