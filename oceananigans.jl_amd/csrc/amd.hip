@@ -17,29 +17,44 @@ namespace OCN_NS {
 using ocn::GridDev;
 using ocn::Lay;
 
+// GEN = false: x, y Periodic -- one parent layout (strides, interior offset) serves u, v, w and the centre fields.  GEN = true: a Bounded
+// x / y gives the Face fields one more point along it, so every field has its own strides (grid_utils.jl:66-72).
+template <bool GEN>
 struct Amd {
     const double *u, *v, *w, *c;  // pointers at the cell (i, j, k)
-    long long s2, s3;
+    long long s2, s3;             // centre fields
+    long long u2, u3, v2, v3, w2, w3;
+    long long oc;                 // offset of the cell in a centre field
     double dx, dy, Fx, Fy;
     Metrics M;
     int k;  // 1-based k of the cell, for the z metrics
-    __device__ __forceinline__ double U(int a, int b, int d) const { return u[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double V(int a, int b, int d) const { return v[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double W(int a, int b, int d) const { return w[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double U(int a, int b, int d) const { return GEN ? u[a + b * u2 + d * u3] : u[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double V(int a, int b, int d) const { return GEN ? v[a + b * v2 + d * v3] : v[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double W(int a, int b, int d) const { return GEN ? w[a + b * w2 + d * w3] : w[a + b * s2 + d * s3]; }
     __device__ __forceinline__ double C(int a, int b, int d) const { return c[a + b * s2 + d * s3]; }
     __device__ __forceinline__ double Fz(int d) const { return 2 * M.dzC(k + d); }
 };
 
 __device__ __forceinline__ double julia_max0(double x) { return (x > 0 || x != x) ? x : 0.0; }
 
-__device__ __forceinline__ Amd make_amd(const GridDev &g, const double *u, const double *v, const double *w, const double *c, int i,
-                                       int j, int k)
+template <bool GEN>
+__device__ __forceinline__ Amd<GEN> make_amd(const GridDev &g, const double *u, const double *v, const double *w, const double *c, int i,
+                                            int j, int k)
 {
     const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
     const long long o = ocn::at(L, i, j, k);
-    Amd A;
-    A.u = u + o; A.v = v + o; A.w = w + o; A.c = c ? c + o : nullptr;
+    Amd<GEN> A;
+    A.oc = o;
     A.s2 = L.s2; A.s3 = L.s3;
+    if (GEN) {
+        const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
+        A.u = u + ocn::at(Lu, i, j, k); A.v = v + ocn::at(Lv, i, j, k); A.w = w + ocn::at(Lw, i, j, k);
+        A.u2 = Lu.s2; A.u3 = Lu.s3; A.v2 = Lv.s2; A.v3 = Lv.s3; A.w2 = Lw.s2; A.w3 = Lw.s3;
+    } else {
+        A.u = u + o; A.v = v + o; A.w = w + o;
+        A.u2 = A.v2 = A.w2 = L.s2; A.u3 = A.v3 = A.w3 = L.s3;
+    }
+    A.c = c ? c + o : nullptr;
     A.dx = g.dx; A.dy = g.dy; A.Fx = 2 * g.dx; A.Fy = 2 * g.dy;
     A.M = make_metrics(g);
     A.k = k;
@@ -66,6 +81,7 @@ struct AmdTracers {
 #define I4SQ(f) (0.5 * (0.5 * (f[0][0] * f[0][0] + f[1][0] * f[1][0]) + 0.5 * (f[0][1] * f[0][1] + f[1][1] * f[1][1])))
 #define I4PR(f, g) (0.5 * (0.5 * (f[0][0] * g[0][0] + f[1][0] * g[1][0]) + 0.5 * (f[0][1] * g[0][1] + f[1][1] * g[1][1])))
 
+template <bool GEN>
 __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
                                                         const double *__restrict__ v, const double *__restrict__ w,
                                                         double *__restrict__ nu_e, AmdTracers tr, int i0, int i1, int KZ, int xcd)
@@ -92,7 +108,7 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
     // velocities and the tracer values are carried in registers (re-evaluating them would give the same bits: same operands, same
     // operations), so an iteration loads 28 values instead of 46.  Built for 3 waves / SIMD (20 spilled VGPRs): config 4 at 512 x 512
     // x 256 steps in 39.7 ms against 40.4 (the compiler's 176 VGPRs, 2 waves) and 40.8 (one plane per iteration recomputed).
-    const Amd A0 = make_amd(g, u, v, w, nullptr, i, j, kb);
+    const Amd<GEN> A0 = make_amd<GEN>(g, u, v, w, nullptr, i, j, kb);
     const double dx = A0.dx, dy = A0.dy, Fx = A0.Fx, Fy = A0.Fy;
 #if OCN_STRICT
 #define AMD_D(num, den) ((num) / (den))
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
             c_dywq[a] = ryz0 * AMD_D(A0.W(a, 0, 0) - A0.W(a, -1, 0), qdy);
         }
         cW = A0.W(0, 0, 0);
-        const long long o0 = A0.u - u;
+        const long long o0 = A0.oc;
 #pragma unroll
         for (int n = 0; n < OCN_AMD_MAX_TRACERS; ++n) {
             tc0[n] = tgz[n] = 0.0;
@@ -137,8 +153,8 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
         }
     }
     for (int k = kb; k <= ke; ++k) {
-    const Amd A = make_amd(g, u, v, w, nullptr, i, j, k);
-    const long long o = A.u - u;
+    const Amd<GEN> A = make_amd<GEN>(g, u, v, w, nullptr, i, j, k);
+    const long long o = A.oc;
     // filter width and spacings of level k (for d2, dzw) and of level k+1 (the new gradients); k is uniform across the workgroup
     const double Fz[2] = {A.Fz(0), A.Fz(1)};
     const double dzf1 = A.M.dzF(k + 1);
@@ -282,7 +298,10 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
     const long long tiles = (long long)((wx + block.x - 1) / block.x) * ((g.Ny + block.y - 1) / block.y);
     while (KZ > 1 && tiles * ((g.Nz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;  // narrow ranges: keep the chip full
     const dim3 nb = ocn::range_grid(block, wx, g.Ny, (g.Nz + KZ - 1) / KZ);
-    hipLaunchKernelGGL(amd_fused_kernel, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
+    if (grid->tx == OCN_BOUNDED || grid->ty == OCN_BOUNDED)  // per-field parent layouts
+        hipLaunchKernelGGL(amd_fused_kernel<true>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
+    else
+        hipLaunchKernelGGL(amd_fused_kernel<false>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

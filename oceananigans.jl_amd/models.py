@@ -191,8 +191,8 @@ class NonhydrostaticModel:
         self.fuse_stage_boundaries = xy_periodic and ((not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
                                                                                    and os.environ.get("OCN_FUSE_GENERAL", "1") != "0"))
         if not xy_periodic:
-            if isinstance(closure, AnisotropicMinimumDissipation):
-                raise NotImplementedError("AnisotropicMinimumDissipation needs Periodic x and y in this backend")
+            if isinstance(closure, AnisotropicMinimumDissipation) and Flat in grid.topology[:2]:
+                raise NotImplementedError("AnisotropicMinimumDissipation needs non-Flat x and y in this backend")
             if hasattr(grid.architecture, "partition"):
                 raise NotImplementedError("a partitioned x needs Periodic y")
         self._alt_velocities = None

@@ -430,3 +430,69 @@ def test_stratified_channel_with_separate_hydrostatic_pressure_matches_oracle(or
     for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "b")):
         assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-11 * max(scale, 1.0), name
     np.testing.assert_allclose(og.interior(from_dev(pm.pHY)), og.interior(om.pHY), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((9, 12, 8), "BPP"), ((34, 17, 20), "BBB")])
+def test_amd_diffusivities_on_closed_grids_bitwise(oracle, ocn, size, topo):
+    """_compute_AMD_viscosity! / _compute_AMD_diffusivity! (anisotropic_minimum_dissipation.jl:125-169) on grids with a Bounded x / y: every
+    staggered field has its own parent shape (the z-marching register-carrying kernel with per-field strides) -- νₑ, κₑ and the variable-ν /
+    variable-κ flux divergences bit for bit against the oracle"""
+    O = oracle
+    rng = np.random.default_rng(34)
+    og, pg = _pair(O, ocn, size, topo)
+    u, v, w, c = _filled(O, og, rng)
+    nu, ka = og.zeros(0), og.zeros(0)
+    O.amd_viscosity(og, 1 / 12, u, v, w, nu)
+    O.amd_diffusivity(og, 1 / 7, u, v, w, c, ka)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
+    dnu, dka = ocn.Field(0, pg), ocn.Field(0, pg)
+    Ck = (C.c_double * 1)(1 / 7)
+    ocn._lib.call("ocn_compute_amd_diffusivities", pg.cref, 1 / 12, du.ptr, dv.ptr, dw.ptr, dnu.ptr, 1, Ck, ocn._lib.ptr_array([dc.ptr]),
+                  ocn._lib.ptr_array([dka.ptr]), 0)
+    ocn.sync_device()
+    np.testing.assert_array_equal(from_dev(dnu), nu, err_msg=f"{topo} nu_e")
+    np.testing.assert_array_equal(from_dev(dka), ka, err_msg=f"{topo} kappa_e")
+    assert og.interior_N(nu).max() > 0 and og.interior_N(ka).max() > 0
+    for a, l in ((nu, 0), (ka, 0)):
+        O.fill_halo_regions(og, a, l)
+    G = [og.zeros(l) for l in LOCS] + [og.zeros(0)]
+    O.momentum_tendencies(og, u, v, w, *G[:3])
+    O.momentum_extra_tendencies(og, O.Physics(nu=0.0), u, v, w, None, None, None, *G[:3], nu_e=nu)
+    O.tracer_tendency(og, u, v, w, c, G[3])
+    O.tracer_diffusion(og, 0.0, c, G[3], kappa_e=ka)
+    ocn.fill_halo_regions((dnu, dka))
+    t = ocn._lib.CModelTerms()
+    t.advection, t.closure, t.nu_e = ocn._lib.ADVECTION_WENO5, 2, dnu.ptr
+    dG = [ocn.Field(l, pg) for l in LOCS + (0,)]
+    ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0, dka.ptr, du.ptr, dv.ptr, dw.ptr, dc.ptr, dG[3].ptr, None, 0)
+    ocn.sync_device()
+    for a, b, name in zip(G, dG, ("Gu", "Gv", "Gw", "Gc")):
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} {name}")
+
+
+def test_les_channel_with_amd_matches_oracle(oracle, ocn):
+    """A (Periodic, Bounded, Bounded) channel with AnisotropicMinimumDissipation, a buoyancy tracer with its pHY' and an f-plane: 3 RK3
+    steps against the oracle's model (the eddy diffusivities are ratios of small numbers: 1e-10 on the fields)"""
+    O = oracle
+    og, pg = _pair(O, ocn, (16, 12, 10), "PBB")
+    rng = np.random.default_rng(35)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    om = O.NonhydrostaticModel(og, tracers=("b",), coriolis_f=0.3, closure=("AMD",), buoyancy="BuoyancyTracer")
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("b",), coriolis=ocn.FPlane(f=0.3), closure=ocn.AnisotropicMinimumDissipation(),
+                                 buoyancy=ocn.BuoyancyTracer())
+    init = {n: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for n, l in zip("uvw", LOCS)}
+    init["b"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
+    om.set(**init)
+    ocn.set(pm, **init)
+    for _ in range(3):
+        om.time_step(2e-3)
+        ocn.time_step(pm, 2e-3)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    scale = max(np.abs(a).max() for a in (om.u, om.v, om.w))
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "b")):
+        assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-10 * max(scale, 1.0), name
+    assert np.abs(om.nu_e).max() > 0
+    assert np.abs(from_dev(pm.diffusivity_fields["nu_e"]) - om.nu_e).max() <= 1e-6 * np.abs(om.nu_e).max()
