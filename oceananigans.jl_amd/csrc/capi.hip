@@ -228,7 +228,7 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
 int ocn_cell_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *result_device,
                                  void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && result_device, "ocn_cell_advection_timescale: null pointer");
     return launch_advection_timescale(grid, u, v, w, result_device, as_stream(stream));

@@ -1139,13 +1139,15 @@ int launch_free_surface_ab2(const ocn_grid *grid, const double *w, double *eta, 
 __global__ __launch_bounds__(256) void advection_timescale_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                                   const double *__restrict__ w, unsigned long long *__restrict__ out)
 {
-    const Lay L = make_lay(g, OCN_LOC_CCC);  // x, y Periodic: u, v, w share strides and offset
+    // every field through its own parent layout (a Face field has one more point along a Bounded direction); a Flat direction
+    // contributes 0 (_inverse_timescale(..., ::Flat) = 0, cell_advection_timescale.jl:21)
+    const Lay Lu = make_lay(g, OCN_LOC_FCC), Lv = make_lay(g, OCN_LOC_CFC), Lw = make_lay(g, OCN_LOC_CCF);
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
     double tau = __longlong_as_double(0x7FF0000000000000LL);
     if (i <= g.Nx && j <= g.Ny) {
-        const long long o = at(L, i, j, k);
-        const double ix = fabs(u[o]) / g.dx, iy = fabs(v[o]) / g.dy;
-        const double iz = (g.tz == OCN_FLAT) ? 0.0 : fabs(w[o]) / (g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz);
+        const double ix = (g.tx == OCN_FLAT) ? 0.0 : fabs(u[at(Lu, i, j, k)]) / g.dx;
+        const double iy = (g.ty == OCN_FLAT) ? 0.0 : fabs(v[at(Lv, i, j, k)]) / g.dy;
+        const double iz = (g.tz == OCN_FLAT) ? 0.0 : fabs(w[at(Lw, i, j, k)]) / (g.dzf ? uniform_load(g.dzf, k + g.Hz - 1) : g.dz);
         const double t = 1 / ((ix + iy) + iz);
         if (t == t) tau = t;
     }

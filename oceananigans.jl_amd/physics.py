@@ -123,7 +123,7 @@ class ScalarDiffusivity:
             raise NotImplementedError("VerticallyImplicitTimeDiscretization is not implemented")
         if formulation != "ThreeDimensional":
             raise NotImplementedError("only the ThreeDimensionalFormulation (isotropic) is implemented")
-        if callable(nu) or callable(kappa) or hasattr(nu, "shape"):
+        if callable(nu) or callable(kappa) or np.ndim(nu) > 0:  # (numpy scalars are numbers)
             raise NotImplementedError("only constant ν, κ are implemented")
         self.nu = float(nu)
         self.kappa = kappa
@@ -206,7 +206,7 @@ class BoundaryCondition:
 
     def __init__(self, kind, condition=0.0, coeff=0.0, parameters=None):
         """condition: a number, an (Nx, Ny) array, or a function f(x, y, t) [f(x, y, t, parameters) with `parameters`] of the two
-        coordinates tangential to a bottom / top boundary and time -- the reference's ContinuousBoundaryFunction without field
+        coordinates tangential to a bottom / top boundary (without those of Flat directions: f(x, t) on an x-z slice) and time -- the reference's ContinuousBoundaryFunction without field
         dependencies (continuous_boundary_function.jl:17-115).  The function is evaluated on the host at the field's own nodes (called
         once with broadcastable arrays) every time the model state is updated, with the clock time of that moment, and uploaded into
         the (Nx, Ny) device array the kernels read."""
@@ -229,9 +229,12 @@ class BoundaryCondition:
             return
         x, y, _ = grid.nodes(loc)
         x, y = x[:grid.Nx].reshape(-1, 1), y[:, :grid.Ny].reshape(1, -1)
-        args = (x, y, float(time)) if self.parameters is None else (x, y, float(time), self.parameters)
+        # the coordinates of Flat directions are not arguments (continuous_boundary_function.jl: a top condition on a
+        # (Bounded, Flat, Bounded) grid is f(x, t[, p]), examples/horizontal_convection.jl:47)
+        coords = tuple(c for c, t in zip((x, y), grid.topology[:2]) if t != "Flat")
+        args = coords + (float(time),) if self.parameters is None else coords + (float(time), self.parameters)
         vals = np.broadcast_to(np.asarray(self.func(*args), dtype=np.float64), (grid.Nx, grid.Ny))
-        self.values = np.ascontiguousarray(vals.T)
+        self.values = np.array(vals.T, dtype=np.float64, order="C")  # (a copy: broadcast views are read-only)
         if self._device_values is None:
             self._device_values = on_architecture(grid.architecture, self.values)
         else:

@@ -496,3 +496,53 @@ def test_les_channel_with_amd_matches_oracle(oracle, ocn):
         assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-10 * max(scale, 1.0), name
     assert np.abs(om.nu_e).max() > 0
     assert np.abs(from_dev(pm.diffusivity_fields["nu_e"]) - om.nu_e).max() <= 1e-6 * np.abs(om.nu_e).max()
+
+
+def test_horizontal_convection_example_setup_matches_oracle(oracle, ocn):
+    """examples/horizontal_convection.jl:23-88 at a reduced size: (Bounded, Flat, Bounded), WENO, RK3, BuoyancyTracer with its pHY',
+    ScalarDiffusivity and the surface Value condition b = -cos(2π x / Lx) given as a FUNCTION f(x, t, p) (no y argument on a Flat y):
+    5 steps against the oracle's model with the same values as an array, 1e-11; u, w impenetrable, v identically 0"""
+    O = oracle
+    Nx, Nz, Lx = 32, 16, 2.0
+    og = O.Grid((Nx, 1, Nz), x=(-1, 1), y=(0, 1), z=(-1, 0), topology="BFB", halo=(3, 3, 3))
+    pg = ocn.RectilinearGrid(ocn.GPU(), size=(Nx, Nz), x=(-1, 1), z=(-1, 0), topology=("Bounded", "Flat", "Bounded"))
+    nu = np.sqrt(1.0 * Lx ** 3 / 1e5)
+    xc = og.nodes(0, False)
+    vals = (-np.cos(2 * np.pi * xc / Lx)).reshape(Nx, 1)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    om = O.NonhydrostaticModel(og, tracers=("b",), closure=(nu, {"b": nu}), buoyancy="BuoyancyTracer",
+                               boundary_conditions={"b": {"top": O.ValueBoundaryCondition(vals)}})
+    surface = lambda x, t, p: -p["bstar"] * np.cos(2 * np.pi * x / p["Lx"])
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("b",), buoyancy=ocn.BuoyancyTracer(), closure=ocn.ScalarDiffusivity(ν=nu, κ=nu),
+                                 boundary_conditions={"b": ocn.FieldBoundaryConditions(top=ocn.ValueBoundaryCondition(surface, parameters=dict(bstar=1.0, Lx=Lx)))})
+    rng = np.random.default_rng(36)
+    init = {"u": 1e-2 * rng.uniform(-1, 1, og.interior(og.zeros(1)).shape), "w": 1e-2 * rng.uniform(-1, 1, og.interior(og.zeros(4)).shape),
+            "b": 1e-2 * rng.uniform(-1, 1, (Nx, 1, Nz))}
+    om.set(**init)
+    ocn.set(pm, **init)
+    for _ in range(5):
+        om.time_step(1e-2)
+        ocn.time_step(pm, 1e-2)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    scale = max(np.abs(a).max() for a in (om.u, om.w))
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "b")):
+        assert np.abs(og.interior(from_dev(f)) - og.interior(a)).max() <= 1e-11 * max(scale, 1.0), name
+    assert np.all(from_dev(pm.v) == 0.0)
+    # the surface value enters through the first halo cell: b[0.5 (Nz, Nz + 1)] = the condition
+    b = from_dev(pm.tracers[0])
+    top = 0.5 * (b[pg.Hx:pg.Hx + Nx, 0, pg.Hz + Nz - 1] + b[pg.Hx:pg.Hx + Nx, 0, pg.Hz + Nz])
+    np.testing.assert_allclose(top, vals[:, 0], rtol=0, atol=1e-14)
+    assert 0 < ocn.AdvectiveCFL(1e-2)(pm) < 1
+
+
+def test_horizontal_convection_example_runs(ocn):
+    """the example script itself, 60 iterations at 64 x 32: finite, |b| within its surface values, the wizard raises Δt from rest"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "horizontal_convection.py"), "--nx", "64", "--nz", "32", "--max-iterations", "60",
+                        "--Ra", "1e6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Iter:     50" in r.stdout and "Nu =" in r.stdout
