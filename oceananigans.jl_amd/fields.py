@@ -63,7 +63,7 @@ class Field:
             except (TypeError, ValueError):
                 a = np.vectorize(value, otypes=[np.float64])(x, y, z)
             a = np.broadcast_to(a, tuple(reversed(iv.shape)))
-            iv.copy_(on_architecture(self.grid.architecture, np.ascontiguousarray(a.T)))
+            iv.copy_(on_architecture(self.grid.architecture, np.array(a.T, dtype=np.float64, order="C")))  # (a copy: broadcast views are read-only)
         else:
             if isinstance(value, torch.Tensor):
                 t = value.to(self.data.device, dtype=torch.float64)

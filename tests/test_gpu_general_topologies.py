@@ -546,3 +546,38 @@ def test_horizontal_convection_example_runs(ocn):
                         "--Ra", "1e6"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Iter:     50" in r.stdout and "Nu =" in r.stdout
+
+
+def test_one_dimensional_diffusion_example(oracle, ocn):
+    """examples/one_dimensional_diffusion.jl:21-60: RectilinearGrid(size = 128, z = (-0.5, 0.5), topology = (Flat, Flat, Bounded)),
+    ScalarDiffusivity(κ = 1), tracer T = exp(-z² / 2 width²), Δt = 0.1 Δz² / κ, the reference's default Centered advection and RK3:
+    1000 iterations.  Bit-identical to the oracle's model on the same grid; the Gaussian spreads as σ² = width² + 2 κ t (second-order
+    accurate: 1e-3 of the peak, with the image sources of the two walls); the column integral is conserved by the no-flux walls."""
+    O = oracle
+    N, width = 128, 0.1
+    og = O.Grid((1, 1, N), x=(0, 1), y=(0, 1), z=(-0.5, 0.5), topology="FFB", halo=(3, 3, 3))
+    pg = ocn.RectilinearGrid(ocn.GPU(), size=N, z=(-0.5, 0.5), topology=("Flat", "Flat", "Bounded"))
+    assert (pg.Nx, pg.Ny, pg.Nz) == (1, 1, N)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    om = O.NonhydrostaticModel(og, tracers=("T",), advection="Centered2", closure=(0.0, {"T": 1.0}))
+    pm = ocn.NonhydrostaticModel(pg, closure=ocn.ScalarDiffusivity(κ=1), tracers="T")
+    zc = og.nodes(2, False)
+    T0 = np.exp(-zc ** 2 / (2 * width ** 2)).reshape(1, 1, N)
+    om.set(T=T0)
+    ocn.set(pm, T=lambda x, y, z: np.exp(-z ** 2 / (2 * width ** 2)))
+    dt = 0.1 * pg.dz ** 2 / 1.0
+    for _ in range(1000):
+        om.time_step(dt)
+        ocn.time_step(pm, dt)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    T = pm.tracers[0].interior()[0, 0, :]
+    np.testing.assert_array_equal(T, og.interior(om.tracers[0])[0, 0, :])
+    t = 1000 * dt
+    s2 = width ** 2 + 2 * t
+    gauss = lambda z: np.sqrt(width ** 2 / s2) * np.exp(-z ** 2 / (2 * s2))
+    exact = gauss(zc) + gauss(-1 - zc) + gauss(1 - zc)   # the no-flux walls at z = -0.5, 0.5: first image sources
+    assert np.abs(T - exact).max() < 1e-3
+    assert abs(T.sum() - T0.sum()) < 1e-12 * T0.sum()
+    for f in pm.velocities:
+        assert np.all(f.interior() == 0.0)
