@@ -60,8 +60,7 @@ while model.clock.time < a.stop_time and not (a.max_iterations and model.clock.i
     if model.clock.iteration % 50 == 0:
         dt = wizard(model, dt)
         print("Iter: %6d, sim time: %1.3f, wall time: %8.2f s, dt: %1.4f, advective CFL: %.2e, diffusive CFL: %.2e" % (
-            model.clock.iteration, model.clock.time, time.perf_counter() - t0, dt, cfl(dt)(model),
-            dt * kappa / min(grid.dx, grid.dz) ** 2 * 2), flush=True)
+            model.clock.iteration, model.clock.time, time.perf_counter() - t0, dt, cfl(dt)(model), ocn.DiffusiveCFL(dt)(model)), flush=True)
     ocn.time_step(model, min(dt, a.stop_time - model.clock.time))
 ocn.flush_tendencies(model)
 ocn.sync_device()

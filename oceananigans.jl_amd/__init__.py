@@ -19,7 +19,7 @@ from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, Runge
                      compute_tendencies, flush_tendencies, RK3Driver, ModelRK3Driver,
                      pressure_correct_velocities, rk3_substep, set, solve_for_pressure, time_step, update_hydrostatic_pressure,
                      update_state)
-from .output import (AdvectiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, hasnan, set_from_checkpoint,
+from .output import (AdvectiveCFL, DiffusiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, cell_diffusion_timescale, hasnan, set_from_checkpoint,
                      write_checkpoint)
 from .physics import (AnisotropicMinimumDissipation, BetaPlane, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
                       GradientBoundaryCondition, LinearEquationOfState, ScalarDiffusivity, SeawaterBuoyancy,

@@ -60,6 +60,35 @@ def cell_advection_timescale(model):
     return float(out.item())
 
 
+def cell_diffusion_timescale(model):
+    """cell_diffusion_timescale(model) (src/TurbulenceClosures/turbulence_closure_diagnostics.jl:20-74): min(Δ² / max ν, Δ² / max κ) with
+    Δ = the smallest cell spacing (1 along Flat directions); ScalarDiffusivity: the numbers ν, κ; AnisotropicMinimumDissipation: the maxima
+    of the eddy-diffusivity fields' parents.  Inf without a closure."""
+    from .physics import AnisotropicMinimumDissipation
+    g, cl = model.grid, model.closure
+    if cl is None:
+        return float("inf")
+    delta = min(g.spacing_extrema(d)[0] if g.topology[d] != "Flat" else 1.0 for d in range(3))
+    div = lambda a, b: a / b if b != 0 else float("inf")
+    if isinstance(cl, AnisotropicMinimumDissipation):
+        d = model.diffusivity_fields
+        max_nu = float(d["nu_e"].data.max())
+        max_kappa = max((float(k.data.max()) for k in d["kappa_e"]), default=float("inf"))
+        return min(div(delta ** 2, max_nu), div(delta ** 2, max_kappa))
+    max_kappa = max((cl.kappa_of(n) for n in model.tracer_names), default=0.0)
+    return min(div(delta ** 2, cl.nu), div(delta ** 2, max_kappa))
+
+
+class DiffusiveCFL:
+    """DiffusiveCFL(Δt)(model) = Δt / cell_diffusion_timescale(model) (src/Diagnostics/cfl.jl)"""
+
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __call__(self, model):
+        return self.dt / cell_diffusion_timescale(model)
+
+
 class AdvectiveCFL:
     """AdvectiveCFL(Δt)(model) = Δt / cell_advection_timescale(model) (src/Diagnostics/cfl.jl)"""
 

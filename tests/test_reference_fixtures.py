@@ -316,3 +316,16 @@ def test_beta_plane_constructor_known_answers():
     earth = ocn.BetaPlane(latitude=45)
     assert earth.f0 == 2 * 7.292115e-5 * physics.sind(45) and earth.beta == 2 * 7.292115e-5 * physics.cosd(45) / 6371.0e3
 
+
+
+def test_diffusive_cfl_doctest():
+    """src/Diagnostics/cfl.jl:66-77: DiffusiveCFL(0.1)(model) == 0.256 for ScalarDiffusivity(ν = 1e-2) on a 16^3 grid of extent 1
+    (cell_diffusion_timescale = min(Δ² / ν, Δ² / max κ) with no tracers: turbulence_closure_diagnostics.jl:20-47) -- host logic only"""
+    from types import SimpleNamespace
+    import oceananigans_jl_amd as ocn
+    g = ocn.RectilinearGrid(None, size=(16, 16, 16), extent=(1, 1, 1))
+    model = SimpleNamespace(grid=g, closure=ocn.ScalarDiffusivity(ν=1e-2), tracer_names=(), diffusivity_fields=None)
+    assert ocn.DiffusiveCFL(0.1)(model) == 0.256
+    assert ocn.cell_diffusion_timescale(SimpleNamespace(grid=g, closure=None, tracer_names=(), diffusivity_fields=None)) == float("inf")
+    model = SimpleNamespace(grid=g, closure=ocn.ScalarDiffusivity(ν=1e-2, κ={"T": 4e-2, "S": 1e-3}), tracer_names=("T", "S"), diffusivity_fields=None)
+    assert ocn.cell_diffusion_timescale(model) == (1 / 16) ** 2 / 4e-2
