@@ -215,6 +215,13 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
 
     if (MODE == 1 || MODE == 2) {
         fft_inv_stages<N, CB>(x, A, W, c, t);
+        if (MODE == 1 && a.scale != 1.0) {  // normalised inverse (the general solver's line transforms: 1 / N)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x[r].x *= a.scale;
+                x[r].y *= a.scale;
+            }
+        }
         if (active) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) base[(long long)(t + T * r) * a.col_stride] = x[r];

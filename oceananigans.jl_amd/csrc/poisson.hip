@@ -153,6 +153,12 @@ struct ocn_poisson {
     // index_permutations.jl:38-90, discrete_transforms.jl:141-176): O(N log N) per line
     Plan gfwd[3], gbwd[3];
     double *gtw[3] = {nullptr, nullptr, nullptr};  // w_k = exp(-i π k / 2N), k < N, of the Bounded dimensions
+    // strided lines (y, z) of the supported lengths go through the column FFT kernels (csrc/colfft.hip: ONE launch per pass; rocFFT's
+    // strided plan needs one launch per z plane for the y lines): their spectra are then in STAGE order along that direction --
+    // eigenvalues and twiddles are stored permuted, gpartner[d][p] = stored position of wavenumber N - k(p) for the cosine transforms
+    bool gcol[3] = {false, false, false};
+    double *gcoltw[3] = {nullptr, nullptr, nullptr};
+    int *gpartner[3] = {nullptr, nullptr, nullptr};
     bool fft_dct = false;
 };
 
@@ -165,6 +171,10 @@ static void free_all(ocn_poisson *s)
         s->gbwd[d].destroy();
         if (s->gtw[d]) (void)hipFree(s->gtw[d]);
         s->gtw[d] = nullptr;
+        if (s->gcoltw[d]) (void)hipFree(s->gcoltw[d]);
+        s->gcoltw[d] = nullptr;
+        if (s->gpartner[d]) (void)hipFree(s->gpartner[d]);
+        s->gpartner[d] = nullptr;
     }
     double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage,
                        &s->tab[0][0], &s->tab[0][1], &s->tab[1][0], &s->tab[1][1], &s->tab[2][0], &s->tab[2][1]};
@@ -238,8 +248,11 @@ __global__ __launch_bounds__(256) void naive_transform_kernel(int Nx, int Ny, in
 //     X[k] = Re(w_k (V[k] + conj V[N-k]))  +  i Im(w_k (V[k] - conj V[N-k])).
 // REDFT01 / 2N (the inverse):  V[k] = (1/2) conj(w_k) (X[k] - i X[N-k]),  X[N] := 0;  v = IFFT_N(V) / N;  x[2n] = v[n], x[2n+1] = v[N-1-n].
 // mode 0: gather (x -> v), 1: forward post-twiddle (V -> X), 2: inverse pre-twiddle (X -> V), 3: scatter (v -> x); out of place.
+// partner != NULL: the spectrum along `dim` is in the column kernels' stage order (position p holds wavenumber k(p)): w[p] = w_k(p),
+// partner[p] = position of wavenumber N - k(p) (position 0 is wavenumber 0 in either order).
 __global__ __launch_bounds__(256) void dct_shuffle_kernel(int Nx, int Ny, int Nz, int dim, int mode, const double2 *__restrict__ in,
-                                                          double2 *__restrict__ out, const double2 *__restrict__ w)
+                                                          double2 *__restrict__ out, const double2 *__restrict__ w,
+                                                          const int *__restrict__ partner)
 {
     const long long n = (long long)Nx * Ny * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -253,13 +266,14 @@ __global__ __launch_bounds__(256) void dct_shuffle_kernel(int Nx, int Ny, int Nz
     } else if (mode == 3) {  // x[q]
         out[t] = (q & 1) ? line[(long long)(N - 1 - (q - 1) / 2) * stride] : line[(long long)(q / 2) * stride];
     } else if (mode == 1) {
-        const double2 a = line[(long long)q * stride], b = line[(long long)((N - q) % N) * stride], wk = w[q];
+        const int qp = partner ? partner[q] : (N - q) % N;
+        const double2 a = line[(long long)q * stride], b = line[(long long)qp * stride], wk = w[q];
         const double sr = a.x + b.x, si = a.y - b.y;  // V[k] + conj V[N-k]
         const double dr = a.x - b.x, di = a.y + b.y;  // V[k] - conj V[N-k]
         out[t] = make_double2(wk.x * sr - wk.y * si, wk.x * di + wk.y * dr);
     } else {
         const double2 a = line[(long long)q * stride];
-        const double2 b = q == 0 ? make_double2(0.0, 0.0) : line[(long long)(N - q) * stride];
+        const double2 b = q == 0 ? make_double2(0.0, 0.0) : line[(long long)(partner ? partner[q] : N - q) * stride];
         const double2 wk = w[q];
         const double zr = a.x + b.y, zi = a.y - b.x;  // X[k] - i X[N-k]
         out[t] = make_double2(0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr));  // (1/2) conj(w_k) z
@@ -283,6 +297,13 @@ static int make_line_plans(ocn_poisson *s, int d, const int N[3])
 
 static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const int N[3], hipStream_t stream)
 {
+    if (s->gcol[d]) {  // one launch of the column kernel; forward: natural -> stage order, inverse: stage order -> natural, scaled 1 / N
+        const long long plane = (long long)N[0] * N[1];
+        if (d == 1) return ocn::launch_colfft(N[1], inverse ? 1 : 0, a, N[0], plane, N[0], N[2], s->gcoltw[d], nullptr, nullptr, nullptr,
+                                              inverse ? 1.0 / N[1] : 1.0, 1, stream);
+        return ocn::launch_colfft(N[2], inverse ? 1 : 0, a, plane, 0, (int)plane, 1, s->gcoltw[d], nullptr, nullptr, nullptr,
+                                  inverse ? 1.0 / N[2] : 1.0, 1, stream);
+    }
     Plan &P = inverse ? s->gbwd[d] : s->gfwd[d];
     if (d != 1) return P.exec(a, nullptr, stream);
     for (int k = 0; k < N[2]; ++k) {
@@ -333,17 +354,45 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         s->fft_dct = !(nv && nv[0] == '1');
         if (s->fft_dct && st == OCN_SUCCESS) {
             ensure_rocfft();
+            const char *gc = std::getenv("OCN_POISSON_GENERAL_COLFFT");
             for (int d = 0; d < 3 && st == OCN_SUCCESS; ++d) {
                 if (topo[d] == OCN_FLAT) continue;
-                st = make_line_plans(s, d, N);
+                s->gcol[d] = d > 0 && ocn::colfft_supported(N[d]) && !(gc && gc[0] == '0');
+                std::vector<int> kofp(N[d]), pofk(N[d]);
+                for (int p = 0; p < N[d]; ++p) {
+                    kofp[p] = s->gcol[d] ? ocn::colfft_wavenumber(N[d], p) : p;
+                    pofk[kofp[p]] = p;
+                }
+                if (s->gcol[d]) {
+                    st = upload(ocn::colfft_twiddles(N[d]), &s->gcoltw[d]);
+                    if (st != OCN_SUCCESS) break;
+                    // eigenvalues in stored order
+                    std::vector<double> ln = eigenvalues(N[d], Ls[d], topo[d]), lp(N[d]);
+                    for (int p = 0; p < N[d]; ++p) lp[p] = ln[kofp[p]];
+                    (void)hipFree(*lam[d]);
+                    *lam[d] = nullptr;
+                    st = upload(lp, lam[d]);
+                    if (st != OCN_SUCCESS) break;
+                } else {
+                    st = make_line_plans(s, d, N);
+                }
                 if (st != OCN_SUCCESS || topo[d] != OCN_BOUNDED) continue;
                 std::vector<double> w(2 * (size_t)N[d]);
-                for (int k = 0; k < N[d]; ++k) {
-                    const long double a = 3.14159265358979323846264338327950288L * k / (2.0L * N[d]);
-                    w[2 * k] = (double)cosl(a);
-                    w[2 * k + 1] = (double)(-sinl(a));
+                for (int p = 0; p < N[d]; ++p) {
+                    const long double a = 3.14159265358979323846264338327950288L * kofp[p] / (2.0L * N[d]);
+                    w[2 * p] = (double)cosl(a);
+                    w[2 * p + 1] = (double)(-sinl(a));
                 }
                 st = upload(w, &s->gtw[d]);
+                if (st == OCN_SUCCESS && s->gcol[d]) {
+                    std::vector<int> partner(N[d]);
+                    for (int p = 0; p < N[d]; ++p) partner[p] = pofk[(N[d] - kofp[p]) % N[d]];
+                    if (hipMalloc((void **)&s->gpartner[d], N[d] * sizeof(int)) != hipSuccess ||
+                        hipMemcpy(s->gpartner[d], partner.data(), N[d] * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                        ocn::set_error("ocn_poisson_create: partner table upload failed");
+                        st = OCN_ERR_ALLOC;
+                    }
+                }
             }
         }
     }
@@ -375,7 +424,8 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     int pst = OCN_SUCCESS;
     auto shuffle = [&](int d, int mode) {
         hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, mode,
-                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[d]));
+                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[d]),
+                           (mode == 1 || mode == 2) ? s->gpartner[d] : nullptr);
         std::swap(a, b);
     };
     auto pass = [&](int d, int inverse) {

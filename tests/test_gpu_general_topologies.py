@@ -267,7 +267,9 @@ def test_scalar_diffusivity_budget(ocn, topo, fieldname):
     assert np.isfinite(final_mean) and abs(final_mean - init_mean) <= np.sqrt(np.finfo(float).eps) * max(abs(init_mean), abs(final_mean))
 
 
-@pytest.mark.parametrize("size,topo", [((7, 11, 16), "BBB"), ((16, 7, 11), "PBB"), ((32, 20, 12), "BPB"), ((9, 1, 14), "BFB"), ((64, 48, 40), "BBB")])
+@pytest.mark.parametrize("size,topo", [((7, 11, 16), "BBB"), ((16, 7, 11), "PBB"), ((32, 20, 12), "BPB"), ((9, 1, 14), "BFB"), ((64, 48, 40), "BBB"),
+                                       # y / z lengths the column FFT kernels take (64 ... 512): spectra in stage order, permuted eigenvalues / twiddles
+                                       ((16, 64, 128), "BBB"), ((24, 128, 64), "PBB"), ((8, 64, 64), "BPB"), ((12, 64, 256), "PPB"), ((128, 64, 64), "BBB")])
 def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, monkeypatch):
     """K11 (index_permutations.jl:38-90, discrete_transforms.jl:141-176): the cosine transforms of the general FFTBasedPoissonSolver built
     from complex FFTs of the same length (even / odd permutation + twiddle factors, Makhoul) against the direct O(N) sums of their
@@ -289,7 +291,7 @@ def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, monkeypa
     sols = []
     for naive in ("0", "1"):
         monkeypatch.setenv("OCN_POISSON_NAIVE_DCT", naive)
-        solver = ocn.FFTBasedPoissonSolver(g)
+        solver = ocn.FFTBasedPoissonSolver(g, general=True)  # (general: the cosine / Fourier line transforms also where x and y are Periodic)
         p = ocn.CenterField(g)
         ocn._lib.call("ocn_poisson_set_source_term", solver._h, Rd.data_ptr(), 0)
         solver.solve(p)
