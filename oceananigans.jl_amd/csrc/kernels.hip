@@ -1280,12 +1280,16 @@ __device__ __forceinline__ double div_ccc(const GridDev &g, const double *__rest
     return (1 / (Az * dzc)) * ((dxu + dyv) + dzw);
 }
 
+// position q of the permuted sequence v of a cosine transform <-> point s of the natural one: v[q] = x[2q] (q < ceil(N/2)), x[2(N-1-q)+1]
+// otherwise; its inverse, used both ways: s -> q when storing, q -> s ... of the INVERSE transform's scatter x[q] = v[dct_perm(q)]
+__device__ __forceinline__ int dct_perm(int q, int N) { return (q & 1) ? N - 1 - (q - 1) / 2 : q / 2; }
+
 // out_mode 0: real divergence; 1: complex rhs = div/dt (K8); 2: complex rhs = (dz*div)/dt (K9);
 //          3: real rhs = div/dt; 4: real rhs = (dz*div)/dt   (real-to-complex FFT path)
 template <int OUT>
 __global__ __launch_bounds__(256) void source_term_kernel(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                           const double *__restrict__ w, double dt, double *__restrict__ out,
-                                                          long long ld1, long long ld2)
+                                                          long long ld1, long long ld2, int perm_dim)
 {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -1293,7 +1297,11 @@ __global__ __launch_bounds__(256) void source_term_kernel(GridDev g, const doubl
     if (i > g.Nx || j > g.Ny) return;
     const Lay Lu = make_lay(g, OCN_LOC_FCC), Lv = make_lay(g, OCN_LOC_CFC), Lw = make_lay(g, OCN_LOC_CCF);
     const double d = div_ccc(g, u, v, w, Lu, Lv, Lw, i, j, k);
-    const long long o = (i - 1) + ld1 * (j - 1) + ld2 * (k - 1);
+    // perm_dim >= 0: the value of point s along that dimension is stored at the position the even / odd permutation of the FFT-based cosine
+    // transform reads it from (index_permutations.jl:38-90: the gather pass of the general solver folded into this store)
+    int c[3] = {i - 1, j - 1, k - 1};
+    if (perm_dim >= 0) c[perm_dim] = dct_perm(c[perm_dim], perm_dim == 0 ? g.Nx : perm_dim == 1 ? g.Ny : g.Nz);
+    const long long o = c[0] + ld1 * c[1] + ld2 * c[2];
     if (OUT == 0) {
         out[o] = d;
     } else if (OUT == 1 || OUT == 2) {
@@ -1305,17 +1313,17 @@ __global__ __launch_bounds__(256) void source_term_kernel(GridDev g, const doubl
 }
 
 int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
-                       double *out, long long ld1, long long ld2, hipStream_t stream)
+                       double *out, long long ld1, long long ld2, hipStream_t stream, int perm_dim)
 {
     GridDev g = to_dev(*grid);
     dim3 block(64, 4, 1);
     dim3 nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz);
     switch (out_mode) {
-        case 0: hipLaunchKernelGGL(source_term_kernel<0>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
-        case 1: hipLaunchKernelGGL(source_term_kernel<1>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
-        case 2: hipLaunchKernelGGL(source_term_kernel<2>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
-        case 3: hipLaunchKernelGGL(source_term_kernel<3>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
-        default: hipLaunchKernelGGL(source_term_kernel<4>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2); break;
+        case 0: hipLaunchKernelGGL(source_term_kernel<0>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2, perm_dim); break;
+        case 1: hipLaunchKernelGGL(source_term_kernel<1>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2, perm_dim); break;
+        case 2: hipLaunchKernelGGL(source_term_kernel<2>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2, perm_dim); break;
+        case 3: hipLaunchKernelGGL(source_term_kernel<3>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2, perm_dim); break;
+        default: hipLaunchKernelGGL(source_term_kernel<4>, nb, block, 0, stream, g, u, v, w, dt, out, ld1, ld2, perm_dim); break;
     }
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
@@ -1374,23 +1382,25 @@ int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const doubl
 
 // K13 copy_real_component! (fft_based_poisson_solver.jl:129-137); STRIDE = 2 reads the real part of a complex array
 template <int STRIDE>
-__global__ __launch_bounds__(256) void copy_real_kernel(GridDev g, const double *__restrict__ phi, double *__restrict__ p)
+__global__ __launch_bounds__(256) void copy_real_kernel(GridDev g, const double *__restrict__ phi, double *__restrict__ p, int perm_dim)
 {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny) return;
     const Lay L = make_lay(g, OCN_LOC_CCC);
-    p[at(L, i, j, k)] = phi[STRIDE * ((i - 1) + (long long)g.Nx * ((j - 1) + (long long)g.Ny * (k - 1)))];
+    int c[3] = {i - 1, j - 1, k - 1};  // perm_dim >= 0: the scatter pass of the last inverse cosine transform folded into this read
+    if (perm_dim >= 0) c[perm_dim] = dct_perm(c[perm_dim], perm_dim == 0 ? g.Nx : perm_dim == 1 ? g.Ny : g.Nz);
+    p[at(L, i, j, k)] = phi[STRIDE * (c[0] + (long long)g.Nx * (c[1] + (long long)g.Ny * c[2]))];
 }
-int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source)
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source, int perm_dim)
 {
     GridDev g = to_dev(*grid);
     dim3 nb((g.Nx + 63) / 64, (g.Ny + 3) / 4, g.Nz), block(64, 4);
     if (real_source)
-        hipLaunchKernelGGL(copy_real_kernel<1>, nb, block, 0, stream, g, phi, p);
+        hipLaunchKernelGGL(copy_real_kernel<1>, nb, block, 0, stream, g, phi, p, perm_dim);
     else
-        hipLaunchKernelGGL(copy_real_kernel<2>, nb, block, 0, stream, g, phi, p);
+        hipLaunchKernelGGL(copy_real_kernel<2>, nb, block, 0, stream, g, phi, p, perm_dim);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

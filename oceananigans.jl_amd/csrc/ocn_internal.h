@@ -38,7 +38,7 @@ int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
 int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream, const int32_t *irange = nullptr);
 int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);
 int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,
-                       double *out, long long ld1, long long ld2, hipStream_t stream);
+                       double *out, long long ld1, long long ld2, hipStream_t stream, int perm_dim = -1);
 int launch_set_source(int Nx, int Ny, int Nz, const double *R, const double *dzc, int Hz, double *out, int complex_out,
                       long long ld1, long long ld2, hipStream_t stream);
 int launch_spectral_solve(int nxh, int Ny, int Nz, const double *lx, const double *ly, const double *lz, double *b,
@@ -47,7 +47,7 @@ int launch_implicit_free_surface_rhs(const ocn_grid *grid, const double *u, cons
                                      double *Qu, double *Qv, double *rhs, hipStream_t stream);
 int launch_barotropic_pressure_correction(const ocn_grid *grid, double *u, double *v, const double *eta, double grav, double dt,
                                           hipStream_t stream);
-int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source);
+int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStream_t stream, int real_source, int perm_dim = -1);
 int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream);
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,

@@ -156,6 +156,7 @@ struct ocn_poisson {
     // strided lines (y, z) of the supported lengths go through the column FFT kernels (csrc/colfft.hip: ONE launch per pass; rocFFT's
     // strided plan needs one launch per z plane for the y lines): their spectra are then in STAGE order along that direction --
     // eigenvalues and twiddles are stored permuted, gpartner[d][p] = stored position of wavenumber N - k(p) for the cosine transforms
+    bool gathered = false;  // compute_source_term stored the source already permuted along the first cosine-transform dimension
     bool gcol[3] = {false, false, false};
     double *gcoltw[3] = {nullptr, nullptr, nullptr};
     int *gpartner[3] = {nullptr, nullptr, nullptr};
@@ -277,6 +278,39 @@ __global__ __launch_bounds__(256) void dct_shuffle_kernel(int Nx, int Ny, int Nz
         const double2 wk = w[q];
         const double zr = a.x + b.y, zi = a.y - b.x;  // X[k] - i X[N-k]
         out[t] = make_double2(0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr));  // (1/2) conj(w_k) z
+    }
+}
+
+// A twiddle pass along `dt` (mode mt = 1 forward post-twiddle, 2 inverse pre-twiddle) and a pure permutation along ANOTHER dimension
+// `dp` (mode mp = 0 gather, 3 scatter) in ONE pass: the permutation only relabels whole lines of the twiddle direction, so
+//   forward:  out = gather_dp(twiddle_dt(in)),   inverse:  out = pretwiddle_dt(scatter_dp(in))
+// both read `in` at the permuted position of the output point (and at its N - k partner along dt).
+__global__ __launch_bounds__(256) void dct_twiddle_permute_kernel(int Nx, int Ny, int Nz, int dt, int mt, int dp, int mp,
+                                                                  const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                                  const double2 *__restrict__ w, const int *__restrict__ partner)
+{
+    const long long n = (long long)Nx * Ny * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int idx[3] = {(int)(t % Nx), (int)((t / Nx) % Ny), (int)(t / ((long long)Nx * Ny))};
+    const int Ns[3] = {Nx, Ny, Nz};
+    const long long strides[3] = {1, Nx, (long long)Nx * Ny};
+    // the permuted source position along dp
+    const int Np = Ns[dp], qp = idx[dp], half = (Np + 1) / 2;
+    const int sp = mp == 0 ? (qp < half ? 2 * qp : 2 * (Np - 1 - qp) + 1) : ((qp & 1) ? Np - 1 - (qp - 1) / 2 : qp / 2);
+    const long long src = t + (long long)(sp - qp) * strides[dp];
+    const int N = Ns[dt], q = idx[dt];
+    const long long st = strides[dt];
+    const double2 *line = in + (src - q * st);
+    const double2 a = line[(long long)q * st], wk = w[q];
+    if (mt == 1) {
+        const int qq = partner ? partner[q] : (N - q) % N;
+        const double2 b = line[(long long)qq * st];
+        const double sr = a.x + b.x, si = a.y - b.y, dr = a.x - b.x, di = a.y + b.y;
+        out[t] = make_double2(wk.x * sr - wk.y * si, wk.x * di + wk.y * dr);
+    } else {
+        const double2 b = q == 0 ? make_double2(0.0, 0.0) : line[(long long)(partner ? partner[q] : N - q) * st];
+        const double zr = a.x + b.y, zi = a.y - b.x;
+        out[t] = make_double2(0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr));
     }
 }
 
@@ -411,6 +445,12 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
     return OCN_SUCCESS;
 }
 
+static bool general_fuse_shuffles()
+{
+    static const bool fuse = !(std::getenv("OCN_POISSON_FUSE_SHUFFLES") && std::getenv("OCN_POISSON_FUSE_SHUFFLES")[0] == '0');
+    return fuse;
+}
+
 // forward transforms Bounded first, then Periodic (plan_transforms.jl:53-57, 129-140); backward in the opposite order
 static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
 {
@@ -428,33 +468,61 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
                            (mode == 1 || mode == 2) ? s->gpartner[d] : nullptr);
         std::swap(a, b);
     };
-    auto pass = [&](int d, int inverse) {
-        if (pst != OCN_SUCCESS) return;
-        if (!s->fft_dct) {
-            hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, topo[d], inverse,
-                               reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[d][0], s->tab[d][1]);
-            std::swap(a, b);
-        } else if (topo[d] == OCN_PERIODIC) {
-            pst = exec_line_plan(s, d, inverse, a, N, stream);
-        } else if (!inverse) {  // REDFT10: gather, FFT, twiddle
-            shuffle(d, 0);
-            pst = exec_line_plan(s, d, 0, a, N, stream);
-            shuffle(d, 1);
-        } else {                // REDFT01 / 2N: twiddle, inverse FFT (scaled 1 / N), scatter
-            shuffle(d, 2);
-            pst = exec_line_plan(s, d, 1, a, N, stream);
-            shuffle(d, 3);
+    auto shuffle2 = [&](int dt, int mt, int dp, int mp) {
+        hipLaunchKernelGGL(dct_twiddle_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], dt, mt, dp, mp,
+                           reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[dt]),
+                           s->gpartner[dt]);
+        std::swap(a, b);
+    };
+    // the passes as a list of operations (kind 0 gather, 1 post-twiddle, 2 pre-twiddle, 3 scatter, 4 line FFT forward, 5 inverse, 6 direct sums),
+    // then a twiddle followed by a permutation along another dimension (forward: 1 then 0; inverse: 3 then 2) runs as ONE pass
+    struct Op { int kind, d; };
+    const bool fuse = general_fuse_shuffles();
+    auto run = [&](const Op *ops, int nops) {
+        for (int q = 0; q < nops && pst == OCN_SUCCESS; ++q) {
+            const Op o = ops[q];
+            if (fuse && q + 1 < nops && o.d != ops[q + 1].d && ((o.kind == 1 && ops[q + 1].kind == 0) || (o.kind == 3 && ops[q + 1].kind == 2))) {
+                if (o.kind == 1) shuffle2(o.d, 1, ops[q + 1].d, 0);
+                else shuffle2(ops[q + 1].d, 2, o.d, 3);
+                ++q;
+            } else if (o.kind <= 3) {
+                shuffle(o.d, o.kind);
+            } else if (o.kind == 6 || o.kind == 7) {
+                hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], o.d, topo[o.d],
+                                   o.kind == 7, reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[o.d][0], s->tab[o.d][1]);
+                std::swap(a, b);
+            } else {
+                pst = exec_line_plan(s, o.d, o.kind == 5, a, N, stream);
+            }
         }
     };
-    for (int q = 0; q < no; ++q) pass(order[q], 0);
+    Op fwd[9], bwd[9];
+    int nf = 0, nb = 0;
+    for (int q = 0; q < no; ++q) {
+        const int d = order[q];
+        if (!s->fft_dct) fwd[nf++] = Op{6, d};
+        else if (topo[d] == OCN_PERIODIC) fwd[nf++] = Op{4, d};
+        else { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }  // REDFT10: gather, FFT, twiddle
+    }
+    for (int q = no - 1; q >= 0; --q) {
+        const int d = order[q];
+        if (!s->fft_dct) bwd[nb++] = Op{7, d};
+        else if (topo[d] == OCN_PERIODIC) bwd[nb++] = Op{5, d};
+        else { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }  // REDFT01 / 2N: twiddle, inverse FFT (scaled 1 / N), scatter
+    }
+    const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
+    s->gathered = false;
+    run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
     if (pst != OCN_SUCCESS) return pst;
     int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
     if (st != OCN_SUCCESS) return st;
-    for (int q = no - 1; q >= 0; --q) pass(order[q], 1);
+    // the scatter pass of the last inverse cosine transform is folded into the read of copy_real_component!
+    const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
+    run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
     if (pst != OCN_SUCCESS) return pst;
     OCN_CHECK_HIP(hipGetLastError());
     if (a != s->spec) std::swap(s->spec, s->spec2);  // the result lives in `a`; keep the handle's roles consistent
-    return ocn::launch_copy_real(g, s->spec, p, stream, 0);
+    return ocn::launch_copy_real(g, s->spec, p, stream, 0, last_scatter);
 }
 
 static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool force_c2c)
@@ -889,7 +957,14 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     int st;
     if (s->kind == 2) {
         // (divᶜᶜᶜ reads u, v, w through their own parent layouts and treats Flat directions: any topology)
-        st = ocn::launch_source_term(g, u, v, w, dt, 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        // the gather pass of the first cosine transform (the first Bounded dimension, transformed first: plan_transforms.jl:53-57) is
+        // folded into this store
+        int first = -1;
+        if (s->fft_dct && general_fuse_shuffles())
+            for (int d = 2; d >= 0; --d)
+                if ((d == 0 ? g->tx : d == 1 ? g->ty : g->tz) == OCN_BOUNDED) first = d;
+        st = ocn::launch_source_term(g, u, v, w, dt, 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
+        s->gathered = (st == OCN_SUCCESS) && first >= 0;
         s->source_set = (st == OCN_SUCCESS);
         return st;
     }
@@ -929,6 +1004,7 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
     }
     s->source_set = (st == OCN_SUCCESS);
     s->source_in_rhs = s->custom_xy;
+    s->gathered = false;  // natural order
     return st;
 }
 
