@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--dist-poisson", choices=("xtri", "alltoall"), default=None,
                     help="pressure solve of a partitioned run: xtri = transpose-free cyclic tridiagonal x solve + one all-gather (default), "
                          "alltoall = the slab FFT pipeline with two RCCL all-to-alls per solve (north_star's pencil transpose)")
+    ap.add_argument("--all-gather", choices=("direct", "collective"), default=None,
+                    help="the xtri solve's one exchange: direct = R - 1 grouped point-to-point transfers, one per xGMI link (default), "
+                         "collective = ncclAllGather")
     return ap.parse_args()
 
 
@@ -304,6 +307,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.dist_poisson is not None:
         os.environ["OCN_DIST_POISSON_XTRI"] = "1" if a.dist_poisson == "xtri" else "0"
+    if a.all_gather is not None:
+        os.environ["OCN_COMM_ALL_GATHER"] = a.all_gather
     # stdout carries exactly ONE line (the JSON of rank 0): RCCL and gloo print banners to the C-level stdout on initialisation, so
     # file descriptor 1 points at stderr until the result is ready
     sys.stdout.flush()
@@ -588,6 +593,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "grid": [Nx, Nx if hydro else N, Nz], "halo": 3, "math": a.math, "partition": f"x-slab/{world}",
                    "finite": finite, "rccl": comm_info, "dist_pressure_pipeline": pipeline,
+                   "all_gather": os.environ.get("OCN_COMM_ALL_GATHER", "direct") if world > 1 else None,
                    "state_checksum": {"sum_of_squares": checksum, "fields": "prognostic fields in model order, global interior",
                                       "after_steps": a.warmup + a.steps,
                                       "comparable_across_n_gpus": True}},

@@ -580,14 +580,16 @@ typedef void *ocn_comm_t;
 #define OCN_COMM_MAX_RANKS 64
 /* The point-to-point schedule a rank issues inside ONE RCCL group, as a pure host function (no device, no communicator): what
  * ocn_halo_exchange_begin / ocn_comm_exchange_strips (OCN_SCHED_STRIPS: slots 0 send_west, 1 send_east, 2 recv_west, 3 recv_east),
- * ocn_halo_exchange_plane (OCN_SCHED_PLANE_EAST / _WEST: slot 0 send, 1 recv) and ocn_comm_all_to_all (OCN_SCHED_ALL_TO_ALL: slot =
- * chunk index) execute, in issue order.  RCCL pairs the k-th send of rank a to rank b with the k-th receive of b from a; the test
+ * ocn_halo_exchange_plane (OCN_SCHED_PLANE_EAST / _WEST: slot 0 send, 1 recv), ocn_comm_all_to_all (OCN_SCHED_ALL_TO_ALL: slot =
+ * chunk index) and ocn_comm_all_gather (OCN_SCHED_ALL_GATHER: send slot 0 to every peer, receive slot s from rank s; the default
+ * on a node's fully connected xGMI links, OCN_COMM_ALL_GATHER=collective selects ncclAllGather) execute, in issue order.  RCCL pairs the k-th send of rank a to rank b with the k-th receive of b from a; the test
  * suite replays the schedules of all ranks for R = 1, 2, 3, 8 and checks every pairing (the MPI tags of
  * halo_communication.jl:100-150 do this job in the reference).  self_via_rccl: a rank's transfers to itself are sends too. */
 #define OCN_SCHED_STRIPS 0
 #define OCN_SCHED_PLANE_EAST 1
 #define OCN_SCHED_PLANE_WEST 2
 #define OCN_SCHED_ALL_TO_ALL 3
+#define OCN_SCHED_ALL_GATHER 4
 typedef struct ocn_comm_op {
     int32_t is_recv; /* 0 send, 1 receive */
     int32_t peer;    /* rank */

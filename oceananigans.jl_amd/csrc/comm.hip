@@ -273,6 +273,8 @@ int make_tuple(const ocn_grid *grid, double *const *fields, const int32_t *locs,
 //     (from east, from west) so that they pair up with that peer's (west, east) sends.
 //   kind OCN_SCHED_PLANE_EAST / _WEST: slot 0 send, 1 recv.  The plane I need from the east is my east neighbour's WEST interior plane.
 //   kind OCN_SCHED_ALL_TO_ALL: slot = chunk index d (send chunk d to rank d, receive chunk d from rank d).
+//   kind OCN_SCHED_ALL_GATHER: send slot 0 (my chunk) to every peer, receive slot s from rank s: the all-gather as R - 1 direct
+//     transfers, one per xGMI link, instead of a ring's R - 1 hops over one link each.
 int build_schedule(int kind, int rank, int nranks, bool self_via_rccl, ocn_comm_op *ops, int cap, int *n)
 {
     const int west = (rank + nranks - 1) % nranks, east = (rank + 1) % nranks;
@@ -301,6 +303,13 @@ int build_schedule(int kind, int rank, int nranks, bool self_via_rccl, ocn_comm_
             for (int d = 0; d < nranks; ++d) {
                 if (d == rank && !self_via_rccl) continue;  // own chunk: a device copy
                 push(0, d, d);
+                push(1, d, d);
+            }
+            break;
+        case OCN_SCHED_ALL_GATHER:
+            for (int d = 0; d < nranks; ++d) {
+                if (d == rank && !self_via_rccl) continue;  // own chunk: a device copy
+                push(0, d, 0);
                 push(1, d, d);
             }
             break;
@@ -670,16 +679,18 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
         OCN_CHECK_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return OCN_SUCCESS;
     }
-    if (c->local) {  // every rank's chunk to every rank (its own included), through the mailboxes
-        for (int d = 0; d < c->nranks; ++d) {
-            int st = local_send(c, send, count, d, s);
-            if (st != OCN_SUCCESS) return st;
-        }
-        for (int r = 0; r < c->nranks; ++r) {
-            int st = local_recv(c, recv + (size_t)r * count, count, r, s);
-            if (st != OCN_SUCCESS) return st;
-        }
-        return OCN_SUCCESS;
+    // the GPUs of one node are fully connected by point-to-point xGMI links: R - 1 direct transfers of my chunk, one per link and all
+    // at once, instead of the collective's ring (R - 1 hops, each bound by one link).  OCN_COMM_ALL_GATHER=collective selects
+    // ncclAllGather (the in-process transport has only the direct form).
+    static const bool collective = [] { const char *e = getenv("OCN_COMM_ALL_GATHER"); return e && !strcmp(e, "collective"); }();
+    if (c->local || !collective) {
+        OCN_REQUIRE(c->nranks <= OCN_COMM_MAX_RANKS, "ocn_comm_all_gather: at most %d ranks", OCN_COMM_MAX_RANKS);
+        if (!c->self_via_rccl)
+            OCN_CHECK_HIP(hipMemcpyAsync(recv + (size_t)c->rank * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+        const double *snd[1] = {send};
+        double *rcv[OCN_COMM_MAX_RANKS];
+        for (int d = 0; d < c->nranks; ++d) rcv[d] = recv + (size_t)d * count;
+        return run_schedule(c, OCN_SCHED_ALL_GATHER, snd, rcv, count, s);
     }
     OCN_CHECK_NCCL(ncclAllGather(send, recv, count, ncclDouble, c->comm, s));
     return OCN_SUCCESS;

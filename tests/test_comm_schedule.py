@@ -81,6 +81,16 @@ def test_all_to_all_delivers_chunk_d_to_rank_d(L, R, self_via_rccl):
     assert got == expect
 
 
+@pytest.mark.parametrize("R", [1, 2, 3, 8])
+@pytest.mark.parametrize("self_via_rccl", [False, True])
+def test_all_gather_delivers_every_chunk_to_every_rank(L, R, self_via_rccl):
+    """MPI.Allgather with equal counts as R - 1 direct transfers: rank s's one send buffer (slot 0) arrives as chunk s (slot s) of every
+    other rank (the xGMI links of a node are point-to-point: one transfer per link instead of the collective's ring)"""
+    got = deliver(L, L.SCHED_ALL_GATHER, R, self_via_rccl)
+    expect = {(d, s): (s, 0) for s in range(R) for d in range(R) if self_via_rccl or s != d}
+    assert got == expect
+
+
 def test_schedule_argument_validation(L):
     import oceananigans_jl_amd as ocn
     ops = (L.CCommOp * 4)()

@@ -860,3 +860,32 @@ def test_rccl_world1_hydrostatic_matches_single_rank(ocn, rccl_arch):
     ref, got = _hydro_state(sm), _hydro_state(m)
     for name in ref:
         np.testing.assert_array_equal(got[name], ref[name], err_msg=name)
+
+
+@pytest.mark.parametrize("mode", ["direct", "collective"])
+def test_all_gather_forms_through_rccl(mode):
+    """ocn_comm_all_gather's two forms through RCCL itself (world 1, the rank's transfer to itself issued as ncclSend / ncclRecv or as
+    ncclAllGather): OCN_COMM_ALL_GATHER is read once per process, so each form runs in a child process."""
+    import subprocess
+    import sys
+    code = r"""
+import os, socket, torch, torch.distributed as dist
+import oceananigans_jl_amd as ocn
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+dist.init_process_group("gloo", rank=0, world_size=1)
+arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+send = torch.arange(1000, dtype=torch.float64, device="cuda") + 0.5
+recv = torch.zeros_like(send)
+arch.fabric.all_gather(recv, send)
+torch.cuda.synchronize()
+assert torch.equal(recv, send)
+arch.fabric.close()
+print("ALL-GATHER-OK")
+"""
+    import os
+    env = dict(os.environ, OCN_COMM_SELF_VIA_RCCL="1", OCN_COMM_ALL_GATHER=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "ALL-GATHER-OK" in p.stdout, p.stderr[-2000:]
