@@ -133,24 +133,24 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double be1 = __builtin_fma((13.0 / 3.0) * D1, D1, E1 * E1);
     const double be2 = __builtin_fma((13.0 / 3.0) * D2, D2, E2 * E2);
     const double tau = fabs(be0 - be2);
-    // per-stencil reconstructions pre-multiplied by the optimal weights C_r (folded into the coefficients at compile time)
-    const double cp0 = ((OCN_C5_0 * OCN_W5P_00) * T2 + (OCN_C5_0 * OCN_W5P_01) * T3) + (OCN_C5_0 * OCN_W5P_02) * T4;
-    const double cp1 = ((OCN_C5_1 * OCN_W5P_10) * T1 + (OCN_C5_1 * OCN_W5P_11) * T2) + (OCN_C5_1 * OCN_W5P_12) * T3;
-    const double cp2 = ((OCN_C5_2 * OCN_W5P_20) * T0 + (OCN_C5_2 * OCN_W5P_21) * T1) + (OCN_C5_2 * OCN_W5P_22) * T2;
     // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = b_r + eps';
     // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2:
     //   m_r = (d_r^2 + tau^2) prod_{s != r} d_s^2,  result = sum (C_r p_r) m_r / sum C_r m_r.
     const double d0 = be0 + (OCN_WENO_EPS / 0.75), d1 = be1 + (OCN_WENO_EPS / 0.75), d2 = be2 + (OCN_WENO_EPS / 0.75);
     const double t2 = tau * tau;
     const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
-    // m_r = (e_r + t2) e_s e_t = e0 e1 e2 + t2 e_s e_t: 4 multiplies + 3 FMAs instead of 3 adds + 6 multiplies
+    // m_r = (e_r + t2) e_s e_t = e0 e1 e2 + t2 e_s e_t
     const double e12 = e1 * e2, e02 = e0 * e2, e01 = e0 * e1, e012 = e0 * e12;
     const double m0 = __builtin_fma(t2, e12, e012);
-    const double m1 = __builtin_fma(t2, e02, e012);
     const double m2 = __builtin_fma(t2, e01, e012);
-    const double num = __builtin_fma(cp2, m2, __builtin_fma(cp1, m1, cp0 * m0));
-    const double den = __builtin_fma(OCN_C5_2, m2, __builtin_fma(OCN_C5_1, m1, OCN_C5_0 * m0));
-    return num * fast_rcp1(den);
+    // sum C_r = 1: den = e0 e1 e2 + t2 (C0 e1 e2 + C1 e0 e2 + C2 e0 e1)
+    const double den = __builtin_fma(t2, __builtin_fma(OCN_C5_2, e01, __builtin_fma(OCN_C5_1, e02, OCN_C5_0 * e12)), e012);
+    // sum w_r p_r = p1 + w0 (p0 - p1) + w2 (p2 - p1), and the differences of the candidate reconstructions are differences of the
+    // second differences already at hand: p0 - p1 = (D1 - D0) / 6, p2 - p1 = (D2 - D1) / 3: the three 3-point candidates (9 operations)
+    // shrink to the centre one (3) plus 6 for the correction
+    const double p1 = (OCN_W5P_10 * T1 + OCN_W5P_11 * T2) + OCN_W5P_12 * T3;
+    const double num = __builtin_fma(OCN_C5_2 / 3.0, m2 * (D2 - D1), (OCN_C5_0 / 6.0) * (m0 * (D1 - D0)));
+    return __builtin_fma(num, fast_rcp1(den), p1);
 #endif
 }
 
