@@ -122,21 +122,23 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
 #else
     // The right-biased stencils are the left-biased ones of the mirrored data: select 5 inputs, then one code path.
     const double T0 = left ? S0 : S5, T1 = left ? S1 : S4, T2 = left ? S2 : S3, T3 = left ? S3 : S2, T4 = left ? S4 : S1;
+    // Everything below is built from the four first differences of the five inputs.
+    const double da = T1 - T0, db = T2 - T1, dc = T3 - T2, dd = T4 - T3;
     // smoothness indicators in difference form: the reference polynomial (coefficients 10,-31,11,25,-19,4 etc.) equals
-    // 13/4 D^2 + 3/4 E^2 with D the second difference and E the one-sided first difference of each sub-stencil.
-    const double D0 = __builtin_fma(-2.0, T3, T2) + T4, E0 = __builtin_fma(-4.0, T3, __builtin_fma(3.0, T2, T4));
-    const double D1 = __builtin_fma(-2.0, T2, T1) + T3, E1 = T1 - T3;
-    const double D2 = __builtin_fma(-2.0, T1, T0) + T2, E2 = __builtin_fma(-4.0, T1, __builtin_fma(3.0, T2, T0));
+    // 13/4 D^2 + 3/4 E^2 with D the second difference and E the one-sided first difference of each sub-stencil:
+    //   E0 = 3 T2 - 4 T3 + T4 = dd - 3 dc,   E1 = T1 - T3 = -(db + dc) (it only enters squared),   E2 = T0 - 4 T1 + 3 T2 = 3 db - da.
+    const double D0 = dd - dc, D1 = dc - db, D2 = db - da;
+    const double E0 = __builtin_fma(-3.0, dc, dd), E1 = db + dc, E2 = __builtin_fma(3.0, db, -da);
     // The weights depend on the betas only through tau/(beta + eps), which is invariant under a common scaling of
-    // (beta, eps): work with b_r = beta_r / 0.75 = E^2 + (13/3) D^2 and eps' = eps / 0.75 (one multiply less per beta).
-    const double be0 = __builtin_fma((13.0 / 3.0) * D0, D0, E0 * E0);
-    const double be1 = __builtin_fma((13.0 / 3.0) * D1, D1, E1 * E1);
-    const double be2 = __builtin_fma((13.0 / 3.0) * D2, D2, E2 * E2);
-    const double tau = fabs(be0 - be2);
-    // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2, d_r = b_r + eps';
+    // (beta, eps): work with b_r = beta_r / 0.75 = E^2 + (13/3) D^2 and eps' = eps / 0.75 (one multiply less per beta);
+    // d_r = b_r + eps' takes eps' as the addend of the first FMA, and tau = |b0 - b2| = |d0 - d2|.
+    const double d0 = __builtin_fma((13.0 / 3.0) * D0, D0, __builtin_fma(E0, E0, OCN_WENO_EPS / 0.75));
+    const double d1 = __builtin_fma((13.0 / 3.0) * D1, D1, __builtin_fma(E1, E1, OCN_WENO_EPS / 0.75));
+    const double d2 = __builtin_fma((13.0 / 3.0) * D2, D2, __builtin_fma(E2, E2, OCN_WENO_EPS / 0.75));
+    const double tau = d0 - d2;
+    // Same rational function with ONE reciprocal: alpha_r = C_r (d_r^2 + tau^2)/d_r^2;
     // multiply numerator and denominator of sum(alpha_r p_r)/sum(alpha_r) by d0^2 d1^2 d2^2:
     //   m_r = (d_r^2 + tau^2) prod_{s != r} d_s^2,  result = sum (C_r p_r) m_r / sum C_r m_r.
-    const double d0 = be0 + (OCN_WENO_EPS / 0.75), d1 = be1 + (OCN_WENO_EPS / 0.75), d2 = be2 + (OCN_WENO_EPS / 0.75);
     const double t2 = tau * tau;
     const double e0 = d0 * d0, e1 = d1 * d1, e2 = d2 * d2;
     // m_r = (e_r + t2) e_s e_t = e0 e1 e2 + t2 e_s e_t
@@ -147,8 +149,8 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double den = __builtin_fma(t2, __builtin_fma(OCN_C5_2, e01, __builtin_fma(OCN_C5_1, e02, OCN_C5_0 * e12)), e012);
     // sum w_r p_r = p1 + w0 (p0 - p1) + w2 (p2 - p1), and the differences of the candidate reconstructions are differences of the
     // second differences already at hand: p0 - p1 = (D1 - D0) / 6, p2 - p1 = (D2 - D1) / 3: the three 3-point candidates (9 operations)
-    // shrink to the centre one (3) plus 6 for the correction
-    const double p1 = (OCN_W5P_10 * T1 + OCN_W5P_11 * T2) + OCN_W5P_12 * T3;
+    // shrink to the centre one, p1 = (-T1 + 5 T2 + 2 T3) / 6 = T2 + db / 6 + dc / 3 (2), plus 6 for the correction
+    const double p1 = __builtin_fma(1.0 / 3.0, dc, __builtin_fma(1.0 / 6.0, db, T2));
     const double num = __builtin_fma(OCN_C5_2 / 3.0, m2 * (D2 - D1), (OCN_C5_0 / 6.0) * (m0 * (D1 - D0)));
     return __builtin_fma(num, fast_rcp1(den), p1);
 #endif
@@ -199,7 +201,8 @@ __device__ __forceinline__ double sym_interp(V val, int idx, int N)
 }
 
 // symmetric interpolation of (a * psi) for a metric `a` that is constant along the line: the reference multiplies every
-// stencil value (strict); the interpolation is linear, so fast math factors the metric out.
+// stencil value (strict); the interpolation is linear, so fast math factors the metric out.  (Folding `a` into the two distinct
+// coefficients saves 4 operations per plane and costs 12 loop-invariant registers: spills in the correction-on-load kernel.)
 template <int TOPO, bool CENTER, class V>
 __device__ __forceinline__ double sym_interp_scaled(V val, double a, int idx, int N)
 {

@@ -236,27 +236,29 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     }
     const double pcdt = fz.pc_dt;
 #if OCN_STRICT
-#define OCN_PC_GRAD(d, h) ((d) / (h))  // reference expression: difference / spacing
+#define OCN_PC_APPLY(raw, d, h) ((raw) - ((d) / (h)) * pcdt)  // reference expression: difference / spacing, times the stage's dt
     const double hx = M.dx, hy = M.dy, hz = M.dz;
 #else
-#define OCN_PC_GRAD(d, h) ((d) * (h))  // fast math: multiply by the reciprocal spacing
-    const double hx = 1.0 / M.dx, hy = 1.0 / M.dy, hz = 1.0 / M.dz;
+    // fast math: one FMA with dt / spacing, which sits in scalar registers (in vector registers the three loop invariants push the
+    // kernel over its 168-register budget: spills inside the plane loop)
+#define OCN_PC_APPLY(raw, d, h) __builtin_fma(-(d), h, raw)
+    const double hx = ocn::to_sgpr(pcdt * (1.0 / M.dx)), hy = ocn::to_sgpr(pcdt * (1.0 / M.dy)), hz = ocn::to_sgpr(pcdt * (1.0 / M.dz));
 #endif
     auto zz = [&](int kk) { return (long long)(wrp(kk, Nz) - 1) * su3; };  // plane offset of p (same strides when periodic)
     auto own_u = [&](int kk) {
         const double raw = pu[(kk - 1) * su3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(pC[zz(kk)] - pWn[zz(kk)], hx) * pcdt;
+        return OCN_PC_APPLY(raw, pC[zz(kk)] - pWn[zz(kk)], hx);
     };
     auto own_v = [&](int kk) {
         const double raw = pv[(kk - 1) * sv3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(pC[zz(kk)] - pSn[zz(kk)], hy) * pcdt;
+        return OCN_PC_APPLY(raw, pC[zz(kk)] - pSn[zz(kk)], hy);
     };
     auto own_w = [&](int kk) {
         const double raw = pw[(kk - 1) * sw3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(pC[zz(kk)] - pC[zz(kk - 1)], hz) * pcdt;
+        return OCN_PC_APPLY(raw, pC[zz(kk)] - pC[zz(kk - 1)], hz);
     };
 #define ZU(k) own_u(k)
 #define ZV(k) own_v(k)
@@ -296,17 +298,17 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     auto ring_u = [&](int s, int kk) {
         const double raw = u[roff[s] + (kk - 1) * su3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpw[s][zz(kk)], hx) * pcdt;
+        return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rpw[s][zz(kk)], hx);
     };
     auto ring_v = [&](int s, int kk) {
         const double raw = v[roff[s] + (kk - 1) * sv3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rps[s][zz(kk)], hy) * pcdt;
+        return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rps[s][zz(kk)], hy);
     };
     auto ring_w = [&](int s, int kk) {
         const double raw = w[roff[s] + (kk - 1) * sw3];
         if (!PC) return raw;
-        return raw - OCN_PC_GRAD(rpc[s][zz(kk)] - rpc[s][zz(kk - 1)], hz) * pcdt;
+        return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rpc[s][zz(kk - 1)], hz);
     };
 
     // z-windows: index m <-> k-2+m
@@ -398,17 +400,17 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                 // corrected values of the next plane, re-using last plane's pressure values (6 p loads instead of 8)
                 const long long o4 = zz(k + 4), o1 = zz(k + 1), o2 = zz(k + 2);
                 const double pc4 = pC[o4], pw4 = pWn[o4], ps4 = pSn[o4];
-                zu_n = pu[(k + 3) * su3] - OCN_PC_GRAD(pc4 - pw4, hx) * pcdt;
-                zv_n = pv[(k + 3) * sv3] - OCN_PC_GRAD(pc4 - ps4, hy) * pcdt;
-                zw_n = pw[(k + 3) * sw3] - OCN_PC_GRAD(pc4 - pc_prev, hz) * pcdt;
+                zu_n = OCN_PC_APPLY(pu[(k + 3) * su3], pc4 - pw4, hx);
+                zv_n = OCN_PC_APPLY(pv[(k + 3) * sv3], pc4 - ps4, hy);
+                zw_n = OCN_PC_APPLY(pw[(k + 3) * sw3], pc4 - pc_prev, hz);
                 pc_prev = pc4;
 #pragma unroll
                 for (int s = 0; s < RPT; ++s)
                     if (ron[s]) {
                         const double pr1 = rp_prev[s], pr2 = rpc[s][o2];
-                        nu[s] = u[roff[s] + k * su3] - OCN_PC_GRAD(pr1 - rpw[s][o1], hx) * pcdt;
-                        nv[s] = v[roff[s] + k * sv3] - OCN_PC_GRAD(pr1 - rps[s][o1], hy) * pcdt;
-                        nw[s] = w[roff[s] + (k + 1) * sw3] - OCN_PC_GRAD(pr2 - pr1, hz) * pcdt;
+                        nu[s] = OCN_PC_APPLY(u[roff[s] + k * su3], pr1 - rpw[s][o1], hx);
+                        nv[s] = OCN_PC_APPLY(v[roff[s] + k * sv3], pr1 - rps[s][o1], hy);
+                        nw[s] = OCN_PC_APPLY(w[roff[s] + (k + 1) * sw3], pr2 - pr1, hz);
                         rp_prev[s] = pr2;
                     }
             } else {
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZU
 #undef ZV
 #undef ZW
-#undef OCN_PC_GRAD
+#undef OCN_PC_APPLY
 #undef Lu
 #undef Lv
 #undef Lw
@@ -1025,13 +1027,12 @@ __global__ void pressure_planes_kernel(GridDev g, double *__restrict__ p, double
     j = j < 1 ? j + g.Ny : (j > g.Ny ? j - g.Ny : j);
     k = k < 1 ? k + g.Nz : (k > g.Nz ? k - g.Nz : k);
     const double *pw = p + ocn::at(L, nx - Hx + 1, j, k);
-#if OCN_STRICT
-    const double grad = (pw[0] - pw[-1]) / g.dx;
-#else
-    const double grad = (pw[0] - pw[-1]) * (1.0 / g.dx);
-#endif
     west[t] = 0.0;
-    east[t] = urow[nx] - grad * pcdt;
+#if OCN_STRICT
+    east[t] = urow[nx] - ((pw[0] - pw[-1]) / g.dx) * pcdt;
+#else
+    east[t] = __builtin_fma(-(pw[0] - pw[-1]), pcdt * (1.0 / g.dx), urow[nx]);  // the expression of the correction on load
+#endif
 }
 int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream)
 {
