@@ -65,26 +65,6 @@ __device__ __forceinline__ double to_sgpr(double x)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// The same for a wave-uniform pointer (load_at / store_at).  Besides the register class this makes the pointer opaque to the optimiser: `uniform base +
-// 32-bit lane offset` then stays in that shape, which is the scalar-base addressing mode of the global loads and stores (otherwise
-// the loop-invariant `field + lane offset` is hoisted into a 64-bit vector register pair per field and column).
-typedef __attribute__((address_space(1))) const double *global_cptr;
-typedef __attribute__((address_space(1))) double *global_ptr;
-__device__ __forceinline__ unsigned long long to_sgpr_bits(const void *q)
-{
-    const unsigned long long b = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-// load / store of a double at (wave-uniform pointer) + (32-bit byte offset of the lane), in the global address space
-__device__ __forceinline__ double load_at(const double *uniform_base, unsigned off)
-{
-    return *reinterpret_cast<global_cptr>(to_sgpr_bits(uniform_base) + off);
-}
-__device__ __forceinline__ void store_at(double *uniform_base, unsigned off, double v)
-{
-    *reinterpret_cast<global_ptr>(to_sgpr_bits(uniform_base) + off) = v;
-}
 
 // Compiler-level fence for software pipelines: memory operations written above it are issued above it (the loads of the NEXT plane must
 // leave at the top of an iteration, not where the scheduler finds their first use).  No instruction is emitted.

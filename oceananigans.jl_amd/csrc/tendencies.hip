@@ -393,8 +393,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                 }
             __syncthreads();
         }
-        // ---- prefetch what the NEXT plane needs; the loads fly under this plane's arithmetic
-        double zu_n = 0, zv_n = 0, zw_n = 0;
+        // ---- prefetch what the NEXT plane needs; the loads fly under this plane's arithmetic.  (Values that are loaded under a
+        // condition and used under the same one are left uninitialised on purpose: a default costs a 64-bit move per plane each.)
+        double zu_n, zv_n, zw_n;
         if (k < k_end) {
             if (PC) {
                 // corrected values of the next plane, re-using last plane's pressure values (6 p loads instead of 8)
@@ -427,13 +428,13 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             }
         }
         // the previous stage's tendencies for the substep epilogue: loaded here so that they arrive under the arithmetic
-        double gmu = 0.0, gmv = 0.0, gmw = 0.0;
+        double gmu, gmv, gmw;
         if (fz.on && fz.has_zeta && writes) {
             const long long o = own0 + (long long)(k - 1) * su3;
             gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o]; gmw = fz.Gm[2][o];
         }
         // ... and the terms the finishing pass has already left in G (fz.acc)
-        double eu = 0.0, ev = 0.0, ew = 0.0;
+        double eu, ev, ew;
         if (fz.acc && writes) {
             const long long o = own0 + (long long)(k - 1) * su3;
             if (i >= r.ou) eu = Gu[o];
@@ -454,7 +455,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             ex[1][tid] = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
         }
         {   // Fuw(i): sym z-face of Ax*u (own column) ; biased x-face of w
-            const double ut = sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
+            const double ut = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zu[2 + m]; }, ax, k, Nz)  // never stretched
+                                                 : sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
             ex[2][tid] = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
         }
         // ---- y-fluxes (consumed by this cell and its SOUTH neighbour)
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             ex[4][tid] = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
         }
         {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
-            const double vt = sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
+            const double vt = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zv[2 + m]; }, ay, k, Nz)
+                                                 : sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
             ex[5][tid] = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
         }
         // ---- z-fluxes on the top face k+1 and at centre k
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             zv[m] = zv[m + 1];
             zw[m] = zw[m + 1];
         }
-        zu[5] = zu_n; zv[5] = zv_n; zw[5] = zw_n;
+        if (k < k_end) { zu[5] = zu_n; zv[5] = zv_n; zw[5] = zw_n; }
     }
 #undef ZU
 #undef ZV
