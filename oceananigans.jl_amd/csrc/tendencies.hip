@@ -755,20 +755,25 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
         }
         __syncthreads();
         const bool more = k < k_end;
-        double rk_n[RPT] = {}, zk_n = 0.0;
-        if (kfld) {
-#pragma unroll
-            for (int s = 0; s < RPT; ++s) rk_n[s] = (more && ron[s]) ? tf.kappa_e[roff[s] + (long long)k * s3] : 0.0;
-            zk_n = more ? pke[(long long)(k + 1) * s3] : 0.0;  // κₑ[k+2]
-        }
+        // (values loaded under a condition and used under the same one carry no default: a default is a 64-bit move or select per plane)
+        double rk_n[RPT], zk_n, rv_n[RPT], uf_n, vf_n, wf_n, znew_n, gm;
         const long long o = own0 + (long long)(k - 1) * s3;
-        double rv_n[RPT];
+        if (more) {
+            if (kfld) {
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) rv_n[s] = (more && ron[s]) ? c[roff[s] + (long long)k * s3] : 0.0;
-        const double uf_n = more ? pu[(long long)k * s3] : 0.0, vf_n = more ? pv[(long long)k * s3] : 0.0;
-        const double wf_n = more ? pw[(long long)(k + 1) * s3] : 0.0;
-        const double znew_n = (k + 1 < k_end) ? pc[(long long)(k + 4) * s3] : 0.0;
-        const double gm = (writes && tf.sc.on && tf.sc.has_zeta) ? tf.sub.Gm[o] : 0.0;
+                for (int s = 0; s < RPT; ++s)
+                    if (ron[s]) rk_n[s] = tf.kappa_e[roff[s] + (long long)k * s3];
+                zk_n = pke[(long long)(k + 1) * s3];  // κₑ[k+2]
+            }
+#pragma unroll
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) rv_n[s] = c[roff[s] + (long long)k * s3];
+            uf_n = pu[(long long)k * s3];
+            vf_n = pv[(long long)k * s3];
+            wf_n = pw[(long long)(k + 1) * s3];
+            if (k + 1 < k_end) znew_n = pc[(long long)(k + 4) * s3];
+        }
+        if (writes && tf.sc.on && tf.sc.has_zeta) gm = tf.sub.Gm[o];
         // Everything above must be REQUESTED here: left alone, the scheduler sinks these loads to their first use -- behind the second
         // barrier, a few hundred cycles before the next iteration waits for them -- and, vector-memory returns being in order, a late G⁻
         // load in the epilogue then waits for the whole prefetch group (profiles/r03a_config4.md: 45 % of the wave cycles parked).
@@ -795,15 +800,19 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
         fzb = fzt;
 #pragma unroll
         for (int m = 0; m < 5; ++m) zc[m] = zc[m + 1];
-        zc[5] = znew;
-        znew = znew_n;
-        uf = uf_n; vf = vf_n; wf = wf_n;
+        if (more) {
+            zc[5] = znew;
+            if (k + 1 < k_end) znew = znew_n;
+            uf = uf_n; vf = vf_n; wf = wf_n;
 #pragma unroll
-        for (int s = 0; s < RPT; ++s) rv[s] = rv_n[s];
-        if (kfld) {
-            zk[0] = zk[1]; zk[1] = zk[2]; zk[2] = zk_n;
+            for (int s = 0; s < RPT; ++s)
+                if (ron[s]) rv[s] = rv_n[s];
+            if (kfld) {
+                zk[0] = zk[1]; zk[1] = zk[2]; zk[2] = zk_n;
 #pragma unroll
-            for (int s = 0; s < RPT; ++s) rk[s] = rk_n[s];
+                for (int s = 0; s < RPT; ++s)
+                    if (ron[s]) rk[s] = rk_n[s];
+            }
         }
     }
 }
