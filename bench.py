@@ -282,6 +282,13 @@ def preflight(a, rank, world, local_rank, stdout_fd):
                     want = 3 if slot == 0 else 2
                     ok &= any(ir and pr == r and sl == want for ir, pr, sl in allops[peer].tolist())
     checks["neighbour_schedule_pairs_up"] = ok
+    # the all-gather of the transpose-free solve as direct transfers: every rank sends its one chunk to every peer and receives chunk s from s
+    gops = (ocn._lib.CCommOp * (2 * world))()
+    ocn._lib.call("ocn_comm_schedule", ocn._lib.SCHED_ALL_GATHER, rank, world, 0, gops, 2 * world, C.byref(n))
+    sends = sorted(gops[q].peer for q in range(n.value) if not gops[q].is_recv)
+    recvs = sorted((gops[q].peer, gops[q].slot) for q in range(n.value) if gops[q].is_recv)
+    others = [r for r in range(world) if r != rank]
+    checks["all_gather_schedule_complete"] = sends == others and recvs == [(r, r) for r in others]
     all_ok = all(checks.values())
     flag = torch.tensor([1 if all_ok else 0], dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
