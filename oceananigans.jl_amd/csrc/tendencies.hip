@@ -445,33 +445,43 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         const double(*swt)[LX] = sw[wslot(k + 1)];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
 
+        // this thread's six shared fluxes stay in registers where there is room, and only the neighbours' come back from LDS (the
+        // correction-on-load variants sit at their register budget: one more spill per plane costs more than the six LDS reads)
+        double myf0, myf1, myf2, myf3, myf4, myf5;
+#define OCN_MYF(q) (PC ? ex[q][tid] : myf##q)
         // ---- x-fluxes (consumed by this cell and its WEST neighbour)
         {   // Fuu(i-1): centre i-1 == face i of the shifted line: u[i-3..i+2]
             const double ut = sym_interp_scaled<P, true>([&](int m) { return su[ly][lx + m]; }, ax, i - 1, Nx);
-            ex[0][tid] = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+            myf0 = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+            ex[0][tid] = myf0;
         }
         {   // Fuv(i): sym y-face of Ax*u ; biased x-face of v
             const double ut = sym_interp_scaled<P, false>([&](int m) { return su[ly + m][lx]; }, ax, j, Ny);
-            ex[1][tid] = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
+            myf1 = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
+            ex[1][tid] = myf1;
         }
         {   // Fuw(i): sym z-face of Ax*u (own column) ; biased x-face of w
             const double ut = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zu[2 + m]; }, ax, k, Nz)  // never stretched
                                                  : sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
-            ex[2][tid] = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
+            myf2 = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
+            ex[2][tid] = myf2;
         }
         // ---- y-fluxes (consumed by this cell and its SOUTH neighbour)
         {   // Fvv(j-1)
             const double vt = sym_interp_scaled<P, true>([&](int m) { return sv[ly + m][lx]; }, ay, j - 1, Ny);
-            ex[3][tid] = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+            myf3 = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+            ex[3][tid] = myf3;
         }
         {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
             const double vt = sym_interp_scaled<P, false>([&](int m) { return sv[ly][lx + m]; }, ay, i, Nx);
-            ex[4][tid] = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
+            myf4 = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
+            ex[4][tid] = myf4;
         }
         {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
             const double vt = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zv[2 + m]; }, ay, k, Nz)
                                                  : sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
-            ex[5][tid] = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
+            myf5 = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
+            ex[5][tid] = myf5;
         }
         // ---- z-fluxes on the top face k+1 and at centre k
         double fwu_top, fwv_top, fww;
@@ -505,20 +515,20 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             const double rVc = recip_volume(M.Az * M.dzC(k));
             const long long ou_ = ocn::at(Lu, i, j, k), ov_ = ocn::at(Lv, i, j, k), ow_ = ocn::at(Lw, i, j, k);
             if (i >= r.ou) {
-                double G = -(rVc * (((ex[0][e] - ex[0][tid]) + (ex[4][n] - ex[4][tid])) + (fwu_top - fwu_bot)));
+                double G = -(rVc * (((ex[0][e] - OCN_MYF(0)) + (ex[4][n] - OCN_MYF(4))) + (fwu_top - fwu_bot)));
                 if (fz.acc) G = G + eu;
                 Gu[ou_] = G;
                 if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmu) : (fz.dt * fz.gamma) * G);
             }
             if (j >= r.ov) {
-                double G = -(rVc * (((ex[1][e] - ex[1][tid]) + (ex[3][n] - ex[3][tid])) + (fwv_top - fwv_bot)));
+                double G = -(rVc * (((ex[1][e] - OCN_MYF(1)) + (ex[3][n] - OCN_MYF(3))) + (fwv_top - fwv_bot)));
                 if (fz.acc) G = G + ev;
                 Gv[ov_] = G;
                 if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmv) : (fz.dt * fz.gamma) * G);
             }
             if (k >= r.ow) {
                 const double rVf = recip_volume(M.Az * M.dzF(k));
-                double G = -(rVf * (((ex[2][e] - ex[2][tid]) + (ex[5][n] - ex[5][tid])) + (fww - fww_prev)));
+                double G = -(rVf * (((ex[2][e] - OCN_MYF(2)) + (ex[5][n] - OCN_MYF(5))) + (fww - fww_prev)));
                 if (fz.acc) G = G + ew;
                 Gw[ow_] = G;
                 // rk3_substep! always excludes the wall face (runge_kutta_3.jl:171-174), even when a KernelParameters range
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZV
 #undef ZW
 #undef OCN_PC_APPLY
+#undef OCN_MYF
 #undef Lu
 #undef Lv
 #undef Lw
