@@ -77,9 +77,15 @@ struct AmdTracers {
 };
 
 // ℑ over a 2x2 set: 0.5 * (0.5*(f[0][0] + f[1][0]) + 0.5*(f[0][1] + f[1][1]))
+#if OCN_STRICT
 #define I4(f) (0.5 * (0.5 * (f[0][0] + f[1][0]) + 0.5 * (f[0][1] + f[1][1])))
 #define I4SQ(f) (0.5 * (0.5 * (f[0][0] * f[0][0] + f[1][0] * f[1][0]) + 0.5 * (f[0][1] * f[0][1] + f[1][1] * f[1][1])))
 #define I4PR(f, g) (0.5 * (0.5 * (f[0][0] * g[0][0] + f[1][0] * g[1][0]) + 0.5 * (f[0][1] * g[0][1] + f[1][1] * g[1][1])))
+#else  // fast math: one factor 1/4 instead of three halves (two multiplies less per average; the halvings are exact, so only the sums' order changes)
+#define I4(f) (0.25 * ((f[0][0] + f[1][0]) + (f[0][1] + f[1][1])))
+#define I4SQ(f) (0.25 * ((f[0][0] * f[0][0] + f[1][0] * f[1][0]) + (f[0][1] * f[0][1] + f[1][1] * f[1][1])))
+#define I4PR(f, g) (0.25 * ((f[0][0] * g[0][0] + f[1][0] * g[1][0]) + (f[0][1] * g[0][1] + f[1][1] * g[1][1])))
+#endif
 
 template <bool GEN>
 __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
@@ -112,10 +118,12 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
     const double dx = A0.dx, dy = A0.dy, Fx = A0.Fx, Fy = A0.Fy;
 #if OCN_STRICT
 #define AMD_D(num, den) ((num) / (den))
+#define AMD_G(r, num, den) ((r) * ((num) / (den)))  /* normalised gradient: filter-width ratio times the derivative */
     const double rxy = Fx / Fy, ryx = Fy / Fx;
     const double qdx = dx, qdy = dy;
 #else
 #define AMD_D(num, den) ((num) * (den))  /* den holds the reciprocal */
+#define AMD_G(r, num, den) ((r) * ((num) * (den)))  /* (folding r * den into one factor saves 32 multiplies and costs 8 registers: slower) */
     const double rFx = fast_rcp(Fx), rFy = fast_rcp(Fy);
     const double rxy = Fx * rFy, ryx = Fy * rFx;
     const double qdx = fast_rcp(dx), qdy = fast_rcp(dy);
@@ -134,11 +142,11 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
         for (int a = 0; a < 2; ++a) {
             cU[a] = A0.U(a, 0, 0);
             cV[a] = A0.V(0, a, 0);
-            c_dzu[a] = rzx0 * AMD_D(A0.U(a, 0, 0) - A0.U(a, 0, -1), qdzf0);
-            c_dxw[a] = rxz0 * AMD_D(A0.W(a, 0, 0) - A0.W(a - 1, 0, 0), qdx);
-            c_dzv[a] = rzy0 * AMD_D(A0.V(0, a, 0) - A0.V(0, a, -1), qdzf0);
-            c_dyw[a] = ryz0 * AMD_D(A0.W(0, a, 0) - A0.W(0, a - 1, 0), qdy);
-            c_dywq[a] = ryz0 * AMD_D(A0.W(a, 0, 0) - A0.W(a, -1, 0), qdy);
+            c_dzu[a] = AMD_G(rzx0, A0.U(a, 0, 0) - A0.U(a, 0, -1), qdzf0);
+            c_dxw[a] = AMD_G(rxz0, A0.W(a, 0, 0) - A0.W(a - 1, 0, 0), qdx);
+            c_dzv[a] = AMD_G(rzy0, A0.V(0, a, 0) - A0.V(0, a, -1), qdzf0);
+            c_dyw[a] = AMD_G(ryz0, A0.W(0, a, 0) - A0.W(0, a - 1, 0), qdy);
+            c_dywq[a] = AMD_G(ryz0, A0.W(a, 0, 0) - A0.W(a, -1, 0), qdy);
         }
         cW = A0.W(0, 0, 0);
         const long long o0 = A0.oc;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
             if (n < tr.n) {
                 const double *pc = tr.c[n] + o0;
                 tc0[n] = pc[0];
-                tgz[n] = Fz0 * AMD_D(tc0[n] - pc[-A0.s3], qdzf0);
+                tgz[n] = AMD_G(Fz0, tc0[n] - pc[-A0.s3], qdzf0);
             }
         }
     }
@@ -173,26 +181,26 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
     double dyu[2][2], dxv[2][2], dzu[2][2], dxw[2][2], dzv[2][2], dyw[2][2], dywq[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        dyu[a][0] = ryx * AMD_D(cU[a] - A.U(a, -1, 0), qdy);       // norm_∂y_u at (i+a, j+b, k)
-        dyu[a][1] = ryx * AMD_D(A.U(a, 1, 0) - cU[a], qdy);
+        dyu[a][0] = AMD_G(ryx, cU[a] - A.U(a, -1, 0), qdy);       // norm_∂y_u at (i+a, j+b, k)
+        dyu[a][1] = AMD_G(ryx, A.U(a, 1, 0) - cU[a], qdy);
         dzu[a][0] = c_dzu[a];                                      // norm_∂z_u at (i+a, j, k+b)
-        dzu[a][1] = rzx1 * AMD_D(uT[a] - cU[a], qdzf1);
+        dzu[a][1] = AMD_G(rzx1, uT[a] - cU[a], qdzf1);
         dxw[a][0] = c_dxw[a];                                      // norm_∂x_w
-        dxw[a][1] = rxz1 * AMD_D(wT[a + 1] - wT[a], qdx);
+        dxw[a][1] = AMD_G(rxz1, wT[a + 1] - wT[a], qdx);
         dzv[a][0] = c_dzv[a];                                      // norm_∂z_v at (i, j+a, k+b)
-        dzv[a][1] = rzy1 * AMD_D(vT[a] - cV[a], qdzf1);
+        dzv[a][1] = AMD_G(rzy1, vT[a] - cV[a], qdzf1);
         dyw[a][0] = c_dyw[a];                                      // norm_∂y_w
         dywq[a][0] = c_dywq[a];                                    // norm_∂y_w at (i+a, j, k+b): the ℑxz quirk
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        dxv[0][b] = rxy * AMD_D(cV[b] - A.V(-1, b, 0), qdx);       // norm_∂x_v at (i+a, j+b, k)
-        dxv[1][b] = rxy * AMD_D(A.V(1, b, 0) - cV[b], qdx);
+        dxv[0][b] = AMD_G(rxy, cV[b] - A.V(-1, b, 0), qdx);       // norm_∂x_v at (i+a, j+b, k)
+        dxv[1][b] = AMD_G(rxy, A.V(1, b, 0) - cV[b], qdx);
     }
-    dyw[0][1] = ryz1 * AMD_D(wT[1] - wS, qdy);
-    dyw[1][1] = ryz1 * AMD_D(wN - wT[1], qdy);
-    dywq[0][1] = ryz1 * AMD_D(wT[1] - wS, qdy);
-    dywq[1][1] = ryz1 * AMD_D(wT[2] - wSE, qdy);
+    dyw[0][1] = AMD_G(ryz1, wT[1] - wS, qdy);
+    dyw[1][1] = AMD_G(ryz1, wN - wT[1], qdy);
+    dywq[0][1] = AMD_G(ryz1, wT[1] - wS, qdy);
+    dywq[1][1] = AMD_G(ryz1, wT[2] - wSE, qdy);
     const double dxu = AMD_D(cU[1] - cU[0], qdx), dyv = AMD_D(cV[1] - cV[0], qdy), dzw = AMD_D(wT[1] - cW, qdzc);
 #if OCN_STRICT
     const double d2 = 3 / ((1 / (Fx * Fx) + 1 / (Fy * Fy)) + 1 / (Fz[0] * Fz[0]));
@@ -240,9 +248,9 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
             const double *pc = tr.c[n] + o;
             const long long s2 = A.s2, s3 = A.s3;
             const double c0 = tc0[n], cT = pc[s3];
-            const double gx0 = Fx * AMD_D(c0 - pc[-1], qdx), gx1 = Fx * AMD_D(pc[1] - c0, qdx);               // norm_∂x_c at i, i+1
-            const double gy0 = Fy * AMD_D(c0 - pc[-s2], qdy), gy1 = Fy * AMD_D(pc[s2] - c0, qdy);             // norm_∂y_c at j, j+1
-            const double gz0 = tgz[n], gz1 = Fz[1] * AMD_D(cT - c0, qdzf1);                                   // norm_∂z_c at k, k+1
+            const double gx0 = AMD_G(Fx, c0 - pc[-1], qdx), gx1 = AMD_G(Fx, pc[1] - c0, qdx);               // norm_∂x_c at i, i+1
+            const double gy0 = AMD_G(Fy, c0 - pc[-s2], qdy), gy1 = AMD_G(Fy, pc[s2] - c0, qdy);             // norm_∂y_c at j, j+1
+            const double gz0 = tgz[n], gz1 = AMD_G(Fz[1], cT - c0, qdzf1);                                   // norm_∂z_c at k, k+1
             tc0[n] = cT; tgz[n] = gz1;
             const double xc2 = 0.5 * (gx0 * gx0 + gx1 * gx1), yc2 = 0.5 * (gy0 * gy0 + gy1 * gy1), zc2 = 0.5 * (gz0 * gz0 + gz1 * gz1);
             const double sigma = (xc2 + yc2) + zc2;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
     cW = wT[1];
     }  // k
 #undef AMD_D
+#undef AMD_G
 #undef AMD_Q
 }
 #undef I4
