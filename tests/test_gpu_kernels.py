@@ -110,6 +110,35 @@ def test_tracer_tendency_strict_bitwise(oracle, ocn, size, topo, z):
     np.testing.assert_array_equal(from_dev(dGc), Gc)
 
 
+@pytest.mark.parametrize("mean,amp", [(20.0, 1e-3), (35.0, 1e-6), (0.0, 1.0), (1e4, 1.0)])
+def test_tracer_tendency_fast_with_large_mean(oracle, ocn, mean, amp):
+    """Fast-math WENO5 (csrc/ocn_weno.h: everything from the first differences of the inputs, centre candidate + correction) on the
+    fields it meets in the ocean configurations: a large mean with a small perturbation (T = 20 +- 1e-3, S = 35 +- 1e-6).  The smoothness
+    indicators see only the perturbation, so the weights must not lose it in the mean: fast vs oracle within 1e-11 of max|G| (G itself is
+    a difference of fluxes ~ mean * u: the cancellation bound eps * mean / amp applies to the strict build just as well, so for the
+    S-like case the tolerance is that bound)."""
+    O = oracle
+    rng = np.random.default_rng(2718)
+    og, pg = make_pair(O, ocn, (20, 18, 12), "PPB", z=stretched_faces(12))
+    u, v, w = (random_parent(og, l, rng) for l in LOCS)
+    c = mean + amp * random_parent(og, 0, rng, -1.0, 1.0)
+    Gc = og.zeros(0)
+    O.tracer_tendency(og, u, v, w, c, Gc)
+    ocn.set_math_mode(ocn.MATH_FAST)
+    try:
+        du, dv, dw = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS, (u, v, w)))
+        dc, dGc = to_dev(ocn, pg, 0, c), ocn.Field(0, pg)
+        ocn._lib.call("ocn_compute_tracer_tendency", pg.cref, du.ptr, dv.ptr, dw.ptr, dc.ptr, dGc.ptr, None, 0)
+        ocn.sync_device()
+    finally:
+        ocn.set_math_mode(ocn.MATH_STRICT)
+    got = from_dev(dGc)
+    assert np.isfinite(got).all()
+    dmin = min(og.dx, og.dy, float(np.min(og.dzc)) if og.dzc is not None else og.dz)
+    flux_scale = (abs(mean) + amp) * max(np.abs(a).max() for a in (u, v, w)) / dmin
+    assert np.abs(got - Gc).max() <= max(1e-11 * np.abs(Gc).max(), 64 * 2.2e-16 * flux_scale)
+
+
 def test_tendency_range_matches_full(oracle, ocn):
     """KernelParameters ranges (interior / buffer split) tile the full :xyz launch exactly."""
     O = oracle
