@@ -23,8 +23,9 @@
  *  - Ordering: work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream) and is asynchronous w.r.t. the host, like KernelAbstractions launches
  *    (src/Utils/kernel_launching.jl:252-253).  One host thread per handle.
- *  - Supported scope: RectilinearGrid, x and y regular, z regular or stretched;
- *    topologies (Periodic,Periodic,{Periodic,Bounded,Flat}); Float64.
+ *  - Supported scope: RectilinearGrid, x and y regular, z regular or stretched; every combination of
+ *    Periodic / Bounded / Flat topologies (LDS-tiled kernels where x and y are Periodic or rank-local
+ *    FullyConnected, direction-generic kernels otherwise: csrc/general.hip); Float64.
  */
 #ifndef OCN_HIP_H
 #define OCN_HIP_H
@@ -62,13 +63,18 @@ extern "C" {
 /* math modes for the WENO tendency kernels (see ocn_set_math_mode) */
 #define OCN_MATH_STRICT 0 /* reference evaluation order, no FMA contraction, IEEE division */
 #define OCN_MATH_FAST 1   /* algebraically identical, FMA + fused-division form */
+/* per-grid selection (ocn_grid.math) */
+#define OCN_GRID_MATH_DEFAULT 0
+#define OCN_GRID_MATH_STRICT 1
+#define OCN_GRID_MATH_FAST 2
 
 /* RectilinearGrid (src/Grids/rectilinear_grid.jl:1-23) reduced to what kernels read. */
 typedef struct ocn_grid {
     int32_t Nx, Ny, Nz;  /* interior size */
     int32_t Hx, Hy, Hz;  /* halo size */
     int32_t tx, ty, tz;  /* topology codes */
-    int32_t _pad;
+    int32_t math;        /* arithmetic variant of the kernels launched for THIS grid: OCN_GRID_MATH_DEFAULT (the process default,
+                          * ocn_set_math_mode), OCN_GRID_MATH_STRICT or OCN_GRID_MATH_FAST: two models of one process may differ */
     double dx, dy, dz;   /* regular spacings (Flat: 1.0); dz ignored when dzc != NULL */
     double Lx, Ly, Lz;   /* domain extents grid.Lx/Ly/Lz (Flat: 1.0), used by poisson_eigenvalues */
     const double *dzc;   /* DEVICE: Δzᵃᵃᶜ[k], element 0 <-> k = 1-Hz, length Nz+2Hz; NULL if z regular */
@@ -90,7 +96,8 @@ int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* d
 int ocn_memset(void *ptr, int value, size_t bytes, void *stream);
 int ocn_sync(void *stream);                          /* sync_device! */
 
-/* Selects the arithmetic variant used by ocn_compute_momentum_tendencies / _tracer_tendency. */
+/* Process default of the arithmetic variant (every kernel compiled in two variants: tendencies, extra terms, AMD, hydrostatic momentum),
+ * used by grids whose `math` field is OCN_GRID_MATH_DEFAULT.  Atomic; handles created from a grid keep that grid's `math`. */
 int ocn_set_math_mode(int mode);
 int ocn_get_math_mode(void);
 
@@ -605,6 +612,13 @@ int ocn_comm_init(ocn_comm_t *comm, int32_t rank, int32_t nranks, const void *un
  * rule (the k-th send a -> b meets the k-th receive of b from a); host-blocking; not a product path.  All ranks pass the same group_key;
  * the call returns when all have joined.  ocn_comm_info reports rccl_version 0. */
 int ocn_comm_init_local(ocn_comm_t *comm, int32_t rank, int32_t nranks, int64_t group_key);
+/* Measurement transport: this process is rank 0 of `nranks` IDENTICAL ranks (an x-periodic flow of period Lx / nranks).  No peer
+ * exists: what a peer would send is what this rank sends to the peer's mirror image, so every receive of a schedule is an asynchronous
+ * device copy from one of the rank's own send buffers.  The schedules, pack / unpack launches, stream ordering, the nranks-rank
+ * interface systems of the transpose-free pressure solve and the C drivers are those of a real nranks-rank run: the time of a step is
+ * what ONE rank of nranks costs before any link time (tools/bench_dist_rank.py).  All-to-all exchanges are refused (OCN_ERR_UNSUPPORTED).
+ * Replaces nothing in the reference. */
+int ocn_comm_init_replica(ocn_comm_t *comm, int32_t nranks);
 int ocn_comm_destroy(ocn_comm_t comm);
 /* rank, the number of ranks RCCL itself reports (ncclCommCount), RCCL version code */
 int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version);

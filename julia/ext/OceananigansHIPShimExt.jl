@@ -105,7 +105,7 @@ math_mode() = Int(ccall((:ocn_get_math_mode, lib), Cint, ()))
 # ---- struct ocn_grid (include/ocn_hip.h) ------------------------------------------------------------------------------
 struct OcnGrid
     Nx::Int32; Ny::Int32; Nz::Int32; Hx::Int32; Hy::Int32; Hz::Int32
-    tx::Int32; ty::Int32; tz::Int32; _pad::Int32
+    tx::Int32; ty::Int32; tz::Int32; math::Int32
     dx::Float64; dy::Float64; dz::Float64; Lx::Float64; Ly::Float64; Lz::Float64
     dzc::Ptr{Float64}; dzf::Ptr{Float64}
 end

@@ -7,11 +7,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libocn_hip.so")
+# OCN_LIB_PATH selects another build of the same library (same-box A/B runs of kernel variants, tools/ab_bench.sh): never a fallback --
+# the file must exist and export every symbol of include/ocn_hip.h, or loading raises as for the default path
+LIB_PATH = os.environ.get("OCN_LIB_PATH") or os.path.join(_HERE, "lib", "libocn_hip.so")
 
 OCN_PERIODIC, OCN_BOUNDED, OCN_FLAT, OCN_FULLY_CONNECTED = 0, 1, 2, 3
 LOC_CCC, LOC_FCC, LOC_CFC, LOC_CCF = 0, 1, 2, 4
 MATH_STRICT, MATH_FAST = 0, 1
+GRID_MATH_DEFAULT, GRID_MATH_STRICT, GRID_MATH_FAST = 0, 1, 2  # ocn_grid.math
 
 
 class OcnError(RuntimeError):
@@ -22,7 +25,7 @@ class CGrid(C.Structure):
     """struct ocn_grid (include/ocn_hip.h)"""
     _fields_ = [("Nx", C.c_int32), ("Ny", C.c_int32), ("Nz", C.c_int32),
                 ("Hx", C.c_int32), ("Hy", C.c_int32), ("Hz", C.c_int32),
-                ("tx", C.c_int32), ("ty", C.c_int32), ("tz", C.c_int32), ("_pad", C.c_int32),
+                ("tx", C.c_int32), ("ty", C.c_int32), ("tz", C.c_int32), ("math", C.c_int32),
                 ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
                 ("Lx", C.c_double), ("Ly", C.c_double), ("Lz", C.c_double),
                 ("dzc", C.c_void_p), ("dzf", C.c_void_p)]
@@ -176,6 +179,7 @@ _SIGS = {
     "ocn_comm_unique_id": [_vp],
     "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
     "ocn_comm_init_local": [C.POINTER(_vp), _i32, _i32, C.c_int64],
+    "ocn_comm_init_replica": [C.POINTER(_vp), _i32],
     "ocn_comm_destroy": [_vp],
     "ocn_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "ocn_halo_exchange_begin": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],

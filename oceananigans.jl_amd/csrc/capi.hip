@@ -1,4 +1,5 @@
 // capi.hip -- extern "C" entry points of libocn_hip.so (see include/ocn_hip.h for the contract).
+#include <atomic>
 #include <cstring>
 #include <string>
 
@@ -7,7 +8,16 @@
 namespace ocn {
 
 static thread_local std::string g_last_error;
-static int g_math_mode = OCN_MATH_STRICT;
+// process default of the arithmetic variant; a grid that carries its own (ocn_grid.math != OCN_GRID_MATH_DEFAULT) overrides it, so two
+// models in one process may differ and a host thread changing the default does not touch another handle's launches
+static std::atomic<int> g_math_mode{OCN_MATH_STRICT};
+static inline bool strict_math(const ocn_grid *grid)
+{
+    const int m = grid ? grid->math : OCN_GRID_MATH_DEFAULT;
+    if (m == OCN_GRID_MATH_STRICT) return true;
+    if (m == OCN_GRID_MATH_FAST) return false;
+    return g_math_mode.load(std::memory_order_relaxed) == OCN_MATH_STRICT;
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -195,9 +205,9 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies: null field pointer");
     if (!xy_periodic(grid))
-        return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
+        return strict_math(grid) ? ocn_strict::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
                                               : ocn_fast::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
-    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, as_stream(stream));
+    if (strict_math(grid)) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, as_stream(stream));
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, nullptr, as_stream(stream));
 }
 
@@ -221,7 +231,7 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     fz.Uo[0] = u_out; fz.Uo[1] = v_out; fz.Uo[2] = w_out;
     fz.dt = dt; fz.gamma = gamma; fz.zeta = zeta; fz.on = 1; fz.has_zeta = has_zeta ? 1 : 0;
     fz.pc_p = p_correct; fz.pc_dt = dt_correct; fz.pc_on = p_correct ? 1 : 0;
-    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
+    if (strict_math(grid)) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
@@ -270,7 +280,7 @@ static int validate_terms(const ocn_grid *grid, const ocn_model_terms *t)
 static int launch_advective_momentum(int advection, const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                      double *Gv, double *Gw, const int32_t *range, hipStream_t s)
 {
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     if (!xy_periodic(grid)) {  // direction-generic kernels (csrc/general.hip)
         const int c2 = advection == OCN_ADVECTION_CENTERED2;
         if (advection == OCN_ADVECTION_UPWIND5)
@@ -294,7 +304,7 @@ static int launch_advective_momentum(int advection, const ocn_grid *grid, const 
 static int launch_advective_tracer(int advection, const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c,
                                    double *Gc, const int32_t *range, hipStream_t s, const TracerFuse *tf)
 {
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     if (!xy_periodic(grid)) {
         if (tf) {
             set_error("the fused tracer stage boundary needs Periodic x and y");
@@ -325,7 +335,7 @@ int ocn_compute_momentum_tendencies_terms(const ocn_grid *grid, const ocn_model_
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw, "ocn_compute_momentum_tendencies_terms: null field pointer");
     OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     hipStream_t s = as_stream(stream);
     st = launch_advective_momentum(terms->advection, grid, u, v, w, Gu, Gv, Gw, range, s);
     if (st != OCN_SUCCESS) return st;
@@ -349,7 +359,7 @@ int ocn_add_momentum_terms(const ocn_grid *grid, const ocn_model_terms *terms, c
     OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && (grid->tz == OCN_FLAT || grid->Hz >= 1), "halo >= 1 required");
     if (!(terms->coriolis || terms->closure || terms->buoyancy)) return OCN_SUCCESS;
     TermsDev t = to_dev(*terms);
-    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
+    return strict_math(grid) ? ocn_strict::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, as_stream(stream))
                                           : ocn_fast::launch_momentum_extra(grid, t, u, v, w, Gu, Gv, Gw, range, as_stream(stream));
 }
 
@@ -446,7 +456,7 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency_terms: null field pointer");
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     hipStream_t s = as_stream(stream);
     st = launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, nullptr);
     if (st != OCN_SUCCESS || !terms->closure) return st;
@@ -474,7 +484,7 @@ int ocn_compute_amd_viscosity(const ocn_grid *grid, double C_nu, const double *u
     int st = validate_amd(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && nu_e, "ocn_compute_amd_viscosity: null field pointer");
-    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream))
+    return strict_math(grid) ? ocn_strict::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream))
                                           : ocn_fast::launch_amd_viscosity(grid, C_nu, u, v, w, nu_e, as_stream(stream));
 }
 
@@ -488,7 +498,7 @@ int ocn_compute_amd_diffusivities(const ocn_grid *grid, double C_nu, const doubl
     OCN_REQUIRE(n_tracers >= 0 && n_tracers <= 4, "ocn_compute_amd_diffusivities: n_tracers = %d outside 0..4", n_tracers);
     OCN_REQUIRE(n_tracers == 0 || (C_kappa && tracers && kappa_e), "ocn_compute_amd_diffusivities: null tracer arrays");
     for (int n = 0; n < n_tracers; ++n) OCN_REQUIRE(tracers[n] && kappa_e[n], "ocn_compute_amd_diffusivities: tracer %d is NULL", n);
-    return g_math_mode == OCN_MATH_STRICT
+    return strict_math(grid)
                ? ocn_strict::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream))
                : ocn_fast::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream));
 }
@@ -506,7 +516,7 @@ int ocn_compute_amd_diffusivities_range(const ocn_grid *grid, double C_nu, const
     OCN_REQUIRE(i_first >= 0 && i_last <= grid->Nx + 1, "ocn_compute_amd_diffusivities_range: i range %d:%d outside 0:%d", i_first, i_last, grid->Nx + 1);
     OCN_REQUIRE((i_first >= 1 && i_last <= grid->Nx) || grid->Hx >= 2, "the halo columns 0 and Nx+1 need Hx >= 2");
     const int32_t ir[2] = {i_first, i_last};
-    return g_math_mode == OCN_MATH_STRICT
+    return strict_math(grid)
                ? ocn_strict::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream), ir)
                : ocn_fast::launch_amd_fused(grid, C_nu, u, v, w, nu_e, n_tracers, C_kappa, tracers, kappa_e, as_stream(stream), ir);
 }
@@ -517,7 +527,7 @@ int ocn_compute_amd_diffusivity(const ocn_grid *grid, double C_kappa, const doub
     int st = validate_amd(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && c && kappa_e, "ocn_compute_amd_diffusivity: null field pointer");
-    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_amd_diffusivity(grid, C_kappa, u, v, w, c, kappa_e, as_stream(stream))
+    return strict_math(grid) ? ocn_strict::launch_amd_diffusivity(grid, C_kappa, u, v, w, c, kappa_e, as_stream(stream))
                                           : ocn_fast::launch_amd_diffusivity(grid, C_kappa, u, v, w, c, kappa_e, as_stream(stream));
 }
 
@@ -622,7 +632,7 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
     mf.sub[1] = SubstepDev{Gmv, v_out};
     mf.sub[2] = SubstepDev{Gmw, w_out};
     mf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     hipStream_t s = as_stream(stream);
     TermsDev t = to_dev(*terms);
     static const bool extra_first = !(std::getenv("OCN_EXTRA_FIRST") && std::getenv("OCN_EXTRA_FIRST")[0] == '0');
@@ -710,7 +720,7 @@ int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_m
     }
     int did = 0;
     hipStream_t s = as_stream(stream);
-    const bool strict = (g_math_mode == OCN_MATH_STRICT);
+    const bool strict = strict_math(grid);
     if (terms->advection == OCN_ADVECTION_WENO5)
         st = strict ? ocn_strict::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did)
                     : ocn_fast::launch_tracer_pair_tendency(grid, u, v, w, c, Gc, range, s, tf, &did);
@@ -824,7 +834,7 @@ int ocn_hydrostatic_momentum_ab2_step(const ocn_grid *grid, const ocn_model_term
     mf.sc = SubstepCoef{dt, 1.5 + chi, -(0.5 + chi), 1, euler ? 0 : 1};
     ocn::HydroFuse hf{eta, gravitational_acceleration, GU, GV, U_star, V_star};
     TermsDev t = to_dev(*terms);
-    return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_hydrostatic_momentum(grid, t, u, v, w, Gu, Gv, mf, hf, as_stream(stream))
+    return strict_math(grid) ? ocn_strict::launch_hydrostatic_momentum(grid, t, u, v, w, Gu, Gv, mf, hf, as_stream(stream))
                                           : ocn_fast::launch_hydrostatic_momentum(grid, t, u, v, w, Gu, Gv, mf, hf, as_stream(stream));
 }
 
@@ -929,9 +939,9 @@ int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const dou
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency: null field pointer");
     if (!xy_periodic(grid))
-        return g_math_mode == OCN_MATH_STRICT ? ocn_strict::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, as_stream(stream))
+        return strict_math(grid) ? ocn_strict::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, as_stream(stream))
                                               : ocn_fast::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, as_stream(stream));
-    if (g_math_mode == OCN_MATH_STRICT) return ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
+    if (strict_math(grid)) return ocn_strict::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
     return ocn_fast::launch_tracer_tendency(grid, u, v, w, c, Gc, range, as_stream(stream));
 }
 
@@ -1061,7 +1071,7 @@ int ocn_halo_pack_pressure(const ocn_grid *grid, const double *p, const double *
     int st = validate_pressure_planes(grid, "ocn_halo_pack_pressure");
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(p && u && send_west && send_east, "ocn_halo_pack_pressure: null pointer");
-    if (g_math_mode == OCN_MATH_STRICT)
+    if (strict_math(grid))
         return ocn_strict::launch_pressure_planes(grid, const_cast<double *>(p), const_cast<double *>(u), dt_correct, send_west, send_east, 0, as_stream(stream));
     return ocn_fast::launch_pressure_planes(grid, const_cast<double *>(p), const_cast<double *>(u), dt_correct, send_west, send_east, 0, as_stream(stream));
 }

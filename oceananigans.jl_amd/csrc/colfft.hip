@@ -542,7 +542,13 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
     switch (Ny / 2) {
         case 64: return launch_realy<64, 16>(inverse, a, stream);
         case 128: return launch_realy<128, 16>(inverse, a, stream);
-        case 256: return launch_realy<256, 16>(inverse, a, stream);
+        case 256: {
+            // 32 columns per workgroup: 256-byte runs of the real rows (rhs / u, v, w / p) instead of 128-byte ones, one workgroup of
+            // 1024 threads and 140 KB of LDS per CU (OCN_REALY_CB = 16 keeps two 16-column workgroups per CU)
+            static const int cb = getenv("OCN_REALY_CB") ? atoi(getenv("OCN_REALY_CB")) : 16;
+            if (cb == 32 && nx >= 32) return launch_realy<256, 32>(inverse, a, stream);
+            return launch_realy<256, 16>(inverse, a, stream);
+        }
         case 512: return launch_realy<512, 8>(inverse, a, stream);
         default: set_error("real y transform of length %d is not supported (128, 256, 512, 1024)", Ny); return OCN_ERR_UNSUPPORTED;
     }

@@ -65,6 +65,10 @@ struct Comm {
     size_t pending_count = 0;
     bool self_via_rccl = false;  // OCN_COMM_SELF_VIA_RCCL=1: a rank's transfers to itself go through ncclSend / ncclRecv too (tests)
     struct LocalGroup *local = nullptr;  // != NULL: the in-process transport below instead of RCCL (ocn_comm_init_local)
+    // ocn_comm_init_replica: this process is rank 0 of `nranks` IDENTICAL ranks (an x-periodic flow of period Lx / nranks): what a peer
+    // would send me is what I send to its mirror image, so every receive is an asynchronous device copy from one of my own send buffers.
+    // Timing of ONE rank of an R-rank run on a one-GPU box with the R-rank schedules, kernels and drivers (tools/bench_dist_rank.py).
+    bool replica = false;
 };
 
 // ---- in-process transport (ocn_comm_init_local): the ranks are THREADS of one process sharing ONE GPU.  RCCL refuses two ranks on one
@@ -352,6 +356,28 @@ int run_schedule(Comm *c, int kind, const double *const *send, double *const *re
     int st = build_schedule(kind, c->rank, c->nranks, c->self_via_rccl, ops, 2 * OCN_COMM_MAX_RANKS, &n);
     if (st != OCN_SUCCESS) return st;
     if (n == 0) return OCN_SUCCESS;
+    if (c->replica) {
+        // the k-th receive from peer s pairs with s's k-th send to me (RCCL's rule) = my k-th send to the mirror peer (R - s) mod R
+        if (kind == OCN_SCHED_ALL_TO_ALL) {
+            ocn::set_error("replica transport: an all-to-all addresses its chunks by absolute rank and has no mirror image (use the transpose-free pressure solve)");
+            return OCN_ERR_UNSUPPORTED;
+        }
+        int taken[OCN_COMM_MAX_RANKS] = {};
+        for (int q = 0; q < n; ++q) {
+            if (!ops[q].is_recv) continue;
+            const int mirror = (c->nranks - ops[q].peer) % c->nranks;
+            int seen = 0, slot = -1;
+            for (int t = 0; t < n && slot < 0; ++t)
+                if (!ops[t].is_recv && ops[t].peer == mirror && seen++ == taken[mirror]) slot = ops[t].slot;
+            if (slot < 0) {
+                ocn::set_error("replica transport: receive %d from rank %d has no matching send to rank %d", q, ops[q].peer, mirror);
+                return OCN_ERR_COMM;
+            }
+            ++taken[mirror];
+            OCN_CHECK_HIP(hipMemcpyAsync(recv[ops[q].slot], send[slot], count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        return OCN_SUCCESS;
+    }
     if (c->local) return local_run_ops(c, ops, n, send, recv, count, stream);
     NcclGroup group;
     OCN_CHECK_NCCL(group.start());
@@ -508,12 +534,36 @@ int ocn_comm_init_local(ocn_comm_t *comm, int32_t rank, int32_t nranks, int64_t 
     return OCN_SUCCESS;
 }
 
+// Rank 0 of `nranks` identical ranks (see Comm::replica): no peer exists; the schedules, pack / unpack launches, stream ordering and
+// drivers are those of an `nranks`-rank run, every transfer is a device copy.  A measurement tool, not a way to run a model.
+int ocn_comm_init_replica(ocn_comm_t *comm, int32_t nranks)
+{
+    OCN_REQUIRE(comm, "ocn_comm_init_replica: null pointer");
+    OCN_REQUIRE(nranks >= 1 && nranks <= OCN_COMM_MAX_RANKS, "ocn_comm_init_replica: 1..%d ranks", OCN_COMM_MAX_RANKS);
+    Comm *c = new Comm();
+    c->rank = 0;
+    c->nranks = nranks;
+    c->west = nranks - 1;
+    c->east = 1 % nranks;
+    c->replica = true;
+    c->self_via_rccl = nranks == 1;  // one rank: its transfers to itself take the schedules too
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        ocn::set_error("ocn_comm_init_replica: stream / event creation failed");
+        delete c;
+        return OCN_ERR_HIP;
+    }
+    *comm = c;
+    return OCN_SUCCESS;
+}
+
 int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl_version)
 {
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c, "ocn_comm_info: null communicator");
     int count = 0, ver = 0;
-    if (c->local) {
+    if (c->local || c->replica) {
         count = c->nranks;  // rccl_version 0: the in-process transport
     } else {
         OCN_CHECK_NCCL(ncclCommCount(c->comm, &count));  // the number of ranks RCCL itself sees
@@ -683,7 +733,7 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
     // at once, instead of the collective's ring (R - 1 hops, each bound by one link).  OCN_COMM_ALL_GATHER=collective selects
     // ncclAllGather (the in-process transport has only the direct form).
     static const bool collective = [] { const char *e = getenv("OCN_COMM_ALL_GATHER"); return e && !strcmp(e, "collective"); }();
-    if (c->local || !collective) {
+    if (c->local || c->replica || !collective) {
         OCN_REQUIRE(c->nranks <= OCN_COMM_MAX_RANKS, "ocn_comm_all_gather: at most %d ranks", OCN_COMM_MAX_RANKS);
         if (!c->self_via_rccl)
             OCN_CHECK_HIP(hipMemcpyAsync(recv + (size_t)c->rank * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -736,6 +786,16 @@ int ocn_comm_allreduce(ocn_comm_t comm, double *buf, size_t count, int32_t op, v
     OCN_REQUIRE(c && buf, "ocn_comm_allreduce: null pointer");
     OCN_REQUIRE(op >= 0 && op <= 2, "ocn_comm_allreduce: op 0 = sum, 1 = max, 2 = min");
     if (c->local) return local_allreduce(c, buf, count, op, as_stream(stream));
+    if (c->replica) {  // identical ranks: max and min are the value itself, the sum is nranks times it
+        if (op != 0 || c->nranks == 1) return OCN_SUCCESS;
+        std::vector<double> h(count);
+        OCN_CHECK_HIP(hipMemcpyAsync(h.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost, as_stream(stream)));
+        OCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+        for (double &x : h) x *= c->nranks;
+        OCN_CHECK_HIP(hipMemcpyAsync(buf, h.data(), count * sizeof(double), hipMemcpyHostToDevice, as_stream(stream)));
+        OCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+        return OCN_SUCCESS;
+    }
     const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
     OCN_CHECK_NCCL(ncclAllReduce(buf, buf, count, ncclDouble, ops[op], c->comm, as_stream(stream)));
     return OCN_SUCCESS;
@@ -752,6 +812,10 @@ int ocn_comm_barrier(ocn_comm_t comm)
     if (c->local) {
         OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
         return local_barrier(c);
+    }
+    if (c->replica) {
+        OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
+        return OCN_SUCCESS;
     }
     OCN_CHECK_NCCL(ncclAllReduce(c->buf[0], c->buf[0], 1, ncclDouble, ncclSum, c->comm, c->stream));
     OCN_CHECK_HIP(hipStreamSynchronize(c->stream));

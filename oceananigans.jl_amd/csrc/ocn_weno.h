@@ -100,28 +100,10 @@ __device__ __forceinline__ double weno3(double S0, double S1, double S2, double 
 #define weno5 weno5_nonlinear_unused
 #define weno3 weno3_nonlinear_unused
 #endif
-__device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
+#if !OCN_STRICT
+// fast-math WENO5 from the five inputs of the selected (mirrored for a right bias) stencil
+__device__ __forceinline__ double weno5_fast_core(double T0, double T1, double T2, double T3, double T4)
 {
-#if OCN_STRICT
-    // left: psi0=(S2,S3,S4) psi1=(S1,S2,S3) psi2=(S0,S1,S2); right: psi0=(S3,S2,S1) psi1=(S4,S3,S2) psi2=(S5,S4,S3)
-    const double a0 = left ? S2 : S3, a1 = left ? S3 : S2, a2 = left ? S4 : S1;
-    const double b0 = left ? S1 : S4, b1 = left ? S2 : S3, b2 = left ? S3 : S2;
-    const double c0 = left ? S0 : S5, c1 = left ? S1 : S4, c2 = left ? S2 : S3;
-    const double be0 = beta3(a0, a1, a2, 10., -31., 11., 25., -19., 4.);
-    const double be1 = beta3(b0, b1, b2, 4., -13., 5., 13., -13., 4.);
-    const double be2 = beta3(c0, c1, c2, 4., -19., 11., 25., -31., 10.);
-    const double tau = fabs(be0 - be2);
-    const double p0 = (OCN_W5P_00 * a0 + OCN_W5P_01 * a1) + OCN_W5P_02 * a2;
-    const double p1 = (OCN_W5P_10 * b0 + OCN_W5P_11 * b1) + OCN_W5P_12 * b2;
-    const double p2 = (OCN_W5P_20 * c0 + OCN_W5P_21 * c1) + OCN_W5P_22 * c2;
-    const double q0 = tau / (be0 + OCN_WENO_EPS), q1 = tau / (be1 + OCN_WENO_EPS), q2 = tau / (be2 + OCN_WENO_EPS);
-    const double al0 = OCN_C5_0 * (1 + q0 * q0), al1 = OCN_C5_1 * (1 + q1 * q1), al2 = OCN_C5_2 * (1 + q2 * q2);
-    const double sa = (al0 + al1) + al2;
-    const double w0 = al0 / sa, w1 = al1 / sa, w2 = al2 / sa;
-    return (w0 * p0 + w1 * p1) + w2 * p2;
-#else
-    // The right-biased stencils are the left-biased ones of the mirrored data: select 5 inputs, then one code path.
-    const double T0 = left ? S0 : S5, T1 = left ? S1 : S4, T2 = left ? S2 : S3, T3 = left ? S3 : S2, T4 = left ? S4 : S1;
     // Everything below is built from the four first differences of the five inputs.
     const double da = T1 - T0, db = T2 - T1, dc = T3 - T2, dd = T4 - T3;
     // smoothness indicators in difference form: the reference polynomial (coefficients 10,-31,11,25,-19,4 etc.) equals
@@ -153,6 +135,41 @@ __device__ __forceinline__ double weno5(double S0, double S1, double S2, double 
     const double p1 = __builtin_fma(1.0 / 3.0, dc, __builtin_fma(1.0 / 6.0, db, T2));
     const double num = __builtin_fma(OCN_C5_2 / 3.0, m2 * (D2 - D1), (OCN_C5_0 / 6.0) * (m0 * (D1 - D0)));
     return __builtin_fma(num, fast_rcp1(den), p1);
+}
+// The same reconstruction for a stencil that sits in LDS (p0 = the element at offset 0 of the line, st = its element stride): the
+// upwind choice selects the ADDRESSES -- element q of the selected stencil is at offset (left ? q - 3 : 2 - q) = c + q d with
+// d = +-st -- so the five inputs are loaded once (5 LDS reads instead of 6) and two 32-bit selects + 4 integer operations replace
+// ten v_cndmask_b32 of the 64-bit value selects.
+__device__ __forceinline__ double weno5_fast_lds(const double *p0, int st, bool left)
+{
+    const int d = left ? st : -st;
+    const double *c = p0 + (left ? -3 * st : 2 * st);
+    return weno5_fast_core(c[0], c[d], c[2 * d], c[3 * d], c[4 * d]);
+}
+#endif
+__device__ __forceinline__ double weno5(double S0, double S1, double S2, double S3, double S4, double S5, bool left)
+{
+#if OCN_STRICT
+    // left: psi0=(S2,S3,S4) psi1=(S1,S2,S3) psi2=(S0,S1,S2); right: psi0=(S3,S2,S1) psi1=(S4,S3,S2) psi2=(S5,S4,S3)
+    const double a0 = left ? S2 : S3, a1 = left ? S3 : S2, a2 = left ? S4 : S1;
+    const double b0 = left ? S1 : S4, b1 = left ? S2 : S3, b2 = left ? S3 : S2;
+    const double c0 = left ? S0 : S5, c1 = left ? S1 : S4, c2 = left ? S2 : S3;
+    const double be0 = beta3(a0, a1, a2, 10., -31., 11., 25., -19., 4.);
+    const double be1 = beta3(b0, b1, b2, 4., -13., 5., 13., -13., 4.);
+    const double be2 = beta3(c0, c1, c2, 4., -19., 11., 25., -31., 10.);
+    const double tau = fabs(be0 - be2);
+    const double p0 = (OCN_W5P_00 * a0 + OCN_W5P_01 * a1) + OCN_W5P_02 * a2;
+    const double p1 = (OCN_W5P_10 * b0 + OCN_W5P_11 * b1) + OCN_W5P_12 * b2;
+    const double p2 = (OCN_W5P_20 * c0 + OCN_W5P_21 * c1) + OCN_W5P_22 * c2;
+    const double q0 = tau / (be0 + OCN_WENO_EPS), q1 = tau / (be1 + OCN_WENO_EPS), q2 = tau / (be2 + OCN_WENO_EPS);
+    const double al0 = OCN_C5_0 * (1 + q0 * q0), al1 = OCN_C5_1 * (1 + q1 * q1), al2 = OCN_C5_2 * (1 + q2 * q2);
+    const double sa = (al0 + al1) + al2;
+    const double w0 = al0 / sa, w1 = al1 / sa, w2 = al2 / sa;
+    return (w0 * p0 + w1 * p1) + w2 * p2;
+#else
+    // The right-biased stencils are the left-biased ones of the mirrored data: select 5 inputs, then one code path.
+    const double T0 = left ? S0 : S5, T1 = left ? S1 : S4, T2 = left ? S2 : S3, T3 = left ? S3 : S2, T4 = left ? S4 : S1;
+    return weno5_fast_core(T0, T1, T2, T3, T4);
 #endif
 }
 
@@ -242,6 +259,19 @@ __device__ __forceinline__ double bias_interp(V val, int idx, int N, bool left)
         }
     }
     return weno5(val(-3), val(-2), val(-1), val(0), val(1), val(2), left);
+}
+
+// biased reconstruction along a Periodic line whose stencil sits in LDS: p0 = the element val(0), st = element stride
+#ifndef OCN_LDS_SELECT
+#define OCN_LDS_SELECT 1
+#endif
+__device__ __forceinline__ double bias_interp_lds(const double *p0, int st, bool left)
+{
+#if !OCN_STRICT && !OCN_UPWIND && OCN_LDS_SELECT
+    return weno5_fast_lds(p0, st, left);
+#else
+    return weno5(p0[-3 * st], p0[-2 * st], p0[-st], p0[0], p0[st], p0[2 * st], left);
+#endif
 }
 
 // grid metrics at Center z-location (spacings_and_areas_and_volumes.jl:106-140, 263-345)

@@ -452,35 +452,35 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         // ---- x-fluxes (consumed by this cell and its WEST neighbour)
         {   // Fuu(i-1): centre i-1 == face i of the shifted line: u[i-3..i+2]
             const double ut = sym_interp_scaled<P, true>([&](int m) { return su[ly][lx + m]; }, ax, i - 1, Nx);
-            myf0 = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+            myf0 = ut * bias_interp_lds(&su[ly][lx], 1, ut > 0);
             ex[0][tid] = myf0;
         }
         {   // Fuv(i): sym y-face of Ax*u ; biased x-face of v
             const double ut = sym_interp_scaled<P, false>([&](int m) { return su[ly + m][lx]; }, ax, j, Ny);
-            myf1 = ut * bias_interp<P, false>([&](int m) { return sv[ly][lx + m]; }, i, Nx, ut > 0);
+            myf1 = ut * bias_interp_lds(&sv[ly][lx], 1, ut > 0);
             ex[1][tid] = myf1;
         }
         {   // Fuw(i): sym z-face of Ax*u (own column) ; biased x-face of w
             const double ut = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zu[2 + m]; }, ax, k, Nz)  // never stretched
                                                  : sym_interp<TZ, false>([&](int m) { return M.Ax(k + m) * zu[2 + m]; }, k, Nz);
-            myf2 = ut * bias_interp<P, false>([&](int m) { return swk[ly][lx + m]; }, i, Nx, ut > 0);
+            myf2 = ut * bias_interp_lds(&swk[ly][lx], 1, ut > 0);
             ex[2][tid] = myf2;
         }
         // ---- y-fluxes (consumed by this cell and its SOUTH neighbour)
         {   // Fvv(j-1)
             const double vt = sym_interp_scaled<P, true>([&](int m) { return sv[ly + m][lx]; }, ay, j - 1, Ny);
-            myf3 = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+            myf3 = vt * bias_interp_lds(&sv[ly][lx], LX, vt > 0);
             ex[3][tid] = myf3;
         }
         {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
             const double vt = sym_interp_scaled<P, false>([&](int m) { return sv[ly][lx + m]; }, ay, i, Nx);
-            myf4 = vt * bias_interp<P, false>([&](int m) { return su[ly + m][lx]; }, j, Ny, vt > 0);
+            myf4 = vt * bias_interp_lds(&su[ly][lx], LX, vt > 0);
             ex[4][tid] = myf4;
         }
         {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
             const double vt = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zv[2 + m]; }, ay, k, Nz)
                                                  : sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
-            myf5 = vt * bias_interp<P, false>([&](int m) { return swk[ly + m][lx]; }, j, Ny, vt > 0);
+            myf5 = vt * bias_interp_lds(&swk[ly][lx], LX, vt > 0);
             ex[5][tid] = myf5;
         }
         // ---- z-fluxes on the top face k+1 and at centre k
@@ -1097,6 +1097,13 @@ static int one_barrier()
     return v;
 }
 
+// 32 x 12 patches (6 waves, 2 workgroups per CU): 31 x 11 of 384 lanes useful (88.8 %) against 31 x 7 of 256 (84.8 %)
+static int tall_tile()
+{
+    static const int v = getenv("OCN_TEND_TALL") ? atoi(getenv("OCN_TEND_TALL")) : 0;
+    return v;
+}
+
 static int xcd_remap()
 {
     static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;  // measured: 4.72 -> 4.60 ms per 512^3 launch
@@ -1188,6 +1195,8 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
             fz.pc_xhalo = grid->tx == OCN_FULLY_CONNECTED;
             if (narrow)
                 launch_tiled<OCN_PERIODIC, 17, 15, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+            else if (tall_tile())
+                launch_tiled<OCN_PERIODIC, 32, 12, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else if (one_barrier() & 1)
                 launch_tiled<OCN_PERIODIC, 32, 8, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
@@ -1200,6 +1209,11 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                 launch_tiled<OCN_PERIODIC, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
                 launch_tiled<OCN_BOUNDED, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+        if (variant == 0 && tall_tile() && grid->tz == OCN_PERIODIC) {
+            launch_tiled<OCN_PERIODIC, 32, 12, false, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }

@@ -10,11 +10,12 @@
 //      p[i-1] - (2 + mu) p[i] + p[i+1] = dx^2 F[i],     mu = dx^2 (ly[ky] + lz[kz]) >= 0,
 // whose eigenvalues are exactly the lx[kx] the reference divides by (poisson_eigenvalues.jl:8-31): solving this cyclic
 // tridiagonal system IS the reference's FFT_x -> divide -> IFFT_x, up to rounding.  It is solved by the partition (SPIKE /
-// Wang) method: every rank solves its local Toeplitz block T = tridiag(1, -(2 + mu), 1) (Thomas, in place), the ranks
-// exchange only the first and last entry of that local solution (2 complex numbers per mode: 4 MB per rank at 512^3
-// instead of 2 x 135-540 MB), every rank solves the circulant 2R x 2R interface system of each mode redundantly (a length-R
-// DFT over the ranks decouples it into 2 x 2 systems) and corrects its block with the two spike vectors, which have the
-// closed form
+// Wang) method: every rank forward-eliminates its local Toeplitz block T = tridiag(1, -(2 + mu), 1) (Thomas, in place) and obtains
+// the first and last entry of the local solution g = T^-1 F from that one pass (xtri_forward_kernel), the ranks exchange only
+// those (2 complex numbers per mode: 4 MB per rank at 512^3 instead of 2 x 135-540 MB), every rank solves the circulant
+// 2R x 2R interface system of each mode redundantly (a length-R DFT over the ranks decouples it into 2 x 2 systems) and back-
+// substitutes its block with the neighbours' values folded into the right-hand side (xtri_backward_kernel): two passes over the
+// spectrum in all.  The spike vectors have the closed form
 //      v_i = T^-1 e_1 = -(r^i - r^(2(n+1)-i)) / (1 - r^(2(n+1))),   w_i = T^-1 e_n = v_(n+1-i),   r + 1/r = 2 + mu, 0 < r < 1.
 // The (ky, kz) = (0, 0) mode (mu = 0, singular: the mean of p is free) is the one line the reference zeroes at kx = 0
 // (distributed_fft_based_poisson_solver.jl:162-164): its right-hand side is gathered whole (nx numbers per rank) and solved
@@ -73,8 +74,11 @@ __device__ __forceinline__ ModeConst mode_const(double mu)
     return c;
 }
 
-// local solve g = T^-1 (dx^2 scale F) in place, boundary values to gsend
-__global__ __launch_bounds__(256) void xtri_sweep_kernel(XTriArgs a)
+// Pass 1 of 2: forward elimination of the local block, d_i = c_i (F_i - d_(i-1)), c_i = 1 / (b - c_(i-1)), stored in place -- and the two
+// numbers the interface system needs, WITHOUT the back substitution: g_n = d_n, and g_1 = e_1' T^-1 F = sum_j v_j F_j (T is symmetric, v
+// the spike of the header), accumulated with P = r^j by products from r and Q = r^(2(n+1)-j) by quotients from r^(2n+1) (where that
+// underflows, Q stays 0 and every term it stands for is below 1e-154).  16 B read + 16 B written per complex element.
+__global__ __launch_bounds__(256) void xtri_forward_kernel(XTriArgs a)
 {
     const long long M = (long long)a.NyH * a.Nz;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,14 +88,16 @@ __global__ __launch_bounds__(256) void xtri_sweep_kernel(XTriArgs a)
     const long long st = a.NyH;  // complex elements between consecutive xl
     cx *p = reinterpret_cast<cx *>(a.a1) + ky + st * ((long long)n * pz);
     cx *gs = reinterpret_cast<cx *>(a.gsend);
-    // mode (0, 0): any positive mu keeps the arithmetic finite; its line is replaced by xtri_finish_kernel
+    // mode (0, 0): any positive mu keeps the arithmetic finite; its line is replaced by xtri_zero_mode_kernel
     const double mu = (m == 0) ? 1.0 : a.dx2 * (a.ly[ky] + a.lz[pz]);
     const ModeConst mc = mode_const(mu);
     const double fs = a.dx2 * a.scale;
+    const double iden = -1.0 / expm1(2.0 * (n + 1) * mc.lnr);  // 1 / (1 - r^(2(n+1)))
+    const double rinv = 1.0 / mc.r;
+    double P = mc.r, Q = exp((2.0 * n + 1.0) * mc.lnr);
     constexpr int B = 8;
-    // ---- forward elimination: c_1 = 1/b, c_i = 1/(b - c_(i-1));  d_i = (F_i - d_(i-1)) c_i
     double c = 0.0;
-    cx d = {0.0, 0.0};
+    cx d = {0.0, 0.0}, g1 = {0.0, 0.0};
     for (int i0 = 0; i0 < n; i0 += B) {
         cx f[B];
 #pragma unroll
@@ -105,41 +111,29 @@ __global__ __launch_bounds__(256) void xtri_sweep_kernel(XTriArgs a)
 #pragma unroll
         for (int q = 0; q < B; ++q)
             if (i0 + q < n) {
+                const cx F = fs * f[q];
                 c = 1.0 / (mc.b - c);
-                d = c * (fs * f[q] - d);
+                d = c * (F - d);
                 f[q] = d;
+                g1 = g1 + (-(P - Q) * iden) * F;
+                P *= mc.r;
+                Q *= rinv;
             }
 #pragma unroll
         for (int q = 0; q < B; ++q)
             if (i0 + q < n) p[st * (i0 + q)] = f[q];
     }
-    // ---- back substitution: x_n = d_n, x_i = d_i - c_i x_(i+1) with c_i = -r (1 - r^2i) / (1 - r^(2i+2)) (the same numbers as above)
-    cx x = d;
-    gs[2 * m + 1] = x;  // g_n
-    const double L2 = 2.0 * mc.lnr;
-    for (int i0 = n - 2; i0 >= 0; i0 -= B) {  // i0: 0-based index of the first element of this batch (descending)
-        cx f[B];
-#pragma unroll
-        for (int q = 0; q < B; ++q)
-            if (i0 - q >= 0) f[q] = p[st * (i0 - q)];
-#pragma unroll
-        for (int q = 0; q < B; ++q)
-            if (i0 - q >= 0) {
-                const double e = expm1(L2 * (double)(i0 - q + 1));  // r^2i - 1, i 1-based
-                const double ci = -mc.r * (-e) / ((-e) + (e + 1.0) * mc.omr2);
-                x = f[q] - ci * x;
-                f[q] = x;
-            }
-#pragma unroll
-        for (int q = 0; q < B; ++q)
-            if (i0 - q >= 0) p[st * (i0 - q)] = f[q];
-    }
-    gs[2 * m] = x;  // g_1 (= g_n when n == 1)
+    gs[2 * m] = g1;
+    gs[2 * m + 1] = d;  // g_n = d_n
 }
 
-// interface system + spike correction (+ the whole line of mode (0, 0))
+// Pass 2 of 2: interface system, then the back substitution of the CORRECTED block in one descending sweep.  With the neighbours'
+// values x0 = x_n of rank - 1 and xn1 = x_1 of rank + 1 the block solves T x = F - e_1 x0 - e_n xn1; forward elimination is linear, so
+// its eliminated right-hand side is d_i - x0 dv_i - xn1 dw_i with dv_i = (-1)^(i-1) prod_(k<=i) c_k = -r^i (1 - r^2) / (1 - r^(2i+2)),
+// dw = c_n e_n, and  x_n = d_n - x0 dv_n - xn1 c_n,  x_i = (d_i - x0 dv_i) - c_i x_(i+1),  c_i = -r (1 - r^2i) / (1 - r^(2i+2)):
+// the spike correction costs no pass of its own (16 B read + 16 B written per complex element; the separate correction was 32 more).
 template <int R>
-__global__ __launch_bounds__(256) void xtri_finish_kernel(XTriArgs a)
+__global__ __launch_bounds__(256) void xtri_backward_kernel(XTriArgs a)
 {
     const long long M = (long long)a.NyH * a.Nz;
     const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,7 +148,7 @@ __global__ __launch_bounds__(256) void xtri_finish_kernel(XTriArgs a)
     const double mu = a.dx2 * (a.ly[ky] + a.lz[pz]);
     const ModeConst mc = mode_const(mu);
     const double den = -expm1(2.0 * (n + 1) * mc.lnr);  // 1 - r^(2(n+1))
-    const double rn = exp(n * mc.lnr), rn1 = rn * mc.r;
+    const double rn = exp(n * mc.lnr);
     const double iden = 1.0 / den;
     const double v1 = -mc.r * (-expm1(2.0 * n * mc.lnr)) * iden;  // -(r - r^(2n+1)) / den
     const double vn = -rn * mc.omr2 * iden;                       // -(r^n - r^(n+2)) / den
@@ -190,37 +184,29 @@ __global__ __launch_bounds__(256) void xtri_finish_kernel(XTriArgs a)
         x0 = x0 + cmul(cx{a.wr[jm], a.wi[jm]}, zh);
         xn1 = xn1 + cmul(cx{a.wr[jp], a.wi[jp]}, ah);
     }
-    // ---- x_i = g_i - v_i x0 - w_i xn1, the elements i and n+1-i together: (r^i, r^(n+1-i)) are each other's pair.  P = r^j by
-    // products from r, Q = r^(n+1-j) by products from r^n: where r^n underflows Q stays 0 and every r^(n+1-j) it stands for is
-    // below 1e-154 for j <= (n+1)/2
-    double P = mc.r, Q = rn;
-    const double rinv = 1.0 / mc.r;
-    constexpr int B = 4;
-    const int half = (n + 1) / 2;  // pairs (j, n+1-j), j = 1..half (the middle element of an odd n pairs with itself)
-    for (int j0 = 1; j0 <= half; j0 += B) {
-        cx lo[B], hi[B];
+    // ---- descending sweep.  em = r^i - 1 by expm1 (no cancellation in 1 - r^2i = -em (2 + em) for the long waves, r -> 1)
+    constexpr int B = 8;
+    cx x = {0.0, 0.0};
+    for (int i0 = n; i0 >= 1; i0 -= B) {  // i0: 1-based index of the first element of this batch (descending)
+        cx f[B];
 #pragma unroll
         for (int q = 0; q < B; ++q)
-            if (j0 + q <= half) {
-                lo[q] = p[st * (j0 + q - 1)];
-                hi[q] = p[st * (n - (j0 + q))];
+            if (i0 - q >= 1) f[q] = p[st * (i0 - q - 1)];
+#pragma unroll
+        for (int q = 0; q < B; ++q)
+            if (i0 - q >= 1) {
+                const int i = i0 - q;
+                const double em = expm1(mc.lnr * (double)i), E = em + 1.0;  // r^i - 1, r^i
+                const double qi = -em * (2.0 + em);                         // 1 - r^2i
+                const double inv = 1.0 / (qi + (E * E) * mc.omr2);          // 1 / (1 - r^(2i+2))
+                const double ci = -mc.r * qi * inv, dvi = -E * mc.omr2 * inv;
+                if (i == n) x = (f[q] - dvi * x0) - ci * xn1;
+                else x = (f[q] - dvi * x0) - ci * x;
+                f[q] = x;
             }
 #pragma unroll
         for (int q = 0; q < B; ++q)
-            if (j0 + q <= half) {
-                const double vj = -(P - rn1 * Q) * iden, wj = -(Q - rn1 * P) * iden;  // v_j = w_(n+1-j), w_j = v_(n+1-j)
-                lo[q] = lo[q] - vj * x0 - wj * xn1;
-                hi[q] = hi[q] - wj * x0 - vj * xn1;
-                P *= mc.r;
-                Q *= rinv;
-            }
-#pragma unroll
-        for (int q = 0; q < B; ++q)
-            if (j0 + q <= half) {
-                const int j = j0 + q;
-                p[st * (j - 1)] = lo[q];
-                if (n - j != j - 1) p[st * (n - j)] = hi[q];
-            }
+            if (i0 - q >= 1) p[st * (i0 - q - 1)] = f[q];
     }
 }
 
@@ -305,7 +291,7 @@ int launch_xtri_sweep(double *a1, const double *ly, const double *lz, int NyH, i
 {
     const XTriArgs a = make_args(a1, ly, lz, NyH, nx, Nz, dx, scale, gsend, nullptr, 0, 1);
     const long long M = (long long)NyH * Nz;
-    hipLaunchKernelGGL(xtri_sweep_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(xtri_forward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, stream, a);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -323,7 +309,7 @@ int launch_xtri_finish(double *a1, const double *ly, const double *lz, int NyH, 
     switch (R) {
 #define OCN_XTRI_CASE(RV)                                                             \
     case RV:                                                                          \
-        hipLaunchKernelGGL(xtri_finish_kernel<RV>, grid, block, 0, stream, a);        \
+        hipLaunchKernelGGL(xtri_backward_kernel<RV>, grid, block, 0, stream, a);        \
         hipLaunchKernelGGL(xtri_zero_mode_kernel<RV>, dim3(1), block, 0, stream, a);  \
         break;
         OCN_XTRI_CASE(1) OCN_XTRI_CASE(2) OCN_XTRI_CASE(3) OCN_XTRI_CASE(4) OCN_XTRI_CASE(5) OCN_XTRI_CASE(6) OCN_XTRI_CASE(7) OCN_XTRI_CASE(8)

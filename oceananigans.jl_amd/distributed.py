@@ -163,6 +163,18 @@ class LocalFabric(RcclFabric):
         self._scratch = None
 
 
+class ReplicaFabric(RcclFabric):
+    """Rank 0 of `size` IDENTICAL ranks (ocn_comm_init_replica): every receive is a device copy from this rank's own send buffer to
+    the mirror-image peer.  Times what one rank of an R-rank run costs before any link time, through the library's R-rank schedules,
+    kernels and C drivers (tools/bench_dist_rank.py); not a way to run a model."""
+
+    def __init__(self, size):
+        self.rank, self.size = 0, int(size)
+        self._h = C.c_void_p()
+        _lib.call("ocn_comm_init_replica", C.byref(self._h), self.size)
+        self._scratch = None
+
+
 def make_distributed(rank=None, world_size=None, local_rank=None, force_communication=None):
     """Distributed(GPU(); partition = Partition(world_size)) with the RCCL transport of libocn_hip.  One process per GPU, started by
     torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment).  A gloo process group

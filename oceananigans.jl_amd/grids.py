@@ -291,7 +291,9 @@ class RectilinearGrid:
         if self._ctor_local:
             raise NotImplementedError("with_halo of a rank-local grid: rebuild it from the global description")
         halo = tuple(int(h) for h, t in zip(new_halo, self.topology) if t != Flat)
-        return RectilinearGrid(self.architecture, halo=halo, **self._ctor)
+        g = RectilinearGrid(self.architecture, halo=halo, **self._ctor)
+        g.c.math = self.c.math
+        return g
 
     # -- sizes ------------------------------------------------------------------------------------
     def parent_shape(self, loc):
@@ -307,6 +309,23 @@ class RectilinearGrid:
     @property
     def cref(self):
         return C.byref(self.c)
+
+    @property
+    def math_mode(self):
+        """None (the process default, ocn.set_math_mode) or MATH_STRICT / MATH_FAST: the arithmetic variant of every kernel launched
+        for this grid (ocn_grid.math)."""
+        return {_lib.GRID_MATH_DEFAULT: None, _lib.GRID_MATH_STRICT: _lib.MATH_STRICT, _lib.GRID_MATH_FAST: _lib.MATH_FAST}[self.c.math]
+
+    def with_math_mode(self, mode):
+        """The same grid (shared device vectors) whose launches use `mode` whatever the process default is: two models of one process
+        may run different arithmetic variants."""
+        import copy
+        if mode not in (None, _lib.MATH_STRICT, _lib.MATH_FAST):
+            raise ValueError(f"math_mode must be None, MATH_STRICT or MATH_FAST, got {mode!r}")
+        g = copy.copy(self)
+        g.c = _lib.CGrid.from_buffer_copy(self.c)
+        g.c.math = {None: _lib.GRID_MATH_DEFAULT, _lib.MATH_STRICT: _lib.GRID_MATH_STRICT, _lib.MATH_FAST: _lib.GRID_MATH_FAST}[mode]
+        return g
 
     def __repr__(self):
         return (f"{self.Nx}x{self.Ny}x{self.Nz} RectilinearGrid on {self.architecture} with "

@@ -150,7 +150,7 @@ class SplitExplicitFreeSurface:
 
 class HydrostaticFreeSurfaceModel:
     def __init__(self, grid, momentum_advection=None, tracer_advection=None, tracers=(), free_surface=None, coriolis=None,
-                 closure=None, buoyancy=None, boundary_conditions=None, fused=None, timestepper="QuasiAdamsBashforth2"):
+                 closure=None, buoyancy=None, boundary_conditions=None, fused=None, timestepper="QuasiAdamsBashforth2", math_mode=None):
         """fused (default: True with VectorInvariant() momentum): one QAB2 step = one pass for the horizontal momentum (tendency, AB2
         step, barotropic forcing and mode), one launch per WENO / UpwindBiased tracer (tendency + AB2 step), the temporally blocked
         substep loop, one pass for the barotropic corrector + w, one halo launch, the hydrostatic pressure; the tendency evaluation
@@ -194,8 +194,9 @@ class HydrostaticFreeSurfaceModel:
         # its pressure solver and w tendency are simply not used
         self._nh = NonhydrostaticModel(grid, advection=container_advection, tracers=tracers, timestepper="QuasiAdamsBashforth2",
                                        closure=closure, buoyancy=buoyancy, coriolis=coriolis, boundary_conditions=boundary_conditions,
-                                       pressure_solver=None)
+                                       pressure_solver=None, math_mode=math_mode)
         nh = self._nh
+        grid = nh.grid  # (halo-inflated / math-mode-pinned by the container model)
         self.grid, self.architecture, self.clock = grid, grid.architecture, nh.clock
         self.free_surface = free_surface
         self.u, self.v, self.w = nh.u, nh.v, nh.w

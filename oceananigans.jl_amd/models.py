@@ -82,7 +82,9 @@ class QuasiAdamsBashforth2TimeStepper(_TendencyStore):
 class NonhydrostaticModel:
     def __init__(self, grid, advection=None, tracers=(), timestepper="RungeKutta3", closure=None, buoyancy=None,
                  coriolis=None, forcing=None, stokes_drift=None, boundary_conditions=None,
-                 hydrostatic_pressure_anomaly="default", pressure_solver="default"):
+                 hydrostatic_pressure_anomaly="default", pressure_solver="default", math_mode=None):
+        """math_mode: None keeps the grid's (default: the process default, ocn.set_math_mode); MATH_STRICT / MATH_FAST pin this
+        model's arithmetic variant whatever other models of the process use (ocn_grid.math)."""
         for name, val in (("forcing", forcing), ("stokes_drift", stokes_drift)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the MI355X hot-path scope (see DESIGN.md)")
@@ -116,6 +118,8 @@ class NonhydrostaticModel:
                                           "adapt_advection_order is not implemented")
         if any(t != Flat and h < required for h, t in zip(H, grid.topology)):
             grid = grid.with_halo(tuple(max(h, required) for h in H))
+        if math_mode is not None:
+            grid = grid.with_math_mode(math_mode)
         self.grid = grid
         self.architecture = grid.architecture
         self.advection = advection

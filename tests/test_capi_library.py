@@ -50,7 +50,7 @@ def test_version_and_math_mode(pkg):
 
 
 def _grid(pkg, **kw):
-    base = dict(Nx=8, Ny=8, Nz=8, Hx=3, Hy=3, Hz=3, tx=0, ty=0, tz=0, _pad=0, dx=1.0, dy=1.0, dz=1.0, Lx=8.0, Ly=8.0, Lz=8.0)
+    base = dict(Nx=8, Ny=8, Nz=8, Hx=3, Hy=3, Hz=3, tx=0, ty=0, tz=0, math=0, dx=1.0, dy=1.0, dz=1.0, Lx=8.0, Ly=8.0, Lz=8.0)
     base.update(kw)
     return pkg._lib.CGrid(**base)
 

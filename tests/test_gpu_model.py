@@ -271,6 +271,75 @@ def test_time_steps_match_oracle(oracle, ocn, size, topo, z, ts, mode):
     assert pm.clock.iteration == 3
 
 
+def test_math_mode_is_a_property_of_the_model(oracle, ocn):
+    """Two models of ONE process with different arithmetic variants (ocn_grid.math): the strict one stays bit-identical to a model run
+    under the strict process default while the process default is FAST and a fast model steps in between; the fast one equals a model
+    run under the FAST default."""
+    O = oracle
+    rng = np.random.default_rng(7)
+    size = (32, 16, 12)
+    og, pg = make_pair(O, ocn, size, "PPP", z=(0, 2.0))
+    init = {n: rng.uniform(-1, 1, size) for n in "uvw"}
+    dt = 0.02 * og.dx
+
+    def run(default, pinned, other=None):
+        ocn.set_math_mode(default)
+        try:
+            m = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), math_mode=pinned)
+            ocn.set(m, **init)
+            o = None
+            if other is not None:
+                o = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), math_mode=other)
+                ocn.set(o, **init)
+            for _ in range(2):
+                ocn.time_step(m, dt)
+                if o is not None:
+                    ocn.time_step(o, dt)
+            ocn.flush_tendencies(m)
+            ocn.sync_device()
+            return [from_dev(f).copy() for f in m.velocities], ([from_dev(f).copy() for f in o.velocities] if o is not None else None)
+        finally:
+            ocn.set_math_mode(ocn.MATH_STRICT)
+
+    ref_strict, _ = run(ocn.MATH_STRICT, None)
+    ref_fast, _ = run(ocn.MATH_FAST, None)
+    assert any(np.abs(a - b).max() > 0 for a, b in zip(ref_strict, ref_fast))  # the variants do differ in the last bits
+    pinned_strict, interleaved_fast = run(ocn.MATH_FAST, ocn.MATH_STRICT, other=ocn.MATH_FAST)
+    for a, b in zip(ref_strict, pinned_strict):
+        assert np.array_equal(a, b)
+    for a, b in zip(ref_fast, interleaved_fast):
+        assert np.array_equal(a, b)
+    assert pg.math_mode is None and ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), math_mode=ocn.MATH_FAST).grid.math_mode == ocn.MATH_FAST
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+def test_config1_two_dimensional_turbulence_at_its_real_size(oracle, ocn, mode):
+    """BASELINE.json configs[0] at its real size: the README example (README.md:111-121) -- 128 x 128 (Periodic, Periodic, Flat), extent
+    2 pi, NonhydrostaticModel with advection = WENO(), RungeKutta3, u, v ~ rand, Dt = 0.01 -- 10 time steps against the oracle, both
+    arithmetic variants.  (The README example also sets a ScalarDiffusivity closure for its long run; the hot path of the benchmark
+    configuration is advection + projection, which is what is compared here.)"""
+    O = oracle
+    rng = np.random.default_rng(1234)
+    og, pg = make_pair(O, ocn, (128, 128, 1), "PPF", x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=None, halo=(3, 3, 0))
+    om = O.NonhydrostaticModel(og, timestepper="RungeKutta3")
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), math_mode=ocn.MATH_STRICT if mode == "strict" else ocn.MATH_FAST)
+    init = {"u": rng.uniform(0, 1, og.interior(om.u).shape), "v": rng.uniform(0, 1, og.interior(om.v).shape), "w": np.zeros(og.interior(om.w).shape)}
+    om.set(**init)
+    ocn.set(pm, **init)
+    for _ in range(10):
+        om.time_step(0.01)
+        ocn.time_step(pm, 0.01)
+    ocn.sync_device()
+    tol = 1e-11 if mode == "strict" else 1e-10
+    scale = max(np.abs(om.u).max(), np.abs(om.v).max())
+    for name, a, d in zip("uv", (om.u, om.v), pm.velocities):
+        err = np.abs(og.interior(from_dev(d)) - og.interior(a)).max()
+        assert err <= tol * scale, f"{name}: {err} > {tol * scale}"
+    assert float(pm.w.data.abs().max()) == 0.0  # Gw = 0 and w stays 0 on a Flat z (flat_advective_fluxes.jl:8-44)
+    assert np.abs(og.interior_N(from_dev(pm.pNHS)) - og.interior_N(om.p)).max() <= 1e-10 * max(1.0, np.abs(om.p).max())
+    assert pm.clock.iteration == 10
+
+
 def test_first_ab2_step_is_euler(ocn):
     """test_time_stepping.jl:90-118 idea: with Δt != last_Δt the QAB2 step is forward Euler (χ = -0.5), so
     u¹ = u⁰ + Δt G⁰ exactly before the projection; here checked through the kernel entry."""

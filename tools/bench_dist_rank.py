@@ -9,7 +9,8 @@ the per-rank compute + host time of an R-GPU step with the communication itself 
 
   tools/bench_dist_rank.py [N] [R] [steps] [workload]      workload = box (512^3-style periodic) | config4 (P,P,B stretched, advection only) | config4amd (its full physics) |
                                                           config5 (2N x 2N x N/4 HydrostaticFreeSurfaceModel as bench.py --workload config5) |
-                                                          driver / driver4 (one C call per rank-step over a one-rank RCCL world: box / config 4's term set)
+                                                          driver / driver4 (one C call per rank-step through the library's replica transport, ocn_comm_init_replica:
+                                                          rank 0 of R identical ranks with the R-rank schedules, pipelines and interface systems: box / config 4's term set)
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -61,14 +62,7 @@ class LoopbackFabric:
 ocn.set_math_mode(ocn.MATH_FAST)
 if workload == "driver4":
     # the same for config 4's term set (ocn_model_driver_create_distributed): a (N / R) x N x (N / 2) slab, stretched Bounded z, AMD, T, S
-    import socket
-    import torch.distributed as dist
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=0, world_size=1)
-    arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
+    arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=ocn.distributed.ReplicaFabric(R), force_communication=True)
     nx, Nz = N // R, N // 2
     Lz, refinement, stretching = 32.0, 1.2, 12.0
     h = lambda k: (k - 1) / Nz
@@ -76,7 +70,7 @@ if workload == "driver4":
                         for k in range(1, Nz + 2)])
 
     def build():
-        g = ocn.RectilinearGrid(arch, size=(nx, N, Nz), x=(0, 64 / R), y=(0, 64), z=z_faces, topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+        g = ocn.RectilinearGrid(arch, size=(N, N, Nz), x=(0, 64), y=(0, 64), z=z_faces, topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
         Q, rho, cp, dTdz = 200.0, 1026.0, 3991.0, 0.01
         bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-1.225 / rho * 2.5e-3 * 10 * 10)),
                "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(Q / (rho * cp)), bottom=ocn.GradientBoundaryCondition(dTdz)),
@@ -119,19 +113,10 @@ if workload == "driver4":
         del m
     sys.exit(0)
 if workload == "driver":
-    # ONE C call per step (ocn_rk3_driver_create_distributed): a slab of the R-rank size as a one-rank RCCL world that exchanges with itself
-    # (force_communication) -- the same kernels at the same local size as one rank of R (the interface systems of the x solve are those
-    # of one rank instead of R), every collective issued by the library.  What it shows: the host enqueue time per rank-step.
-    import socket
-    import torch.distributed as dist
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=0, world_size=1)
-    arch = ocn.distributed.make_distributed(0, 1, 0, force_communication=True)
-    nx = N // R
-    g = ocn.RectilinearGrid(arch, size=(nx, N, N), x=(0, 2 * np.pi / R), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=("Periodic",) * 3, halo=(3, 3, 3))
+    # ONE C call per step (ocn_rk3_driver_create_distributed) on rank 0 of R identical ranks (the library's replica transport): the
+    # kernels, schedules, pressure pipeline (transpose-free for R > 1) and interface systems of an R-rank run, every transfer a device copy.
+    arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=ocn.distributed.ReplicaFabric(R), force_communication=True)
+    g = ocn.RectilinearGrid(arch, size=(N, N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=("Periodic",) * 3, halo=(3, 3, 3))
     m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
     for f in m.velocities:
@@ -139,7 +124,11 @@ if workload == "driver":
         v.copy_(2 * torch.rand(v.shape, generator=gen, device="cuda", dtype=torch.float64) - 1)
     ocn.set(m)
     dt = 0.1 * g.dx / max(float(f.interior_view().abs().max()) for f in m.velocities)
-    for name, stepper, flush in (("python host", lambda: ocn.time_step(m, dt), lambda: ocn.flush_tendencies(m)), ("C driver", None, None)):
+    variants = (("python host", lambda: ocn.time_step(m, dt), lambda: ocn.flush_tendencies(m)), ("C driver", None, None))
+    only = os.environ.get("OCN_BDR_ONLY")  # "c" / "python": one host only (kernel traces)
+    if only:
+        variants = tuple(v for v in variants if v[0][0].lower() == only[0].lower())
+    for name, stepper, flush in variants:
         if stepper is None:
             drv = ocn.RK3Driver(m)
             stepper, flush = (lambda: drv.time_step(dt)), drv.flush
