@@ -34,6 +34,9 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ALGO_BYTES_PER_CELL_STEP = 1680.0  # 560 + 584 + 536 B per cell per RK3 step (REFERENCE kernel decomposition)
+# THIS backend's compulsory traffic per cell per RK3 step on one GPU: per stage the fused tendency launch with the
+# correction on load and the substep epilogue (104) + the 5-pass Poisson pipeline (104) = 208; three identical stage boundaries per step
+BACKEND_BYTES_PER_CELL_STEP = 624.0
 TENDENCY_BYTES_PLAIN = 48.0        # fused compute_Gu/Gv/Gw launch: read u, v, w once, write Gu, Gv, Gw (fp64)
 TENDENCY_BYTES_IN_STEP = 104.0     # as the step runs it: + p (correction on load) + G- read + U_out (3) write + ...
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -229,6 +232,19 @@ def event_time(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+def mapped_libraries(pattern):
+    """Files matching `pattern` that are mapped into this process (/proc/self/maps): which librccl.so / libocn_hip.so actually run."""
+    out = []
+    try:
+        for ln in open("/proc/self/maps"):
+            path = ln.split(None, 5)[-1].strip() if ln.count(" ") >= 5 else ""
+            if pattern in os.path.basename(path) and path not in out:
+                out.append(path)
+    except OSError:
+        pass
+    return out
+
+
 def preflight(a, rank, world, local_rank, stdout_fd):
     """Everything a multi-GPU launch needs BEFORE the first GPU call, so that plumbing cannot be what fails on the 8-GPU node: the ranks
     exist and agree on the world, the gloo rendezvous on MASTER_ADDR:MASTER_PORT works, rank 0's RCCL unique id (ncclGetUniqueId needs
@@ -246,6 +262,12 @@ def preflight(a, rank, world, local_rank, stdout_fd):
             "ocn_halo_exchange_pressure", "ocn_comm_all_gather", "ocn_comm_all_to_all", "ocn_dist_poisson_create", "ocn_comm_schedule"]
     checks["library_symbols"] = all(hasattr(lib, n) for n in need)
     checks["ipc_mode_env"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    # ONE librccl in the process, and the one this host always binds: libocn_hip.so names librccl.so.1 and `import torch` has mapped
+    # its bundled copy first, so the loader resolves the name to that file (a plain-C host binds /opt/rocm/lib's through the rpath)
+    rccl_files = mapped_libraries("librccl")
+    import torch as _torch
+    checks["one_librccl_mapped"] = len(rccl_files) == 1
+    checks["librccl_is_torch_bundled"] = len(rccl_files) == 1 and os.path.dirname(rccl_files[0]) == os.path.join(os.path.dirname(_torch.__file__), "lib")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     checks["master_addr_is_loopback_or_set"] = bool(os.environ["MASTER_ADDR"])
@@ -293,7 +315,7 @@ def preflight(a, rank, world, local_rank, stdout_fd):
     flag = torch.tensor([1 if all_ok else 0], dtype=torch.int64)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     out = {"preflight": "ok" if int(flag[0]) == 1 else "FAILED", "ranks": world, "local_ranks_seen": [int(v) - 1 for v in ranks],
-           "visible_devices": ndev, "checks_rank0": checks, "master": f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
+           "visible_devices": ndev, "checks_rank0": checks, "librccl": rccl_files, "master": f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
            "gpu_touched": False}
     dist.barrier()
     dist.destroy_process_group()
@@ -340,6 +362,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         arch = ocn.distributed.make_distributed(rank, world, local_rank)  # RCCL behind the C ABI (ocn_comm_*); gloo only bootstraps
         comm_info = arch.fabric.info()
+        comm_info["library"] = mapped_libraries("librccl")  # the file(s) RCCL calls resolve to in this process (preflight asserts: one)
+        comm_info["libocn_hip"] = mapped_libraries("libocn_hip")
         dist = arch.fabric
     else:
         dist = None
@@ -355,6 +379,7 @@ def main():
         gen.manual_seed(1234 + field_counter[0])
         field_counter[0] += 1
         nz_, ny_, nx_ = shape
+        # (the whole global field is materialised on every rank -- a 1 GiB temporary per field at 512^3 -- and sliced: simple and rank-count independent)
         full = torch.rand((nz_, ny_, nx_ * world), generator=gen, device="cuda", dtype=torch.float64)
         out = (full[:, :, rank * nx_:(rank + 1) * nx_] * 2 - 1).contiguous()
         del full
@@ -429,24 +454,41 @@ def main():
         else:
             step, flush = (lambda: ocn.time_step(model, dt)), (lambda: ocn.flush_tendencies(model))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    sync_timeout = float(os.environ.get("OCN_BENCH_SYNC_TIMEOUT_S", "300"))
 
-    def timed(nsteps):
+    def die(msg):
+        """A rank that cannot finish (a collective whose peer never arrived) reports and exits non-zero: no retry, no re-exec."""
+        print(f"[bench] rank {rank} of {world}: {msg}", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def barrier():
+        try:
+            # host waits with a deadline (ocn_sync_timeout polls an event; ocn_comm_barrier's all-reduce is waited for the same way)
+            ocn._lib.call("ocn_sync_timeout", ocn.architectures.stream_ptr(), sync_timeout)  # (torch's current stream: every launch of a step)
+            if dist is not None:
+                dist.barrier()
+        except ocn.OcnError as e:
+            die(str(e))
+
+    def timed(nsteps, mark=False):
         barrier()
+        if mark:  # two empty marker launches delimit the timed steps in rocprofv3's per-dispatch output (tools/summarize_profile.py)
+            ocn._lib.call("ocn_profile_marker", ocn.architectures.stream_ptr())
+            barrier()
         t0 = time.perf_counter()
         for _ in range(nsteps):
             step()
         flush()  # the deferred last compute_tendencies! belongs to the timed steps
         barrier()
-        return time.perf_counter() - t0
+        el_ = time.perf_counter() - t0
+        if mark:
+            ocn._lib.call("ocn_profile_marker", ocn.architectures.stream_ptr())
+        return el_
 
     for _ in range(a.warmup):
         step()
     flush()
-    el = timed(a.steps)
+    el = timed(a.steps, mark=True)
     if dist is not None:
         el = float(dist.allreduce_max(torch.tensor([el], device="cuda", dtype=torch.float64))[0])
     finite = bool(all(torch.isfinite(f.data).all() for f in prognostic))
@@ -454,9 +496,39 @@ def main():
     # initial fields do not depend on the number of ranks, so a --gpus N line can be checked against the --gpus 1 line of the same
     # command (agreement to ~1e-9 relative: the pressure solvers of the two paths differ in rounding).
     sums = torch.stack([(f.interior_view() ** 2).sum() for f in prognostic])
+    checksum_global = True
     if dist is not None:
-        sums = dist.allreduce_sum(sums) if hasattr(dist, "allreduce_sum") else sums
+        if hasattr(dist, "allreduce_sum"):
+            sums = dist.allreduce_sum(sums)
+        else:
+            checksum_global = False  # a transport without a sum all-reduce: the sums are this rank's only
     checksum = [float(v) for v in sums]
+
+    # where a multi-GPU step spends its exchange time, measured on the device by the library (ocn_comm_enable_stats): 3 more steps
+    comm_stats = None
+    if dist is not None and hasattr(dist, "_h"):
+        try:
+            import ctypes as C
+            ocn._lib.call("ocn_comm_enable_stats", dist._h, 1)
+            nstat = 3
+            for _ in range(nstat):
+                step()
+            flush()
+            barrier()
+            ms = (C.c_double * 8)()
+            ocn._lib.call("ocn_comm_stats", dist._h, ms)
+            ocn._lib.call("ocn_comm_enable_stats", dist._h, 0)
+            mine = torch.tensor(list(ms)[:5], device="cuda", dtype=torch.float64) / nstat
+            worst = dist.allreduce_max(mine.clone())
+            comm_stats = {"steps": nstat, "what": "device-side ms per step, rank 0 / max over ranks (events around each exchange on the stream it runs on)",
+                          "strip_exchange_on_comm_stream_ms": [float(mine[0]), float(worst[0])],
+                          "halo_wait_on_compute_stream_ms": [float(mine[1]), float(worst[1])],
+                          "pressure_solve_exchange_ms": [float(mine[2]), float(worst[2])],
+                          "pressure_plane_exchange_ms": [float(mine[3]), float(worst[3])],
+                          "single_plane_exchange_ms": [float(mine[4]), float(worst[4])],
+                          "strip_exchanges_per_step": ms[5] / nstat, "solve_exchanges_per_step": ms[6] / nstat}
+        except ocn.OcnError as e:
+            die(str(e))
 
     # the bit-exact (strict IEEE, reference operand order) build of the same step, driver-visible
     strict_ms = None
@@ -469,8 +541,6 @@ def main():
             strict_ms = float(dist.allreduce_max(torch.tensor([strict_ms], device="cuda", dtype=torch.float64))[0])
         ocn.set_math_mode(ocn.MATH_FAST)
 
-    if a.driver == "auto":
-        a.driver = "python"
     local_cells = grid.Nx * grid.Ny * grid.Nz
     cells = Nx * (Nx if hydro else N) * Nz
     value = cells * a.steps / el
@@ -511,17 +581,24 @@ def main():
         ref_ms = in_step_ms if in_step_ms is not None else plain_ms
         instr = pk.get("SQ_INSTS_VALU")  # VALU wave-instructions per launch of the profiled variant (committed PMC pass)
         achieved = None if instr is None else instr * (local_cells / prof.get("cells", local_cells)) / (ref_ms * 1e-3) / 1e9
+        # achieved = ALGORITHMIC HBM bytes of the launch / its live duration, against the 8 TB/s roofline.  The kernel is
+        # bound by fp64 VALU issue (9 WENO5 reconstructions per cell), so this fraction is low by construction; `valu` carries the issue-
+        # rate figures (VALU wave-instructions per launch from the committed --pmc pass / the live launch time).
+        algo_bytes = in_step_bytes if in_step_ms is not None else TENDENCY_BYTES_PLAIN
+        hbm_achieved = algo_bytes * local_cells / (ref_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "valu_fp64", "kernel": "momentum_tendencies_tiled (fused compute_Gu/Gv/Gw, WENO5)",
-            "achieved": achieved, "peak": VALU_PEAK_GWAVEINSTR, "unit": "G wave-instr/s",
-            "frac": None if achieved is None else achieved / VALU_PEAK_GWAVEINSTR,
-            # SURVEY 8(d)'s definition of the same launch: algorithmic HBM bytes / launch time / 8 TB/s (the kernel is VALU-bound, so this is low by construction)
-            "frac_hbm": (in_step_bytes * local_cells / (in_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if in_step_ms is not None
-                        else TENDENCY_BYTES_PLAIN * local_cells / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "sustained_GHz": pk.get("clock_GHz_under_pmc"),  # GRBM_GUI_ACTIVE / 8 XCDs / launch time of the committed PMC pass
-            "traffic": pk.get("traffic_bytes"),
+            "bound": "hbm", "kernel": "momentum_tendencies_tiled (fused compute_Gu/Gv/Gw, WENO5)",
+            "achieved": hbm_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBPS,
+            "traffic": pk.get("traffic_bytes"),  # measured HBM bytes per launch (FETCH_SIZE + WRITE_SIZE of the committed --pmc passes, calibrated)
+            "algorithmic_bytes_per_cell": algo_bytes, "cells_per_launch": local_cells,
             "kernel_ms": ref_ms, "variant": "in-step (correction on load + substep epilogue)" if in_step_ms is not None else "plain",
-            "valu_wave_instr_per_launch": instr, "valu_busy_frac_pmc": pk.get("valu_busy"),
+            "frac_hbm": hbm_achieved / HBM_PEAK_GBPS,  # (same number; kept under the name earlier records use)
+            "valu": {"bound": "valu_fp64", "achieved": achieved, "peak": VALU_PEAK_GWAVEINSTR, "unit": "G wave-instr/s",
+                     "frac": None if achieved is None else achieved / VALU_PEAK_GWAVEINSTR,
+                     "sustained_GHz": pk.get("clock_GHz_under_pmc"),  # GRBM_GUI_ACTIVE / 8 XCDs / launch time of the committed PMC pass
+                     "valu_wave_instr_per_launch": instr, "valu_busy_frac_pmc": pk.get("valu_busy"),
+                     "note": "the limiter of this kernel: VALU wave-instructions per launch (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass "
+                             "named in pmc_source) / the launch time measured live here; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"},
             "hbm": {"in_step": None if in_step_ms is None else {
                         "algorithmic_bytes_per_cell": in_step_bytes, "kernel_ms": in_step_ms,
                         "achieved_GBps": in_step_bytes * local_cells / (in_step_ms * 1e-3) / 1e9,
@@ -532,10 +609,7 @@ def main():
                               "frac": TENDENCY_BYTES_PLAIN * local_cells / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                               "measured_bytes_per_cell": kern.get("plain", {}).get("traffic_bytes_per_cell")},
                     "peak_GBps": HBM_PEAK_GBPS},
-            "pmc_source": prof_path,
-            "note": "the kernel is bound by fp64 VALU issue, not HBM: `achieved` = VALU wave-instructions per launch (SQ_INSTS_VALU of the "
-                    "committed rocprofv3 --pmc pass named in pmc_source) / the launch time measured live here; peak = 1024 SIMDs x 2.4 GHz "
-                    "/ 4 cycles per wave64 instruction.  `hbm` gives the same launches against the 8 TB/s HBM roofline."}
+            "pmc_source": prof_path}
         if a.workload == "config4":
             measured = None if prof is None else prof.get("step_bytes_per_cell")
             step_roofline = {"measured_bytes_per_cell_step": measured,  # committed PMC passes of this workload (set! and warm-up launches included)
@@ -545,9 +619,14 @@ def main():
         if a.workload == "box":
             measured = None if prof is None else prof.get("step_bytes_per_cell")
             step_roofline = {
-                "measured_bytes_per_cell_step": measured,  # sum over the step's launches of FETCH_SIZE + WRITE_SIZE (committed PMC passes)
+                "measured_bytes_per_cell_step": measured,  # sum over the TIMED steps' launches of FETCH_SIZE + WRITE_SIZE (committed PMC passes, marker-delimited)
                 "measured_GBps": None if measured is None else measured * value / 1e9,
                 "frac_of_8TBps": None if measured is None else measured * value / 1e9 / (HBM_PEAK_GBPS * world),
+                "algorithmic_bytes_per_cell_step": BACKEND_BYTES_PER_CELL_STEP,  # THIS backend's compulsory traffic (3 x (104 tendency launch + 104 Poisson pipeline))
+                "algorithmic_GBps": BACKEND_BYTES_PER_CELL_STEP * value / 1e9,
+                "algorithmic_frac_of_8TBps": BACKEND_BYTES_PER_CELL_STEP * value / 1e9 / (HBM_PEAK_GBPS * world),
+                "measured_over_algorithmic": None if measured is None else measured / BACKEND_BYTES_PER_CELL_STEP,
+                "measured_window": None if prof is None else prof.get("window"),
                 "reference_decomposition_bytes_per_cell_step": ALGO_BYTES_PER_CELL_STEP,
                 "reference_equivalent_GBps": ALGO_BYTES_PER_CELL_STEP * value / 1e9,  # what the REFERENCE's launch sequence would have to move at this step rate; not HBM traffic of this backend
                 "pmc_source": prof_path}
@@ -603,7 +682,8 @@ def main():
                    "all_gather": os.environ.get("OCN_COMM_ALL_GATHER", "direct") if world > 1 else None,
                    "state_checksum": {"sum_of_squares": checksum, "fields": "prognostic fields in model order, global interior",
                                       "after_steps": a.warmup + a.steps,
-                                      "comparable_across_n_gpus": True}},
+                                      "comparable_across_n_gpus": checksum_global}},
+        "comm_stats": comm_stats,
         "strict_ms_per_step": strict_ms,
         "roofline": roofline,
         "step_roofline": step_roofline,

@@ -44,6 +44,7 @@ extern "C" {
 #define OCN_ERR_ROCFFT (-4)
 #define OCN_ERR_ALLOC (-5)
 #define OCN_ERR_COMM (-6) /* an RCCL call failed */
+#define OCN_ERR_TIMEOUT (-7) /* ocn_sync_timeout / ocn_comm_wait: the device work did not finish within the deadline */
 
 /* topology codes: src/Grids/Grids.jl Periodic / Bounded / Flat */
 #define OCN_PERIODIC 0
@@ -95,6 +96,15 @@ int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* device_copy_to! */
 int ocn_memset(void *ptr, int value, size_t bytes, void *stream);
 int ocn_sync(void *stream);                          /* sync_device! */
+/* sync_device! with a host-side deadline: polls the stream (no blocking wait) and returns OCN_ERR_TIMEOUT after `seconds` -- a
+ * stuck collective of a multi-GPU run must end in an error of THIS rank, not in a hang (the caller exits non-zero; nothing is
+ * retried or re-executed). */
+int ocn_sync_timeout(void *stream, double seconds);
+/* Measurement aid: an empty one-thread kernel (`ocn::profile_marker_kernel`) whose dispatches delimit a region of interest in
+ * rocprofv3's per-dispatch output (kernel trace and --pmc passes carry no other marker: marker trace domains cannot be combined with
+ * counter collection on this pool).  bench.py brackets its timed steps with two of them; tools/summarize_profile.py sums what lies
+ * between.  Replaces nothing in the reference. */
+int ocn_profile_marker(void *stream);
 
 /* Process default of the arithmetic variant (every kernel compiled in two variants: tendencies, extra terms, AMD, hydrostatic momentum),
  * used by grids whose `math` field is OCN_GRID_MATH_DEFAULT.  Atomic; handles created from a grid keep that grid's `math`. */
@@ -645,6 +655,20 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
 int ocn_dist_poisson_exchange(ocn_dist_poisson_t solver, ocn_comm_t comm, int32_t direction, void *stream);
 int ocn_comm_allreduce(ocn_comm_t comm, double *buffer, size_t count, int32_t op /* 0 sum, 1 max, 2 min */, void *stream);
 int ocn_comm_barrier(ocn_comm_t comm);
+/* Device-side timing of the exchanges, for diagnosing a multi-GPU run (off by default: timing events cost a little per call).  While
+ * enabled, every exchange is bracketed by events on the stream it runs on; ocn_comm_stats synchronises the device, adds up the
+ * elapsed milliseconds per category since the last call and clears them.  out_ms[8]:
+ *   [0] strip exchange on the communication stream (grouped send / recv of ocn_halo_exchange_begin: link time + peer skew)
+ *   [1] what the CALLER's stream waited at ocn_halo_exchange_end (0 when the exchange was hidden under the pressure solve)
+ *   [2] all-gather / all-to-all of the pressure solve (in stream order: on the critical path)
+ *   [3] pressure-plane exchange of the correction-on-load stage (in stream order)
+ *   [4] single-plane exchanges (in stream order)
+ *   [5] number of strip exchanges, [6] number of all-gathers / all-to-alls, [7] reserved */
+int ocn_comm_enable_stats(ocn_comm_t comm, int32_t enable);
+int ocn_comm_stats(ocn_comm_t comm, double *out_ms);
+/* Host-side wait for the communication stream with a deadline: OCN_ERR_TIMEOUT if the exchanges posted so far have not completed
+ * within `seconds` (a peer that never posted its half). */
+int ocn_comm_wait(ocn_comm_t comm, double seconds);
 
 /* The same one-call RK3 time_step! for ONE RANK of a slab-x run (Distributed(GPU(); partition = Partition(R)),
  * distributed_architectures.jl:167-297): local (FullyConnected, Periodic, Periodic) grid, the rank's ocn_dist_poisson_t (slab

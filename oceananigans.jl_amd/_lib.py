@@ -180,6 +180,11 @@ _SIGS = {
     "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
     "ocn_comm_init_local": [C.POINTER(_vp), _i32, _i32, C.c_int64],
     "ocn_comm_init_replica": [C.POINTER(_vp), _i32],
+    "ocn_comm_enable_stats": [_vp, _i32],
+    "ocn_comm_stats": [_vp, C.POINTER(C.c_double)],
+    "ocn_comm_wait": [_vp, C.c_double],
+    "ocn_sync_timeout": [_vp, C.c_double],
+    "ocn_profile_marker": [_vp],
     "ocn_comm_destroy": [_vp],
     "ocn_comm_info": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
     "ocn_halo_exchange_begin": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],

@@ -149,6 +149,13 @@ int ocn_sync(void *stream)
     return OCN_SUCCESS;
 }
 
+int ocn_sync_timeout(void *stream, double seconds)
+{
+    return ocn::wait_stream(as_stream(stream), seconds, "ocn_sync_timeout");
+}
+
+int ocn_profile_marker(void *stream) { return ocn::launch_profile_marker(as_stream(stream)); }
+
 int ocn_set_math_mode(int mode)
 {
     OCN_REQUIRE(mode == OCN_MATH_STRICT || mode == OCN_MATH_FAST, "unknown math mode %d", mode);

@@ -155,6 +155,28 @@ __device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, 
     radix8<true>(x);
 }
 
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with its own L2.  Column blocks that are neighbours
+// in memory share the cache lines their runs straddle (rows of Nx/2 + 1 = 257 complex numbers or of haloed reals are never line-
+// aligned: a 128-byte run touches two lines, both shared with a neighbour), so with the plain mapping every such line is fetched into two
+// L2s and written back from two as partial lines.  Hardware workgroup b (XCD b % 8) takes the logical block start_(b % 8) + b / 8:
+// each XCD walks its own contiguous range of blocks (x-fastest) and meets its neighbours' lines in its own L2.  A bijection for any n.
+__device__ __forceinline__ void xcd_block(int on, unsigned &bx, unsigned &by)
+{
+    bx = blockIdx.x; by = blockIdx.y;
+    if (!on) return;
+    const unsigned nx = gridDim.x, n = nx * gridDim.y;
+    const unsigned b = bx + nx * by;
+    const unsigned q = b & 7u, chunk = n >> 3, rem = n & 7u;
+    const unsigned logical = q * chunk + (q < rem ? q : rem) + (b >> 3);
+    bx = logical % nx;
+    by = logical / nx;
+}
+static int fft_xcd_remap()
+{
+    static const int v = getenv("OCN_FFT_XCD") ? atoi(getenv("OCN_FFT_XCD")) : 1;
+    return v;
+}
+
 struct ColFFTArgs {
     double *data;            // complex interleaved
     long long col_stride;    // elements between consecutive points of one column
@@ -169,6 +191,7 @@ struct ColFFTArgs {
     double scale;
     int inner;               // number of kx per ky
     int zero_mode;           // MODE 2: this launch holds the (0,0,0) mode (column 0 of batch 0, position 0) and zeroes it
+    int xcd;                 // XCD-contiguous block order (xcd_block)
 };
 
 // MODE 0: forward (natural -> stage order), 1: inverse (stage order -> natural), 2: forward, spectral solve, inverse
@@ -180,8 +203,10 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     cplx *A = reinterpret_cast<cplx *>(lds_raw);          // N * CB exchange buffer, layout [e][c]
     cplx *W = reinterpret_cast<cplx *>(lds_raw) + N * CB;  // twiddle table
     const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
-    const int col0 = blockIdx.x * CB;
-    const int batch = blockIdx.y;
+    unsigned lbx, lby;
+    xcd_block(a.xcd, lbx, lby);
+    const int col0 = lbx * CB;
+    const int batch = lby;
     for (int j = tid; j < N; j += CB * T) W[j] = reinterpret_cast<const cplx *>(a.tw)[j];
     const bool active = (col0 + c) < a.ncols;
     cplx *base = reinterpret_cast<cplx *>(a.data) + (long long)batch * a.batch_stride + (col0 + (active ? c : 0));
@@ -279,7 +304,7 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
                   hipStream_t stream, int zero_mode)
 {
-    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode};
+    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode, fft_xcd_remap()};
     switch (N) {
         case 64: return launch_n<64, 16>(mode, a, stream);
         case 128: return launch_n<128, 16>(mode, a, stream);
@@ -340,6 +365,7 @@ struct RealYArgs {
     long long chunk;
     int scale_dz;        // source term times Δzᶜ (solve_for_pressure.jl:33-38)
     double scale;        // inverse: applied to the real output
+    int xcd;             // XCD-contiguous block order (xcd_block)
     __device__ __forceinline__ long long spec_at(int k, int xl, int z, int NYH) const
     {
         if (kc == 0) return k + (long long)NYH * (xl + (long long)nx * z);
@@ -373,7 +399,9 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
     cplx *W = A + CB * NYH;
     cplx *WN = W + H;
     const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
-    const int col0 = blockIdx.x * CB, z = blockIdx.y;
+    unsigned lbx, lby;
+    xcd_block(a.xcd, lbx, lby);
+    const int col0 = lbx * CB, z = lby;
     for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
     for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
     const bool active = (col0 + c) < a.nx;
@@ -421,7 +449,9 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_inv_kernel(RealYArgs a)
     cplx *W = A + CB * NYH;
     cplx *WN = W + H;
     const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
-    const int col0 = blockIdx.x * CB, z = blockIdx.y;
+    unsigned lbx, lby;
+    xcd_block(a.xcd, lbx, lby);
+    const int col0 = lbx * CB, z = lby;
     for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
     for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
     const cplx *in = reinterpret_cast<const cplx *>(a.spec);
@@ -533,7 +563,7 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
                      const double *twH, const double *twN, hipStream_t stream, const ocn_grid *grid, const double *u, const double *v,
                      const double *w, double dt, int kc, long long chunk, int scale_dz, double scale)
 {
-    RealYArgs a{rhs, GridDev{}, u, v, w, dt, spec, p, p_s2, p_s3, nx, Nz, twH, twN, kc, chunk, scale_dz, scale};
+    RealYArgs a{rhs, GridDev{}, u, v, w, dt, spec, p, p_s2, p_s3, nx, Nz, twH, twN, kc, chunk, scale_dz, scale, fft_xcd_remap()};
     if (grid) a.g = to_dev(*grid);
     if (!inverse && !rhs && !(grid && u && v && w)) {
         set_error("launch_realfft_y: the forward transform needs either rhs or (grid, u, v, w)");
@@ -542,13 +572,7 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
     switch (Ny / 2) {
         case 64: return launch_realy<64, 16>(inverse, a, stream);
         case 128: return launch_realy<128, 16>(inverse, a, stream);
-        case 256: {
-            // 32 columns per workgroup: 256-byte runs of the real rows (rhs / u, v, w / p) instead of 128-byte ones, one workgroup of
-            // 1024 threads and 140 KB of LDS per CU (OCN_REALY_CB = 16 keeps two 16-column workgroups per CU)
-            static const int cb = getenv("OCN_REALY_CB") ? atoi(getenv("OCN_REALY_CB")) : 16;
-            if (cb == 32 && nx >= 32) return launch_realy<256, 32>(inverse, a, stream);
-            return launch_realy<256, 16>(inverse, a, stream);
-        }
+        case 256: return launch_realy<256, 16>(inverse, a, stream);  // (32 columns per workgroup, 256-byte runs, one workgroup per CU: no faster, round 4)
         case 512: return launch_realy<512, 8>(inverse, a, stream);
         default: set_error("real y transform of length %d is not supported (128, 256, 512, 1024)", Ny); return OCN_ERR_UNSUPPORTED;
     }

@@ -24,6 +24,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ocn_internal.h"
@@ -69,6 +70,31 @@ struct Comm {
     // would send me is what I send to its mirror image, so every receive is an asynchronous device copy from one of my own send buffers.
     // Timing of ONE rank of an R-rank run on a one-GPU box with the R-rank schedules, kernels and drivers (tools/bench_dist_rank.py).
     bool replica = false;
+    // ocn_comm_enable_stats: event pairs around every exchange (category, start, stop), summed by ocn_comm_stats
+    bool stats = false;
+    struct StatPair { int cat; hipEvent_t a, b; };
+    std::vector<StatPair> pairs;
+    double counts[8] = {};
+};
+
+// brackets a piece of work on `s` with timing events while the communicator's stats are enabled
+struct StatScope {
+    Comm *c; int cat; hipStream_t s; hipEvent_t a = nullptr;
+    StatScope(Comm *c_, int cat_, hipStream_t s_) : c(c_), cat(cat_), s(s_)
+    {
+        if (c->stats && hipEventCreate(&a) == hipSuccess) (void)hipEventRecord(a, s);
+    }
+    ~StatScope()
+    {
+        if (!a) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) == hipSuccess) {
+            (void)hipEventRecord(b, s);
+            c->pairs.push_back({cat, a, b});
+        } else {
+            (void)hipEventDestroy(a);
+        }
+    }
 };
 
 // ---- in-process transport (ocn_comm_init_local): the ranks are THREADS of one process sharing ONE GPU.  RCCL refuses two ranks on one
@@ -594,8 +620,12 @@ int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const
     if (st != OCN_SUCCESS) return st;
     OCN_CHECK_HIP(hipEventRecord(c->ready, s));
     OCN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
-    st = post_exchange(c, c->buf[0], c->buf[1], c->buf[2], c->buf[3], count);
+    {
+        StatScope sc(c, 0, c->stream);
+        st = post_exchange(c, c->buf[0], c->buf[1], c->buf[2], c->buf[3], count);
+    }
     if (st != OCN_SUCCESS) return st;
+    c->counts[5] += 1;
     OCN_CHECK_HIP(hipEventRecord(c->done, c->stream));
     c->pending = true;
     c->pending_count = count;
@@ -613,7 +643,10 @@ int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(strip_doubles(grid, locs, n) == c->pending_count, "ocn_halo_exchange_end: not the tuple the exchange was started with");
     hipStream_t s = as_stream(stream);
-    OCN_CHECK_HIP(hipStreamWaitEvent(s, c->done, 0));
+    {
+        StatScope sc(c, 1, s);  // what the caller's stream waits for the exchange
+        OCN_CHECK_HIP(hipStreamWaitEvent(s, c->done, 0));
+    }
     st = launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], 1, s);
     if (st == OCN_SUCCESS) c->pending = false;  // a failed unpack leaves the exchange pending: the caller may call _end again
     return st;
@@ -650,6 +683,7 @@ int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field
     {
         const double *snd[2] = {c->plane[0], nullptr};
         double *rcv[2] = {nullptr, c->plane[1]};
+        StatScope sc(c, 4, s);
         st = run_schedule(c, east ? OCN_SCHED_PLANE_EAST : OCN_SCHED_PLANE_WEST, snd, rcv, count, s);
         if (st != OCN_SUCCESS) return st;
     }
@@ -677,7 +711,10 @@ int ocn_halo_exchange_pressure(ocn_comm_t comm, const ocn_grid *grid, double *p,
     }
     int st = ocn_halo_pack_pressure(grid, p, u, dt_correct, c->pbuf[0], c->pbuf[1], stream);
     if (st != OCN_SUCCESS) return st;
-    st = ocn_comm_exchange_strips(comm, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], count, stream);
+    {
+        StatScope sc(c, 3, as_stream(stream));
+        st = ocn_comm_exchange_strips(comm, c->pbuf[0], c->pbuf[1], c->pbuf[2], c->pbuf[3], count, stream);
+    }
     if (st != OCN_SUCCESS) return st;
     return ocn_halo_unpack_pressure(grid, p, u, c->pbuf[2], c->pbuf[3], stream);
 }
@@ -703,6 +740,8 @@ int ocn_comm_all_to_all(ocn_comm_t comm, const double *send, double *recv, size_
     OCN_REQUIRE(c && send && recv, "ocn_comm_all_to_all: null pointer");
     OCN_REQUIRE(send != recv, "ocn_comm_all_to_all: in-place exchange is not supported");
     hipStream_t s = as_stream(stream);
+    StatScope sc(c, 2, s);
+    c->counts[6] += 1;
     // the chunk a rank keeps for itself (1 / R of the payload) is a device copy at HBM speed; the R - 1 others are one grouped
     // send / recv per peer, each over its own xGMI link
     if (!c->self_via_rccl)
@@ -725,6 +764,8 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c && send && recv, "ocn_comm_all_gather: null pointer");
     hipStream_t s = as_stream(stream);
+    StatScope sc(c, 2, s);
+    c->counts[6] += 1;
     if (c->nranks == 1 && !c->self_via_rccl) {
         OCN_CHECK_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
         return OCN_SUCCESS;
@@ -780,6 +821,53 @@ int ocn_dist_poisson_exchange(ocn_dist_poisson_t handle, ocn_comm_t comm, int32_
     return ocn_comm_all_to_all(comm, src, dst, per_peer, stream);
 }
 
+int ocn_comm_enable_stats(ocn_comm_t comm, int32_t enable)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_comm_enable_stats: null communicator");
+    c->stats = enable != 0;
+    return OCN_SUCCESS;
+}
+
+int ocn_comm_stats(ocn_comm_t comm, double *out_ms)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && out_ms, "ocn_comm_stats: null pointer");
+    for (int q = 0; q < 8; ++q) out_ms[q] = 0.0;
+    int st = OCN_SUCCESS;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto &p : c->pairs) {
+        // the stop events complete in stream order: wait for each with a deadline (a stuck exchange must not hang the caller)
+        while (st == OCN_SUCCESS) {
+            const hipError_t e = hipEventQuery(p.b);
+            if (e == hipSuccess) break;
+            if (e != hipErrorNotReady) { ocn::set_error("ocn_comm_stats: %s", hipGetErrorString(e)); st = OCN_ERR_HIP; }
+            else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                ocn::set_error("ocn_comm_stats: an exchange did not complete within 120 s");
+                st = OCN_ERR_TIMEOUT;
+            } else std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        if (st != OCN_SUCCESS) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && p.cat >= 0 && p.cat < 5) out_ms[p.cat] += ms;
+    }
+    if (st == OCN_SUCCESS) {
+        for (auto &p : c->pairs) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        out_ms[5] = c->counts[5];
+        out_ms[6] = c->counts[6];
+    }
+    c->pairs.clear();  // (after a timeout the unfinished events are leaked on purpose)
+    c->counts[5] = c->counts[6] = 0.0;
+    return st;
+}
+
+int ocn_comm_wait(ocn_comm_t comm, double seconds)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_comm_wait: null communicator");
+    return ocn::wait_stream(c->stream, seconds, "ocn_comm_wait");
+}
+
 int ocn_comm_allreduce(ocn_comm_t comm, double *buf, size_t count, int32_t op, void *stream)
 {
     Comm *c = static_cast<Comm *>(comm);
@@ -818,8 +906,9 @@ int ocn_comm_barrier(ocn_comm_t comm)
         return OCN_SUCCESS;
     }
     OCN_CHECK_NCCL(ncclAllReduce(c->buf[0], c->buf[0], 1, ncclDouble, ncclSum, c->comm, c->stream));
-    OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
-    return OCN_SUCCESS;
+    // host wait with a deadline (OCN_COMM_TIMEOUT_S, default 300): a rank whose peers never arrive gets OCN_ERR_TIMEOUT instead of hanging
+    static const double deadline = getenv("OCN_COMM_TIMEOUT_S") ? atof(getenv("OCN_COMM_TIMEOUT_S")) : 300.0;
+    return ocn::wait_stream(c->stream, deadline, "ocn_comm_barrier");
 }
 
 }  // extern "C"

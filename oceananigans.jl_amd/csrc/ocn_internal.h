@@ -35,6 +35,8 @@ int launch_apply_flux_bcs(const ocn_grid *grid, const FieldTuple &G, const Field
 int launch_apply_flux_bcs_lateral(const ocn_grid *grid, const FieldTuple &G, const FieldTuple &fields, const SideBcTuple &bcs, hipStream_t stream);
 int launch_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *out, hipStream_t stream);
 int launch_hasnan(const double *a, long long n, int *flag, hipStream_t stream);
+int launch_profile_marker(hipStream_t stream);
+int wait_stream(hipStream_t stream, double seconds, const char *who);
 int launch_hydrostatic_pressure(const ocn_grid *grid, const TermsDev &t, double *pHY, hipStream_t stream, const int32_t *irange = nullptr);
 int launch_stepper(const ocn_grid *grid, const StepTuple &st, int mode, double dt, double c1, double c2, hipStream_t stream);
 int launch_source_term(const ocn_grid *grid, const double *u, const double *v, const double *w, double dt, int out_mode,

@@ -1097,13 +1097,6 @@ static int one_barrier()
     return v;
 }
 
-// 32 x 12 patches (6 waves, 2 workgroups per CU): 31 x 11 of 384 lanes useful (88.8 %) against 31 x 7 of 256 (84.8 %)
-static int tall_tile()
-{
-    static const int v = getenv("OCN_TEND_TALL") ? atoi(getenv("OCN_TEND_TALL")) : 0;
-    return v;
-}
-
 static int xcd_remap()
 {
     static const int v = getenv("OCN_XCD_REMAP") ? atoi(getenv("OCN_XCD_REMAP")) : 1;  // measured: 4.72 -> 4.60 ms per 512^3 launch
@@ -1195,8 +1188,6 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
             fz.pc_xhalo = grid->tx == OCN_FULLY_CONNECTED;
             if (narrow)
                 launch_tiled<OCN_PERIODIC, 17, 15, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
-            else if (tall_tile())
-                launch_tiled<OCN_PERIODIC, 32, 12, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else if (one_barrier() & 1)
                 launch_tiled<OCN_PERIODIC, 32, 8, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
@@ -1209,11 +1200,6 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                 launch_tiled<OCN_PERIODIC, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else
                 launch_tiled<OCN_BOUNDED, 17, 15, false, false>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
-            OCN_CHECK_HIP(hipGetLastError());
-            return OCN_SUCCESS;
-        }
-        if (variant == 0 && tall_tile() && grid->tz == OCN_PERIODIC) {
-            launch_tiled<OCN_PERIODIC, 32, 12, false, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }

@@ -34,13 +34,46 @@ def load_stats(d):
     return rows
 
 
-def load_pmc(d, sub, counter):
+MARKER = "profile_marker_kernel"  # ocn_profile_marker: bench.py launches one right before and one right after its timed steps
+
+
+def load_pmc(d, sub, counter, windowed=False):
+    """per kernel: the counter values of its dispatches (windowed: only those between the two marker dispatches, if the run has them)"""
     f = glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True)
+    rows = [r for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == counter or MARKER in r["Kernel_Name"]]
+    lo = hi = None
+    if windowed:
+        marks = sorted({int(r["Dispatch_Id"]) for r in rows if MARKER in r["Kernel_Name"]})
+        if len(marks) >= 2:
+            lo, hi = marks[0], marks[1]
     acc = defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] == counter:
-            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for r in rows:
+        if MARKER in r["Kernel_Name"] or r["Counter_Name"] != counter:
+            continue
+        if lo is not None and not (lo < int(r["Dispatch_Id"]) < hi):
+            continue
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    acc["__windowed__"] = lo is not None
     return acc
+
+
+def load_trace_window(d):
+    """per-kernel (calls, total ms) between the two marker dispatches of the kernel trace, or None"""
+    f = glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    if not f:
+        return None
+    rows = list(csv.DictReader(open(f[0])))
+    marks = sorted(int(r["Start_Timestamp"]) for r in rows if MARKER in r["Kernel_Name"])
+    if len(marks) < 2:
+        return None
+    out = defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        t = int(r["Start_Timestamp"])
+        if marks[0] < t < marks[1] and MARKER not in r["Kernel_Name"]:
+            e = out[short(r["Kernel_Name"])]
+            e[0] += 1
+            e[1] += (int(r["End_Timestamp"]) - t) / 1e6
+    return {k: tuple(v) for k, v in out.items()}
 
 
 SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU",
@@ -59,6 +92,12 @@ def main():
     stats = load_stats(d)
     fetch = load_pmc(d, "pmc_fetch", "FETCH_SIZE")
     write = load_pmc(d, "pmc_write", "WRITE_SIZE")
+    # the same two passes restricted to the timed steps (marker-delimited), for the step totals
+    fetch_w = load_pmc(d, "pmc_fetch", "FETCH_SIZE", windowed=True)
+    write_w = load_pmc(d, "pmc_write", "WRITE_SIZE", windowed=True)
+    windowed = bool(fetch_w.pop("__windowed__")) and bool(write_w.pop("__windowed__"))
+    fetch.pop("__windowed__", None); write.pop("__windowed__", None)
+    trace_w = load_trace_window(d)
     cells = int(sys.argv[4]) if len(sys.argv) > 4 else n ** 3
     steps_profiled = int(sys.argv[5]) if len(sys.argv) > 5 else None
     sq = {}
@@ -85,6 +124,13 @@ def main():
     out = {"tag": tag, "n": n, "name": name, "cells": cells, "command": command, "steps_profiled": steps_profiled,
            "read_calibration_factor": read_factor, "write_calibration_factor": write_factor, "kernels": []}
     step_bytes = 0.0
+    if windowed and read_factor:
+        # exact: every dispatch between the markers, each with its own counter value (no medians, no set! / warm-up launches)
+        step_bytes = sum(sum(v) for v in fetch_w.values()) * 1024 * read_factor + sum(sum(v) for v in write_w.values()) * 1024 * write_factor
+        out["window"] = "timed steps only: dispatches between the two ocn_profile_marker launches of bench.py"
+        if trace_w:
+            out["window_kernels"] = {k: {"calls": c, "total_ms": t} for k, (c, t) in sorted(trace_w.items(), key=lambda kv: -kv[1][1])}
+            out["window_gpu_ms"] = sum(t for _, t in trace_w.values())
     for s in stats:
         k = dict(s)
         if s["name"] in fetch and s["name"] in write and read_factor:
@@ -93,7 +139,11 @@ def main():
             k.update(read_bytes=rd, write_bytes=wr, traffic_bytes=rd + wr, traffic_bytes_per_cell=(rd + wr) / cells,
                      hbm_GBps=(rd + wr) / (s["avg_us"] * 1e-6) / 1e9,
                      raw_fetch_KiB=med(fetch[s["name"]]), raw_write_KiB=med(write[s["name"]]))
-            step_bytes += (rd + wr) * s["calls"]
+            if not windowed:
+                step_bytes += (rd + wr) * s["calls"]
+            else:
+                k["window_calls"] = len(fetch_w.get(s["name"], []))
+                k["window_traffic_bytes"] = sum(fetch_w.get(s["name"], [])) * 1024 * read_factor + sum(write_w.get(s["name"], [])) * 1024 * write_factor
         for c in SQ_COUNTERS:
             if c in sq and s["name"] in sq[c]:
                 k[c] = med(sq[c][s["name"]])
@@ -130,8 +180,16 @@ def main():
                 "command; see tools/profile_bench.sh / tools/summarize_profile.py.  valu busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x "
                 "GRBM_GUI_ACTIVE / 8 XCDs); VALU instr/cell = SQ_INSTS_VALU (wave instructions) / cells.\n\n")
         if "step_bytes_per_cell" in out:
-            f.write(f"Measured HBM traffic of the whole command / ({steps_profiled} steps x {cells} cells) = "
-                    f"**{out['step_bytes_per_cell']:.0f} B per cell per step** (includes set! and warm-up launches).\n\n")
+            if windowed:
+                f.write(f"Measured HBM traffic of the TIMED steps (every dispatch between bench.py's two marker launches) / ({steps_profiled} steps x "
+                        f"{cells} cells) = **{out['step_bytes_per_cell']:.0f} B per cell per step**.\n\n")
+                if "window_kernels" in out:
+                    f.write("Kernels of the timed steps (kernel trace, same window): " + ", ".join(
+                        f"`{k.split('::')[-1][:48]}` {v['calls']} x {v['total_ms'] / max(v['calls'], 1) * 1e3:.0f} us" for k, v in list(out["window_kernels"].items())[:12])
+                        + f"; GPU time {out['window_gpu_ms'] / steps_profiled:.2f} ms per step.\n\n")
+            else:
+                f.write(f"Measured HBM traffic of the whole command / ({steps_profiled} steps x {cells} cells) = "
+                        f"**{out['step_bytes_per_cell']:.0f} B per cell per step** (includes set! and warm-up launches).\n\n")
         f.write(f"PMC calibration on `{cal}` (known fields read / written): read x{read_factor}, write x{write_factor}\n\n")
         f.write("| kernel | calls | avg us | % GPU time | HBM traffic/launch (B/cell) | HBM GB/s | VALU wave-instr/cell | valu busy | GHz under PMC |\n|---|---|---|---|---|---|---|---|---|\n")
         for k in out["kernels"][:25]:
