@@ -227,9 +227,13 @@ static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u,
             return st;
         }
     }
-    // fold the pressure correction into the loads of the fused launch: all-periodic grids the tiled kernel covers; always on a slab
-    const char *e = std::getenv("OCN_CORRECT_ON_LOAD");
-    d->correct_on_load = comm || (grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4 && !(e && e[0] == '0'));
+    // fold the pressure correction into the loads of the fused launch: all-periodic grids the tiled kernel covers, one GPU or a slab.
+    // OCN_CORRECT_ON_LOAD=0 (on a slab also OCN_DIST_CORRECT_ON_LOAD=0, the Python host's switch) is the conservative path for a first
+    // multi-GPU run: every stage = synchronous halo exchange -> solve -> synchronous pressure exchange -> pressure_correct_velocities!
+    // -> synchronous exchange -> one plain fused launch; no exchange is in flight while the solver's collective runs.
+    const char *e = std::getenv("OCN_CORRECT_ON_LOAD"), *ed = std::getenv("OCN_DIST_CORRECT_ON_LOAD");
+    const bool off = (e && e[0] == '0') || (comm && ed && ed[0] == '0');
+    d->correct_on_load = (comm || (grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4)) && !off;
     const char *dc = std::getenv("OCN_DRIVER_DEFER_CORRECTION");
     d->defer_correction = d->correct_on_load && !(dc && dc[0] == '0');
     st = fill_velocities(d, 0, stream);  // update_state!(model; compute_tendencies = false) of the constructor
@@ -259,7 +263,6 @@ extern "C" int ocn_rk3_driver_configure(ocn_rk3_driver_t d, int32_t defer_correc
     OCN_REQUIRE(d, "ocn_rk3_driver_configure: null driver");
     OCN_REQUIRE(!d->correction_pending, "ocn_rk3_driver_configure: flush first (a deferred pressure correction is pending)");
     OCN_REQUIRE(!defer_correction || d->correct_on_load, "ocn_rk3_driver_configure: deferring the correction needs correction on load (all-periodic grid)");
-    OCN_REQUIRE(defer_correction || !d->comm, "ocn_rk3_driver_configure: a distributed driver always defers the third stage's correction");
     d->defer_correction = defer_correction != 0;
     return OCN_SUCCESS;
 }

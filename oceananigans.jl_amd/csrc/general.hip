@@ -402,12 +402,71 @@ static gen::Fields make_fields(const ocn_grid *grid, const double *u, const doub
     if (wx < 1 || wy < 1 || wz < 1) return OCN_SUCCESS;                                                \
     const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz)
 
+#define OCN_GEN_DIMS_VOID(r)                                                                          \
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;                       \
+    if (wx < 1 || wy < 1 || wz < 1) return;                                                            \
+    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz)
+
+// tendencies.hip (same namespace): the LDS-tiled kernels over the interior box of a grid with walls in x / y
+int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
+                                   const int32_t box[4], int *launched, hipStream_t stream);
+int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                               const int32_t box[4], int *launched, hipStream_t stream);
+
+// Interior box + wall frames.  The topology-conditional reconstructions of a Bounded direction differ from the Periodic ones only within
+// a stencil of the walls (topologically_conditional_interpolation.jl:46-52: full order for faces 4 .. N-2 and centres 3 .. N-2), so every
+// cell with 4 <= i <= Nx-3 (and the same in y) gets the LDS-tiled shared-flux kernel of tendencies.hip with per-field layouts -- the same
+// expressions on the same operands as the per-cell kernel, bit for bit -- and only the frames next to the walls run the per-cell kernel
+// with its run-time topology.  Returns the box {i0, i1, j0, j1}, or false when the grid has no wall in x / y, a Flat x / y / z, a scheme
+// the tiles do not carry, or a box too small for them (OCN_GENERAL_TILED=0 switches the decomposition off).
+static bool interior_box(const ocn_grid *grid, int centered2, const int32_t *range, int32_t box[4])
+{
+    static const bool off = [] { const char *e = getenv("OCN_GENERAL_TILED"); return e && e[0] == '0'; }();
+    if (off || centered2 || range) return false;
+    if (grid->tx == OCN_FLAT || grid->ty == OCN_FLAT || grid->tz == OCN_FLAT) return false;
+    if (grid->tx != OCN_BOUNDED && grid->ty != OCN_BOUNDED) return false;
+    box[0] = grid->tx == OCN_BOUNDED ? 4 : 1; box[1] = grid->tx == OCN_BOUNDED ? grid->Nx - 3 : grid->Nx;
+    box[2] = grid->ty == OCN_BOUNDED ? 4 : 1; box[3] = grid->ty == OCN_BOUNDED ? grid->Ny - 3 : grid->Ny;
+    return box[1] - box[0] + 1 >= 16 && box[3] - box[2] + 1 >= 8 && grid->Nz >= 4 && grid->Hx >= 3 && grid->Hy >= 3 && grid->Hz >= 3;
+}
+
+// the (up to four) frames around the box, each as a range of the per-cell kernel; `r` carries the periphery offsets of the whole grid
+template <class Launch>
+static void for_each_frame(const ocn_grid *grid, const int32_t box[4], const gen::GRange &whole, Launch launch)
+{
+    const int spans[4][4] = {{1, box[0] - 1, 1, grid->Ny},                 // west
+                             {box[1] + 1, grid->Nx, 1, grid->Ny},          // east
+                             {box[0], box[1], 1, box[2] - 1},              // south (between the x frames)
+                             {box[0], box[1], box[3] + 1, grid->Ny}};      // north
+    for (const auto &sp : spans) {
+        if (sp[1] < sp[0] || sp[3] < sp[2]) continue;
+        gen::GRange r = whole;
+        r.i0 = sp[0]; r.i1 = sp[1]; r.j0 = sp[2]; r.j1 = sp[3];
+        launch(r);
+    }
+}
+
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
                                        double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
 {
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+    int32_t box[4];
+    if (interior_box(grid, centered2, range, box)) {
+        int launched = 0;
+        st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream);
+        if (st != OCN_SUCCESS) return st;
+        if (launched) {
+            const gen::Fields F = make_fields(grid, u, v, w, centered2);
+            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
+                OCN_GEN_DIMS_VOID(fr);
+                hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, F, Gu, Gv, Gw, fr);
+            });
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+    }
     OCN_GEN_DIMS(r);
     hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), Gu, Gv, Gw, r);
     OCN_CHECK_HIP(hipGetLastError());
@@ -420,6 +479,21 @@ int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const do
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+    int32_t box[4];
+    if (interior_box(grid, centered2, range, box)) {
+        int launched = 0;
+        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream);
+        if (st != OCN_SUCCESS) return st;
+        if (launched) {
+            const gen::Fields F = make_fields(grid, u, v, w, centered2);
+            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
+                OCN_GEN_DIMS_VOID(fr);
+                hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, F, c, Gc, fr);
+            });
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+    }
     OCN_GEN_DIMS(r);
     hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), c, Gc, r);
     OCN_CHECK_HIP(hipGetLastError());

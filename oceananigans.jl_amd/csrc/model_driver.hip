@@ -9,6 +9,7 @@
 //   nu_e, kappa_e -> momentum: tiled advection launch + one finishing pass (extra terms, u / v boundary fluxes, next substep) ->
 //   one launch per tracer (advection, diffusion, boundary flux, next substep) -> velocity halos -> Poisson solve -> pressure halos ->
 //   pressure correction.  Substep results land in a second set of arrays whose roles then alternate; G^n / G^- swap.
+#include <cstdlib>
 #include <cstring>
 
 #include "ocn_internal.h"
@@ -41,6 +42,10 @@ struct ocn_model_driver {
     // slab-x rank (ocn_model_driver_create_distributed): RCCL communicator + distributed Poisson handle, both borrowed
     ocn_comm_t comm = nullptr;
     ocn_dist_poisson_t dsolver = nullptr;
+    // interior / buffer split of a slab's stage boundary (update_state_split): the east buffer strip runs on a side stream
+    bool split = false;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 
 namespace {
@@ -68,11 +73,15 @@ void refresh_terms(ocn_model_driver *d)  // the buoyancy tracers' storage altern
 }
 
 // fill_halo_regions!(fields): one launch for the tuple, the fields' own bottom / top Value / Gradient conditions included
-int fill(ocn_model_driver *d, double *const *fields, const int32_t *locs, const ocn_field_bcs *const *bcs, int n, int fbnv, void *stream)
+int fill_local(ocn_model_driver *d, double *const *fields, const int32_t *locs, const ocn_field_bcs *const *bcs, int n, int fbnv, void *stream)
 {
     bool any = false;
     for (int f = 0; f < n && bcs; ++f) any = any || bcs[f];
-    int st = any ? ocn_fill_halo_regions_bcs(&d->grid, fields, locs, bcs, n, fbnv, stream) : ocn_fill_halo_regions(&d->grid, fields, locs, n, fbnv, stream);
+    return any ? ocn_fill_halo_regions_bcs(&d->grid, fields, locs, bcs, n, fbnv, stream) : ocn_fill_halo_regions(&d->grid, fields, locs, n, fbnv, stream);
+}
+int fill(ocn_model_driver *d, double *const *fields, const int32_t *locs, const ocn_field_bcs *const *bcs, int n, int fbnv, void *stream)
+{
+    int st = fill_local(d, fields, locs, bcs, n, fbnv, stream);
     if (st != OCN_SUCCESS || !d->comm) return st;
     // a slab: local (y, z) fills first, the x exchange with the neighbours last (fill_halo_regions.jl:148-196); synchronous
     st = ocn_halo_exchange_begin(d->comm, &d->grid, fields, locs, n, stream);
@@ -154,16 +163,17 @@ int compute_tendencies(ocn_model_driver *d, void *stream)
 }
 
 // compute_tendencies! + the next rk3_substep! of every prognostic field, then the two sets of arrays trade places
-int fused_launch(ocn_model_driver *d, double dt, double gamma, double zeta, int has_zeta, void *stream)
+// the launches of one stage boundary over `range` (NULL = the whole slab): tendencies + next substep of every prognostic field
+int launch_tendencies(ocn_model_driver *d, double dt, double gamma, double zeta, int has_zeta, const int32_t *range, void *stream)
 {
     int st;
     if (d->momentum_extra)
         st = ocn_compute_momentum_tendencies_terms_rk3(&d->grid, &d->terms, flux_bcs(d, 0), flux_bcs(d, 1), d->U[0], d->U[1], d->U[2], d->Gn[0],
                                                        d->Gn[1], d->Gn[2], d->Gm[0], d->Gm[1], d->Gm[2], d->A[0], d->A[1], d->A[2], dt, gamma, zeta,
-                                                       has_zeta, nullptr, stream);
+                                                       has_zeta, range, stream);
     else
         st = ocn_compute_momentum_tendencies_rk3(&d->grid, d->U[0], d->U[1], d->U[2], d->Gn[0], d->Gn[1], d->Gn[2], d->Gm[0], d->Gm[1], d->Gm[2],
-                                                 d->A[0], d->A[1], d->A[2], dt, gamma, zeta, has_zeta, nullptr, 0.0, nullptr, stream);
+                                                 d->A[0], d->A[1], d->A[2], dt, gamma, zeta, has_zeta, nullptr, 0.0, range, stream);
     if (st != OCN_SUCCESS) return st;
     int q = 0;
     while (q < d->nt) {
@@ -177,7 +187,7 @@ int fused_launch(ocn_model_driver *d, double dt, double gamma, double zeta, int 
             double *out[2] = {d->A[3 + q], d->A[4 + q]};
             int32_t did = 0;
             st = ocn_compute_tracer_pair_tendency_terms_rk3(&d->grid, &d->terms, kap, ke, fb, d->U[0], d->U[1], d->U[2], c, G, Gp, out, dt, gamma,
-                                                            zeta, has_zeta, nullptr, &did, stream);
+                                                            zeta, has_zeta, range, &did, stream);
             if (st != OCN_SUCCESS) return st;
             if (did) {
                 q += 2;
@@ -186,13 +196,80 @@ int fused_launch(ocn_model_driver *d, double dt, double gamma, double zeta, int 
         }
         st = ocn_compute_tracer_tendency_terms_rk3(&d->grid, &d->terms, kap[0], d->terms.closure == 2 ? d->kappa_e[q] : nullptr, flux_bcs(d, 3 + q),
                                                    d->U[0], d->U[1], d->U[2], d->U[3 + q], d->Gn[3 + q], d->Gm[3 + q], d->A[3 + q], dt, gamma, zeta,
-                                                   has_zeta, nullptr, stream);
+                                                   has_zeta, range, stream);
         if (st != OCN_SUCCESS) return st;
         q += 1;
     }
+    return OCN_SUCCESS;
+}
+
+void swap_sets(ocn_model_driver *d)
+{
     for (int f = 0; f < d->n; ++f) std::swap(d->U[f], d->A[f]);
     refresh_terms(d);
     d->pending = false;
+}
+
+// compute_tendencies! + the next rk3_substep! of every prognostic field, then the two sets of arrays trade places
+int fused_launch(ocn_model_driver *d, double dt, double gamma, double zeta, int has_zeta, void *stream)
+{
+    int st = launch_tendencies(d, dt, gamma, zeta, has_zeta, nullptr, stream);
+    if (st != OCN_SUCCESS) return st;
+    swap_sets(d);
+    return OCN_SUCCESS;
+}
+
+// update_state! + compute_tendencies! + the next substep on a slab WITH the interior / buffer split of
+// interleave_communication_and_computation.jl:29-67 and compute_nonhydrostatic_buffer_tendencies.jl:10-83 (the choreography of
+// distributed.py::update_state_general, launch for launch): the x exchange of the prognostic fields flies under the auxiliaries and
+// tendencies of the columns that read no x halo; the diffusivities and pHY' of the edge and halo columns are RECOMPUTED from the
+// exchanged halos (:55-68: what the neighbour computes for its own edge column -- same inputs, same arithmetic -- instead of a
+// second exchange), then the two Hx-wide buffer strips, the east one on a side stream.
+int update_state_split(ocn_model_driver *d, double dt, double gamma, double zeta, int has_zeta, void *stream)
+{
+    const int nx = d->grid.Nx, Hx = d->grid.Hx, Ny = d->grid.Ny, Nz = d->grid.Nz;
+    const bool amd = d->terms.closure == 2;
+    double *aux[1 + OCN_MODEL_MAX_TRACERS];
+    int32_t auxl[1 + OCN_MODEL_MAX_TRACERS];
+    aux[0] = d->nu_e; auxl[0] = OCN_LOC_CCC;
+    for (int t = 0; t < d->nt; ++t) { aux[1 + t] = d->kappa_e[t]; auxl[1 + t] = OCN_LOC_CCC; }
+    auto diffusivities = [&](int i0, int i1, void *s) {
+        return amd ? ocn_compute_amd_diffusivities_range(&d->grid, d->Cnu, d->U[0], d->U[1], d->U[2], d->nu_e, d->nt, d->Ck, d->U + 3, d->kappa_e, i0, i1, s)
+                   : OCN_SUCCESS;
+    };
+    auto hydrostatic = [&](int i0, int i1, void *s) {
+        return d->pHY ? ocn_update_hydrostatic_pressure_range(&d->grid, &d->terms, d->pHY, i0, i1, s) : OCN_SUCCESS;
+    };
+#define OCN_TRY(expr) do { int st_ = (expr); if (st_ != OCN_SUCCESS) return st_; } while (0)
+    OCN_TRY(fill_local(d, d->U, d->locs, d->bcs, d->n, 0, stream));
+    OCN_TRY(ocn_halo_exchange_begin(d->comm, &d->grid, d->U, d->locs, d->n, stream));
+    // interior: the diffusivities of columns 2 .. nx-1 read u, v, w, c at i-1 .. i+1 (local); pHY' of a column reads that column only
+    OCN_TRY(diffusivities(2, nx - 1, stream));
+    OCN_TRY(hydrostatic(1, nx, stream));
+    if (amd) OCN_TRY(ocn_fill_halo_regions(&d->grid, aux, auxl, 1 + d->nt, 1, stream));  // their y / z halos
+    const int32_t interior[6] = {Hx + 1, nx - Hx, 1, Ny, 1, Nz};
+    OCN_TRY(launch_tendencies(d, dt, gamma, zeta, has_zeta, interior, stream));
+    OCN_TRY(ocn_halo_exchange_end(d->comm, &d->grid, d->U, d->locs, d->n, stream));
+    OCN_TRY(diffusivities(0, 1, stream));
+    OCN_TRY(diffusivities(nx, nx + 1, stream));
+    OCN_TRY(hydrostatic(0, 0, stream));
+    OCN_TRY(hydrostatic(nx + 1, nx + 1, stream));
+    if (amd) OCN_TRY(ocn_fill_halo_regions(&d->grid, aux, auxl, 1 + d->nt, 1, stream));
+    const int w1 = Hx < nx ? Hx : nx, e0 = (nx - Hx + 1 > w1 + 1) ? nx - Hx + 1 : w1 + 1;
+    const int32_t west[6] = {1, w1, 1, Ny, 1, Nz}, east[6] = {e0, nx, 1, Ny, 1, Nz};
+    if (e0 <= nx) {  // the two strips are independent and each too small to fill the chip: side by side
+        hipStream_t cur = ocn::as_stream(stream);
+        OCN_CHECK_HIP(hipEventRecord(d->fork, cur));
+        OCN_CHECK_HIP(hipStreamWaitEvent(d->side, d->fork, 0));
+        OCN_TRY(launch_tendencies(d, dt, gamma, zeta, has_zeta, east, d->side));
+        OCN_CHECK_HIP(hipEventRecord(d->join, d->side));
+        OCN_TRY(launch_tendencies(d, dt, gamma, zeta, has_zeta, west, stream));
+        OCN_CHECK_HIP(hipStreamWaitEvent(cur, d->join, 0));
+    } else {
+        OCN_TRY(launch_tendencies(d, dt, gamma, zeta, has_zeta, west, stream));
+    }
+#undef OCN_TRY
+    swap_sets(d);
     return OCN_SUCCESS;
 }
 
@@ -233,6 +310,7 @@ int project_and_advance(ocn_model_driver *d, double dt, double stage_dt, double 
     int st = project(d, stage_dt, true, stream);
     if (st != OCN_SUCCESS) return st;
     for (int f = 0; f < d->n; ++f) std::swap(d->Gn[f], d->Gm[f]);  // cache_previous_tendencies! as a role swap
+    if (d->split) return update_state_split(d, dt, gamma_next, zeta_next, 1, stream);
     st = update_state(d, stream);
     if (st != OCN_SUCCESS) return st;
     return fused_launch(d, dt, gamma_next, zeta_next, 1, stream);
@@ -243,6 +321,9 @@ extern "C" int ocn_model_driver_destroy(ocn_model_driver_t d)
 {
     if (!d) return OCN_SUCCESS;
     if (d->solver && d->owns_solver) ocn_poisson_destroy(d->solver);
+    if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
+    if (d->fork) (void)hipEventDestroy(d->fork);
+    if (d->join) (void)hipEventDestroy(d->join);
     for (int f = 0; f < NF; ++f) {
         if (d->own[f]) (void)hipFree(d->own[f]);
         if (d->Gn[f]) (void)hipFree(d->Gn[f]);
@@ -342,6 +423,16 @@ static int model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, co
     refresh_terms(d);
     if (comm) {
         d->owns_solver = false;
+        // interior / buffer split of the stage boundaries (OCN_DIST_GENERAL_OVERLAP=0: every exchange synchronous, as before round 4)
+        const char *e = std::getenv("OCN_DIST_GENERAL_OVERLAP");
+        d->split = grid->Nx - 2 * grid->Hx >= 1 && grid->Hx >= 2 && !(e && e[0] == '0');
+        if (d->split && (hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&d->fork, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&d->join, hipEventDisableTiming) != hipSuccess)) {
+            ocn::set_error("ocn_model_driver_create_distributed: stream / event creation failed");
+            ocn_model_driver_destroy(d);
+            return OCN_ERR_HIP;
+        }
     } else if (solver) {
         d->solver = solver;
         d->owns_solver = false;

@@ -1531,10 +1531,10 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
     OCN_REQUIRE(s && u && v && w, "ocn_dist_poisson_source_term: null argument");
     const ocn_grid *g = &s->grid;
     if (s->fast) {
-        // evaluating the source term inside the real y transform saves a pass, but with 16-column runs its six loads per point are
-        // partial cache lines; on thin slabs (nx <= 64: R = 8 at 512^3) the separate, fully coalesced pass is 0.1 ms per step faster
+        // evaluating the source term inside the real y transform saves a pass (with the XCD-contiguous block order of round 4 also on
+        // thin slabs: 4.14 against 4.18 ms per rank-step at nx = 64; OCN_DIST_FUSED_SOURCE=0 keeps the separate pass)
         static const char *env = std::getenv("OCN_DIST_FUSED_SOURCE");
-        const bool fused = s->tri || (env ? env[0] != '0' : s->nx > 64);
+        const bool fused = s->tri || !(env && env[0] == '0');
         s->src_u = fused ? u : nullptr; s->src_v = v; s->src_w = w; s->src_dt = dt;
         if (fused) return OCN_SUCCESS;  // evaluated by forward_yz from the same (unchanged) velocity arrays
     }

@@ -174,7 +174,10 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
 //    Patches therefore overlap by one column/row: (TX-1) x (TY-1) outputs per TX x TY threads.
 // All flux expressions are the same as in the direct kernel, so strict mode stays bit-identical to the oracle.
 // ---------------------------------------------------------------------------------------------------
-template <int TZ, int TX, int TY, int W, bool PC, bool OB = false>
+// GL ("general layouts"): the fields have their own parent layouts -- a Bounded x (y) gives u (v) one more point along it
+// (grid_utils.jl:66-72).  Used for the INTERIOR BOX of grids with walls in x / y (launch_momentum_tendencies_box): every cell of that
+// box is at least a full stencil away from the walls, where the topology-conditional reconstructions are the Periodic ones.
+template <int TZ, int TX, int TY, int W, bool PC, bool OB = false, bool GL = false>
 __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
                                                                        const double *__restrict__ v,
                                                                        const double *__restrict__ w, double *__restrict__ Gu,
@@ -198,10 +201,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     if (TZ == OCN_PERIODIC) M.dzc = M.dzf = nullptr;  // a Periodic z is never stretched: lets the compiler fold the metric loads
     // x and y are Periodic for every supported grid, so the row/plane strides and the interior offset are the same for
     // all staggered locations (only the number of z planes differs): one layout serves u, v, w, G and p.
+    static_assert(!(GL && PC), "the correction on load shares one layout between p, u, v, w");
     const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);
-#define Lu L0
-#define Lv L0
-#define Lw L0
+    const Lay Lu = GL ? ocn::make_lay(g, OCN_LOC_FCC) : L0, Lv = GL ? ocn::make_lay(g, OCN_LOC_CFC) : L0, Lw = GL ? ocn::make_lay(g, OCN_LOC_CCF) : L0;
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
     const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
     int bx, by, bz;
@@ -216,11 +218,10 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     const int lx = tx + 3, ly = ty + 3;  // own cell inside the LDS tile
 
     // one element offset addresses u, v, w (and G) of the own column: same layout for every field (see above)
-    const long long own0 = ocn::at(L0, i, j, 1);
-    const double *pu = u + own0, *pv = v + own0, *pw = w + own0;
-    const long long su3 = L0.s3;
-#define sv3 su3
-#define sw3 su3
+    const long long own0 = ocn::at(Lu, i, j, 1);
+    const long long ownv = GL ? ocn::at(Lv, i, j, 1) : own0, ownw = GL ? ocn::at(Lw, i, j, 1) : own0;
+    const double *pu = u + own0, *pv = v + ownv, *pw = w + ownw;
+    const long long su3 = Lu.s3, sv3 = GL ? Lv.s3 : su3, sw3 = GL ? Lw.s3 : su3;
     // PC: the previous stage's pressure correction is applied on load (indices wrap periodically, so neither the
     // pressure halos nor re-filled velocity halos are needed): same expression as pressure_correct_kernel.
     auto wrp = [](int q, int N) { return q < 1 ? q + N : (q > N ? q - N : q); };
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     // Static ring assignment: ring cell q (0 <= q < NRING) <-> tile cell (cx, cy) outside the TX x TY core.
     int rcx[RPT], rcy[RPT];
     bool ron[RPT];
-    long long roff[RPT];  // ring cell offset (plane 1), shared by u, v, w
+    long long roff[RPT], roffv[RPT], roffw[RPT];  // ring cell offset (plane 1): one value shared by u, v, w unless GL
     const double *rpc[RPT] = {}, *rpw[RPT] = {}, *rps[RPT] = {};
 #pragma unroll
     for (int s = 0; s < RPT; ++s) {
@@ -286,7 +287,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         if (!ron[s]) { cx = 0; cy = 0; }
         rcx[s] = cx; rcy[s] = cy;
         const int gi = min(ti0 - 3 + cx, imax), gj = min(tj0 - 3 + cy, jmax);
-        roff[s] = ocn::at(L0, gi, gj, 1);
+        roff[s] = ocn::at(Lu, gi, gj, 1);
+        roffv[s] = GL ? ocn::at(Lv, gi, gj, 1) : roff[s];
+        roffw[s] = GL ? ocn::at(Lw, gi, gj, 1) : roff[s];
         if (PC) {
             const Lay &Lp = L0;
             rpc[s] = fz.pc_p + ocn::at(Lp, wrx(gi), wrp(gj, Ny), 1);
@@ -301,12 +304,12 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rpw[s][zz(kk)], hx);
     };
     auto ring_v = [&](int s, int kk) {
-        const double raw = v[roff[s] + (kk - 1) * sv3];
+        const double raw = v[roffv[s] + (kk - 1) * sv3];
         if (!PC) return raw;
         return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rps[s][zz(kk)], hy);
     };
     auto ring_w = [&](int s, int kk) {
-        const double raw = w[roff[s] + (kk - 1) * sw3];
+        const double raw = w[roffw[s] + (kk - 1) * sw3];
         if (!PC) return raw;
         return OCN_PC_APPLY(raw, rpc[s][zz(kk)] - rpc[s][zz(kk - 1)], hz);
     };
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                     if (ron[s]) {
                         const double pr1 = rp_prev[s], pr2 = rpc[s][o2];
                         nu[s] = OCN_PC_APPLY(u[roff[s] + k * su3], pr1 - rpw[s][o1], hx);
-                        nv[s] = OCN_PC_APPLY(v[roff[s] + k * sv3], pr1 - rps[s][o1], hy);
-                        nw[s] = OCN_PC_APPLY(w[roff[s] + (k + 1) * sw3], pr2 - pr1, hz);
+                        nv[s] = OCN_PC_APPLY(v[roffv[s] + k * sv3], pr1 - rps[s][o1], hy);
+                        nw[s] = OCN_PC_APPLY(w[roffw[s] + (k + 1) * sw3], pr2 - pr1, hz);
                         rp_prev[s] = pr2;
                     }
             } else {
@@ -452,7 +455,11 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         // ---- x-fluxes (consumed by this cell and its WEST neighbour)
         {   // Fuu(i-1): centre i-1 == face i of the shifted line: u[i-3..i+2]
             const double ut = sym_interp_scaled<P, true>([&](int m) { return su[ly][lx + m]; }, ax, i - 1, Nx);
+#if OCN_LDS_SELECT == 2  // same field and line as the symmetric interpolation above: the six loads serve both (value selects)
+            myf0 = ut * bias_interp<P, true>([&](int m) { return su[ly][lx + m]; }, i - 1, Nx, ut > 0);
+#else
             myf0 = ut * bias_interp_lds(&su[ly][lx], 1, ut > 0);
+#endif
             ex[0][tid] = myf0;
         }
         {   // Fuv(i): sym y-face of Ax*u ; biased x-face of v
@@ -469,7 +476,11 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         // ---- y-fluxes (consumed by this cell and its SOUTH neighbour)
         {   // Fvv(j-1)
             const double vt = sym_interp_scaled<P, true>([&](int m) { return sv[ly + m][lx]; }, ay, j - 1, Ny);
+#if OCN_LDS_SELECT == 2
+            myf3 = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
+#else
             myf3 = vt * bias_interp_lds(&sv[ly][lx], LX, vt > 0);
+#endif
             ex[3][tid] = myf3;
         }
         {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
@@ -554,11 +565,6 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZW
 #undef OCN_PC_APPLY
 #undef OCN_MYF
-#undef Lu
-#undef Lv
-#undef Lw
-#undef sv3
-#undef sw3
 }
 
 // K4 tracer: flux = (A * U[i,j,k]) * cR   (upwind_biased_advective_fluxes.jl:99-121)
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256) void tracer_tendency_direct(GridDev g, const d
 //  * thread (i, j) evaluates the west-face and south-face fluxes of its cell and the top-face flux; the east / north ones come
 //    from the neighbouring threads through LDS, the bottom one is last iteration's top flux.
 // 3 flux evaluations per thread and plane instead of 6; the flux expressions are those of the direct kernel (bit-identical).
-template <int TZ, int TX, int TY, int W = 1>
+template <int TZ, int TX, int TY, int W = 1, bool GL = false>
 __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, const double *__restrict__ u, const double *__restrict__ v,
                                                                const double *__restrict__ w, const double *__restrict__ c,
                                                                double *__restrict__ Gc, Range r, int KZ, ocn::TracerFuse tf)
@@ -695,7 +701,11 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
     const int lx = tx + 3, ly = ty + 3;
     const long long s3 = L0.s3;
     const long long own0 = ocn::at(L0, i, j, 1);
-    const double *pc = c + own0, *pu = u + own0, *pv = v + own0, *pw = w + own0;
+    // GL (see momentum_tendencies_tiled): the velocities have their own parent layouts on grids with a Bounded x / y
+    const Lay Lu = GL ? ocn::make_lay(g, OCN_LOC_FCC) : L0, Lv = GL ? ocn::make_lay(g, OCN_LOC_CFC) : L0, Lw = GL ? ocn::make_lay(g, OCN_LOC_CCF) : L0;
+    const long long su3 = GL ? Lu.s3 : s3, sv3 = GL ? Lv.s3 : s3, sw3 = GL ? Lw.s3 : s3;
+    const double *pc = c + own0, *pu = u + (GL ? ocn::at(Lu, i, j, 1) : own0), *pv = v + (GL ? ocn::at(Lv, i, j, 1) : own0),
+                 *pw = w + (GL ? ocn::at(Lw, i, j, 1) : own0);
 
     // static ring assignment (as in momentum_tendencies_tiled)
     int rcx[RPT], rcy[RPT];
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
     double fzb;
     {   // bottom-face flux of plane k_start: stencil c[k-3 .. k+2]
         const double cm3 = pc[(long long)(k - 4) * s3];
-        const double wf = pw[(long long)(k - 1) * s3];
+        const double wf = pw[(long long)(k - 1) * sw3];
         const double S[6] = {cm3, zc[0], zc[1], zc[2], zc[3], zc[4]};
         fzb = (az * wf) * bias_interp<TZ, false>([&](int m) { return S[m + 3]; }, k, Nz, wf > 0);
     }
@@ -748,9 +758,9 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
     double rv[RPT], uf, vf, wf, znew;
 #pragma unroll
     for (int s = 0; s < RPT; ++s) rv[s] = ron[s] ? c[roff[s] + (long long)(k - 1) * s3] : 0.0;
-    uf = pu[(long long)(k - 1) * s3];
-    vf = pv[(long long)(k - 1) * s3];
-    wf = pw[(long long)k * s3];
+    uf = pu[(long long)(k - 1) * su3];
+    vf = pv[(long long)(k - 1) * sv3];
+    wf = pw[(long long)k * sw3];
     znew = (k < k_end) ? pc[(long long)(k + 3) * s3] : 0.0;
     for (; k <= k_end; ++k) {
         // stage plane k (the previous iteration's readers of sc are past its second barrier)
@@ -779,9 +789,9 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
 #pragma unroll
             for (int s = 0; s < RPT; ++s)
                 if (ron[s]) rv_n[s] = c[roff[s] + (long long)k * s3];
-            uf_n = pu[(long long)k * s3];
-            vf_n = pv[(long long)k * s3];
-            wf_n = pw[(long long)(k + 1) * s3];
+            uf_n = pu[(long long)k * su3];
+            vf_n = pv[(long long)k * sv3];
+            wf_n = pw[(long long)(k + 1) * sw3];
             if (k + 1 < k_end) znew_n = pc[(long long)(k + 4) * s3];
         }
         if (writes && tf.sc.on && tf.sc.has_zeta) gm = tf.sub.Gm[o];
@@ -1146,6 +1156,63 @@ static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
         r.ou = r.ov = 1;  // x, y are never Bounded in the supported scope
         r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;  // periphery_offset(Face, Bounded, N) (:113-114)
     }
+    return OCN_SUCCESS;
+}
+
+// The interior box of a grid with walls in x / y (csrc/general.hip launch_*_general): cells i0..i1 x j0..j1 whose x and y reconstructions
+// are all the full-order ones (topologically_conditional_interpolation.jl:46-52: faces 4 .. N-2 and centres 3 .. N-2 of a Bounded
+// direction), so the LDS-tiled kernels apply with per-field parent layouts (GL); z stays topology-conditional inside the kernel.
+// Returns 0 in *launched when the box is too small for the tiles (the caller then covers everything with the per-cell kernel).
+int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
+                                   const int32_t box[4], int *launched, hipStream_t stream)
+{
+    *launched = 0;
+    Range r;
+    r.xcd = xcd_remap();
+    r.i0 = box[0]; r.i1 = box[1]; r.j0 = box[2]; r.j1 = box[3]; r.k0 = 1; r.k1 = grid->Nz;
+    r.ou = r.ov = 1;
+    r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = grid->Nz;
+    if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    ocn::FuseArgs fz{};
+    constexpr int TX = 32, TY = 8;
+    const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+    int KZ = wz;
+    while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+    dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+    if (grid->tz == OCN_PERIODIC)
+        hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_PERIODIC, TX, TY, 3, false, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, Gw, r, KZ, fz);
+    else
+        hipLaunchKernelGGL((momentum_tendencies_tiled<OCN_BOUNDED, TX, TY, 3, false, false, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, Gw, r, KZ, fz);
+    OCN_CHECK_HIP(hipGetLastError());
+    *launched = 1;
+    return OCN_SUCCESS;
+}
+
+int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                               const int32_t box[4], int *launched, hipStream_t stream)
+{
+    *launched = 0;
+    Range r;
+    r.xcd = xcd_remap();
+    r.i0 = box[0]; r.i1 = box[1]; r.j0 = box[2]; r.j1 = box[3]; r.k0 = 1; r.k1 = grid->Nz;
+    r.ou = r.ov = r.ow = 1;
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = grid->Nz;
+    if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    ocn::TracerFuse tf{};
+    constexpr int TX = 32, TY = 8;
+    const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
+    int KZ = wz;
+    while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
+    dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
+    if (grid->tz == OCN_PERIODIC)
+        hipLaunchKernelGGL((tracer_tendency_tiled<OCN_PERIODIC, TX, TY, 1, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+    else
+        hipLaunchKernelGGL((tracer_tendency_tiled<OCN_BOUNDED, TX, TY, 1, true>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, c, Gc, r, KZ, tf);
+    OCN_CHECK_HIP(hipGetLastError());
+    *launched = 1;
     return OCN_SUCCESS;
 }
 

@@ -695,6 +695,28 @@ def _time_step_qab2(model, dt, euler=False):
     update_state(model, compute_tendencies=True)
 
 
+def _advance_clock_one_rk3_step(model, dt):
+    """the clock after one time_step!(model::RungeKutta3, dt), as _time_step_rk3 leaves it"""
+    ts, clock = model.timestepper, model.clock
+    t_next = clock.time + dt
+    t2 = (clock.time + ts.g1 * dt) + (ts.g2 + ts.z2) * dt
+    clock.last_stage_dt = t_next - t2  # corrected_third_stage_Δt
+    clock.time = t_next
+    clock.iteration += 1
+    clock.stage = 1
+    clock.last_dt = dt
+
+
+def _adopt_driver_tendencies(model, pointers):
+    """G^n of a C driver (device pointers, one per prognostic field) -> the model's time stepper: the Python host's tendencies are then
+    current and nothing is pending."""
+    s = stream_ptr()
+    for G, ptr in zip(model.timestepper._Gn, pointers):
+        if ptr and ptr != G.ptr:
+            _lib.call("ocn_memcpy_d2d", G.ptr, ptr, G.data.numel() * 8, s)
+    model._pending_tendencies = False
+
+
 class RK3Driver:
     """The whole RK3 time_step! behind ONE entry point of the C ABI (ocn_rk3_driver_*, csrc/driver.hip): what a Julia host binds
     when it wants the fused stage boundaries without managing alternating array roles itself.  Wraps the velocity and pressure
@@ -729,10 +751,14 @@ class RK3Driver:
 
     def time_step(self, dt):
         _lib.call("ocn_rk3_driver_time_step", self._h, float(dt), stream_ptr())
+        _advance_clock_one_rk3_step(self.model, dt)
 
     def flush(self):
-        """velocities back in the model's fields, deferred tendencies completed"""
+        """velocities back in the model's fields, deferred tendencies completed -- in the driver's own G^n arrays, which are copied into the
+        model's time stepper so that the state is the one `time_step(model, dt)` + flush_tendencies leaves: a following
+        ocn.time_step(model, dt) or write_checkpoint sees the current G^n, not the values from before the driver took over."""
         _lib.call("ocn_rk3_driver_flush", self._h, stream_ptr())
+        _adopt_driver_tendencies(self.model, self.tendency_pointers())
 
     def tendency_pointers(self):
         ptrs = [C.c_void_p() for _ in range(6)]
@@ -833,14 +859,13 @@ class ModelRK3Driver:
 
     def time_step(self, dt):
         _lib.call("ocn_model_driver_time_step", self._h, float(dt), stream_ptr())
-        clock = self.model.clock
-        clock.time += dt
-        clock.iteration += 1
-        clock.last_dt = dt
+        _advance_clock_one_rk3_step(self.model, dt)
 
     def flush(self):
-        """every prognostic field back in the model's arrays, deferred tendencies completed"""
+        """every prognostic field back in the model's arrays, deferred tendencies completed and copied into the model's time stepper
+        (see RK3Driver.flush)"""
         _lib.call("ocn_model_driver_flush", self._h, stream_ptr())
+        _adopt_driver_tendencies(self.model, [self.tendency_pointer(n) for n in range(len(self.model.prognostic_fields()))])
 
     def tendency_pointer(self, n):
         f, G = C.c_void_p(), C.c_void_p()

@@ -513,7 +513,8 @@ def test_rccl_transport_world1_matches_single_rank_and_oracle(ocn, oracle, rccl_
             assert np.abs(a.interior() - og.interior(b)).max() <= 1e-11 * scale, name
 
 
-@pytest.mark.parametrize("N,pipeline", [((64, 128, 64), "alltoall"), ((48, 128, 64), "xtri"), ((16, 128, 64), "xtri")])
+@pytest.mark.parametrize("N,pipeline", [((64, 128, 64), "alltoall"), ((48, 128, 64), "xtri"), ((16, 128, 64), "xtri"),
+                                        ((48, 128, 64), "xtri-conservative")])
 def test_c_distributed_driver_equals_python_host_and_single_rank(ocn, rccl_arch, N, pipeline, monkeypatch):
     """ocn_rk3_driver_create_distributed: the whole RK3 step of ONE RANK of a slab-x run behind one C call -- local fills, the u plane,
     the strips of u*, v*, w* in flight under the distributed pressure solve, the pressure planes, one full-slab launch that corrects on
@@ -521,6 +522,12 @@ def test_c_distributed_driver_equals_python_host_and_single_rank(ocn, rccl_arch,
     of one rank talking to itself).  After flush: bit-identical (strict math) to the Python host driving the per-call entry points on
     the same architecture, and within 1e-11 / 1e-10 of the single-rank model."""
     P = "Periodic"
+    # "-conservative": the switches documented for a first multi-GPU run (OCN_DIST_CORRECT_ON_LOAD=0): the C driver then runs every
+    # exchange synchronously (no strip exchange in flight while the solver's collective runs), the Python host its interior / strip split
+    conservative = pipeline.endswith("-conservative")
+    pipeline = pipeline.split("-")[0]
+    if conservative:
+        monkeypatch.setenv("OCN_DIST_CORRECT_ON_LOAD", "0")
     monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1" if pipeline == "xtri" else "0")
     ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
     rng = np.random.default_rng(21)
@@ -535,7 +542,7 @@ def test_c_distributed_driver_equals_python_host_and_single_rank(ocn, rccl_arch,
 
     single = build(ocn.GPU())
     host = build(rccl_arch)
-    assert host.dist_correct_on_load
+    assert host.dist_correct_on_load == (not conservative)
     for _ in range(3):
         ocn.time_step(single, dt)
         ocn.time_step(host, dt)
@@ -881,6 +888,23 @@ recv = torch.zeros_like(send)
 arch.fabric.all_gather(recv, send)
 torch.cuda.synchronize()
 assert torch.equal(recv, send)
+# a strip exchange in flight on the communication stream WHILE the solver's exchange runs on the compute stream, both on ONE
+# communicator -- the order the distributed stage issues them in (csrc/driver.hip project_for_load): begin -> all_gather -> end
+g = ocn.RectilinearGrid(arch, size=(32, 16, 12), x=(0, 1), y=(0, 1), z=(0, 1), topology=("Periodic",) * 3, halo=(3, 3, 3))
+fields = [ocn.Field(l, g) for l in (1, 2, 4)]
+for n, f in enumerate(fields):
+    f.interior_view().copy_(torch.rand(f.interior_view().shape, device="cuda", dtype=torch.float64) + n)
+for rep in range(3):
+    arch.ops.local_fill(g, fields, False)
+    arch.fabric.halo_exchange_begin(g, fields)
+    recv.zero_()
+    arch.fabric.all_gather(recv, send + rep)
+    arch.fabric.halo_exchange_end(g, fields)
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send + rep)
+    for f in fields:
+        d, nx, H = f.data, g.Nx, 3
+        assert torch.equal(d[:, :, :H], d[:, :, nx:nx + H]) and torch.equal(d[:, :, nx + H:nx + 2 * H], d[:, :, H:2 * H])
 arch.fabric.close()
 print("ALL-GATHER-OK")
 """

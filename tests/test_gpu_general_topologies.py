@@ -19,6 +19,11 @@ CASES = [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((16, 1, 10), "PFB"), ((9, 1
          ((7, 8, 9), "PBP")]
 
 
+# large enough for the interior box of csrc/general.hip (cells a full stencil away from the x / y walls -> the LDS-tiled kernels with
+# per-field layouts; the frames next to the walls -> the per-cell kernel): every launch combination, ragged tile edges included
+BOX_CASES = [((40, 20, 9), "PBB"), ((30, 18, 8), "BBB"), ((26, 12, 10), "BPP"), ((45, 16, 12), "BPB"), ((33, 19, 9), "PBP"), ((70, 41, 6), "BBB")]
+
+
 def _pair(O, ocn, size, topo):
     return make_pair(O, ocn, size, topo, x=(0, 1.3), y=(0, 0.9), z=(-0.7, 0))
 
@@ -71,7 +76,7 @@ def test_value_and_gradient_conditions_on_x_y_walls(oracle, ocn, size, topo):
     np.testing.assert_array_equal(from_dev(d), a)
 
 
-@pytest.mark.parametrize("size,topo", CASES)
+@pytest.mark.parametrize("size,topo", CASES + BOX_CASES)
 @pytest.mark.parametrize("scheme", ["WENO5", "Centered2", "UpwindBiased5"])
 def test_advective_tendencies_strict_bitwise(oracle, ocn, size, topo, scheme):
     """compute_Gu! / Gv! / Gw! / Gc! with the order reduction near x / y walls, Flat shortcuts, per-location parent shapes and the
@@ -107,7 +112,47 @@ def test_advective_tendencies_strict_bitwise(oracle, ocn, size, topo, scheme):
             np.testing.assert_array_equal(from_dev(b), a)
 
 
-@pytest.mark.parametrize("size,topo", CASES)
+@pytest.mark.parametrize("size,topo", BOX_CASES)
+def test_interior_box_decomposition_equals_the_per_cell_kernel(ocn, size, topo):
+    """box (tiled, per-field layouts) + wall frames (per-cell) against the per-cell kernel over the whole grid (OCN_GENERAL_TILED=0, read
+    once per process: a child process), strict and fast math: the two launch plans evaluate the same expressions on the same operands"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+import oceananigans_jl_amd as ocn
+size, topo, mode = eval(sys.argv[1]), sys.argv[2], int(sys.argv[3])
+T = {"P": "Periodic", "B": "Bounded"}
+g = ocn.RectilinearGrid(ocn.GPU(), size=size, x=(0, 1.3), y=(0, 0.9), z=(-0.7, 0), topology=tuple(T[t] for t in topo), halo=(3, 3, 3)).with_math_mode(mode)
+gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+f = [ocn.Field(l, g) for l in (1, 2, 4, 0)]
+for q in f:
+    q.data.copy_(torch.rand(q.data.shape, generator=gen, device="cuda", dtype=torch.float64) - 0.5)
+ocn.fill_halo_regions(f)
+G = [ocn.Field(l, g) for l in (1, 2, 4, 0)]
+ocn._lib.call("ocn_compute_momentum_tendencies", g.cref, f[0].ptr, f[1].ptr, f[2].ptr, G[0].ptr, G[1].ptr, G[2].ptr, None, 0)
+ocn._lib.call("ocn_compute_tracer_tendency", g.cref, f[0].ptr, f[1].ptr, f[2].ptr, f[3].ptr, G[3].ptr, None, 0)
+ocn.sync_device()
+np.savez(sys.argv[4], *[q.data.cpu().numpy() for q in G])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    for mode in (ocn.MATH_STRICT, ocn.MATH_FAST):
+        outs = []
+        with tempfile.TemporaryDirectory() as td:
+            for tiled in ("1", "0"):
+                path = os.path.join(td, f"g{tiled}.npz")
+                p = subprocess.run([sys.executable, "-c", code, repr(size), topo, str(mode), path], env=dict(os.environ, OCN_GENERAL_TILED=tiled),
+                                   capture_output=True, text=True, timeout=300, cwd=root)
+                assert p.returncode == 0, p.stderr[-2000:]
+                outs.append(np.load(path))
+            for k in outs[0].files:
+                np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=f"{topo} mode {mode} {k}")
+                assert np.abs(outs[0][k]).max() > 0
+
+
+@pytest.mark.parametrize("size,topo", CASES + BOX_CASES)
 def test_advective_tendencies_fast_tolerance(oracle, ocn, size, topo):
     O = oracle
     if any(n < 3 for n, t in zip(size, topo) if t != "F"):

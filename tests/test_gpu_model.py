@@ -618,6 +618,41 @@ def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own, def
     del drv
 
 
+@pytest.mark.parametrize("size,topo,z", [((32, 16, 12), "PPP", (0, 2.0)), ((16, 12, 9), "PPB", "stretched")])
+def test_python_host_continues_after_a_c_driver(oracle, ocn, size, topo, z):
+    """Two steps through the C driver, flush, then ocn.time_step(model, dt) on the same model: flush hands the driver's G^n to the model's
+    time stepper and the clock has advanced, so the mixed run equals three steps of the Python host bit for bit (strict math) --
+    velocities, pressure, G^n, clock."""
+    O = oracle
+    rng = np.random.default_rng(11)
+    og, pg = _grid(O, ocn, size, topo, z)
+    init = {name: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for name, l in zip("uvw", LOCS)}
+    dt = 0.01
+
+    def build():
+        m = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), math_mode=ocn.MATH_STRICT)
+        ocn.set(m, **init)
+        return m
+
+    ref = build()
+    for _ in range(3):
+        ocn.time_step(ref, dt)
+    ocn.flush_tendencies(ref)
+    m = build()
+    drv = ocn.RK3Driver(m)
+    drv.time_step(dt)
+    drv.time_step(dt)
+    drv.flush()
+    assert m.clock.iteration == 2 and abs(m.clock.time - 2 * dt) < 1e-15
+    ocn.time_step(m, dt)
+    ocn.flush_tendencies(m)
+    ocn.sync_device()
+    for a, b in zip(ref.velocities + (ref.pNHS,) + tuple(ref.timestepper.Gn), m.velocities + (m.pNHS,) + tuple(m.timestepper.Gn)):
+        np.testing.assert_array_equal(og.interior_N(from_dev(a)), og.interior_N(from_dev(b)))
+    assert m.clock.iteration == ref.clock.iteration == 3 and m.clock.time == ref.clock.time and m.clock.last_stage_dt == ref.clock.last_stage_dt
+    del drv
+
+
 def test_plain_c_host_of_the_c_abi_matches_the_python_host(ocn, tmp_path):
     """examples/c_abi_rk3.c (built by __graft_entry__.build()): a C99 program with no Python and no torch allocates through
     ocn_malloc, runs set! and three RK3 time_step!s through ocn_rk3_driver_* and writes u, v, w.  The Python host driving the same

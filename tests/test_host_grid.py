@@ -120,3 +120,36 @@ def test_hydrostatic_timestepper_argument(pkg):
     import inspect
     sig = inspect.signature(pkg.HydrostaticFreeSurfaceModel.__init__)
     assert sig.parameters["timestepper"].default == "QuasiAdamsBashforth2"
+
+
+def test_julia_range_restatement_properties():
+    """grids._JuliaRange restates Base's TwicePrecision `range(start, stop, length = n)`; Julia is not installed, so the general case has
+    no reference value to compare with (the pins are the doctest prints of tests/golden/reference_fixtures.json).  What bounds a wrong
+    branch (the rational one, the truncated-step one with its bits = min(27, ...) rule, either reference index): for random (start,
+    stop, n) -- negative, irrational, tiny and huge end points -- the first and last elements ARE the end points, the elements are strictly
+    increasing (wherever the step is resolved by doubles of that magnitude), and each is within 1 ulp of the exactly interpolated rational start + (i - 1) (stop - start) / (n - 1)."""
+    import math
+    from fractions import Fraction
+    from oceananigans_jl_amd.grids import _JuliaRange
+    rng = np.random.default_rng(2024)
+    cases = [(0.0, 2 * math.pi, 129), (-math.pi, math.pi, 65), (0.0, 1.0, 4), (-1.0, 0.0, 1025), (0.1, 0.3, 3), (1e-9, 3e-9, 17),
+             (-5e6, 7.25e6, 513), (-0.7, 0.0, 9), (1 / 3, 2 / 3, 11), (-2.0 ** 0.5, 3.0 ** 0.5, 258)]
+    for _ in range(300):
+        a = float(rng.choice([rng.uniform(-10, 10), rng.uniform(-1e-6, 1e-6), rng.uniform(-1e7, 1e7), float(rng.integers(-50, 50)), rng.normal()]))
+        L = float(rng.choice([rng.uniform(1e-3, 10), rng.uniform(1e-9, 1e-6), rng.uniform(1e3, 1e7), float(rng.integers(1, 100)), math.pi * rng.uniform(0.1, 4)]))
+        cases.append((a, a + L, int(rng.integers(2, 2000))))
+    for start, stop, n in cases:
+        if not stop > start:
+            continue
+        r = _JuliaRange(start, stop, n)
+        vals = [r[i] for i in range(1, n + 1)]
+        assert vals[0] == start and vals[-1] == stop, (start, stop, n)
+        resolved = (stop - start) / (n - 1) > 4 * math.ulp(max(abs(start), abs(stop)))  # (a step below the spacing of doubles cannot be strict)
+        assert all((b > a) if resolved else (b >= a) for a, b in zip(vals, vals[1:])), (start, stop, n)
+        fs, fe = Fraction(start), Fraction(stop)
+        for i in (1, 2, n // 3 + 1, n // 2 + 1, n - 1, n):
+            if not 1 <= i <= n:
+                continue
+            exact = fs + (fe - fs) * Fraction(i - 1, n - 1)
+            scale = max(abs(start), abs(stop))  # ulp of the range's magnitude: elements near zero of a wide range are not relatively exact
+            assert abs(Fraction(vals[i - 1]) - exact) <= Fraction(math.ulp(scale)), (start, stop, n, i)

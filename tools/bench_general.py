@@ -32,6 +32,17 @@ for topo in ("PPP", "PPB", "PBB", "BBB"):
     for _ in range(5):
         ocn.solve_for_pressure(m.pNHS, m.pressure_solver, dt, m.velocities)
     e1.record(); torch.cuda.synchronize()
+    # the momentum tendency launch alone (box + frames on grids with walls; OCN_GENERAL_TILED=0: the per-cell kernel over everything)
+    Gn = m.timestepper.Gn
+    t0e, t1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    call = lambda: ocn._lib.call("ocn_compute_momentum_tendencies", g.cref, m.u.ptr, m.v.ptr, m.w.ptr, Gn[0].ptr, Gn[1].ptr, Gn[2].ptr, None, 0)
+    call(); torch.cuda.synchronize()
+    t0e.record()
+    for _ in range(10):
+        call()
+    t1e.record(); torch.cuda.synchronize()
+    tend_ms = t0e.elapsed_time(t1e) / 10
+    print(f"{topo} N={N}: momentum tendencies {tend_ms:.3f} ms per launch (OCN_GENERAL_TILED={os.environ.get('OCN_GENERAL_TILED', '1')})", flush=True)
     print(f"{topo} N={N}: {ms:.2f} ms/step ({N**3/ms/1e6:.0f} Mcell-updates/s), solve_for_pressure {e0.elapsed_time(e1)/5:.2f} ms, fused={m.fuse_stage_boundaries}", flush=True)
     del m, g
     torch.cuda.empty_cache()
