@@ -239,6 +239,8 @@ int ocn_update_hydrostatic_pressure_range(const ocn_grid *grid, const ocn_model_
 #define OCN_BC_FLUX 1
 #define OCN_BC_VALUE 2
 #define OCN_BC_GRADIENT 3
+#define OCN_BC_OPEN 4      /* OpenBoundaryCondition(value): the wall-normal velocity on the boundary face (fill_halo_regions_open.jl:65-70); on the
+                            * side of a field that is not Face-located along it the kind is ignored */
 typedef struct ocn_bc {
     int32_t kind;
     int32_t _pad;
@@ -626,8 +628,8 @@ int ocn_comm_init_local(ocn_comm_t *comm, int32_t rank, int32_t nranks, int64_t 
  * exists: what a peer would send is what this rank sends to the peer's mirror image, so every receive of a schedule is an asynchronous
  * device copy from one of the rank's own send buffers.  The schedules, pack / unpack launches, stream ordering, the nranks-rank
  * interface systems of the transpose-free pressure solve and the C drivers are those of a real nranks-rank run: the time of a step is
- * what ONE rank of nranks costs before any link time (tools/bench_dist_rank.py).  All-to-all exchanges have no mirror image: they move the
- * right bytes with the wrong contents (own chunk 0 forward, zeros back) -- timing only, the pressure of such a run is not a solution.
+ * what ONE rank of nranks costs before any link time (tools/bench_dist_rank.py).  All-to-all exchanges are refused (OCN_ERR_UNSUPPORTED):
+ * their chunks are addressed by absolute rank and have no mirror image.
  * Replaces nothing in the reference. */
 int ocn_comm_init_replica(ocn_comm_t *comm, int32_t nranks);
 int ocn_comm_destroy(ocn_comm_t comm);

@@ -22,7 +22,7 @@ from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, Runge
 from .output import (AdvectiveCFL, DiffusiveCFL, NaNChecker, TimeStepWizard, cell_advection_timescale, cell_diffusion_timescale, hasnan, set_from_checkpoint,
                      write_checkpoint)
 from .physics import (AnisotropicMinimumDissipation, BetaPlane, BoundaryCondition, BuoyancyTracer, Centered, FieldBoundaryConditions, FluxBoundaryCondition, FPlane,
-                      GradientBoundaryCondition, LinearEquationOfState, ScalarDiffusivity, SeawaterBuoyancy,
+                      GradientBoundaryCondition, LinearEquationOfState, OpenBoundaryCondition, ScalarDiffusivity, SeawaterBuoyancy,
                       ValueBoundaryCondition)
 from .solvers import (BatchedTridiagonalSolver, FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver,
                       nonhydrostatic_pressure_solver, solve)

@@ -68,7 +68,7 @@ class CCommOp(C.Structure):
 SCHED_STRIPS, SCHED_PLANE_EAST, SCHED_PLANE_WEST, SCHED_ALL_TO_ALL, SCHED_ALL_GATHER = 0, 1, 2, 3, 4
 ADVECTION_WENO5, ADVECTION_CENTERED2, ADVECTION_UPWIND5 = 0, 1, 2
 BUOYANCY_NONE, BUOYANCY_TRACER, BUOYANCY_SEAWATER_TS, BUOYANCY_SEAWATER_T, BUOYANCY_SEAWATER_S = 0, 1, 2, 3, 4
-BC_DEFAULT, BC_FLUX, BC_VALUE, BC_GRADIENT = 0, 1, 2, 3
+BC_DEFAULT, BC_FLUX, BC_VALUE, BC_GRADIENT, BC_OPEN = 0, 1, 2, 3, 4
 
 _lib = None
 

@@ -581,10 +581,11 @@ static int make_zbc_tuple(const ocn_grid *grid, const int32_t *locs, const ocn_f
         const ocn_bc *side[2] = {&b.bottom, &b.top};
         for (int sd = 0; sd < 2; ++sd) {
             const ocn_bc &c = *side[sd];
-            OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+            OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "field %d: unknown boundary condition kind %d", f, c.kind);
             if (c.kind == OCN_BC_DEFAULT) continue;
             OCN_REQUIRE(grid->tz == OCN_BOUNDED, "bottom / top boundary conditions need a Bounded z (topology %d)", grid->tz);
-            OCN_REQUIRE(!(locs[f] & 4), "field %d: w keeps its impenetrable bottom / top condition", f);
+            OCN_REQUIRE(((locs[f] & 4) != 0) == (c.kind == OCN_BC_OPEN),
+                        "field %d: the wall-normal velocity takes an Open condition (its value on the boundary face), the other fields Flux / Value / Gradient", f);
             OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions are not supported on a partitioned grid");
             if (flux_only && c.kind != OCN_BC_FLUX) continue;
             ZBc &d = sd ? z.top[f] : z.bottom[f];
@@ -605,7 +606,7 @@ static int flux_side(const ocn_grid *grid, const ocn_field_bcs *b, const char *n
     const ocn_bc *side[2] = {&b->bottom, &b->top};
     for (int sd = 0; sd < 2; ++sd) {
         const ocn_bc &c = *side[sd];
-        OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "%s: unknown boundary condition kind %d", name, c.kind);
+        OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "%s: unknown boundary condition kind %d", name, c.kind);
         if (c.kind != OCN_BC_FLUX) continue;
         OCN_REQUIRE(grid->tz == OCN_BOUNDED, "bottom / top boundary conditions need a Bounded z (topology %d)", grid->tz);
         OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions are not supported on a partitioned grid");
@@ -875,10 +876,11 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
             const ocn_bc *side[6] = {&bcs[f]->west, &bcs[f]->east, &bcs[f]->south, &bcs[f]->north, &bcs[f]->bottom, &bcs[f]->top};
             for (int q = 0; q < 6; ++q) {
                 const ocn_bc &c = *side[q];
-                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "field %d: unknown boundary condition kind %d", f, c.kind);
                 if (c.kind == OCN_BC_DEFAULT) continue;
                 OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
-                OCN_REQUIRE(!((locs[f] >> (q / 2)) & 1), "field %d: the wall-normal velocity keeps its impenetrable condition", f);
+                OCN_REQUIRE((((locs[f] >> (q / 2)) & 1) != 0) == (c.kind == OCN_BC_OPEN),
+                            "field %d: the wall-normal velocity takes an Open condition (its value on the boundary face), the other fields Flux / Value / Gradient", f);
                 sb.side[q][f] = ZBc{c.kind, c.value, c.coeff, c.values};
                 any = true;
             }
@@ -912,7 +914,7 @@ int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *con
             const ocn_bc *side[6] = {&bcs[f]->west, &bcs[f]->east, &bcs[f]->south, &bcs[f]->north, &bcs[f]->bottom, &bcs[f]->top};
             for (int q = 0; q < 6; ++q) {
                 const ocn_bc &c = *side[q];
-                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_GRADIENT, "field %d: unknown boundary condition kind %d", f, c.kind);
+                OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "field %d: unknown boundary condition kind %d", f, c.kind);
                 if (c.kind != OCN_BC_FLUX) continue;
                 OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
                 OCN_REQUIRE(!((locs[f] >> (q / 2)) & 1), "field %d: the wall-normal velocity keeps its impenetrable condition", f);

@@ -70,7 +70,6 @@ struct Comm {
     // would send me is what I send to its mirror image, so every receive is an asynchronous device copy from one of my own send buffers.
     // Timing of ONE rank of an R-rank run on a one-GPU box with the R-rank schedules, kernels and drivers (tools/bench_dist_rank.py).
     bool replica = false;
-    unsigned replica_a2a = 0;  // all-to-alls issued (replica transport: forward / return alternate)
     // ocn_comm_enable_stats: event pairs around every exchange (category, start, stop), summed by ocn_comm_stats
     bool stats = false;
     struct StatPair { int cat; hipEvent_t a, b; };
@@ -386,17 +385,10 @@ int run_schedule(Comm *c, int kind, const double *const *send, double *const *re
     if (c->replica) {
         // the k-th receive from peer s pairs with s's k-th send to me (RCCL's rule) = my k-th send to the mirror peer (R - s) mod R
         if (kind == OCN_SCHED_ALL_TO_ALL) {
-            // An all-to-all addresses its chunks by absolute rank and has no mirror image.  TIMING ONLY (the Bounded-z slab solver has
-            // no transpose-free form yet): the forward exchange of a solve delivers this rank's own chunk 0 as every peer's chunk (what
-            // identical ranks send), the return exchange zeros -- the other ranks' parts of the solution are never computed here, so the
-            // pressure is not the true one; the same bytes move and the same kernels run.
-            const bool forward = (c->replica_a2a++ % 2) == 0;
-            for (int q = 0; q < n; ++q) {
-                if (!ops[q].is_recv) continue;
-                if (forward) OCN_CHECK_HIP(hipMemcpyAsync(recv[ops[q].slot], send[0], count * sizeof(double), hipMemcpyDeviceToDevice, stream));
-                else OCN_CHECK_HIP(hipMemsetAsync(recv[ops[q].slot], 0, count * sizeof(double), stream));
-            }
-            return OCN_SUCCESS;
+            // chunks are addressed by absolute rank: the return exchange of a solve would have to deliver the other ranks' parts of the
+            // solution, which nobody computes here (tried: zeros / own chunks -- the resulting pressure destabilises the run within two steps)
+            ocn::set_error("replica transport: an all-to-all has no mirror image (use the transpose-free pressure solve, or a one-rank RCCL world at the local size)");
+            return OCN_ERR_UNSUPPORTED;
         }
         int taken[OCN_COMM_MAX_RANKS] = {};
         for (int q = 0; q < n; ++q) {

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a
         double val = c[at(L, si, sj, sk)];
         if (TZ == OCN_BOUNDED && has_bc && sk != k) {  // first z-halo plane of a Center-in-z field
             const ZBc &bc = (k == 0) ? zbc.bottom[f] : zbc.top[f];
-            if (bc.kind >= OCN_BC_VALUE) {
+            if (bc.kind == OCN_BC_VALUE || bc.kind == OCN_BC_GRADIENT) {
                 const int kb = (k == 0) ? 1 : g.Nz + 1;  // boundary face index kᴮ
                 const double D = g.dzf ? uniform_load(g.dzf, kb + g.Hz - 1) : g.dz;
                 const double bv = bc_condition(bc, si, sj, g.Nx, val);
@@ -85,14 +85,15 @@ __global__ __launch_bounds__(256) void fill_halos_kernel(GridDev g, FieldTuple a
     }
 }
 
-// Impenetrable walls: wall-normal velocity on both boundary faces <- 0 (fill_halo_regions_open.jl:65-70)
-__global__ void open_fill_z_kernel(GridDev g, double *__restrict__ w)
+// Open fill: the wall-normal velocity on both boundary faces <- getbc (fill_halo_regions_open.jl:65-70): 0 for the default Impenetrable
+// condition, the number / array of an OpenBoundaryCondition(value) (OCN_BC_OPEN) otherwise
+__global__ void open_fill_z_kernel(GridDev g, double *__restrict__ w, ZBc bottom, ZBc top)
 {
     const Lay L = make_lay(g, OCN_LOC_CCF);
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x, j = 1 + blockIdx.y;
     if (i > g.Nx) return;
-    w[at(L, i, j, 1)] = 0.0;
-    w[at(L, i, j, g.Nz + 1)] = 0.0;
+    w[at(L, i, j, 1)] = bottom.kind == OCN_BC_OPEN ? bc_condition(bottom, i, j, g.Nx, 0.0) : 0.0;
+    w[at(L, i, j, g.Nz + 1)] = top.kind == OCN_BC_OPEN ? bc_condition(top, i, j, g.Nx, 0.0) : 0.0;
 }
 
 int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill, int only_dir, hipStream_t stream,
@@ -105,7 +106,7 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
     if (open_fill && grid->tz == OCN_BOUNDED) {
         for (int f = 0; f < ft.n; ++f)
             if (ft.loc[f] == OCN_LOC_CCF)
-                hipLaunchKernelGGL(open_fill_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, stream, g, ft.f[f]);
+                hipLaunchKernelGGL(open_fill_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, stream, g, ft.f[f], zbc.bottom[f], zbc.top[f]);
     }
     const int wrap_x = (grid->tx == OCN_PERIODIC);
     long long maxcells = 0;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, Fiel
         if (mirror && has_bc) {
             const int d = mirror_dir, lo = idx[d] == 0;
             const ZBc &bc = bcs.side[2 * d + (lo ? 0 : 1)][f];
-            if (bc.kind >= OCN_BC_VALUE) {  // fill_halo_regions_value_gradient.jl:5-103
+            if (bc.kind == OCN_BC_VALUE || bc.kind == OCN_BC_GRADIENT) {  // fill_halo_regions_value_gradient.jl:5-103
                 const int ib = lo ? 1 : N[d] + 1;  // boundary face index
                 const double D = d == 0 ? g.dx : d == 1 ? g.dy : (g.dzf ? uniform_load(g.dzf, ib + g.Hz - 1) : g.dz);
                 const int a1 = d == 0 ? src[1] : src[0], a2 = d == 2 ? src[1] : src[2];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, Fiel
 }
 
 // Impenetrable walls in direction d for the field whose wall-normal direction it is (fill_halo_regions_open.jl:65-70)
-__global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int loc, int d)
+__global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int loc, int d, ZBc blo, ZBc bhi)
 {
     const Lay L = make_lay(g, loc);
     const int N[3] = {g.Nx, g.Ny, g.Nz};
@@ -234,8 +235,9 @@ __global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int 
     lo[d2] = hi[d2] = b;
     lo[d] = 1;
     hi[d] = N[d] + 1;
-    c[at(L, lo[0], lo[1], lo[2])] = 0.0;
-    c[at(L, hi[0], hi[1], hi[2])] = 0.0;
+    // getbc(bc, a, b): 0 for the default Impenetrable condition, the number / array of an OpenBoundaryCondition(value) otherwise
+    c[at(L, lo[0], lo[1], lo[2])] = blo.kind == OCN_BC_OPEN ? bc_condition(blo, a, b, N[d1], 0.0) : 0.0;
+    c[at(L, hi[0], hi[1], hi[2])] = bhi.kind == OCN_BC_OPEN ? bc_condition(bhi, a, b, N[d1], 0.0) : 0.0;
 }
 
 int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int open_fill, hipStream_t stream, const SideBcTuple *bcs_in)
@@ -250,7 +252,8 @@ int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int op
             for (int d = 0; d < 3; ++d)
                 if (T[d] == OCN_BOUNDED && ft.loc[f] == (1 << d)) {
                     const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
-                    hipLaunchKernelGGL(open_fill_general_kernel, dim3((N[d1] + 63) / 64, N[d2]), dim3(64), 0, stream, g, ft.f[f], ft.loc[f], d);
+                    hipLaunchKernelGGL(open_fill_general_kernel, dim3((N[d1] + 63) / 64, N[d2]), dim3(64), 0, stream, g, ft.f[f], ft.loc[f], d,
+                                       bcs.side[2 * d][f], bcs.side[2 * d + 1][f]);
                 }
     }
     long long maxcells = 0;

@@ -247,7 +247,15 @@ int update_state_split(ocn_model_driver *d, double dt, double gamma, double zeta
     OCN_TRY(diffusivities(2, nx - 1, stream));
     OCN_TRY(hydrostatic(1, nx, stream));
     if (amd) OCN_TRY(ocn_fill_halo_regions(&d->grid, aux, auxl, 1 + d->nt, 1, stream));  // their y / z halos
-    const int32_t interior[6] = {Hx + 1, nx - Hx, 1, Ny, 1, Nz};
+    // The reference's buffers are Hx wide (compute_nonhydrostatic_buffer_tendencies.jl:28-39); any width >= Hx gives the same result
+    // cell for cell (OCN_DIST_BUFFER_WIDTH).  Measured at the R = 8 local size of config 4 (64 x 512 x 256, no link time): no split 5.96
+    // ms per rank-step, Hx-wide buffers 7.24, 16-wide buffers (full tile columns) 7.75 -- the wider strips serialise more work behind
+    // the exchange than their better tiles save.
+    static const int forced = std::getenv("OCN_DIST_BUFFER_WIDTH") ? std::atoi(std::getenv("OCN_DIST_BUFFER_WIDTH")) : 0;
+    int W = forced > 0 ? forced : Hx;
+    if (W < Hx) W = Hx;
+    if (nx - 2 * W < 1) W = Hx;
+    const int32_t interior[6] = {W + 1, nx - W, 1, Ny, 1, Nz};
     OCN_TRY(launch_tendencies(d, dt, gamma, zeta, has_zeta, interior, stream));
     OCN_TRY(ocn_halo_exchange_end(d->comm, &d->grid, d->U, d->locs, d->n, stream));
     OCN_TRY(diffusivities(0, 1, stream));
@@ -255,7 +263,7 @@ int update_state_split(ocn_model_driver *d, double dt, double gamma, double zeta
     OCN_TRY(hydrostatic(0, 0, stream));
     OCN_TRY(hydrostatic(nx + 1, nx + 1, stream));
     if (amd) OCN_TRY(ocn_fill_halo_regions(&d->grid, aux, auxl, 1 + d->nt, 1, stream));
-    const int w1 = Hx < nx ? Hx : nx, e0 = (nx - Hx + 1 > w1 + 1) ? nx - Hx + 1 : w1 + 1;
+    const int w1 = W < nx ? W : nx, e0 = (nx - W + 1 > w1 + 1) ? nx - W + 1 : w1 + 1;
     const int32_t west[6] = {1, w1, 1, Ny, 1, Nz}, east[6] = {e0, nx, 1, Ny, 1, Nz};
     if (e0 <= nx) {  // the two strips are independent and each too small to fill the chip: side by side
         hipStream_t cur = ocn::as_stream(stream);

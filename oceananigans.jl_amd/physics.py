@@ -200,7 +200,8 @@ class SeawaterBuoyancy:
 # Boundary conditions
 # --------------------------------------------------------------------------------------------------------
 class BoundaryCondition:
-    """BoundaryCondition(classification, condition).  `condition` is a number or an (Nx, Ny) array; `coeff` restates the
+    """BoundaryCondition(classification, condition).  `condition` is a number, an array over the boundary's two tangential directions
+    or a function of the tangential coordinates and time; `coeff` restates the
     ContinuousBoundaryFunction  f(x, y, t, c, p) = p * c  with field_dependencies = the field itself as
     condition + coeff * c[i, j, boundary-adjacent cell] (include/ocn_hip.h: struct ocn_bc)."""
 
@@ -223,17 +224,31 @@ class BoundaryCondition:
             self.values = np.ascontiguousarray(np.asarray(condition, dtype=np.float64).T)  # stored [j, i]: x fastest
         self._device_values = None
 
-    def refresh(self, grid, loc, time):
-        """Re-evaluate a function-valued condition at `time` (no-op otherwise)."""
+    # the two directions tangential to a side, in the order the kernels index `values` (first one fastest): csrc/kernels.hip
+    # fill_halos_general_kernel / apply_flux_bcs_lateral_kernel / apply_flux_bcs_kernel -> values[(a1 - 1) + n1 (a2 - 1)]
+    _TANGENTIAL = {"west": (1, 2), "east": (1, 2), "south": (0, 2), "north": (0, 2), "bottom": (0, 1), "top": (0, 1)}
+
+    def _extents(self, grid, side):
+        N = (grid.Nx, grid.Ny, grid.Nz)
+        d1, d2 = self._TANGENTIAL[side]
+        return N[d1], N[d2]
+
+    def refresh(self, grid, loc, time, side="top"):
+        """Re-evaluate a function-valued condition at `time` (no-op otherwise): f(ξ, η, t[, p]) of the two coordinates tangential to the
+        boundary -- (x, y) on bottom / top, (y, z) on west / east, (x, z) on south / north -- at the field's own nodes there
+        (continuous_boundary_function.jl:17-115: the reference's ContinuousBoundaryFunction without field dependencies)."""
         if self.func is None:
             return
-        x, y, _ = grid.nodes(loc)
-        x, y = x[:grid.Nx].reshape(-1, 1), y[:, :grid.Ny].reshape(1, -1)
-        # the coordinates of Flat directions are not arguments (continuous_boundary_function.jl: a top condition on a
-        # (Bounded, Flat, Bounded) grid is f(x, t[, p]), examples/horizontal_convection.jl:47)
-        coords = tuple(c for c, t in zip((x, y), grid.topology[:2]) if t != "Flat")
+        d1, d2 = self._TANGENTIAL[side]
+        n1, n2 = self._extents(grid, side)
+        nodes = grid.nodes(loc)
+        c1 = np.asarray(nodes[d1]).reshape(-1)[:n1].reshape(-1, 1)
+        c2 = np.asarray(nodes[d2]).reshape(-1)[:n2].reshape(1, -1)
+        # the coordinates of Flat directions are not arguments (a top condition on a (Bounded, Flat, Bounded) grid is f(x, t[, p]),
+        # examples/horizontal_convection.jl:47)
+        coords = tuple(c for c, d in zip((c1, c2), (d1, d2)) if grid.topology[d] != "Flat")
         args = coords + (float(time),) if self.parameters is None else coords + (float(time), self.parameters)
-        vals = np.broadcast_to(np.asarray(self.func(*args), dtype=np.float64), (grid.Nx, grid.Ny))
+        vals = np.broadcast_to(np.asarray(self.func(*args), dtype=np.float64), (n1, n2))
         self.values = np.array(vals.T, dtype=np.float64, order="C")  # (a copy: broadcast views are read-only)
         if self._device_values is None:
             self._device_values = on_architecture(grid.architecture, self.values)
@@ -241,13 +256,14 @@ class BoundaryCondition:
             import torch
             self._device_values.copy_(torch.from_numpy(self.values))
 
-    def c_struct(self, grid):
+    def c_struct(self, grid, side="top"):
         ptr = None
         if self.func is not None and self._device_values is None:
             raise RuntimeError("function-valued boundary condition used before its first evaluation (update_boundary_conditions)")
         if self.values is not None:
-            if self.values.shape != (grid.Ny, grid.Nx):
-                raise ValueError(f"array boundary condition has shape {self.values.T.shape}, expected {(grid.Nx, grid.Ny)}")
+            n1, n2 = self._extents(grid, side)
+            if self.values.shape != (n2, n1):
+                raise ValueError(f"array boundary condition on the {side} boundary has shape {self.values.T.shape}, expected {(n1, n2)}")
             if self._device_values is None:
                 self._device_values = on_architecture(grid.architecture, self.values)
             ptr = self._device_values.data_ptr()
@@ -266,21 +282,25 @@ def GradientBoundaryCondition(condition=0.0, parameters=None):
     return BoundaryCondition(_lib.BC_GRADIENT, condition, parameters=parameters)
 
 
+def OpenBoundaryCondition(condition=0.0, parameters=None):
+    """OpenBoundaryCondition(value) on the side a velocity component is normal to: that component ON the boundary face is set to the
+    value (a number, an array over the tangential directions or a function of the tangential coordinates and time) by every halo fill
+    that fills boundary-normal velocities (fill_halo_regions_open.jl:9-70); the default Impenetrable condition is Open(nothing) = 0."""
+    return BoundaryCondition(_lib.BC_OPEN, condition, parameters=parameters)
+
+
 class FieldBoundaryConditions:
     """FieldBoundaryConditions(; west, east, south, north, bottom, top); unspecified sides keep the topology defaults
-    (field_boundary_conditions.jl:15-33).  Flux, Value, Gradient on every side of a Bounded direction (west / east / south / north:
-    numbers only; the fluxes enter through apply_x_bcs! / apply_y_bcs!, apply_flux_bcs.jl:38-146)."""
+    (field_boundary_conditions.jl:15-33).  Flux, Value, Gradient on every side of a Bounded direction, each a number, condition +
+    coeff * c, an array over the two tangential directions ((Ny, Nz) on west / east, (Nx, Nz) on south / north, (Nx, Ny) on bottom /
+    top) or a function of the tangential coordinates and time; the fluxes of the lateral sides enter through apply_x_bcs! /
+    apply_y_bcs! (apply_flux_bcs.jl:38-146)."""
     SIDES = ("west", "east", "south", "north", "bottom", "top")
 
     def __init__(self, **sides):
         for k in sides:
             if k not in self.SIDES:
                 raise TypeError(f"unknown boundary {k!r}")
-        for k in ("west", "east", "south", "north"):
-            b = sides.get(k)
-            if b is not None and (b.values is not None or b.func is not None):
-                raise NotImplementedError("array / function boundary conditions on west / east / south / north are not implemented "
-                                          "(numbers and condition + coeff * c are)")
         self.sides = {k: sides.get(k) for k in self.SIDES}
         self._c = None
 
@@ -289,9 +309,9 @@ class FieldBoundaryConditions:
 
     def refresh(self, grid, loc, time):
         """update_boundary_condition! for function-valued conditions: evaluate them at the clock time"""
-        for v in self.sides.values():
+        for k, v in self.sides.items():
             if v is not None:
-                v.refresh(grid, loc, time)
+                v.refresh(grid, loc, time, k)
 
     def has_flux(self):
         return any(v is not None and v.kind == _lib.BC_FLUX for v in self.sides.values())
@@ -299,5 +319,5 @@ class FieldBoundaryConditions:
     def c_struct(self, grid):
         if self._c is None:
             default = _lib.CBc(_lib.BC_DEFAULT, 0, 0.0, 0.0, None)
-            self._c = _lib.CFieldBcs(*[(default if self.sides[k] is None else self.sides[k].c_struct(grid)) for k in self.SIDES])
+            self._c = _lib.CFieldBcs(*[(default if self.sides[k] is None else self.sides[k].c_struct(grid, k)) for k in self.SIDES])
         return self._c

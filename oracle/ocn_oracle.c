@@ -735,7 +735,8 @@ void ocn_oracle_tracer_diffusion(const ocn_grid *g, double kappa, const double *
     ocn_oracle_tracer_diffusion_kappa(g, kappa, NULL, c, Gc);
 }
 
-/* Boundary conditions on one side.  kind: 0 default (Periodic / no-flux / impenetrable), 1 Flux, 2 Value, 3 Gradient.
+/* Boundary conditions on one side.  kind: 0 default (Periodic / no-flux / impenetrable), 1 Flux, 2 Value, 3 Gradient, 4 Open (a
+ * prescribed wall-normal velocity).
  * The condition is  value + coeff * c[interior cell next to the boundary]  (coeff = 0 for a plain number; the
  * coeff form restates a ContinuousBoundaryFunction  f(x, y, t, c, p) = p * c  with field_dependencies = the field itself,
  * whose argument is c[i, j, Nz] (continuous_boundary_function.jl:107-115, 73-74)), or values[(i-1) + n1*(j-1)]
@@ -1128,9 +1129,10 @@ void ocn_oracle_fill_flux(const ocn_grid *g, int loc, double *c, int dir)
             c[AT(L, hi[0], hi[1], hi[2])] = c[AT(L, hi_src[0], hi_src[1], hi_src[2])];
         }
 }
-/* Open (impenetrable) fill: wall-normal velocity on boundary faces set to 0
- * (fill_halo_regions_open.jl:65-70, boundary_condition.jl:90,113). */
-void ocn_oracle_fill_open(const ocn_grid *g, int loc, double *c, int dir)
+/* Open fill (fill_halo_regions_open.jl:65-70): the wall-normal velocity on the two boundary faces is set to getbc(bc, ...) -- 0 for the
+ * default Impenetrable condition Open(nothing) (boundary_condition.jl:90,113), the number / array of an OpenBoundaryCondition(value)
+ * (kind 4) otherwise; left / right may be NULL (default). */
+void ocn_oracle_fill_open_bcs(const ocn_grid *g, int loc, double *c, int dir, const ocn_bc *left, const ocn_bc *right)
 {
     lay L = mklay(g, loc & 1, (loc >> 1) & 1, (loc >> 2) & 1);
     int N[3] = {g->Nx, g->Ny, g->Nz};
@@ -1142,10 +1144,11 @@ void ocn_oracle_fill_open(const ocn_grid *g, int loc, double *c, int dir)
             lo[d2] = hi[d2] = b;
             lo[dir] = 1;
             hi[dir] = N[dir] + 1;
-            c[AT(L, lo[0], lo[1], lo[2])] = 0.0;
-            c[AT(L, hi[0], hi[1], hi[2])] = 0.0;
+            c[AT(L, lo[0], lo[1], lo[2])] = (left && left->kind == 4) ? getbc(left, a, b, N[d1], 0.0) : 0.0;
+            c[AT(L, hi[0], hi[1], hi[2])] = (right && right->kind == 4) ? getbc(right, a, b, N[d1], 0.0) : 0.0;
         }
 }
+void ocn_oracle_fill_open(const ocn_grid *g, int loc, double *c, int dir) { ocn_oracle_fill_open_bcs(g, loc, c, dir, NULL, NULL); }
 
 /* =====================================================================================
  * Fourier-tridiagonal solver pieces

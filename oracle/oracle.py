@@ -216,7 +216,7 @@ class _CBC(C.Structure):
 class BC:
     """One side's boundary condition: kind in {"flux", "value", "gradient"}; the condition is a number, a 2-D array over
     the boundary's interior extent, or `value + coeff * c[interior neighbour]` (see ocn_bc in ocn_oracle.c)."""
-    KINDS = {"default": 0, "flux": 1, "value": 2, "gradient": 3}
+    KINDS = {"default": 0, "flux": 1, "value": 2, "gradient": 3, "open": 4}
 
     def __init__(self, kind, value=0.0, coeff=0.0, values=None):
         self.kind = self.KINDS[kind]
@@ -239,6 +239,11 @@ def GradientBoundaryCondition(v=0.0):
     return BC("gradient", v) if np.isscalar(v) else BC("gradient", values=v)
 
 
+def OpenBoundaryCondition(v=0.0):
+    """OpenBoundaryCondition(value): the wall-normal velocity on the boundary face (boundary_condition.jl, fill_halo_regions_open.jl:65-70)"""
+    return BC("open", v) if np.isscalar(v) else BC("open", values=v)
+
+
 _SIDES = (("west", "east"), ("south", "north"), ("bottom", "top"))
 
 
@@ -255,7 +260,9 @@ def fill_halo_regions(g, a, loc, fill_boundary_normal_velocities=True, bcs=None)
     if fill_boundary_normal_velocities:
         for d in range(3):  # fill_open_boundary_regions! (fill_halo_regions_open.jl:9-34)
             if g.topo[d] == BOUNDED and (loc >> d) & 1 and loc in (1, 2, 4):
-                L.ocn_oracle_fill_open(g.cref, loc, _p(a), d)
+                lo, hi = bcs.get(_SIDES[d][0]), bcs.get(_SIDES[d][1])
+                clo, chi = (None if lo is None else lo.c()), (None if hi is None else hi.c())
+                L.ocn_oracle_fill_open_bcs(g.cref, loc, _p(a), d, None if clo is None else C.byref(clo), None if chi is None else C.byref(chi))
     for d in range(3):  # non-periodic first
         if g.topo[d] == BOUNDED and not ((loc >> d) & 1):
             lo, hi = bcs.get(_SIDES[d][0]), bcs.get(_SIDES[d][1])
