@@ -152,6 +152,16 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
                                         int32_t has_zeta, const double *p_correct, double dt_correct, const int32_t *range,
                                         void *stream);
+/* The same launch for the correction-on-load stage of ONE RANK of a slab-x run (p_correct required, full range) that additionally writes
+ * the stepped velocities of its Hx westmost / eastmost columns into the send buffers of the next x-halo exchange
+ * (ocn_halo_exchange_buffers: field q at q * field_doubles, then h + Hx * parent row; interior rows only), so that
+ * ocn_halo_exchange_begin_packed can post the exchange without a pack launch (Fields/field_boundary_buffers.jl:276-308 fills its
+ * buffers with a separate broadcast per field and side).  No reference counterpart; results identical. */
+int ocn_compute_momentum_tendencies_rk3_strips(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                               double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
+                                               double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
+                                               int32_t has_zeta, const double *p_correct, double dt_correct, double *strip_west,
+                                               double *strip_east, int64_t field_doubles, void *stream);
 /* compute_Gc! (compute_nonhydrostatic_tendencies.jl:186-195; tracer_tendency :228-259) */
 int ocn_compute_tracer_tendency(const ocn_grid *grid, const double *u, const double *v, const double *w,
                                 const double *c, double *Gc, const int32_t *range, void *stream);
@@ -640,6 +650,14 @@ int ocn_comm_info(ocn_comm_t comm, int32_t *rank, int32_t *nranks, int32_t *rccl
  * grouped send / recv per neighbour (rank -+ 1, wrapping) on the communication stream.  `stream` stays free for the interior
  * tendency launch (interleave_communication_and_computation.jl:29-67). */
 int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
+/* The send buffers of the next ocn_halo_exchange_begin_packed for fields of these locations (one cross-section, Periodic y and z) and the
+ * number of doubles per field in them; valid until the next exchange of a larger tuple. */
+int ocn_halo_exchange_buffers(ocn_comm_t comm, const ocn_grid *grid, const int32_t *locs, int32_t n, double **send_west, double **send_east,
+                              int64_t *field_doubles);
+/* ocn_halo_exchange_begin without its pack launch: the send buffers were filled on `stream` (interior rows only) by
+ * ocn_compute_momentum_tendencies_rk3_strips; ocn_halo_exchange_end unpacks with periodically wrapped (j, k), which gives every
+ * halo cell -- corners included -- the value the local fills + full-cross-section strips of ocn_halo_exchange_begin give it. */
+int ocn_halo_exchange_begin_packed(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
 /* synchronize_communication!: `stream` waits for the exchange (event) and unpacks the received strips into the x halos. */
 int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream);
 /* one x plane from a neighbour, in stream order (side 0: field[nx+1] <- east neighbour's field[1]; 1: field[0] <- west's field[nx]) */

@@ -101,6 +101,8 @@ sync_device!(::HIPGPU) = check(ccall((:ocn_sync, lib), Cint, (Ptr{Cvoid},), C_NU
 "OCN_MATH_STRICT (0): the reference's operand order, bit-identical to its CPU arithmetic; OCN_MATH_FAST (1): FMA contraction."
 set_math_mode!(mode::Integer) = check(ccall((:ocn_set_math_mode, lib), Cint, (Cint,), mode))
 math_mode() = Int(ccall((:ocn_get_math_mode, lib), Cint, ()))
+"ocn_grid.math of the grids this extension builds: 0 process default, 1 strict, 2 fast"
+const HIP_MATH_MODE = Ref{Int32}(0)
 
 # ---- struct ocn_grid (include/ocn_hip.h) ------------------------------------------------------------------------------
 struct OcnGrid
@@ -117,7 +119,8 @@ const HIPGrid = RectilinearGrid{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:Any,
 function OcnGrid(g::RectilinearGrid)
     TX, TY, TZ = topology(g)
     stretched = !(g.z.Δᵃᵃᶜ isa Number)
-    OcnGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, topo_code(TX), topo_code(TY), topo_code(TZ), 0,
+    # `math`: 0 = the process default (set_math_mode!), 1 = strict, 2 = fast -- a per-grid / per-model choice (HIP_MATH_MODE[] here)
+    OcnGrid(g.Nx, g.Ny, g.Nz, g.Hx, g.Hy, g.Hz, topo_code(TX), topo_code(TY), topo_code(TZ), HIP_MATH_MODE[],
             g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, stretched ? 0.0 : g.z.Δᵃᵃᶜ, g.Lx, g.Ly, g.Lz,
             stretched ? parent(g.z.Δᵃᵃᶜ).ptr : Ptr{Float64}(C_NULL),          # element 0 <-> k = 1-Hz
             stretched ? parent(g.z.Δᵃᵃᶠ).ptr + 8 : Ptr{Float64}(C_NULL))      # parent starts at k = -Hz -> skip one
@@ -329,6 +332,15 @@ exchange_plane!(c::HIPShimComm, grid, f, side::Integer) = GC.@preserve f check(c
 allreduce!(c::HIPShimComm, buf::HIPShimArray{Float64}, op::Integer) = GC.@preserve buf check(ccall((:ocn_comm_allreduce, lib), Cint,
     (Ptr{Cvoid}, Ptr{Float64}, Csize_t, Int32, Ptr{Cvoid}), c.handle, buf.ptr, length(buf), op, C_NULL))
 barrier(c::HIPShimComm) = check(ccall((:ocn_comm_barrier, lib), Cint, (Ptr{Cvoid},), c.handle))
+# Host waits with a deadline (a peer that never arrives ends in an error of THIS rank, not in a hang) and device-side exchange timing
+sync_device_with_deadline(seconds::Real) = check(ccall((:ocn_sync_timeout, lib), Cint, (Ptr{Cvoid}, Float64), C_NULL, seconds))
+wait_for_communication(c::HIPShimComm, seconds::Real) = check(ccall((:ocn_comm_wait, lib), Cint, (Ptr{Cvoid}, Float64), c.handle, seconds))
+enable_exchange_timing!(c::HIPShimComm, on::Bool) = check(ccall((:ocn_comm_enable_stats, lib), Cint, (Ptr{Cvoid}, Int32), c.handle, on))
+function exchange_timing(c::HIPShimComm)   # ms since the last call: strips, halo wait, solve exchange, pressure planes, single planes, counts
+    ms = zeros(Float64, 8)
+    GC.@preserve ms check(ccall((:ocn_comm_stats, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.handle, ms))
+    ms
+end
 
 # DistributedFFTBasedPoissonSolver / DistributedFourierTridiagonalPoissonSolver (distributed_fft_based_poisson_solver.jl:141-178)
 mutable struct HIPDistributedPoissonSolver

@@ -88,6 +88,7 @@ _SIGS = {
     "ocn_fill_halo_periodic": [C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _i32, _vp],
     "ocn_compute_momentum_tendencies": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_momentum_tendencies_rk3": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, C.POINTER(_i32), _vp],
+    "ocn_compute_momentum_tendencies_rk3_strips": [C.POINTER(CGrid)] + [_vp] * 12 + [_dbl, _dbl, _dbl, _i32, _vp, _dbl, _vp, _vp, C.c_int64, _vp],
     "ocn_compute_tracer_tendency": [C.POINTER(CGrid), _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_momentum_tendencies_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
     "ocn_compute_tracer_tendency_terms": [C.POINTER(CGrid), C.POINTER(CModelTerms), _dbl, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32), _vp],
@@ -180,6 +181,8 @@ _SIGS = {
     "ocn_comm_init": [C.POINTER(_vp), _i32, _i32, _vp],
     "ocn_comm_init_local": [C.POINTER(_vp), _i32, _i32, C.c_int64],
     "ocn_comm_init_replica": [C.POINTER(_vp), _i32],
+    "ocn_halo_exchange_buffers": [_vp, C.POINTER(CGrid), C.POINTER(_i32), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64)],
+    "ocn_halo_exchange_begin_packed": [_vp, C.POINTER(CGrid), C.POINTER(_vp), C.POINTER(_i32), _i32, _vp],
     "ocn_comm_enable_stats": [_vp, _i32],
     "ocn_comm_stats": [_vp, C.POINTER(C.c_double)],
     "ocn_comm_wait": [_vp, C.c_double],

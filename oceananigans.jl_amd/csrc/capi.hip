@@ -242,6 +242,31 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, range, &fz, as_stream(stream));
 }
 
+int ocn_compute_momentum_tendencies_rk3_strips(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
+                                               double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
+                                               double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
+                                               int32_t has_zeta, const double *p_correct, double dt_correct, double *strip_west,
+                                               double *strip_east, int64_t field_doubles, void *stream)
+{
+    int st = validate_weno(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(u && v && w && Gu && Gv && Gw && u_out && v_out && w_out, "ocn_compute_momentum_tendencies_rk3_strips: null field pointer");
+    OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_rk3_strips: G⁻ pointers are required when has_zeta != 0");
+    OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_rk3_strips: outputs must not alias the inputs");
+    OCN_REQUIRE(p_correct && strip_west && strip_east && field_doubles > 0,
+                "ocn_compute_momentum_tendencies_rk3_strips: the correction-on-load stage of a slab (p_correct) and both strip buffers");
+    OCN_REQUIRE(grid->tx == OCN_FULLY_CONNECTED && grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC,
+                "ocn_compute_momentum_tendencies_rk3_strips: a (FullyConnected, Periodic, Periodic) local grid");
+    FuseArgs fz{};
+    fz.Gm[0] = Gmu; fz.Gm[1] = Gmv; fz.Gm[2] = Gmw;
+    fz.Uo[0] = u_out; fz.Uo[1] = v_out; fz.Uo[2] = w_out;
+    fz.dt = dt; fz.gamma = gamma; fz.zeta = zeta; fz.on = 1; fz.has_zeta = has_zeta ? 1 : 0;
+    fz.pc_p = p_correct; fz.pc_dt = dt_correct; fz.pc_on = 1;
+    fz.strip_w = strip_west; fz.strip_e = strip_east; fz.strip_field = field_doubles;
+    if (strict_math(grid)) return ocn_strict::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, nullptr, &fz, as_stream(stream));
+    return ocn_fast::launch_momentum_tendencies(grid, u, v, w, Gu, Gv, Gw, nullptr, &fz, as_stream(stream));
+}
+
 int ocn_cell_advection_timescale(const ocn_grid *grid, const double *u, const double *v, const double *w, double *result_device,
                                  void *stream)
 {

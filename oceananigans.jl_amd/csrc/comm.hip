@@ -64,6 +64,8 @@ struct Comm {
     size_t pcap = 0;
     bool pending = false;
     size_t pending_count = 0;
+    bool pending_wrap = false;  // the exchange in flight carries interior rows only (ocn_halo_exchange_begin_packed): unpack wraps
+    double *scalar = nullptr;   // one double for ocn_comm_barrier's all-reduce (the strip buffers may hold strips written by a tendency launch)
     bool self_via_rccl = false;  // OCN_COMM_SELF_VIA_RCCL=1: a rank's transfers to itself go through ncclSend / ncclRecv too (tests)
     struct LocalGroup *local = nullptr;  // != NULL: the in-process transport below instead of RCCL (ocn_comm_init_local)
     // ocn_comm_init_replica: this process is rank 0 of `nranks` IDENTICAL ranks (an x-periodic flow of period Lx / nranks): what a peer
@@ -486,6 +488,7 @@ int ocn_comm_destroy(ocn_comm_t comm)
         if (b) (void)hipFree(b);
     for (double *b : c->pbuf)
         if (b) (void)hipFree(b);
+    if (c->scalar) (void)hipFree(c->scalar);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -634,6 +637,62 @@ int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const
     return OCN_SUCCESS;
 }
 
+// The send buffers of the next ocn_halo_exchange_begin_packed of this tuple (device pointers, layout: field q at q * field_doubles, then
+// h + Hx * parent row): a tendency launch writes the stepped values of the Hx westmost / eastmost columns straight into them.
+int ocn_halo_exchange_buffers(ocn_comm_t comm, const ocn_grid *grid, const int32_t *locs, int32_t n, double **send_west, double **send_east,
+                              int64_t *field_doubles)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c && locs && send_west && send_east && field_doubles, "ocn_halo_exchange_buffers: null pointer");
+    OCN_REQUIRE(!c->pending, "ocn_halo_exchange_buffers: an exchange is in flight");
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC, "ocn_halo_exchange_buffers: Periodic y and z (the receiver wraps the halo rows)");
+    for (int q = 1; q < n; ++q) {
+        GridDev g = to_dev(*grid);
+        Lay L0 = make_lay(g, locs[0]), L = make_lay(g, locs[q]);
+        OCN_REQUIRE(L.sy == L0.sy && L.sz == L0.sz, "ocn_halo_exchange_buffers: fields of one cross-section");
+    }
+    const size_t count = strip_doubles(grid, locs, n);
+    st = ensure(c, count);
+    if (st != OCN_SUCCESS) return st;
+    *send_west = c->buf[0];
+    *send_east = c->buf[1];
+    *field_doubles = (int64_t)(count / (size_t)n);
+    return OCN_SUCCESS;
+}
+
+// ocn_halo_exchange_begin without the pack launch: the send buffers (ocn_halo_exchange_buffers) were filled on `stream` -- interior rows
+// only -- by the launch that produced the fields; ocn_halo_exchange_end then unpacks with periodically wrapped (j, k).
+int ocn_halo_exchange_begin_packed(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream)
+{
+    Comm *c = static_cast<Comm *>(comm);
+    OCN_REQUIRE(c, "ocn_halo_exchange_begin_packed: null communicator");
+    OCN_REQUIRE(!c->pending, "ocn_halo_exchange_begin_packed: an exchange is already in flight (call ocn_halo_exchange_end first)");
+    int st = validate_grid(grid);
+    if (st != OCN_SUCCESS) return st;
+    OCN_REQUIRE(grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC, "ocn_halo_exchange_begin_packed: Periodic y and z");
+    FieldTuple ft;
+    st = make_tuple(grid, fields, locs, n, ft);
+    if (st != OCN_SUCCESS) return st;
+    const size_t count = strip_doubles(grid, locs, n);
+    OCN_REQUIRE(count <= c->cap && c->buf[0], "ocn_halo_exchange_begin_packed: call ocn_halo_exchange_buffers first");
+    hipStream_t s = as_stream(stream);
+    OCN_CHECK_HIP(hipEventRecord(c->ready, s));
+    OCN_CHECK_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+    {
+        StatScope sc(c, 0, c->stream);
+        st = post_exchange(c, c->buf[0], c->buf[1], c->buf[2], c->buf[3], count);
+    }
+    if (st != OCN_SUCCESS) return st;
+    c->counts[5] += 1;
+    OCN_CHECK_HIP(hipEventRecord(c->done, c->stream));
+    c->pending = true;
+    c->pending_wrap = true;
+    c->pending_count = count;
+    return OCN_SUCCESS;
+}
+
 // synchronize_communication! (distributed_fields.jl:58-75): `stream` waits for the exchange (an event, not the host) and unpacks.
 int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, void *stream)
 {
@@ -649,8 +708,8 @@ int ocn_halo_exchange_end(ocn_comm_t comm, const ocn_grid *grid, double *const *
         StatScope sc(c, 1, s);  // what the caller's stream waits for the exchange
         OCN_CHECK_HIP(hipStreamWaitEvent(s, c->done, 0));
     }
-    st = launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], 1, s);
-    if (st == OCN_SUCCESS) c->pending = false;  // a failed unpack leaves the exchange pending: the caller may call _end again
+    st = launch_halo_pack_x_fields(grid, ft, c->buf[2], c->buf[3], c->pending_wrap ? 2 : 1, s);
+    if (st == OCN_SUCCESS) c->pending = c->pending_wrap = false;  // a failed unpack leaves the exchange pending: the caller may call _end again
     return st;
 }
 
@@ -897,8 +956,7 @@ int ocn_comm_barrier(ocn_comm_t comm)
 {
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c, "ocn_comm_barrier: null communicator");
-    int st = ensure(c, 1);
-    if (st != OCN_SUCCESS) return st;
+    if (!c->scalar) OCN_CHECK_HIP(hipMalloc(&c->scalar, sizeof(double)));
     OCN_REQUIRE(!c->pending, "ocn_comm_barrier: a halo exchange is in flight");
     if (c->local) {
         OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -908,7 +966,7 @@ int ocn_comm_barrier(ocn_comm_t comm)
         OCN_CHECK_HIP(hipStreamSynchronize(c->stream));
         return OCN_SUCCESS;
     }
-    OCN_CHECK_NCCL(ncclAllReduce(c->buf[0], c->buf[0], 1, ncclDouble, ncclSum, c->comm, c->stream));
+    OCN_CHECK_NCCL(ncclAllReduce(c->scalar, c->scalar, 1, ncclDouble, ncclSum, c->comm, c->stream));
     // host wait with a deadline (OCN_COMM_TIMEOUT_S, default 300): a rank whose peers never arrive gets OCN_ERR_TIMEOUT instead of hanging
     static const double deadline = getenv("OCN_COMM_TIMEOUT_S") ? atof(getenv("OCN_COMM_TIMEOUT_S")) : 300.0;
     return ocn::wait_stream(c->stream, deadline, "ocn_comm_barrier");

@@ -40,6 +40,9 @@ struct ocn_rk3_driver {
     // slab-x rank (ocn_rk3_driver_create_distributed): RCCL communicator + distributed Poisson handle, both borrowed
     ocn_comm_t comm = nullptr;
     ocn_dist_poisson_t dsolver = nullptr;
+    // the last fused launch also wrote the x strips of its stepped velocities into the communicator's send buffers
+    // (ocn_compute_momentum_tendencies_rk3_strips): the next exchange of U is posted without a pack launch
+    bool use_strips = false, strips_ready = false;
 };
 
 namespace {
@@ -48,6 +51,7 @@ const int32_t LOCS[3] = {OCN_LOC_FCC, OCN_LOC_CFC, OCN_LOC_CCF};
 // fill_halo_regions!(velocities): local periodic / wall fills, then -- on a slab -- the x exchange with the neighbours (synchronous)
 int fill_velocities(ocn_rk3_driver *d, int fbnv, void *stream)
 {
+    d->strips_ready = false;  // (this exchange packs into the same send buffers)
     int st = ocn_fill_halo_regions(&d->grid, d->U, LOCS, 3, fbnv, stream);
     if (st != OCN_SUCCESS || !d->comm) return st;
     st = ocn_halo_exchange_begin(d->comm, &d->grid, d->U, LOCS, 3, stream);
@@ -88,9 +92,22 @@ int solve(ocn_rk3_driver *d, double stage_dt, void *stream)
 int fused_launch(ocn_rk3_driver *d, double dt, double gamma, double zeta, int has_zeta, const double *p_correct, double dt_correct,
                  void *stream)
 {
-    int st = ocn_compute_momentum_tendencies_rk3(&d->grid, d->U[0], d->U[1], d->U[2], d->Gn[0], d->Gn[1], d->Gn[2], d->Gm[0], d->Gm[1],
+    int st;
+    d->strips_ready = false;
+    if (d->use_strips && p_correct) {
+        double *sw = nullptr, *se = nullptr;
+        int64_t per_field = 0;
+        st = ocn_halo_exchange_buffers(d->comm, &d->grid, LOCS, 3, &sw, &se, &per_field);
+        if (st != OCN_SUCCESS) return st;
+        st = ocn_compute_momentum_tendencies_rk3_strips(&d->grid, d->U[0], d->U[1], d->U[2], d->Gn[0], d->Gn[1], d->Gn[2], d->Gm[0], d->Gm[1],
+                                                        d->Gm[2], d->A[0], d->A[1], d->A[2], dt, gamma, zeta, has_zeta, p_correct, dt_correct,
+                                                        sw, se, per_field, stream);
+        d->strips_ready = st == OCN_SUCCESS;
+    } else {
+        st = ocn_compute_momentum_tendencies_rk3(&d->grid, d->U[0], d->U[1], d->U[2], d->Gn[0], d->Gn[1], d->Gn[2], d->Gm[0], d->Gm[1],
                                                  d->Gm[2], d->A[0], d->A[1], d->A[2], dt, gamma, zeta, has_zeta, p_correct, dt_correct,
                                                  nullptr, stream);
+    }
     if (st != OCN_SUCCESS) return st;
     for (int f = 0; f < 3; ++f) std::swap(d->U[f], d->A[f]);
     d->pending = false;
@@ -112,7 +129,10 @@ int project_for_load(ocn_rk3_driver *d, double stage_dt, void *stream)
     if (d->comm) {
         st = ocn_halo_exchange_plane(d->comm, &d->grid, d->U[0], OCN_LOC_FCC, 0, stream);  // u[nx+1] <- east neighbour's u[1]
         if (st != OCN_SUCCESS) return st;
-        st = ocn_halo_exchange_begin(d->comm, &d->grid, d->U, LOCS, 3, stream);
+        // the strips of u*, v*, w*: already in the send buffers when the last fused launch wrote them (no pack launch), packed here otherwise
+        st = d->strips_ready ? ocn_halo_exchange_begin_packed(d->comm, &d->grid, d->U, LOCS, 3, stream)
+                             : ocn_halo_exchange_begin(d->comm, &d->grid, d->U, LOCS, 3, stream);
+        d->strips_ready = false;
         if (st != OCN_SUCCESS) return st;
     }
     st = solve(d, stage_dt, stream);
@@ -234,6 +254,9 @@ static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u,
     const char *e = std::getenv("OCN_CORRECT_ON_LOAD"), *ed = std::getenv("OCN_DIST_CORRECT_ON_LOAD");
     const bool off = (e && e[0] == '0') || (comm && ed && ed[0] == '0');
     d->correct_on_load = (comm || (grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4)) && !off;
+    // strips written by the fused launch's epilogue (OCN_DIST_EPILOGUE_STRIPS=0: every exchange packs its strips with its own launch)
+    const char *es = std::getenv("OCN_DIST_EPILOGUE_STRIPS");
+    d->use_strips = comm && d->correct_on_load && grid->Nx >= 2 * grid->Hx && !(es && es[0] == '0');
     const char *dc = std::getenv("OCN_DRIVER_DEFER_CORRECTION");
     d->defer_correction = d->correct_on_load && !(dc && dc[0] == '0');
     st = fill_velocities(d, 0, stream);  // update_state!(model; compute_tendencies = false) of the constructor

@@ -1724,6 +1724,7 @@ struct PackTuple {
     double *f[MAX_TUPLE];
     int sx[MAX_TUPLE];
     long long rows[MAX_TUPLE], off[MAX_TUPLE];
+    int sy, Ny, Nz, Hy, Hz;  // unpack == 2: the sender filled interior rows only; a halo row takes its periodic image's
 };
 __global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *__restrict__ west, double *__restrict__ east, int unpack)
 {
@@ -1733,11 +1734,18 @@ __global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *_
     const int h = t % Hx;
     const long long row = t / Hx;
     double *crow = a.f[fi] + row * a.sx[fi];
-    const long long b = a.off[fi] + t;
+    long long b = a.off[fi] + t;
     if (!unpack) {
         west[b] = crow[Hx + h];
         east[b] = crow[nx + h];
     } else {
+        if (unpack == 2) {  // strips written by the tendency launch's epilogue (interior rows): wrap (j, k) periodically
+            const int jp = (int)(row % a.sy), kp = (int)(row / a.sy);
+            int j = jp - a.Hy + 1, k = kp - a.Hz + 1;
+            j = j < 1 ? j + a.Ny : (j > a.Ny ? j - a.Ny : j);
+            k = k < 1 ? k + a.Nz : (k > a.Nz ? k - a.Nz : k);
+            b = a.off[fi] + h + (long long)Hx * ((j + a.Hy - 1) + (long long)a.sy * (k + a.Hz - 1));
+        }
         crow[h] = west[b];
         crow[nx + Hx + h] = east[b];
     }
@@ -1755,7 +1763,9 @@ int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double
         a.off[q] = off;
         off += a.rows[q] * g.Hx;
         most = a.rows[q] * g.Hx > most ? a.rows[q] * g.Hx : most;
+        a.sy = L.sy;  // (unpack == 2 is used on Periodic y, z: every field of the tuple has this cross-section)
     }
+    a.Ny = g.Ny; a.Nz = g.Nz; a.Hy = g.Hy; a.Hz = g.Hz;
     hipLaunchKernelGGL(halo_pack_x_fields_kernel, dim3((unsigned)((most + 255) / 256), ft.n), dim3(256), 0, stream, g.Hx, g.Nx, a, west, east, unpack);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;

@@ -118,6 +118,11 @@ struct FuseArgs {
     // G already holds the terms that do not come from advection (momentum_extra_* in `pre` mode ran first): G <- advection + G before it is
     // stored and used by the substep.  Fast math only: the sum is the reference's with the advective term added last instead of first.
     int acc;
+    // slab-x rank, correction-on-load stage: the substep results of the Hx westmost / eastmost columns are ALSO written into the send
+    // buffers of the next x-halo exchange (layout of halo_pack_x_fields_kernel: field f at strip_field * f, then h + Hx * parent row), so
+    // the exchange needs no pack launch; only interior rows are written -- the receiver wraps (ocn_halo_exchange_begin_packed)
+    double *strip_w, *strip_e;
+    long long strip_field;
 };
 
 // device-side copy of ocn_model_terms (physics.hip)

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void momentum_tendencies_direct(GridDev g, con
 // GL ("general layouts"): the fields have their own parent layouts -- a Bounded x (y) gives u (v) one more point along it
 // (grid_utils.jl:66-72).  Used for the INTERIOR BOX of grids with walls in x / y (launch_momentum_tendencies_box): every cell of that
 // box is at least a full stencil away from the walls, where the topology-conditional reconstructions are the Periodic ones.
-template <int TZ, int TX, int TY, int W, bool PC, bool OB = false, bool GL = false>
+// ST ("strips"): the epilogue also writes the stepped velocities of the Hx westmost / eastmost columns into the send buffers of the next
+// x-halo exchange of a slab-x rank (FuseArgs::strip_w / strip_e): the exchange then needs no pack launch.
+template <int TZ, int TX, int TY, int W, bool PC, bool OB = false, bool GL = false, bool ST = false>
 __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g, const double *__restrict__ u,
                                                                        const double *__restrict__ v,
                                                                        const double *__restrict__ w, double *__restrict__ Gu,
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     // x and y are Periodic for every supported grid, so the row/plane strides and the interior offset are the same for
     // all staggered locations (only the number of z planes differs): one layout serves u, v, w, G and p.
     static_assert(!(GL && PC), "the correction on load shares one layout between p, u, v, w");
+    static_assert(!ST || (PC && TZ == OCN_PERIODIC && !GL), "strips are written by the correction-on-load stage of a periodic-z slab");
     const Lay L0 = ocn::make_lay(g, OCN_LOC_CCC);
     const Lay Lu = GL ? ocn::make_lay(g, OCN_LOC_FCC) : L0, Lv = GL ? ocn::make_lay(g, OCN_LOC_CFC) : L0, Lw = GL ? ocn::make_lay(g, OCN_LOC_CCF) : L0;
     const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz;
@@ -525,17 +528,39 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             const int e = tid + 1, n = tid + TX;
             const double rVc = recip_volume(M.Az * M.dzC(k));
             const long long ou_ = ocn::at(Lu, i, j, k), ov_ = ocn::at(Lv, i, j, k), ow_ = ocn::at(Lw, i, j, k);
+            // ST: this cell's slot in the west / east strip (or -1): h + Hx * (parent row), the layout of halo_pack_x_fields_kernel
+            long long sw_ = -1, se_ = -1;
+            if (ST) {
+                const long long row = (j + g.Hy - 1) + (long long)L0.sy * (k + g.Hz - 1);
+                if (i <= g.Hx) sw_ = (i - 1) + g.Hx * row;
+                if (i > Nx - g.Hx) se_ = (i - (Nx - g.Hx + 1)) + g.Hx * row;
+            }
+#define OCN_STRIP(f, val)                                                   \
+    do {                                                                    \
+        if (ST) {                                                           \
+            if (sw_ >= 0) fz.strip_w[(f) * fz.strip_field + sw_] = (val);   \
+            if (se_ >= 0) fz.strip_e[(f) * fz.strip_field + se_] = (val);   \
+        }                                                                   \
+    } while (0)
             if (i >= r.ou) {
                 double G = -(rVc * (((ex[0][e] - OCN_MYF(0)) + (ex[4][n] - OCN_MYF(4))) + (fwu_top - fwu_bot)));
                 if (fz.acc) G = G + eu;
                 Gu[ou_] = G;
-                if (fz.on) fz.Uo[0][ou_] = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmu) : (fz.dt * fz.gamma) * G);
+                if (fz.on) {
+                    const double un = zu[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmu) : (fz.dt * fz.gamma) * G);
+                    fz.Uo[0][ou_] = un;
+                    OCN_STRIP(0, un);
+                }
             }
             if (j >= r.ov) {
                 double G = -(rVc * (((ex[1][e] - OCN_MYF(1)) + (ex[3][n] - OCN_MYF(3))) + (fwv_top - fwv_bot)));
                 if (fz.acc) G = G + ev;
                 Gv[ov_] = G;
-                if (fz.on) fz.Uo[1][ov_] = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmv) : (fz.dt * fz.gamma) * G);
+                if (fz.on) {
+                    const double vn = zv[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmv) : (fz.dt * fz.gamma) * G);
+                    fz.Uo[1][ov_] = vn;
+                    OCN_STRIP(1, vn);
+                }
             }
             if (k >= r.ow) {
                 const double rVf = recip_volume(M.Az * M.dzF(k));
@@ -545,7 +570,11 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
                 // rk3_substep! always excludes the wall face (runge_kutta_3.jl:171-174), even when a KernelParameters range
                 // made the tendency kernel write Gw there
                 const bool wall = (TZ == OCN_BOUNDED) && k == 1 && Nz > 1;
-                if (fz.on) fz.Uo[2][ow_] = wall ? zw[2] : zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmw) : (fz.dt * fz.gamma) * G);
+                if (fz.on) {
+                    const double wn = wall ? zw[2] : zw[2] + (fz.has_zeta ? fz.dt * (fz.gamma * G + fz.zeta * gmw) : (fz.dt * fz.gamma) * G);
+                    fz.Uo[2][ow_] = wn;
+                    OCN_STRIP(2, wn);
+                }
             } else if (fz.on) {
                 fz.Uo[2][ow_] = zw[2];  // wall face: neither the tendency nor the substep touch it (exclude_periphery)
             }
@@ -565,6 +594,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #undef ZW
 #undef OCN_PC_APPLY
 #undef OCN_MYF
+#undef OCN_STRIP
 }
 
 // K4 tracer: flux = (A * U[i,j,k]) * cR   (upwind_biased_advective_fluxes.jl:99-121)
@@ -1129,7 +1159,7 @@ static bool narrow_tile(int wx, int wy)
     return lanes_per_column(17, 15, wx, wy) * 1.08 < lanes_per_column(32, 8, wx, wy);
 }
 
-template <int TZ, int TX, int TY, bool PC, bool OB>
+template <int TZ, int TX, int TY, bool PC, bool OB, bool ST = false>
 static void launch_tiled(const GridDev &g, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw, const Range &r,
                          const ocn::FuseArgs &fz, int wx, int wy, int wz, hipStream_t stream)
 {
@@ -1137,7 +1167,7 @@ static void launch_tiled(const GridDev &g, const double *u, const double *v, con
     int KZ = wz;  // z-chunk: enough workgroups to fill the chip, long enough to amortise the 3-flux prologue
     while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < min_blocks()) KZ = (KZ + 1) / 2;
     dim3 nbt((wx + TX - 2) / (TX - 1), (wy + TY - 2) / (TY - 1), (wz + KZ - 1) / KZ);
-    hipLaunchKernelGGL((momentum_tendencies_tiled<TZ, TX, TY, 3, PC, OB>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, Gw, r, KZ, fz);
+    hipLaunchKernelGGL((momentum_tendencies_tiled<TZ, TX, TY, 3, PC, OB, false, ST>), nbt, dim3(TX * TY), 0, stream, g, u, v, w, Gu, Gv, Gw, r, KZ, fz);
 }
 
 static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
@@ -1253,6 +1283,16 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                 return OCN_ERR_UNSUPPORTED;
             }
             fz.pc_xhalo = grid->tx == OCN_FULLY_CONNECTED;
+            if (fz.strip_w) {  // slab-x rank whose next exchange takes its strips from this launch
+                if (!fz.pc_xhalo || !fz.strip_e || !fz.on || wx < 2 * g.Hx) {
+                    ocn::set_error("strips are written by the correction-on-load stage of a slab at least 2 Hx wide");
+                    return OCN_ERR_INVALID_ARGUMENT;
+                }
+                if (narrow) launch_tiled<OCN_PERIODIC, 17, 15, true, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+                else launch_tiled<OCN_PERIODIC, 32, 8, true, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
+                OCN_CHECK_HIP(hipGetLastError());
+                return OCN_SUCCESS;
+            }
             if (narrow)
                 launch_tiled<OCN_PERIODIC, 17, 15, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else if (one_barrier() & 1)

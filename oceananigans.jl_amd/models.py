@@ -146,8 +146,12 @@ class NonhydrostaticModel:
                         continue
                     if grid.topology[d] != "Bounded":
                         raise ValueError(f"Cannot set {side} boundary condition of {name} in a `{grid.topology[d]}` direction!")
-                    if side in normal.get(name, ()):
-                        raise NotImplementedError(f"{name} keeps its impenetrable {side} boundary condition (open boundaries are not implemented)")
+                    is_open = b.sides[side].kind == _lib.BC_OPEN
+                    if side in normal.get(name, ()) and not is_open:
+                        raise NotImplementedError(f"{name} keeps its impenetrable {side} boundary condition, or takes OpenBoundaryCondition(value) "
+                                                  "(its value on the boundary face)")
+                    if is_open and side not in normal.get(name, ()):
+                        raise ValueError(f"OpenBoundaryCondition on the {side} boundary applies to the velocity component normal to it, not to {name}")
         self.u, self.v, self.w = XFaceField(grid, bcs.get("u")), YFaceField(grid, bcs.get("v")), ZFaceField(grid, bcs.get("w"))
         self.velocities = (self.u, self.v, self.w)
         self.tracer_names = tracers

@@ -115,6 +115,27 @@ def test_open_boundary_conditions_with_a_value(oracle, ocn, size, topo):
         ocn.fill_halo_regions(c)
 
 
+def test_uniform_through_flow_with_open_boundaries_is_steady(ocn):
+    """NonhydrostaticModel on a (Bounded, Periodic, Bounded) grid with u = U0 prescribed on the west and east faces
+    (OpenBoundaryCondition(U0)) and u = U0 inside: the uniform through-flow is an exact steady state of the discrete equations (zero
+    advective tendency, zero divergence, zero pressure), so three RK3 steps leave u = U0 on every face, boundary faces included, and
+    v = w = 0 -- a closed-form check (the reference has no offline value for an open-boundary run: parity unpinned)."""
+    U0 = 0.3
+    g = ocn.RectilinearGrid(ocn.GPU(), size=(24, 12, 10), x=(0, 2.0), y=(0, 1.0), z=(-1.0, 0), topology=("Bounded", "Periodic", "Bounded"))
+    bcs = {"u": ocn.FieldBoundaryConditions(west=ocn.OpenBoundaryCondition(U0), east=ocn.OpenBoundaryCondition(U0))}
+    m = ocn.NonhydrostaticModel(g, advection=ocn.WENO(), boundary_conditions=bcs, math_mode=ocn.MATH_STRICT)
+    ocn.set(m, u=np.full((25, 12, 10), U0))
+    for _ in range(3):
+        ocn.time_step(m, 0.01)
+    ocn.flush_tendencies(m)
+    ocn.sync_device()
+    u = m.u.interior()
+    assert u.shape[0] == 25 and np.abs(u - U0).max() <= 1e-13, np.abs(u - U0).max()
+    assert np.abs(m.v.interior()).max() <= 1e-13 and np.abs(m.w.interior()).max() <= 1e-13
+    with pytest.raises(ValueError, match="normal"):
+        ocn.NonhydrostaticModel(g, advection=ocn.WENO(), boundary_conditions={"v": ocn.FieldBoundaryConditions(west=ocn.OpenBoundaryCondition(1.0))})
+
+
 @pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB")])
 def test_array_and_function_conditions_on_x_y_walls(oracle, ocn, size, topo):
     """Array- and function-valued conditions on the lateral walls (boundary_condition.jl getbc for AbstractArray; continuous_boundary_

@@ -393,8 +393,9 @@ def test_model_argument_errors(ocn):
         ocn.NonhydrostaticModel(g, advection=ocn.WENO(), buoyancy=ocn.BuoyancyTracer())
     with pytest.raises(NotImplementedError):
         ocn.NonhydrostaticModel(g, advection=ocn.WENO(), closure="AnisotropicMinimumDissipation")
-    with pytest.raises(NotImplementedError):
-        ocn.FieldBoundaryConditions(west=ocn.FluxBoundaryCondition(np.ones((8, 8))))
+    ocn.FieldBoundaryConditions(west=ocn.FluxBoundaryCondition(np.ones((8, 8))))  # (arrays on lateral walls are accepted since round 4)
+    with pytest.raises(ValueError, match="expected"):
+        ocn.FieldBoundaryConditions(west=ocn.FluxBoundaryCondition(np.ones((5, 8)))).c_struct(g)  # ... with the boundary's own extents
     with pytest.raises(ValueError, match="Cannot set west"):  # validate_boundary_condition_topology (boundary_condition.jl:128-130)
         ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers="c",
                                 boundary_conditions={"c": ocn.FieldBoundaryConditions(west=ocn.FluxBoundaryCondition(1.0))})
