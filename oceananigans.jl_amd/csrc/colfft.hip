@@ -314,9 +314,11 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
             return launch_n<256, 16>(mode, a, stream);
         }
         case 512: {
-            // 16 columns per workgroup = 256-B runs per row (one workgroup of 1024 threads per CU): 2.87 ms per 512^3 solve against
-            // 2.96 ms with 8 columns (128-B runs, 2 workgroups per CU)
-            static const int cb = getenv("OCN_COLFFT_CB") ? atoi(getenv("OCN_COLFFT_CB")) : 16;
+            // 8 columns per workgroup (128-B runs, two workgroups per CU whose load / transform / store phases overlap) since the
+            // XCD-contiguous block order keeps the lines two neighbouring blocks share in one L2: 2.72 ms per 512^3 solve against 2.89 ms
+            // with 16 columns (256-B runs, one workgroup of 1024 threads per CU) and 2.80 with 16 for the plain passes + 8 for the fused z
+            // pass (the round-3 default; before the block order 8 columns lost: 2.96 against 2.87)
+            static const int cb = getenv("OCN_COLFFT_CB") ? atoi(getenv("OCN_COLFFT_CB")) : 8;
             // the fused FFT-solve-IFFT pass holds 94 VGPRs and works twice as long per byte: two 8-column workgroups per CU overlap one's
             // loads / stores with the other's arithmetic (512^3 step 27.15 vs 27.35 ms, same box)
             static const int cb2 = getenv("OCN_COLFFT_CB2") ? atoi(getenv("OCN_COLFFT_CB2")) : (getenv("OCN_COLFFT_CB") ? cb : 8);
