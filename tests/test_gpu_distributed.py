@@ -714,6 +714,54 @@ def test_library_transport_ranks_match_single_rank(ocn, R, N, pipeline, monkeypa
             assert np.abs(a - c[sl]).max() <= tol, f"rank {r} field {name} vs the single-rank model"
 
 
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_replica_transport_equals_every_rank_of_a_replicated_flow(ocn, R, monkeypatch):
+    """The measurement transport (ocn_comm_init_replica: this process is rank 0 of R identical ranks, every receive a device copy from
+    its own send buffer to the mirror-image peer) against the real thing: an initial condition of x-period Lx / R on R ranks as threads over
+    the library's in-process transport (R DISTINCT peers, csrc/comm.hip's schedules between them).  Every one of those ranks must then
+    hold exactly what the single replica process holds -- velocities and pressure, C driver, strict math, bit for bit -- which is what
+    makes the per-rank timings of tools/bench_dist_rank.py the timings of a rank of a real R-rank run."""
+    P = "Periodic"
+    monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
+    nx = 32
+    N = (nx * R, 64, 64)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
+    rng = np.random.default_rng(31)
+    slab = {n: rng.uniform(-1, 1, (nx,) + N[1:]) for n in "uvw"}   # one slab, repeated R times along x
+    dt = 0.1 * (2 * np.pi / N[0])
+    ocn.set_math_mode(ocn.MATH_STRICT)
+
+    def run(arch):
+        g = ocn.RectilinearGrid(arch, size=N, **ext)
+        assert g.Nx == nx
+        m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
+        ocn.set(m, **slab)
+        drv = ocn.RK3Driver(m)
+        for _ in range(3):
+            drv.time_step(dt)
+        drv.flush()
+        ocn.sync_device()
+        out = [f.interior() for f in m.velocities] + [m.pNHS.interior()]
+        del drv
+        return out
+
+    fabric = ocn.distributed.ReplicaFabric(R)
+    info = fabric.info()
+    assert info["ranks_seen_by_rccl"] == R and info["rccl_version"] == 0 and info["rank"] == 0
+    replica = run(ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric, force_communication=True))
+    fabric.close()
+
+    def rank_main(r, fab):
+        out = run(ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fab))
+        fab.barrier()
+        return out
+
+    for r, got in enumerate(_run_ranks_local(ocn, R, rank_main)):
+        for a, b, name in zip(got, replica, ("u", "v", "w", "p")):
+            np.testing.assert_array_equal(a, b, err_msg=f"rank {r} of {R}, {name}")
+    assert max(np.abs(a).max() for a in replica[:3]) > 0.1
+
+
 @pytest.mark.parametrize("R", [2, 4])
 def test_library_transport_config4_terms_match_single_rank(ocn, R):
     """Config 4's term set (T, S, SeawaterBuoyancy + pHY', FPlane, AMD, flux / gradient conditions, stretched Bounded z, the distributed
