@@ -724,7 +724,7 @@ def test_replica_transport_equals_every_rank_of_a_replicated_flow(ocn, R, monkey
     P = "Periodic"
     monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
     nx = 32
-    N = (nx * R, 64, 64)
+    N = (nx * R, 128, 64)
     ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
     rng = np.random.default_rng(31)
     slab = {n: rng.uniform(-1, 1, (nx,) + N[1:]) for n in "uvw"}   # one slab, repeated R times along x
