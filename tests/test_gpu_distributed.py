@@ -719,8 +719,8 @@ def test_replica_transport_equals_every_rank_of_a_replicated_flow(ocn, R, monkey
     """The measurement transport (ocn_comm_init_replica: this process is rank 0 of R identical ranks, every receive a device copy from
     its own send buffer to the mirror-image peer) against the real thing: an initial condition of x-period Lx / R on R ranks as threads over
     the library's in-process transport (R DISTINCT peers, csrc/comm.hip's schedules between them).  Every one of those ranks must then
-    hold exactly what the single replica process holds -- velocities and pressure, C driver, strict math, bit for bit -- which is what
-    makes the per-rank timings of tools/bench_dist_rank.py the timings of a rank of a real R-rank run."""
+    hold what the single replica process holds -- velocities and pressure after three steps of the C driver, to 1e-12 (see below why not
+    bit for bit) -- which is what makes the per-rank timings of tools/bench_dist_rank.py the timings of a rank of a real R-rank run."""
     P = "Periodic"
     monkeypatch.setenv("OCN_DIST_POISSON_XTRI", "1")
     nx = 32
@@ -756,10 +756,15 @@ def test_replica_transport_equals_every_rank_of_a_replicated_flow(ocn, R, monkey
         fab.barrier()
         return out
 
+    scale = max(np.abs(a).max() for a in replica[:3])
+    assert scale > 0.1
     for r, got in enumerate(_run_ranks_local(ocn, R, rank_main)):
         for a, b, name in zip(got, replica, ("u", "v", "w", "p")):
-            np.testing.assert_array_equal(a, b, err_msg=f"rank {r} of {R}, {name}")
-    assert max(np.abs(a).max() for a in replica[:3]) > 0.1
+            # not bit for bit: the R ranks of a real run are not EXACTLY replicas of each other -- the (ky, kz) = (0, 0) line of the pressure
+            # solve is a prefix sum over the global line, whose rounding differs from slab to slab -- so after the first projection they
+            # differ among themselves by a few ulps, and from the replica process by as much
+            tol = 1e-12 * (scale if name != "p" else max(1.0, np.abs(b).max()))
+            assert np.abs(a - b).max() <= tol, f"rank {r} of {R}, {name}: {np.abs(a - b).max()}"
 
 
 @pytest.mark.parametrize("R", [2, 4])
