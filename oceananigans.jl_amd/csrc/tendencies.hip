@@ -14,6 +14,10 @@
 #include "ocn_weno.h"
 
 
+#ifndef OCN_TRACER_LDS_SELECT
+#define OCN_TRACER_LDS_SELECT 0
+#endif
+
 namespace OCN_NS {
 
 using ocn::GridDev;
@@ -830,8 +834,13 @@ __global__ __launch_bounds__(TX *TY, W) void tracer_tendency_tiled(GridDev g, co
         // load in the epilogue then waits for the whole prefetch group (profiles/r03a_config4.md: 45 % of the wave cycles parked).
         OCN_ISSUE_LOADS_HERE();
         const double ax = M.Ax(k), ay = M.Ay(k);
+#if OCN_TRACER_LDS_SELECT  // address-selected stencils as in the momentum kernel (A/B switch)
+        const double fxw = (ax * uf) * bias_interp_lds(&sc[ly][lx], 1, uf > 0);
+        const double fys = (ay * vf) * bias_interp_lds(&sc[ly][lx], LX, vf > 0);
+#else
         const double fxw = (ax * uf) * bias_interp<P, false>([&](int m) { return sc[ly][lx + m]; }, i, Nx, uf > 0);
         const double fys = (ay * vf) * bias_interp<P, false>([&](int m) { return sc[ly + m][lx]; }, j, Ny, vf > 0);
+#endif
         const double fzt = (az * wf) * bias_interp<TZ, false>([&](int m) { return zc[m + 3]; }, k + 1, Nz, wf > 0);
         const double cxm = sc[ly][lx - 1], cxp = sc[ly][lx + 1], cym = sc[ly - 1][lx], cyp = sc[ly + 1][lx];
         Kappa7 K{tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa, tf.kappa};
