@@ -574,7 +574,11 @@ int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, doubl
     switch (Ny / 2) {
         case 64: return launch_realy<64, 16>(inverse, a, stream);
         case 128: return launch_realy<128, 16>(inverse, a, stream);
-        case 256: return launch_realy<256, 16>(inverse, a, stream);  // (32 columns per workgroup, 256-byte runs, one workgroup per CU: no faster, round 4)
+        case 256: {  // (32 columns per workgroup, 256-byte runs, one workgroup per CU: no faster, round 4)
+            static const int cb = getenv("OCN_REALY_CB") ? atoi(getenv("OCN_REALY_CB")) : 16;
+            if (cb == 8) return launch_realy<256, 8>(inverse, a, stream);
+            return launch_realy<256, 16>(inverse, a, stream);
+        }
         case 512: return launch_realy<512, 8>(inverse, a, stream);
         default: set_error("real y transform of length %d is not supported (128, 256, 512, 1024)", Ny); return OCN_ERR_UNSUPPORTED;
     }
