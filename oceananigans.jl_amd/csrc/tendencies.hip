@@ -14,6 +14,9 @@
 #include "ocn_weno.h"
 
 
+#ifndef OCN_NARROW_PAD
+#define OCN_NARROW_PAD 0
+#endif
 #ifndef OCN_TRACER_LDS_SELECT
 #define OCN_TRACER_LDS_SELECT 0
 #endif
@@ -192,13 +195,14 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 {
     constexpr int P = OCN_PERIODIC;
     constexpr int LX = TX + 5, LY = TY + 5, NT = TX * TY;
+    constexpr int LXP = LX + (TX == 17 ? OCN_NARROW_PAD : 0);  // row stride of the LDS planes (padding experiment for the 17-wide patches)
     constexpr int NRING = LX * LY - NT;         // ring cells of one tile
     constexpr int RPT = (NRING + NT - 1) / NT;  // ring cells per thread (1 or 2)
     static_assert(RPT <= 2, "tile too small for its ring");
     // OB ("one barrier"): planes k and k+1 of u, v and k, k+1, k+2 of w are resident and the flux exchange is double-buffered, so the
     // staging of the NEXT plane moves behind this plane's flux evaluation and shares its barrier with the flux exchange.
     constexpr int NUV = OB ? 2 : 1, NW_ = OB ? 3 : 2, NEX = OB ? 2 : 1;
-    __shared__ double su_[NUV][LY][LX], sv_[NUV][LY][LX], sw[NW_][LY][LX];
+    __shared__ double su_[NUV][LY][LXP], sv_[NUV][LY][LXP], sw[NW_][LY][LXP];
     __shared__ double ex_[NEX][6][NT];  // Fuu_w, Fuv, Fuw (read by the west neighbour), Fvv_s, Fvu, Fvw (by the south one)
     auto uvslot = [](int kk) { return OB ? (kk & 1) : 0; };
     auto wslot = [](int kk) { return OB ? (kk % 3) : (kk & 1); };
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             for (int s = 0; s < RPT; ++s) rp_prev[s] = ron[s] ? rpc[s][zz(k + 1)] : 0.0;
         }
         const double um3 = ZU(k - 3), vm3 = ZV(k - 3), wm3 = ZW(k - 3);
-        const double(*swk)[LX] = sw[wslot(k)];
+        const double(*swk)[LXP] = sw[wslot(k)];
         {   // Fwu(k): sym x-face of Az*w at plane k ; biased z-face of u
             const double a = M.Az;
             const double wt = sym_interp_scaled<P, false>([&](int m) { return swk[ly][lx + m]; }, a, i, Nx);
@@ -386,8 +390,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
     }
 
     for (; k <= k_end; ++k) {
-        double(*su)[LX] = su_[uvslot(k)];
-        double(*sv)[LX] = sv_[uvslot(k)];
+        double(*su)[LXP] = su_[uvslot(k)];
+        double(*sv)[LXP] = sv_[uvslot(k)];
         double(*ex)[NT] = ex_[uvslot(k)];
         if (!OB) {
             // ---- stage plane k of u, v and plane k+1 of w (plane k of w is already resident) from registers
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             if (j >= r.ov) ev = Gv[o];
             if (k >= r.ow) ew = Gw[o];
         }
-        const double(*swk)[LX] = sw[wslot(k)];
-        const double(*swt)[LX] = sw[wslot(k + 1)];
+        const double(*swk)[LXP] = sw[wslot(k)];
+        const double(*swt)[LXP] = sw[wslot(k + 1)];
         const double ax = M.Ax(k), ay = M.Ay(k), az = M.Az;
 
         // this thread's six shared fluxes stay in registers where there is room, and only the neighbours' come back from LDS (the
@@ -486,19 +490,19 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
 #if OCN_LDS_SELECT == 2
             myf3 = vt * bias_interp<P, true>([&](int m) { return sv[ly + m][lx]; }, j - 1, Ny, vt > 0);
 #else
-            myf3 = vt * bias_interp_lds(&sv[ly][lx], LX, vt > 0);
+            myf3 = vt * bias_interp_lds(&sv[ly][lx], LXP, vt > 0);
 #endif
             ex[3][tid] = myf3;
         }
         {   // Fvu(j): sym x-face of Ay*v ; biased y-face of u
             const double vt = sym_interp_scaled<P, false>([&](int m) { return sv[ly][lx + m]; }, ay, i, Nx);
-            myf4 = vt * bias_interp_lds(&su[ly][lx], LX, vt > 0);
+            myf4 = vt * bias_interp_lds(&su[ly][lx], LXP, vt > 0);
             ex[4][tid] = myf4;
         }
         {   // Fvw(j): sym z-face of Ay*v (own column) ; biased y-face of w
             const double vt = TZ == OCN_PERIODIC ? sym_interp_scaled<TZ, false>([&](int m) { return zv[2 + m]; }, ay, k, Nz)
                                                  : sym_interp<TZ, false>([&](int m) { return M.Ay(k + m) * zv[2 + m]; }, k, Nz);
-            myf5 = vt * bias_interp_lds(&swk[ly][lx], LX, vt > 0);
+            myf5 = vt * bias_interp_lds(&swk[ly][lx], LXP, vt > 0);
             ex[5][tid] = myf5;
         }
         // ---- z-fluxes on the top face k+1 and at centre k
