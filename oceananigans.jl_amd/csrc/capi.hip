@@ -54,8 +54,10 @@ static int validate_grid_impl(const ocn_grid *g, bool any_xy)
         set_error("only x is ever partitioned (slab decomposition)");
         return OCN_ERR_UNSUPPORTED;
     }
-    if (any_xy && (g->tx == OCN_BOUNDED || g->ty == OCN_BOUNDED || g->tx == OCN_FLAT || g->ty == OCN_FLAT) && g->tx == OCN_FULLY_CONNECTED) {
-        set_error("a partitioned x needs a Periodic y");
+    // a slab of a (Periodic, Bounded, *) grid: the direction-generic kernels read the exchanged x halos like periodic images and treat
+    // the y walls locally (distributed_grids.jl:75-118)
+    if (any_xy && g->ty == OCN_FLAT && g->tx == OCN_FULLY_CONNECTED) {
+        set_error("a partitioned x needs a Periodic or Bounded y");
         return OCN_ERR_UNSUPPORTED;
     }
     if (g->tz == OCN_FULLY_CONNECTED) {
@@ -579,7 +581,7 @@ int ocn_update_hydrostatic_pressure(const ocn_grid *grid, const ocn_model_terms 
 int ocn_update_hydrostatic_pressure_range(const ocn_grid *grid, const ocn_model_terms *terms, double *pHY, int32_t i_first, int32_t i_last,
                                           void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(terms != nullptr && pHY != nullptr, "ocn_update_hydrostatic_pressure_range: null argument");
     OCN_REQUIRE(terms->buoyancy != OCN_BUOYANCY_NONE, "ocn_update_hydrostatic_pressure_range: buoyancy is nothing");
@@ -1069,14 +1071,14 @@ int ocn_batched_tridiagonal_solve_z(int32_t Nx, int32_t Ny, int32_t Nz, const do
 
 int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, double *send_west, double *send_east, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(field && send_west && send_east, "ocn_halo_pack_x: null pointer");
     return launch_halo_pack_x(grid, field, loc, send_west, send_east, 0, as_stream(stream));
 }
 int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const double *recv_west, const double *recv_east, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(field && recv_west && recv_east, "ocn_halo_unpack_x: null pointer");
     return launch_halo_pack_x(grid, field, loc, const_cast<double *>(recv_west), const_cast<double *>(recv_east), 1, as_stream(stream));
@@ -1084,7 +1086,7 @@ int ocn_halo_unpack_x(const ocn_grid *grid, double *field, int32_t loc, const do
 
 int ocn_halo_plane_x(const ocn_grid *grid, double *field, int32_t loc, int32_t which, double *buffer, int32_t unpack, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(field && buffer, "ocn_halo_plane_x: null pointer");
     OCN_REQUIRE(which == 0 || which == 1, "ocn_halo_plane_x: which must be 0 (west) or 1 (east)");
@@ -1119,7 +1121,7 @@ int ocn_halo_unpack_pressure(const ocn_grid *grid, double *p, double *u, const d
 int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, double *send_west,
                            double *send_east, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(send_west && send_east, "ocn_halo_pack_x_fields: null buffer");
     FieldTuple ft;
@@ -1130,7 +1132,7 @@ int ocn_halo_pack_x_fields(const ocn_grid *grid, double *const *fields, const in
 int ocn_halo_unpack_x_fields(const ocn_grid *grid, double *const *fields, const int32_t *locs, int32_t n, const double *recv_west,
                              const double *recv_east, void *stream)
 {
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(recv_west && recv_east, "ocn_halo_unpack_x_fields: null buffer");
     FieldTuple ft;

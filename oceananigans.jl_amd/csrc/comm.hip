@@ -612,7 +612,7 @@ int ocn_halo_exchange_begin(ocn_comm_t comm, const ocn_grid *grid, double *const
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c, "ocn_halo_exchange_begin: null communicator");
     OCN_REQUIRE(!c->pending, "ocn_halo_exchange_begin: an exchange is already in flight (call ocn_halo_exchange_end first)");
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     FieldTuple ft;
     st = make_tuple(grid, fields, locs, n, ft);
@@ -721,7 +721,7 @@ int ocn_halo_exchange_plane(ocn_comm_t comm, const ocn_grid *grid, double *field
     Comm *c = static_cast<Comm *>(comm);
     OCN_REQUIRE(c && field, "ocn_halo_exchange_plane: null pointer");
     OCN_REQUIRE(!c->pending, "ocn_halo_exchange_plane: a strip exchange is in flight");
-    int st = validate_grid(grid);
+    int st = validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     GridDev g = to_dev(*grid);
     Lay L = make_lay(g, loc);

@@ -142,13 +142,15 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
 //                         sits inside 1:N (so corners of two walls, deeper halo cells and halos behind a Face-located wall keep
 //                         their values, exactly as the reference leaves them); otherwise its own index.
 // Source cells are never written by the same launch.
-__global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, FieldTuple a, SideBcTuple bcs, int has_bc)
+// skip_x: x is partitioned (FullyConnected) -- its halos come from the neighbours, this launch leaves them alone (the local y / z fills of the
+// halo columns are overwritten by the exchange, which carries the whole cross-section)
+__global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, FieldTuple a, SideBcTuple bcs, int has_bc, int skip_x)
 {
     const int f = blockIdx.y;
     double *__restrict__ c = a.f[f];
     const int loc = a.loc[f];
     const Lay L = make_lay(g, loc);
-    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {skip_x ? -1 : g.tx, g.ty, g.tz};
     const int S[3] = {L.sx, L.sy, L.sz};
     const long long nzi = S[2] - 2 * H[2], nyi = S[1] - 2 * H[1];
     const long long A = (long long)S[0] * S[1] * 2 * H[2];
@@ -266,7 +268,8 @@ int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int op
     if (maxcells == 0) return OCN_SUCCESS;
     long long nb = (maxcells + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(fill_halos_general_kernel, dim3((unsigned)nb, ft.n), dim3(256), 0, stream, g, ft, bcs, has_bc);
+    hipLaunchKernelGGL(fill_halos_general_kernel, dim3((unsigned)nb, ft.n), dim3(256), 0, stream, g, ft, bcs, has_bc,
+                       grid->tx == OCN_FULLY_CONNECTED ? 1 : 0);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

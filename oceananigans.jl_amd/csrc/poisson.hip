@@ -1126,6 +1126,9 @@ struct ocn_dist_poisson {
     // reference's extra transpose pair to a z-local pencil is not needed), inverse x, transpose back, inverse y.
     bool tri = false;
     bool ycol = false;             // y transforms by the column-FFT kernel (stage-ordered ky) instead of rocFFT
+    bool ybounded = false;         // Bounded y: REDFT10 / REDFT01 from the complex FFT (gather, FFT, twiddle: dct_shuffle_kernel), scratch = send
+    double *ytw = nullptr;         // e^{-i pi k / 2 Ny} by stored position
+    int *ypartner = nullptr;       // stored position of wavenumber Ny - k (stage order only)
     double *tw_y = nullptr;        // column-FFT twiddles
     double *xsol = nullptr;        // tridiagonal solution (x-local layout)
     double *diag = nullptr, *lower = nullptr, *tscr = nullptr;
@@ -1150,12 +1153,17 @@ static void free_all(ocn_dist_poisson *s)
     s->fyz.destroy(); s->byz.destroy(); s->fx.destroy(); s->bx.destroy();
     if (s->fast) s->yfield = nullptr;  // alias of recv
     double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv,
-                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x, &s->gsend, &s->grecv};
+                       &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x, &s->gsend, &s->grecv,
+                       &s->ytw};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
         }
+    if (s->ypartner) {
+        (void)hipFree(s->ypartner);
+        s->ypartner = nullptr;
+    }
 }
 
 static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c);
@@ -1236,12 +1244,15 @@ static int dist_real_plans_self_test(ocn_dist_poisson *s)
 static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c)
 {
     OCN_REQUIRE(out && lg, "ocn_dist_poisson_create: null argument");
-    int st = ocn::validate_grid(lg);
+    int st = ocn::validate_grid_any(lg);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(R >= 1 && rank >= 0 && rank < R, "ocn_dist_poisson_create: bad rank %d of %d", rank, R);
     OCN_REQUIRE(global_Lx > 0, "ocn_dist_poisson_create: global_Lx must be positive");
-    OCN_REQUIRE(lg->ty == OCN_PERIODIC && ((lg->tz == OCN_PERIODIC && lg->dzc == nullptr) || lg->tz == OCN_BOUNDED),
-                "ocn_dist_poisson_create: supports (x-partitioned, Periodic, Periodic) regular grids and (x-partitioned, Periodic, Bounded)");
+    // (distributed_fft_based_poisson_solver.jl:62-66: a Periodic z needs a Periodic y)
+    OCN_REQUIRE((lg->ty == OCN_PERIODIC && ((lg->tz == OCN_PERIODIC && lg->dzc == nullptr) || lg->tz == OCN_BOUNDED)) ||
+                    (lg->ty == OCN_BOUNDED && lg->tz == OCN_BOUNDED),
+                "ocn_dist_poisson_create: supports (x-partitioned, Periodic, Periodic) regular grids, (x-partitioned, Periodic, Bounded) and "
+                "(x-partitioned, Bounded, Bounded)");
     // validate_poisson_solver_distributed_grid (distributed_fft_based_poisson_solver.jl:211-229)
     OCN_REQUIRE(lg->Ny % R == 0, "ocn_dist_poisson_create: Ny = %d must be divisible by the number of ranks %d", lg->Ny, R);
     ensure_rocfft();
@@ -1255,7 +1266,7 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
     const char *efast = std::getenv("OCN_DIST_POISSON_FAST");
-    if (lg->tz == OCN_BOUNDED && !(efast && efast[0] == '0') && R >= 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
+    if (lg->tz == OCN_BOUNDED && lg->ty == OCN_PERIODIC && !(efast && efast[0] == '0') && R >= 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
         ocn::colfft_supported(Nxg)) {
         // Slab pipeline, tridiagonal flavour: real y transform (source term x Δzᶜ evaluated on load) writing the all-to-all layout
         // [d][ky_l + c (z + Nz xl)] (ky = d c + ky_l, c = ceil((Ny/2+1) / R), padded entries stay 0) -> exchange -> x is a strided
@@ -1328,9 +1339,27 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
         TRY(upload(eigenvalues(Nxg, global_Lx, OCN_PERIODIC), &s->lx));
         // y transforms: the column-FFT kernel leaves ky in stage order, so the eigenvalue of a stored position is permuted
         s->ycol = ocn::colfft_supported(Ny);
-        std::vector<double> lyn = eigenvalues(Ny, lg->Ly, OCN_PERIODIC), lys(Ny);
+        s->ybounded = lg->ty == OCN_BOUNDED;
+        std::vector<double> lyn = eigenvalues(Ny, lg->Ly, lg->ty), lys(Ny);
         for (int q = 0; q < Ny; ++q) lys[q] = s->ycol ? lyn[ocn::colfft_wavenumber(Ny, q)] : lyn[q];
         TRY(upload(lys, &s->ly));
+        if (s->ybounded) {  // the twiddles of the cosine transforms by stored position, and where wavenumber Ny - k is stored
+            std::vector<int> kofp(Ny), pofk(Ny), partner(Ny);
+            for (int q = 0; q < Ny; ++q) {
+                kofp[q] = s->ycol ? ocn::colfft_wavenumber(Ny, q) : q;
+                pofk[kofp[q]] = q;
+            }
+            std::vector<double> w(2 * (size_t)Ny);
+            for (int q = 0; q < Ny; ++q) {
+                const long double a = 3.14159265358979323846264338327950288L * kofp[q] / (2.0L * Ny);
+                w[2 * q] = (double)cosl(a);
+                w[2 * q + 1] = (double)(-sinl(a));
+                partner[q] = pofk[(Ny - kofp[q]) % Ny];
+            }
+            TRY(upload(w, &s->ytw));
+            TRY_HIP(hipMalloc((void **)&s->ypartner, Ny * sizeof(int)));
+            TRY_HIP(hipMemcpy(s->ypartner, partner.data(), Ny * sizeof(int), hipMemcpyHostToDevice));
+        }
         if (s->ycol) {
             TRY(upload(ocn::colfft_twiddles(Ny), &s->tw_y));
         } else {  // rocFFT, one z-plane per execution: (nx columns at distance 1) x (Ny points at stride nx)
@@ -1545,17 +1574,35 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
 }
 
 // y transform of the slab (nx, Ny, Nz) for the tridiagonal flavour: column-FFT kernel (stage-ordered ky) or rocFFT per plane
-static int dist_tri_y_transform(ocn_dist_poisson *s, int inverse, hipStream_t stream)
+static int dist_tri_y_fft(ocn_dist_poisson *s, int inverse, double *a, hipStream_t stream)
 {
     const int nx = s->nx, Ny = s->grid.Ny, Nz = s->grid.Nz;
     if (s->ycol)
-        return ocn::launch_colfft(Ny, inverse ? 1 : 0, s->yfield, nx, (long long)nx * Ny, nx, Nz, s->tw_y, nullptr, nullptr,
-                                  nullptr, 1.0, 1, stream);
+        return ocn::launch_colfft(Ny, inverse ? 1 : 0, a, nx, (long long)nx * Ny, nx, Nz, s->tw_y, nullptr, nullptr, nullptr, 1.0, 1, stream);
     Plan &P = inverse ? s->byz : s->fyz;
     for (int k = 0; k < Nz; ++k) {
-        int st = P.exec(s->yfield + 2 * (size_t)nx * Ny * k, nullptr, stream);
+        int st = P.exec(a + 2 * (size_t)nx * Ny * k, nullptr, stream);
         if (st != OCN_SUCCESS) return st;
     }
+    return OCN_SUCCESS;
+}
+// Bounded y: the cosine transforms of the single-process solver (dct_shuffle_kernel: Makhoul's gather / twiddle around the complex FFT),
+// out of place through `send`, which is idle while the spectrum is y-local.  The inverse's 1 / Ny rides on the x inverse like the FFT's.
+static int dist_tri_y_transform(ocn_dist_poisson *s, int inverse, hipStream_t stream)
+{
+    if (!s->ybounded) return dist_tri_y_fft(s, inverse, s->yfield, stream);
+    const int nx = s->nx, Ny = s->grid.Ny, Nz = s->grid.Nz;
+    const long long n = (long long)nx * Ny * Nz;
+    auto shuffle = [&](int mode, const double *in, double *out) {
+        hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nx, Ny, Nz, 1, mode,
+                           reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(out), reinterpret_cast<const double2 *>(s->ytw),
+                           (mode == 1 || mode == 2) ? s->ypartner : nullptr);
+    };
+    shuffle(inverse ? 2 : 0, s->yfield, s->send);
+    int st = dist_tri_y_fft(s, inverse, s->send, stream);
+    if (st != OCN_SUCCESS) return st;
+    shuffle(inverse ? 3 : 1, s->send, s->yfield);
+    OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
 

@@ -797,12 +797,13 @@ class DistributedFourierTridiagonalPoissonSolver(DistributedFFTBasedPoissonSolve
     with this rank's ky range -> IFFT_x -> x->y all-to-all -> IFFT_y -> real part.  z stays local in both layouts, so the
     reference's additional transposes to a z-local pencil are not needed; the same `solve` choreography as the FFT solver
     applies with the library's handle in its tridiagonal mode.  The (kx, ky) = (0, 0) column gets the zero-mean gauge of the
-    single-process solver (the reference's distributed solver leaves that constant undetermined)."""
+    single-process solver (the reference's distributed solver leaves that constant undetermined).  A Bounded y (the channel:
+    (Periodic, Bounded, Bounded)) takes the cosine transforms of the single-process solver in place of FFT_y / IFFT_y."""
 
     @staticmethod
     def _check_topology(grid):
-        if grid.topology[1] != Periodic or grid.topology[2] != Bounded:
-            raise NotImplementedError("DistributedFourierTridiagonalPoissonSolver: (x-partitioned, Periodic, Bounded) only")
+        if grid.topology[1] not in (Periodic, Bounded) or grid.topology[2] != Bounded:
+            raise NotImplementedError("DistributedFourierTridiagonalPoissonSolver: (x-partitioned, Periodic or Bounded, Bounded) only")
 
 
 class _DevBuf:

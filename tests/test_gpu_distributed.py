@@ -79,10 +79,11 @@ def _run_ranks(R, fn):
 
 
 @pytest.mark.parametrize("R", [2, 4])
-@pytest.mark.parametrize("topo", ["PPP", "PPB"])
+@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB"])
 def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
     """Two RK3 steps on R slab-x ranks against the single-rank model AND, directly, against the CPU oracle; "PPB" = stretched Bounded
-    z, i.e. the distributed Fourier-tridiagonal solver (config 4's solver at 1 -> 8 GPUs)."""
+    z, i.e. the distributed Fourier-tridiagonal solver (config 4's solver at 1 -> 8 GPUs); "PBB" = the channel: walls in y too (cosine
+    transforms in y, the direction-generic kernels on every slab; distributed_grids.jl:75-118)."""
     from helpers import stretched_faces
     P = "Periodic"
     N = (32, 16, 12)
@@ -90,12 +91,16 @@ def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
         ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
         solver_class = ocn.DistributedFFTBasedPoissonSolver
     else:
-        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=stretched_faces(N[2], 2.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
+        # (a regular z under the walls in y: the single-rank reference of "PBB" is the FFT-based solver with cosine transforms)
+        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=stretched_faces(N[2], 2.0) if topo == "PPB" else (0, 2.0),
+                   topology=(P, P if topo == "PPB" else "Bounded", "Bounded"), halo=(3, 3, 3))
         solver_class = ocn.DistributedFourierTridiagonalPoissonSolver
     rng = np.random.default_rng(1234)
     init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
-    if topo == "PPB":
+    if topo != "PPP":
         init["w"] = rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
+    if topo == "PBB":
+        init["v"] = rng.uniform(-1, 1, (N[0], N[1] + 1, N[2]))
     dt = 0.01
     ocn.set_math_mode(ocn.MATH_STRICT)
     sg = ocn.RectilinearGrid(ocn.GPU(), size=N, **ext)
@@ -129,10 +134,12 @@ def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
             tol = 1e-11 * scale if name != "p" else 1e-10 * max(1.0, np.abs(ref[3]).max())
             assert np.abs(a - b[sl]).max() <= tol, f"rank {r} field {name}"
         for a, b, name in zip(G, refG, "uvw"):
-            if topo == "PPB" and name == "w":
+            if topo != "PPP" and name == "w":
                 # the wall face k = 1 of Gw: the serial launch excludes the periphery, a KernelParameters launch (distributed)
                 # writes it (kernel_launching.jl:236-240); no kernel ever reads it
                 a, b = a[:, :, 1:], b[:, :, 1:]
+            if topo == "PBB" and name == "v":
+                a, b = a[:, 1:, :], b[:, 1:, :]
             assert np.abs(a - b[sl]).max() <= 1e-9 * max(1.0, np.abs(b).max())
     # the same two steps on the CPU oracle: the distributed result is compared with it directly, not only through the single-rank model
     O = oracle
@@ -299,8 +306,10 @@ def test_transpose_free_poisson_extreme_aspect_ratios(ocn, Lx, Ly, Lz, monkeypat
 
 
 @pytest.mark.parametrize("R", [2, 4])
-@pytest.mark.parametrize("closure,stepper", [("constant", "RungeKutta3"), ("AMD", "RungeKutta3"), ("AMD", "QuasiAdamsBashforth2")])
-def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, stepper):
+@pytest.mark.parametrize("closure,stepper,ytopo", [("constant", "RungeKutta3", "Periodic"), ("AMD", "RungeKutta3", "Periodic"),
+                                                   ("AMD", "QuasiAdamsBashforth2", "Periodic"), ("constant", "RungeKutta3", "Bounded"),
+                                                   ("AMD", "RungeKutta3", "Bounded")])
+def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, stepper, ytopo):
     """Config 4's physics (buoyancy, Coriolis, diffusivity, flux / gradient boundary conditions; the LES closure as written or
     replaced by a constant ScalarDiffusivity) on R slab-x ranks against the single-rank model: 2 steps.  The ranks compute the
     interior auxiliaries and tendencies while the halo exchange is in flight and the edge / halo columns of pHY′, νₑ, κₑ from the
@@ -308,9 +317,11 @@ def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, s
     from helpers import stretched_faces
     P = "Periodic"
     N = (32, 16, 12)
-    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0), topology=(P, P, "Bounded"), halo=(3, 3, 3))
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0) if ytopo == P else (-32.0, 0.0), topology=(P, ytopo, "Bounded"), halo=(3, 3, 3))
     rng = np.random.default_rng(77)
     init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    if ytopo == "Bounded":  # the channel: walls in y (the direction-generic kernels and the cosine transforms on every slab)
+        init["v"] = 1e-2 * rng.uniform(-1, 1, (N[0], N[1] + 1, N[2]))
     init["w"] = 1e-2 * rng.uniform(-1, 1, (N[0], N[1], N[2] + 1))
     init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
     init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
@@ -767,17 +778,23 @@ def test_replica_transport_equals_every_rank_of_a_replicated_flow(ocn, R, monkey
             assert np.abs(a - b).max() <= tol, f"rank {r} of {R}, {name}: {np.abs(a - b).max()}"
 
 
-@pytest.mark.parametrize("R", [2, 4])
-def test_library_transport_config4_terms_match_single_rank(ocn, R):
+@pytest.mark.parametrize("R,ytopo", [(2, "Periodic"), (4, "Periodic"), (2, "Bounded"), (4, "Bounded")])
+def test_library_transport_config4_terms_match_single_rank(ocn, R, ytopo):
     """Config 4's term set (T, S, SeawaterBuoyancy + pHY', FPlane, AMD, flux / gradient conditions, stretched Bounded z, the distributed
     Fourier-tridiagonal solver) on R ranks over the library's transport: Python host (interior / buffer split, diffusivities recomputed in
     the edge and halo columns) and the C model driver (ocn_model_driver_create_distributed), rank by rank bit-identical to each other and
-    within 1e-10 of the single-rank model."""
+    within 1e-10 of the single-rank model.  ytopo = "Bounded": the same physics in a channel (walls in y, regular z), Python host only --
+    the slabs run the direction-generic kernels (interior box + wall frames) and the cosine transforms in y (Ny = 128: the column kernel
+    with stage-ordered wavenumbers), every exchange through the library's transport."""
     from helpers import stretched_faces
     N = (64 * R // 2, 128, 32)
-    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0), topology=("Periodic", "Periodic", "Bounded"), halo=(3, 3, 3))
+    channel = ytopo == "Bounded"
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=(-32.0, 0.0) if channel else stretched_faces(N[2], 32.0), topology=("Periodic", ytopo, "Bounded"),
+               halo=(3, 3, 3))
     rng = np.random.default_rng(25)
     init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    if channel:
+        init["v"] = 1e-2 * rng.uniform(-1, 1, (N[0], N[1] + 1, N[2]))
     init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
     init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
     ocn.set_math_mode(ocn.MATH_STRICT)
@@ -803,7 +820,7 @@ def test_library_transport_config4_terms_match_single_rank(ocn, R):
         arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
         nx = N[0] // R
         out = []
-        for use_driver in (False, True):
+        for use_driver in ((False,) if channel else (False, True)):
             m = build(arch, slice(r * nx, (r + 1) * nx))
             if use_driver:
                 drv = ocn.ModelRK3Driver(m)
@@ -824,7 +841,8 @@ def test_library_transport_config4_terms_match_single_rank(ocn, R):
     nx = N[0] // R
     scale = max(np.abs(a).max() for a in ref[:3])
     names = ("u", "v", "w", "T", "S", "p")
-    for r, (host, drv) in enumerate(outs):
+    for r, out in enumerate(outs):
+        host, drv = out[0], out[-1]
         sl = slice(r * nx, (r + 1) * nx)
         for a, b, c, name in zip(host, drv, ref, names):
             np.testing.assert_array_equal(a, b, err_msg=f"rank {r} {name}: C model driver vs Python host")
