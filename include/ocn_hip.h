@@ -330,11 +330,15 @@ int ocn_divergence(const ocn_grid *grid, const double *u, const double *v, const
 /* Poisson solver handle = FFTBasedPoissonSolver (src/Solvers/fft_based_poisson_solver.jl:5-125) when z is
  * regular and Periodic/Flat, FourierTridiagonalPoissonSolver (fourier_tridiagonal_poisson_solver.jl:6-147)
  * when z is Bounded (regular or stretched) -- the dispatch of
- * src/Models/NonhydrostaticModels/NonhydrostaticModels.jl:25-62.  The handle owns its storage and rocFFT plans. */
+ * src/Models/NonhydrostaticModels/NonhydrostaticModels.jl:25-62.  Grids with a Bounded / Flat x or y: the FFT-based
+ * solver with cosine transforms when every direction is regular, the Fourier-tridiagonal solver (cosine / Fourier
+ * transforms along x and y, Thomas sweep along z) when z is stretched -- or when the environment variable
+ * OCN_POISSON_GENERAL_TRI=1 asks for it on a regular Bounded z.  The handle owns its storage and rocFFT plans. */
 typedef struct ocn_poisson *ocn_poisson_t;
 int ocn_poisson_create(ocn_poisson_t *solver, const ocn_grid *grid);
 int ocn_poisson_destroy(ocn_poisson_t solver);
-/* introspection: kind 0 = FFT-based, 1 = Fourier-tridiagonal; r2c = real-to-complex transforms in use;
+/* introspection: kind 0 = FFT-based, 1 = Fourier-tridiagonal, 2 = FFT-based with cosine transforms (a Bounded / Flat x or y),
+ * 3 = Fourier-tridiagonal on such a grid; r2c = real-to-complex transforms in use;
  * direct_out = inverse transform writes straight into the pressure interior (no copy_real_component! pass) */
 int ocn_poisson_info(ocn_poisson_t solver, int32_t *kind, int32_t *r2c, int32_t *direct_out);
 /* compute_source_term! (src/Models/NonhydrostaticModels/solve_for_pressure.jl:12-17,33-38,57-76) */

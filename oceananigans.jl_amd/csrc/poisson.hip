@@ -161,6 +161,10 @@ struct ocn_poisson {
     double *gcoltw[3] = {nullptr, nullptr, nullptr};
     int *gpartner[3] = {nullptr, nullptr, nullptr};
     bool fft_dct = false;
+    // ... with the z direction solved by the batched Thomas sweep instead of a third transform: FourierTridiagonalPoissonSolver on grids
+    // with a Bounded / Flat x or y (XYRegularRG with any (x, y) topology: fourier_tridiagonal_poisson_solver.jl:82-147) -- the only solver
+    // of a channel with a stretched z
+    bool gtri = false;
 };
 
 static void free_all(ocn_poisson *s)
@@ -349,8 +353,11 @@ static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const i
 
 static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
 {
-    if (grid->dzc != nullptr) {
-        ocn::set_error("FFTBasedPoissonSolver requires regular spacings in every direction (a stretched z needs Periodic x and y)");
+    // a stretched z (or OCN_POISSON_GENERAL_TRI=1 on a regular Bounded z): transforms along x and y, tridiagonal solve along z
+    const char *etri = std::getenv("OCN_POISSON_GENERAL_TRI");
+    const bool gtri = grid->dzc != nullptr || (etri && etri[0] == '1' && grid->tz == OCN_BOUNDED);
+    if (gtri && (grid->tz != OCN_BOUNDED || grid->Nz < 2)) {
+        ocn::set_error("`FourierTridiagonalPoissonSolver` can only be used when the stretched direction's topology is `Bounded` (and Nz >= 2)");
         return OCN_ERR_UNSUPPORTED;
     }
     for (int t : {grid->tx, grid->ty, grid->tz})
@@ -361,9 +368,10 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
     ocn_poisson *s = new ocn_poisson();
     s->grid = *grid;
     s->kind = 2;
+    s->gtri = gtri;
     s->c2c = true;
     s->direct_out = false;
-    const int N[3] = {grid->Nx, grid->Ny, grid->Nz}, topo[3] = {grid->tx, grid->ty, grid->tz};
+    const int N[3] = {grid->Nx, grid->Ny, grid->Nz}, topo[3] = {grid->tx, grid->ty, gtri ? OCN_FLAT : grid->tz};  // (no transform along z)
     const double Ls[3] = {grid->Lx, grid->Ly, grid->Lz};
     s->nxh = N[0];
     const size_t n = (size_t)N[0] * N[1] * N[2];
@@ -435,6 +443,37 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         ocn::set_error("ocn_poisson_create: out of device memory");
         st = OCN_ERR_ALLOC;
     }
+    if (st == OCN_SUCCESS && gtri) {
+        // own copies of the spacings, lower = upper = 1/Δzᶠ[q], q = 2..Nz, main diagonal with the (stored-order) eigenvalues of x and y
+        // (fourier_tridiagonal_poisson_solver.jl:41-51, 97-99)
+        const int Nz = grid->Nz, Hz = grid->Hz;
+        const size_t nf = (size_t)Nz + 2 * Hz;
+        std::vector<double> hf(nf, grid->dz);
+        bool ok = true;
+        if (grid->dzc) {
+            ok = hipMalloc((void **)&s->dzc, nf * sizeof(double)) == hipSuccess && hipMalloc((void **)&s->dzf, nf * sizeof(double)) == hipSuccess &&
+                 hipMemcpy(s->dzc, grid->dzc, nf * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess &&
+                 hipMemcpy(s->dzf, grid->dzf, nf * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess &&
+                 hipMemcpy(hf.data(), grid->dzf, nf * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+            s->grid.dzc = s->dzc;
+            s->grid.dzf = s->dzf;
+        }
+        ok = ok && hipMalloc((void **)&s->diag, n * sizeof(double)) == hipSuccess && hipMalloc((void **)&s->tscr, n * sizeof(double)) == hipSuccess;
+        if (!ok) {
+            ocn::set_error("ocn_poisson_create: out of device memory (tridiagonal arrays)");
+            st = OCN_ERR_ALLOC;
+        }
+        if (st == OCN_SUCCESS) {
+            std::vector<double> low(Nz - 1, 0.0);
+            for (int q = 2; q <= Nz; ++q) low[q - 2] = 1 / hf[q + Hz - 1];
+            st = upload(low, &s->lower);
+        }
+        if (st == OCN_SUCCESS) st = ocn::launch_main_diagonal(&s->grid, N[0], s->lx, s->ly, s->diag, nullptr);
+        if (st == OCN_SUCCESS && hipDeviceSynchronize() != hipSuccess) {
+            ocn::set_error("ocn_poisson_create: main diagonal kernel failed");
+            st = OCN_ERR_HIP;
+        }
+    }
     if (st != OCN_SUCCESS) {
         free_all(s);
         delete s;
@@ -455,7 +494,7 @@ static bool general_fuse_shuffles()
 static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
 {
     const ocn_grid *g = &s->grid;
-    const int N[3] = {g->Nx, g->Ny, g->Nz}, topo[3] = {g->tx, g->ty, g->tz};
+    const int N[3] = {g->Nx, g->Ny, g->Nz}, topo[3] = {g->tx, g->ty, s->gtri ? OCN_FLAT : g->tz};
     const long long n = (long long)N[0] * N[1] * N[2];
     double *a = s->spec, *b = s->spec2;
     int order[3], no = 0;
@@ -514,7 +553,15 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     s->gathered = false;
     run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
     if (pst != OCN_SUCCESS) return pst;
-    int st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
+    int st;
+    if (s->gtri) {  // batched Thomas sweep along z, then the zero-mean gauge on the (kx, ky) = (0, 0) column (stored position 0 in either order)
+        st = ocn::launch_tridiag_z(N[0], N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
+        if (st != OCN_SUCCESS) return st;
+        std::swap(a, b);
+        st = ocn::launch_remove_mean_mode((long long)N[0] * N[1], N[2], a, stream);
+    } else {
+        st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
+    }
     if (st != OCN_SUCCESS) return st;
     // the scatter pass of the last inverse cosine transform is folded into the read of copy_real_component!
     const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
@@ -534,7 +581,8 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
         if (bounded_xy || (eg && eg[0] == '1' && grid->dzc == nullptr)) {
             // (the solver only touches a Center field, whose layout does not depend on the topology: its own light validation)
             OCN_REQUIRE(grid->Nx >= 1 && grid->Ny >= 1 && grid->Nz >= 1 && grid->Hx >= 0 && grid->Hy >= 0 && grid->Hz >= 0, "bad grid size / halo");
-            OCN_REQUIRE(grid->dx > 0 && grid->dy > 0 && grid->dz > 0 && grid->Lx > 0 && grid->Ly > 0 && grid->Lz > 0, "spacings and extents must be positive");
+            OCN_REQUIRE(grid->dx > 0 && grid->dy > 0 && (grid->dzc || grid->dz > 0) && grid->Lx > 0 && grid->Ly > 0 && grid->Lz > 0, "spacings and extents must be positive");
+            OCN_REQUIRE((grid->dzc == nullptr) == (grid->dzf == nullptr), "dzc and dzf must both be set or both be NULL");
             return poisson_create_general(out, grid);
         }
     }
@@ -943,7 +991,7 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s)
 extern "C" int ocn_poisson_info(ocn_poisson_t s, int32_t *kind, int32_t *r2c, int32_t *direct_out)
 {
     OCN_REQUIRE(s, "ocn_poisson_info: null solver");
-    if (kind) *kind = s->kind;
+    if (kind) *kind = s->gtri ? 3 : s->kind;  // 3: Fourier-tridiagonal on a grid with a Bounded / Flat x or y
     if (r2c) *r2c = !s->c2c;
     if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0) + 4 * (s->custom_xy ? 1 : 0);
     return OCN_SUCCESS;
@@ -961,9 +1009,10 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
         // folded into this store
         int first = -1;
         if (s->fft_dct && general_fuse_shuffles())
-            for (int d = 2; d >= 0; --d)
+            for (int d = s->gtri ? 1 : 2; d >= 0; --d)
                 if ((d == 0 ? g->tx : d == 1 ? g->ty : g->tz) == OCN_BOUNDED) first = d;
-        st = ocn::launch_source_term(g, u, v, w, dt, 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
+        // (the tridiagonal flavour's right-hand side carries Δzᶜ: _fourier_tridiagonal_source_term!, solve_for_pressure.jl:33-38)
+        st = ocn::launch_source_term(g, u, v, w, dt, s->gtri ? 2 : 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
         s->gathered = (st == OCN_SUCCESS) && first >= 0;
         s->source_set = (st == OCN_SUCCESS);
         return st;
@@ -988,9 +1037,10 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
     OCN_REQUIRE(s && R, "ocn_poisson_set_source_term: null argument");
     const ocn_grid *g = &s->grid;
     // set_source_term! multiplies by Δzᶜ for the Fourier-tridiagonal solver (fourier_tridiagonal_poisson_solver.jl:155-177)
-    const double *dzc = (s->kind == 1) ? g->dzc : nullptr;
+    const bool tri = s->kind == 1 || s->gtri;
+    const double *dzc = tri ? g->dzc : nullptr;
     int st;
-    if (s->kind == 1 && !g->dzc) {
+    if (tri && !g->dzc) {
         // regular Bounded z: Δz is a scalar; scale on the fly through a constant array is not needed -- use a tiny device array
         std::vector<double> h(g->Nz + 2 * g->Hz, g->dz);
         double *d = nullptr;
@@ -1012,7 +1062,7 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
 extern "C" int ocn_poisson_solve_shifted(ocn_poisson_t s, double *p, double m, void *stream_)
 {
     OCN_REQUIRE(s && p, "ocn_poisson_solve_shifted: null argument");
-    OCN_REQUIRE(s->kind != 1, "ocn_poisson_solve_shifted: FFT-based solvers only");
+    OCN_REQUIRE(s->kind != 1 && !s->gtri, "ocn_poisson_solve_shifted: FFT-based solvers only");
     OCN_REQUIRE(!s->custom_xy && !s->fused_z, "ocn_poisson_solve_shifted: not available on the fused transform pipelines (a Flat or small z "
                 "uses the plain path; OCN_POISSON_CUSTOM_XY=0 OCN_POISSON_FUSED_Z=0 select it elsewhere)");
     s->shift = m;

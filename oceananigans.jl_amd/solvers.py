@@ -79,12 +79,26 @@ class FFTBasedPoissonSolver(_PoissonHandle):
 
 
 class FourierTridiagonalPoissonSolver(_PoissonHandle):
-    """src/Solvers/fourier_tridiagonal_poisson_solver.jl:82-147, tridiagonal direction z (Bounded)."""
+    """src/Solvers/fourier_tridiagonal_poisson_solver.jl:82-147, tridiagonal direction z (Bounded, regular or stretched); x and y regular
+    with any topology (XYRegularRG): Periodic -> Fourier, Bounded -> cosine transforms, Flat -> none."""
 
     def __init__(self, grid):
+        import os
         if grid.topology[2] != Bounded:
             raise ValueError("`FourierTridiagonalPoissonSolver` can only be used when the stretched direction's topology is `Bounded`.")
-        super().__init__(grid)
+        if (Bounded in grid.topology[:2] or Flat in grid.topology[:2]) and grid._dzc is None:
+            # a regular z next to walls in x / y: the library would pick the cosine-transform solver; ask for the Thomas sweep
+            old = os.environ.get("OCN_POISSON_GENERAL_TRI")
+            os.environ["OCN_POISSON_GENERAL_TRI"] = "1"
+            try:
+                super().__init__(grid)
+            finally:
+                if old is None:
+                    os.environ.pop("OCN_POISSON_GENERAL_TRI")
+                else:
+                    os.environ["OCN_POISSON_GENERAL_TRI"] = old
+        else:
+            super().__init__(grid)
 
 
 def nonhydrostatic_pressure_solver(grid):
@@ -93,7 +107,9 @@ def nonhydrostatic_pressure_solver(grid):
     if hook is not None:
         return hook(grid)
     if Bounded in grid.topology[:2] or Flat in grid.topology[:2]:
-        return FFTBasedPoissonSolver(grid)  # XYZRegularRG (NonhydrostaticModels.jl:25-62); a stretched z there has no solver in the reference either
+        if grid._dzc is not None:  # XYRegularRG with a stretched z: GridWithFourierTridiagonalSolver (Solvers.jl:51-52)
+            return FourierTridiagonalPoissonSolver(grid)
+        return FFTBasedPoissonSolver(grid)  # XYZRegularRG (NonhydrostaticModels.jl:25-62)
     if grid.topology[2] == Bounded:
         return FourierTridiagonalPoissonSolver(grid)
     return FFTBasedPoissonSolver(grid)

@@ -91,9 +91,8 @@ def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
         ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
         solver_class = ocn.DistributedFFTBasedPoissonSolver
     else:
-        # (a regular z under the walls in y: the single-rank reference of "PBB" is the FFT-based solver with cosine transforms)
-        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=stretched_faces(N[2], 2.0) if topo == "PPB" else (0, 2.0),
-                   topology=(P, P if topo == "PPB" else "Bounded", "Bounded"), halo=(3, 3, 3))
+        ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=stretched_faces(N[2], 2.0), topology=(P, P if topo == "PPB" else "Bounded", "Bounded"),
+                   halo=(3, 3, 3))
         solver_class = ocn.DistributedFourierTridiagonalPoissonSolver
     rng = np.random.default_rng(1234)
     init = {n: rng.uniform(-1, 1, N) for n in "uvw"}
@@ -317,7 +316,7 @@ def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, s
     from helpers import stretched_faces
     P = "Periodic"
     N = (32, 16, 12)
-    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0) if ytopo == P else (-32.0, 0.0), topology=(P, ytopo, "Bounded"), halo=(3, 3, 3))
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=stretched_faces(N[2], 32.0), topology=(P, ytopo, "Bounded"), halo=(3, 3, 3))
     rng = np.random.default_rng(77)
     init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
     if ytopo == "Bounded":  # the channel: walls in y (the direction-generic kernels and the cosine transforms on every slab)
@@ -783,14 +782,15 @@ def test_library_transport_config4_terms_match_single_rank(ocn, R, ytopo):
     """Config 4's term set (T, S, SeawaterBuoyancy + pHY', FPlane, AMD, flux / gradient conditions, stretched Bounded z, the distributed
     Fourier-tridiagonal solver) on R ranks over the library's transport: Python host (interior / buffer split, diffusivities recomputed in
     the edge and halo columns) and the C model driver (ocn_model_driver_create_distributed), rank by rank bit-identical to each other and
-    within 1e-10 of the single-rank model.  ytopo = "Bounded": the same physics in a channel (walls in y, regular z), Python host only --
+    within 1e-10 of the single-rank model.  ytopo = "Bounded": the same physics in a channel (walls in y; stretched z at R = 2, regular z --
+    whose single-rank reference is the cosine-transform FFT solver -- at R = 4), Python host only --
     the slabs run the direction-generic kernels (interior box + wall frames) and the cosine transforms in y (Ny = 128: the column kernel
     with stage-ordered wavenumbers), every exchange through the library's transport."""
     from helpers import stretched_faces
     N = (64 * R // 2, 128, 32)
     channel = ytopo == "Bounded"
-    ext = dict(x=(0, 64.0), y=(0, 64.0), z=(-32.0, 0.0) if channel else stretched_faces(N[2], 32.0), topology=("Periodic", ytopo, "Bounded"),
-               halo=(3, 3, 3))
+    ext = dict(x=(0, 64.0), y=(0, 64.0), z=(-32.0, 0.0) if (channel and R == 4) else stretched_faces(N[2], 32.0),
+               topology=("Periodic", ytopo, "Bounded"), halo=(3, 3, 3))
     rng = np.random.default_rng(25)
     init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
     if channel:

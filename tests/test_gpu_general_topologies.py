@@ -410,6 +410,83 @@ def test_time_steps_match_oracle_on_closed_and_sliced_grids(oracle, ocn, size, t
                 assert np.all(a[tuple(idx)] == 0.0)
 
 
+@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PBB"), ((12, 12, 10), "BBB"), ((32, 1, 16), "PFB"), ((64, 128, 12), "PBB"), ((10, 9, 8), "BPB")])
+@pytest.mark.parametrize("zkind", ["stretched", "regular"])
+def test_fourier_tridiagonal_solver_with_walls_in_x_or_y(oracle, ocn, size, topo, zkind):
+    """FourierTridiagonalPoissonSolver on XYRegularRG grids whose x / y are Bounded or Flat (fourier_tridiagonal_poisson_solver.jl:82-147:
+    cosine / Fourier transforms along x and y, batched Thomas sweep along z): the only solver of a channel with a stretched z.  Source =
+    the divergence of a random velocity (the library's K9 with its Δzᶜ factor); the solution equals the oracle's solver to 1e-10 and
+    satisfies the discrete Poisson equation; (64, 128, ·) runs the y lines through the column kernel (stage-ordered wavenumbers)."""
+    from helpers import stretched_faces
+    O = oracle
+    z = stretched_faces(size[2], 0.7) if zkind == "stretched" else (-0.7, 0)
+    og, pg = make_pair(O, ocn, size, topo, x=(0, 1.3), y=(0, 0.9), z=z)
+    rng = np.random.default_rng(19)
+    U = []
+    for loc in LOCS:
+        a = og.zeros(loc)
+        og.interior(a)[...] = rng.uniform(-1, 1, og.interior(a).shape)
+        if topo[{1: 0, 2: 1, 4: 2}[loc]] == "F":
+            a[...] = 0
+        O.fill_halo_regions(og, a, loc)
+        U.append(a)
+    dU = [to_dev(ocn, pg, l, a) for l, a in zip(LOCS, U)]
+    solver = ocn.nonhydrostatic_pressure_solver(pg) if zkind == "stretched" else ocn.FourierTridiagonalPoissonSolver(pg)
+    assert isinstance(solver, ocn.FourierTridiagonalPoissonSolver) and solver.info()["kind"] == 3
+    p = ocn.CenterField(pg)
+    ocn.solve_for_pressure(p, solver, 0.7, dU)
+    ocn.fill_halo_regions(p)
+    ocn.sync_device()
+    S = O.FourierTridiagonalPoissonSolver(og)
+    p0 = og.zeros(0)
+    S.source_term(*U, 0.7)
+    S.solve(p0)
+    got = np.asfortranarray(from_dev(p))
+    assert np.abs(og.interior(got) - og.interior(p0)).max() <= 1e-10 * max(1.0, np.abs(p0).max())
+    R = O.divergence(og, *U) / 0.7
+    lap = O.laplacian(og, got)
+    assert np.linalg.norm(lap - R) <= 1e-9 * np.linalg.norm(R)
+    # set_source_term! (fourier_tridiagonal_poisson_solver.jl:155-177: multiplies by Δzᶜ itself) gives the same solution
+    solver.set_source_term(R)
+    q = ocn.CenterField(pg)
+    solver.solve(q)
+    ocn.sync_device()
+    assert np.abs(q.interior() - p.interior()).max() <= 1e-10 * max(1.0, np.abs(p0).max())
+
+
+@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PBB"), ((12, 12, 10), "BBB"), ((32, 1, 16), "PFB")])
+def test_time_steps_match_oracle_with_a_stretched_z_under_walls(oracle, ocn, size, topo):
+    """Three RK3 steps (WENO, a tracer) on a channel, a closed box and an x-z slice with a STRETCHED z against the oracle's model: the model
+    picks the Fourier-tridiagonal solver (NonhydrostaticModels.jl:25-62: GridWithFourierTridiagonalSolver), strict math, 1e-11."""
+    from helpers import stretched_faces
+    O = oracle
+    og, pg = make_pair(O, ocn, size, topo, x=(0, 1.3), y=(0, 0.9), z=stretched_faces(size[2], 0.7))
+    rng = np.random.default_rng(16)
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    om = O.NonhydrostaticModel(og, tracers=("c",))
+    pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("c",))
+    assert isinstance(pm.pressure_solver, ocn.FourierTridiagonalPoissonSolver) and pm.pressure_solver.info()["kind"] == 3
+    init = {}
+    for name, loc in zip("uvw", LOCS):
+        if topo[{"u": 0, "v": 1, "w": 2}[name]] == "F":
+            continue
+        init[name] = rng.uniform(-1, 1, og.interior(og.zeros(loc)).shape)
+    init["c"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
+    om.set(**init)
+    ocn.set(pm, **init)
+    dt = 2e-3
+    for _ in range(3):
+        om.time_step(dt)
+        ocn.time_step(pm, dt)
+    ocn.flush_tendencies(pm)
+    ocn.sync_device()
+    scale = max(np.abs(a).max() for a in (om.u, om.v, om.w))
+    for a, f, name in zip((om.u, om.v, om.w, om.tracers[0]), pm.velocities + pm.tracers, ("u", "v", "w", "c")):
+        err = np.abs(og.interior(from_dev(f)) - og.interior(a)).max()
+        assert err <= 1e-11 * max(scale, 1.0), f"{topo} {name}: {err}"
+    assert np.abs(og.interior(from_dev(pm.pNHS)) - og.interior(om.p)).max() <= 1e-10 * max(1.0, np.abs(om.p).max())
+
+
 @pytest.mark.parametrize("topo,fieldname", [("PBB", "c"), ("PBB", "u"), ("BBB", "c"), ("BPB", "c"), ("BPB", "v"), ("PPB", "u"), ("PPB", "v")])
 def test_scalar_diffusivity_budget(ocn, topo, fieldname):
     """test/test_dynamics.jl:35-59, 436-455 (test_ScalarDiffusivity_budget on (Periodic, Bounded, Bounded) and (Bounded, Bounded, Bounded);
