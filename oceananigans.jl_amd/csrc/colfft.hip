@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <type_traits>
+
 #include "ocn_internal.h"
 
 namespace ocn {
@@ -373,6 +375,13 @@ struct RealYArgs {
         if (kc == 0) return k + (long long)NYH * (xl + (long long)nx * z);
         return (long long)(k / kc) * chunk + (k % kc) + (long long)kc * (z + (long long)Nz * xl);
     }
+    // the same with the layout known at compile time (the run-time division by kc stays out of the unrolled A1 loops)
+    template <bool A1>
+    __device__ __forceinline__ long long spec_at_t(int k, int xl, int z, int NYH) const
+    {
+        if (A1) return k + (long long)NYH * (xl + (long long)nx * z);
+        return (long long)(k / kc) * chunk + (k % kc) + (long long)kc * (z + (long long)Nz * xl);
+    }
 };
 
 // Real FFT of length Ny = 2H along y for CB adjacent x columns of one z plane: z_m = s[2m] + i s[2m+1], complex FFT of length H,
@@ -392,6 +401,9 @@ __device__ __forceinline__ double slab_source(const RealYArgs &a, const Lay &L, 
     return a.scale_dz ? (dzc * d) / a.dt : d / a.dt;
 }
 
+#ifndef OCN_REALY_BATCHED_SOURCE
+#define OCN_REALY_BATCHED_SOURCE 1
+#endif
 template <int H, int CB, bool SRC>
 __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
 {
@@ -411,11 +423,48 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
     if (SRC) {
         const Lay L = make_lay(a.g, OCN_LOC_CCC);  // x, y, z Periodic: one layout for u, v, w
         const int i = col0 + (active ? c : 0) + 1, k = z + 1;
+#if OCN_REALY_BATCHED_SOURCE
+        // The 11 values of every pair of rows are LOADED for four pairs at a time (44 loads in flight per thread) before any of them is
+        // used: left to itself the compiler interleaves each divergence with its own loads and waits for memory two dozen times per thread
+        // (`s_waitcnt vmcnt(0)` after every 2 - 5 loads; the kernel ran at 3.7 TB/s with 60 VGPRs of the 128 its occupancy leaves).  Same
+        // expressions on the same operands as slab_source.
+        const GridDev &g = a.g;
+        const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
+        const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
+        const double rV = 1 / (Az * dzc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double uu[4][4], vv[4][3], ww[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = t + T * (4 * h + q);
+                const long long o = at(L, i, 2 * m + 1, k), o2 = o + L.s2;
+                uu[q][0] = a.u[o]; uu[q][1] = a.u[o + 1]; uu[q][2] = a.u[o2]; uu[q][3] = a.u[o2 + 1];
+                vv[q][0] = a.v[o]; vv[q][1] = a.v[o2]; vv[q][2] = a.v[o2 + L.s2];
+                ww[q][0] = a.w[o]; ww[q][1] = a.w[o + L.s3]; ww[q][2] = a.w[o2]; ww[q][3] = a.w[o2 + L.s3];
+            }
+            OCN_ISSUE_LOADS_HERE();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double sv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const double dxu = Ax * uu[q][2 * e + 1] - Ax * uu[q][2 * e];
+                    const double dyv = Ay * vv[q][e + 1] - Ay * vv[q][e];
+                    const double dzw = Az * ww[q][2 * e + 1] - Az * ww[q][2 * e];
+                    const double d = rV * ((dxu + dyv) + dzw);
+                    sv[e] = a.scale_dz ? (dzc * d) / a.dt : d / a.dt;
+                }
+                x[4 * h + q] = active ? cplx{sv[0], sv[1]} : cplx{0, 0};
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int m = t + T * r;
             x[r] = active ? cplx{slab_source(a, L, i, 2 * m + 1, k), slab_source(a, L, i, 2 * m + 2, k)} : cplx{0, 0};
         }
+#endif
     } else {
         const double *src = a.rhs + (col0 + (active ? c : 0)) + (long long)a.nx * ((long long)(2 * H) * z);
 #pragma unroll
@@ -430,15 +479,23 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
     for (int m = 0; m < 8; ++m) A[c * NYH + stage_wavenumber<H>(8 * t + m)] = x[m];
     __syncthreads();
     cplx *out = reinterpret_cast<cplx *>(a.spec);
-    for (int idx = tid; idx < CB * NYH; idx += NT) {
-        const int cc = idx / NYH, k = idx % NYH;
-        if (col0 + cc >= a.nx) continue;
-        const cplx Zk = A[cc * NYH + (k == H ? 0 : k)], Zc = cconj(A[cc * NYH + ((H - k) % H)]);
-        const cplx E = {0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y)};
-        const cplx D = {0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y)};
-        const cplx O = {D.y, -D.x};  // D / i
-        out[a.spec_at(k, col0 + cc, z, NYH)] = cadd(E, cmul(WN[k], O));
-    }
+    constexpr int NIO = (CB * NYH + NT - 1) / NT;
+    auto store = [&](auto a1) {
+#pragma unroll
+        for (int q = 0; q < NIO; ++q) {
+            const int idx = tid + q * NT;
+            if (idx >= CB * NYH) break;
+            const int cc = idx / NYH, k = idx % NYH;
+            if (col0 + cc >= a.nx) continue;
+            const cplx Zk = A[cc * NYH + (k == H ? 0 : k)], Zc = cconj(A[cc * NYH + ((H - k) % H)]);
+            const cplx E = {0.5 * (Zk.x + Zc.x), 0.5 * (Zk.y + Zc.y)};
+            const cplx D = {0.5 * (Zk.x - Zc.x), 0.5 * (Zk.y - Zc.y)};
+            const cplx O = {D.y, -D.x};  // D / i
+            out[a.template spec_at_t<decltype(a1)::value>(k, col0 + cc, z, NYH)] = cadd(E, cmul(WN[k], O));
+        }
+    };
+    if (a.kc == 0) store(std::true_type{});
+    else store(std::false_type{});
 }
 
 // Inverse of the above: Hermitian half spectrum (ky fastest) -> real rows of the haloed pressure field (unnormalised: x H).
@@ -457,9 +514,25 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_inv_kernel(RealYArgs a)
     for (int j = tid; j < H; j += NT) W[j] = reinterpret_cast<const cplx *>(a.twH)[j];
     for (int j = tid; j < NYH; j += NT) WN[j] = reinterpret_cast<const cplx *>(a.twN)[j];
     const cplx *in = reinterpret_cast<const cplx *>(a.spec);
-    for (int idx = tid; idx < CB * NYH; idx += NT) {
-        const int cc = idx / NYH, k = idx % NYH;
-        A[idx] = (col0 + cc < a.nx) ? in[a.spec_at(k, col0 + cc, z, NYH)] : cplx{0, 0};
+    {   // every load of the thread in flight before the first LDS store (the rolled loop waited for each one: one load in flight per thread)
+        constexpr int NIO = (CB * NYH + NT - 1) / NT;
+        cplx tmp[NIO];
+        auto load = [&](auto a1) {
+#pragma unroll
+            for (int q = 0; q < NIO; ++q) {
+                const int idx = tid + q * NT;
+                const int cc = idx / NYH, k = idx % NYH;
+                tmp[q] = (idx < CB * NYH && col0 + cc < a.nx) ? in[a.template spec_at_t<decltype(a1)::value>(k, col0 + cc, z, NYH)] : cplx{0, 0};
+            }
+        };
+        if (a.kc == 0) load(std::true_type{});
+        else load(std::false_type{});
+        OCN_ISSUE_LOADS_HERE();
+#pragma unroll
+        for (int q = 0; q < NIO; ++q) {
+            const int idx = tid + q * NT;
+            if (idx < CB * NYH) A[idx] = tmp[q];
+        }
     }
     __syncthreads();
     cplx x[8];
