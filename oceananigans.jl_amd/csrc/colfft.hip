@@ -387,23 +387,7 @@ struct RealYArgs {
 // Real FFT of length Ny = 2H along y for CB adjacent x columns of one z plane: z_m = s[2m] + i s[2m+1], complex FFT of length H,
 // split step X[k] = E[k] + W_Ny^k O[k] with E = (Z[k] + conj Z[H-k]) / 2, O = (Z[k] - conj Z[H-k]) / (2i), k = 0..H; the H + 1
 // outputs of a column are written as one contiguous run (ky fastest).
-// same expression as kernels.hip div_ccc / source_term_kernel (x, y Periodic; every field shares one set of strides)
-__device__ __forceinline__ double slab_source(const RealYArgs &a, const Lay &L, int i, int j, int k)
-{
-    const GridDev &g = a.g;
-    const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
-    const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
-    const long long o = at(L, i, j, k);
-    const double dxu = Ax * a.u[o + 1] - Ax * a.u[o];
-    const double dyv = Ay * a.v[o + L.s2] - Ay * a.v[o];
-    const double dzw = Az * a.w[o + L.s3] - Az * a.w[o];
-    const double d = (1 / (Az * dzc)) * ((dxu + dyv) + dzw);
-    return a.scale_dz ? (dzc * d) / a.dt : d / a.dt;
-}
 
-#ifndef OCN_REALY_BATCHED_SOURCE
-#define OCN_REALY_BATCHED_SOURCE 1
-#endif
 template <int H, int CB, bool SRC>
 __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
 {
@@ -423,11 +407,10 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
     if (SRC) {
         const Lay L = make_lay(a.g, OCN_LOC_CCC);  // x, y, z Periodic: one layout for u, v, w
         const int i = col0 + (active ? c : 0) + 1, k = z + 1;
-#if OCN_REALY_BATCHED_SOURCE
         // The 11 values of every pair of rows are LOADED for four pairs at a time (44 loads in flight per thread) before any of them is
         // used: left to itself the compiler interleaves each divergence with its own loads and waits for memory two dozen times per thread
         // (`s_waitcnt vmcnt(0)` after every 2 - 5 loads; the kernel ran at 3.7 TB/s with 60 VGPRs of the 128 its occupancy leaves).  Same
-        // expressions on the same operands as slab_source.
+        // expression as kernels.hip div_ccc / source_term_kernel (x, y Periodic; every field shares one set of strides).
         const GridDev &g = a.g;
         const double dzc = g.dzc ? uniform_load(g.dzc, k + g.Hz - 1) : g.dz;
         const double Ax = g.dy * dzc, Ay = g.dx * dzc, Az = g.dx * g.dy;
@@ -458,13 +441,6 @@ __global__ __launch_bounds__(CB *(H / 8)) void realfft_y_fwd_kernel(RealYArgs a)
                 x[4 * h + q] = active ? cplx{sv[0], sv[1]} : cplx{0, 0};
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int m = t + T * r;
-            x[r] = active ? cplx{slab_source(a, L, i, 2 * m + 1, k), slab_source(a, L, i, 2 * m + 2, k)} : cplx{0, 0};
-        }
-#endif
     } else {
         const double *src = a.rhs + (col0 + (active ? c : 0)) + (long long)a.nx * ((long long)(2 * H) * z);
 #pragma unroll

@@ -14,10 +14,6 @@
 #include "ocn_weno.h"
 
 
-// planes per iteration of the marching loop of the momentum kernel (2: the compiler renames the z windows instead of moving them)
-#ifndef OCN_PLANE_UNROLL
-#define OCN_PLANE_UNROLL 1
-#endif
 #ifndef OCN_NARROW_PAD
 #define OCN_NARROW_PAD 0
 #endif
@@ -393,9 +389,9 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         }
     }
 
-    // one plane of the march; the loop below calls it once or (OCN_PLANE_UNROLL=2) twice per iteration -- a loop with barriers is never
-    // unrolled by the compiler, and two planes of straight-line code let it rename the z windows instead of moving them
-    auto plane = [&](const int k) __attribute__((always_inline)) {
+    // (two planes per iteration -- the body as a forced-inline lambda called twice, since the compiler never unrolls a loop with barriers --
+    // were measured in round 4: more VALU instructions and scratch accesses than two single planes)
+    for (; k <= k_end; ++k) {
         double(*su)[LXP] = su_[uvslot(k)];
         double(*sv)[LXP] = sv_[uvslot(k)];
         double(*ex)[NT] = ex_[uvslot(k)];
@@ -602,16 +598,7 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
             zw[m] = zw[m + 1];
         }
         if (k < k_end) { zu[5] = zu_n; zv[5] = zv_n; zw[5] = zw_n; }
-    };
-#if OCN_PLANE_UNROLL > 1
-    for (; k + 1 <= k_end; k += 2) {
-        plane(k);
-        plane(k + 1);
     }
-    if (k <= k_end) plane(k);
-#else
-    for (; k <= k_end; ++k) plane(k);
-#endif
 #undef ZU
 #undef ZV
 #undef ZW
