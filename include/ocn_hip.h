@@ -54,6 +54,12 @@ extern "C" {
  * turns Periodic into FullyConnected): halos come from neighbour ranks, interior
  * arithmetic identical to Periodic. */
 #define OCN_FULLY_CONNECTED 3
+/* the first and the last slab of a grid whose partitioned x is Bounded (distributed_grids.jl:339-346): RightConnected = wall on the
+ * west side, neighbour on the east (rank 0); LeftConnected = neighbour on the west, wall on the east (the last rank; its x-Face fields
+ * carry the wall face: Nx + 1 points, grid_utils.jl:43).  "Half Bounded" topologies (inactive_node.jl:48-52): the order reduction of
+ * the reconstructions, the excluded periphery, the wall fills and the active-node tests apply on the walled side only. */
+#define OCN_RIGHT_CONNECTED 4
+#define OCN_LEFT_CONNECTED 5
 
 /* field location bitmask: bit0 = Face in x, bit1 = Face in y, bit2 = Face in z */
 #define OCN_LOC_CCC 0
@@ -572,6 +578,11 @@ typedef struct ocn_dist_poisson *ocn_dist_poisson_t;
 /* global_Lx: extent of the *global* domain in x (global_grid.Lx), used for the global eigenvalues λx (:104-106) */
 int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, const ocn_grid *local_grid, int32_t rank, int32_t nranks,
                             double global_Lx);
+/* ... with the topology of the GLOBAL x direction said (the local grids of a Bounded x are RightConnected / FullyConnected /
+ * LeftConnected slabs): global_tx = OCN_PERIODIC is ocn_dist_poisson_create; OCN_BOUNDED needs Bounded y and z
+ * (distributed_fft_based_poisson_solver.jl:62-66) and takes cosine transforms along x after the transpose. */
+int ocn_dist_poisson_create_global(ocn_dist_poisson_t *solver, const ocn_grid *local_grid, int32_t rank, int32_t nranks,
+                                   double global_Lx, int32_t global_tx);
 int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
 /* device pointers to the solver's y-local field, x-local field and the two transpose buffers */
 int ocn_dist_poisson_buffers(ocn_dist_poisson_t solver, double **yfield, double **xfield, double **send, double **recv);

@@ -19,7 +19,7 @@ module OceananigansHIPShimExt
 
 using Oceananigans
 using Oceananigans.Architectures: CPU, GPU
-using Oceananigans.Grids: RectilinearGrid, Periodic, Bounded, Flat, FullyConnected, topology
+using Oceananigans.Grids: RectilinearGrid, Periodic, Bounded, Flat, FullyConnected, RightConnected, LeftConnected, topology
 using Oceananigans.Fields: Field, XFaceField, YFaceField, ZFaceField
 using Oceananigans.Models.NonhydrostaticModels: NonhydrostaticModel
 using Oceananigans.TimeSteppers: RungeKutta3TimeStepper, tick!
@@ -115,6 +115,8 @@ topo_code(::Type{Periodic}) = Int32(0)
 topo_code(::Type{Bounded}) = Int32(1)
 topo_code(::Type{Flat}) = Int32(2)
 topo_code(::Type{FullyConnected}) = Int32(3)
+topo_code(::Type{RightConnected}) = Int32(4)   # the first slab of a Bounded partitioned x: wall on its west side
+topo_code(::Type{LeftConnected}) = Int32(5)    # the last one: wall on its east side
 const HIPGrid = RectilinearGrid{<:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:Any, <:HIPGPU}
 function OcnGrid(g::RectilinearGrid)
     TX, TY, TZ = topology(g)
@@ -348,10 +350,11 @@ mutable struct HIPDistributedPoissonSolver
     comm   :: HIPShimComm
     fast   :: Int32      # ocn_dist_poisson_pipeline: 0 transposing rocFFT path, 1 / 2 slab pipelines, 3 transpose-free (csrc/xtri.hip)
 end
-function HIPDistributedPoissonSolver(local_grid, c::HIPShimComm, global_Lx)
+function HIPDistributedPoissonSolver(local_grid, c::HIPShimComm, global_Lx; global_x_topology = Periodic)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:ocn_dist_poisson_create, lib), Cint, (Ptr{Ptr{Cvoid}}, Ref{OcnGrid}, Int32, Int32, Float64),
-                h, Ref(OcnGrid(local_grid)), c.rank, c.nranks, global_Lx))
+    # (topology(global_grid, 1): the slabs of a Bounded x are RightConnected / FullyConnected / LeftConnected, so the solver is told)
+    check(ccall((:ocn_dist_poisson_create_global, lib), Cint, (Ptr{Ptr{Cvoid}}, Ref{OcnGrid}, Int32, Int32, Float64, Int32),
+                h, Ref(OcnGrid(local_grid)), c.rank, c.nranks, global_Lx, topo_code(global_x_topology)))
     fast = Ref{Int32}(0)
     check(ccall((:ocn_dist_poisson_pipeline, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), h[], fast))
     s = HIPDistributedPoissonSolver(h[], c, fast[])

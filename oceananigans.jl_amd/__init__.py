@@ -13,7 +13,7 @@ from .architectures import CPU, GPU, on_architecture, sync_device, zeros
 from .distributed import (Distributed, DistributedFFTBasedPoissonSolver, DistributedFourierTridiagonalPoissonSolver, Partition,
                           TorchDistributedFabric)
 from .fields import CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions
-from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
+from .grids import Bounded, Center, Face, Flat, FullyConnected, LeftConnected, Periodic, RectilinearGrid, RightConnected
 from .models import (NonhydrostaticModel, QuasiAdamsBashforth2TimeStepper, RungeKutta3TimeStepper, ab2_step,
                      cache_previous_tendencies, calculate_pressure_correction, compute_auxiliaries, compute_diffusivities,
                      compute_tendencies, flush_tendencies, RK3Driver, ModelRK3Driver,

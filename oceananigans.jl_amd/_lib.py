@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # the file must exist and export every symbol of include/ocn_hip.h, or loading raises as for the default path
 LIB_PATH = os.environ.get("OCN_LIB_PATH") or os.path.join(_HERE, "lib", "libocn_hip.so")
 
-OCN_PERIODIC, OCN_BOUNDED, OCN_FLAT, OCN_FULLY_CONNECTED = 0, 1, 2, 3
+OCN_PERIODIC, OCN_BOUNDED, OCN_FLAT, OCN_FULLY_CONNECTED, OCN_RIGHT_CONNECTED, OCN_LEFT_CONNECTED = 0, 1, 2, 3, 4, 5
 LOC_CCC, LOC_FCC, LOC_CFC, LOC_CCF = 0, 1, 2, 4
 MATH_STRICT, MATH_FAST = 0, 1
 GRID_MATH_DEFAULT, GRID_MATH_STRICT, GRID_MATH_FAST = 0, 1, 2  # ocn_grid.math
@@ -167,6 +167,7 @@ _SIGS = {
     "ocn_transpose_pack_x_to_y": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "ocn_transpose_unpack_y_from_x": [_i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "ocn_dist_poisson_create": [C.POINTER(_vp), C.POINTER(CGrid), _i32, _i32, _dbl],
+    "ocn_dist_poisson_create_global": [C.POINTER(_vp), C.POINTER(CGrid), _i32, _i32, _dbl, _i32],
     "ocn_dist_poisson_destroy": [_vp],
     "ocn_dist_poisson_buffers": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "ocn_dist_poisson_layout": [_vp, C.POINTER(_i32), C.POINTER(C.c_int64), C.POINTER(_i32)],

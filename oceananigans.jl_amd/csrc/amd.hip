@@ -307,7 +307,7 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
     const long long tiles = (long long)((wx + block.x - 1) / block.x) * ((g.Ny + block.y - 1) / block.y);
     while (KZ > 1 && tiles * ((g.Nz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;  // narrow ranges: keep the chip full
     const dim3 nb = ocn::range_grid(block, wx, g.Ny, (g.Nz + KZ - 1) / KZ);
-    if (grid->tx == OCN_BOUNDED || grid->ty == OCN_BOUNDED)  // per-field parent layouts
+    if (ocn::x_wall_west(*grid) || ocn::x_wall_east(*grid) || grid->ty == OCN_BOUNDED)  // per-field parent layouts
         hipLaunchKernelGGL(amd_fused_kernel<true>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     else
         hipLaunchKernelGGL(amd_fused_kernel<false>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);

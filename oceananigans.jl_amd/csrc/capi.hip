@@ -41,7 +41,7 @@ static int validate_grid_impl(const ocn_grid *g, bool any_xy)
     const int N[3] = {g->Nx, g->Ny, g->Nz};
     const int H[3] = {g->Hx, g->Hy, g->Hz};
     for (int d = 0; d < 3; ++d) {
-        OCN_REQUIRE(t[d] >= OCN_PERIODIC && t[d] <= OCN_FULLY_CONNECTED, "unknown topology code %d", t[d]);
+        OCN_REQUIRE(t[d] >= OCN_PERIODIC && t[d] <= (d == 0 ? OCN_LEFT_CONNECTED : OCN_FULLY_CONNECTED), "unknown topology code %d", t[d]);
         if (t[d] == OCN_FLAT) OCN_REQUIRE(N[d] == 1 && H[d] == 0, "Flat dimension %d must have N = 1, H = 0", d);
         // halo must not exceed the interior (Grids/input_validation.jl: halo <= size)
         if (t[d] != OCN_FLAT) OCN_REQUIRE(H[d] <= N[d], "halo %d larger than size %d in dimension %d", H[d], N[d], d);
@@ -56,10 +56,14 @@ static int validate_grid_impl(const ocn_grid *g, bool any_xy)
     }
     // a slab of a (Periodic, Bounded, *) grid: the direction-generic kernels read the exchanged x halos like periodic images and treat
     // the y walls locally (distributed_grids.jl:75-118)
-    if (any_xy && g->ty == OCN_FLAT && g->tx == OCN_FULLY_CONNECTED) {
+    const bool partitioned_x = g->tx == OCN_FULLY_CONNECTED || g->tx == OCN_RIGHT_CONNECTED || g->tx == OCN_LEFT_CONNECTED;
+    if (any_xy && g->ty == OCN_FLAT && partitioned_x) {
         set_error("a partitioned x needs a Periodic or Bounded y");
         return OCN_ERR_UNSUPPORTED;
     }
+    // the first / last slab of a Bounded x (RightConnected / LeftConnected): the interior must reach past the wall stencils
+    if (g->tx == OCN_RIGHT_CONNECTED || g->tx == OCN_LEFT_CONNECTED)
+        OCN_REQUIRE(g->Nx >= 2, "a half-Bounded slab needs Nx >= 2 (got %d)", g->Nx);
     if (g->tz == OCN_FULLY_CONNECTED) {
         set_error("z is never partitioned (distributed_architectures.jl:223-225)");
         return OCN_ERR_UNSUPPORTED;

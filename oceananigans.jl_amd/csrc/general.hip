@@ -25,31 +25,33 @@ using ocn::Lay;
 
 namespace gen {
 
+// topology of one direction as the kernels see it: Periodic / Bounded / Flat, and for Bounded which sides have a wall -- both, or only
+// one on the first / last slab of a grid whose partitioned x is Bounded (RightConnected / LeftConnected: the "half Bounded" topologies
+// of topologically_conditional_interpolation.jl:55-65, whose order reduction applies on the walled side only)
+struct Topo {
+    int t;
+    bool wl, wh;  // wall at the low-index / high-index end
+};
+
 // topologically conditional interpolation with the topology as a run-time value (ocn_weno.h: sym_interp / bias_interp)
 template <bool CENTER, class V>
-__device__ __forceinline__ double sym_rt(int topo, V val, int idx, int N)
+__device__ __forceinline__ double sym_rt(Topo tp, V val, int idx, int N)
 {
-    if (topo == OCN_FLAT) return val(CENTER ? -1 : 0);
-    if (topo == OCN_BOUNDED) {
-        const bool hi = CENTER ? (idx >= 3 && idx <= N + 1 - 3) : (idx >= 4 && idx <= N + 1 - 3);
+    if (tp.t == OCN_FLAT) return val(CENTER ? -1 : 0);
+    if (tp.t == OCN_BOUNDED) {
+        const bool hi = (!tp.wl || idx >= (CENTER ? 3 : 4)) && (!tp.wh || idx <= N + 1 - 3);
         if (!hi) return 0.5 * val(-1) + 0.5 * val(0);
     }
     return centered4(val(-2), val(-1), val(0), val(1));
 }
 
 template <bool CENTER, class V>
-__device__ __forceinline__ double bias_rt(int topo, V val, int idx, int N, bool left)
+__device__ __forceinline__ double bias_rt(Topo tp, V val, int idx, int N, bool left)
 {
-    if (topo == OCN_FLAT) return val(CENTER ? -1 : 0);
-    if (topo == OCN_BOUNDED) {
-        bool ok5, ok3;
-        if (CENTER) {
-            ok5 = (idx >= 3) && (idx <= N + 1 - 3);
-            ok3 = (idx >= 2) && (idx <= N + 1 - 2);
-        } else {
-            ok5 = (idx >= 4) && (idx <= N + 1 - 3);
-            ok3 = (idx >= 3) && (idx <= N + 1 - 2);
-        }
+    if (tp.t == OCN_FLAT) return val(CENTER ? -1 : 0);
+    if (tp.t == OCN_BOUNDED) {
+        const bool ok5 = (!tp.wl || idx >= (CENTER ? 3 : 4)) && (!tp.wh || idx <= N + 1 - 3);
+        const bool ok3 = (!tp.wl || idx >= (CENTER ? 2 : 3)) && (!tp.wh || idx <= N + 1 - 2);
         if (!ok5) {
             if (ok3) return weno3(val(-2), val(-1), val(0), val(1), left);
             return left ? val(-1) : val(0);
@@ -73,7 +75,12 @@ struct Fields {
     int centered2;  // advection = Centered(order = 2) instead of the build's upwind scheme
 };
 
-__device__ __forceinline__ int topo_of(const GridDev &g, int d) { return d == 0 ? g.tx : d == 1 ? g.ty : g.tz; }
+__device__ __forceinline__ Topo topo_of(const GridDev &g, int d)
+{
+    if (d == 0) return Topo{g.tx, g.xw != 0, g.xe != 0};
+    const int t = d == 1 ? g.ty : g.tz;
+    return Topo{t, t == OCN_BOUNDED, t == OCN_BOUNDED};
+}
 __device__ __forceinline__ int size_of(const GridDev &g, int d) { return d == 0 ? g.Nx : d == 1 ? g.Ny : g.Nz; }
 __device__ __forceinline__ long long stride_of(const Lay &L, int d) { return d == 0 ? 1 : d == 1 ? L.s2 : L.s3; }
 
@@ -83,7 +90,7 @@ template <int CA, int DA, bool ACEN, int CB, int DB, bool BCEN>
 __device__ __forceinline__ double mom_flux(const Fields &F, const Metrics &M, int i, int j, int k)
 {
     const GridDev &g = F.g;
-    if (topo_of(g, CA) == OCN_FLAT) return 0.0;  // the flux THROUGH a Flat direction is zero (flat_advective_fluxes.jl:8-22)
+    if (topo_of(g, CA).t == OCN_FLAT) return 0.0;  // the flux THROUGH a Flat direction is zero (flat_advective_fluxes.jl:8-22)
     const double *fa = CA == 0 ? F.u : CA == 1 ? F.v : F.w;
     const double *fb = CB == 0 ? F.u : CB == 1 ? F.v : F.w;
     const Lay &La = CA == 0 ? F.Lu : CA == 1 ? F.Lv : F.Lw;
@@ -98,8 +105,8 @@ __device__ __forceinline__ double mom_flux(const Fields &F, const Metrics &M, in
     const int ka = qa[2];
     if (F.centered2) {
         // A(flux location) * sym(U) * sym(u), left-associated; the area is NOT inside the interpolation
-        const double ua = c2_rt<ACEN>(topo_of(g, DA), [&](int m) { return pa[m * sa]; });
-        const double ub = c2_rt<BCEN>(topo_of(g, DB), [&](int m) { return pb[m * sb]; });
+        const double ua = c2_rt<ACEN>(topo_of(g, DA).t, [&](int m) { return pa[m * sa]; });
+        const double ub = c2_rt<BCEN>(topo_of(g, DB).t, [&](int m) { return pb[m * sb]; });
         const bool zf = (CB == 2 && CA != 2);  // z-location of the flux: Face for Uw, Vw
         const double dzk = zf ? M.dzF(k) : M.dzC(k);
         const double area = CA == 0 ? M.dy * dzk : CA == 1 ? M.dx * dzk : M.Az;
@@ -128,7 +135,7 @@ template <int D>
 __device__ __forceinline__ double tracer_flux(const Fields &F, const Metrics &M, const double *__restrict__ c, int i, int j, int k)
 {
     const GridDev &g = F.g;
-    if (topo_of(g, D) == OCN_FLAT) return 0.0;
+    if (topo_of(g, D).t == OCN_FLAT) return 0.0;
     const double *fa = D == 0 ? F.u : D == 1 ? F.v : F.w;
     const Lay &La = D == 0 ? F.Lu : D == 1 ? F.Lv : F.Lw;
     const double ut = fa[ocn::at(La, i, j, k)];
@@ -136,7 +143,7 @@ __device__ __forceinline__ double tracer_flux(const Fields &F, const Metrics &M,
     const long long sc = stride_of(F.Lc, D);
     const int ijk[3] = {i, j, k};
     const double area = D == 0 ? M.Ax(k) : D == 1 ? M.Ay(k) : M.Az;
-    if (F.centered2) return (area * ut) * c2_rt<false>(topo_of(g, D), [&](int m) { return pc[m * sc]; });
+    if (F.centered2) return (area * ut) * c2_rt<false>(topo_of(g, D).t, [&](int m) { return pc[m * sc]; });
     const double cr = bias_rt<false>(topo_of(g, D), [&](int m) { return pc[m * sc]; }, ijk[D], size_of(g, D), ut > 0);
     return (area * ut) * cr;
 }
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn
     // inactive_cell (Grids/inactive_node.jl:35-95) and the peripheral-node tests of the Coriolis average
     auto inactive = [&](int a, int b, int c) {
         bool q = false;
-        if (g.tx == OCN_BOUNDED) q |= (a < 1) | (a > g.Nx);
+        if (g.tx == OCN_BOUNDED) q |= (g.xw && a < 1) | (g.xe && a > g.Nx);  // (inactive_node.jl:5-25: by side on the half-Bounded slabs)
         if (g.ty == OCN_BOUNDED) q |= (b < 1) | (b > g.Ny);
         if (g.tz == OCN_BOUNDED) q |= (c < 1) | (c > g.Nz);
         return q;
@@ -377,7 +384,7 @@ static int make_grange(const ocn_grid *grid, const int32_t *range, gen::GRange &
         r.ou = r.ov = r.ow = 1;  // KernelParameters: periphery not excluded
     } else {
         r.i0 = 1; r.i1 = grid->Nx; r.j0 = 1; r.j1 = grid->Ny; r.k0 = 1; r.k1 = grid->Nz;
-        r.ou = (grid->tx == OCN_BOUNDED && grid->Nx > 1) ? 2 : 1;  // periphery_offset(Face, Bounded, N) (kernel_launching.jl:113-114)
+        r.ou = (ocn::x_wall_west(*grid) && grid->Nx > 1) ? 2 : 1;  // periphery_offset(Face, Bounded, N) (kernel_launching.jl:113-114)
         r.ov = (grid->ty == OCN_BOUNDED && grid->Ny > 1) ? 2 : 1;
         r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
     }
@@ -424,8 +431,9 @@ static bool interior_box(const ocn_grid *grid, int centered2, const int32_t *ran
     static const bool off = [] { const char *e = getenv("OCN_GENERAL_TILED"); return e && e[0] == '0'; }();
     if (off || centered2 || range) return false;
     if (grid->tx == OCN_FLAT || grid->ty == OCN_FLAT || grid->tz == OCN_FLAT) return false;
-    if (grid->tx != OCN_BOUNDED && grid->ty != OCN_BOUNDED) return false;
-    box[0] = grid->tx == OCN_BOUNDED ? 4 : 1; box[1] = grid->tx == OCN_BOUNDED ? grid->Nx - 3 : grid->Nx;
+    const bool xw = ocn::x_wall_west(*grid), xe = ocn::x_wall_east(*grid);
+    if (!xw && !xe && grid->ty != OCN_BOUNDED) return false;
+    box[0] = xw ? 4 : 1; box[1] = xe ? grid->Nx - 3 : grid->Nx;
     box[2] = grid->ty == OCN_BOUNDED ? 4 : 1; box[3] = grid->ty == OCN_BOUNDED ? grid->Ny - 3 : grid->Ny;
     return box[1] - box[0] + 1 >= 16 && box[3] - box[2] + 1 >= 8 && grid->Nz >= 4 && grid->Hx >= 3 && grid->Hy >= 3 && grid->Hz >= 3;
 }

@@ -142,15 +142,16 @@ int launch_fill_halos(const ocn_grid *grid, const FieldTuple &ft, int open_fill,
 //                         sits inside 1:N (so corners of two walls, deeper halo cells and halos behind a Face-located wall keep
 //                         their values, exactly as the reference leaves them); otherwise its own index.
 // Source cells are never written by the same launch.
-// skip_x: x is partitioned (FullyConnected) -- its halos come from the neighbours, this launch leaves them alone (the local y / z fills of the
-// halo columns are overwritten by the exchange, which carries the whole cross-section)
+// skip_x (bit 0: the west side, bit 1: the east side): that side of x is partitioned (FullyConnected, or the connected side of a
+// RightConnected / LeftConnected slab) -- its halos come from the neighbour, this launch leaves them alone (the local y / z fills of those
+// halo columns are overwritten by the exchange, which carries the whole cross-section); the other side of a half-Bounded slab is a wall
 __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, FieldTuple a, SideBcTuple bcs, int has_bc, int skip_x)
 {
     const int f = blockIdx.y;
     double *__restrict__ c = a.f[f];
     const int loc = a.loc[f];
     const Lay L = make_lay(g, loc);
-    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {skip_x ? -1 : g.tx, g.ty, g.tz};
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {skip_x == 3 ? -1 : g.tx, g.ty, g.tz};
     const int S[3] = {L.sx, L.sy, L.sz};
     const long long nzi = S[2] - 2 * H[2], nyi = S[1] - 2 * H[1];
     const long long A = (long long)S[0] * S[1] * 2 * H[2];
@@ -183,10 +184,14 @@ __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, Fiel
         int idx[3], src[3];
         int mirror_dir = -1;
         bool mirror_ok = true;
+        // a cell beyond the CONNECTED side of a half-Bounded slab belongs to the neighbour: x is then no wall for it
+        const int ix = P[0] - H[0] + 1;
+        const bool x_connected_here = (skip_x & 1 && ix < 1) || (skip_x & 2 && ix > N[0]);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             idx[d] = P[d] - H[d] + 1;
             src[d] = idx[d];
+            if (d == 0 && x_connected_here) continue;
             if (T[d] == OCN_PERIODIC) {
                 src[d] = wrap1(idx[d], N[d]);
             } else if (T[d] == OCN_BOUNDED) {
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, Fiel
         if (mirror_dir >= 0 && mirror_dir < 3) {
 #pragma unroll
             for (int d = 0; d < 3; ++d)
-                if (d != mirror_dir && T[d] == OCN_BOUNDED && (idx[d] < 1 || idx[d] > N[d])) mirror_dir = 3;
+                if (d != mirror_dir && T[d] == OCN_BOUNDED && !(d == 0 && x_connected_here) && (idx[d] < 1 || idx[d] > N[d])) mirror_dir = 3;
         }
         const bool mirror = mirror_dir >= 0 && mirror_dir < 3;
         if (mirror) src[mirror_dir] = (idx[mirror_dir] == 0) ? 1 : N[mirror_dir];
@@ -224,8 +229,9 @@ __global__ __launch_bounds__(256) void fill_halos_general_kernel(GridDev g, Fiel
     }
 }
 
-// Impenetrable walls in direction d for the field whose wall-normal direction it is (fill_halo_regions_open.jl:65-70)
-__global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int loc, int d, ZBc blo, ZBc bhi)
+// Impenetrable walls in direction d for the field whose wall-normal direction it is (fill_halo_regions_open.jl:65-70); sides: bit 0 the
+// low-index face, bit 1 the high-index one (a half-Bounded slab of a partitioned x has one wall)
+__global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int loc, int d, ZBc blo, ZBc bhi, int sides)
 {
     const Lay L = make_lay(g, loc);
     const int N[3] = {g.Nx, g.Ny, g.Nz};
@@ -238,8 +244,8 @@ __global__ void open_fill_general_kernel(GridDev g, double *__restrict__ c, int 
     lo[d] = 1;
     hi[d] = N[d] + 1;
     // getbc(bc, a, b): 0 for the default Impenetrable condition, the number / array of an OpenBoundaryCondition(value) otherwise
-    c[at(L, lo[0], lo[1], lo[2])] = blo.kind == OCN_BC_OPEN ? bc_condition(blo, a, b, N[d1], 0.0) : 0.0;
-    c[at(L, hi[0], hi[1], hi[2])] = bhi.kind == OCN_BC_OPEN ? bc_condition(bhi, a, b, N[d1], 0.0) : 0.0;
+    if (sides & 1) c[at(L, lo[0], lo[1], lo[2])] = blo.kind == OCN_BC_OPEN ? bc_condition(blo, a, b, N[d1], 0.0) : 0.0;
+    if (sides & 2) c[at(L, hi[0], hi[1], hi[2])] = bhi.kind == OCN_BC_OPEN ? bc_condition(bhi, a, b, N[d1], 0.0) : 0.0;
 }
 
 int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int open_fill, hipStream_t stream, const SideBcTuple *bcs_in)
@@ -248,14 +254,15 @@ int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int op
     const int has_bc = bcs_in != nullptr;
     if (bcs_in) bcs = *bcs_in;
     GridDev g = to_dev(*grid);
-    const int T[3] = {grid->tx, grid->ty, grid->tz}, N[3] = {g.Nx, g.Ny, g.Nz};
+    const int T[3] = {g.tx, grid->ty, grid->tz}, N[3] = {g.Nx, g.Ny, g.Nz};  // (g.tx: Bounded also for the half-Bounded slabs)
     if (open_fill) {
         for (int f = 0; f < ft.n; ++f)
             for (int d = 0; d < 3; ++d)
                 if (T[d] == OCN_BOUNDED && ft.loc[f] == (1 << d)) {
                     const int d1 = d == 0 ? 1 : 0, d2 = d == 2 ? 1 : 2;
+                    const int sides = d == 0 ? (g.xw ? 1 : 0) | (g.xe ? 2 : 0) : 3;
                     hipLaunchKernelGGL(open_fill_general_kernel, dim3((N[d1] + 63) / 64, N[d2]), dim3(64), 0, stream, g, ft.f[f], ft.loc[f], d,
-                                       bcs.side[2 * d][f], bcs.side[2 * d + 1][f]);
+                                       bcs.side[2 * d][f], bcs.side[2 * d + 1][f], sides);
                 }
     }
     long long maxcells = 0;
@@ -269,7 +276,7 @@ int launch_fill_halos_general(const ocn_grid *grid, const FieldTuple &ft, int op
     long long nb = (maxcells + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(fill_halos_general_kernel, dim3((unsigned)nb, ft.n), dim3(256), 0, stream, g, ft, bcs, has_bc,
-                       grid->tx == OCN_FULLY_CONNECTED ? 1 : 0);
+                       (x_connected_west(*grid) ? 1 : 0) | (x_connected_east(*grid) ? 2 : 0));
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -1272,7 +1279,7 @@ __global__ __launch_bounds__(256) void stepper_kernel(GridDev g, StepTuple a, do
         const int loc = a.loc[f];
         // launch!(..., :xyz; exclude_periphery=true): Face in a Bounded dim starts at 2 (kernel_launching.jl:113-161)
         if (MODE != 3 && (loc & 4) && g.tz == OCN_BOUNDED && g.Nz > 1 && k < 2) continue;
-        if (MODE != 3 && (loc & 1) && g.tx == OCN_BOUNDED && g.Nx > 1 && i < 2) continue;
+        if (MODE != 3 && (loc & 1) && g.xw && g.Nx > 1 && i < 2) continue;
         if (MODE != 3 && (loc & 2) && g.ty == OCN_BOUNDED && g.Ny > 1 && j < 2) continue;
         const Lay L = make_lay(g, loc);
         const long long o = at(L, i, j, k);
@@ -1669,8 +1676,10 @@ int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t strea
 // ---------------------------------------------------------------------------------------------------
 // Distributed slab-x staging (field_boundary_buffers.jl:276-308) and transposes (distributed_transpose.jl:25-95)
 // ---------------------------------------------------------------------------------------------------
+// sides (unpack only): bit 0 the west halo, bit 1 the east halo -- the walled side of a half-Bounded slab keeps its wall fill (what the ring
+// delivered there comes from the slab at the other end of the domain and is dropped)
 __global__ void halo_pack_x_kernel(int Hx, int nx, int sx, long long rows, const double *__restrict__ c,
-                                   double *__restrict__ west, double *__restrict__ east, int unpack)
+                                   double *__restrict__ west, double *__restrict__ east, int unpack, int sides)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * Hx) return;
@@ -1682,17 +1691,19 @@ __global__ void halo_pack_x_kernel(int Hx, int nx, int sx, long long rows, const
         east[t] = crow[nx + h];  // parent[1+nx : nx+Hx]
     } else {
         double *wrow = const_cast<double *>(crow);
-        wrow[h] = west[t];            // parent[1 : Hx]
-        wrow[nx + Hx + h] = east[t];  // parent[1+nx+Hx : nx+2Hx]
+        if (sides & 1) wrow[h] = west[t];            // parent[1 : Hx]
+        if (sides & 2) wrow[nx + Hx + h] = east[t];  // parent[1+nx+Hx : nx+2Hx]
     }
 }
+static int unpack_sides(const ocn_grid *grid) { return (grid->tx != OCN_RIGHT_CONNECTED ? 1 : 0) | (grid->tx != OCN_LEFT_CONNECTED ? 2 : 0); }
 int launch_halo_pack_x(const ocn_grid *grid, const double *field, int loc, double *west, double *east, int unpack, hipStream_t stream)
 {
     GridDev g = to_dev(*grid);
     Lay L = make_lay(g, loc);
     long long rows = (long long)L.sy * L.sz;
     long long n = rows * g.Hx;
-    hipLaunchKernelGGL(halo_pack_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g.Hx, g.Nx, L.sx, rows, field, west, east, unpack);
+    hipLaunchKernelGGL(halo_pack_x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g.Hx, g.Nx, L.sx, rows, field, west, east, unpack,
+                       unpack_sides(grid));
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -1715,6 +1726,7 @@ int launch_halo_plane_x(const ocn_grid *grid, double *field, int loc, int which,
     GridDev g = to_dev(*grid);
     Lay L = make_lay(g, loc);
     const long long rows = (long long)L.sy * L.sz;
+    if (unpack && !(unpack_sides(grid) & (which ? 2 : 1))) return OCN_SUCCESS;  // that side of the slab is a wall: its fill stays
     hipLaunchKernelGGL(halo_plane_x_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, g.Hx, g.Nx, L.sx, rows, field, buf,
                        which, unpack);
     OCN_CHECK_HIP(hipGetLastError());
@@ -1729,7 +1741,7 @@ struct PackTuple {
     long long rows[MAX_TUPLE], off[MAX_TUPLE];
     int sy, Ny, Nz, Hy, Hz;  // unpack == 2: the sender filled interior rows only; a halo row takes its periodic image's
 };
-__global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *__restrict__ west, double *__restrict__ east, int unpack)
+__global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *__restrict__ west, double *__restrict__ east, int unpack, int sides)
 {
     const int fi = blockIdx.y;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1749,8 +1761,8 @@ __global__ void halo_pack_x_fields_kernel(int Hx, int nx, PackTuple a, double *_
             k = k < 1 ? k + a.Nz : (k > a.Nz ? k - a.Nz : k);
             b = a.off[fi] + h + (long long)Hx * ((j + a.Hy - 1) + (long long)a.sy * (k + a.Hz - 1));
         }
-        crow[h] = west[b];
-        crow[nx + Hx + h] = east[b];
+        if (sides & 1) crow[h] = west[b];
+        if (sides & 2) crow[nx + Hx + h] = east[b];
     }
 }
 int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream)
@@ -1769,7 +1781,8 @@ int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double
         a.sy = L.sy;  // (unpack == 2 is used on Periodic y, z: every field of the tuple has this cross-section)
     }
     a.Ny = g.Ny; a.Nz = g.Nz; a.Hy = g.Hy; a.Hz = g.Hz;
-    hipLaunchKernelGGL(halo_pack_x_fields_kernel, dim3((unsigned)((most + 255) / 256), ft.n), dim3(256), 0, stream, g.Hx, g.Nx, a, west, east, unpack);
+    hipLaunchKernelGGL(halo_pack_x_fields_kernel, dim3((unsigned)((most + 255) / 256), ft.n), dim3(256), 0, stream, g.Hx, g.Nx, a, west, east, unpack,
+                       unpack_sides(grid));
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -35,14 +35,27 @@ struct GridDev {
     int Nx, Ny, Nz, Hx, Hy, Hz, tx, ty, tz;
     double dx, dy, dz;
     const double *dzc, *dzf;
+    // walls of the x direction by side: both for Bounded, one for the first (RightConnected: west) and the last (LeftConnected: east)
+    // slab of a grid whose partitioned x is Bounded; tx is OCN_BOUNDED for all three (kernels that never meet an x wall ignore these)
+    int xw, xe;
 };
+
+// x walls of a host-side grid description
+inline bool x_wall_west(const ocn_grid &g) { return g.tx == OCN_BOUNDED || g.tx == OCN_RIGHT_CONNECTED; }
+inline bool x_wall_east(const ocn_grid &g) { return g.tx == OCN_BOUNDED || g.tx == OCN_LEFT_CONNECTED; }
+// x halos that come from a neighbour rank (by side)
+inline bool x_connected_west(const ocn_grid &g) { return g.tx == OCN_FULLY_CONNECTED || g.tx == OCN_LEFT_CONNECTED; }
+inline bool x_connected_east(const ocn_grid &g) { return g.tx == OCN_FULLY_CONNECTED || g.tx == OCN_RIGHT_CONNECTED; }
 
 inline GridDev to_dev(const ocn_grid &g)
 {
     GridDev d;
     d.Nx = g.Nx; d.Ny = g.Ny; d.Nz = g.Nz;
     d.Hx = g.Hx; d.Hy = g.Hy; d.Hz = g.Hz;
-    d.tx = g.tx == OCN_FULLY_CONNECTED ? OCN_PERIODIC : g.tx;  // interior arithmetic identical to Periodic
+    d.xw = x_wall_west(g) ? 1 : 0;
+    d.xe = x_wall_east(g) ? 1 : 0;
+    // FullyConnected: interior arithmetic identical to Periodic; the half-Bounded slabs: Bounded, qualified by xw / xe
+    d.tx = g.tx == OCN_FULLY_CONNECTED ? OCN_PERIODIC : ((d.xw || d.xe) ? OCN_BOUNDED : g.tx);
     d.ty = g.ty; d.tz = g.tz;
     d.dx = g.dx; d.dy = g.dy; d.dz = g.dz;
     d.dzc = g.dzc; d.dzf = g.dzf;
@@ -82,11 +95,11 @@ __host__ __device__ inline int ocn_ext(int N, int H, int topo, int face)
     return N + 2 * H + ((face && topo == OCN_BOUNDED) ? 1 : 0);
 }
 
-template <class G>
-__host__ __device__ inline Lay make_lay(const G &g, int loc)
+__host__ __device__ inline Lay make_lay(const GridDev &g, int loc)
 {
     Lay L;
-    L.sx = ocn_ext(g.Nx, g.Hx, g.tx, loc & 1);
+    // (x: the extra Face point belongs to the side with the EAST wall -- Bounded, or the last slab of a partitioned Bounded x)
+    L.sx = g.Nx + 2 * g.Hx + (((loc & 1) && g.xe) ? 1 : 0);
     L.sy = ocn_ext(g.Ny, g.Hy, g.ty, loc & 2);
     L.sz = ocn_ext(g.Nz, g.Hz, g.tz, loc & 4);
     L.s2 = L.sx;

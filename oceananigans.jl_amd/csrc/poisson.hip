@@ -1179,6 +1179,8 @@ struct ocn_dist_poisson {
     bool ybounded = false;         // Bounded y: REDFT10 / REDFT01 from the complex FFT (gather, FFT, twiddle: dct_shuffle_kernel), scratch = send
     double *ytw = nullptr;         // e^{-i pi k / 2 Ny} by stored position
     int *ypartner = nullptr;       // stored position of wavenumber Ny - k (stage order only)
+    bool xbounded = false;         // the partitioned x is Bounded: cosine transforms along x of the x-local field (natural order, rocFFT lines)
+    double *xtw = nullptr;         // e^{-i pi k / 2 Nxg}
     double *tw_y = nullptr;        // column-FFT twiddles
     double *xsol = nullptr;        // tridiagonal solution (x-local layout)
     double *diag = nullptr, *lower = nullptr, *tscr = nullptr;
@@ -1204,7 +1206,7 @@ static void free_all(ocn_dist_poisson *s)
     if (s->fast) s->yfield = nullptr;  // alias of recv
     double **ptrs[] = {&s->lx, &s->ly, &s->lz, &s->rhs, &s->yfield, &s->xfield, &s->send, &s->recv,
                        &s->tw_y, &s->xsol, &s->diag, &s->lower, &s->tscr, &s->dzc, &s->dzf, &s->tw_h, &s->tw_z, &s->tw_x, &s->gsend, &s->grecv,
-                       &s->ytw};
+                       &s->ytw, &s->xtw};
     for (auto p : ptrs)
         if (*p) {
             (void)hipFree(*p);
@@ -1216,11 +1218,21 @@ static void free_all(ocn_dist_poisson *s)
     }
 }
 
-static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c);
+static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c,
+                            int global_tx = OCN_PERIODIC);
 
 extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx)
 {
     return dist_create_impl(out, lg, rank, R, global_Lx, false);
+}
+
+// ... of a grid whose partitioned x is Bounded (global_tx = OCN_BOUNDED; the local grids are RightConnected / FullyConnected /
+// LeftConnected slabs, so the global topology has to be said): (Bounded, Bounded, Bounded) only (distributed_fft_based_poisson_solver.jl:62-66)
+extern "C" int ocn_dist_poisson_create_global(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx,
+                                              int32_t global_tx)
+{
+    OCN_REQUIRE(global_tx == OCN_PERIODIC || global_tx == OCN_BOUNDED, "ocn_dist_poisson_create_global: global_tx must be Periodic or Bounded");
+    return dist_create_impl(out, lg, rank, R, global_Lx, false, global_tx);
 }
 
 // real (y, z) plan pair of the slab: forward + inverse must reproduce a pseudo-random field (see poisson_plans_self_test)
@@ -1291,9 +1303,18 @@ static int dist_real_plans_self_test(ocn_dist_poisson *s)
     return OCN_SUCCESS;
 }
 
-static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c)
+static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t rank, int32_t R, double global_Lx, bool force_c2c, int global_tx)
 {
     OCN_REQUIRE(out && lg, "ocn_dist_poisson_create: null argument");
+    const bool xbounded = global_tx == OCN_BOUNDED;
+    {   // the slab's x topology must be the one its rank has in that global grid
+        const int want = !xbounded ? (lg->tx == OCN_PERIODIC ? OCN_PERIODIC : OCN_FULLY_CONNECTED)
+                                   : (R == 1 ? OCN_BOUNDED : rank == 0 ? OCN_RIGHT_CONNECTED : rank == R - 1 ? OCN_LEFT_CONNECTED : OCN_FULLY_CONNECTED);
+        OCN_REQUIRE(lg->tx == want, "ocn_dist_poisson_create: rank %d of %d of a %s x must hold a slab of x topology %d, got %d", rank, R,
+                    xbounded ? "Bounded" : "Periodic", want, lg->tx);
+        OCN_REQUIRE(!xbounded || (lg->ty == OCN_BOUNDED && lg->tz == OCN_BOUNDED),
+                    "ocn_dist_poisson_create: a Bounded x needs Bounded y and z (distributed_fft_based_poisson_solver.jl:62-66)");
+    }
     int st = ocn::validate_grid_any(lg);
     if (st != OCN_SUCCESS) return st;
     OCN_REQUIRE(R >= 1 && rank >= 0 && rank < R, "ocn_dist_poisson_create: bad rank %d of %d", rank, R);
@@ -1316,7 +1337,7 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
 #define TRY(expr) do { int _st = (expr); if (_st != OCN_SUCCESS) { free_all(s); delete s; return _st; } } while (0)
 #define TRY_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ocn::set_error("%s failed: %s", #expr, hipGetErrorString(_e)); free_all(s); delete s; return OCN_ERR_ALLOC; } } while (0)
     const char *efast = std::getenv("OCN_DIST_POISSON_FAST");
-    if (lg->tz == OCN_BOUNDED && lg->ty == OCN_PERIODIC && !(efast && efast[0] == '0') && R >= 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
+    if (lg->tz == OCN_BOUNDED && lg->ty == OCN_PERIODIC && !xbounded && !(efast && efast[0] == '0') && R >= 1 && Nz > 1 && ocn::realfft_y_supported(Ny) &&
         ocn::colfft_supported(Nxg)) {
         // Slab pipeline, tridiagonal flavour: real y transform (source term x Δzᶜ evaluated on load) writing the all-to-all layout
         // [d][ky_l + c (z + Nz xl)] (ky = d c + ky_l, c = ceil((Ny/2+1) / R), padded entries stay 0) -> exchange -> x is a strided
@@ -1386,7 +1407,17 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
         }
         TRY_HIP(hipMalloc((void **)&s->diag, n * sizeof(double)));
         TRY_HIP(hipMalloc((void **)&s->tscr, n * sizeof(double)));
-        TRY(upload(eigenvalues(Nxg, global_Lx, OCN_PERIODIC), &s->lx));
+        TRY(upload(eigenvalues(Nxg, global_Lx, xbounded ? OCN_BOUNDED : OCN_PERIODIC), &s->lx));
+        s->xbounded = xbounded;
+        if (xbounded) {
+            std::vector<double> w(2 * (size_t)Nxg);
+            for (int q = 0; q < Nxg; ++q) {
+                const long double a = 3.14159265358979323846264338327950288L * q / (2.0L * Nxg);
+                w[2 * q] = (double)cosl(a);
+                w[2 * q + 1] = (double)(-sinl(a));
+            }
+            TRY(upload(w, &s->xtw));
+        }
         // y transforms: the column-FFT kernel leaves ky in stage order, so the eigenvalue of a stored position is permuted
         s->ycol = ocn::colfft_supported(Ny);
         s->ybounded = lg->ty == OCN_BOUNDED;
@@ -1555,7 +1586,7 @@ static int dist_create_impl(ocn_dist_poisson_t *out, const ocn_grid *lg, int32_t
     if (s->r2c && dist_real_plans_self_test(s) != OCN_SUCCESS) {  // see poisson_create_impl: fall back to complex plans
         free_all(s);
         delete s;
-        return dist_create_impl(out, lg, rank, R, global_Lx, true);
+        return dist_create_impl(out, lg, rank, R, global_Lx, true, global_tx);
     }
     *out = s;
     return OCN_SUCCESS;
@@ -1711,8 +1742,25 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
         return ocn::launch_colfft(s->Nxg, 2, s->recv, S, 0, (int)S, 1, s->tw_x, s->ly, s->lz + (size_t)s->rank * cz, s->lx, scale, NyH,
                                   stream, s->rank == 0);
     }
-    int st = s->fx.exec(s->xfield, nullptr, stream);
-    if (st != OCN_SUCCESS) return st;
+    int st;
+    // Bounded x: REDFT10 / REDFT01 along the lines of the x-local field (Nxg, ny, Nz) -- gather / twiddle passes of the single-process
+    // solver around the same complex line FFTs, out of place between xfield and xsol; the inverse's 1 / Nxg rides on the plan's scale
+    auto xshuffle = [&](int mode, const double *in, double *outp) {
+        const long long n = (long long)s->Nxg * s->ny * s->grid.Nz;
+        hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s->Nxg, s->ny, s->grid.Nz, 0, mode,
+                           reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(outp), reinterpret_cast<const double2 *>(s->xtw),
+                           (const int *)nullptr);
+    };
+    if (s->xbounded) {
+        OCN_REQUIRE(s->tri, "ocn_dist_poisson_solve_x: a Bounded x runs the tridiagonal flavour");
+        xshuffle(0, s->xfield, s->xsol);
+        st = s->fx.exec(s->xsol, nullptr, stream);
+        if (st != OCN_SUCCESS) return st;
+        xshuffle(1, s->xsol, s->xfield);
+    } else {
+        st = s->fx.exec(s->xfield, nullptr, stream);
+        if (st != OCN_SUCCESS) return st;
+    }
     if (s->tri) {
         const int Nz = s->grid.Nz;
         st = ocn::launch_tridiag_z(s->Nxg, s->ny, Nz, s->lower, s->diag, s->lower, s->xfield, s->tscr, s->xsol, stream);
@@ -1722,6 +1770,14 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s, void *stream_)
         if (s->rank == 0) {
             st = ocn::launch_remove_mean_mode((long long)s->Nxg * s->ny, Nz, s->xsol, stream);
             if (st != OCN_SUCCESS) return st;
+        }
+        if (s->xbounded) {
+            xshuffle(2, s->xsol, s->xfield);
+            st = s->bx.exec(s->xfield, s->xsol, stream);
+            if (st != OCN_SUCCESS) return st;
+            xshuffle(3, s->xsol, s->xfield);
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
         }
         return s->bx.exec(s->xsol, s->xfield, stream);
     }

@@ -26,7 +26,7 @@ import torch
 
 from . import _lib
 from .architectures import GPU, device, stream_ptr
-from .grids import Bounded, FullyConnected, Periodic, RectilinearGrid
+from .grids import Bounded, FullyConnected, LeftConnected, Periodic, RectilinearGrid, RightConnected
 
 
 class Partition:
@@ -591,8 +591,11 @@ def distributed_rectilinear_grid(arch, size, x=None, y=None, z=None, topology=(P
     """RectilinearGrid(arch::Distributed; ...): the rank-local portion (distributed_grids.jl:75-118)."""
     R, r = arch.partition.x, arch.local_rank
     Nx = size[0]
-    if topology[0] != Periodic:
-        raise NotImplementedError("the partitioned x direction must be Periodic")
+    if topology[0] not in (Periodic, Bounded):
+        raise NotImplementedError("the partitioned x direction must be Periodic or Bounded")
+    if topology[0] == Bounded and (tuple(topology[1:]) != (Bounded, Bounded) or (R == 1 and arch.communicates)):
+        # (distributed_fft_based_poisson_solver.jl:62-66: if y is Periodic, so must x be; if z is Periodic, so must y and x be)
+        raise NotImplementedError("a Bounded partitioned x needs (Bounded, Bounded, Bounded) and more than one rank")
     if Nx % R:
         raise ValueError(f"Nx = {Nx} must be divisible by the number of ranks {R} (equal slabs)")
     nx = Nx // R
@@ -603,11 +606,14 @@ def distributed_rectilinear_grid(arch, size, x=None, y=None, z=None, topology=(P
         for _ in range(r):
             lo = lo + dl * nx
         xl = (lo, lo + dl * nx)
-        topo = (FullyConnected,) + tuple(topology[1:])  # insert_connected_topology (distributed_grids.jl:339-346)
+        # insert_connected_topology (distributed_grids.jl:339-346): a Bounded x leaves a wall on the first and on the last slab
+        tx = FullyConnected if (topology[0] == Periodic or 0 < r < R - 1) else (RightConnected if r == 0 else LeftConnected)
+        topo = (tx,) + tuple(topology[1:])
     else:
         xl, topo = x, tuple(topology)
     g = RectilinearGrid(arch, (nx,) + tuple(size[1:]), x=xl, y=y, z=z, topology=topo, halo=halo, _local=True)
     g.global_size = tuple(size)
+    g.global_topology = tuple(topology)
     from fractions import Fraction
     g.global_Lx = float(Fraction(float(x[1])) - Fraction(float(x[0])))
     return g
@@ -619,8 +625,9 @@ class _HipDistPoisson:
     def __init__(self, grid, arch):
         self.grid, self.R = grid, arch.partition.x
         self._h = C.c_void_p()
-        _lib.call("ocn_dist_poisson_create", C.byref(self._h), grid.cref, arch.local_rank, self.R,
-                  C.c_double(getattr(grid, "global_Lx", grid.Lx * self.R)))
+        gtx = _lib.OCN_BOUNDED if getattr(grid, "global_topology", (Periodic,))[0] == Bounded else _lib.OCN_PERIODIC
+        _lib.call("ocn_dist_poisson_create_global", C.byref(self._h), grid.cref, arch.local_rank, self.R,
+                  C.c_double(getattr(grid, "global_Lx", grid.Lx * self.R)), gtx)
         ptrs = [C.c_void_p() for _ in range(4)]
         _lib.call("ocn_dist_poisson_buffers", self._h, *[C.byref(p) for p in ptrs])
         nyt, nel, r2c = C.c_int32(), C.c_int64(), C.c_int32()

@@ -13,7 +13,12 @@ from . import _lib
 from .architectures import child_architecture, device
 
 Periodic, Bounded, Flat, FullyConnected = "Periodic", "Bounded", "Flat", "FullyConnected"
-_CODE = {Periodic: _lib.OCN_PERIODIC, Bounded: _lib.OCN_BOUNDED, Flat: _lib.OCN_FLAT, FullyConnected: _lib.OCN_FULLY_CONNECTED}
+# the first / last slab of a grid whose partitioned x is Bounded (Grids.jl:97-108): wall on the west / on the east side only
+RightConnected, LeftConnected = "RightConnected", "LeftConnected"
+_CODE = {Periodic: _lib.OCN_PERIODIC, Bounded: _lib.OCN_BOUNDED, Flat: _lib.OCN_FLAT, FullyConnected: _lib.OCN_FULLY_CONNECTED,
+         RightConnected: _lib.OCN_RIGHT_CONNECTED, LeftConnected: _lib.OCN_LEFT_CONNECTED}
+# topologies whose Face fields carry the east boundary face: N + 1 points (BoundedTopology, grid_utils.jl:43)
+_EAST_FACE = (Bounded, LeftConnected)
 
 
 class Center:
@@ -227,7 +232,7 @@ class RectilinearGrid:
         if r is None:
             N = (self.Nx, self.Ny, self.Nz)[d]
             H = (self.Hx, self.Hy, self.Hz)[d]
-            bounded = self.topology[d] == Bounded
+            bounded = self.topology[d] in _EAST_FACE
             c1, c2 = (Fraction(v) for v in self._interval[d])
             L = c2 - c1
             D = L / N                                                # BigFloat arithmetic of the reference, here exact
@@ -248,7 +253,7 @@ class RectilinearGrid:
         topo = self.topology[d]
         if topo == Flat:
             return np.zeros(1)
-        n = N + 1 if (face and topo == Bounded) else N
+        n = N + 1 if (face and topo in _EAST_FACE) else N
         if d == 2 and self.z_faces is not None:
             Fall = np.asarray(self.z_faces)
             if with_halos:
@@ -300,7 +305,7 @@ class RectilinearGrid:
         """(sx, sy, sz) of the OffsetArray parent for a field at `loc` (grid_utils.jl:66-72)."""
         N = (self.Nx, self.Ny, self.Nz)
         H = (self.Hx, self.Hy, self.Hz)
-        return tuple(N[d] + 2 * H[d] + (1 if ((loc >> d) & 1 and self.topology[d] == Bounded) else 0) for d in range(3))
+        return tuple(N[d] + 2 * H[d] + (1 if ((loc >> d) & 1 and self.topology[d] in _EAST_FACE) else 0) for d in range(3))
 
     @property
     def size(self):

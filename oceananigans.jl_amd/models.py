@@ -201,10 +201,11 @@ class NonhydrostaticModel:
         if not xy_periodic:
             if isinstance(closure, AnisotropicMinimumDissipation) and Flat in grid.topology[:2]:
                 raise NotImplementedError("AnisotropicMinimumDissipation needs non-Flat x and y in this backend")
-            if hasattr(grid.architecture, "partition") and not (grid.topology[0] in ("Periodic", "FullyConnected") and grid.topology[1] == "Bounded"
-                                                                   and grid.topology[2] == "Bounded"):
-                # (distributed_fft_based_poisson_solver.jl:62-66: a Bounded y needs a Bounded z; the partitioned x is Periodic here)
-                raise NotImplementedError("a partitioned x needs (Periodic, Periodic, *) or (Periodic, Bounded, Bounded)")
+            if hasattr(grid.architecture, "partition") and not (
+                    grid.topology[0] in ("Periodic", "FullyConnected", "RightConnected", "LeftConnected", "Bounded")
+                    and grid.topology[1] == "Bounded" and grid.topology[2] == "Bounded"):
+                # (distributed_fft_based_poisson_solver.jl:62-66: a Bounded y needs a Bounded z, a Bounded x a Bounded y)
+                raise NotImplementedError("a partitioned x needs (Periodic, Periodic, *), (Periodic, Bounded, Bounded) or (Bounded, Bounded, Bounded)")
         self._alt_velocities = None
         self._alt_fields = None
         # defer the last compute_tendencies! of a step and fuse it with the first substep of the next one

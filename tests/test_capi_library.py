@@ -74,6 +74,18 @@ def test_argument_validation_needs_no_gpu(pkg):
         call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, tx=3, ty=1, tz=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, None, 0.0, None, None)
     with pytest.raises(pkg.OcnError, match="Periodic or Bounded y"):
         call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, tx=3, ty=2, Ny=1, Hy=0)), 1, 1, 1, 1, 1, 1, None, None)
+    # the first / last slab of a Bounded partitioned x (RightConnected = 4, LeftConnected = 5): x only; the distributed solver checks that
+    # the slab's topology is the one its rank has in the global grid
+    for tx in (4, 5):
+        with pytest.raises(pkg.OcnError, match="null field pointer"):
+            call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, tx=tx, ty=1, tz=1)), None, 1, 1, 1, 1, 1, None, None)
+    with pytest.raises(pkg.OcnError, match="unknown topology code"):
+        call("ocn_fill_halo_regions", C.byref(_grid(pkg, ty=4)), fake, ia([0]), 1, 1, None)
+    h = C.c_void_p()
+    with pytest.raises(pkg.OcnError, match="must hold a slab of x topology 4"):
+        call("ocn_dist_poisson_create_global", C.byref(h), C.byref(_grid(pkg, tx=3, ty=1, tz=1)), 0, 4, 32.0, 1)
+    with pytest.raises(pkg.OcnError, match="a Bounded x needs Bounded y and z"):
+        call("ocn_dist_poisson_create_global", C.byref(h), C.byref(_grid(pkg, tx=5, ty=0, tz=1)), 3, 4, 32.0, 1)
     with pytest.raises(pkg.OcnError, match="number of fields"):
         call("ocn_fill_halo_regions", C.byref(_grid(pkg)), fake, ia([0]), 0, 1, None)
     with pytest.raises(pkg.OcnError, match="location mask"):
