@@ -18,7 +18,7 @@ REQUIRED = {
     "ocn_cache_previous_tendencies", "ocn_poisson_create", "ocn_poisson_destroy", "ocn_solve_for_pressure",
     "ocn_pressure_correct_velocities", "ocn_rk3_driver_create", "ocn_rk3_driver_time_step", "ocn_rk3_driver_flush",
     "ocn_rk3_driver_create_distributed", "ocn_rk3_driver_configure", "ocn_model_driver_create", "ocn_model_driver_time_step", "ocn_model_driver_flush",
-    "ocn_comm_unique_id", "ocn_comm_init", "ocn_halo_exchange_begin", "ocn_halo_exchange_end", "ocn_dist_poisson_create",
+    "ocn_comm_unique_id", "ocn_comm_init", "ocn_halo_exchange_begin", "ocn_halo_exchange_end", "ocn_dist_poisson_create_global",
     "ocn_dist_poisson_exchange", "ocn_compute_momentum_tendencies_terms", "ocn_compute_tracer_tendency_terms",
 }
 
