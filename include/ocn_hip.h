@@ -25,7 +25,8 @@
  *    (src/Utils/kernel_launching.jl:252-253).  One host thread per handle.
  *  - Supported scope: RectilinearGrid, x and y regular, z regular or stretched; every combination of
  *    Periodic / Bounded / Flat topologies (LDS-tiled kernels where x and y are Periodic or rank-local
- *    FullyConnected, direction-generic kernels otherwise: csrc/general.hip); Float64.
+ *    FullyConnected, direction-generic kernels otherwise: csrc/general.hip); slabs of an x-partitioned
+ *    (Periodic, Periodic, *), (Periodic, Bounded, Bounded) or (Bounded, Bounded, Bounded) grid; Float64.
  */
 #ifndef OCN_HIP_H
 #define OCN_HIP_H
