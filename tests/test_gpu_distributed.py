@@ -165,10 +165,11 @@ def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
             assert np.abs(a - og.interior(b)[xs(name, r)]).max() <= 1e-11 * scale, f"rank {r} field {name} vs the oracle"
 
 
-@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB", "BBB"])
+@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB", "BBB", "BBB-faces"])
 @pytest.mark.parametrize("size", [(44, 44, 8), (16, 44, 8)])
 def test_divergence_free_poisson_solution_on_four_ranks(ocn, oracle, size, topo):
-    """test_distributed_poisson_solvers.jl:34-89, 128-136 re-expressed with its sizes, its (4, 1, 1) ranks and its four topologies: a
+    """test_distributed_poisson_solvers.jl:34-89, 128-136 re-expressed with its sizes, its (4, 1, 1) ranks and its four topologies (and
+    :91-126, 150-154, "BBB-faces": the tridiagonal solver's own test -- z given as an array of faces, halo (2, 2, 2)): a
     random velocity on every slab (halos filled across the slabs), R = div U, solve_for_pressure! with Δt = 1, then ∇²ϕ ≈ R on every rank
     (the reference's `≈`: sqrt(eps) relative) -- and the assembled pressure equals the oracle's single-process solve to 1e-10.  (A Bounded
     z takes the Fourier-tridiagonal solver here, an exact solver of the same discrete system; 44 is not a length of the column kernels:
@@ -176,8 +177,12 @@ def test_divergence_free_poisson_solution_on_four_ranks(ocn, oracle, size, topo)
     O = oracle
     R = 4
     names = {"P": "Periodic", "B": "Bounded"}
-    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=tuple(names[t] for t in topo), halo=(3, 3, 3))
-    og = O.Grid(size, x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=topo, halo=(3, 3, 3))
+    faces = topo.endswith("-faces")
+    topo = topo[:3]
+    H = 2 if faces else 3
+    z = np.linspace(0, 2 * np.pi, size[2] + 1) if faces else (0, 2 * np.pi)  # collect(range(0, 2π, length = Nz + 1)) (:101-103)
+    ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=tuple(names[t] for t in topo), halo=(H, H, H))
+    og = O.Grid(size, x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=z, topology=topo, halo=(H, H, H))
     rng = np.random.default_rng(1234)
     U = []
     for loc in (1, 2, 4):
@@ -208,9 +213,8 @@ def test_divergence_free_poisson_solution_on_four_ranks(ocn, oracle, size, topo)
         return phi.parent()
 
     for r, parent in enumerate(_run_ranks(R, rank_main)):
-        # the local Laplacian through the oracle on a grid of the slab's shape: x halos as exchanged (treated as periodic images)
-        H = 3
-        interior = parent[H:-H, H:-H, H:-H] if topo[2] != "F" else parent
+        # the Laplacian of the slab's solution from its parent array: x halos as exchanged, y / z halos as filled
+        interior = parent[H:-H, H:-H, H:-H]
         sl = slice(r * nxl, (r + 1) * nxl)
         ref = og.interior(p0)[sl]
         assert np.abs(interior - ref).max() <= 1e-10 * max(1.0, np.abs(p0).max()), f"rank {r}"

@@ -4,6 +4,6 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/r04w
 mkdir -p $O
 cd $ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_distributed.py -x -q -k "ocean_mixing_physics or library_transport_config4" > $O/pytest.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_distributed.py -x -q -k "divergence_free_poisson" > $O/pytest.log 2>&1
 echo "rc=$?" >> $O/pytest.log
 tail -40 $O/pytest.log
