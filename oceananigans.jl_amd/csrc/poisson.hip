@@ -165,12 +165,21 @@ struct ocn_poisson {
     // with a Bounded / Flat x or y (XYRegularRG with any (x, y) topology: fourier_tridiagonal_poisson_solver.jl:82-147) -- the only solver
     // of a channel with a stretched z
     bool gtri = false;
+    // x Periodic (even Nx) next to a Bounded y / z: the source term is REAL and a cosine transform maps reals to reals, so the transforms
+    // along the Bounded y / z run on the real array VIEWED as complex numbers of x-adjacent pairs (Nx / 2 complex columns: the complex
+    // transform of a line is the transform of its real and of its imaginary part, separated by the Hermitian symmetry the twiddle passes
+    // already apply) -- half the bytes per pass -- then x is a real-to-complex transform to the half spectrum (Nx / 2 + 1), on which the
+    // remaining Periodic direction, the solve and the way back run.  Same arithmetic per line as the complex path.
+    bool gpacked = false;
+    Plan xr2c, xc2r;
 };
 
 static void free_all(ocn_poisson *s)
 {
     s->fwd.destroy();
     s->bwd.destroy();
+    s->xr2c.destroy();
+    s->xc2r.destroy();
     for (int d = 0; d < 3; ++d) {
         s->gfwd[d].destroy();
         s->gbwd[d].destroy();
@@ -351,6 +360,9 @@ static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const i
     return OCN_SUCCESS;
 }
 
+static thread_local bool g_no_packed = false;  // the retry of poisson_create_general after a failed self test of the real x plans
+static int packed_plans_self_test(ocn_poisson *s);
+
 static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
 {
     // a stretched z (or OCN_POISSON_GENERAL_TRI=1 on a regular Bounded z): transforms along x and y, tridiagonal solve along z
@@ -394,6 +406,11 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
     {   // FFT-based transforms (default); OCN_POISSON_NAIVE_DCT=1 keeps the direct sums of the definitions (the checker of the tests)
         const char *nv = std::getenv("OCN_POISSON_NAIVE_DCT");
         s->fft_dct = !(nv && nv[0] == '1');
+        {
+            const char *ep = std::getenv("OCN_POISSON_PACKED");
+            s->gpacked = s->fft_dct && !g_no_packed && topo[0] == OCN_PERIODIC && N[0] % 2 == 0 && N[0] >= 4 &&
+                         (topo[1] == OCN_BOUNDED || topo[2] == OCN_BOUNDED) && !(ep && ep[0] == '0');
+        }
         if (s->fft_dct && st == OCN_SUCCESS) {
             ensure_rocfft();
             const char *gc = std::getenv("OCN_POISSON_GENERAL_COLFFT");
@@ -415,6 +432,12 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
                     *lam[d] = nullptr;
                     st = upload(lp, lam[d]);
                     if (st != OCN_SUCCESS) break;
+                } else if (s->gpacked && d == 0) {
+                    // x: real-to-complex / complex-to-real lines (below)
+                } else if (s->gpacked) {
+                    // y / z lines of the packed views: Nx / 2 complex columns under a cosine transform, the half spectrum under an FFT
+                    const int Nd[3] = {topo[d] == OCN_BOUNDED ? N[0] / 2 : N[0] / 2 + 1, N[1], N[2]};
+                    st = make_line_plans(s, d, Nd);
                 } else {
                     st = make_line_plans(s, d, N);
                 }
@@ -443,6 +466,24 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         ocn::set_error("ocn_poisson_create: out of device memory");
         st = OCN_ERR_ALLOC;
     }
+    if (st == OCN_SUCCESS && s->gpacked) {
+        const size_t len[1] = {(size_t)N[0]}, one[1] = {1};
+        const size_t nxh = (size_t)N[0] / 2 + 1, batch = (size_t)N[1] * N[2];
+        st = make_plan(s->xr2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward, 1, len, batch, rocfft_array_type_real,
+                       rocfft_array_type_hermitian_interleaved, one, (size_t)N[0], one, nxh, 1.0);
+        if (st == OCN_SUCCESS)
+            st = make_plan(s->xc2r, rocfft_placement_notinplace, rocfft_transform_type_real_inverse, 1, len, batch,
+                           rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, one, nxh, one, (size_t)N[0], 1.0 / N[0]);
+        if (st == OCN_SUCCESS) st = packed_plans_self_test(s);
+        if (st != OCN_SUCCESS) {  // rocFFT's real plans are verified at creation like the periodic solver's (see Plan::destroy): complex path instead
+            free_all(s);
+            delete s;
+            g_no_packed = true;
+            const int st2 = poisson_create_general(out, grid);
+            g_no_packed = false;
+            return st2;
+        }
+    }
     if (st == OCN_SUCCESS && gtri) {
         // own copies of the spacings, lower = upper = 1/Δzᶠ[q], q = 2..Nz, main diagonal with the (stored-order) eigenvalues of x and y
         // (fourier_tridiagonal_poisson_solver.jl:41-51, 97-99)
@@ -468,7 +509,7 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
             for (int q = 2; q <= Nz; ++q) low[q - 2] = 1 / hf[q + Hz - 1];
             st = upload(low, &s->lower);
         }
-        if (st == OCN_SUCCESS) st = ocn::launch_main_diagonal(&s->grid, N[0], s->lx, s->ly, s->diag, nullptr);
+        if (st == OCN_SUCCESS) st = ocn::launch_main_diagonal(&s->grid, s->gpacked ? N[0] / 2 + 1 : N[0], s->lx, s->ly, s->diag, nullptr);
         if (st == OCN_SUCCESS && hipDeviceSynchronize() != hipSuccess) {
             ocn::set_error("ocn_poisson_create: main diagonal kernel failed");
             st = OCN_ERR_HIP;
@@ -495,20 +536,26 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
 {
     const ocn_grid *g = &s->grid;
     const int N[3] = {g->Nx, g->Ny, g->Nz}, topo[3] = {g->tx, g->ty, s->gtri ? OCN_FLAT : g->tz};
-    const long long n = (long long)N[0] * N[1] * N[2];
     double *a = s->spec, *b = s->spec2;
     int order[3], no = 0;
     for (int d = 0; d < 3; ++d) if (topo[d] == OCN_BOUNDED) order[no++] = d;
     for (int d = 0; d < 3; ++d) if (topo[d] == OCN_PERIODIC) order[no++] = d;
     int pst = OCN_SUCCESS;
+    // the extents of the (complex) array the passes see: the grid's, or -- packed -- Nx / 2 complex columns of x-adjacent real pairs under the
+    // cosine transforms and the half spectrum (Nx / 2 + 1) between the real x transforms
+    const int nxh = N[0] / 2 + 1;
+    const int Nfull[3] = {N[0], N[1], N[2]}, Npair[3] = {N[0] / 2, N[1], N[2]}, Nhalf[3] = {nxh, N[1], N[2]};
+    const int *Nv = Nfull;
     auto shuffle = [&](int d, int mode) {
-        hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], d, mode,
+        const long long n = (long long)Nv[0] * Nv[1] * Nv[2];
+        hipLaunchKernelGGL(dct_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Nv[0], Nv[1], Nv[2], d, mode,
                            reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[d]),
                            (mode == 1 || mode == 2) ? s->gpartner[d] : nullptr);
         std::swap(a, b);
     };
     auto shuffle2 = [&](int dt, int mt, int dp, int mp) {
-        hipLaunchKernelGGL(dct_twiddle_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], dt, mt, dp, mp,
+        const long long n = (long long)Nv[0] * Nv[1] * Nv[2];
+        hipLaunchKernelGGL(dct_twiddle_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, Nv[0], Nv[1], Nv[2], dt, mt, dp, mp,
                            reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), reinterpret_cast<const double2 *>(s->gtw[dt]),
                            s->gpartner[dt]);
         std::swap(a, b);
@@ -527,16 +574,70 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
             } else if (o.kind <= 3) {
                 shuffle(o.d, o.kind);
             } else if (o.kind == 6 || o.kind == 7) {
+                const long long n = (long long)N[0] * N[1] * N[2];
                 hipLaunchKernelGGL(naive_transform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], o.d, topo[o.d],
                                    o.kind == 7, reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[o.d][0], s->tab[o.d][1]);
                 std::swap(a, b);
             } else {
-                pst = exec_line_plan(s, o.d, o.kind == 5, a, N, stream);
+                pst = exec_line_plan(s, o.d, o.kind == 5, a, Nv, stream);
             }
         }
     };
+    auto solve = [&](int nx) {  // the division by the eigenvalues, or the Thomas sweep along z, on an (nx, Ny, Nz) spectrum
+        int st;
+        if (s->gtri) {  // batched Thomas sweep along z, then the zero-mean gauge on the (kx, ky) = (0, 0) column (stored position 0 in either order)
+            st = ocn::launch_tridiag_z(nx, N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
+            if (st != OCN_SUCCESS) return st;
+            std::swap(a, b);
+            return ocn::launch_remove_mean_mode((long long)nx * N[1], N[2], a, stream);
+        }
+        // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
+        return ocn::launch_spectral_solve(nx, N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);
+    };
     Op fwd[9], bwd[9];
     int nf = 0, nb = 0;
+    if (s->gpacked) {
+        // ---- cosine transforms along the Bounded y / z on the real array viewed as Nx / 2 complex columns
+        Nv = Npair;
+        for (int q = 0; q < no; ++q) {
+            const int d = order[q];
+            if (topo[d] == OCN_BOUNDED) { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }
+        }
+        for (int q = no - 1; q >= 0; --q) {
+            const int d = order[q];
+            if (topo[d] == OCN_BOUNDED) { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }
+        }
+        const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
+        s->gathered = false;
+        run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
+        if (pst != OCN_SUCCESS) return pst;
+        // ---- x: real rows -> half spectrum; the other Periodic direction on the half spectrum
+        int st = s->xr2c.exec(a, b, stream);
+        if (st != OCN_SUCCESS) return st;
+        std::swap(a, b);
+        Nv = Nhalf;
+        Op pf[2], pb[2];
+        int np = 0;
+        for (int d = 1; d < 3; ++d)
+            if (topo[d] == OCN_PERIODIC) { pf[np] = Op{4, d}; pb[np] = Op{5, d}; ++np; }
+        run(pf, np);
+        if (pst != OCN_SUCCESS) return pst;
+        st = solve(nxh);
+        if (st != OCN_SUCCESS) return st;
+        for (int q = np - 1; q >= 0 && pst == OCN_SUCCESS; --q) run(pb + q, 1);
+        if (pst != OCN_SUCCESS) return pst;
+        st = s->xc2r.exec(a, b, stream);  // (scaled 1 / Nx)
+        if (st != OCN_SUCCESS) return st;
+        std::swap(a, b);
+        // ---- inverse cosine transforms on the pair view; the last scatter is folded into the copy into the pressure field
+        Nv = Npair;
+        const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
+        run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
+        if (pst != OCN_SUCCESS) return pst;
+        OCN_CHECK_HIP(hipGetLastError());
+        if (a != s->spec) std::swap(s->spec, s->spec2);
+        return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+    }
     for (int q = 0; q < no; ++q) {
         const int d = order[q];
         if (!s->fft_dct) fwd[nf++] = Op{6, d};
@@ -553,15 +654,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     s->gathered = false;
     run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
     if (pst != OCN_SUCCESS) return pst;
-    int st;
-    if (s->gtri) {  // batched Thomas sweep along z, then the zero-mean gauge on the (kx, ky) = (0, 0) column (stored position 0 in either order)
-        st = ocn::launch_tridiag_z(N[0], N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
-        if (st != OCN_SUCCESS) return st;
-        std::swap(a, b);
-        st = ocn::launch_remove_mean_mode((long long)N[0] * N[1], N[2], a, stream);
-    } else {
-        st = ocn::launch_spectral_solve(N[0], N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);  // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
-    }
+    int st = solve(N[0]);
     if (st != OCN_SUCCESS) return st;
     // the scatter pass of the last inverse cosine transform is folded into the read of copy_real_component!
     const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
@@ -570,6 +663,52 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     OCN_CHECK_HIP(hipGetLastError());
     if (a != s->spec) std::swap(s->spec, s->spec2);  // the result lives in `a`; keep the handle's roles consistent
     return ocn::launch_copy_real(g, s->spec, p, stream, 0, last_scatter);
+}
+
+// The real x plans of the packed general solver against known answers: the spectrum of one pseudo-random row against the DFT of its
+// definition, and the round trip of a block of rows (see Plan::destroy for why rocFFT's real plans are not trusted unverified).
+static int packed_plans_self_test(ocn_poisson *s)
+{
+    const ocn_grid *g = &s->grid;
+    const int N0 = g->Nx, nxh = N0 / 2 + 1;
+    const size_t rows = (size_t)g->Ny * g->Nz, n = (size_t)N0 * rows;
+    const size_t m = std::min(n, (size_t)1 << 18) / N0 * N0;  // whole rows
+    std::vector<double> in(m), back(m), spec(2 * (size_t)nxh);
+    unsigned long long x = 88172645463325252ULL;
+    for (size_t q = 0; q < m; ++q) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        in[q] = (double)(x >> 11) / 9007199254740992.0 - 0.5;
+    }
+    OCN_CHECK_HIP(hipMemset(s->spec, 0, n * sizeof(double)));
+    OCN_CHECK_HIP(hipMemcpy(s->spec, in.data(), m * sizeof(double), hipMemcpyHostToDevice));
+    int st = s->xr2c.exec(s->spec, s->spec2, nullptr);
+    if (st != OCN_SUCCESS) return st;
+    OCN_CHECK_HIP(hipDeviceSynchronize());
+    OCN_CHECK_HIP(hipMemcpy(spec.data(), s->spec2, spec.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const double two_pi = 6.283185307179586476925286766559;
+    double err = 0.0, scale = 0.0;
+    for (int k = 0; k < nxh; ++k) {
+        double re = 0.0, im = 0.0;
+        for (int q = 0; q < N0; ++q) {
+            const double ang = two_pi * (double)(((long long)k * q) % N0) / N0;
+            re += in[q] * std::cos(ang);
+            im -= in[q] * std::sin(ang);
+        }
+        err = std::max(err, std::max(std::fabs(re - spec[2 * k]), std::fabs(im - spec[2 * k + 1])));
+        scale = std::max(scale, std::max(std::fabs(re), std::fabs(im)));
+    }
+    st = s->xc2r.exec(s->spec2, s->spec, nullptr);
+    if (st != OCN_SUCCESS) return st;
+    OCN_CHECK_HIP(hipDeviceSynchronize());
+    OCN_CHECK_HIP(hipMemcpy(back.data(), s->spec, m * sizeof(double), hipMemcpyDeviceToHost));
+    double rt = 0.0;
+    for (size_t q = 0; q < m; ++q) rt = std::max(rt, std::fabs(back[q] - in[q]));
+    OCN_CHECK_HIP(hipMemset(s->spec, 0, n * 2 * sizeof(double)));
+    if (!(err <= 1e-11 * std::max(scale, 1.0) * N0 && rt <= 1e-12)) {
+        ocn::set_error("rocFFT real x plans of the packed general solver failed their self test (spectrum %.3e, round trip %.3e)", err, rt);
+        return OCN_ERR_ROCFFT;
+    }
+    return OCN_SUCCESS;
 }
 
 static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool force_c2c)
@@ -1012,7 +1151,9 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
             for (int d = s->gtri ? 1 : 2; d >= 0; --d)
                 if ((d == 0 ? g->tx : d == 1 ? g->ty : g->tz) == OCN_BOUNDED) first = d;
         // (the tridiagonal flavour's right-hand side carries Δzᶜ: _fourier_tridiagonal_source_term!, solve_for_pressure.jl:33-38)
-        st = ocn::launch_source_term(g, u, v, w, dt, s->gtri ? 2 : 1, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
+        // (packed: the source stays a REAL array -- modes 3 / 4 -- whose x-adjacent pairs the cosine transforms read as complex numbers)
+        const int mode = s->gpacked ? (s->gtri ? 4 : 3) : (s->gtri ? 2 : 1);
+        st = ocn::launch_source_term(g, u, v, w, dt, mode, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
         s->gathered = (st == OCN_SUCCESS) && first >= 0;
         s->source_set = (st == OCN_SUCCESS);
         return st;
@@ -1046,11 +1187,11 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
         double *d = nullptr;
         OCN_CHECK_HIP(hipMalloc((void **)&d, h.size() * sizeof(double)));
         OCN_CHECK_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ocn::as_stream(stream)));
-        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, d, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, d, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
         OCN_CHECK_HIP(hipStreamSynchronize(ocn::as_stream(stream)));
         OCN_CHECK_HIP(hipFree(d));
     } else {
-        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, dzc, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, dzc, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     }
     s->source_set = (st == OCN_SUCCESS);
     s->source_in_rhs = s->custom_xy;
