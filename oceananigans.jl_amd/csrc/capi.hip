@@ -56,8 +56,8 @@ static int validate_grid_impl(const ocn_grid *g, bool any_xy)
     }
     // a slab of a (Periodic, Bounded, *) grid: the direction-generic kernels read the exchanged x halos like periodic images and treat
     // the y walls locally (distributed_grids.jl:75-118)
-    const bool partitioned_x = g->tx == OCN_FULLY_CONNECTED || g->tx == OCN_RIGHT_CONNECTED || g->tx == OCN_LEFT_CONNECTED;
-    if (any_xy && g->ty == OCN_FLAT && partitioned_x) {
+    const bool part_x = g->tx == OCN_FULLY_CONNECTED || g->tx == OCN_RIGHT_CONNECTED || g->tx == OCN_LEFT_CONNECTED;
+    if (any_xy && g->ty == OCN_FLAT && part_x) {
         set_error("a partitioned x needs a Periodic or Bounded y");
         return OCN_ERR_UNSUPPORTED;
     }
@@ -75,6 +75,15 @@ static int validate_grid_impl(const ocn_grid *g, bool any_xy)
 int validate_grid(const ocn_grid *g) { return validate_grid_impl(g, false); }
 int validate_grid_any(const ocn_grid *g) { return validate_grid_impl(g, true); }
 // x and y Periodic (x possibly partitioned): the tiled / shared-layout kernels apply; otherwise the direction-generic ones
+// west / east conditions on a slab of a partitioned x: the slab that holds the wall takes them, the others drop them (the host checks the
+// GLOBAL topology: a slab between the walls cannot tell a Bounded from a Periodic x)
+static bool partitioned_x(const ocn_grid *g) { return g->tx == OCN_FULLY_CONNECTED || g->tx == OCN_RIGHT_CONNECTED || g->tx == OCN_LEFT_CONNECTED; }
+static bool side_has_wall(const ocn_grid *g, int q)
+{
+    if (q == 0) return x_wall_west(*g);
+    if (q == 1) return x_wall_east(*g);
+    return (q < 4 ? g->ty : g->tz) == OCN_BOUNDED;
+}
 static bool xy_periodic(const ocn_grid *g) { return (g->tx == OCN_PERIODIC || g->tx == OCN_FULLY_CONNECTED) && g->ty == OCN_PERIODIC; }
 
 // WENO5 reads 3 halo cells (nonhydrostatic_model.jl:183, 243-257 inflates the halo to >= 3)
@@ -909,7 +918,8 @@ int ocn_fill_halo_regions_bcs(const ocn_grid *grid, double *const *fields, const
                 const ocn_bc &c = *side[q];
                 OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "field %d: unknown boundary condition kind %d", f, c.kind);
                 if (c.kind == OCN_BC_DEFAULT) continue;
-                OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
+                if (q < 2 && partitioned_x(grid) && !(q == 0 ? x_wall_west(*grid) : x_wall_east(*grid))) continue;  // another slab's wall
+                OCN_REQUIRE(side_has_wall(grid, q), "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
                 OCN_REQUIRE((((locs[f] >> (q / 2)) & 1) != 0) == (c.kind == OCN_BC_OPEN),
                             "field %d: the wall-normal velocity takes an Open condition (its value on the boundary face), the other fields Flux / Value / Gradient", f);
                 sb.side[q][f] = ZBc{c.kind, c.value, c.coeff, c.values};
@@ -947,7 +957,8 @@ int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *con
                 const ocn_bc &c = *side[q];
                 OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "field %d: unknown boundary condition kind %d", f, c.kind);
                 if (c.kind != OCN_BC_FLUX) continue;
-                OCN_REQUIRE(T[q / 2] == OCN_BOUNDED, "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
+                if (q < 2 && partitioned_x(grid) && !(q == 0 ? x_wall_west(*grid) : x_wall_east(*grid))) continue;  // another slab's wall
+                OCN_REQUIRE(side_has_wall(grid, q), "field %d: a boundary condition on side %d needs a Bounded direction (topology %d)", f, q, T[q / 2]);
                 OCN_REQUIRE(!((locs[f] >> (q / 2)) & 1), "field %d: the wall-normal velocity keeps its impenetrable condition", f);
                 if (q < 4) {
                     sb.side[q][f] = ZBc{c.kind, c.value, c.coeff, c.values};

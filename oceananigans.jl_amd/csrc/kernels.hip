@@ -325,12 +325,13 @@ __global__ __launch_bounds__(256) void apply_flux_bcs_lateral_kernel(GridDev g, 
     int q[3];
     q[d1] = a;
     q[2] = k;
-    if (lo.kind == OCN_BC_FLUX) {
+    // (x: only the slab that holds the wall applies its flux -- a half-Bounded slab of a partitioned x has one)
+    if (lo.kind == OCN_BC_FLUX && (dir != 0 || g.xw)) {
         q[dir] = 1;
         const long long o = at(L, q[0], q[1], q[2]);
         G.f[f][o] += bc_condition(lo, a, k, N[d1], c.f[f][o]) * area / V;
     }
-    if (hi.kind == OCN_BC_FLUX) {
+    if (hi.kind == OCN_BC_FLUX && (dir != 0 || g.xe)) {
         q[dir] = N[dir];
         const long long o = at(L, q[0], q[1], q[2]);
         G.f[f][o] -= bc_condition(hi, a, k, N[d1], c.f[f][o]) * area / V;

@@ -139,13 +139,16 @@ class NonhydrostaticModel:
                 raise TypeError("boundary_conditions values must be FieldBoundaryConditions")
         # validate_boundary_condition_topology (boundary_condition.jl:128-136) + the impenetrable wall-normal component
         normal = {"u": ("west", "east"), "v": ("south", "north"), "w": ("bottom", "top")}
+        # (a rank-local grid answers with the topology of the GLOBAL grid: the slabs of a Bounded x are RightConnected / FullyConnected /
+        #  LeftConnected, every rank is given the same conditions and the slab that holds the wall applies them)
+        gtopo = getattr(grid, "global_topology", None) or grid.topology
         for name, b in bcs.items():
             for d, pair in enumerate((("west", "east"), ("south", "north"), ("bottom", "top"))):
                 for side in pair:
                     if b.sides[side] is None:
                         continue
-                    if grid.topology[d] != "Bounded":
-                        raise ValueError(f"Cannot set {side} boundary condition of {name} in a `{grid.topology[d]}` direction!")
+                    if gtopo[d] != "Bounded":
+                        raise ValueError(f"Cannot set {side} boundary condition of {name} in a `{gtopo[d]}` direction!")
                     is_open = b.sides[side].kind == _lib.BC_OPEN
                     if side in normal.get(name, ()) and not is_open:
                         raise NotImplementedError(f"{name} keeps its impenetrable {side} boundary condition, or takes OpenBoundaryCondition(value) "

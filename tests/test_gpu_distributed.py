@@ -445,6 +445,63 @@ def test_distributed_ocean_mixing_physics_matches_single_rank(ocn, R, closure, s
             assert np.abs(a - b[sl]).max() <= tol * scale, f"rank {r} field {name}: {np.abs(a - b[sl]).max()} vs {tol * scale}"
 
 
+@pytest.mark.parametrize("R", [2, 4])
+def test_conditions_on_the_west_and_east_walls_of_a_partitioned_box(ocn, R):
+    """Every rank of a (Bounded, Bounded, Bounded) run is given the same boundary conditions; the slab that holds a wall applies the ones
+    on it (a heated west wall as a Value condition, a flux through the east wall, a gradient on the south wall, a bottom flux), the slabs
+    between drop them: two RK3 steps with a constant diffusivity against the single-rank model."""
+    N = (32, 16, 12)
+    B = "Bounded"
+    ext = dict(x=(0, 2.0), y=(0, 1.0), z=(-1.0, 0.0), topology=(B, B, B), halo=(3, 3, 3))
+    rng = np.random.default_rng(5)
+    init = {"u": 1e-2 * rng.uniform(-1, 1, (N[0] + 1, N[1], N[2])), "v": 1e-2 * rng.uniform(-1, 1, (N[0], N[1] + 1, N[2])),
+            "w": 1e-2 * rng.uniform(-1, 1, (N[0], N[1], N[2] + 1)), "T": 1 + 1e-2 * rng.uniform(-1, 1, N)}
+
+    def build(grid):
+        bcs = {"T": ocn.FieldBoundaryConditions(west=ocn.ValueBoundaryCondition(2.0), east=ocn.FluxBoundaryCondition(3e-3),
+                                                south=ocn.GradientBoundaryCondition(0.5), bottom=ocn.FluxBoundaryCondition(-1e-3)),
+               "v": ocn.FieldBoundaryConditions(west=ocn.ValueBoundaryCondition(0.0), east=ocn.ValueBoundaryCondition(0.0))}  # no-slip side walls
+        return ocn.NonhydrostaticModel(grid, advection=ocn.WENO(), tracers=("T",), closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-2),
+                                       buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4), constant_salinity=35.0),
+                                       boundary_conditions=bcs)
+
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    sm = build(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext))
+    ocn.set(sm, **init)
+    for _ in range(2):
+        ocn.time_step(sm, 5e-3)
+    ocn.sync_device()
+    ref = [f.interior() for f in sm.prognostic_fields()]
+    nx = N[0] // R
+
+    def xs(name, r):
+        return slice(r * nx, (r + 1) * nx + (1 if (name == "u" and r == R - 1) else 0))
+
+    def rank_main(r, fabric):
+        arch = ocn.Distributed(ocn.GPU(), partition=ocn.Partition(R), fabric=fabric)
+        m = build(ocn.RectilinearGrid(arch, size=N, **ext))
+        ocn.set(m, **{k: v[xs(k, r)] for k, v in init.items()})
+        for _ in range(2):
+            ocn.time_step(m, 5e-3)
+        ocn.sync_device()
+        return [f.interior() for f in m.prognostic_fields()]
+
+    vscale = max(np.abs(a).max() for a in ref[:3])
+    for r, fields in enumerate(_run_ranks(R, rank_main)):
+        for a, b, name in zip(fields, ref, ("u", "v", "w", "T")):
+            scale = vscale if name in "uvw" else np.abs(b).max()
+            assert np.abs(a - b[xs(name, r)]).max() <= 1e-11 * scale, f"rank {r} field {name}"
+    # the conditions did something: the first column next to the heated wall differs from a run without them
+    plain = ocn.NonhydrostaticModel(ocn.RectilinearGrid(ocn.GPU(), size=N, **ext), advection=ocn.WENO(), tracers=("T",),
+                                    closure=ocn.ScalarDiffusivity(ν=1e-2, κ=2e-2),
+                                    buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4), constant_salinity=35.0))
+    ocn.set(plain, **init)
+    for _ in range(2):
+        ocn.time_step(plain, 5e-3)
+    ocn.sync_device()
+    assert np.abs(plain.tracers[0].interior()[0] - ref[3][0]).max() > 1e-4
+
+
 @pytest.mark.parametrize("topo", ["PPP", "PPB"])
 def test_distributed_large_slabs_match_single_rank(ocn, topo):
     """The slab pipelines at production-like extents (256 x 256 x 128 on R = 4 ranks: 64-wide slabs as at 512^3 / 8, column
