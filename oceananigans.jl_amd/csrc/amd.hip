@@ -24,14 +24,16 @@ struct Amd {
     const double *u, *v, *w, *c;  // pointers at the cell (i, j, k)
     long long s2, s3;             // centre fields
     long long u2, u3, v2, v3, w2, w3;
+    int sa;                       // stride of a step in x: 1, or 0 along a Flat x (GEN only; a Flat y has zero j strides): differences along a
+                                  // Flat direction vanish and its interpolations return the value itself (flat grids: Δ = 1)
     long long oc;                 // offset of the cell in a centre field
     double dx, dy, Fx, Fy;
     Metrics M;
     int k;  // 1-based k of the cell, for the z metrics
-    __device__ __forceinline__ double U(int a, int b, int d) const { return GEN ? u[a + b * u2 + d * u3] : u[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double V(int a, int b, int d) const { return GEN ? v[a + b * v2 + d * v3] : v[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double W(int a, int b, int d) const { return GEN ? w[a + b * w2 + d * w3] : w[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double C(int a, int b, int d) const { return c[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double U(int a, int b, int d) const { return GEN ? u[a * sa + b * u2 + d * u3] : u[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double V(int a, int b, int d) const { return GEN ? v[a * sa + b * v2 + d * v3] : v[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double W(int a, int b, int d) const { return GEN ? w[a * sa + b * w2 + d * w3] : w[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double C(int a, int b, int d) const { return c[a * (GEN ? sa : 1) + b * s2 + d * s3]; }
     __device__ __forceinline__ double Fz(int d) const { return 2 * M.dzC(k + d); }
 };
 
@@ -46,10 +48,13 @@ __device__ __forceinline__ Amd<GEN> make_amd(const GridDev &g, const double *u, 
     Amd<GEN> A;
     A.oc = o;
     A.s2 = L.s2; A.s3 = L.s3;
+    A.sa = 1;
     if (GEN) {
         const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
         A.u = u + ocn::at(Lu, i, j, k); A.v = v + ocn::at(Lv, i, j, k); A.w = w + ocn::at(Lw, i, j, k);
         A.u2 = Lu.s2; A.u3 = Lu.s3; A.v2 = Lv.s2; A.v3 = Lv.s3; A.w2 = Lw.s2; A.w3 = Lw.s3;
+        if (g.tx == OCN_FLAT) A.sa = 0;
+        if (g.ty == OCN_FLAT) A.u2 = A.v2 = A.w2 = A.s2 = 0;
     } else {
         A.u = u + o; A.v = v + o; A.w = w + o;
         A.u2 = A.v2 = A.w2 = L.s2; A.u3 = A.v3 = A.w3 = L.s3;
@@ -247,8 +252,9 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
             if (n >= tr.n) break;
             const double *pc = tr.c[n] + o;
             const long long s2 = A.s2, s3 = A.s3;
+            const int sa = GEN ? A.sa : 1;
             const double c0 = tc0[n], cT = pc[s3];
-            const double gx0 = AMD_G(Fx, c0 - pc[-1], qdx), gx1 = AMD_G(Fx, pc[1] - c0, qdx);               // norm_∂x_c at i, i+1
+            const double gx0 = AMD_G(Fx, c0 - pc[-sa], qdx), gx1 = AMD_G(Fx, pc[sa] - c0, qdx);             // norm_∂x_c at i, i+1
             const double gy0 = AMD_G(Fy, c0 - pc[-s2], qdy), gy1 = AMD_G(Fy, pc[s2] - c0, qdy);             // norm_∂y_c at j, j+1
             const double gz0 = tgz[n], gz1 = AMD_G(Fz[1], cT - c0, qdzf1);                                   // norm_∂z_c at k, k+1
             tc0[n] = cT; tgz[n] = gz1;
@@ -307,7 +313,8 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
     const long long tiles = (long long)((wx + block.x - 1) / block.x) * ((g.Ny + block.y - 1) / block.y);
     while (KZ > 1 && tiles * ((g.Nz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;  // narrow ranges: keep the chip full
     const dim3 nb = ocn::range_grid(block, wx, g.Ny, (g.Nz + KZ - 1) / KZ);
-    if (ocn::x_wall_west(*grid) || ocn::x_wall_east(*grid) || grid->ty == OCN_BOUNDED)  // per-field parent layouts
+    if (ocn::x_wall_west(*grid) || ocn::x_wall_east(*grid) || grid->ty == OCN_BOUNDED || grid->tx == OCN_FLAT ||
+        grid->ty == OCN_FLAT)  // per-field parent layouts; zero strides along a Flat direction
         hipLaunchKernelGGL(amd_fused_kernel<true>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     else
         hipLaunchKernelGGL(amd_fused_kernel<false>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);

@@ -519,9 +519,9 @@ static int validate_amd(const ocn_grid *grid)
 {
     int st = validate_grid_any(grid);  // Bounded x / y: the kernel takes per-field parent layouts
     if (st != OCN_SUCCESS) return st;
-    OCN_REQUIRE(grid->tx != OCN_FLAT && grid->ty != OCN_FLAT, "AnisotropicMinimumDissipation needs non-Flat x and y in this backend");
     OCN_REQUIRE(grid->tz != OCN_FLAT, "AnisotropicMinimumDissipation needs a non-Flat z");
-    OCN_REQUIRE(grid->Hx >= 1 && grid->Hy >= 1 && grid->Hz >= 1, "AnisotropicMinimumDissipation needs halo >= 1");
+    OCN_REQUIRE((grid->tx == OCN_FLAT || grid->Hx >= 1) && (grid->ty == OCN_FLAT || grid->Hy >= 1) && grid->Hz >= 1,
+                "AnisotropicMinimumDissipation needs halo >= 1");
     return OCN_SUCCESS;
 }
 

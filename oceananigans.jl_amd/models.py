@@ -202,8 +202,6 @@ class NonhydrostaticModel:
         self.fuse_stage_boundaries = xy_periodic and ((not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
                                                                                    and os.environ.get("OCN_FUSE_GENERAL", "1") != "0"))
         if not xy_periodic:
-            if isinstance(closure, AnisotropicMinimumDissipation) and Flat in grid.topology[:2]:
-                raise NotImplementedError("AnisotropicMinimumDissipation needs non-Flat x and y in this backend")
             if hasattr(grid.architecture, "partition") and not (
                     grid.topology[0] in ("Periodic", "FullyConnected", "RightConnected", "LeftConnected", "Bounded")
                     and grid.topology[1] == "Bounded" and grid.topology[2] == "Bounded"):

@@ -835,10 +835,14 @@ typedef struct {
     double Fx, Fy; /* Δᶠx, Δᶠy */
 } amd_ctx;
 typedef double (*amd_fn)(const amd_ctx *, int, int, int);
-#define AU(i, j, k) A->u[AT(A->Lu, i, j, k)]
-#define AV(i, j, k) A->v[AT(A->Lv, i, j, k)]
-#define AW(i, j, k) A->w[AT(A->Lw, i, j, k)]
-#define AC(i, j, k) A->c[AT(A->Lc, i, j, k)]
+/* a Flat direction: its derivatives vanish and its interpolations return the value itself (derivative_operators.jl, interpolation_operators.jl
+ * :103-110 on Flat grids; Δ = 1) -- every index along it is the one cell there is */
+#define AFI(i) (A->g->tx == OCN_FLAT ? 1 : (i))
+#define AFJ(j) (A->g->ty == OCN_FLAT ? 1 : (j))
+#define AU(i, j, k) A->u[AT(A->Lu, AFI(i), AFJ(j), k)]
+#define AV(i, j, k) A->v[AT(A->Lv, AFI(i), AFJ(j), k)]
+#define AW(i, j, k) A->w[AT(A->Lw, AFI(i), AFJ(j), k)]
+#define AC(i, j, k) A->c[AT(A->Lc, AFI(i), AFJ(j), k)]
 static inline double amd_Fz(const amd_ctx *A, int k) { return 2 * dzc_at(A->g, k); }
 static double n_dx_u(const amd_ctx *A, int i, int j, int k) { return (AU(i + 1, j, k) - AU(i, j, k)) / A->g->dx; }
 static double n_dy_v(const amd_ctx *A, int i, int j, int k) { return (AV(i, j + 1, k) - AV(i, j, k)) / A->g->dy; }
@@ -947,6 +951,8 @@ void ocn_oracle_amd_diffusivity(const ocn_grid *g, double Ck, const double *u, c
 #undef AV
 #undef AW
 #undef AC
+#undef AFI
+#undef AFJ
 
 /* =====================================================================================
  * Time-stepper kernels

@@ -682,11 +682,13 @@ def test_stratified_channel_with_separate_hydrostatic_pressure_matches_oracle(or
     np.testing.assert_allclose(og.interior(from_dev(pm.pHY)), og.interior(om.pHY), rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((9, 12, 8), "BPP"), ((34, 17, 20), "BBB")])
+@pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((9, 12, 8), "BPP"), ((34, 17, 20), "BBB"), ((16, 1, 10), "PFB"),
+                                       ((1, 10, 9), "FBB"), ((12, 1, 9), "BFB")])
 def test_amd_diffusivities_on_closed_grids_bitwise(oracle, ocn, size, topo):
     """_compute_AMD_viscosity! / _compute_AMD_diffusivity! (anisotropic_minimum_dissipation.jl:125-169) on grids with a Bounded x / y: every
     staggered field has its own parent shape (the z-marching register-carrying kernel with per-field strides) -- νₑ, κₑ and the variable-ν /
-    variable-κ flux divergences bit for bit against the oracle"""
+    variable-κ flux divergences bit for bit against the oracle.  x-z and y-z slices (a Flat y / x): the derivatives along the Flat direction
+    vanish and its interpolations are the identity (zero strides in the kernel, the one cell there is in the oracle; Δ = 1 there)."""
     O = oracle
     rng = np.random.default_rng(34)
     og, pg = _pair(O, ocn, size, topo)
@@ -722,11 +724,12 @@ def test_amd_diffusivities_on_closed_grids_bitwise(oracle, ocn, size, topo):
         np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} {name}")
 
 
-def test_les_channel_with_amd_matches_oracle(oracle, ocn):
-    """A (Periodic, Bounded, Bounded) channel with AnisotropicMinimumDissipation, a buoyancy tracer with its pHY' and an f-plane: 3 RK3
-    steps against the oracle's model (the eddy diffusivities are ratios of small numbers: 1e-10 on the fields)"""
+@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PBB"), ((32, 1, 16), "PFB"), ((24, 1, 12), "BFB")])
+def test_les_channel_with_amd_matches_oracle(oracle, ocn, size, topo):
+    """A (Periodic, Bounded, Bounded) channel -- and x-z slices with a Flat y -- with AnisotropicMinimumDissipation, a buoyancy tracer with
+    its pHY' and an f-plane: 3 RK3 steps against the oracle's model (the eddy diffusivities are ratios of small numbers: 1e-10 on the fields)"""
     O = oracle
-    og, pg = _pair(O, ocn, (16, 12, 10), "PBB")
+    og, pg = _pair(O, ocn, size, topo)
     rng = np.random.default_rng(35)
     ocn.set_math_mode(ocn.MATH_STRICT)
     om = O.NonhydrostaticModel(og, tracers=("b",), coriolis_f=0.3, closure=("AMD",), buoyancy="BuoyancyTracer")
