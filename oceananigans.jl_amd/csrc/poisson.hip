@@ -172,6 +172,10 @@ struct ocn_poisson {
     // remaining Periodic direction, the solve and the way back run.  Same arithmetic per line as the complex path.
     bool gpacked = false;
     Plan xr2c, xc2r;
+    // ... and the closed box / the y-z wall slices (x AND y Bounded, z Bounded or Flat, even Nx and Ny): nothing ever becomes complex -- the
+    // transforms along y / z on x-adjacent pairs as above, the one along x on pairs of ROWS (dct_rowpair_kernel), a real division by the
+    // eigenvalues
+    bool gallreal = false;
 };
 
 static void free_all(ocn_poisson *s)
@@ -294,6 +298,54 @@ __global__ __launch_bounds__(256) void dct_shuffle_kernel(int Nx, int Ny, int Nz
     }
 }
 
+// The same four passes for the lines ALONG x of a REAL array (Nx, Ny, Nz), Ny even: the complex line (i, jp, k), jp < Ny / 2, is the pair of real
+// rows j = 2 jp (real part) and 2 jp + 1 (imaginary part) -- a cosine transform maps reals to reals, and the complex transform of a line is the
+// transform of its real and of its imaginary part, so two rows ride on one complex FFT.  Modes 0 and 2 read the real array (split: the two
+// parts Nx doubles apart) and write an interleaved complex array (Nx, Ny / 2, Nz) for the line FFTs; modes 1 and 3 read that and write the
+// real array.  Natural wavenumber order (rocFFT lines).
+__global__ __launch_bounds__(256) void dct_rowpair_kernel(int Nx, int Nyp, int Nz, int mode, const double *__restrict__ in, double *__restrict__ out,
+                                                          const double2 *__restrict__ w)
+{
+    const long long n = (long long)Nx * Nyp * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int q = (int)(t % Nx), jp = (int)((t / Nx) % Nyp), k = (int)(t / ((long long)Nx * Nyp));
+    const int N = Nx, half = (N + 1) / 2;
+    const long long row = (long long)Nx * (2 * jp + (long long)2 * Nyp * k);  // the real row j = 2 jp of plane k; the odd row follows at + Nx
+    const double2 *cin = reinterpret_cast<const double2 *>(in) + (t - q);      // the interleaved complex line
+    double2 *cout = reinterpret_cast<double2 *>(out);
+    auto split_in = [&](int m) { return make_double2(in[row + m], in[row + Nx + m]); };
+    auto split_out = [&](double2 v) { out[row + q] = v.x; out[row + Nx + q] = v.y; };
+    if (mode == 0) {         // v[q], real rows -> complex
+        cout[t] = q < half ? split_in(2 * q) : split_in(2 * (N - 1 - q) + 1);
+    } else if (mode == 3) {  // x[q], complex -> real rows
+        split_out((q & 1) ? cin[N - 1 - (q - 1) / 2] : cin[q / 2]);
+    } else if (mode == 1) {  // post-twiddle, complex -> real rows
+        const double2 a = cin[q], b = cin[(N - q) % N], wk = w[q];
+        const double sr = a.x + b.x, si = a.y - b.y, dr = a.x - b.x, di = a.y + b.y;
+        split_out(make_double2(wk.x * sr - wk.y * si, wk.x * di + wk.y * dr));
+    } else {                 // pre-twiddle, real rows -> complex
+        const double2 a = split_in(q);
+        const double2 b = q == 0 ? make_double2(0.0, 0.0) : split_in(N - q);
+        const double2 wk = w[q];
+        const double zr = a.x + b.y, zi = a.y - b.x;
+        cout[t] = make_double2(0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr));
+    }
+}
+
+// -b / (λx + λy + λz [- m]) of a REAL spectrum (every direction a cosine transform), mode (1, 1, 1) := 0 iff m === 0
+__global__ __launch_bounds__(256) void spectral_solve_real_kernel(int Nx, int Ny, int Nz, const double *__restrict__ lx, const double *__restrict__ ly,
+                                                                  const double *__restrict__ lz, double *__restrict__ b, double m, int shifted)
+{
+    const long long n = (long long)Nx * Ny * Nz, t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = (int)(t % Nx), j = (int)((t / Nx) % Ny), k = (int)(t / ((long long)Nx * Ny));
+    double lam = (lx[i] + ly[j]) + lz[k];
+    if (shifted) lam = lam - m;
+    double val = -b[t] / lam;
+    if (!shifted && t == 0) val = 0.0;
+    b[t] = val;
+}
+
 // A twiddle pass along `dt` (mode mt = 1 forward post-twiddle, 2 inverse pre-twiddle) and a pure permutation along ANOTHER dimension
 // `dp` (mode mp = 0 gather, 3 scatter) in ONE pass: the permutation only relabels whole lines of the twiddle direction, so
 //   forward:  out = gather_dp(twiddle_dt(in)),   inverse:  out = pretwiddle_dt(scatter_dp(in))
@@ -410,6 +462,8 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
             const char *ep = std::getenv("OCN_POISSON_PACKED");
             s->gpacked = s->fft_dct && !g_no_packed && topo[0] == OCN_PERIODIC && N[0] % 2 == 0 && N[0] >= 4 &&
                          (topo[1] == OCN_BOUNDED || topo[2] == OCN_BOUNDED) && !(ep && ep[0] == '0');
+            s->gallreal = s->fft_dct && !gtri && topo[0] == OCN_BOUNDED && topo[1] == OCN_BOUNDED && (topo[2] == OCN_BOUNDED || topo[2] == OCN_FLAT) &&
+                          N[0] % 2 == 0 && N[1] % 2 == 0 && !(ep && ep[0] == '0');
         }
         if (s->fft_dct && st == OCN_SUCCESS) {
             ensure_rocfft();
@@ -432,6 +486,10 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
                     *lam[d] = nullptr;
                     st = upload(lp, lam[d]);
                     if (st != OCN_SUCCESS) break;
+                } else if (s->gallreal) {
+                    // x lines of row pairs (Nx, Ny / 2, Nz); y / z lines of x-adjacent pairs (Nx / 2, Ny, Nz)
+                    const int Nd[3] = {d == 0 ? N[0] : N[0] / 2, d == 0 ? N[1] / 2 : N[1], N[2]};
+                    st = make_line_plans(s, d, Nd);
                 } else if (s->gpacked && d == 0) {
                     // x: real-to-complex / complex-to-real lines (below)
                 } else if (s->gpacked) {
@@ -596,6 +654,43 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     };
     Op fwd[9], bwd[9];
     int nf = 0, nb = 0;
+    if (s->gallreal) {
+        // ---- y, z on the pair view (the source's rows are already gathered along y when compute_source_term stored it that way)
+        Nv = Npair;
+        for (int d = 1; d < 3; ++d)
+            if (topo[d] == OCN_BOUNDED) { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }
+        for (int d = 2; d >= 1; --d)
+            if (topo[d] == OCN_BOUNDED) { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }
+        const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
+        s->gathered = false;
+        run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
+        if (pst != OCN_SUCCESS) return pst;
+        // ---- x on pairs of rows: gather, line FFT, twiddle back to the real array; the division; and back
+        const int Nrow[3] = {N[0], N[1] / 2, N[2]};
+        const long long nr = (long long)Nrow[0] * Nrow[1] * Nrow[2], nreal = (long long)N[0] * N[1] * N[2];
+        auto rowpair = [&](int mode) {
+            hipLaunchKernelGGL(dct_rowpair_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, stream, Nrow[0], Nrow[1], Nrow[2], mode, a, b,
+                               reinterpret_cast<const double2 *>(s->gtw[0]));
+            std::swap(a, b);
+        };
+        rowpair(0);
+        pst = exec_line_plan(s, 0, 0, a, Nrow, stream);
+        if (pst != OCN_SUCCESS) return pst;
+        rowpair(1);
+        hipLaunchKernelGGL(spectral_solve_real_kernel, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], s->lx, s->ly,
+                           s->lz, a, s->shift, s->shifted ? 1 : 0);
+        rowpair(2);
+        pst = exec_line_plan(s, 0, 1, a, Nrow, stream);
+        if (pst != OCN_SUCCESS) return pst;
+        rowpair(3);
+        // ---- z, y back on the pair view; the last scatter is folded into the copy into the pressure field
+        const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
+        run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
+        if (pst != OCN_SUCCESS) return pst;
+        OCN_CHECK_HIP(hipGetLastError());
+        if (a != s->spec) std::swap(s->spec, s->spec2);
+        return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+    }
     if (s->gpacked) {
         // ---- cosine transforms along the Bounded y / z on the real array viewed as Nx / 2 complex columns
         Nv = Npair;
@@ -1148,11 +1243,11 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
         // folded into this store
         int first = -1;
         if (s->fft_dct && general_fuse_shuffles())
-            for (int d = s->gtri ? 1 : 2; d >= 0; --d)
+            for (int d = s->gtri ? 1 : 2; d >= (s->gallreal ? 1 : 0); --d)  // (all-real boxes transform y first: their x lines pair rows)
                 if ((d == 0 ? g->tx : d == 1 ? g->ty : g->tz) == OCN_BOUNDED) first = d;
         // (the tridiagonal flavour's right-hand side carries Δzᶜ: _fourier_tridiagonal_source_term!, solve_for_pressure.jl:33-38)
         // (packed: the source stays a REAL array -- modes 3 / 4 -- whose x-adjacent pairs the cosine transforms read as complex numbers)
-        const int mode = s->gpacked ? (s->gtri ? 4 : 3) : (s->gtri ? 2 : 1);
+        const int mode = (s->gpacked || s->gallreal) ? (s->gtri ? 4 : 3) : (s->gtri ? 2 : 1);
         st = ocn::launch_source_term(g, u, v, w, dt, mode, s->spec, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream), first);
         s->gathered = (st == OCN_SUCCESS) && first >= 0;
         s->source_set = (st == OCN_SUCCESS);
@@ -1187,11 +1282,11 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
         double *d = nullptr;
         OCN_CHECK_HIP(hipMalloc((void **)&d, h.size() * sizeof(double)));
         OCN_CHECK_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ocn::as_stream(stream)));
-        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, d, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, d, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked && !s->gallreal, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
         OCN_CHECK_HIP(hipStreamSynchronize(ocn::as_stream(stream)));
         OCN_CHECK_HIP(hipFree(d));
     } else {
-        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, dzc, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
+        st = ocn::launch_set_source(g->Nx, g->Ny, g->Nz, R, dzc, g->Hz, s->c2c ? s->spec : s->rhs, s->c2c && !s->gpacked && !s->gallreal, g->Nx, (long long)g->Nx * g->Ny, ocn::as_stream(stream));
     }
     s->source_set = (st == OCN_SUCCESS);
     s->source_in_rhs = s->custom_xy;
