@@ -43,6 +43,6 @@ for topo in ("PPP", "PPB", "PBB", "BBB"):
     t1e.record(); torch.cuda.synchronize()
     tend_ms = t0e.elapsed_time(t1e) / 10
     print(f"{topo} N={N}: momentum tendencies {tend_ms:.3f} ms per launch (OCN_GENERAL_TILED={os.environ.get('OCN_GENERAL_TILED', '1')})", flush=True)
-    print(f"{topo} N={N}: {ms:.2f} ms/step ({N**3/ms/1e6:.0f} Mcell-updates/s), solve_for_pressure {e0.elapsed_time(e1)/5:.2f} ms, fused={m.fuse_stage_boundaries}", flush=True)
+    print(f"{topo} N={N}: {ms:.2f} ms/step ({N**3/ms/1e6:.2f} Gcell-updates/s), solve_for_pressure {e0.elapsed_time(e1)/5:.2f} ms, fused={m.fuse_stage_boundaries}", flush=True)
     del m, g
     torch.cuda.empty_cache()
