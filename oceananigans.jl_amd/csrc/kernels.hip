@@ -1526,10 +1526,22 @@ int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const 
 
 // K14 solve_batched_tridiagonal_system_z! (batched_tridiagonal_solver.jl:209-235).  One thread per (i,j) column,
 // i across lanes so every k-plane access is coalesced; serial Thomas sweep in k.
+// T: double2 (a complex spectrum: the real and the imaginary part are two independent solves with the same real coefficients) or double (the
+// all-real spectrum of a closed box, csrc/poisson.hip).
+__device__ __forceinline__ double2 tz_zero(double2) { return make_double2(0.0, 0.0); }
+__device__ __forceinline__ double tz_zero(double) { return 0.0; }
+__device__ __forceinline__ double2 tz_div(double2 v, double s) { return make_double2(v.x / s, v.y / s); }
+__device__ __forceinline__ double tz_div(double v, double s) { return v / s; }
+// (v - s * w) / d   and   v - s * w, per component in the reference's order
+__device__ __forceinline__ double2 tz_star(double2 v, double s, double2 w, double d) { return make_double2((v.x - s * w.x) / d, (v.y - s * w.y) / d); }
+__device__ __forceinline__ double tz_star(double v, double s, double w, double d) { return (v - s * w) / d; }
+__device__ __forceinline__ double2 tz_back(double2 v, double s, double2 w) { return make_double2(v.x - s * w.x, v.y - s * w.y); }
+__device__ __forceinline__ double tz_back(double v, double s, double w) { return v - s * w; }
+template <class T>
 __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long sj, long long s3, int Nz,
                                                        const double *__restrict__ a, const double *__restrict__ b,
-                                                       const double *__restrict__ c, const double2 *__restrict__ f,
-                                                       double *__restrict__ t, double2 *__restrict__ phi)
+                                                       const double *__restrict__ c, const T *__restrict__ f,
+                                                       double *__restrict__ t, T *__restrict__ phi)
 {
     // column (i, j) at i + sj j, planes s3 apart (see main_diagonal_kernel for the two layouts in use)
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1541,26 +1553,24 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
     // distributed run has too few columns to hide it with occupancy).
     constexpr int PF = 8;
     double beta = b[o];
-    double2 prev = f[o];
-    prev.x = prev.x / beta;
-    prev.y = prev.y / beta;
+    T prev = tz_div(f[o], beta);
     phi[o] = prev;
     double bq[PF];
-    double2 fq[PF];
+    T fq[PF];
 #pragma unroll
     for (int m = 0; m < PF; ++m) {
         const int k = 1 + m;
         bq[m] = (k < Nz) ? b[o + k * s3] : 1.0;
-        fq[m] = (k < Nz) ? f[o + k * s3] : make_double2(0.0, 0.0);
+        fq[m] = (k < Nz) ? f[o + k * s3] : tz_zero(T{});
     }
     for (int k0 = 1; k0 < Nz; k0 += PF) {
         double bn[PF];
-        double2 fn[PF];
+        T fn[PF];
 #pragma unroll
         for (int m = 0; m < PF; ++m) {  // next block's operands
             const int k = k0 + PF + m;
             bn[m] = (k < Nz) ? b[o + k * s3] : 1.0;
-            fn[m] = (k < Nz) ? f[o + k * s3] : make_double2(0.0, 0.0);
+            fn[m] = (k < Nz) ? f[o + k * s3] : tz_zero(T{});
         }
 #pragma unroll
         for (int m = 0; m < PF; ++m) {
@@ -1571,10 +1581,7 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
                 t[o + k * s3] = tk;
                 beta = bk - ak * tk;
                 const bool dd = fabs(beta) > tiny;
-                const double2 fk = fq[m];
-                double2 star;
-                star.x = (fk.x - ak * prev.x) / beta;
-                star.y = (fk.y - ak * prev.y) / beta;
+                const T star = tz_star(fq[m], ak, prev, beta);
                 if (dd) {
                     phi[o + k * s3] = star;
                     prev = star;
@@ -1591,29 +1598,27 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
     }
     // back substitution, same prefetch distance (t and phi were written by this thread: visible to it in program order)
     double tq[PF];
-    double2 pq[PF];
+    T pq[PF];
 #pragma unroll
     for (int m = 0; m < PF; ++m) {
         const int k = Nz - 2 - m;
         tq[m] = (k >= 0) ? t[o + (k + 1) * s3] : 0.0;
-        pq[m] = (k >= 0) ? phi[o + k * s3] : make_double2(0.0, 0.0);
+        pq[m] = (k >= 0) ? phi[o + k * s3] : tz_zero(T{});
     }
     for (int k0 = Nz - 2; k0 >= 0; k0 -= PF) {
         double tn[PF];
-        double2 pn[PF];
+        T pn[PF];
 #pragma unroll
         for (int m = 0; m < PF; ++m) {
             const int k = k0 - PF - m;
             tn[m] = (k >= 0) ? t[o + (k + 1) * s3] : 0.0;
-            pn[m] = (k >= 0) ? phi[o + k * s3] : make_double2(0.0, 0.0);
+            pn[m] = (k >= 0) ? phi[o + k * s3] : tz_zero(T{});
         }
 #pragma unroll
         for (int m = 0; m < PF; ++m) {
             const int k = k0 - m;
             if (k >= 0) {
-                double2 cur = pq[m];
-                cur.x -= tq[m] * prev.x;
-                cur.y -= tq[m] * prev.y;
+                const T cur = tz_back(pq[m], tq[m], prev);
                 phi[o + k * s3] = cur;
                 prev = cur;
             }
@@ -1629,8 +1634,18 @@ int launch_tridiag_z_strided(int ni, int nj, long long sj, long long sk, int Nz,
                              const double *f, double *t, double *phi, hipStream_t stream)
 {
     const long long n = (long long)ni * nj;
-    hipLaunchKernelGGL(tridiag_z_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ni, nj, sj, sk, Nz, a, b, c,
+    hipLaunchKernelGGL(tridiag_z_kernel<double2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ni, nj, sj, sk, Nz, a, b, c,
                        reinterpret_cast<const double2 *>(f), t, reinterpret_cast<double2 *>(phi));
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+// the same sweep over a REAL right-hand side (Nx, Ny, Nz), and the zero-mean gauge on its (0, 0) column
+int launch_tridiag_z_real(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t, double *phi,
+                          hipStream_t stream)
+{
+    const long long n = (long long)Nx * Ny;
+    hipLaunchKernelGGL(tridiag_z_kernel<double>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, Nx, Ny, (long long)Nx, (long long)Nx * Ny, Nz, a,
+                       b, c, f, t, phi);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -1666,6 +1681,26 @@ __global__ void remove_mean_mode_kernel(long long s3, int Nz, double2 *__restric
         phi[k * s3].x -= mre;
         phi[k * s3].y -= mim;
     }
+}
+__global__ void remove_mean_mode_real_kernel(long long s3, int Nz, double *__restrict__ phi)
+{
+    __shared__ double sre[256];
+    double re = 0;
+    for (int k = threadIdx.x; k < Nz; k += blockDim.x) re += phi[k * s3];
+    sre[threadIdx.x] = re;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sre[threadIdx.x] += sre[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double mre = sre[0] / Nz;
+    for (int k = threadIdx.x; k < Nz; k += blockDim.x) phi[k * s3] -= mre;
+}
+int launch_remove_mean_mode_real(long long s3, int Nz, double *phi, hipStream_t stream)
+{
+    hipLaunchKernelGGL(remove_mean_mode_real_kernel, dim3(1), dim3(256), 0, stream, s3, Nz, phi);
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
 }
 int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream)
 {

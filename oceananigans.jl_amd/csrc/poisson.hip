@@ -174,7 +174,7 @@ struct ocn_poisson {
     Plan xr2c, xc2r;
     // ... and the closed box / the y-z wall slices (x AND y Bounded, z Bounded or Flat, even Nx and Ny): nothing ever becomes complex -- the
     // transforms along y / z on x-adjacent pairs as above, the one along x on pairs of ROWS (dct_rowpair_kernel), a real division by the
-    // eigenvalues
+    // eigenvalues or (stretched z) the Thomas sweep on reals
     bool gallreal = false;
 };
 
@@ -462,7 +462,7 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
             const char *ep = std::getenv("OCN_POISSON_PACKED");
             s->gpacked = s->fft_dct && !g_no_packed && topo[0] == OCN_PERIODIC && N[0] % 2 == 0 && N[0] >= 4 &&
                          (topo[1] == OCN_BOUNDED || topo[2] == OCN_BOUNDED) && !(ep && ep[0] == '0');
-            s->gallreal = s->fft_dct && !gtri && topo[0] == OCN_BOUNDED && topo[1] == OCN_BOUNDED && (topo[2] == OCN_BOUNDED || topo[2] == OCN_FLAT) &&
+            s->gallreal = s->fft_dct && topo[0] == OCN_BOUNDED && topo[1] == OCN_BOUNDED && (topo[2] == OCN_BOUNDED || topo[2] == OCN_FLAT) &&
                           N[0] % 2 == 0 && N[1] % 2 == 0 && !(ep && ep[0] == '0');
         }
         if (s->fft_dct && st == OCN_SUCCESS) {
@@ -677,8 +677,16 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         pst = exec_line_plan(s, 0, 0, a, Nrow, stream);
         if (pst != OCN_SUCCESS) return pst;
         rowpair(1);
-        hipLaunchKernelGGL(spectral_solve_real_kernel, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], s->lx, s->ly,
-                           s->lz, a, s->shift, s->shifted ? 1 : 0);
+        if (s->gtri) {  // the Thomas sweep along the stretched z of a closed box, on reals, and the zero-mean gauge on the (0, 0) column
+            int st = ocn::launch_tridiag_z_real(N[0], N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
+            if (st != OCN_SUCCESS) return st;
+            std::swap(a, b);
+            st = ocn::launch_remove_mean_mode_real((long long)N[0] * N[1], N[2], a, stream);
+            if (st != OCN_SUCCESS) return st;
+        } else {
+            hipLaunchKernelGGL(spectral_solve_real_kernel, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], s->lx, s->ly,
+                               s->lz, a, s->shift, s->shifted ? 1 : 0);
+        }
         rowpair(2);
         pst = exec_line_plan(s, 0, 1, a, Nrow, stream);
         if (pst != OCN_SUCCESS) return pst;
