@@ -1308,7 +1308,10 @@ int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const doub
                 OCN_CHECK_HIP(hipGetLastError());
                 return OCN_SUCCESS;
             }
-            if (narrow)
+            // 17 x 15 patches (16 x 14 cells owned: 87.8 % of the lanes useful against 84.8 % of 32 x 8) also on full boxes: 24.42 against
+            // 24.56 ms per 512^3 step, six same-box pairs (round 4; 16 x 16 patches: 24.9 - 25.4); OCN_PC_TILE=32 selects the 32 x 8 patches
+            static const int pc_tile = getenv("OCN_PC_TILE") ? atoi(getenv("OCN_PC_TILE")) : 17;
+            if (narrow || pc_tile == 17)
                 launch_tiled<OCN_PERIODIC, 17, 15, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
             else if (one_barrier() & 1)
                 launch_tiled<OCN_PERIODIC, 32, 8, true, true>(g, u, v, w, Gu, Gv, Gw, r, fz, wx, wy, wz, stream);
