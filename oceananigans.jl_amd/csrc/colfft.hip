@@ -196,7 +196,15 @@ struct ColFFTArgs {
     int xcd;                 // XCD-contiguous block order (xcd_block)
 };
 
-// MODE 0: forward (natural -> stage order), 1: inverse (stage order -> natural), 2: forward, spectral solve, inverse
+template <int N>
+__device__ __forceinline__ int stage_wavenumber(int p);
+
+// MODE 0: forward (natural -> stage order), 1: inverse (stage order -> natural), 2: forward, spectral solve, inverse;
+// MODE 3 / 4: the cosine transforms of the general Poisson solver (REDFT10 / REDFT01 / 2N of the real and of the imaginary part of every
+// column, Makhoul 1980: poisson.hip dct_shuffle_kernel) with their permutation and twiddle passes INSIDE the column transform -- 3: gather on
+// load (v[n] = x[2n], v[N-1-n] = x[2n+1]), FFT, then X[k] = Re(w_k (V[k] + conj V[N-k])) + i Im(w_k (V[k] - conj V[N-k])) through one more
+// LDS exchange, stored in NATURAL wavenumber order; 4: V[k] = conj(w_k) (X[k] - i X[N-k]) / 2 from the natural-order column in LDS, inverse
+// FFT scaled by a.scale, scatter on store.  a.lc = w_k = e^{-i pi k / 2N}, k < N (complex, natural order).  One pass each instead of three.
 template <int N, int CB, int MODE>
 __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
 {
@@ -213,6 +221,56 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     const bool active = (col0 + c) < a.ncols;
     cplx *base = reinterpret_cast<cplx *>(a.data) + (long long)batch * a.batch_stride + (col0 + (active ? c : 0));
     cplx x[8];
+    constexpr int HALF = (N + 1) / 2;
+
+    if (MODE == 3) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = t + T * r, src = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
+            x[r] = active ? base[(long long)src * a.col_stride] : cplx{0, 0};
+        }
+        fft_fwd_stages<N, CB>(x, A, W, c, t);
+        __syncthreads();  // the exchange buffer is free: the spectrum by natural wavenumber
+#pragma unroll
+        for (int m = 0; m < 8; ++m) A[stage_wavenumber<N>(8 * t + m) * CB + c] = x[m];
+        __syncthreads();
+        const cplx *wd = reinterpret_cast<const cplx *>(a.lc);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = t + T * r;
+                const cplx va = A[k * CB + c], vb = A[((N - k) % N) * CB + c], wk = wd[k];
+                const double sr = va.x + vb.x, si = va.y - vb.y, dr = va.x - vb.x, di = va.y + vb.y;
+                base[(long long)k * a.col_stride] = cplx{wk.x * sr - wk.y * si, wk.x * di + wk.y * dr};
+            }
+        }
+        return;
+    }
+    if (MODE == 4) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = t + T * r;
+            A[k * CB + c] = active ? base[(long long)k * a.col_stride] : cplx{0, 0};
+        }
+        __syncthreads();
+        const cplx *wd = reinterpret_cast<const cplx *>(a.lc);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = stage_wavenumber<N>(8 * t + m);
+            const cplx va = A[k * CB + c], vb = k == 0 ? cplx{0, 0} : A[(N - k) * CB + c], wk = wd[k];
+            const double zr = va.x + vb.y, zi = va.y - vb.x;
+            x[m] = cplx{0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr)};
+        }
+        fft_inv_stages<N, CB>(x, A, W, c, t);  // (its first write into the exchange buffer comes after a barrier)
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int e = t + T * r, dst = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
+                base[(long long)dst * a.col_stride] = cplx{x[r].x * a.scale, x[r].y * a.scale};
+            }
+        }
+        return;
+    }
 
     if (MODE == 0 || MODE == 2) {
 #pragma unroll
@@ -292,6 +350,12 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
     } else if (mode == 1) {
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((colfft_kernel<N, CB, 1>), grid, block, lds, stream, a);
+    } else if (mode == 3) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_kernel<N, CB, 3>), grid, block, lds, stream, a);
+    } else if (mode == 4) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_kernel<N, CB, 4>), grid, block, lds, stream, a);
     } else {
         // (measured and rejected, round 3: a persistent variant that requests the next column set's values before transforming the current
         //  one -- 2.93 ms per 512^3 solve at 166 VGPRs / one workgroup per CU, 3.17 ms with the registers capped for two, against 2.85 ms)

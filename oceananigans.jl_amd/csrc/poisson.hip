@@ -158,6 +158,9 @@ struct ocn_poisson {
     // eigenvalues and twiddles are stored permuted, gpartner[d][p] = stored position of wavenumber N - k(p) for the cosine transforms
     bool gathered = false;  // compute_source_term stored the source already permuted along the first cosine-transform dimension
     bool gcol[3] = {false, false, false};
+    // ... and a Bounded dimension on the column kernel runs its cosine transform in ONE pass (colfft.hip MODE 3 / 4: permutation and twiddle
+    // inside the kernel, natural wavenumber order on both sides, so eigenvalues and twiddles stay natural)  [OCN_POISSON_FUSED_DCT=0: three passes]
+    bool gdct[3] = {false, false, false};
     double *gcoltw[3] = {nullptr, nullptr, nullptr};
     int *gpartner[3] = {nullptr, nullptr, nullptr};
     bool fft_dct = false;
@@ -394,13 +397,16 @@ static int make_line_plans(ocn_poisson *s, int d, const int N[3])
                      rocfft_array_type_complex_interleaved, rocfft_array_type_complex_interleaved, stride, dist, stride, dist, 1.0 / N[d]);
 }
 
-static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const int N[3], hipStream_t stream)
+static int exec_line_plan(ocn_poisson *s, int d, int inverse, double *a, const int N[3], hipStream_t stream, bool dct = false)
 {
     if (s->gcol[d]) {  // one launch of the column kernel; forward: natural -> stage order, inverse: stage order -> natural, scaled 1 / N
+        // (a whole cosine transform, natural order on both sides, when `dct`)
         const long long plane = (long long)N[0] * N[1];
-        if (d == 1) return ocn::launch_colfft(N[1], inverse ? 1 : 0, a, N[0], plane, N[0], N[2], s->gcoltw[d], nullptr, nullptr, nullptr,
+        const int mode = dct ? (inverse ? 4 : 3) : (inverse ? 1 : 0);
+        const double *wd = dct ? s->gtw[d] : nullptr;
+        if (d == 1) return ocn::launch_colfft(N[1], mode, a, N[0], plane, N[0], N[2], s->gcoltw[d], nullptr, nullptr, wd,
                                               inverse ? 1.0 / N[1] : 1.0, 1, stream);
-        return ocn::launch_colfft(N[2], inverse ? 1 : 0, a, plane, 0, (int)plane, 1, s->gcoltw[d], nullptr, nullptr, nullptr,
+        return ocn::launch_colfft(N[2], mode, a, plane, 0, (int)plane, 1, s->gcoltw[d], nullptr, nullptr, wd,
                                   inverse ? 1.0 / N[2] : 1.0, 1, stream);
     }
     Plan &P = inverse ? s->gbwd[d] : s->gfwd[d];
@@ -471,12 +477,17 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
             for (int d = 0; d < 3 && st == OCN_SUCCESS; ++d) {
                 if (topo[d] == OCN_FLAT) continue;
                 s->gcol[d] = d > 0 && ocn::colfft_supported(N[d]) && !(gc && gc[0] == '0');
+                const char *fd = std::getenv("OCN_POISSON_FUSED_DCT");
+                s->gdct[d] = s->gcol[d] && topo[d] == OCN_BOUNDED && !(fd && fd[0] == '0');
                 std::vector<int> kofp(N[d]), pofk(N[d]);
                 for (int p = 0; p < N[d]; ++p) {
-                    kofp[p] = s->gcol[d] ? ocn::colfft_wavenumber(N[d], p) : p;
+                    kofp[p] = (s->gcol[d] && !s->gdct[d]) ? ocn::colfft_wavenumber(N[d], p) : p;
                     pofk[kofp[p]] = p;
                 }
-                if (s->gcol[d]) {
+                if (s->gdct[d]) {
+                    st = upload(ocn::colfft_twiddles(N[d]), &s->gcoltw[d]);
+                    if (st != OCN_SUCCESS) break;
+                } else if (s->gcol[d]) {
                     st = upload(ocn::colfft_twiddles(N[d]), &s->gcoltw[d]);
                     if (st != OCN_SUCCESS) break;
                     // eigenvalues in stored order
@@ -507,7 +518,7 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
                     w[2 * p + 1] = (double)(-sinl(a));
                 }
                 st = upload(w, &s->gtw[d]);
-                if (st == OCN_SUCCESS && s->gcol[d]) {
+                if (st == OCN_SUCCESS && s->gcol[d] && !s->gdct[d]) {
                     std::vector<int> partner(N[d]);
                     for (int p = 0; p < N[d]; ++p) partner[p] = pofk[(N[d] - kofp[p]) % N[d]];
                     if (hipMalloc((void **)&s->gpartner[d], N[d] * sizeof(int)) != hipSuccess ||
@@ -618,7 +629,8 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
                            s->gpartner[dt]);
         std::swap(a, b);
     };
-    // the passes as a list of operations (kind 0 gather, 1 post-twiddle, 2 pre-twiddle, 3 scatter, 4 line FFT forward, 5 inverse, 6 direct sums),
+    // the passes as a list of operations (kind 0 gather, 1 post-twiddle, 2 pre-twiddle, 3 scatter, 4 line FFT forward, 5 inverse, 6 direct sums,
+    // 8 / 9 a whole forward / inverse cosine transform in the column kernel),
     // then a twiddle followed by a permutation along another dimension (forward: 1 then 0; inverse: 3 then 2) runs as ONE pass
     struct Op { int kind, d; };
     const bool fuse = general_fuse_shuffles();
@@ -637,7 +649,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
                                    o.kind == 7, reinterpret_cast<const double2 *>(a), reinterpret_cast<double2 *>(b), s->tab[o.d][0], s->tab[o.d][1]);
                 std::swap(a, b);
             } else {
-                pst = exec_line_plan(s, o.d, o.kind == 5, a, Nv, stream);
+                pst = exec_line_plan(s, o.d, o.kind == 5 || o.kind == 9, a, Nv, stream, o.kind >= 8);
             }
         }
     };
@@ -654,13 +666,21 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
     };
     Op fwd[9], bwd[9];
     int nf = 0, nb = 0;
+    auto push_fwd = [&](int d) {  // REDFT10: gather, FFT, twiddle -- or the one fused pass
+        if (s->gdct[d]) { fwd[nf++] = Op{8, d}; return; }
+        fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d};
+    };
+    auto push_bwd = [&](int d) {  // REDFT01 / 2N: twiddle, inverse FFT (scaled 1 / N), scatter -- or the one fused pass
+        if (s->gdct[d]) { bwd[nb++] = Op{9, d}; return; }
+        bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d};
+    };
     if (s->gallreal) {
         // ---- y, z on the pair view (the source's rows are already gathered along y when compute_source_term stored it that way)
         Nv = Npair;
         for (int d = 1; d < 3; ++d)
-            if (topo[d] == OCN_BOUNDED) { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }
+            if (topo[d] == OCN_BOUNDED) push_fwd(d);
         for (int d = 2; d >= 1; --d)
-            if (topo[d] == OCN_BOUNDED) { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }
+            if (topo[d] == OCN_BOUNDED) push_bwd(d);
         const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
         s->gathered = false;
         run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
@@ -704,11 +724,11 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         Nv = Npair;
         for (int q = 0; q < no; ++q) {
             const int d = order[q];
-            if (topo[d] == OCN_BOUNDED) { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }
+            if (topo[d] == OCN_BOUNDED) push_fwd(d);
         }
         for (int q = no - 1; q >= 0; --q) {
             const int d = order[q];
-            if (topo[d] == OCN_BOUNDED) { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }
+            if (topo[d] == OCN_BOUNDED) push_bwd(d);
         }
         const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
         s->gathered = false;
@@ -745,13 +765,13 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         const int d = order[q];
         if (!s->fft_dct) fwd[nf++] = Op{6, d};
         else if (topo[d] == OCN_PERIODIC) fwd[nf++] = Op{4, d};
-        else { fwd[nf++] = Op{0, d}; fwd[nf++] = Op{4, d}; fwd[nf++] = Op{1, d}; }  // REDFT10: gather, FFT, twiddle
+        else push_fwd(d);
     }
     for (int q = no - 1; q >= 0; --q) {
         const int d = order[q];
         if (!s->fft_dct) bwd[nb++] = Op{7, d};
         else if (topo[d] == OCN_PERIODIC) bwd[nb++] = Op{5, d};
-        else { bwd[nb++] = Op{2, d}; bwd[nb++] = Op{5, d}; bwd[nb++] = Op{3, d}; }  // REDFT01 / 2N: twiddle, inverse FFT (scaled 1 / N), scatter
+        else push_bwd(d);
     }
     const bool skip_gather = s->gathered && nf > 0 && fwd[0].kind == 0;
     s->gathered = false;
@@ -1253,6 +1273,7 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
         if (s->fft_dct && general_fuse_shuffles())
             for (int d = s->gtri ? 1 : 2; d >= (s->gallreal ? 1 : 0); --d)  // (all-real boxes transform y first: their x lines pair rows)
                 if ((d == 0 ? g->tx : d == 1 ? g->ty : g->tz) == OCN_BOUNDED) first = d;
+        if (first >= 0 && s->gdct[first]) first = -1;  // (the fused cosine transform gathers on its own load)
         // (the tridiagonal flavour's right-hand side carries Δzᶜ: _fourier_tridiagonal_source_term!, solve_for_pressure.jl:33-38)
         // (packed: the source stays a REAL array -- modes 3 / 4 -- whose x-adjacent pairs the cosine transforms read as complex numbers)
         const int mode = (s->gpacked || s->gallreal) ? (s->gtri ? 4 : 3) : (s->gtri ? 2 : 1);
