@@ -398,6 +398,149 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Cosine transforms along x of a REAL array (Nx, Ny, Nz), Ny even, in place: the closed boxes of the general solver (poisson.hip,
+// `gallreal`).  The complex line (jp, kz) is the pair of real rows j = 2 jp (real part) and 2 jp + 1 (imaginary part) -- a cosine transform
+// maps reals to reals, so two rows ride on one complex FFT (poisson.hip dct_rowpair_kernel states the four passes this replaces).
+// MODE 5: REDFT10 (gather on load, FFT, twiddle through LDS, natural wavenumbers);  6: REDFT01 / 2N (pre-twiddle from LDS, inverse FFT, scatter
+// on store);  7: forward, -b / (λx + λy + λz [- m]) with the mode (1, 1, 1) := 0 iff m === 0, inverse -- the whole x part of a solve in ONE pass
+// over the array (16 B per cell instead of seven passes and 112).  Thread (c, t): line c of the workgroup's CB, elements t + (N / 8) r.
+// ---------------------------------------------------------------------------------------------------
+struct RowDCTArgs {
+    double *data;
+    int Nyp, Nz;             // row pairs per plane, planes
+    const double *tw;        // W_N^j
+    const double *wd;        // w_k = e^{-i pi k / 2N} (complex, natural order)
+    const double *lx, *ly, *lz;  // MODE 7: eigenvalues by stored position along x (natural), y, z
+    double scale;            // of the inverse: 1 / N
+    double shift;
+    int shifted;
+    int xcd;
+};
+
+template <int N, int CB, int MODE>
+__global__ __launch_bounds__(CB *(N / 8)) void rowdct_kernel(RowDCTArgs a)
+{
+    constexpr int T = N / 8, HALF = N / 2;
+    extern __shared__ double lds_raw[];
+    cplx *A = reinterpret_cast<cplx *>(lds_raw);
+    cplx *W = reinterpret_cast<cplx *>(lds_raw) + N * CB;
+    const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
+    unsigned lbx, lby;
+    xcd_block(a.xcd, lbx, lby);
+    const int jp0 = lbx * CB, kz = lby;
+    for (int j = tid; j < N; j += CB * T) W[j] = reinterpret_cast<const cplx *>(a.tw)[j];
+    const bool active = (jp0 + c) < a.Nyp;
+    const int jp = active ? jp0 + c : jp0;
+    double *re = a.data + (long long)N * (2 * jp + (long long)2 * a.Nyp * kz), *im = re + N;
+    const cplx *wd = reinterpret_cast<const cplx *>(a.wd);
+    cplx x[8];
+
+    if (MODE == 5 || MODE == 7) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = t + T * r, src = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
+            x[r] = active ? cplx{re[src], im[src]} : cplx{0, 0};
+        }
+        fft_fwd_stages<N, CB>(x, A, W, c, t);
+        __syncthreads();  // the exchange buffer is free: the spectrum by natural wavenumber
+#pragma unroll
+        for (int m = 0; m < 8; ++m) A[stage_wavenumber<N>(8 * t + m) * CB + c] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = t + T * r;
+            const cplx va = A[k * CB + c], vb = A[((N - k) % N) * CB + c], wk = wd[k];
+            const double sr = va.x + vb.x, si = va.y - vb.y, dr = va.x - vb.x, di = va.y + vb.y;
+            x[r] = cplx{wk.x * sr - wk.y * si, wk.x * di + wk.y * dr};
+        }
+        if (MODE == 5) {
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    re[t + T * r] = x[r].x;
+                    im[t + T * r] = x[r].y;
+                }
+            }
+            return;
+        }
+        // (the association of spectral_solve_real_kernel: (λx + λy) + λz)
+        const double ly0 = a.ly[2 * jp], ly1 = a.ly[2 * jp + 1], lz = a.lz[kz];
+        __syncthreads();  // every V[k], V[N - k] has been read
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = t + T * r;
+            const double lxk = a.lx[k];
+            double l0 = (lxk + ly0) + lz, l1 = (lxk + ly1) + lz;
+            if (a.shifted) { l0 = l0 - a.shift; l1 = l1 - a.shift; }
+            cplx v{-x[r].x / l0, -x[r].y / l1};
+            if (!a.shifted && k == 0 && jp == 0 && kz == 0) v.x = 0.0;
+            A[k * CB + c] = v;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = t + T * r;
+            A[k * CB + c] = active ? cplx{re[k], im[k]} : cplx{0, 0};
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int k = stage_wavenumber<N>(8 * t + m);
+        const cplx va = A[k * CB + c], vb = k == 0 ? cplx{0, 0} : A[(N - k) * CB + c], wk = wd[k];
+        const double zr = va.x + vb.y, zi = va.y - vb.x;
+        x[m] = cplx{0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr)};
+    }
+    fft_inv_stages<N, CB>(x, A, W, c, t);  // (its first write into the exchange buffer comes after a barrier)
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = t + T * r, dst = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
+            re[dst] = x[r].x * a.scale;
+            im[dst] = x[r].y * a.scale;
+        }
+    }
+}
+
+template <int N, int CB>
+static int launch_rowdct_n(int mode, const RowDCTArgs &a, hipStream_t stream)
+{
+    const dim3 grid((a.Nyp + CB - 1) / CB, a.Nz), block(CB * (N / 8));
+    const size_t lds = (size_t)(N * CB + N) * sizeof(cplx);
+    if (mode == 5) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rowdct_kernel<N, CB, 5>), grid, block, lds, stream, a);
+    } else if (mode == 6) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rowdct_kernel<N, CB, 6>), grid, block, lds, stream, a);
+    } else {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rowdct_kernel<N, CB, 7>), grid, block, lds, stream, a);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    return OCN_SUCCESS;
+}
+
+// mode 5 forward, 6 inverse, 7 forward + division by the eigenvalues + inverse, of the x lines of the real array `data` (Nx, Ny, Nz), Ny even
+int launch_rowdct(int Nx, int Ny, int Nz, int mode, double *data, const double *tw, const double *wd, const double *lx, const double *ly,
+                  const double *lz, double shift, int shifted, hipStream_t stream)
+{
+    if (Ny % 2 != 0 || mode < 5 || mode > 7) {
+        set_error("row cosine transform: Ny = %d must be even and the mode (%d) 5, 6 or 7", Ny, mode);
+        return OCN_ERR_INVALID_ARGUMENT;
+    }
+    RowDCTArgs a{data, Ny / 2, Nz, tw, wd, lx, ly, lz, 1.0 / Nx, shift, shifted, fft_xcd_remap()};
+    switch (Nx) {
+        case 64: return launch_rowdct_n<64, 16>(mode, a, stream);
+        case 128: return launch_rowdct_n<128, 16>(mode, a, stream);
+        case 256: return launch_rowdct_n<256, 8>(mode, a, stream);
+        case 512: return launch_rowdct_n<512, 8>(mode, a, stream);
+        default: set_error("row cosine transform length %d is not supported (64, 128, 256, 512)", Nx); return OCN_ERR_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Slab pipeline of the distributed solver (poisson.hip, ocn_dist_poisson "fast" mode): x is partitioned, so the local
 // directions y and z are transformed first -- y as a REAL transform of strided columns, z as a column FFT that writes straight
 // into the all-to-all send layout -- and x after the exchange with the fused FFT -> divide -> IFFT column kernel above.

@@ -111,6 +111,8 @@ int launch_free_surface_ab2(const ocn_grid *grid, const double *w, double *eta, 
                             hipStream_t stream);
 int launch_halo_plane_x(const ocn_grid *grid, double *field, int loc, int which, double *buf, int unpack, hipStream_t stream);
 int launch_halo_pack_x_fields(const ocn_grid *grid, const FieldTuple &ft, double *west, double *east, int unpack, hipStream_t stream);
+int launch_rowdct(int Nx, int Ny, int Nz, int mode, double *data, const double *tw, const double *wd, const double *lx, const double *ly,
+                  const double *lz, double shift, int shifted, hipStream_t stream);
 int launch_colfft_slab_z(int Nz, int inverse, const double *in, double *out, int nx, int NyH, int R, const double *tw, hipStream_t stream);
 // row FFTs (rowfft.hip): inverse = 0: [div(u,v,w)/dt | real_in] -> half spectrum;  1: half spectrum -> rows of haloed p
 bool rowfft_supported(int Nx);

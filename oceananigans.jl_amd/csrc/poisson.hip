@@ -161,6 +161,10 @@ struct ocn_poisson {
     // ... and a Bounded dimension on the column kernel runs its cosine transform in ONE pass (colfft.hip MODE 3 / 4: permutation and twiddle
     // inside the kernel, natural wavenumber order on both sides, so eigenvalues and twiddles stay natural)  [OCN_POISSON_FUSED_DCT=0: three passes]
     bool gdct[3] = {false, false, false};
+    // ... and the x lines of an all-real closed box (row pairs) with Nx = 64 ... 512 run in colfft.hip's row kernel: forward transform,
+    // division by the eigenvalues and inverse in ONE in-place pass (two around the Thomas sweep of a stretched z)  [OCN_POISSON_ROW_DCT=0:
+    // gather, rocFFT lines, twiddle, solve, twiddle, lines, scatter]
+    bool growdct = false;
     double *gcoltw[3] = {nullptr, nullptr, nullptr};
     int *gpartner[3] = {nullptr, nullptr, nullptr};
     bool fft_dct = false;
@@ -497,6 +501,10 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
                     *lam[d] = nullptr;
                     st = upload(lp, lam[d]);
                     if (st != OCN_SUCCESS) break;
+                } else if (s->gallreal && d == 0 && ocn::colfft_supported(N[0]) && !(gc && gc[0] == '0') &&
+                           !(std::getenv("OCN_POISSON_ROW_DCT") && std::getenv("OCN_POISSON_ROW_DCT")[0] == '0')) {
+                    s->growdct = true;
+                    st = upload(ocn::colfft_twiddles(N[0]), &s->gcoltw[0]);
                 } else if (s->gallreal) {
                     // x lines of row pairs (Nx, Ny / 2, Nz); y / z lines of x-adjacent pairs (Nx / 2, Ny, Nz)
                     const int Nd[3] = {d == 0 ? N[0] : N[0] / 2, d == 0 ? N[1] / 2 : N[1], N[2]};
@@ -693,24 +701,42 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
                                reinterpret_cast<const double2 *>(s->gtw[0]));
             std::swap(a, b);
         };
-        rowpair(0);
-        pst = exec_line_plan(s, 0, 0, a, Nrow, stream);
-        if (pst != OCN_SUCCESS) return pst;
-        rowpair(1);
-        if (s->gtri) {  // the Thomas sweep along the stretched z of a closed box, on reals, and the zero-mean gauge on the (0, 0) column
-            int st = ocn::launch_tridiag_z_real(N[0], N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
-            if (st != OCN_SUCCESS) return st;
-            std::swap(a, b);
-            st = ocn::launch_remove_mean_mode_real((long long)N[0] * N[1], N[2], a, stream);
-            if (st != OCN_SUCCESS) return st;
+        auto xrow = [&](int mode) {  // 5 forward, 6 inverse, 7 forward + division + inverse: the row kernel, in place
+            return ocn::launch_rowdct(N[0], N[1], N[2], mode, a, s->gcoltw[0], s->gtw[0], s->lx, s->ly, s->lz, s->shift, s->shifted ? 1 : 0, stream);
+        };
+        if (s->growdct && !s->gtri) {
+            pst = xrow(7);
+            if (pst != OCN_SUCCESS) return pst;
         } else {
-            hipLaunchKernelGGL(spectral_solve_real_kernel, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], s->lx, s->ly,
-                               s->lz, a, s->shift, s->shifted ? 1 : 0);
+            if (s->growdct) {
+                pst = xrow(5);
+            } else {
+                rowpair(0);
+                pst = exec_line_plan(s, 0, 0, a, Nrow, stream);
+                if (pst != OCN_SUCCESS) return pst;
+                rowpair(1);
+            }
+            if (pst != OCN_SUCCESS) return pst;
+            if (s->gtri) {  // the Thomas sweep along the stretched z of a closed box, on reals, and the zero-mean gauge on the (0, 0) column
+                int st = ocn::launch_tridiag_z_real(N[0], N[1], N[2], s->lower, s->diag, s->lower, a, s->tscr, b, stream);
+                if (st != OCN_SUCCESS) return st;
+                std::swap(a, b);
+                st = ocn::launch_remove_mean_mode_real((long long)N[0] * N[1], N[2], a, stream);
+                if (st != OCN_SUCCESS) return st;
+            } else {
+                hipLaunchKernelGGL(spectral_solve_real_kernel, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, stream, N[0], N[1], N[2], s->lx,
+                                   s->ly, s->lz, a, s->shift, s->shifted ? 1 : 0);
+            }
+            if (s->growdct) {
+                pst = xrow(6);
+            } else {
+                rowpair(2);
+                pst = exec_line_plan(s, 0, 1, a, Nrow, stream);
+                if (pst != OCN_SUCCESS) return pst;
+                rowpair(3);
+            }
+            if (pst != OCN_SUCCESS) return pst;
         }
-        rowpair(2);
-        pst = exec_line_plan(s, 0, 1, a, Nrow, stream);
-        if (pst != OCN_SUCCESS) return pst;
-        rowpair(3);
         // ---- z, y back on the pair view; the last scatter is folded into the copy into the pressure field
         const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
         run(bwd, nb - (last_scatter >= 0 ? 1 : 0));

@@ -410,13 +410,15 @@ def test_time_steps_match_oracle_on_closed_and_sliced_grids(oracle, ocn, size, t
                 assert np.all(a[tuple(idx)] == 0.0)
 
 
-@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PBB"), ((12, 12, 10), "BBB"), ((32, 1, 16), "PFB"), ((64, 128, 12), "PBB"), ((10, 9, 8), "BPB")])
+@pytest.mark.parametrize("size,topo", [((16, 12, 10), "PBB"), ((12, 12, 10), "BBB"), ((32, 1, 16), "PFB"), ((64, 128, 12), "PBB"), ((10, 9, 8), "BPB"),
+                                       ((128, 64, 10), "BBB")])
 @pytest.mark.parametrize("zkind", ["stretched", "regular"])
 def test_fourier_tridiagonal_solver_with_walls_in_x_or_y(oracle, ocn, size, topo, zkind):
     """FourierTridiagonalPoissonSolver on XYRegularRG grids whose x / y are Bounded or Flat (fourier_tridiagonal_poisson_solver.jl:82-147:
     cosine / Fourier transforms along x and y, batched Thomas sweep along z): the only solver of a channel with a stretched z.  Source =
     the divergence of a random velocity (the library's K9 with its Δzᶜ factor); the solution equals the oracle's solver to 1e-10 and
-    satisfies the discrete Poisson equation; (64, 128, ·) runs the y lines through the column kernel (stage-ordered wavenumbers)."""
+    satisfies the discrete Poisson equation; (64, 128, ·) runs the y lines through the column kernel, (128, 64, ·) "BBB" also the x lines
+    through the row kernel (forward and inverse around the Thomas sweep)."""
     from helpers import stretched_faces
     O = oracle
     z = stretched_faces(size[2], 0.7) if zkind == "stretched" else (-0.7, 0)
@@ -518,7 +520,7 @@ def test_scalar_diffusivity_budget(ocn, topo, fieldname):
 @pytest.mark.parametrize("size,topo", [((7, 11, 16), "BBB"), ((16, 7, 11), "PBB"), ((32, 20, 12), "BPB"), ((9, 1, 14), "BFB"), ((64, 48, 40), "BBB"),
                                        # y / z lengths the column FFT kernels take (64 ... 512): spectra in stage order, permuted eigenvalues / twiddles
                                        ((16, 64, 128), "BBB"), ((24, 128, 64), "PBB"), ((8, 64, 64), "BPB"), ((12, 64, 256), "PPB"), ((128, 64, 64), "BBB"),
-                                       ((4, 512, 64), "PBB"), ((6, 64, 512), "BBB")])
+                                       ((4, 512, 64), "PBB"), ((6, 64, 512), "BBB"), ((256, 6, 4), "BBB"), ((512, 4, 1), "BBF")])
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, fused, monkeypatch):
     """K11 (index_permutations.jl:38-90, discrete_transforms.jl:141-176): the cosine transforms of the general FFTBasedPoissonSolver built
@@ -527,9 +529,10 @@ def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, fused, m
     of max|ϕ|, and ∇²ϕ reproduces the zero-mean source to sqrt(eps).  fused = "1" (default): a y / z cosine transform of length 64 ... 512 is
     ONE pass of the column kernel (permutation and twiddle inside, natural wavenumber order); "0": gather, FFT, twiddle passes"""
     import torch
-    if fused == "0" and max(size[1:]) < 64:
-        pytest.skip("no column-kernel lengths: the switch changes nothing")
+    if fused == "0" and max(size[1:]) < 64 and not (topo in ("BBB", "BBF") and size[0] in (64, 128, 256, 512)):
+        pytest.skip("no column- or row-kernel lengths: the switches change nothing")
     monkeypatch.setenv("OCN_POISSON_FUSED_DCT", fused)
+    monkeypatch.setenv("OCN_POISSON_ROW_DCT", fused)  # the x lines of an all-real box: one pass (transform, division, inverse) or seven
     T = {"P": "Periodic", "B": "Bounded", "F": "Flat"}
     nonflat = [d for d in range(3) if topo[d] != "F"]
     kw = dict(size=tuple(size[d] for d in nonflat), topology=tuple(T[t] for t in topo), halo=tuple(3 for _ in nonflat))
