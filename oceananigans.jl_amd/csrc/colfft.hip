@@ -404,6 +404,10 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
 // MODE 5: REDFT10 (gather on load, FFT, twiddle through LDS, natural wavenumbers);  6: REDFT01 / 2N (pre-twiddle from LDS, inverse FFT, scatter
 // on store);  7: forward, -b / (λx + λy + λz [- m]) with the mode (1, 1, 1) := 0 iff m === 0, inverse -- the whole x part of a solve in ONE pass
 // over the array (16 B per cell instead of seven passes and 112).  Thread (c, t): line c of the workgroup's CB, elements t + (N / 8) r.
+// MODE 8: a PERIODIC x (channels, `gpacked` without another Periodic direction): the row pair z = a + i b through one complex FFT,
+// Z = A + i B with Hermitian A, B; the division scales A by s0(k) = -1 / λ(k, j0, kz) and B by s1(k) (real, even in k), so
+// Z'[k] = (s0 + s1) / 2 Z[k] + (s0 - s1) / 2 conj Z[N - k], and the inverse FFT returns the two solved rows: real-to-complex transform,
+// division and complex-to-real transform (three passes, 64 B per cell) in one.
 // ---------------------------------------------------------------------------------------------------
 struct RowDCTArgs {
     double *data;
@@ -435,6 +439,38 @@ __global__ __launch_bounds__(CB *(N / 8)) void rowdct_kernel(RowDCTArgs a)
     const cplx *wd = reinterpret_cast<const cplx *>(a.wd);
     cplx x[8];
 
+    if (MODE == 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = active ? cplx{re[t + T * r], im[t + T * r]} : cplx{0, 0};
+        fft_fwd_stages<N, CB>(x, A, W, c, t);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) A[stage_wavenumber<N>(8 * t + m) * CB + c] = x[m];
+        __syncthreads();
+        const double ly0 = a.ly[2 * jp], ly1 = a.ly[2 * jp + 1], lz = a.lz[kz];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = stage_wavenumber<N>(8 * t + m);
+            const cplx za = A[k * CB + c], zb = A[((N - k) % N) * CB + c];
+            const double lxk = a.lx[k];
+            double l0 = (lxk + ly0) + lz, l1 = (lxk + ly1) + lz;
+            if (a.shifted) { l0 = l0 - a.shift; l1 = l1 - a.shift; }
+            double s0 = -1.0 / l0;
+            const double s1 = -1.0 / l1;
+            if (!a.shifted && k == 0 && jp == 0 && kz == 0) s0 = 0.0;
+            const double p = 0.5 * (s0 + s1), q = 0.5 * (s0 - s1);
+            x[m] = cplx{p * za.x + q * zb.x, p * za.y - q * zb.y};
+        }
+        fft_inv_stages<N, CB>(x, A, W, c, t);  // (its first write into the exchange buffer comes after a barrier)
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                re[t + T * r] = x[r].x * a.scale;
+                im[t + T * r] = x[r].y * a.scale;
+            }
+        }
+        return;
+    }
     if (MODE == 5 || MODE == 7) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -514,6 +550,9 @@ static int launch_rowdct_n(int mode, const RowDCTArgs &a, hipStream_t stream)
     } else if (mode == 6) {
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rowdct_kernel<N, CB, 6>), grid, block, lds, stream, a);
+    } else if (mode == 8) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rowdct_kernel<N, CB, 8>), grid, block, lds, stream, a);
     } else {
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)rowdct_kernel<N, CB, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((rowdct_kernel<N, CB, 7>), grid, block, lds, stream, a);
@@ -522,12 +561,13 @@ static int launch_rowdct_n(int mode, const RowDCTArgs &a, hipStream_t stream)
     return OCN_SUCCESS;
 }
 
-// mode 5 forward, 6 inverse, 7 forward + division by the eigenvalues + inverse, of the x lines of the real array `data` (Nx, Ny, Nz), Ny even
+// mode 5 forward, 6 inverse, 7 forward + division by the eigenvalues + inverse (cosine transforms), 8 the same around the FFT of a Periodic x,
+// of the x lines of the real array `data` (Nx, Ny, Nz), Ny even
 int launch_rowdct(int Nx, int Ny, int Nz, int mode, double *data, const double *tw, const double *wd, const double *lx, const double *ly,
                   const double *lz, double shift, int shifted, hipStream_t stream)
 {
-    if (Ny % 2 != 0 || mode < 5 || mode > 7) {
-        set_error("row cosine transform: Ny = %d must be even and the mode (%d) 5, 6 or 7", Ny, mode);
+    if (Ny % 2 != 0 || mode < 5 || mode > 8) {
+        set_error("row transform: Ny = %d must be even and the mode (%d) 5 ... 8", Ny, mode);
         return OCN_ERR_INVALID_ARGUMENT;
     }
     RowDCTArgs a{data, Ny / 2, Nz, tw, wd, lx, ly, lz, 1.0 / Nx, shift, shifted, fft_xcd_remap()};

@@ -510,7 +510,13 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
                     const int Nd[3] = {d == 0 ? N[0] : N[0] / 2, d == 0 ? N[1] / 2 : N[1], N[2]};
                     st = make_line_plans(s, d, Nd);
                 } else if (s->gpacked && d == 0) {
-                    // x: real-to-complex / complex-to-real lines (below)
+                    // x: real-to-complex / complex-to-real lines (below) -- or, on a regular (Periodic, Bounded / Flat, Bounded / Flat) channel
+                    // with Nx = 64 ... 512 and an even Ny, transform, division and inverse in one pass of the row kernel (colfft.hip MODE 8)
+                    if (!gtri && topo[1] != OCN_PERIODIC && topo[2] != OCN_PERIODIC && N[1] % 2 == 0 && ocn::colfft_supported(N[0]) &&
+                        !(gc && gc[0] == '0') && !(std::getenv("OCN_POISSON_ROW_DCT") && std::getenv("OCN_POISSON_ROW_DCT")[0] == '0')) {
+                        s->growdct = true;
+                        st = upload(ocn::colfft_twiddles(N[0]), &s->gcoltw[0]);
+                    }
                 } else if (s->gpacked) {
                     // y / z lines of the packed views: Nx / 2 complex columns under a cosine transform, the half spectrum under an FFT
                     const int Nd[3] = {topo[d] == OCN_BOUNDED ? N[0] / 2 : N[0] / 2 + 1, N[1], N[2]};
@@ -543,7 +549,7 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         ocn::set_error("ocn_poisson_create: out of device memory");
         st = OCN_ERR_ALLOC;
     }
-    if (st == OCN_SUCCESS && s->gpacked) {
+    if (st == OCN_SUCCESS && s->gpacked && !s->growdct) {
         const size_t len[1] = {(size_t)N[0]}, one[1] = {1};
         const size_t nxh = (size_t)N[0] / 2 + 1, batch = (size_t)N[1] * N[2];
         st = make_plan(s->xr2c, rocfft_placement_notinplace, rocfft_transform_type_real_forward, 1, len, batch, rocfft_array_type_real,
@@ -760,6 +766,16 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         s->gathered = false;
         run(fwd + (skip_gather ? 1 : 0), nf - (skip_gather ? 1 : 0));
         if (pst != OCN_SUCCESS) return pst;
+        if (s->growdct) {  // x: transform, division and inverse of row pairs in place, then straight to the inverse cosine transforms
+            int st = ocn::launch_rowdct(N[0], N[1], N[2], 8, a, s->gcoltw[0], nullptr, s->lx, s->ly, s->lz, s->shift, s->shifted ? 1 : 0, stream);
+            if (st != OCN_SUCCESS) return st;
+            const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
+            run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
+            if (pst != OCN_SUCCESS) return pst;
+            OCN_CHECK_HIP(hipGetLastError());
+            if (a != s->spec) std::swap(s->spec, s->spec2);
+            return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+        }
         // ---- x: real rows -> half spectrum; the other Periodic direction on the half spectrum
         int st = s->xr2c.exec(a, b, stream);
         if (st != OCN_SUCCESS) return st;

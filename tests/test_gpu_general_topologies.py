@@ -520,7 +520,9 @@ def test_scalar_diffusivity_budget(ocn, topo, fieldname):
 @pytest.mark.parametrize("size,topo", [((7, 11, 16), "BBB"), ((16, 7, 11), "PBB"), ((32, 20, 12), "BPB"), ((9, 1, 14), "BFB"), ((64, 48, 40), "BBB"),
                                        # y / z lengths the column FFT kernels take (64 ... 512): spectra in stage order, permuted eigenvalues / twiddles
                                        ((16, 64, 128), "BBB"), ((24, 128, 64), "PBB"), ((8, 64, 64), "BPB"), ((12, 64, 256), "PPB"), ((128, 64, 64), "BBB"),
-                                       ((4, 512, 64), "PBB"), ((6, 64, 512), "BBB"), ((256, 6, 4), "BBB"), ((512, 4, 1), "BBF")])
+                                       ((4, 512, 64), "PBB"), ((6, 64, 512), "BBB"), ((256, 6, 4), "BBB"), ((512, 4, 1), "BBF"),
+                                       # x lines in the row kernel: cosine transforms of a closed box, the FFT of a channel's Periodic x
+                                       ((64, 12, 10), "PBB"), ((256, 64, 6), "PBB"), ((128, 6, 1), "PBF"), ((512, 4, 64), "PBB")])
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, fused, monkeypatch):
     """K11 (index_permutations.jl:38-90, discrete_transforms.jl:141-176): the cosine transforms of the general FFTBasedPoissonSolver built
@@ -529,10 +531,10 @@ def test_fft_based_cosine_transforms_equal_direct_sums(ocn, size, topo, fused, m
     of max|ϕ|, and ∇²ϕ reproduces the zero-mean source to sqrt(eps).  fused = "1" (default): a y / z cosine transform of length 64 ... 512 is
     ONE pass of the column kernel (permutation and twiddle inside, natural wavenumber order); "0": gather, FFT, twiddle passes"""
     import torch
-    if fused == "0" and max(size[1:]) < 64 and not (topo in ("BBB", "BBF") and size[0] in (64, 128, 256, 512)):
+    if fused == "0" and max(size[1:]) < 64 and not (topo in ("BBB", "BBF", "PBB", "PBF") and size[0] in (64, 128, 256, 512)):
         pytest.skip("no column- or row-kernel lengths: the switches change nothing")
     monkeypatch.setenv("OCN_POISSON_FUSED_DCT", fused)
-    monkeypatch.setenv("OCN_POISSON_ROW_DCT", fused)  # the x lines of an all-real box: one pass (transform, division, inverse) or seven
+    monkeypatch.setenv("OCN_POISSON_ROW_DCT", fused)  # the x lines of a closed box or a channel: one pass (transform, division, inverse) or 7 / 3
     T = {"P": "Periodic", "B": "Bounded", "F": "Flat"}
     nonflat = [d for d in range(3) if topo[d] != "F"]
     kw = dict(size=tuple(size[d] for d in nonflat), topology=tuple(T[t] for t in topo), halo=tuple(3 for _ in nonflat))
