@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Step time of NonhydrostaticModel(advection = WENO()) on grids with walls (the direction-generic kernels + the cosine-transform Poisson
-solver) next to the periodic box of the same size:  tools/bench_general.py [N] [steps]"""
+solver) next to the periodic box of the same size:  tools/bench_general.py [N] [steps] [topologies, e.g. PBB,BBB]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ocn.set_math_mode(ocn.MATH_FAST)
 T = {"P": "Periodic", "B": "Bounded"}
-for topo in ("PPP", "PPB", "PBB", "BBB"):
+for topo in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("PPP", "PPB", "PBB", "BBB")):
     g = ocn.RectilinearGrid(ocn.GPU(), size=(N, N, N), x=(0, 1), y=(0, 1), z=(0, 1), topology=tuple(T[t] for t in topo))
     m = ocn.NonhydrostaticModel(g, advection=ocn.WENO())
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
