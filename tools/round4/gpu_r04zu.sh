@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 4, call zu: the config-4 term set on a channel and a closed box against the (Periodic, Periodic, Bounded) grid, 256 x 256 x 128, with a kernel trace
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$ROOT/gpurun_out/r04zu
+mkdir -p $O
+cd $ROOT
+timeout -k 10 300 python tools/bench_general_terms.py 256 128 10 > $O/bench.txt 2>&1 || { tail -20 $O/bench.txt; exit 1; }
+cat $O/bench.txt
+cd /tmp && export TMPDIR=/tmp
+for t in PPB PBB; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$t -- python3 $ROOT/tools/bench_general_terms.py 256 128 20 $t > $O/$t.log 2>&1 || { tail -5 $O/$t.log; exit 1; }
+  f=$(find $O/$t -name "*kernel_stats.csv" | head -1)
+  python3 - "$f" > $O/${t}_stats.txt <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"total kernel time {tot/1e6:.1f} ms")
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:26]:
+    print(f'{float(r["TotalDurationNs"])/1e6:9.2f} ms {int(r["Calls"]):6d} calls {float(r["AverageNs"])/1e3:9.1f} us  {r["Name"][:120]}')
+PY
+  cat $O/${t}_stats.txt
+  find $O/$t -name "*kernel_trace.csv" -delete
+done
