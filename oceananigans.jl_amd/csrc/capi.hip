@@ -505,12 +505,17 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
     OCN_REQUIRE(u && v && w && c && Gc, "ocn_compute_tracer_tendency_terms: null field pointer");
     const bool strict = strict_math(grid);
     hipStream_t s = as_stream(stream);
+    OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
+    if (!xy_periodic(grid) && terms->closure) {  // advection and diffusion in one call: the interior box adds both before its store
+        const int c2 = terms->advection == OCN_ADVECTION_CENTERED2;
+        if (terms->advection == OCN_ADVECTION_UPWIND5)
+            return strict ? ocn_strict_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, 1, kappa, kappa_e)
+                          : ocn_fast_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, 1, kappa, kappa_e);
+        return strict ? ocn_strict::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, 1, kappa, kappa_e)
+                      : ocn_fast::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, 1, kappa, kappa_e);
+    }
     st = launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, nullptr);
     if (st != OCN_SUCCESS || !terms->closure) return st;
-    OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
-    if (!xy_periodic(grid))
-        return strict ? ocn_strict::launch_tracer_diffusion_general(grid, kappa, kappa_e, c, Gc, range, s)
-                      : ocn_fast::launch_tracer_diffusion_general(grid, kappa, kappa_e, c, Gc, range, s);
     return strict ? ocn_strict::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s)
                   : ocn_fast::launch_tracer_diffusion(grid, kappa, kappa_e, c, Gc, range, s);
 }

@@ -418,7 +418,12 @@ static gen::Fields make_fields(const ocn_grid *grid, const double *u, const doub
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
                                    const int32_t box[4], int *launched, hipStream_t stream);
 int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
-                               const int32_t box[4], int *launched, hipStream_t stream);
+                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+#if !OCN_UPWIND
+// physics.hip (compiled for the WENO namespaces only; the extra terms do not depend on the advection scheme): the tiled finishing pass
+int launch_momentum_extra_box(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin);
+#endif
 
 // Interior box + wall frames.  The topology-conditional reconstructions of a Bounded direction differ from the Periodic ones only within
 // a stencil of the walls (topologically_conditional_interpolation.jl:46-52: full order for faces 4 .. N-2 and centres 3 .. N-2), so every
@@ -481,22 +486,30 @@ int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, cons
     return OCN_SUCCESS;
 }
 
+// diffusion != 0: Gc = -div_Uc - ∇_dot_qᶜ in the same call (κ a number or the field κₑ): the box kernel adds the diffusive flux divergence
+// to its advective one before the store (the epilogue of the Periodic grids' tiled kernel, same sum), the frames run both per-cell kernels
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream)
+                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion, double kappa, const double *kappa_e)
 {
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+    const GridDev gd = ocn::to_dev(*grid);
     int32_t box[4];
     if (interior_box(grid, centered2, range, box)) {
         int launched = 0;
-        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream);
+        ocn::TracerFuse tf{};
+        tf.diffusion = diffusion ? 1 : 0;
+        tf.kappa = kappa;
+        tf.kappa_e = kappa_e;
+        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, diffusion ? &tf : nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) {
             const gen::Fields F = make_fields(grid, u, v, w, centered2);
             for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
                 OCN_GEN_DIMS_VOID(fr);
                 hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, F, c, Gc, fr);
+                if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, kappa, kappa_e, c, Gc, fr);
             });
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
@@ -504,6 +517,7 @@ int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const do
     }
     OCN_GEN_DIMS(r);
     hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), c, Gc, r);
+    if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, kappa, kappa_e, c, Gc, r);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -514,6 +528,24 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+#if !OCN_UPWIND
+    // interior box (the tiled finishing pass with per-field layouts: every stress once per face, velocities through LDS) + wall frames
+    int32_t box[4];
+    if (interior_box(grid, 0, range, box)) {
+        int launched = 0;
+        st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, nullptr);
+        if (st != OCN_SUCCESS) return st;
+        if (launched) {
+            const gen::Fields F = make_fields(grid, u, v, w, 0);
+            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
+                OCN_GEN_DIMS_VOID(fr);
+                hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, F, t, Gu, Gv, Gw, fr);
+            });
+            OCN_CHECK_HIP(hipGetLastError());
+            return OCN_SUCCESS;
+        }
+    }
+#endif
     OCN_GEN_DIMS(r);
     hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, make_fields(grid, u, v, w, 0), t, Gu, Gv, Gw, r);
     OCN_CHECK_HIP(hipGetLastError());

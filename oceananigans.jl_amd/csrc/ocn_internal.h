@@ -129,7 +129,8 @@ namespace ocn_strict {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
                                        double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream);
+                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
+                                   const double *kappa_e = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
                                   double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
@@ -163,7 +164,8 @@ namespace ocn_fast {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
                                        double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream);
+                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
+                                   const double *kappa_e = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
                                   double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
@@ -199,7 +201,8 @@ namespace ocn_strict_up {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
                                        double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream);
+                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
+                                   const double *kappa_e = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
                                   double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
@@ -215,7 +218,8 @@ namespace ocn_fast_up {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
                                        double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream);
+                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
+                                   const double *kappa_e = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
                                   double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,

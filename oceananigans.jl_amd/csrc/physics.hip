@@ -198,24 +198,31 @@ struct ExtraLoads {
     double gm_u, gm_v, gm_w, ph_c, ph_w, ph_s, Gu_in, Gv_in, Gw_in, zb_w;
     bool w_cell;
 };
+// offsets of the cell (i, j, k) in the parent arrays of the Face fields where they differ from the centre fields' `o` (grids with a Bounded
+// x / y: one more point along it, grid_utils.jl:66-72; the interior box of general.hip) and the plane stride of w; NULL: all of them are `o`
+struct FieldOffs {
+    long long u, v, w, w3;
+};
 template <int TZ, bool HYD = false>
 __device__ __forceinline__ ExtraLoads momentum_extra_loads(const TermsDev &t, const ocn::MomentumFinal &mf, const PRange &r, int k, long long o,
                                                            long long s2, long long s3, const double *__restrict__ Gu,
-                                                           const double *__restrict__ Gv, const double *__restrict__ Gw)
+                                                           const double *__restrict__ Gv, const double *__restrict__ Gw,
+                                                           const FieldOffs *fo = nullptr)
 {
     constexpr bool ZF = (TZ == OCN_FLAT);
     ExtraLoads ld;
+    const long long ou = fo ? fo->u : o, ov = fo ? fo->v : o, ow = fo ? fo->w : o;
     const bool use_gm = mf.sc.has_zeta && (HYD || mf.sc.on);
-    ld.gm_u = use_gm ? mf.sub[0].Gm[o] : 0.0;
-    ld.gm_v = use_gm ? mf.sub[1].Gm[o] : 0.0;
+    ld.gm_u = use_gm ? mf.sub[0].Gm[ou] : 0.0;
+    ld.gm_v = use_gm ? mf.sub[1].Gm[ov] : 0.0;
     ld.w_cell = !HYD && k >= r.ow;
-    ld.gm_w = (use_gm && ld.w_cell) ? mf.sub[2].Gm[o] : 0.0;
+    ld.gm_w = (use_gm && ld.w_cell) ? mf.sub[2].Gm[ow] : 0.0;
     ld.ph_c = t.pHY ? t.pHY[o] : 0.0;
     ld.ph_w = t.pHY ? t.pHY[o - 1] : 0.0;
     ld.ph_s = t.pHY ? t.pHY[o - s2] : 0.0;
-    ld.Gu_in = (HYD || mf.pre) ? 0.0 : Gu[o];
-    ld.Gv_in = (HYD || mf.pre) ? 0.0 : Gv[o];
-    ld.Gw_in = (ld.w_cell && !mf.pre) ? Gw[o] : 0.0;
+    ld.Gu_in = (HYD || mf.pre) ? 0.0 : Gu[ou];
+    ld.Gv_in = (HYD || mf.pre) ? 0.0 : Gv[ov];
+    ld.Gw_in = (ld.w_cell && !mf.pre) ? Gw[ow] : 0.0;
     ld.zb_w = 0.0;  // maybe_z_dot_g_bᶜᶜᶠ: only without a separate hydrostatic pressure anomaly
     if (ld.w_cell && t.buoyancy && !t.pHY) ld.zb_w = ZF ? buoyancy_ccc(t, o) : 1 * (0.5 * (buoyancy_ccc(t, o - s3) + buoyancy_ccc(t, o)));
     return ld;
@@ -233,9 +240,10 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
                                                     FN NEf, double *__restrict__ Gu, double *__restrict__ Gv,
                                                     double *__restrict__ Gw, const PRange &r, const ocn::MomentumFinal &mf,
                                                     const ExtraLoads &ld, double G0u = 0.0, double G0v = 0.0, double *res = nullptr,
-                                                    const Stresses *sh = nullptr)
+                                                    const Stresses *sh = nullptr, const FieldOffs *fo = nullptr)
 {
     constexpr bool ZF = (TZ == OCN_FLAT);
+    const long long o_u = fo ? fo->u : o, o_v = fo ? fo->v : o, o_w = fo ? fo->w : o, w3 = fo ? fo->w3 : s3;
     const double dx = M.dx, dy = M.dy, nu = t.nu;
     const double dzc = M.dzC(k), dzf = M.dzF(k), dzf1 = ZF ? dzf : M.dzF(k + 1), dzcm = ZF ? dzc : M.dzC(k - 1);
 #if !OCN_STRICT
@@ -294,7 +302,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             if (k == 1 && mf.bottom[0].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(1));
             if (k == g.Nz && mf.top[0].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[0], i, j, g.Nx, Uf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
-        Gu[o] = G;
+        Gu[o_u] = G;
         if (HYD) {
             const double gm = gm_u;
             const double un = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
@@ -302,7 +310,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             res[0] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;  // ab2_step_G (compute_slow_tendencies.jl:34-46)
             res[1] = un;
         } else if (mf.sc.on)
-            mf.sub[0].out[o] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_u) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[0].out[o_u] = Uf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_u) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     {   // ---------------- Gv at (c,f,c)
         double G = Gv_in;
@@ -334,7 +342,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             if (k == 1 && mf.bottom[1].kind == OCN_BC_FLUX) G += ocn::bc_condition(mf.bottom[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(1));
             if (k == g.Nz && mf.top[1].kind == OCN_BC_FLUX) G -= ocn::bc_condition(mf.top[1], i, j, g.Nx, Vf(0, 0, 0)) * Az / (Az * M.dzC(g.Nz));
         }
-        Gv[o] = G;
+        Gv[o_v] = G;
         if (HYD) {
             const double gm = gm_v;
             const double vn = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm) : (mf.sc.dt * mf.sc.gamma) * G);
@@ -342,7 +350,7 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             res[2] = mf.sc.has_zeta ? mf.sc.gamma * G - (-mf.sc.zeta) * gm : mf.sc.gamma * G;
             res[3] = vn;
         } else if (mf.sc.on)
-            mf.sub[1].out[o] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_v) : (mf.sc.dt * mf.sc.gamma) * G);
+            mf.sub[1].out[o_v] = Vf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_v) : (mf.sc.dt * mf.sc.gamma) * G);
     }
     if (HYD) return;  // w is diagnostic in the hydrostatic model
     if (k >= r.ow) {  // ---------------- Gw at (c,c,f)
@@ -368,13 +376,13 @@ __device__ __forceinline__ void momentum_extra_cell(const GridDev &g, const Term
             }
             G = G - recip_volume(Az * dzf) * (((Axf * t13e - Axf * t13w) + (Ayf * t23n - Ayf * t23s)) + dzF);
         }
-        Gw[o] = G;
+        Gw[o_w] = G;
         const bool wall = (TZ == OCN_BOUNDED) && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face
-        if (mf.sc.on) mf.sub[2].out[o] = wall ? Wf(0, 0, 0) : Wf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_w) : (mf.sc.dt * mf.sc.gamma) * G);
+        if (mf.sc.on) mf.sub[2].out[o_w] = wall ? Wf(0, 0, 0) : Wf(0, 0, 0) + (mf.sc.has_zeta ? mf.sc.dt * (mf.sc.gamma * G + mf.sc.zeta * gm_w) : (mf.sc.dt * mf.sc.gamma) * G);
     } else if (mf.sc.on) {
-        mf.sub[2].out[o] = Wf(0, 0, 0);  // wall face (exclude_periphery): carried over unchanged
+        mf.sub[2].out[o_w] = Wf(0, 0, 0);  // wall face (exclude_periphery): carried over unchanged
     }
-    if (mf.sc.on && TZ == OCN_BOUNDED && k == g.Nz) mf.sub[2].out[o + s3] = Wf(0, 0, 1);  // top wall face k = Nz+1
+    if (mf.sc.on && TZ == OCN_BOUNDED && k == g.Nz) mf.sub[2].out[o_w + w3] = Wf(0, 0, 1);  // top wall face k = Nz+1
 }
 
 // `mf`: the flux boundary contributions of u, v (apply_flux_bcs.jl:107-160) and the NEXT stage's rk3 substep of u, v, w into a
@@ -405,7 +413,9 @@ __global__ __launch_bounds__(256) void momentum_extra_kernel(GridDev g, TermsDev
 // k-1, k, k+1 of u, v, w (and νₑ) live in a 3-slot LDS ring with a one-cell rim, so every value enters the workgroup once per
 // plane (1.33x with the rim) instead of once per stencil tap (~60 taps per cell hit L2 in the direct kernel: the 3 planes x
 // 4 fields of a workgroup do not fit the 32 KB L1).  pHY′, G, G⁻ are touched once per cell and stay in global memory.
-template <int TZ, bool SH>
+// GL ("general layouts"): the interior box of a grid with a Bounded x / y (general.hip) -- u, v, w (and their G, G⁻, stepped copies) have
+// their own parent layouts; every cell of the box is a full stencil away from the walls, where the expressions are the Periodic ones.
+template <int TZ, bool SH, bool GL = false>
 __global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev g, TermsDev t, const double *__restrict__ u,
                                                             const double *__restrict__ v, const double *__restrict__ w,
                                                             double *__restrict__ Gu, double *__restrict__ Gv,
@@ -429,27 +439,34 @@ __global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev 
     const Metrics M = make_metrics(g);
     const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
     const long long s2 = L.s2, s3 = L.s3;
+    const Lay LFu = GL ? ocn::make_lay(g, OCN_LOC_FCC) : L, LFv = GL ? ocn::make_lay(g, OCN_LOC_CFC) : L, LFw = GL ? ocn::make_lay(g, OCN_LOC_CCF) : L;
     const bool has_nu = t.nu_e != nullptr;
     // Staging of plane kk (tile + rim, indices clamped to the first halo cell) into ring slot kk % 3 is split in two so that the
     // global loads of plane k+2 are in flight while plane k is being computed: fetch() -> registers, commit() -> LDS.
     constexpr int NS = (PL + TX * TY - 1) / (TX * TY);  // cells staged per thread (2)
-    long long soff[NS];
+    long long soff[NS], soffu[GL ? NS : 1], soffv[GL ? NS : 1], soffw[GL ? NS : 1];
     bool son[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
         const int idx = tid + q * TX * TY;
         son[q] = idx < PL;
         const int li = son[q] ? idx % SX : 0, lj = son[q] ? idx / SX : 0;
-        soff[q] = ocn::at(L, min(i0 - 1 + li, g.Nx + 1), min(j0 - 1 + lj, g.Ny + 1), 0);  // plane 0: add kk * s3
+        const int si = min(i0 - 1 + li, g.Nx + 1), sj = min(j0 - 1 + lj, g.Ny + 1);
+        soff[q] = ocn::at(L, si, sj, 0);  // plane 0: add kk * s3
+        if (GL) {
+            soffu[q] = ocn::at(LFu, si, sj, 0);
+            soffv[q] = ocn::at(LFv, si, sj, 0);
+            soffw[q] = ocn::at(LFw, si, sj, 0);
+        }
     }
     double fu[NS], fv[NS], fw[NS], fn[NS];
     auto fetch = [&](int kk) {
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const long long oo = soff[q] + (long long)kk * s3;
-            fu[q] = son[q] ? u[oo] : 0.0;
-            fv[q] = son[q] ? v[oo] : 0.0;
-            fw[q] = son[q] ? w[oo] : 0.0;
+            fu[q] = son[q] ? u[GL ? soffu[q] + (long long)kk * LFu.s3 : oo] : 0.0;
+            fv[q] = son[q] ? v[GL ? soffv[q] + (long long)kk * LFv.s3 : oo] : 0.0;
+            fw[q] = son[q] ? w[GL ? soffw[q] + (long long)kk * LFw.s3 : oo] : 0.0;
             fn[q] = (son[q] && has_nu) ? t.nu_e[oo] : 0.0;
         }
     };
@@ -486,9 +503,12 @@ __global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev 
     for (int k = kb; k <= ke; ++k) {
         commit(k + 1);
         __syncthreads();
-        const long long o = ocn::at(L, active ? i : r.i1, active ? j : r.j1, k);
+        const int ia = active ? i : r.i1, ja = active ? j : r.j1;
+        const long long o = ocn::at(L, ia, ja, k);
+        const FieldOffs fov{GL ? ocn::at(LFu, ia, ja, k) : o, GL ? ocn::at(LFv, ia, ja, k) : o, GL ? ocn::at(LFw, ia, ja, k) : o, GL ? LFw.s3 : s3};
+        const FieldOffs *fo = GL ? &fov : nullptr;
         ExtraLoads ld{};
-        if (active) ld = momentum_extra_loads<TZ>(t, mf, r, k, o, s2, s3, Gu, Gv, Gw);  // this plane's own values first ...
+        if (active) ld = momentum_extra_loads<TZ>(t, mf, r, k, o, s2, s3, Gu, Gv, Gw, fo);  // this plane's own values first ...
         OCN_ISSUE_LOADS_HERE();
         if (k < ke) fetch(k + 2);  // ... then the staging values of plane k + 2, consumed by the next iteration's commit
         OCN_ISSUE_LOADS_HERE();
@@ -571,7 +591,7 @@ __global__ __launch_bounds__(256, SH ? 3 : 4) void momentum_extra_tiled(GridDev 
                 [&](int a, int b, int c) { return Lv[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Lw[(base + c) % 3][c0 + a + b * SX]; },
                 [&](int a, int b, int c) { return Ln[(base + c) % 3][c0 + a + b * SX]; }, Gu, Gv, Gw, r, mf, ld, 0.0, 0.0, nullptr,
-                SH ? &sh : nullptr);
+                SH ? &sh : nullptr, fo);
         }
         // Unshared: everyone must be done with slot (k - 1) % 3 before the next iteration's commit overwrites it.  Shared: nothing reads plane
         // k - 1 after the first iteration's stress phase (T13, T23 of plane k and T33 of k - 1 are carried), which the barrier above already
@@ -864,6 +884,44 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
     }
     const dim3 block = ocn::range_block(r.i1 - r.i0 + 1), nb = ocn::range_grid(block, r.i1 - r.i0 + 1, r.j1 - r.j0 + 1, r.k1 - r.k0 + 1);
     OCN_LAUNCH_TZ(momentum_extra_kernel, g, t, u, v, w, Gu, Gv, Gw, r, mf);
+    return OCN_SUCCESS;
+}
+
+// The finishing pass on the INTERIOR BOX {i0, i1, j0, j1} of a grid with walls in x / y (general.hip: every cell at least a full stencil
+// away from the walls, where the per-cell kernel with its run-time topology evaluates exactly these expressions): the tiled kernel with
+// per-field parent layouts.  *launched = 0 when the box is too small for the tiles (the caller then runs the per-cell kernel everywhere).
+int launch_momentum_extra_box(const ocn_grid *grid, const TermsDev &t, const double *u, const double *v, const double *w, double *Gu, double *Gv,
+                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin)
+{
+    *launched = 0;
+    ocn::MomentumFinal mf{};
+    if (fin) mf = *fin;
+    mf.xcd = xcd_remap_on();
+    static const bool share_env = !(getenv("OCN_SHARE_STRESSES") && getenv("OCN_SHARE_STRESSES")[0] == '0');
+    const bool share = share_env && t.closure != 0;
+    PRange r;
+    r.i0 = box[0]; r.i1 = box[1]; r.j0 = box[2]; r.j1 = box[3]; r.k0 = 1; r.k1 = grid->Nz;
+    r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = grid->Nz;
+    if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4 || grid->Hz < 1) return OCN_SUCCESS;
+    GridDev g = ocn::to_dev(*grid);
+    const int tiles = ((wx + 31) / 32) * ((wy + 7) / 8);
+    int KZ = wz;
+    while (KZ > 16 && tiles * ((wz + KZ - 1) / KZ) < 4096) KZ = (KZ + 1) / 2;
+    dim3 nbt((wx + 31) / 32, (wy + 7) / 8, (wz + KZ - 1) / KZ);
+    if (grid->tz == OCN_PERIODIC) {
+        if (share)
+            hipLaunchKernelGGL((momentum_extra_tiled<OCN_PERIODIC, true, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        else
+            hipLaunchKernelGGL((momentum_extra_tiled<OCN_PERIODIC, false, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+    } else {
+        if (share)
+            hipLaunchKernelGGL((momentum_extra_tiled<OCN_BOUNDED, true, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+        else
+            hipLaunchKernelGGL((momentum_extra_tiled<OCN_BOUNDED, false, true>), nbt, dim3(256), 0, stream, g, t, u, v, w, Gu, Gv, Gw, r, mf, KZ);
+    }
+    OCN_CHECK_HIP(hipGetLastError());
+    *launched = 1;
     return OCN_SUCCESS;
 }
 

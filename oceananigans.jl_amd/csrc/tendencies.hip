@@ -1236,7 +1236,7 @@ int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const 
 }
 
 int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
-                               const int32_t box[4], int *launched, hipStream_t stream)
+                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse)
 {
     *launched = 0;
     Range r;
@@ -1247,6 +1247,7 @@ int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const doub
     if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
     ocn::TracerFuse tf{};
+    if (fuse) tf = *fuse;  // (diffusion, bottom / top fluxes, the next substep: all on centre fields, whose layout has no walls in it)
     constexpr int TX = 32, TY = 8;
     const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
     int KZ = wz;

@@ -300,33 +300,64 @@ def test_advective_tendencies_fast_tolerance(oracle, ocn, size, topo):
         assert np.abs(from_dev(b) - a).max() <= 1e-12 * max(np.abs(a).max(), 1e-300)
 
 
-@pytest.mark.parametrize("size,topo", CASES)
-def test_extra_terms_and_diffusion_strict_bitwise(oracle, ocn, size, topo):
+@pytest.mark.parametrize("size,topo", CASES + BOX_CASES)
+@pytest.mark.parametrize("variant", ["numbers-centered", "numbers-weno", "fields-weno"])
+def test_extra_terms_and_diffusion_strict_bitwise(oracle, ocn, size, topo, variant):
     """FPlane Coriolis with the active-node weighting near walls, ScalarDiffusivity stress divergence and tracer diffusion, BuoyancyTracer
-    acting on w (no separate pHY'): added to G in the reference's order, bit-identical to the oracle"""
+    acting on w (no separate pHY'): added to G in the reference's order, bit-identical to the oracle.  On the BOX_CASES the cells a full
+    stencil away from the walls take the tiled finishing pass with per-field layouts (stresses shared through LDS) and the tiled tracer
+    kernel with the diffusive flux divergence folded in, the frames the per-cell kernels.  "fields": the eddy viscosity / diffusivity arrays
+    of an LES closure in place of the numbers, and a separate hydrostatic pressure anomaly with SeawaterBuoyancy."""
     O = oracle
+    weno = variant.endswith("weno")
+    fields = variant.startswith("fields")
+    if weno and any(n < 3 for n, t in zip(size, topo) if t != "F"):
+        pytest.skip("WENO needs 3 cells")
+    if not weno and (size, topo) in BOX_CASES[2:]:
+        pytest.skip("covered by the WENO variants")
     rng = np.random.default_rng(13)
     og, pg = _pair(O, ocn, size, topo)
     u, v, w, c = _filled(O, og, rng)
-    ph = O.Physics(f=0.7, nu=0.013, kappa=0.021, buoyancy="BuoyancyTracer")
+    sch = O.ADV_WENO5 if weno else O.ADV_CENTERED2
     G = [og.zeros(l) for l in LOCS]
-    O.momentum_tendencies(og, u, v, w, *G, scheme=O.ADV_CENTERED2)
-    O.momentum_extra_tendencies(og, ph, u, v, w, c, None, None, *G)
     Gc = og.zeros(0)
-    O.tracer_tendency(og, u, v, w, c, Gc, scheme=O.ADV_CENTERED2)
-    O.tracer_diffusion(og, 0.021, c, Gc)
+    O.momentum_tendencies(og, u, v, w, *G, scheme=sch)
+    O.tracer_tendency(og, u, v, w, c, Gc, scheme=sch)
+    nu_e = kappa_e = pHY = S = None
+    if fields:
+        nu_e, kappa_e, pHY, S = (np.abs(random_parent(og, 0, rng)) * sc for sc in (0.02, 0.03, 1.0, 1.0))
+        for a in (nu_e, kappa_e, pHY, S):
+            O.fill_halo_regions(og, a, 0)
+        ph = O.Physics(f=0.7, nu=0.0, kappa=0.0, buoyancy=("SeawaterBuoyancy", 9.81, 2e-4, 8e-4))
+        O.momentum_extra_tendencies(og, ph, u, v, w, c, S, pHY, *G, nu_e=nu_e)
+        O.tracer_diffusion(og, 0.0, c, Gc, kappa_e=kappa_e)
+    else:
+        ph = O.Physics(f=0.7, nu=0.013, kappa=0.021, buoyancy="BuoyancyTracer")
+        O.momentum_extra_tendencies(og, ph, u, v, w, c, None, None, *G)
+        O.tracer_diffusion(og, 0.021, c, Gc)
     ocn.set_math_mode(ocn.MATH_STRICT)
     du, dv, dw, dc = (to_dev(ocn, pg, l, a) for l, a in zip(LOCS + (0,), (u, v, w, c)))
     dG = [ocn.Field(l, pg) for l in LOCS]
     dGc = ocn.Field(0, pg)
     t = ocn._lib.CModelTerms()
-    t.advection, t.coriolis, t.f, t.closure, t.nu = ocn._lib.ADVECTION_CENTERED2, 1, 0.7, 1, 0.013
-    t.buoyancy, t.T = ocn._lib.BUOYANCY_TRACER, dc.ptr
+    t.advection = ocn._lib.ADVECTION_WENO5 if weno else ocn._lib.ADVECTION_CENTERED2
+    t.coriolis, t.f = 1, 0.7
+    keep = []
+    if fields:
+        dn, dk, dp, dS = (to_dev(ocn, pg, 0, a) for a in (nu_e, kappa_e, pHY, S))
+        keep = [dn, dk, dp, dS]
+        t.closure, t.nu_e = 2, dn.ptr
+        t.buoyancy, t.g, t.alpha, t.beta, t.T, t.S, t.pHY = ocn._lib.BUOYANCY_SEAWATER_TS, 9.81, 2e-4, 8e-4, dc.ptr, dS.ptr, dp.ptr
+    else:
+        t.closure, t.nu = 1, 0.013
+        t.buoyancy, t.T = ocn._lib.BUOYANCY_TRACER, dc.ptr
     ocn._lib.call("ocn_compute_momentum_tendencies_terms", pg.cref, C.byref(t), du.ptr, dv.ptr, dw.ptr, dG[0].ptr, dG[1].ptr, dG[2].ptr, None, 0)
-    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.021, None, du.ptr, dv.ptr, dw.ptr, dc.ptr, dGc.ptr, None, 0)
+    ocn._lib.call("ocn_compute_tracer_tendency_terms", pg.cref, C.byref(t), 0.0 if fields else 0.021, dk.ptr if fields else None, du.ptr, dv.ptr,
+                  dw.ptr, dc.ptr, dGc.ptr, None, 0)
     ocn.sync_device()
     for a, b, name in zip(G + [Gc], dG + [dGc], ("Gu", "Gv", "Gw", "Gc")):
-        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} {name}")
+        np.testing.assert_array_equal(from_dev(b), a, err_msg=f"{topo} {variant} {name}")
+    del keep
 
 
 @pytest.mark.parametrize("size,topo", [((12, 10, 9), "PBB"), ((11, 9, 8), "BBB"), ((16, 1, 10), "PFB")])
