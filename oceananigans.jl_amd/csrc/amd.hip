@@ -17,9 +17,10 @@ namespace OCN_NS {
 using ocn::GridDev;
 using ocn::Lay;
 
-// GEN = false: x, y Periodic -- one parent layout (strides, interior offset) serves u, v, w and the centre fields.  GEN = true: a Bounded
+// GEN = 0: x, y Periodic -- one parent layout (strides, interior offset) serves u, v, w and the centre fields.  GEN = 1: walls, no Flat
+// direction (per-field strides, a step in x is one element: the x offsets of the stencil stay immediates of the loads).  GEN = 2: a Bounded
 // x / y gives the Face fields one more point along it, so every field has its own strides (grid_utils.jl:66-72).
-template <bool GEN>
+template <int GEN>
 struct Amd {
     const double *u, *v, *w, *c;  // pointers at the cell (i, j, k)
     long long s2, s3;             // centre fields
@@ -30,16 +31,17 @@ struct Amd {
     double dx, dy, Fx, Fy;
     Metrics M;
     int k;  // 1-based k of the cell, for the z metrics
-    __device__ __forceinline__ double U(int a, int b, int d) const { return GEN ? u[a * sa + b * u2 + d * u3] : u[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double V(int a, int b, int d) const { return GEN ? v[a * sa + b * v2 + d * v3] : v[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double W(int a, int b, int d) const { return GEN ? w[a * sa + b * w2 + d * w3] : w[a + b * s2 + d * s3]; }
-    __device__ __forceinline__ double C(int a, int b, int d) const { return c[a * (GEN ? sa : 1) + b * s2 + d * s3]; }
+    __device__ __forceinline__ int SA() const { return GEN == 2 ? sa : 1; }
+    __device__ __forceinline__ double U(int a, int b, int d) const { return GEN ? u[a * SA() + b * u2 + d * u3] : u[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double V(int a, int b, int d) const { return GEN ? v[a * SA() + b * v2 + d * v3] : v[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double W(int a, int b, int d) const { return GEN ? w[a * SA() + b * w2 + d * w3] : w[a + b * s2 + d * s3]; }
+    __device__ __forceinline__ double C(int a, int b, int d) const { return c[a * SA() + b * s2 + d * s3]; }
     __device__ __forceinline__ double Fz(int d) const { return 2 * M.dzC(k + d); }
 };
 
 __device__ __forceinline__ double julia_max0(double x) { return (x > 0 || x != x) ? x : 0.0; }
 
-template <bool GEN>
+template <int GEN>
 __device__ __forceinline__ Amd<GEN> make_amd(const GridDev &g, const double *u, const double *v, const double *w, const double *c, int i,
                                             int j, int k)
 {
@@ -53,8 +55,8 @@ __device__ __forceinline__ Amd<GEN> make_amd(const GridDev &g, const double *u, 
         const Lay Lu = ocn::make_lay(g, OCN_LOC_FCC), Lv = ocn::make_lay(g, OCN_LOC_CFC), Lw = ocn::make_lay(g, OCN_LOC_CCF);
         A.u = u + ocn::at(Lu, i, j, k); A.v = v + ocn::at(Lv, i, j, k); A.w = w + ocn::at(Lw, i, j, k);
         A.u2 = Lu.s2; A.u3 = Lu.s3; A.v2 = Lv.s2; A.v3 = Lv.s3; A.w2 = Lw.s2; A.w3 = Lw.s3;
-        if (g.tx == OCN_FLAT) A.sa = 0;
-        if (g.ty == OCN_FLAT) A.u2 = A.v2 = A.w2 = A.s2 = 0;
+        if (GEN == 2 && g.tx == OCN_FLAT) A.sa = 0;
+        if (GEN == 2 && g.ty == OCN_FLAT) A.u2 = A.v2 = A.w2 = A.s2 = 0;
     } else {
         A.u = u + o; A.v = v + o; A.w = w + o;
         A.u2 = A.v2 = A.w2 = L.s2; A.u3 = A.v3 = A.w3 = L.s3;
@@ -92,7 +94,7 @@ struct AmdTracers {
 #define I4PR(f, g) (0.25 * ((f[0][0] * g[0][0] + f[1][0] * g[1][0]) + (f[0][1] * g[0][1] + f[1][1] * g[1][1])))
 #endif
 
-template <bool GEN>
+template <int GEN>
 __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu, const double *__restrict__ u,
                                                         const double *__restrict__ v, const double *__restrict__ w,
                                                         double *__restrict__ nu_e, AmdTracers tr, int i0, int i1, int KZ, int xcd)
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void amd_fused_kernel(GridDev g, double Cnu
             if (n >= tr.n) break;
             const double *pc = tr.c[n] + o;
             const long long s2 = A.s2, s3 = A.s3;
-            const int sa = GEN ? A.sa : 1;
+            const int sa = A.SA();
             const double c0 = tc0[n], cT = pc[s3];
             const double gx0 = AMD_G(Fx, c0 - pc[-sa], qdx), gx1 = AMD_G(Fx, pc[sa] - c0, qdx);             // norm_∂x_c at i, i+1
             const double gy0 = AMD_G(Fy, c0 - pc[-s2], qdy), gy1 = AMD_G(Fy, pc[s2] - c0, qdy);             // norm_∂y_c at j, j+1
@@ -313,11 +315,12 @@ int launch_amd_fused(const ocn_grid *grid, double Cnu, const double *u, const do
     const long long tiles = (long long)((wx + block.x - 1) / block.x) * ((g.Ny + block.y - 1) / block.y);
     while (KZ > 1 && tiles * ((g.Nz + KZ - 1) / KZ) < 2048) KZ = (KZ + 1) / 2;  // narrow ranges: keep the chip full
     const dim3 nb = ocn::range_grid(block, wx, g.Ny, (g.Nz + KZ - 1) / KZ);
-    if (ocn::x_wall_west(*grid) || ocn::x_wall_east(*grid) || grid->ty == OCN_BOUNDED || grid->tx == OCN_FLAT ||
-        grid->ty == OCN_FLAT)  // per-field parent layouts; zero strides along a Flat direction
-        hipLaunchKernelGGL(amd_fused_kernel<true>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
+    if (grid->tx == OCN_FLAT || grid->ty == OCN_FLAT)  // zero strides along a Flat direction
+        hipLaunchKernelGGL(amd_fused_kernel<2>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
+    else if (ocn::x_wall_west(*grid) || ocn::x_wall_east(*grid) || grid->ty == OCN_BOUNDED)  // per-field parent layouts
+        hipLaunchKernelGGL(amd_fused_kernel<1>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     else
-        hipLaunchKernelGGL(amd_fused_kernel<false>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
+        hipLaunchKernelGGL(amd_fused_kernel<0>, nb, block, 0, stream, g, Cnu, u, v, w, nu_e, tr, i0, i1, KZ, xcd);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
