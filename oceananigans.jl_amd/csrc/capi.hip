@@ -245,8 +245,17 @@ int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, c
     OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_rk3: G⁻ pointers are required when has_zeta != 0");
     OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_rk3: outputs must not alias the inputs");
     if (!xy_periodic(grid)) {
-        set_error("the fused stage boundaries need Periodic x and y: use ocn_compute_momentum_tendencies + ocn_rk3_substep on this grid");
-        return OCN_ERR_UNSUPPORTED;
+        // walls in x / y: the substep as the epilogue of the tiled kernel on the interior box, as one more per-cell kernel on the wall frames
+        // (wall faces carried over); no correction on load (its wrapped indices are the Periodic grids')
+        OCN_REQUIRE(!p_correct, "ocn_compute_momentum_tendencies_rk3: the pressure correction on load needs Periodic x and y");
+        OCN_REQUIRE(!range, "ocn_compute_momentum_tendencies_rk3: ranges need Periodic x and y");
+        MomentumFinal mf{};
+        mf.sub[0] = SubstepDev{Gmu, u_out};
+        mf.sub[1] = SubstepDev{Gmv, v_out};
+        mf.sub[2] = SubstepDev{Gmw, w_out};
+        mf.sc = SubstepCoef{dt, gamma, zeta, 1, has_zeta ? 1 : 0};
+        return strict_math(grid) ? ocn_strict::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, nullptr, as_stream(stream), &mf)
+                                 : ocn_fast::launch_momentum_tendencies_general(grid, 0, u, v, w, Gu, Gv, Gw, nullptr, as_stream(stream), &mf);
     }
     FuseArgs fz{};
     fz.Gm[0] = Gmu; fz.Gm[1] = Gmv; fz.Gm[2] = Gmw;
@@ -352,17 +361,13 @@ static int launch_advective_tracer(int advection, const ocn_grid *grid, const do
                                    double *Gc, const int32_t *range, hipStream_t s, const TracerFuse *tf)
 {
     const bool strict = strict_math(grid);
-    if (!xy_periodic(grid)) {
-        if (tf) {
-            set_error("the fused tracer stage boundary needs Periodic x and y");
-            return OCN_ERR_UNSUPPORTED;
-        }
+    if (!xy_periodic(grid)) {  // (tf: diffusion / bottom and top fluxes / the next substep ride along, general.hip)
         const int c2 = advection == OCN_ADVECTION_CENTERED2;
         if (advection == OCN_ADVECTION_UPWIND5)
-            return strict ? ocn_strict_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s)
-                          : ocn_fast_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s);
-        return strict ? ocn_strict::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s)
-                      : ocn_fast::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s);
+            return strict ? ocn_strict_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, tf)
+                          : ocn_fast_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, tf);
+        return strict ? ocn_strict::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, tf)
+                      : ocn_fast::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, tf);
     }
     switch (advection) {
         case OCN_ADVECTION_WENO5:
@@ -507,12 +512,11 @@ int ocn_compute_tracer_tendency_terms(const ocn_grid *grid, const ocn_model_term
     hipStream_t s = as_stream(stream);
     OCN_REQUIRE(!kappa_e || terms->closure == 2, "kappa_e is only meaningful with closure == 2");
     if (!xy_periodic(grid) && terms->closure) {  // advection and diffusion in one call: the interior box adds both before its store
-        const int c2 = terms->advection == OCN_ADVECTION_CENTERED2;
-        if (terms->advection == OCN_ADVECTION_UPWIND5)
-            return strict ? ocn_strict_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, 1, kappa, kappa_e)
-                          : ocn_fast_up::launch_tracer_tendency_general(grid, 0, u, v, w, c, Gc, range, s, 1, kappa, kappa_e);
-        return strict ? ocn_strict::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, 1, kappa, kappa_e)
-                      : ocn_fast::launch_tracer_tendency_general(grid, c2, u, v, w, c, Gc, range, s, 1, kappa, kappa_e);
+        TracerFuse tf{};
+        tf.diffusion = 1;
+        tf.kappa = kappa;
+        tf.kappa_e = kappa_e;
+        return launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, &tf);
     }
     st = launch_advective_tracer(terms->advection, grid, u, v, w, c, Gc, range, s, nullptr);
     if (st != OCN_SUCCESS || !terms->closure) return st;
@@ -646,15 +650,17 @@ static int flux_side(const ocn_grid *grid, const ocn_field_bcs *b, const char *n
     bottom = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
     top = ZBc{OCN_BC_DEFAULT, 0.0, 0.0, nullptr};
     if (!b) return OCN_SUCCESS;
-    OCN_REQUIRE(b->west.kind == OCN_BC_DEFAULT && b->east.kind == OCN_BC_DEFAULT && b->south.kind == OCN_BC_DEFAULT &&
-                    b->north.kind == OCN_BC_DEFAULT, "%s: only bottom / top boundary conditions are supported", name);
+    // (Value / Gradient / Open conditions on x / y walls live in the halo fills; FLUXES through them are added by ocn_apply_flux_bcs on the
+    //  unfused path only)
+    OCN_REQUIRE(b->west.kind != OCN_BC_FLUX && b->east.kind != OCN_BC_FLUX && b->south.kind != OCN_BC_FLUX && b->north.kind != OCN_BC_FLUX,
+                "%s: the fused stage boundaries take flux conditions at the bottom / top only", name);
     const ocn_bc *side[2] = {&b->bottom, &b->top};
     for (int sd = 0; sd < 2; ++sd) {
         const ocn_bc &c = *side[sd];
         OCN_REQUIRE(c.kind >= OCN_BC_DEFAULT && c.kind <= OCN_BC_OPEN, "%s: unknown boundary condition kind %d", name, c.kind);
         if (c.kind != OCN_BC_FLUX) continue;
         OCN_REQUIRE(grid->tz == OCN_BOUNDED, "bottom / top boundary conditions need a Bounded z (topology %d)", grid->tz);
-        OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions are not supported on a partitioned grid");
+        OCN_REQUIRE(!c.values || grid->tx == OCN_PERIODIC, "array boundary conditions need a Periodic x (not partitioned, no x walls)");
         ZBc &d = sd ? top : bottom;
         d.kind = c.kind; d.value = c.value; d.coeff = c.coeff; d.values = c.values;
     }
@@ -669,10 +675,7 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
-    if (!xy_periodic(grid)) {
-        set_error("ocn_compute_momentum_tendencies_terms_rk3: the fused stage boundaries need Periodic x and y");
-        return OCN_ERR_UNSUPPORTED;
-    }
+    OCN_REQUIRE(xy_periodic(grid) || !range, "ocn_compute_momentum_tendencies_terms_rk3: ranges need Periodic x and y");
     OCN_REQUIRE(u && v && w && Gu && Gv && Gw && u_out && v_out && w_out, "ocn_compute_momentum_tendencies_terms_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || (Gmu && Gmv && Gmw), "ocn_compute_momentum_tendencies_terms_rk3: G⁻ pointers are required when has_zeta != 0");
     OCN_REQUIRE(u_out != u && v_out != v && w_out != w, "ocn_compute_momentum_tendencies_terms_rk3: outputs must not alias the inputs");
@@ -688,6 +691,14 @@ int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_mo
     const bool strict = strict_math(grid);
     hipStream_t s = as_stream(stream);
     TermsDev t = to_dev(*terms);
+    if (!xy_periodic(grid)) {
+        // walls in x / y: advection (box + frames), then the finishing pass in the reference's order with the boundary fluxes and the substep --
+        // inside the tiled kernel on the interior box, as per-cell kernels on the frames (general.hip)
+        st = launch_advective_momentum(terms->advection, grid, u, v, w, Gu, Gv, Gw, nullptr, s);
+        if (st != OCN_SUCCESS) return st;
+        return strict ? ocn_strict::launch_momentum_extra_general(grid, t, u, v, w, Gu, Gv, Gw, nullptr, s, &mf)
+                      : ocn_fast::launch_momentum_extra_general(grid, t, u, v, w, Gu, Gv, Gw, nullptr, s, &mf);
+    }
     static const bool extra_first = !(std::getenv("OCN_EXTRA_FIRST") && std::getenv("OCN_EXTRA_FIRST")[0] == '0');
     if (!strict && extra_first && terms->advection != OCN_ADVECTION_CENTERED2) {
         // Fast math: the finishing pass runs FIRST and leaves the non-advective terms (and the u / v boundary fluxes) in G; the WENO
@@ -721,10 +732,7 @@ int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
-    if (!xy_periodic(grid)) {
-        set_error("ocn_compute_tracer_tendency_terms_rk3: the fused stage boundaries need Periodic x and y");
-        return OCN_ERR_UNSUPPORTED;
-    }
+    OCN_REQUIRE(xy_periodic(grid) || !range, "ocn_compute_tracer_tendency_terms_rk3: ranges need Periodic x and y");
     OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
     OCN_REQUIRE(u && v && w && c && Gc && c_out, "ocn_compute_tracer_tendency_terms_rk3: null field pointer");
     OCN_REQUIRE(!has_zeta || Gmc, "ocn_compute_tracer_tendency_terms_rk3: G⁻ is required when has_zeta != 0");
@@ -749,12 +757,9 @@ int ocn_compute_tracer_pair_tendency_terms_rk3(const ocn_grid *grid, const ocn_m
 {
     int st = validate_terms(grid, terms);
     if (st != OCN_SUCCESS) return st;
-    if (!xy_periodic(grid)) {
-        set_error("ocn_compute_tracer_pair_tendency_terms_rk3: the fused stage boundaries need Periodic x and y");
-        return OCN_ERR_UNSUPPORTED;
-    }
     OCN_REQUIRE(launched, "ocn_compute_tracer_pair_tendency_terms_rk3: launched is NULL");
     *launched = 0;
+    if (!xy_periodic(grid)) return OCN_SUCCESS;  // walls in x / y: one tracer per launch (ocn_compute_tracer_tendency_terms_rk3)
     OCN_REQUIRE(terms->advection != OCN_ADVECTION_CENTERED2, "ocn_compute_tracer_pair_tendency_terms_rk3: advection must be WENO5 or UpwindBiased5");
     OCN_REQUIRE(u && v && w && c && Gc && c_out && kappa, "ocn_compute_tracer_pair_tendency_terms_rk3: null pointer");
     TracerFuse tf[2];

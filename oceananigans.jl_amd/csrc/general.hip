@@ -370,6 +370,79 @@ __global__ __launch_bounds__(256) void tracer_diffusion_general(GridDev g, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The fused stage boundary on the FRAMES of a grid with walls (the interior box takes the epilogues of the tiled kernels): the bottom / top
+// flux contributions (apply_z_bcs!, apply_flux_bcs.jl:107-160) added to a complete G, then the NEXT stage's rk3_substep! into the second
+// storage (runge_kutta_3.jl:150-175) -- the expressions of momentum_extra_cell / tracer_finish.  Wall faces (the excluded periphery of a
+// Face field along a Bounded direction: first index, and the face N + 1 behind the last cell) are carried over unchanged.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double substep_value(const ocn::SubstepCoef &sc, double U, double G, const double *Gm, long long o)
+{
+    return U + (sc.has_zeta ? sc.dt * (sc.gamma * G + sc.zeta * Gm[o]) : (sc.dt * sc.gamma) * G);
+}
+
+__global__ __launch_bounds__(256) void momentum_finish_general(gen::Fields F, double *__restrict__ Gu, double *__restrict__ Gv, double *__restrict__ Gw,
+                                                               ocn::MomentumFinal mf, gen::GRange r)
+{
+    using namespace gen;
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const GridDev &g = F.g;
+    const Metrics M = make_metrics(g);
+    const double Az = M.Az;
+    const bool zb = g.tz == OCN_BOUNDED;
+    for (int f = 0; f < 2; ++f) {  // u, v
+        const Lay &L = f ? F.Lv : F.Lu;
+        const double *U = f ? F.v : F.u;
+        double *G_ = f ? Gv : Gu;
+        const long long o = ocn::at(L, i, j, k);
+        const double val = U[o];
+        const bool stepped = f ? (j >= r.ov) : (i >= r.ou);
+        double G = G_[o];
+        if (zb) {  // (apply_z_bcs! runs over every column of the grid, the excluded wall faces included: their G is never read)
+            bool touched = false;
+            if (k == 1 && mf.bottom[f].kind == OCN_BC_FLUX) { G += ocn::bc_condition(mf.bottom[f], i, j, g.Nx, val) * Az / (Az * M.dzC(1)); touched = true; }
+            if (k == g.Nz && mf.top[f].kind == OCN_BC_FLUX) { G -= ocn::bc_condition(mf.top[f], i, j, g.Nx, val) * Az / (Az * M.dzC(g.Nz)); touched = true; }
+            if (touched) G_[o] = G;
+        }
+        if (mf.sc.on) mf.sub[f].out[o] = stepped ? substep_value(mf.sc, val, G, mf.sub[f].Gm, o) : val;
+        if (mf.sc.on) {  // the wall face behind the last cell
+            if (!f && i == g.Nx && g.xe) { const long long o2 = ocn::at(L, g.Nx + 1, j, k); mf.sub[0].out[o2] = U[o2]; }
+            if (f && j == g.Ny && g.ty == OCN_BOUNDED) { const long long o2 = ocn::at(L, i, g.Ny + 1, k); mf.sub[1].out[o2] = U[o2]; }
+        }
+    }
+    if (mf.sc.on) {
+        const long long o = ocn::at(F.Lw, i, j, k);
+        const double val = F.w[o];
+        const bool wall = zb && k == 1 && g.Nz > 1;  // rk3_substep! never steps the wall face
+        mf.sub[2].out[o] = (k >= r.ow && !wall) ? substep_value(mf.sc, val, Gw[o], mf.sub[2].Gm, o) : val;
+        if (zb && k == g.Nz) mf.sub[2].out[o + F.Lw.s3] = F.w[o + F.Lw.s3];
+    }
+}
+
+__global__ __launch_bounds__(256) void tracer_finish_general(GridDev g, const double *__restrict__ c, double *__restrict__ Gc, ocn::TracerFuse tf,
+                                                             gen::GRange r)
+{
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1) return;
+    const Metrics M = make_metrics(g);
+    const double az = M.Az;
+    const long long o = ocn::at(ocn::make_lay(g, OCN_LOC_CCC), i, j, k);
+    const double c0 = c[o];
+    double G = Gc[o];
+    if (g.tz == OCN_BOUNDED) {
+        bool touched = false;
+        if (k == 1 && tf.bottom.kind == OCN_BC_FLUX) { G += ocn::bc_condition(tf.bottom, i, j, g.Nx, c0) * az / (az * M.dzC(1)); touched = true; }
+        if (k == g.Nz && tf.top.kind == OCN_BC_FLUX) { G -= ocn::bc_condition(tf.top, i, j, g.Nx, c0) * az / (az * M.dzC(g.Nz)); touched = true; }
+        if (touched) Gc[o] = G;
+    }
+    if (tf.sc.on) tf.sub.out[o] = substep_value(tf.sc, c0, G, tf.sub.Gm, o);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
 static int make_grange(const ocn_grid *grid, const int32_t *range, gen::GRange &r)
@@ -416,7 +489,7 @@ static gen::Fields make_fields(const ocn_grid *grid, const double *u, const doub
 
 // tendencies.hip (same namespace): the LDS-tiled kernels over the interior box of a grid with walls in x / y
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
-                                   const int32_t box[4], int *launched, hipStream_t stream);
+                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse = nullptr);
 int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
                                const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 #if !OCN_UPWIND
@@ -459,72 +532,89 @@ static void for_each_frame(const ocn_grid *grid, const int32_t box[4], const gen
     }
 }
 
+// fin != NULL (a model without extra terms): the next substep rides on this launch -- the epilogue of the tiled kernel on the box, the
+// finishing kernel on the frames
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
-                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin)
 {
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+    const bool finish = fin && (fin->sc.on || fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind);
     int32_t box[4];
-    if (interior_box(grid, centered2, range, box)) {
+    if (interior_box(grid, centered2, range, box) && !(fin && (fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind))) {
         int launched = 0;
-        st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream);
+        ocn::FuseArgs fz{};
+        if (fin && fin->sc.on) {
+            for (int f = 0; f < 3; ++f) { fz.Gm[f] = fin->sub[f].Gm; fz.Uo[f] = fin->sub[f].out; }
+            fz.dt = fin->sc.dt; fz.gamma = fin->sc.gamma; fz.zeta = fin->sc.zeta; fz.on = 1; fz.has_zeta = fin->sc.has_zeta;
+        }
+        st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream, (fin && fin->sc.on) ? &fz : nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) {
             const gen::Fields F = make_fields(grid, u, v, w, centered2);
             for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
                 OCN_GEN_DIMS_VOID(fr);
                 hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, F, Gu, Gv, Gw, fr);
+                if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, fr);
             });
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }
     }
     OCN_GEN_DIMS(r);
-    hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), Gu, Gv, Gw, r);
+    const gen::Fields F = make_fields(grid, u, v, w, centered2);
+    hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, F, Gu, Gv, Gw, r);
+    if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, r);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
 
-// diffusion != 0: Gc = -div_Uc - ∇_dot_qᶜ in the same call (κ a number or the field κₑ): the box kernel adds the diffusive flux divergence
-// to its advective one before the store (the epilogue of the Periodic grids' tiled kernel, same sum), the frames run both per-cell kernels
+// fuse != NULL: what the Periodic grids' tiled kernel folds in besides advection -- Gc = -div_Uc - ∇_dot_qᶜ (κ a number or the field κₑ), the
+// bottom / top flux contributions, the next substep -- in the same call: the box kernel takes the whole TracerFuse (centre fields: their
+// layout has no walls in it), the frames run the per-cell kernels one after the other (same sums in the same order)
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion, double kappa, const double *kappa_e)
+                                   double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse)
 {
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
     const GridDev gd = ocn::to_dev(*grid);
+    ocn::TracerFuse tf{};
+    if (fuse) tf = *fuse;
+    const bool diffusion = tf.diffusion != 0, finish = tf.bottom.kind || tf.top.kind || tf.sc.on;
+    auto cells = [&](const gen::Fields &F, const gen::GRange &fr, dim3 nb, dim3 block) {
+        hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, F, c, Gc, fr);
+        if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, tf.kappa, tf.kappa_e, c, Gc, fr);
+        if (finish) hipLaunchKernelGGL(tracer_finish_general, nb, block, 0, stream, gd, c, Gc, tf, fr);
+    };
     int32_t box[4];
     if (interior_box(grid, centered2, range, box)) {
         int launched = 0;
-        ocn::TracerFuse tf{};
-        tf.diffusion = diffusion ? 1 : 0;
-        tf.kappa = kappa;
-        tf.kappa_e = kappa_e;
-        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, diffusion ? &tf : nullptr);
+        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, fuse ? &tf : nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) {
             const gen::Fields F = make_fields(grid, u, v, w, centered2);
             for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
                 OCN_GEN_DIMS_VOID(fr);
-                hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, F, c, Gc, fr);
-                if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, kappa, kappa_e, c, Gc, fr);
+                cells(F, fr, nb, block);
             });
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
         }
     }
     OCN_GEN_DIMS(r);
-    hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, make_fields(grid, u, v, w, centered2), c, Gc, r);
-    if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, kappa, kappa_e, c, Gc, r);
+    cells(make_fields(grid, u, v, w, centered2), r, nb, block);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
 
+// fin != NULL: the u / v bottom / top flux contributions and the next substep of u, v, w ride on this last pass over G (the finishing pass of
+// the Periodic grids): inside the tiled kernel on the box, as one more per-cell kernel on the frames
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
-                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream)
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin)
 {
+    const bool finish = fin && (fin->sc.on || fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind);
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
@@ -533,13 +623,14 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
     int32_t box[4];
     if (interior_box(grid, 0, range, box)) {
         int launched = 0;
-        st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, nullptr);
+        st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, fin);
         if (st != OCN_SUCCESS) return st;
         if (launched) {
             const gen::Fields F = make_fields(grid, u, v, w, 0);
             for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
                 OCN_GEN_DIMS_VOID(fr);
                 hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, F, t, Gu, Gv, Gw, fr);
+                if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, fr);
             });
             OCN_CHECK_HIP(hipGetLastError());
             return OCN_SUCCESS;
@@ -547,7 +638,9 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
     }
 #endif
     OCN_GEN_DIMS(r);
-    hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, make_fields(grid, u, v, w, 0), t, Gu, Gv, Gw, r);
+    const gen::Fields F = make_fields(grid, u, v, w, 0);
+    hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, F, t, Gu, Gv, Gw, r);
+    if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, r);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }

@@ -1586,7 +1586,12 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
                     phi[o + k * s3] = star;
                     prev = star;
                 } else {
-                    prev = phi[o + k * s3];  // keep what storage held (batched_tridiagonal_solver.jl:224-228)
+                    // batched_tridiagonal_solver.jl:224-228 keeps what the storage held: the singular (kx, ky) = (0, 0) column ends in a pivot
+                    // of rounding size, its last unknown is the free constant of the gauge, removed again by the zero-mean step.  "What the
+                    // storage held" is whatever an earlier solve -- or, the first time, the allocator -- left there: a constant of 2^99 from
+                    // recycled memory cost every digit of that column (seen once in a long test process).  The constant is 0 here.
+                    prev = tz_zero(T{});
+                    phi[o + k * s3] = prev;
                 }
             }
         }

@@ -127,12 +127,11 @@ int launch_transpose(int mode, int nx, int Ny, int Nz, int R, const double *src,
 
 namespace ocn_strict {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
-                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
-                                   const double *kappa_e = nullptr);
+                                   double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
-                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                                     const int32_t *range, hipStream_t stream);
 int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
@@ -162,12 +161,11 @@ int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, con
 }
 namespace ocn_fast {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
-                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
-                                   const double *kappa_e = nullptr);
+                                   double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
-                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                                     const int32_t *range, hipStream_t stream);
 int launch_pressure_planes(const ocn_grid *grid, double *p, double *u, double dt, double *west, double *east, int unpack, hipStream_t stream);
@@ -199,12 +197,11 @@ int launch_amd_diffusivity(const ocn_grid *grid, double Ck, const double *u, con
 // advection = UpwindBiased(order=5): tendencies.hip compiled with OCN_UPWIND=1
 namespace ocn_strict_up {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
-                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
-                                   const double *kappa_e = nullptr);
+                                   double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
-                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                                     const int32_t *range, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
@@ -216,12 +213,11 @@ int launch_tracer_pair_tendency(const ocn_grid *grid, const double *u, const dou
 }
 namespace ocn_fast_up {
 int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, double *Gu,
-                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                       double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const double *u, const double *v, const double *w, const double *c,
-                                   double *Gc, const int32_t *range, hipStream_t stream, int diffusion = 0, double kappa = 0.0,
-                                   const double *kappa_e = nullptr);
+                                   double *Gc, const int32_t *range, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
 int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu,
-                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream);
+                                  double *Gv, double *Gw, const int32_t *range, hipStream_t stream, const ocn::MomentumFinal *fin = nullptr);
 int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const double *kappa_e, const double *c, double *Gc,
                                     const int32_t *range, hipStream_t stream);
 int launch_momentum_tendencies(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,

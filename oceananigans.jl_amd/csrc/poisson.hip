@@ -604,6 +604,7 @@ static int poisson_create_general(ocn_poisson_t *out, const ocn_grid *grid)
         return st;
     }
     (void)hipMemset(s->spec, 0, n * 2 * sizeof(double));
+    (void)hipMemset(s->spec2, 0, n * 2 * sizeof(double));
     *out = s;
     return OCN_SUCCESS;
 }

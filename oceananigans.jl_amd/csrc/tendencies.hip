@@ -447,15 +447,17 @@ __global__ __launch_bounds__(TX *TY, W) void momentum_tendencies_tiled(GridDev g
         double gmu, gmv, gmw;
         if (fz.on && fz.has_zeta && writes) {
             const long long o = own0 + (long long)(k - 1) * su3;
-            gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o]; gmw = fz.Gm[2][o];
+            const long long o_v = GL ? ownv + (long long)(k - 1) * sv3 : o, o_w = GL ? ownw + (long long)(k - 1) * sw3 : o;
+            gmu = fz.Gm[0][o]; gmv = fz.Gm[1][o_v]; gmw = fz.Gm[2][o_w];
         }
         // ... and the terms the finishing pass has already left in G (fz.acc)
         double eu, ev, ew;
         if (fz.acc && writes) {
             const long long o = own0 + (long long)(k - 1) * su3;
+            const long long o_v = GL ? ownv + (long long)(k - 1) * sv3 : o, o_w = GL ? ownw + (long long)(k - 1) * sw3 : o;
             if (i >= r.ou) eu = Gu[o];
-            if (j >= r.ov) ev = Gv[o];
-            if (k >= r.ow) ew = Gw[o];
+            if (j >= r.ov) ev = Gv[o_v];
+            if (k >= r.ow) ew = Gw[o_w];
         }
         const double(*swk)[LXP] = sw[wslot(k)];
         const double(*swt)[LXP] = sw[wslot(k + 1)];
@@ -1209,7 +1211,7 @@ static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 // direction), so the LDS-tiled kernels apply with per-field parent layouts (GL); z stays topology-conditional inside the kernel.
 // Returns 0 in *launched when the box is too small for the tiles (the caller then covers everything with the per-cell kernel).
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
-                                   const int32_t box[4], int *launched, hipStream_t stream)
+                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse)
 {
     *launched = 0;
     Range r;
@@ -1221,6 +1223,7 @@ int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const 
     if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
     ocn::FuseArgs fz{};
+    if (fuse) fz = *fuse;  // (the next substep as the epilogue: per-field offsets like the G stores)
     constexpr int TX = 32, TY = 8;
     const int tiles = ((wx + TX - 2) / (TX - 1)) * ((wy + TY - 2) / (TY - 1));
     int KZ = wz;

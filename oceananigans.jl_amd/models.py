@@ -199,8 +199,26 @@ class NonhydrostaticModel:
         self._general_fused = self.general_terms or bool(self.tracers)
         # grids with a Bounded or Flat x / y run the direction-generic kernels (csrc/general.hip) with the reference's launch sequence
         xy_periodic = grid.topology[0] in ("Periodic", "FullyConnected") and grid.topology[1] == "Periodic"
-        self.fuse_stage_boundaries = xy_periodic and ((not self._general_fused) or (isinstance(advection, (WENO, UpwindBiased))
-                                                                                   and os.environ.get("OCN_FUSE_GENERAL", "1") != "0"))
+        # ... and since round 4 the stage boundaries of grids with walls / Flat directions in x, y fuse too on one GPU (the substep as the
+        # epilogue of the tiled kernels on the interior box, one more per-cell kernel on the wall frames: csrc/general.hip) -- unless a flux
+        # goes through an x / y wall (ocn_apply_flux_bcs adds those on the unfused path) or a bottom / top flux is an array on a grid
+        # with x walls  [OCN_FUSE_WALLS=0: the reference's launch sequence]
+        def _fusable_conditions(b):
+            if b is None:
+                return True
+            for side, v in b.sides.items():
+                if v is None or v.kind != _lib.BC_FLUX:
+                    continue
+                if side in ("west", "east", "south", "north"):
+                    return False
+                if (v.values is not None or v.func is not None) and grid.topology[0] != "Periodic":
+                    return False
+            return True
+        walls_fusable = (not xy_periodic and not hasattr(grid.architecture, "partition") and os.environ.get("OCN_FUSE_WALLS", "1") != "0"
+                         and isinstance(advection, (WENO, UpwindBiased)) and isinstance(self.timestepper, RungeKutta3TimeStepper)
+                         and all(_fusable_conditions(b) for b in bcs.values()))
+        self.fuse_stage_boundaries = (xy_periodic or walls_fusable) and ((not self._general_fused) or (
+            isinstance(advection, (WENO, UpwindBiased)) and os.environ.get("OCN_FUSE_GENERAL", "1") != "0"))
         if not xy_periodic:
             if hasattr(grid.architecture, "partition") and not (
                     grid.topology[0] in ("Periodic", "FullyConnected", "RightConnected", "LeftConnected", "Bounded")
@@ -795,7 +813,8 @@ class ModelRK3Driver:
     def __init__(self, model, own_solver=False):
         if not isinstance(model.timestepper, RungeKutta3TimeStepper):
             raise NotImplementedError("ModelRK3Driver: RungeKutta3")
-        if not (model.fuse_stage_boundaries and model._general_fused):
+        if not (model.fuse_stage_boundaries and model._general_fused and model.grid.topology[0] in ("Periodic", "FullyConnected")
+                and model.grid.topology[1] == "Periodic"):
             raise NotImplementedError("ModelRK3Driver: a model on the general fused path (tracers and / or extra terms, WENO / UpwindBiased "
                                       "advection, Periodic x and y); plain WENO models take RK3Driver")
         arch = model.grid.architecture

@@ -406,7 +406,7 @@ def test_time_steps_match_oracle_on_closed_and_sliced_grids(oracle, ocn, size, t
     ocn.set_math_mode(ocn.MATH_STRICT)
     om = O.NonhydrostaticModel(og, tracers=("c",), timestepper=stepper)
     pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("c",), timestepper=stepper)
-    assert not pm.fuse_stage_boundaries
+    assert pm.fuse_stage_boundaries == (stepper == "RungeKutta3")  # (round 4: the stage boundaries of grids with walls fuse too)
     init = {}
     for name, loc in zip("uvw", LOCS):
         if topo[{"u": 0, "v": 1, "w": 2}[name]] == "F":
@@ -708,7 +708,7 @@ def test_stratified_channel_with_separate_hydrostatic_pressure_matches_oracle(or
     om = O.NonhydrostaticModel(og, tracers=("b",), coriolis_f=0.3, closure=(0.02, {"b": 0.03}), buoyancy="BuoyancyTracer")
     pm = ocn.NonhydrostaticModel(pg, advection=ocn.WENO(), tracers=("b",), coriolis=ocn.FPlane(f=0.3), closure=ocn.ScalarDiffusivity(ν=0.02, κ=0.03),
                                  buoyancy=ocn.BuoyancyTracer())
-    assert pm.pHY is not None and not pm.fuse_stage_boundaries
+    assert pm.pHY is not None and pm.fuse_stage_boundaries
     init = {n: rng.uniform(-1, 1, og.interior(og.zeros(l)).shape) for n, l in zip("uvw", LOCS)}
     init["b"] = rng.uniform(0, 1, og.interior(og.zeros(0)).shape)
     om.set(**init)

