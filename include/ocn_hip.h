@@ -153,7 +153,9 @@ int ocn_compute_momentum_tendencies(const ocn_grid *grid, const double *u, const
  * wrapped indices, so (u, v, w) are the *uncorrected* fields with valid halos and p needs no halos.
  * (Periodic, Periodic, Periodic) grids with an interior of at least 16 x 8 x 4 and range = NULL only; otherwise
  * OCN_ERR_UNSUPPORTED.  On a (FullyConnected, Periodic, Periodic) local grid of a slab-x run the x indices are not wrapped: p must
- * hold the neighbours' planes in its x halos and u[1 - Hx] must already be corrected (ocn_halo_exchange_pressure). */
+ * hold the neighbours' planes in its x halos and u[1 - Hx] must already be corrected (ocn_halo_exchange_pressure).
+ * Grids with a Bounded / Flat x or y (range = NULL, p_correct = NULL): the substep is the epilogue of the tiled kernel on the interior box
+ * and one more per-cell kernel on the wall frames; the wall faces of u, v, w (first index and the face N + 1) are carried over. */
 int ocn_compute_momentum_tendencies_rk3(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu,
                                         double *Gv, double *Gw, const double *Gmu, const double *Gmv, const double *Gmw,
                                         double *u_out, double *v_out, double *w_out, double dt, double gamma, double zeta,
@@ -284,14 +286,17 @@ int ocn_apply_flux_bcs(const ocn_grid *grid, double *const *G, const double *con
  * identical to ocn_compute_*_tendencies_terms + ocn_apply_flux_bcs + ocn_rk3_substep, bit for bit in strict math):
  * the tendencies of the current state INCLUDING the bottom / top flux boundary contributions land in G, and the NEXT stage's
  *   U_out = U + Δt (γ G + ζ G⁻)   (has_zeta = 0:  U_out = U + (Δt γ) G)
- * is written to a second storage (must not alias the inputs; the wall faces of w are carried over).  bcs_* may be NULL. */
+ * is written to a second storage (must not alias the inputs; the wall faces of w are carried over).  bcs_* may be NULL.
+ * Grids with a Bounded / Flat x or y (range = NULL): the finishing pass with fluxes and substep runs inside the tiled kernel on the interior
+ * box and as per-cell kernels on the wall frames (wall faces of u, v carried over too); conditions on the x / y walls may be Value /
+ * Gradient / Open (they live in the halo fills) but not Flux (OCN_ERR_INVALID_ARGUMENT: ocn_apply_flux_bcs adds those, unfused). */
 int ocn_compute_momentum_tendencies_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, const ocn_field_bcs *bcs_u,
                                               const ocn_field_bcs *bcs_v, const double *u, const double *v, const double *w,
                                               double *Gu, double *Gv, double *Gw, const double *Gmu, const double *Gmv,
                                               const double *Gmw, double *u_out, double *v_out, double *w_out, double dt,
                                               double gamma, double zeta, int32_t has_zeta, const int32_t *range, void *stream);
 /* same for one tracer; advection must be OCN_ADVECTION_WENO5 or OCN_ADVECTION_UPWIND5 (advection, diffusion, boundary flux
- * and substep are ONE kernel) */
+ * and substep are ONE kernel -- on grids with walls in x / y: on the interior box; three per-cell kernels on the frames) */
 int ocn_compute_tracer_tendency_terms_rk3(const ocn_grid *grid, const ocn_model_terms *terms, double kappa, const double *kappa_e,
                                           const ocn_field_bcs *bcs_c, const double *u, const double *v, const double *w,
                                           const double *c, double *Gc, const double *Gmc, double *c_out, double dt, double gamma,
