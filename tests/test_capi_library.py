@@ -62,16 +62,20 @@ def test_argument_validation_needs_no_gpu(pkg):
         call("ocn_compute_w_from_continuity", C.byref(_grid(pkg, tx=1)), 1, 1, 1, None)
     with pytest.raises(pkg.OcnError, match="only x is ever partitioned"):
         call("ocn_fill_halo_regions", C.byref(_grid(pkg, ty=3)), fake, ia([0]), 1, 1, None)
-    with pytest.raises(pkg.OcnError, match="fused stage boundaries need Periodic x and y"):
-        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, ty=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, None, 0.0, None, None)
+    # (grids with walls take the fused stage boundary since round 4 -- but neither the correction on load nor a range)
+    with pytest.raises(pkg.OcnError, match="pressure correction on load needs Periodic x and y"):
+        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, ty=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, 0x2000, 0.0, None, None)
+    with pytest.raises(pkg.OcnError, match="ranges need Periodic x and y"):
+        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, ty=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, None, 0.0,
+             ia([1, 2, 1, 2, 1, 2]), None)
     with pytest.raises(pkg.OcnError, match="Flat dimension"):
         call("ocn_fill_halo_regions", C.byref(_grid(pkg, tz=2)), fake, ia([0]), 1, 1, None)
     # a slab (FullyConnected x) of a channel is a grid the direction-generic entry points take: the walls in y pass the grid check (the
-    # call then stops at its next check), the fused entry points and a Flat y on a slab do not
+    # call then stops at its next check), the correction on load and a Flat y on a slab do not
     with pytest.raises(pkg.OcnError, match="null field pointer"):
         call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, tx=3, ty=1, tz=1)), None, 1, 1, 1, 1, 1, None, None)
-    with pytest.raises(pkg.OcnError, match="fused stage boundaries need Periodic x and y"):
-        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, tx=3, ty=1, tz=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, None, 0.0, None, None)
+    with pytest.raises(pkg.OcnError, match="pressure correction on load needs Periodic x and y"):
+        call("ocn_compute_momentum_tendencies_rk3", C.byref(_grid(pkg, tx=3, ty=1, tz=1)), *range(16, 16 * 13, 16), 0.1, 0.5, 0.0, 0, 0x2000, 0.0, None, None)
     with pytest.raises(pkg.OcnError, match="Periodic or Bounded y"):
         call("ocn_compute_momentum_tendencies", C.byref(_grid(pkg, tx=3, ty=2, Ny=1, Hy=0)), 1, 1, 1, 1, 1, 1, None, None)
     # the first / last slab of a Bounded partitioned x (RightConnected = 4, LeftConnected = 5): x only; the distributed solver checks that
