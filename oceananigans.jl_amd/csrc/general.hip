@@ -16,6 +16,8 @@
 // bit-identical to the CPU oracle.
 //
 // Compiled twice like tendencies.hip (namespaces via ocn_weno.h): strict / fast, WENO5 or UpwindBiased(order = 5).
+#include <cstring>
+
 #include "ocn_weno.h"
 
 namespace OCN_NS {
@@ -153,17 +155,42 @@ struct GRange {
     int ou, ov, ow;  // first index written for Gu (in i), Gv (in j), Gw (in k)
 };
 
+// The ranges of ONE launch: a whole range, or the (up to four) wall frames around the interior box -- four thin launches in a row are
+// four times the latency of one thread's work (a frame fills a fraction of the chip), one launch over all of them is once.  Blocks are
+// 256 threads, bdx x (256 / bdx) cells of range f (ocn::range_block: thin x strips fold towards y); linear block b belongs to the range
+// whose [first[f], first[f + 1]) holds it; all ranges share k0 .. k1 (blockIdx.y).
+struct GFrames {
+    int n;
+    GRange r[4];
+    int bdx[4], nbx[4], first[5];
+};
+
+__device__ __forceinline__ bool frame_cell(const GFrames &F, GRange &r, int &i, int &j, int &k)
+{
+    const int b = blockIdx.x;
+    int f = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < F.n && b >= F.first[q]) f = q;
+    r = F.r[f];
+    const int local = b - F.first[f], bdx = F.bdx[f], nbx = F.nbx[f];
+    const int tx = threadIdx.x % bdx, ty = threadIdx.x / bdx;
+    i = r.i0 + (local % nbx) * bdx + tx;
+    j = r.j0 + (local / nbx) * (256 / bdx) + ty;
+    k = r.k0 + blockIdx.y;
+    return i <= r.i1 && j <= r.j1;
+}
+
 }  // namespace gen
 
 // compute_Gu! / Gv! / Gw!: G = -div_𝐯u etc. (momentum_advection_operators.jl:46-83)
 __global__ __launch_bounds__(256) void momentum_tendencies_general(gen::Fields F, double *__restrict__ Gu, double *__restrict__ Gv,
-                                                                   double *__restrict__ Gw, gen::GRange r)
+                                                                   double *__restrict__ Gw, gen::GFrames fr)
 {
     using namespace gen;
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const GridDev &g = F.g;
     const Metrics M = make_metrics(g);
     const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT, fz = g.tz == OCN_FLAT;
@@ -191,13 +218,12 @@ __global__ __launch_bounds__(256) void momentum_tendencies_general(gen::Fields F
 }
 
 // compute_Gc!: Gc = -div_Uc (tracer_advection_operators.jl:30-34)
-__global__ __launch_bounds__(256) void tracer_tendency_general(gen::Fields F, const double *__restrict__ c, double *__restrict__ Gc, gen::GRange r)
+__global__ __launch_bounds__(256) void tracer_tendency_general(gen::Fields F, const double *__restrict__ c, double *__restrict__ Gc, gen::GFrames fr)
 {
     using namespace gen;
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const GridDev &g = F.g;
     const Metrics M = make_metrics(g);
     const double dxF = g.tx == OCN_FLAT ? 0.0 : tracer_flux<0>(F, M, c, i + 1, j, k) - tracer_flux<0>(F, M, c, i, j, k);
@@ -229,13 +255,12 @@ __device__ __forceinline__ double gen_buoyancy(const ocn::TermsDev &t, long long
 }
 
 __global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn::TermsDev t, double *__restrict__ Gu, double *__restrict__ Gv,
-                                                              double *__restrict__ Gw, gen::GRange r)
+                                                              double *__restrict__ Gw, gen::GFrames fr)
 {
     using namespace gen;
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const GridDev &g = F.g;
     const Metrics M = make_metrics(g);
     const Lay &Lu = F.Lu, &Lv = F.Lv, &Lw = F.Lw, &Lc = F.Lc;
@@ -345,12 +370,11 @@ __global__ __launch_bounds__(256) void momentum_extra_general(gen::Fields F, ocn
 
 // Gc <- Gc - ∇_dot_qᶜ (closure_kernel_operators.jl:48-53), κ a number or the eddy diffusivity field interpolated to the faces
 __global__ __launch_bounds__(256) void tracer_diffusion_general(GridDev g, double kappa, const double *__restrict__ kappa_e,
-                                                                const double *__restrict__ c, double *__restrict__ Gc, gen::GRange r)
+                                                                const double *__restrict__ c, double *__restrict__ Gc, gen::GFrames fr)
 {
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const Metrics M = make_metrics(g);
     const Lay L = ocn::make_lay(g, OCN_LOC_CCC);
     const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT, fz = g.tz == OCN_FLAT;
@@ -381,13 +405,12 @@ __device__ __forceinline__ double substep_value(const ocn::SubstepCoef &sc, doub
 }
 
 __global__ __launch_bounds__(256) void momentum_finish_general(gen::Fields F, double *__restrict__ Gu, double *__restrict__ Gv, double *__restrict__ Gw,
-                                                               ocn::MomentumFinal mf, gen::GRange r)
+                                                               ocn::MomentumFinal mf, gen::GFrames fr)
 {
     using namespace gen;
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const GridDev &g = F.g;
     const Metrics M = make_metrics(g);
     const double Az = M.Az;
@@ -422,12 +445,11 @@ __global__ __launch_bounds__(256) void momentum_finish_general(gen::Fields F, do
 }
 
 __global__ __launch_bounds__(256) void tracer_finish_general(GridDev g, const double *__restrict__ c, double *__restrict__ Gc, ocn::TracerFuse tf,
-                                                             gen::GRange r)
+                                                             gen::GFrames fr)
 {
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1) return;
+    gen::GRange r;
+    int i, j, k;
+    if (!gen::frame_cell(fr, r, i, j, k)) return;
     const Metrics M = make_metrics(g);
     const double az = M.Az;
     const long long o = ocn::at(ocn::make_lay(g, OCN_LOC_CCC), i, j, k);
@@ -477,16 +499,6 @@ static gen::Fields make_fields(const ocn_grid *grid, const double *u, const doub
     return F;
 }
 
-#define OCN_GEN_DIMS(r)                                                                               \
-    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;                       \
-    if (wx < 1 || wy < 1 || wz < 1) return OCN_SUCCESS;                                                \
-    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz)
-
-#define OCN_GEN_DIMS_VOID(r)                                                                          \
-    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;                       \
-    if (wx < 1 || wy < 1 || wz < 1) return;                                                            \
-    const dim3 block = ocn::range_block(wx), nb = ocn::range_grid(block, wx, wy, wz)
-
 // tendencies.hip (same namespace): the LDS-tiled kernels over the interior box of a grid with walls in x / y
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
                                    const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse = nullptr);
@@ -516,21 +528,52 @@ static bool interior_box(const ocn_grid *grid, int centered2, const int32_t *ran
     return box[1] - box[0] + 1 >= 16 && box[3] - box[2] + 1 >= 8 && grid->Nz >= 4 && grid->Hx >= 3 && grid->Hy >= 3 && grid->Hz >= 3;
 }
 
-// the (up to four) frames around the box, each as a range of the per-cell kernel; `r` carries the periphery offsets of the whole grid
-template <class Launch>
-static void for_each_frame(const ocn_grid *grid, const int32_t box[4], const gen::GRange &whole, Launch launch)
+// one more range of a launch (empty ranges are skipped)
+static void add_range(gen::GFrames &F, const gen::GRange &r)
+{
+    const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = r.k1 - r.k0 + 1;
+    if (wx < 1 || wy < 1 || wz < 1 || F.n >= 4) return;
+    const dim3 block = ocn::range_block(wx);
+    const int f = F.n++;
+    F.r[f] = r;
+    F.bdx[f] = (int)block.x;
+    F.nbx[f] = (wx + (int)block.x - 1) / (int)block.x;
+    F.first[f + 1] = F.first[f] + F.nbx[f] * ((wy + (int)block.y - 1) / (int)block.y);
+}
+static gen::GFrames whole_range(const gen::GRange &r)
+{
+    gen::GFrames F{};
+    add_range(F, r);
+    return F;
+}
+// the (up to four) frames around the box as the ranges of ONE launch; `whole` carries the periphery offsets of the whole grid
+static gen::GFrames frames_around(const ocn_grid *grid, const int32_t box[4], const gen::GRange &whole)
 {
     const int spans[4][4] = {{1, box[0] - 1, 1, grid->Ny},                 // west
                              {box[1] + 1, grid->Nx, 1, grid->Ny},          // east
                              {box[0], box[1], 1, box[2] - 1},              // south (between the x frames)
                              {box[0], box[1], box[3] + 1, grid->Ny}};      // north
+    gen::GFrames F{};
     for (const auto &sp : spans) {
-        if (sp[1] < sp[0] || sp[3] < sp[2]) continue;
         gen::GRange r = whole;
         r.i0 = sp[0]; r.i1 = sp[1]; r.j0 = sp[2]; r.j1 = sp[3];
-        launch(r);
+        add_range(F, r);
     }
+    return F;
 }
+// launch `kernel(args..., F)` over the ranges of F -- or, OCN_GENERAL_FRAMES=separate, one launch per range as before round 4's last change
+#define OCN_GEN_LAUNCH(kernel, F_, ...)                                                                                              \
+    do {                                                                                                                             \
+        static const bool sep_ = [] { const char *e = getenv("OCN_GENERAL_FRAMES"); return e && !strcmp(e, "separate"); }();         \
+        if ((F_).n > 0 && !sep_) {                                                                                                   \
+            hipLaunchKernelGGL(kernel, dim3((F_).first[(F_).n], (F_).r[0].k1 - (F_).r[0].k0 + 1), dim3(256), 0, stream, __VA_ARGS__, (F_)); \
+        } else {                                                                                                                     \
+            for (int f_ = 0; f_ < (F_).n; ++f_) {                                                                                    \
+                const gen::GFrames one_ = whole_range((F_).r[f_]);                                                                   \
+                hipLaunchKernelGGL(kernel, dim3(one_.first[1], one_.r[0].k1 - one_.r[0].k0 + 1), dim3(256), 0, stream, __VA_ARGS__, one_); \
+            }                                                                                                                        \
+        }                                                                                                                            \
+    } while (0)
 
 // fin != NULL (a model without extra terms): the next substep rides on this launch -- the epilogue of the tiled kernel on the box, the
 // finishing kernel on the frames
@@ -540,9 +583,12 @@ int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, cons
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
-    const bool finish = fin && (fin->sc.on || fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind);
+    const bool fluxes = fin && (fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind);
+    const bool finish = fin && (fin->sc.on || fluxes);
+    const gen::Fields F = make_fields(grid, u, v, w, centered2);
+    gen::GFrames cells = whole_range(r);
     int32_t box[4];
-    if (interior_box(grid, centered2, range, box) && !(fin && (fin->bottom[0].kind || fin->bottom[1].kind || fin->top[0].kind || fin->top[1].kind))) {
+    if (interior_box(grid, centered2, range, box) && !fluxes) {
         int launched = 0;
         ocn::FuseArgs fz{};
         if (fin && fin->sc.on) {
@@ -551,21 +597,10 @@ int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, cons
         }
         st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream, (fin && fin->sc.on) ? &fz : nullptr);
         if (st != OCN_SUCCESS) return st;
-        if (launched) {
-            const gen::Fields F = make_fields(grid, u, v, w, centered2);
-            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
-                OCN_GEN_DIMS_VOID(fr);
-                hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, F, Gu, Gv, Gw, fr);
-                if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, fr);
-            });
-            OCN_CHECK_HIP(hipGetLastError());
-            return OCN_SUCCESS;
-        }
+        if (launched) cells = frames_around(grid, box, r);
     }
-    OCN_GEN_DIMS(r);
-    const gen::Fields F = make_fields(grid, u, v, w, centered2);
-    hipLaunchKernelGGL(momentum_tendencies_general, nb, block, 0, stream, F, Gu, Gv, Gw, r);
-    if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, r);
+    OCN_GEN_LAUNCH(momentum_tendencies_general, cells, F, Gu, Gv, Gw);
+    if (finish) OCN_GEN_LAUNCH(momentum_finish_general, cells, F, Gu, Gv, Gw, *fin);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -583,28 +618,18 @@ int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const do
     ocn::TracerFuse tf{};
     if (fuse) tf = *fuse;
     const bool diffusion = tf.diffusion != 0, finish = tf.bottom.kind || tf.top.kind || tf.sc.on;
-    auto cells = [&](const gen::Fields &F, const gen::GRange &fr, dim3 nb, dim3 block) {
-        hipLaunchKernelGGL(tracer_tendency_general, nb, block, 0, stream, F, c, Gc, fr);
-        if (diffusion) hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, gd, tf.kappa, tf.kappa_e, c, Gc, fr);
-        if (finish) hipLaunchKernelGGL(tracer_finish_general, nb, block, 0, stream, gd, c, Gc, tf, fr);
-    };
+    const gen::Fields F = make_fields(grid, u, v, w, centered2);
+    gen::GFrames cells = whole_range(r);
     int32_t box[4];
     if (interior_box(grid, centered2, range, box)) {
         int launched = 0;
         st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, fuse ? &tf : nullptr);
         if (st != OCN_SUCCESS) return st;
-        if (launched) {
-            const gen::Fields F = make_fields(grid, u, v, w, centered2);
-            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
-                OCN_GEN_DIMS_VOID(fr);
-                cells(F, fr, nb, block);
-            });
-            OCN_CHECK_HIP(hipGetLastError());
-            return OCN_SUCCESS;
-        }
+        if (launched) cells = frames_around(grid, box, r);
     }
-    OCN_GEN_DIMS(r);
-    cells(make_fields(grid, u, v, w, centered2), r, nb, block);
+    OCN_GEN_LAUNCH(tracer_tendency_general, cells, F, c, Gc);
+    if (diffusion) OCN_GEN_LAUNCH(tracer_diffusion_general, cells, gd, tf.kappa, tf.kappa_e, c, Gc);
+    if (finish) OCN_GEN_LAUNCH(tracer_finish_general, cells, gd, c, Gc, tf);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -618,6 +643,8 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
+    const gen::Fields F = make_fields(grid, u, v, w, 0);
+    gen::GFrames cells = whole_range(r);
 #if !OCN_UPWIND
     // interior box (the tiled finishing pass with per-field layouts: every stress once per face, velocities through LDS) + wall frames
     int32_t box[4];
@@ -625,22 +652,11 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
         int launched = 0;
         st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, fin);
         if (st != OCN_SUCCESS) return st;
-        if (launched) {
-            const gen::Fields F = make_fields(grid, u, v, w, 0);
-            for_each_frame(grid, box, r, [&](const gen::GRange &fr) {
-                OCN_GEN_DIMS_VOID(fr);
-                hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, F, t, Gu, Gv, Gw, fr);
-                if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, fr);
-            });
-            OCN_CHECK_HIP(hipGetLastError());
-            return OCN_SUCCESS;
-        }
+        if (launched) cells = frames_around(grid, box, r);
     }
 #endif
-    OCN_GEN_DIMS(r);
-    const gen::Fields F = make_fields(grid, u, v, w, 0);
-    hipLaunchKernelGGL(momentum_extra_general, nb, block, 0, stream, F, t, Gu, Gv, Gw, r);
-    if (finish) hipLaunchKernelGGL(momentum_finish_general, nb, block, 0, stream, F, Gu, Gv, Gw, *fin, r);
+    OCN_GEN_LAUNCH(momentum_extra_general, cells, F, t, Gu, Gv, Gw);
+    if (finish) OCN_GEN_LAUNCH(momentum_finish_general, cells, F, Gu, Gv, Gw, *fin);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -651,8 +667,8 @@ int launch_tracer_diffusion_general(const ocn_grid *grid, double kappa, const do
     gen::GRange r;
     int st = make_grange(grid, range, r);
     if (st != OCN_SUCCESS) return st;
-    OCN_GEN_DIMS(r);
-    hipLaunchKernelGGL(tracer_diffusion_general, nb, block, 0, stream, ocn::to_dev(*grid), kappa, kappa_e, c, Gc, r);
+    const gen::GFrames cells = whole_range(r);
+    OCN_GEN_LAUNCH(tracer_diffusion_general, cells, ocn::to_dev(*grid), kappa, kappa_e, c, Gc);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
