@@ -16,6 +16,7 @@
 // bit-identical to the CPU oracle.
 //
 // Compiled twice like tendencies.hip (namespaces via ocn_weno.h): strict / fast, WENO5 or UpwindBiased(order = 5).
+#include <algorithm>
 #include <cstring>
 
 #include "ocn_weno.h"
@@ -501,13 +502,13 @@ static gen::Fields make_fields(const ocn_grid *grid, const double *u, const doub
 
 // tendencies.hip (same namespace): the LDS-tiled kernels over the interior box of a grid with walls in x / y
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
-                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse = nullptr);
+                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse = nullptr, int ranged = 0);
 int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
-                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr);
+                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse = nullptr, int ranged = 0);
 #if !OCN_UPWIND
 // physics.hip (compiled for the WENO namespaces only; the extra terms do not depend on the advection scheme): the tiled finishing pass
 int launch_momentum_extra_box(const ocn_grid *grid, const ocn::TermsDev &t, const double *u, const double *v, const double *w, double *Gu, double *Gv,
-                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin);
+                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin, int ranged = 0);
 #endif
 
 // Interior box + wall frames.  The topology-conditional reconstructions of a Bounded direction differ from the Periodic ones only within
@@ -516,15 +517,22 @@ int launch_momentum_extra_box(const ocn_grid *grid, const ocn::TermsDev &t, cons
 // expressions on the same operands as the per-cell kernel, bit for bit -- and only the frames next to the walls run the per-cell kernel
 // with its run-time topology.  Returns the box {i0, i1, j0, j1}, or false when the grid has no wall in x / y, a Flat x / y / z, a scheme
 // the tiles do not carry, or a box too small for them (OCN_GENERAL_TILED=0 switches the decomposition off).
+// A range (KernelParameters: the interior / buffer split of a slab, interleave_communication_and_computation.jl:29-67) with the full
+// k extent is intersected with the box: the interior range of a channel's slab keeps the tiled kernels.
 static bool interior_box(const ocn_grid *grid, int centered2, const int32_t *range, int32_t box[4])
 {
     static const bool off = [] { const char *e = getenv("OCN_GENERAL_TILED"); return e && e[0] == '0'; }();
-    if (off || centered2 || range) return false;
+    if (off || centered2) return false;
+    if (range && (range[4] != 1 || range[5] != grid->Nz)) return false;
     if (grid->tx == OCN_FLAT || grid->ty == OCN_FLAT || grid->tz == OCN_FLAT) return false;
     const bool xw = ocn::x_wall_west(*grid), xe = ocn::x_wall_east(*grid);
     if (!xw && !xe && grid->ty != OCN_BOUNDED) return false;
     box[0] = xw ? 4 : 1; box[1] = xe ? grid->Nx - 3 : grid->Nx;
     box[2] = grid->ty == OCN_BOUNDED ? 4 : 1; box[3] = grid->ty == OCN_BOUNDED ? grid->Ny - 3 : grid->Ny;
+    if (range) {
+        box[0] = std::max(box[0], range[0]); box[1] = std::min(box[1], range[1]);
+        box[2] = std::max(box[2], range[2]); box[3] = std::min(box[3], range[3]);
+    }
     return box[1] - box[0] + 1 >= 16 && box[3] - box[2] + 1 >= 8 && grid->Nz >= 4 && grid->Hx >= 3 && grid->Hy >= 3 && grid->Hz >= 3;
 }
 
@@ -549,10 +557,11 @@ static gen::GFrames whole_range(const gen::GRange &r)
 // the (up to four) frames around the box as the ranges of ONE launch; `whole` carries the periphery offsets of the whole grid
 static gen::GFrames frames_around(const ocn_grid *grid, const int32_t box[4], const gen::GRange &whole)
 {
-    const int spans[4][4] = {{1, box[0] - 1, 1, grid->Ny},                 // west
-                             {box[1] + 1, grid->Nx, 1, grid->Ny},          // east
-                             {box[0], box[1], 1, box[2] - 1},              // south (between the x frames)
-                             {box[0], box[1], box[3] + 1, grid->Ny}};      // north
+    (void)grid;
+    const int spans[4][4] = {{whole.i0, box[0] - 1, whole.j0, whole.j1},          // west
+                             {box[1] + 1, whole.i1, whole.j0, whole.j1},          // east
+                             {box[0], box[1], whole.j0, box[2] - 1},              // south (between the x frames)
+                             {box[0], box[1], box[3] + 1, whole.j1}};             // north
     gen::GFrames F{};
     for (const auto &sp : spans) {
         gen::GRange r = whole;
@@ -595,7 +604,7 @@ int launch_momentum_tendencies_general(const ocn_grid *grid, int centered2, cons
             for (int f = 0; f < 3; ++f) { fz.Gm[f] = fin->sub[f].Gm; fz.Uo[f] = fin->sub[f].out; }
             fz.dt = fin->sc.dt; fz.gamma = fin->sc.gamma; fz.zeta = fin->sc.zeta; fz.on = 1; fz.has_zeta = fin->sc.has_zeta;
         }
-        st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream, (fin && fin->sc.on) ? &fz : nullptr);
+        st = launch_momentum_tendencies_box(grid, u, v, w, Gu, Gv, Gw, box, &launched, stream, (fin && fin->sc.on) ? &fz : nullptr, range != nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) cells = frames_around(grid, box, r);
     }
@@ -623,7 +632,7 @@ int launch_tracer_tendency_general(const ocn_grid *grid, int centered2, const do
     int32_t box[4];
     if (interior_box(grid, centered2, range, box)) {
         int launched = 0;
-        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, fuse ? &tf : nullptr);
+        st = launch_tracer_tendency_box(grid, u, v, w, c, Gc, box, &launched, stream, fuse ? &tf : nullptr, range != nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) cells = frames_around(grid, box, r);
     }
@@ -650,7 +659,7 @@ int launch_momentum_extra_general(const ocn_grid *grid, const ocn::TermsDev &t, 
     int32_t box[4];
     if (interior_box(grid, 0, range, box)) {
         int launched = 0;
-        st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, fin);
+        st = launch_momentum_extra_box(grid, t, u, v, w, Gu, Gv, Gw, box, &launched, stream, fin, range != nullptr);
         if (st != OCN_SUCCESS) return st;
         if (launched) cells = frames_around(grid, box, r);
     }

@@ -891,7 +891,7 @@ int launch_momentum_extra(const ocn_grid *grid, const TermsDev &t, const double 
 // away from the walls, where the per-cell kernel with its run-time topology evaluates exactly these expressions): the tiled kernel with
 // per-field parent layouts.  *launched = 0 when the box is too small for the tiles (the caller then runs the per-cell kernel everywhere).
 int launch_momentum_extra_box(const ocn_grid *grid, const TermsDev &t, const double *u, const double *v, const double *w, double *Gu, double *Gv,
-                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin)
+                              double *Gw, const int32_t box[4], int *launched, hipStream_t stream, const ocn::MomentumFinal *fin, int ranged)
 {
     *launched = 0;
     ocn::MomentumFinal mf{};
@@ -901,7 +901,7 @@ int launch_momentum_extra_box(const ocn_grid *grid, const TermsDev &t, const dou
     const bool share = share_env && t.closure != 0;
     PRange r;
     r.i0 = box[0]; r.i1 = box[1]; r.j0 = box[2]; r.j1 = box[3]; r.k0 = 1; r.k1 = grid->Nz;
-    r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    r.ow = (!ranged && grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;  // (KernelParameters: periphery not excluded, as make_prange)
     const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = grid->Nz;
     if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4 || grid->Hz < 1) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);

@@ -1211,14 +1211,14 @@ static int make_range(const ocn_grid *grid, const int32_t *range, Range &r)
 // direction), so the LDS-tiled kernels apply with per-field parent layouts (GL); z stays topology-conditional inside the kernel.
 // Returns 0 in *launched when the box is too small for the tiles (the caller then covers everything with the per-cell kernel).
 int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const double *v, const double *w, double *Gu, double *Gv, double *Gw,
-                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse)
+                                   const int32_t box[4], int *launched, hipStream_t stream, const ocn::FuseArgs *fuse, int ranged)
 {
     *launched = 0;
     Range r;
     r.xcd = xcd_remap();
     r.i0 = box[0]; r.i1 = box[1]; r.j0 = box[2]; r.j1 = box[3]; r.k0 = 1; r.k1 = grid->Nz;
     r.ou = r.ov = 1;
-    r.ow = (grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;
+    r.ow = (!ranged && grid->tz == OCN_BOUNDED && grid->Nz > 1) ? 2 : 1;  // (KernelParameters: periphery not excluded)
     const int wx = r.i1 - r.i0 + 1, wy = r.j1 - r.j0 + 1, wz = grid->Nz;
     if (grid->tz == OCN_FLAT || wx < 16 || wy < 8 || wz < 4) return OCN_SUCCESS;
     GridDev g = ocn::to_dev(*grid);
@@ -1239,8 +1239,9 @@ int launch_momentum_tendencies_box(const ocn_grid *grid, const double *u, const 
 }
 
 int launch_tracer_tendency_box(const ocn_grid *grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
-                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse)
+                               const int32_t box[4], int *launched, hipStream_t stream, const ocn::TracerFuse *fuse, int ranged)
 {
+    (void)ranged;  // (a centre field has no excluded periphery)
     *launched = 0;
     Range r;
     r.xcd = xcd_remap();

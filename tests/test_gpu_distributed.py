@@ -79,7 +79,7 @@ def _run_ranks(R, fn):
 
 
 @pytest.mark.parametrize("R", [2, 4])
-@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB", "BBB"])
+@pytest.mark.parametrize("topo", ["PPP", "PPB", "PBB", "BBB", "PBB-wide", "BBB-wide"])
 def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
     """Two RK3 steps on R slab-x ranks against the single-rank model AND, directly, against the CPU oracle; "PPB" = stretched Bounded
     z, i.e. the distributed Fourier-tridiagonal solver (config 4's solver at 1 -> 8 GPUs); "PBB" = the channel: walls in y too (cosine
@@ -90,6 +90,10 @@ def test_distributed_steps_match_single_rank(ocn, oracle, R, topo):
     from helpers import stretched_faces
     P = "Periodic"
     N = (32, 16, 12)
+    if topo.endswith("-wide"):  # slabs whose interior range (nx - 2 Hx columns) keeps an interior box: tiled kernels on a RANGE + wall frames
+        if R != 2:
+            pytest.skip("one wide case")
+        topo, N = topo[:3], (64, 20, 10)
     if topo == "PPP":
         ext = dict(x=(0, 2 * np.pi), y=(0, 2 * np.pi), z=(0, 2 * np.pi), topology=(P, P, P), halo=(3, 3, 3))
         solver_class = ocn.DistributedFFTBasedPoissonSolver

@@ -256,8 +256,17 @@ ocn.fill_halo_regions(f)
 G = [ocn.Field(l, g) for l in (1, 2, 4, 0)]
 ocn._lib.call("ocn_compute_momentum_tendencies", g.cref, f[0].ptr, f[1].ptr, f[2].ptr, G[0].ptr, G[1].ptr, G[2].ptr, None, 0)
 ocn._lib.call("ocn_compute_tracer_tendency", g.cref, f[0].ptr, f[1].ptr, f[2].ptr, f[3].ptr, G[3].ptr, None, 0)
+# ... and over a RANGE with the full k extent (the interior range of a slab: the box is intersected with it, the periphery is not excluded),
+# with the other terms (Coriolis, stress divergence, tracer diffusion) behind the advective ones
+import ctypes as C
+R = [ocn.Field(l, g) for l in (1, 2, 4, 0)]
+rng = ocn._lib.i32_array([2, g.Nx - 1, 1, g.Ny, 1, g.Nz])
+t = ocn._lib.CModelTerms()
+t.advection, t.coriolis, t.f, t.closure, t.nu = ocn._lib.ADVECTION_WENO5, 1, 0.7, 1, 0.013
+ocn._lib.call("ocn_compute_momentum_tendencies_terms", g.cref, C.byref(t), f[0].ptr, f[1].ptr, f[2].ptr, R[0].ptr, R[1].ptr, R[2].ptr, rng, 0)
+ocn._lib.call("ocn_compute_tracer_tendency_terms", g.cref, C.byref(t), 0.021, None, f[0].ptr, f[1].ptr, f[2].ptr, f[3].ptr, R[3].ptr, rng, 0)
 ocn.sync_device()
-np.savez(sys.argv[4], *[q.data.cpu().numpy() for q in G])
+np.savez(sys.argv[4], *[q.data.cpu().numpy() for q in G + R])
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import tempfile
