@@ -471,7 +471,9 @@ int ocn_explicit_free_surface_ab2_step(const ocn_grid *grid, const double *w, do
                                        double dt, double chi, void *stream);
 
 /* ---- time_step!(model, Δt) of the RungeKutta3 NonhydrostaticModel in ONE call (src/TimeSteppers/runge_kutta_3.jl:77-151):
- * WENO5 advection, no tracers / extra terms, (Periodic, Periodic, Periodic | Bounded | Flat), one GPU.  The handle owns a second
+ * WENO5 advection, no tracers / extra terms, one GPU: (Periodic, Periodic, Periodic | Bounded | Flat), and since round 4 grids with a
+ * Bounded / Flat x or y (channels, closed boxes, slices: `solver` then is the general / Fourier-tridiagonal handle of that grid, the
+ * fused launch runs the tiled epilogue on the interior box and a finishing kernel on the wall frames).  The handle owns a second
  * set of velocity arrays, G^n, G^- and the pressure solver, and alternates their roles so that the stage boundaries run fused
  * (DESIGN.md section 5); it issues the same entry points in the same order as the Python host and is bit-identical to it.
  *   create:    u, v, w, p = the caller's parent arrays (initial velocities in the interiors); fills their halos.  `solver`: an

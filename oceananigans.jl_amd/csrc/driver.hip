@@ -197,7 +197,9 @@ static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u,
                          ocn_dist_poisson_t dsolver, ocn_comm_t comm, void *stream)
 {
     OCN_REQUIRE(out && grid && u && v && w && p, "ocn_rk3_driver_create: null argument");
-    int st = ocn::validate_grid(grid);
+    // one GPU: any topology the per-call entry points take -- on grids with walls / Flat directions in x, y the fused launch runs the tiled
+    // epilogue on the interior box and the finishing kernel on the wall frames (general.hip), without the correction on load
+    int st = comm ? ocn::validate_grid(grid) : ocn::validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     if (comm) {
         OCN_REQUIRE(grid->tx == OCN_FULLY_CONNECTED && grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC && dsolver,
@@ -213,7 +215,8 @@ static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u,
         OCN_REQUIRE(grid->Nx >= 16 && grid->Nx >= grid->Hx + 1 && grid->Ny >= 8 && grid->Nz >= 4,
                     "ocn_rk3_driver_create_distributed: the local slab must be at least 16 x 8 x 4");
     } else {
-        OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_rk3_driver_create: x and y must be Periodic (one GPU)");
+        OCN_REQUIRE(grid->tx == OCN_PERIODIC || grid->tx == OCN_BOUNDED || grid->tx == OCN_FLAT,
+                    "ocn_rk3_driver_create: a partitioned x (topology %d) needs ocn_rk3_driver_create_distributed", grid->tx);
     }
     ocn_rk3_driver *d = new ocn_rk3_driver();
     d->grid = *grid;
@@ -253,7 +256,8 @@ static int driver_create(ocn_rk3_driver_t *out, const ocn_grid *grid, double *u,
     // -> synchronous exchange -> one plain fused launch; no exchange is in flight while the solver's collective runs.
     const char *e = std::getenv("OCN_CORRECT_ON_LOAD"), *ed = std::getenv("OCN_DIST_CORRECT_ON_LOAD");
     const bool off = (e && e[0] == '0') || (comm && ed && ed[0] == '0');
-    d->correct_on_load = (comm || (grid->tz == OCN_PERIODIC && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4)) && !off;
+    const bool all_periodic = grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC && grid->tz == OCN_PERIODIC;
+    d->correct_on_load = (comm || (all_periodic && grid->Nx >= 16 && grid->Ny >= 8 && grid->Nz >= 4)) && !off;
     // strips written by the fused launch's epilogue instead of a pack launch: OCN_DIST_EPILOGUE_STRIPS=1.  Off by default -- measured at
     // the local sizes of one rank of 2 / of 8 (512^3, replica transport): 14.79 / 4.09 ms per rank-step with, 14.61 / 4.05 without: the
     // scattered 8-byte stores of the edge tiles and the wrapping unpack cost what the 40-us pack launch saves.

@@ -570,7 +570,10 @@ def test_advective_cfl_reference_doctest_value(ocn):
 
 @pytest.mark.parametrize("size,topo,z,own", [((32, 16, 12), "PPP", (0, 2.0), False), ((16, 12, 9), "PPB", "stretched", False),
                                              ((12, 9, 5), "PPP", (0, 1.0), False), ((24, 16, 1), "PPF", None, False),
-                                             ((128, 64, 64), "PPP", (0, 2.0), True)])  # own solver handle: hand-written FFT pipeline
+                                             ((128, 64, 64), "PPP", (0, 2.0), True),  # own solver handle: hand-written FFT pipeline
+                                             # grids with walls (round 4): tiled epilogue on the interior box, finishing kernel on the frames
+                                             ((40, 20, 9), "PBB", (-0.7, 0), False), ((30, 18, 8), "BBB", "stretched", True),
+                                             ((12, 10, 9), "BBB", (-0.7, 0), False), ((26, 12, 10), "BPP", (0, 1.0), False)])
 @pytest.mark.parametrize("defer", [None, False])
 def test_c_driver_equals_host_orchestration(oracle, ocn, size, topo, z, own, defer):
     """ocn_rk3_driver_time_step (the whole RK3 step behind one C entry point, csrc/driver.hip) against the Python host's
