@@ -505,7 +505,9 @@ int ocn_rk3_driver_configure(ocn_rk3_driver_t driver, int32_t defer_correction);
  * the Python host (models.py::_time_step_rk3 on the general fused path), bit-identical to it.  The handle owns a second set of every
  * prognostic array, G^n and G^-; nu_e, kappa_e, pHY and p stay the caller's.  Number-valued and array-valued conditions are supported
  * (the arrays are the caller's device arrays, read at every stage); conditions that are functions of time must be refreshed by the
- * caller between steps (they are then piecewise constant over a step, unlike the reference, which evaluates them per stage). */
+ * caller between steps (they are then piecewise constant over a step, unlike the reference, which evaluates them per stage).
+ * One GPU: Periodic x and y, and since round 4 grids with a Bounded / Flat x or y (the fused stage boundaries of such grids; no flux
+ * condition on an x / y wall, no array-valued bottom / top flux next to x walls: OCN_ERR_INVALID_ARGUMENT at creation). */
 #define OCN_MODEL_MAX_TRACERS 4
 typedef struct ocn_model_driver_desc {
     ocn_model_terms terms;    /* terms.T / terms.S are ignored: tracer_T / tracer_S below name the tracers the buoyancy reads */

@@ -345,7 +345,9 @@ static int model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, co
                                double *p, ocn_poisson_t solver, ocn_dist_poisson_t dsolver, ocn_comm_t comm, void *stream)
 {
     OCN_REQUIRE(out && grid && desc && u && v && w && p, "ocn_model_driver_create: null argument");
-    int st = ocn::validate_grid(grid);
+    // one GPU: any topology the per-call entry points take (walls / Flat directions in x, y since round 4: the fused stage boundaries of
+    // general.hip -- tiled epilogues on the interior box, finishing kernels on the wall frames)
+    int st = comm ? ocn::validate_grid(grid) : ocn::validate_grid_any(grid);
     if (st != OCN_SUCCESS) return st;
     if (comm) {
         OCN_REQUIRE(grid->tx == OCN_FULLY_CONNECTED && grid->ty == OCN_PERIODIC && dsolver,
@@ -360,7 +362,17 @@ static int model_driver_create(ocn_model_driver_t *out, const ocn_grid *grid, co
         }
         OCN_REQUIRE(grid->Nx >= grid->Hx, "ocn_model_driver_create_distributed: the local slab must be at least a halo wide");
     } else {
-        OCN_REQUIRE(grid->tx == OCN_PERIODIC && grid->ty == OCN_PERIODIC, "ocn_model_driver_create: x and y must be Periodic (one GPU)");
+        OCN_REQUIRE(grid->tx == OCN_PERIODIC || grid->tx == OCN_BOUNDED || grid->tx == OCN_FLAT,
+                    "ocn_model_driver_create: a partitioned x (topology %d) needs ocn_model_driver_create_distributed", grid->tx);
+        if (grid->tx != OCN_PERIODIC || grid->ty != OCN_PERIODIC)
+            for (int f = 0; f < 3 + desc->n_tracers && f < 3 + OCN_MODEL_MAX_TRACERS; ++f) {
+                const ocn_field_bcs *b = desc->bcs[f];
+                if (!b) continue;
+                OCN_REQUIRE(b->west.kind != OCN_BC_FLUX && b->east.kind != OCN_BC_FLUX && b->south.kind != OCN_BC_FLUX && b->north.kind != OCN_BC_FLUX,
+                            "ocn_model_driver_create: field %d: a flux through an x / y wall needs the unfused sequence (ocn_apply_flux_bcs)", f);
+                OCN_REQUIRE(grid->tx == OCN_PERIODIC || ((b->bottom.kind != OCN_BC_FLUX || !b->bottom.values) && (b->top.kind != OCN_BC_FLUX || !b->top.values)),
+                            "ocn_model_driver_create: field %d: array-valued bottom / top fluxes need a Periodic x", f);
+            }
     }
     OCN_REQUIRE(desc->n_tracers >= 0 && desc->n_tracers <= OCN_MODEL_MAX_TRACERS, "ocn_model_driver_create: n_tracers %d outside 0..%d",
                 desc->n_tracers, OCN_MODEL_MAX_TRACERS);

@@ -813,10 +813,10 @@ class ModelRK3Driver:
     def __init__(self, model, own_solver=False):
         if not isinstance(model.timestepper, RungeKutta3TimeStepper):
             raise NotImplementedError("ModelRK3Driver: RungeKutta3")
-        if not (model.fuse_stage_boundaries and model._general_fused and model.grid.topology[0] in ("Periodic", "FullyConnected")
-                and model.grid.topology[1] == "Periodic"):
+        xy_periodic = model.grid.topology[0] in ("Periodic", "FullyConnected") and model.grid.topology[1] == "Periodic"
+        if not (model.fuse_stage_boundaries and model._general_fused and (xy_periodic or not hasattr(model.grid.architecture, "partition"))):
             raise NotImplementedError("ModelRK3Driver: a model on the general fused path (tracers and / or extra terms, WENO / UpwindBiased "
-                                      "advection, Periodic x and y); plain WENO models take RK3Driver")
+                                      "advection; on a Distributed architecture Periodic x and y); plain WENO models take RK3Driver")
         arch = model.grid.architecture
         comm = impl = None
         if hasattr(arch, "partition"):

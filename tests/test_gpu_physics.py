@@ -598,21 +598,35 @@ def test_plain_weno_fused_stage_boundaries_on_grids_with_walls(ocn, topo, N):
 
 @pytest.mark.parametrize("closure", ["none", "scalar", "amd", "buoyancy_tracer"])
 def test_c_model_driver_equals_python_host(ocn, closure):
+    _c_model_driver_against_host(ocn, closure, "PPB")
+
+
+@pytest.mark.parametrize("closure", ["none", "amd"])
+def test_c_model_driver_on_a_closed_box(ocn, closure):
+    """... and on a (Bounded, Bounded, Bounded) box of 64 x 64 x 9 (round 4: the fused stage boundaries of grids with walls behind the same
+    entry point; sizes whose x and y transforms are the library's own kernels, see test_general_fused_stage_boundaries_equal_unfused)"""
+    _c_model_driver_against_host(ocn, closure, "BBB")
+
+
+def _c_model_driver_against_host(ocn, closure, walls):
     """ocn_model_driver_time_step (csrc/model_driver.hip: the whole RK3 step of a model with tracers and the §8(f) terms behind one C
     entry point -- halo fills, compute_auxiliaries!, fused tendency / substep launches, projection) against the Python host's time_step:
     same launches in the same order, so every prognostic field, the pressure, the diffusivities and G^n agree bit for bit after 3 steps
     and an intermediate flush (which brings the fields home after an odd number of role swaps)."""
     import torch
     rng = np.random.default_rng(43)
-    N = (32, 16, 12)
+    N = (32, 16, 12) if walls == "PPB" else (64, 64, 9)
     z = stretched_faces(N[2], 32.0)
-    init = {n: 1e-2 * rng.uniform(-1, 1, N) for n in "uv"}
+    B = walls == "BBB"
+    init = {"u": 1e-2 * rng.uniform(-1, 1, (N[0] + B, N[1], N[2])), "v": 1e-2 * rng.uniform(-1, 1, (N[0], N[1] + B, N[2]))}
     names = ("b", "c") if closure == "buoyancy_tracer" else ("T", "S")
     init[names[0]] = 20 + 1e-2 * rng.uniform(-1, 1, N)
     init[names[1]] = 35 + 1e-2 * rng.uniform(-1, 1, N)
 
     def build():
         topo = ("Periodic", "Periodic", "Periodic" if closure == "buoyancy_tracer" else "Bounded")
+        if B:
+            topo = ("Bounded", "Bounded", "Bounded")
         g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 64), y=(0, 64), z=(-32, 0) if closure == "buoyancy_tracer" else z, topology=topo)
         if closure == "none":  # plain WENO model that merely carries tracers
             return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=names)
