@@ -805,8 +805,8 @@ class ModelRK3Driver:
     """time_step!(model, Δt) of a model WITH tracers and the §8(f) terms (config 4's term set) behind ONE entry point of the C ABI
     (ocn_model_driver_*, csrc/model_driver.hip): halo fills, compute_auxiliaries!, the fused tendency / substep launches and the pressure
     projection are issued by the library in the order `time_step(model, dt)` issues them on the general fused path, so after flush() the
-    state is bit-identical to the Python host's -- without an interpreter between the ~20 launches of a stage.  One GPU with Periodic x / y,
-    or ONE RANK of a slab-x run over the RCCL transport (ocn_model_driver_create_distributed: every exchange is issued by the library too;
+    state is bit-identical to the Python host's -- without an interpreter between the ~20 launches of a stage.  One GPU (any x / y topology the
+    fused stage boundaries take: Periodic, and since round 4 walls / Flat directions without a flux through an x / y wall), or ONE RANK of a slab-x run over the RCCL transport (ocn_model_driver_create_distributed: every exchange is issued by the library too;
     synchronous, without the interior / buffer split of distributed.py); WENO or UpwindBiased advection, RungeKutta3; number- or
     array-valued boundary conditions (functions of time are refused)."""
 
