@@ -567,19 +567,22 @@ def test_general_fused_stage_boundaries_equal_unfused(ocn, closure, topo, N):
             np.testing.assert_array_equal(a, b, err_msg=f"{topo} {closure} array {q}")
 
 
-@pytest.mark.parametrize("topo,N", [("PBB", (32, 16, 12)), ("BBB", (40, 20, 9)), ("BBB", (12, 10, 9)), ("BPP", (26, 12, 10))])
+@pytest.mark.parametrize("topo,N", [("PBB", (32, 16, 12)), ("BBB", (40, 20, 9)), ("BBB", (12, 10, 9)), ("BPP", (26, 12, 10)), ("BBF", (40, 20, 1)),
+                                    ("FBB", (1, 20, 12))])
 def test_plain_weno_fused_stage_boundaries_on_grids_with_walls(ocn, topo, N):
     """NonhydrostaticModel(advection = WENO()) without tracers or extra terms on grids with walls: ocn_compute_momentum_tendencies_rk3 with
     the substep in the epilogue of the box kernel and in the finishing kernel of the frames -- bit-identical to the unfused sequence"""
     rng = np.random.default_rng(42)
-    T = {"P": "Periodic", "B": "Bounded"}
+    T = {"P": "Periodic", "B": "Bounded", "F": "Flat"}
     shape = {"u": (N[0] + (topo[0] == "B"), N[1], N[2]), "v": (N[0], N[1] + (topo[1] == "B"), N[2]), "w": (N[0], N[1], N[2] + (topo[2] == "B"))}
-    init = {n: rng.uniform(-1, 1, shape[n]) for n in "uvw"}
+    init = {n: rng.uniform(-1, 1, shape[n]) for n, t in zip("uvw", topo) if t != "F"}  # (no velocity along a Flat direction)
     ocn.set_math_mode(ocn.MATH_STRICT)
     out = []
     models = []
+    ext = {"x": (0, 1.3), "y": (0, 0.9), "z": (-0.7, 0)}
     for _ in range(2):  # (both built before either steps: see test_general_fused_stage_boundaries_equal_unfused)
-        g = ocn.RectilinearGrid(ocn.GPU(), size=N, x=(0, 1.3), y=(0, 0.9), z=(-0.7, 0), topology=tuple(T[t] for t in topo))
+        g = ocn.RectilinearGrid(ocn.GPU(), size=tuple(n for n, t in zip(N, topo) if t != "F"), topology=tuple(T[t] for t in topo),
+                                **{k: v for k, v, t in zip("xyz", (ext["x"], ext["y"], ext["z"]), topo) if t != "F"})
         models.append(ocn.NonhydrostaticModel(g, advection=ocn.WENO()))
     for fused, m in zip((True, False), models):
         assert m.fuse_stage_boundaries and m.defer_final_tendencies and not m._general_fused
