@@ -194,6 +194,12 @@ struct ColFFTArgs {
     int inner;               // number of kx per ky
     int zero_mode;           // MODE 2: this launch holds the (0,0,0) mode (column 0 of batch 0, position 0) and zeroes it
     int xcd;                 // XCD-contiguous block order (xcd_block)
+    // MODE 4 as the LAST pass of a solve on real pairs: the result goes straight into the (haloed) pressure field instead of back into the
+    // spectrum -- element `dst` of column col holds the x-adjacent cells (2 ip, 2 ip + 1): pdim = 1: (ip, j, k) = (col, dst, batch),
+    // pdim = 2: (col % inner, col / inner, dst); preal + p0 is the first interior cell, ps2 / ps3 its row / plane strides.  NULL: in place.
+    double *preal;
+    long long p0, ps2, ps3;
+    int pdim;
 };
 
 template <int N>
@@ -262,7 +268,18 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
             x[m] = cplx{0.5 * (wk.x * zr + wk.y * zi), 0.5 * (wk.x * zi - wk.y * zr)};
         }
         fft_inv_stages<N, CB>(x, A, W, c, t);  // (its first write into the exchange buffer comes after a barrier)
-        if (active) {
+        if (active && a.preal) {
+            const int col = col0 + c;
+            const long long ip = a.pdim == 1 ? col : col % a.inner, jk = a.pdim == 1 ? batch : col / a.inner;
+            double *pr = a.preal + a.p0 + 2 * ip + (a.pdim == 1 ? a.ps3 : a.ps2) * jk;
+            const long long ps = a.pdim == 1 ? a.ps2 : a.ps3;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int e = t + T * r, dst = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
+                pr[ps * dst] = x[r].x * a.scale;
+                pr[ps * dst + 1] = x[r].y * a.scale;
+            }
+        } else if (active) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int e = t + T * r, dst = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
@@ -366,11 +383,29 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
     return OCN_SUCCESS;
 }
 
+static int launch_colfft_args(int N, int mode, const ColFFTArgs &a, hipStream_t stream);
+
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
                   hipStream_t stream, int zero_mode)
 {
-    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode, fft_xcd_remap()};
+    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode, fft_xcd_remap(),
+                 nullptr, 0, 0, 0, 0};
+    return launch_colfft_args(N, mode, a, stream);
+}
+
+// the inverse cosine transform (MODE 4) of real pairs as the last pass of a solve: written into the pressure field `p` (ColFFTArgs::preal)
+int launch_colfft_dct_to_field(int N, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch, const double *tw,
+                               const double *wd, double scale, int inner, int pdim, double *p, long long p0, long long ps2, long long ps3,
+                               hipStream_t stream)
+{
+    ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, nullptr, nullptr, wd, scale, inner > 0 ? inner : 1, 1, fft_xcd_remap(),
+                 p, p0, ps2, ps3, pdim};
+    return launch_colfft_args(N, 4, a, stream);
+}
+
+static int launch_colfft_args(int N, int mode, const ColFFTArgs &a, hipStream_t stream)
+{
     switch (N) {
         case 64: return launch_n<64, 16>(mode, a, stream);
         case 128: return launch_n<128, 16>(mode, a, stream);

@@ -70,6 +70,9 @@ std::vector<double> colfft_twiddles(int N);
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
                   hipStream_t stream, int zero_mode = 1);
+int launch_colfft_dct_to_field(int N, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch, const double *tw,
+                               const double *wd, double scale, int inner, int pdim, double *p, long long p0, long long ps2, long long ps3,
+                               hipStream_t stream);
 // slab pipeline of the distributed solver (colfft.hip): real y transform and z transform into / out of the all-to-all layout
 bool realfft_y_supported(int Ny);
 int launch_realfft_y(int Ny, int inverse, const double *rhs, double *spec, double *p, long long p_s2, long long p_s3, int nx, int Nz,

@@ -679,6 +679,32 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         // -b / (λx + λy + λz [- m]), mode (1,1,1) := 0 iff m === 0
         return ocn::launch_spectral_solve(nx, N[1], N[2], s->lx, s->ly, s->lz, a, 1, 0, 0, stream, s->shift, s->shifted);
     };
+    // the inverse cosine transforms of a solve on real pairs (Nv == Npair) and the way into the pressure field: when the last of them is a
+    // one-pass column transform it stores straight into p (colfft.hip MODE 4, ColFFTArgs::preal) -- no copy_real_component! pass;
+    // otherwise the last scatter is folded into the copy  [OCN_POISSON_DCT_TO_FIELD=0: always the copy]
+    auto finish_real = [&](const Op *ops, int nops) -> int {
+        static const bool direct = !(std::getenv("OCN_POISSON_DCT_TO_FIELD") && std::getenv("OCN_POISSON_DCT_TO_FIELD")[0] == '0');
+        if (direct && nops > 0 && ops[nops - 1].kind == 9) {
+            run(ops, nops - 1);
+            if (pst != OCN_SUCCESS) return pst;
+            const int d = ops[nops - 1].d;
+            const ocn::GridDev gd = ocn::to_dev(*g);
+            const ocn::Lay Lp = ocn::make_lay(gd, OCN_LOC_CCC);
+            const long long p0 = ocn::at(Lp, 1, 1, 1), plane = (long long)Nv[0] * Nv[1];
+            int st = d == 1 ? ocn::launch_colfft_dct_to_field(N[1], a, Nv[0], plane, Nv[0], Nv[2], s->gcoltw[1], s->gtw[1], 1.0 / N[1], Nv[0], 1, p,
+                                                              p0, Lp.s2, Lp.s3, stream)
+                            : ocn::launch_colfft_dct_to_field(N[2], a, plane, 0, (int)plane, 1, s->gcoltw[2], s->gtw[2], 1.0 / N[2], Nv[0], 2, p, p0,
+                                                              Lp.s2, Lp.s3, stream);
+            if (a != s->spec) std::swap(s->spec, s->spec2);
+            return st;
+        }
+        const int last_scatter = (fuse && nops > 0 && ops[nops - 1].kind == 3) ? ops[nops - 1].d : -1;
+        run(ops, nops - (last_scatter >= 0 ? 1 : 0));
+        if (pst != OCN_SUCCESS) return pst;
+        OCN_CHECK_HIP(hipGetLastError());
+        if (a != s->spec) std::swap(s->spec, s->spec2);
+        return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+    };
     Op fwd[9], bwd[9];
     int nf = 0, nb = 0;
     auto push_fwd = [&](int d) {  // REDFT10: gather, FFT, twiddle -- or the one fused pass
@@ -745,12 +771,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
             if (pst != OCN_SUCCESS) return pst;
         }
         // ---- z, y back on the pair view; the last scatter is folded into the copy into the pressure field
-        const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
-        run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
-        if (pst != OCN_SUCCESS) return pst;
-        OCN_CHECK_HIP(hipGetLastError());
-        if (a != s->spec) std::swap(s->spec, s->spec2);
-        return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+        return finish_real(bwd, nb);
     }
     if (s->gpacked) {
         // ---- cosine transforms along the Bounded y / z on the real array viewed as Nx / 2 complex columns
@@ -770,12 +791,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         if (s->growdct) {  // x: transform, division and inverse of row pairs in place, then straight to the inverse cosine transforms
             int st = ocn::launch_rowdct(N[0], N[1], N[2], 8, a, s->gcoltw[0], nullptr, s->lx, s->ly, s->lz, s->shift, s->shifted ? 1 : 0, stream);
             if (st != OCN_SUCCESS) return st;
-            const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
-            run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
-            if (pst != OCN_SUCCESS) return pst;
-            OCN_CHECK_HIP(hipGetLastError());
-            if (a != s->spec) std::swap(s->spec, s->spec2);
-            return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+            return finish_real(bwd, nb);
         }
         // ---- x: real rows -> half spectrum; the other Periodic direction on the half spectrum
         int st = s->xr2c.exec(a, b, stream);
@@ -797,12 +813,7 @@ static int poisson_solve_general(ocn_poisson *s, double *p, hipStream_t stream)
         std::swap(a, b);
         // ---- inverse cosine transforms on the pair view; the last scatter is folded into the copy into the pressure field
         Nv = Npair;
-        const int last_scatter = (fuse && nb > 0 && bwd[nb - 1].kind == 3) ? bwd[nb - 1].d : -1;
-        run(bwd, nb - (last_scatter >= 0 ? 1 : 0));
-        if (pst != OCN_SUCCESS) return pst;
-        OCN_CHECK_HIP(hipGetLastError());
-        if (a != s->spec) std::swap(s->spec, s->spec2);
-        return ocn::launch_copy_real(g, s->spec, p, stream, /*real_source=*/1, last_scatter);
+        return finish_real(bwd, nb);
     }
     for (int q = 0; q < no; ++q) {
         const int d = order[q];
