@@ -508,7 +508,7 @@ def test_ocean_wind_mixing_and_convection_matches_oracle(oracle, ocn, adv, ts, m
         assert np.abs(from_dev(d) - a).max() <= 1e-6 * max(np.abs(a).max(), nus)
 
 
-@pytest.mark.parametrize("closure", ["none", "scalar", "amd"])
+@pytest.mark.parametrize("closure", ["none", "scalar", "amd", "upwind"])
 @pytest.mark.parametrize("topo,N", [("PPB", (32, 16, 12)), ("PBB", (32, 16, 12)), ("BBB", (40, 20, 9)), ("BBB", (12, 10, 9)), ("BPB", (30, 12, 10)),
                                     ("PFB", (32, 1, 12))])
 def test_general_fused_stage_boundaries_equal_unfused(ocn, closure, topo, N):
@@ -535,8 +535,9 @@ def test_general_fused_stage_boundaries_equal_unfused(ocn, closure, topo, N):
         bcs = {"u": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(-3e-4)),
                "T": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
                "S": ocn.FieldBoundaryConditions(top=ocn.FluxBoundaryCondition(0.0, coeff=-2.8e-7))}
-        cl = ocn.ScalarDiffusivity(ν=1e-3, κ={"T": 2e-3, "S": 5e-4}) if closure == "scalar" else ocn.AnisotropicMinimumDissipation()
-        return ocn.NonhydrostaticModel(g, advection=ocn.WENO(), tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4), closure=cl,
+        cl = ocn.AnisotropicMinimumDissipation() if closure == "amd" else ocn.ScalarDiffusivity(ν=1e-3, κ={"T": 2e-3, "S": 5e-4})
+        adv = ocn.UpwindBiased(order=5) if closure == "upwind" else ocn.WENO()  # (the UpwindBiased builds of the tiled and per-cell kernels)
+        return ocn.NonhydrostaticModel(g, advection=adv, tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4), closure=cl,
                                        buoyancy=ocn.SeawaterBuoyancy(equation_of_state=ocn.LinearEquationOfState(2e-4, 8e-4)),
                                        boundary_conditions=bcs)
 
