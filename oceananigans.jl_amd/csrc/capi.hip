@@ -1091,7 +1091,8 @@ int ocn_batched_tridiagonal_solve_z(int32_t Nx, int32_t Ny, int32_t Nz, const do
 {
     OCN_REQUIRE(Nx >= 1 && Ny >= 1 && Nz >= 1, "bad sizes (%d, %d, %d)", Nx, Ny, Nz);
     OCN_REQUIRE(a && b && c && f && t && phi, "ocn_batched_tridiagonal_solve_z: null pointer");
-    return launch_tridiag_z(Nx, Ny, Nz, a, b, c, f, t, phi, as_stream(stream));
+    // (where the pivot is not definitely diagonally dominant the caller's ϕ stays: batched_tridiagonal_solver.jl:224-228)
+    return launch_tridiag_z(Nx, Ny, Nz, a, b, c, f, t, phi, as_stream(stream), /*keep_storage=*/1);
 }
 
 int ocn_halo_pack_x(const ocn_grid *grid, const double *field, int32_t loc, double *send_west, double *send_east, void *stream)

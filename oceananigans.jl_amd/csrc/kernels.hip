@@ -1541,7 +1541,7 @@ template <class T>
 __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long sj, long long s3, int Nz,
                                                        const double *__restrict__ a, const double *__restrict__ b,
                                                        const double *__restrict__ c, const T *__restrict__ f,
-                                                       double *__restrict__ t, T *__restrict__ phi)
+                                                       double *__restrict__ t, T *__restrict__ phi, int keep_storage)
 {
     // column (i, j) at i + sj j, planes s3 apart (see main_diagonal_kernel for the two layouts in use)
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1589,9 +1589,14 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
                     // batched_tridiagonal_solver.jl:224-228 keeps what the storage held: the singular (kx, ky) = (0, 0) column ends in a pivot
                     // of rounding size, its last unknown is the free constant of the gauge, removed again by the zero-mean step.  "What the
                     // storage held" is whatever an earlier solve -- or, the first time, the allocator -- left there: a constant of 2^99 from
-                    // recycled memory cost every digit of that column (seen once in a long test process).  The constant is 0 here.
-                    prev = tz_zero(T{});
-                    phi[o + k * s3] = prev;
+                    // recycled memory cost every digit of that column (seen once in a long test process).  The Poisson solvers take 0 as
+                    // the constant; the stand-alone BatchedTridiagonalSolver (keep_storage: the caller's ϕ) keeps the reference's semantics.
+                    if (keep_storage) {
+                        prev = phi[o + k * s3];
+                    } else {
+                        prev = tz_zero(T{});
+                        phi[o + k * s3] = prev;
+                    }
                 }
             }
         }
@@ -1636,11 +1641,11 @@ __global__ __launch_bounds__(64) void tridiag_z_kernel(int ni, int nj, long long
     }
 }
 int launch_tridiag_z_strided(int ni, int nj, long long sj, long long sk, int Nz, const double *a, const double *b, const double *c,
-                             const double *f, double *t, double *phi, hipStream_t stream)
+                             const double *f, double *t, double *phi, hipStream_t stream, int keep_storage)
 {
     const long long n = (long long)ni * nj;
     hipLaunchKernelGGL(tridiag_z_kernel<double2>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, ni, nj, sj, sk, Nz, a, b, c,
-                       reinterpret_cast<const double2 *>(f), t, reinterpret_cast<double2 *>(phi));
+                       reinterpret_cast<const double2 *>(f), t, reinterpret_cast<double2 *>(phi), keep_storage);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
@@ -1650,14 +1655,14 @@ int launch_tridiag_z_real(int Nx, int Ny, int Nz, const double *a, const double 
 {
     const long long n = (long long)Nx * Ny;
     hipLaunchKernelGGL(tridiag_z_kernel<double>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, Nx, Ny, (long long)Nx, (long long)Nx * Ny, Nz, a,
-                       b, c, f, t, phi);
+                       b, c, f, t, phi, 0);
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
 }
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
-                     double *phi, hipStream_t stream)
+                     double *phi, hipStream_t stream, int keep_storage)
 {
-    return launch_tridiag_z_strided(Nx, Ny, Nx, (long long)Nx * Ny, Nz, a, b, c, f, t, phi, stream);
+    return launch_tridiag_z_strided(Nx, Ny, Nx, (long long)Nx * Ny, Nz, a, b, c, f, t, phi, stream, keep_storage);
 }
 
 // zero-mean gauge (fourier_tridiagonal_poisson_solver.jl:142) applied in spectral space: subtracting the volume

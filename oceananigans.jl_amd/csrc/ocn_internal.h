@@ -53,12 +53,12 @@ int launch_copy_real(const ocn_grid *grid, const double *phi, double *p, hipStre
 int launch_pressure_correct(const ocn_grid *grid, double *u, double *v, double *w, const double *p, double dt, hipStream_t stream);
 int launch_main_diagonal(const ocn_grid *grid, int nxh, const double *lx, const double *ly, double *D, hipStream_t stream);
 int launch_tridiag_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t,
-                     double *phi, hipStream_t stream);
+                     double *phi, hipStream_t stream, int keep_storage = 0);
 int launch_tridiag_z_real(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c, const double *f, double *t, double *phi,
                           hipStream_t stream);
 int launch_remove_mean_mode_real(long long s3, int Nz, double *phi, hipStream_t stream);
 int launch_tridiag_z_strided(int ni, int nj, long long sj, long long sk, int Nz, const double *a, const double *b, const double *c,
-                             const double *f, double *t, double *phi, hipStream_t stream);
+                             const double *f, double *t, double *phi, hipStream_t stream, int keep_storage = 0);
 int launch_main_diagonal_strided(const ocn_grid *grid, int ni, int nj, long long sj, long long sk, const double *lx, const double *ly,
                                  double *D, hipStream_t stream);
 int launch_remove_mean_mode(long long s3, int Nz, double *phi, hipStream_t stream);
