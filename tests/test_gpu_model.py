@@ -219,6 +219,19 @@ def test_batched_tridiagonal_solver_bitwise_vs_oracle(oracle, ocn):
     np.testing.assert_array_equal(phi, ref)
 
 
+def test_batched_tridiagonal_solver_keeps_storage_at_a_singular_pivot(ocn):
+    """batched_tridiagonal_solver.jl:224-228: where a pivot is not definitely diagonally dominant (|β| <= 10 eps) ϕ[k] keeps what the storage
+    held -- the caller's ϕ for the stand-alone solver (the Poisson solvers take 0 there: the free constant of the singular column).
+    b = (1, 1), a = c = (1): β₂ = 1 - 1 * 1 = 0, so ϕ₂ = ϕ⁰₂ and ϕ₁ = f₁ / b₁ - ϕ⁰₂."""
+    a, c = np.array([1.0]), np.array([1.0])
+    b = np.ones((3, 2, 2))
+    f = np.arange(12, dtype=np.float64).reshape(3, 2, 2) + 1j * np.arange(12, dtype=np.float64).reshape(3, 2, 2)[::-1]
+    phi0 = np.full((3, 2, 2), 7.0 - 2.0j)
+    phi = ocn.BatchedTridiagonalSolver(ocn.GPU(), a, b, c).solve(f, phi0)
+    np.testing.assert_array_equal(phi[..., 1], phi0[..., 1])
+    np.testing.assert_array_equal(phi[..., 0], f[..., 0] / 1.0 - 1.0 * phi0[..., 1])
+
+
 MODEL_CASES = [((16, 16, 16), "PPP", (0, 2 * np.pi), "RungeKutta3"),
                ((16, 16, 16), "PPP", (0, 2 * np.pi), "QuasiAdamsBashforth2"),
                ((13, 17, 19), "PPP", (0, 1.0), "RungeKutta3"),
