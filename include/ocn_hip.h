@@ -351,7 +351,10 @@ int ocn_poisson_create(ocn_poisson_t *solver, const ocn_grid *grid);
 int ocn_poisson_destroy(ocn_poisson_t solver);
 /* introspection: kind 0 = FFT-based, 1 = Fourier-tridiagonal, 2 = FFT-based with cosine transforms (a Bounded / Flat x or y),
  * 3 = Fourier-tridiagonal on such a grid; r2c = real-to-complex transforms in use;
- * direct_out = inverse transform writes straight into the pressure interior (no copy_real_component! pass) */
+ * direct_out = bit 0: inverse transform writes straight into the pressure interior (no copy_real_component! pass); bit 1: the fused
+ * FFT_z / division / IFFT_z column pass; bit 2: the library's own row / column kernels for x and y; bit 3: kind 1 on a REGULAR z of a
+ * column-kernel length -- the Thomas sweep replaced by its exact spectral twin, cosine transform / division / inverse cosine transform in
+ * one column pass (what the reference's FFTBasedPoissonSolver does on such a grid; OCN_POISSON_DCT_Z=0 keeps the sweep) */
 int ocn_poisson_info(ocn_poisson_t solver, int32_t *kind, int32_t *r2c, int32_t *direct_out);
 /* compute_source_term! (src/Models/NonhydrostaticModels/solve_for_pressure.jl:12-17,33-38,57-76) */
 int ocn_poisson_compute_source_term(ocn_poisson_t solver, const double *u, const double *v, const double *w, double dt,

@@ -200,6 +200,7 @@ struct ColFFTArgs {
     double *preal;
     long long p0, ps2, ps3;
     int pdim;
+    const double *lx2;       // MODE 5: eigenvalue per NATURAL wavenumber along the column (lc holds the cosine-transform twiddles there)
 };
 
 template <int N>
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     cplx x[8];
     constexpr int HALF = (N + 1) / 2;
 
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 5) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int e = t + T * r, src = e < HALF ? 2 * e : 2 * (N - 1 - e) + 1;
@@ -241,24 +242,48 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
         for (int m = 0; m < 8; ++m) A[stage_wavenumber<N>(8 * t + m) * CB + c] = x[m];
         __syncthreads();
         const cplx *wd = reinterpret_cast<const cplx *>(a.lc);
-        if (active) {
+        if (MODE == 3) {
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = t + T * r;
+                    const cplx va = A[k * CB + c], vb = A[((N - k) % N) * CB + c], wk = wd[k];
+                    const double sr = va.x + vb.x, si = va.y - vb.y, dr = va.x - vb.x, di = va.y + vb.y;
+                    base[(long long)k * a.col_stride] = cplx{wk.x * sr - wk.y * si, wk.x * di + wk.y * dr};
+                }
+            }
+            return;
+        }
+        // MODE 5: X[k] of both parts, -X / ((λx + λy) + λz[k]) (the zero mode := 0), back into the exchange buffer by natural wavenumber
+        {
+            const int col = col0 + c;
+            const double lxy = active ? a.lx[col % a.inner] + a.ly[col / a.inner] : 1.0;
+            const bool zero_col = a.zero_mode && (col == 0) && (batch == 0);
+            cplx y[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int k = t + T * r;
                 const cplx va = A[k * CB + c], vb = A[((N - k) % N) * CB + c], wk = wd[k];
                 const double sr = va.x + vb.x, si = va.y - vb.y, dr = va.x - vb.x, di = va.y + vb.y;
-                base[(long long)k * a.col_stride] = cplx{wk.x * sr - wk.y * si, wk.x * di + wk.y * dr};
+                double sc = -1.0 / (lxy + a.lx2[k]);
+                if (zero_col && k == 0) sc = 0.0;
+                y[r] = cplx{(wk.x * sr - wk.y * si) * sc, (wk.x * di + wk.y * dr) * sc};
             }
-        }
-        return;
-    }
-    if (MODE == 4) {
+            __syncthreads();  // every V[k], V[N - k] has been read
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = t + T * r;
-            A[k * CB + c] = active ? base[(long long)k * a.col_stride] : cplx{0, 0};
+            for (int r = 0; r < 8; ++r) A[(t + T * r) * CB + c] = y[r];
+            __syncthreads();
         }
-        __syncthreads();
+    }
+    if (MODE == 4 || MODE == 5) {
+        if (MODE == 4) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = t + T * r;
+                A[k * CB + c] = active ? base[(long long)k * a.col_stride] : cplx{0, 0};
+            }
+            __syncthreads();
+        }
         const cplx *wd = reinterpret_cast<const cplx *>(a.lc);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -373,6 +398,9 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
     } else if (mode == 4) {
         OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((colfft_kernel<N, CB, 4>), grid, block, lds, stream, a);
+    } else if (mode == 5) {
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((colfft_kernel<N, CB, 5>), grid, block, lds, stream, a);
     } else {
         // (measured and rejected, round 3: a persistent variant that requests the next column set's values before transforming the current
         //  one -- 2.93 ms per 512^3 solve at 166 VGPRs / one workgroup per CU, 3.17 ms with the registers capped for two, against 2.85 ms)
@@ -390,8 +418,18 @@ int launch_colfft(int N, int mode, double *data, long long col_stride, long long
                   hipStream_t stream, int zero_mode)
 {
     ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, lx, ly, lc, scale, inner > 0 ? inner : 1, zero_mode, fft_xcd_remap(),
-                 nullptr, 0, 0, 0, 0};
+                 nullptr, 0, 0, 0, 0, nullptr};
     return launch_colfft_args(N, mode, a, stream);
+}
+
+// MODE 5: REDFT10 along the column, -b / ((λx + λy) + λz) with the zero mode := 0, REDFT01 / 2N back -- the whole z part of a solve on a
+// (Periodic, Periodic, Bounded) grid with a REGULAR z in ONE pass over the half spectrum (the cosine-transform twin of MODE 2; the Thomas
+// sweep it replaces moves 88 B per element instead of 32).  lz: eigenvalues by natural wavenumber, wd: w_k = e^{-i pi k / 2N}.
+int launch_colfft_dct_solve(int N, double *data, long long col_stride, int ncols, const double *tw, const double *wd, const double *lx,
+                            const double *ly, const double *lz, double scale, int inner, hipStream_t stream)
+{
+    ColFFTArgs a{data, col_stride, 0, ncols, 1, tw, lx, ly, wd, scale, inner > 0 ? inner : 1, 1, fft_xcd_remap(), nullptr, 0, 0, 0, 0, lz};
+    return launch_colfft_args(N, 5, a, stream);
 }
 
 // the inverse cosine transform (MODE 4) of real pairs as the last pass of a solve: written into the pressure field `p` (ColFFTArgs::preal)
@@ -400,7 +438,7 @@ int launch_colfft_dct_to_field(int N, double *data, long long col_stride, long l
                                hipStream_t stream)
 {
     ColFFTArgs a{data, col_stride, batch_stride, ncols, nbatch, tw, nullptr, nullptr, wd, scale, inner > 0 ? inner : 1, 1, fft_xcd_remap(),
-                 p, p0, ps2, ps3, pdim};
+                 p, p0, ps2, ps3, pdim, nullptr};
     return launch_colfft_args(N, 4, a, stream);
 }
 

@@ -70,6 +70,8 @@ std::vector<double> colfft_twiddles(int N);
 int launch_colfft(int N, int mode, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch,
                   const double *tw, const double *lx, const double *ly, const double *lc, double scale, int inner,
                   hipStream_t stream, int zero_mode = 1);
+int launch_colfft_dct_solve(int N, double *data, long long col_stride, int ncols, const double *tw, const double *wd, const double *lx,
+                            const double *ly, const double *lz, double scale, int inner, hipStream_t stream);
 int launch_colfft_dct_to_field(int N, double *data, long long col_stride, long long batch_stride, int ncols, int nbatch, const double *tw,
                                const double *wd, double scale, int inner, int pdim, double *p, long long p0, long long ps2, long long ps3,
                                hipStream_t stream);

@@ -141,6 +141,11 @@ struct ocn_poisson {
     bool custom_xy = false;     // x passes by rowfft.hip (fused with the source term / the write into p), y passes by colfft.hip
     double *twMx = nullptr, *twNx = nullptr, *twy = nullptr, *ly_stage = nullptr;
     bool custom_tri = false;    // Fourier-tridiagonal flavour of custom_xy: row / column kernels for (x, y), Thomas sweep in z, no rocFFT
+    // ... and on a REGULAR Bounded z of a supported length the sweep is replaced by its exact spectral twin: cosine transform, division by
+    // the eigenvalues, inverse cosine transform in ONE column pass (colfft.hip MODE 5) -- what the reference's FFTBasedPoissonSolver does on
+    // such a grid (plan_transforms.jl:129-140), 32 instead of 88 B per element  [OCN_POISSON_DCT_Z=0: the Thomas sweep]
+    bool dct_z = false;
+    double *wdz = nullptr, *lz_bounded = nullptr;
     bool source_in_rhs = false; // custom_xy: the source was given as a real array (set_source_term!) and still needs its x transform
     bool direct_out = true;  // r2c path: inverse transform writes straight into the haloed pressure interior
     bool source_set = false;
@@ -201,7 +206,7 @@ static void free_all(ocn_poisson *s)
         if (s->gpartner[d]) (void)hipFree(s->gpartner[d]);
         s->gpartner[d] = nullptr;
     }
-    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage,
+    double **ptrs[] = {&s->dzc, &s->dzf, &s->lx, &s->ly, &s->lz, &s->rhs, &s->spec, &s->spec2, &s->diag, &s->tscr, &s->lower, &s->tw, &s->lz_stage, &s->twMx, &s->twNx, &s->twy, &s->ly_stage, &s->wdz, &s->lz_bounded,
                        &s->tab[0][0], &s->tab[0][1], &s->tab[1][0], &s->tab[1][1], &s->tab[2][0], &s->tab[2][1]};
     for (auto p : ptrs)
         if (*p) {
@@ -982,6 +987,19 @@ static int poisson_create_impl(ocn_poisson_t *out, const ocn_grid *grid, bool fo
             for (int p = 0; p < Ny; ++p) lys[p] = lyn[ocn::colfft_wavenumber(Ny, p)];
             TRY(upload(lys, &s->ly_stage));
             s->custom_xy = true;
+            const char *ez = std::getenv("OCN_POISSON_DCT_Z");
+            s->dct_z = grid->dzc == nullptr && ocn::colfft_supported(Nz) && !(ez && ez[0] == '0');
+            if (s->dct_z) {
+                TRY(upload(ocn::colfft_twiddles(Nz), &s->tw));
+                std::vector<double> w(2 * (size_t)Nz);
+                for (int k = 0; k < Nz; ++k) {
+                    const long double ang = 3.14159265358979323846264338327950288L * k / (2.0L * Nz);
+                    w[2 * k] = (double)cosl(ang);
+                    w[2 * k + 1] = (double)(-sinl(ang));
+                }
+                TRY(upload(w, &s->wdz));
+                TRY(upload(eigenvalues(Nz, grid->Lz, OCN_BOUNDED), &s->lz_bounded));
+            }
         }
         TRY(ocn::launch_main_diagonal(&s->grid, s->nxh, s->lx, s->custom_tri ? s->ly_stage : s->ly, s->diag, nullptr));
     }
@@ -1309,7 +1327,7 @@ extern "C" int ocn_poisson_info(ocn_poisson_t s, int32_t *kind, int32_t *r2c, in
     OCN_REQUIRE(s, "ocn_poisson_info: null solver");
     if (kind) *kind = s->gtri ? 3 : s->kind;  // 3: Fourier-tridiagonal on a grid with a Bounded / Flat x or y
     if (r2c) *r2c = !s->c2c;
-    if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0) + 4 * (s->custom_xy ? 1 : 0);
+    if (direct_out) *direct_out = (!s->c2c && s->direct_out) + 2 * (s->fused_z ? 1 : 0) + 4 * (s->custom_xy ? 1 : 0) + 8 * (s->dct_z ? 1 : 0);
     return OCN_SUCCESS;
 }
 
@@ -1338,7 +1356,7 @@ extern "C" int ocn_poisson_compute_source_term(ocn_poisson_t s, const double *u,
     }
     if (s->custom_xy) {  // K8 fused with the forward x transform: the divergence goes straight into the half spectrum
         st = ocn::launch_rowfft(g, 0, u, v, w, nullptr, dt, s->spec, nullptr, s->twMx, s->twNx, 1.0, ocn::as_stream(stream),
-                                s->custom_tri ? 1 : 0);
+                                (s->custom_tri && !s->dct_z) ? 1 : 0);  // (Δzᶜ rides on the tridiagonal system only)
         s->source_in_rhs = false;
         s->source_set = (st == OCN_SUCCESS);
         return st;
@@ -1356,7 +1374,7 @@ extern "C" int ocn_poisson_set_source_term(ocn_poisson_t s, const double *R, voi
     OCN_REQUIRE(s && R, "ocn_poisson_set_source_term: null argument");
     const ocn_grid *g = &s->grid;
     // set_source_term! multiplies by Δzᶜ for the Fourier-tridiagonal solver (fourier_tridiagonal_poisson_solver.jl:155-177)
-    const bool tri = s->kind == 1 || s->gtri;
+    const bool tri = (s->kind == 1 && !s->dct_z) || s->gtri;
     const double *dzc = tri ? g->dzc : nullptr;
     int st;
     if (tri && !g->dzc) {
@@ -1410,6 +1428,15 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *p, void *stream_)
         // FFT_y (stage order out) -> FFT_z + solve + IFFT_z -> IFFT_y -> inverse x transform into the rows of p
         st = ocn::launch_colfft(g->Ny, 0, s->spec, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
         if (st != OCN_SUCCESS) return st;
+        if (s->custom_tri && s->dct_z) {  // ... -> REDFT10_z, division, REDFT01_z in one column pass (regular z) -> IFFT_y -> x
+            st = ocn::launch_colfft_dct_solve(g->Nz, s->spec, plane, (int)plane, s->tw, s->wdz, s->lx, s->ly_stage, s->lz_bounded,
+                                              1.0 / g->Nz, s->nxh, stream);
+            if (st != OCN_SUCCESS) return st;
+            st = ocn::launch_colfft(g->Ny, 1, s->spec, s->nxh, plane, s->nxh, g->Nz, s->twy, nullptr, nullptr, nullptr, 1.0, 1, stream);
+            if (st != OCN_SUCCESS) return st;
+            return ocn::launch_rowfft(g, 1, nullptr, nullptr, nullptr, nullptr, 1.0, s->spec, p, s->twMx, s->twNx,
+                                      2.0 / ((double)g->Nx * g->Ny), stream);
+        }
         if (s->custom_tri) {  // ... -> Thomas sweep in z (diagonal built with the stage-ordered λy) + zero-mean gauge -> IFFT_y -> x
             st = ocn::launch_tridiag_z(s->nxh, g->Ny, g->Nz, s->lower, s->diag, s->lower, s->spec, s->tscr, s->spec2, stream);
             if (st != OCN_SUCCESS) return st;

@@ -28,7 +28,7 @@ class _PoissonHandle:
     def info(self):
         k, r, d = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.call("ocn_poisson_info", self._h, C.byref(k), C.byref(r), C.byref(d))
-        return {"kind": k.value, "r2c": bool(r.value), "direct_out": d.value, "fused_z": bool(d.value & 2)}
+        return {"kind": k.value, "r2c": bool(r.value), "direct_out": d.value, "fused_z": bool(d.value & 2), "dct_z": bool(d.value & 8)}
 
     def compute_source_term(self, u, v, w, dt):
         """compute_source_term!(pressure, solver, Δt, Ũ) (solve_for_pressure.jl:57-76)"""
