@@ -834,7 +834,10 @@ int ocn_comm_all_gather(ocn_comm_t comm, const double *send, double *recv, size_
     // the GPUs of one node are fully connected by point-to-point xGMI links: R - 1 direct transfers of my chunk, one per link and all
     // at once, instead of the collective's ring (R - 1 hops, each bound by one link).  OCN_COMM_ALL_GATHER=collective selects
     // ncclAllGather (the in-process transport has only the direct form).
-    static const bool collective = [] { const char *e = getenv("OCN_COMM_ALL_GATHER"); return e && !strcmp(e, "collective"); }();
+    // (read per call, not once per process: bench.py's conservative leg and the fast leg of one process differ in it; every rank of
+    // a run must hold the same value when it calls)
+    const char *form = getenv("OCN_COMM_ALL_GATHER");
+    const bool collective = form && !strcmp(form, "collective");
     if (c->local || c->replica || !collective) {
         OCN_REQUIRE(c->nranks <= OCN_COMM_MAX_RANKS, "ocn_comm_all_gather: at most %d ranks", OCN_COMM_MAX_RANKS);
         if (!c->self_via_rccl)

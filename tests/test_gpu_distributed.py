@@ -1093,7 +1093,7 @@ def test_rccl_world1_hydrostatic_matches_single_rank(ocn, rccl_arch):
 @pytest.mark.parametrize("mode", ["direct", "collective"])
 def test_all_gather_forms_through_rccl(mode):
     """ocn_comm_all_gather's two forms through RCCL itself (world 1, the rank's transfer to itself issued as ncclSend / ncclRecv or as
-    ncclAllGather): OCN_COMM_ALL_GATHER is read once per process, so each form runs in a child process."""
+    ncclAllGather), each form in a child process of its own (OCN_COMM_ALL_GATHER is read per call since round 4: bench.py's two legs)."""
     import subprocess
     import sys
     code = r"""
