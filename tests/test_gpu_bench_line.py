@@ -18,7 +18,7 @@ def _run(extra_env, timeout=400):
     env.update(extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "128", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--no-strict"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
