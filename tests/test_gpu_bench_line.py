@@ -36,7 +36,7 @@ def test_partitioned_bench_line_carries_the_conservative_measurement():
     # same synthetic initial state, same number of steps: the two sequences agree to rounding (their pressure solves differ in order)
     for x, y in zip(c["sum_of_squares"], d["config"]["state_checksum"]["sum_of_squares"]):
         assert abs(x - y) <= 1e-9 * abs(y)
-    assert c["ms_per_step"] > 0 and d["ms_per_step"] > 0
+    assert c["ms_per_step"] > 0 and d["ms_per_step"] > 0 and rccl["legs_relative_difference"] <= 1e-9
 
 
 def test_default_sequence_that_never_returns_ends_in_the_conservative_line():
@@ -46,3 +46,12 @@ def test_default_sequence_that_never_returns_ends_in_the_conservative_line():
     assert d["config"]["rccl"]["fast_path"].startswith("did not finish within")
     assert d["ms_per_step"] == d["config"]["rccl"]["conservative"]["ms_per_step"] and d["value"] > 0
     assert "reporting the conservative measurement" in p.stderr
+
+
+def test_default_sequence_with_a_different_state_ends_in_the_conservative_line():
+    """The two legs start from the same state and take the same steps; a default sequence whose global sums differ from the conservative
+    one's beyond OCN_BENCH_LEGS_RTOL (here: a tolerance nothing can meet) is not reported."""
+    p, d = _run({"OCN_BENCH_LEGS_RTOL": "-1"})
+    assert p.returncode == 0, p.stderr[-4000:]
+    assert d["fallback"] is True and d["driver"] == "python"
+    assert d["config"]["rccl"]["fast_path"].startswith("finished with a different state")
