@@ -93,6 +93,54 @@ __device__ __forceinline__ void radix_last(cplx *z)
     }
 }
 
+// ---- the exchange between the second and the third radix-8 stage without LDS (N = 512, CB = 8) ---------------------------------------
+// There thread (c, t = 8 q + t2) sits in lane c + 8 t2 of wave q, and the exchange is an 8 x 8 transpose between the register index and
+// t2 inside one wave: thread (q, t2) register qq  <->  thread (q, qq) register t2.  Three rounds, one per bit: register bit 2 against
+// lane bit 5 and register bit 1 against lane bit 4 with gfx950's v_permlane32_swap / v_permlane16_swap (one instruction per dword, no
+// select), register bit 0 against lane bit 3 with two bank-masked row_ror:8 DPP moves per dword.  80 VALU instructions per thread
+// replace 8 ds_write_b128 + 8 ds_read_b128 + two barriers; the fused z pass is bound by the LDS pipeline, the
+// VALU is busy a third of its cycles.  Pure data movement: results are bit-identical to the LDS exchange.
+#ifndef OCN_FFT_LANE_TRANSPOSE
+#define OCN_FFT_LANE_TRANSPOSE 1
+#endif
+template <int WHICH>  // 32, 16: permlane swaps; 8: DPP
+__device__ __forceinline__ void lane_swap_dword(unsigned &a, unsigned &b)
+{
+    if (WHICH == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);  // lanes 32..63 of a <-> lanes 0..31 of b
+        a = r[0];
+        b = r[1];
+    } else if (WHICH == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);  // odd rows of a <-> even rows of b
+        a = r[0];
+        b = r[1];
+    } else {
+        // row_ror:8 = lane i reads lane i ^ 8 of its row; bank_mask 0xC writes lanes 8..15 of each row, 0x3 lanes 0..7
+        const unsigned na = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false);
+        const unsigned nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);
+        a = na;
+        b = nb;
+    }
+}
+template <int WHICH>
+__device__ __forceinline__ void lane_swap(cplx &A, cplx &B)
+{
+    unsigned a0 = (unsigned)__double2loint(A.x), a1 = (unsigned)__double2hiint(A.x), a2 = (unsigned)__double2loint(A.y), a3 = (unsigned)__double2hiint(A.y);
+    unsigned b0 = (unsigned)__double2loint(B.x), b1 = (unsigned)__double2hiint(B.x), b2 = (unsigned)__double2loint(B.y), b3 = (unsigned)__double2hiint(B.y);
+    lane_swap_dword<WHICH>(a0, b0);
+    lane_swap_dword<WHICH>(a1, b1);
+    lane_swap_dword<WHICH>(a2, b2);
+    lane_swap_dword<WHICH>(a3, b3);
+    A = cplx{__hiloint2double((int)a1, (int)a0), __hiloint2double((int)a3, (int)a2)};
+    B = cplx{__hiloint2double((int)b1, (int)b0), __hiloint2double((int)b3, (int)b2)};
+}
+__device__ __forceinline__ void lane_transpose8(cplx *x)
+{
+    lane_swap<32>(x[0], x[4]); lane_swap<32>(x[1], x[5]); lane_swap<32>(x[2], x[6]); lane_swap<32>(x[3], x[7]);
+    lane_swap<16>(x[0], x[2]); lane_swap<16>(x[1], x[3]); lane_swap<16>(x[4], x[6]); lane_swap<16>(x[5], x[7]);
+    lane_swap<8>(x[0], x[1]); lane_swap<8>(x[2], x[3]); lane_swap<8>(x[4], x[5]); lane_swap<8>(x[6], x[7]);
+}
+
 // Forward stage sequence of one column: x[r] = element t + (N/8) r (natural order) -> x[m] = spectrum at STORED position
 // 8 t + m (stage order, colfft_wavenumber).  A = N*CB exchange buffer [e][c], W = W_N^j table (the first barrier also makes
 // the caller's table writes visible).
@@ -116,13 +164,17 @@ __device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, 
     if (T2 > 1) {
 #pragma unroll
         for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(8 * t2 * qq) % N]);
-        __syncthreads();
-#pragma unroll
-        for (int qq = 0; qq < 8; ++qq) A[((q * 8 + qq) * T2 + t2) * CB + c] = x[qq];
-        __syncthreads();
         // ---- stage 3: thread t owns stored positions p = 8 t .. 8 t + 7 (G groups of T2)
+        if constexpr (T2 == 8 && CB == 8 && OCN_FFT_LANE_TRANSPOSE) {
+            lane_transpose8(x);  // (the callers' next write into the exchange buffer comes after a barrier of their own)
+        } else {
+            __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 8; ++m) x[m] = A[(8 * t + m) * CB + c];
+            for (int qq = 0; qq < 8; ++qq) A[((q * 8 + qq) * T2 + t2) * CB + c] = x[qq];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 8; ++m) x[m] = A[(8 * t + m) * CB + c];
+        }
         radix_last<T2, false>(x);
     }
 }
@@ -136,12 +188,16 @@ __device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, 
     // ---- inverse: conjugate-transpose stage sequence
     if (T2 > 1) {
         radix_last<T2, true>(x);
-        __syncthreads();
+        if constexpr (T2 == 8 && CB == 8 && OCN_FFT_LANE_TRANSPOSE) {
+            lane_transpose8(x);
+        } else {
+            __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 8; ++m) A[(8 * t + m) * CB + c] = x[m];
-        __syncthreads();
+            for (int m = 0; m < 8; ++m) A[(8 * t + m) * CB + c] = x[m];
+            __syncthreads();
 #pragma unroll
-        for (int qq = 0; qq < 8; ++qq) x[qq] = A[((q * 8 + qq) * T2 + t2) * CB + c];
+            for (int qq = 0; qq < 8; ++qq) x[qq] = A[((q * 8 + qq) * T2 + t2) * CB + c];
+        }
 #pragma unroll
         for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(8 * t2 * qq) % N]));
     }
