@@ -144,7 +144,12 @@ __device__ __forceinline__ void lane_transpose8(cplx *x)
 // Forward stage sequence of one column: x[r] = element t + (N/8) r (natural order) -> x[m] = spectrum at STORED position
 // 8 t + m (stage order, colfft_wavenumber).  A = N*CB exchange buffer [e][c], W = W_N^j table (the first barrier also makes
 // the caller's table writes visible).
-template <int N, int CB>
+// SPLIT: the one exchange that crosses waves moves the real parts, then the imaginary parts, through a buffer of N * CB DOUBLES (half
+// the LDS: a third workgroup of the fused z pass fits a CU); same values, two more barriers per exchange.
+#ifndef OCN_FFT_SPLIT_EXCHANGE
+#define OCN_FFT_SPLIT_EXCHANGE 0
+#endif
+template <int N, int CB, bool SPLIT = false>
 __device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, int c, int t)
 {
     constexpr int T = N / 8, T2 = N / 64;
@@ -154,12 +159,28 @@ __device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, 
     radix8<false>(x);
 #pragma unroll
     for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], W[(t * qq) % N]);
+    if constexpr (SPLIT) {
+        double *Ad = reinterpret_cast<double *>(A);
+        double xr[8];
 #pragma unroll
-    for (int qq = 0; qq < 8; ++qq) A[(qq * T + t) * CB + c] = x[qq];
-    __syncthreads();
-    // ---- stage 2: thread (q, t2) takes A1[q][t2 + T2 r2]
+        for (int qq = 0; qq < 8; ++qq) Ad[(qq * T + t) * CB + c] = x[qq].x;
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; ++r) x[r] = A[(q * T + t2 + T2 * r) * CB + c];
+        for (int r = 0; r < 8; ++r) xr[r] = Ad[(q * T + t2 + T2 * r) * CB + c];
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) Ad[(qq * T + t) * CB + c] = x[qq].y;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = cplx{xr[r], Ad[(q * T + t2 + T2 * r) * CB + c]};
+    } else {
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) A[(qq * T + t) * CB + c] = x[qq];
+        __syncthreads();
+        // ---- stage 2: thread (q, t2) takes A1[q][t2 + T2 r2]
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = A[(q * T + t2 + T2 * r) * CB + c];
+    }
     radix8<false>(x);
     if (T2 > 1) {
 #pragma unroll
@@ -180,7 +201,7 @@ __device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, 
 }
 
 // Inverse stage sequence: x[m] at stored position 8 t + m -> x[r] = (unnormalised) element t + (N/8) r in natural order.
-template <int N, int CB>
+template <int N, int CB, bool SPLIT = false>
 __device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, int c, int t)
 {
     constexpr int T = N / 8, T2 = N / 64;
@@ -203,11 +224,27 @@ __device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, 
     }
     radix8<true>(x);
     __syncthreads();
+    if constexpr (SPLIT) {
+        double *Ad = reinterpret_cast<double *>(A);
+        double xr[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) A[(q * T + t2 + T2 * r) * CB + c] = x[r];
-    __syncthreads();
+        for (int r = 0; r < 8; ++r) Ad[(q * T + t2 + T2 * r) * CB + c] = x[r].x;
+        __syncthreads();
 #pragma unroll
-    for (int qq = 0; qq < 8; ++qq) x[qq] = A[(qq * T + t) * CB + c];
+        for (int qq = 0; qq < 8; ++qq) xr[qq] = Ad[(qq * T + t) * CB + c];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) Ad[(q * T + t2 + T2 * r) * CB + c] = x[r].y;
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) x[qq] = cplx{xr[qq], Ad[(qq * T + t) * CB + c]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) A[(q * T + t2 + T2 * r) * CB + c] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) x[qq] = A[(qq * T + t) * CB + c];
+    }
 #pragma unroll
     for (int qq = 1; qq < 8; ++qq) x[qq] = cmul(x[qq], cconj(W[(t * qq) % N]));
     radix8<true>(x);
@@ -269,12 +306,15 @@ __device__ __forceinline__ int stage_wavenumber(int p);
 // LDS exchange, stored in NATURAL wavenumber order; 4: V[k] = conj(w_k) (X[k] - i X[N-k]) / 2 from the natural-order column in LDS, inverse
 // FFT scaled by a.scale, scatter on store.  a.lc = w_k = e^{-i pi k / 2N}, k < N (complex, natural order).  One pass each instead of three.
 template <int N, int CB, int MODE>
-__global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
+constexpr bool colfft_split = (OCN_FFT_SPLIT_EXCHANGE != 0) && (OCN_FFT_LANE_TRANSPOSE != 0) && MODE == 2 && N == 512 && CB == 8;
+template <int N, int CB, int MODE>
+__global__ __launch_bounds__(CB *(N / 8), (colfft_split<N, CB, MODE> ? 6 : 1)) void colfft_kernel(ColFFTArgs a)
 {
     constexpr int T = N / 8;    // threads per column
+    constexpr bool SPLIT = colfft_split<N, CB, MODE>;
     extern __shared__ double lds_raw[];
-    cplx *A = reinterpret_cast<cplx *>(lds_raw);          // N * CB exchange buffer, layout [e][c]
-    cplx *W = reinterpret_cast<cplx *>(lds_raw) + N * CB;  // twiddle table
+    cplx *A = reinterpret_cast<cplx *>(lds_raw);          // N * CB exchange buffer, layout [e][c] (SPLIT: of doubles)
+    cplx *W = reinterpret_cast<cplx *>(lds_raw) + (SPLIT ? N * CB / 2 : N * CB);  // twiddle table
     const int tid = threadIdx.x, c = tid % CB, t = tid / CB;
     unsigned lbx, lby;
     xcd_block(a.xcd, lbx, lby);
@@ -373,7 +413,7 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     if (MODE == 0 || MODE == 2) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = active ? base[(long long)(t + T * r) * a.col_stride] : cplx{0, 0};
-        fft_fwd_stages<N, CB>(x, A, W, c, t);
+        fft_fwd_stages<N, CB, SPLIT>(x, A, W, c, t);
         // x[m] is the spectrum at stored position p = 8 t + m
     } else {
 #pragma unroll
@@ -397,7 +437,7 @@ __global__ __launch_bounds__(CB *(N / 8)) void colfft_kernel(ColFFTArgs a)
     }
 
     if (MODE == 1 || MODE == 2) {
-        fft_inv_stages<N, CB>(x, A, W, c, t);
+        fft_inv_stages<N, CB, SPLIT>(x, A, W, c, t);
         if (MODE == 1 && a.scale != 1.0) {  // normalised inverse (the general solver's line transforms: 1 / N)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -460,8 +500,9 @@ static int launch_n(int mode, const ColFFTArgs &a, hipStream_t stream)
     } else {
         // (measured and rejected, round 3: a persistent variant that requests the next column set's values before transforming the current
         //  one -- 2.93 ms per 512^3 solve at 166 VGPRs / one workgroup per CU, 3.17 ms with the registers capped for two, against 2.85 ms)
-        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((colfft_kernel<N, CB, 2>), grid, block, lds, stream, a);
+        const size_t lds2 = colfft_split<N, CB, 2> ? (size_t)(N * CB / 2 + N) * sizeof(cplx) : lds;
+        OCN_CHECK_HIP(hipFuncSetAttribute((const void *)colfft_kernel<N, CB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL((colfft_kernel<N, CB, 2>), grid, block, lds2, stream, a);
     }
     OCN_CHECK_HIP(hipGetLastError());
     return OCN_SUCCESS;
