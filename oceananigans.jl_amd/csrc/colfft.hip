@@ -141,6 +141,30 @@ __device__ __forceinline__ void lane_transpose8(cplx *x)
     lane_swap<8>(x[0], x[1]); lane_swap<8>(x[2], x[3]); lane_swap<8>(x[4], x[5]); lane_swap<8>(x[6], x[7]);
 }
 
+// N = 256, CB = 16: thread (c, t = 4 q + t2) sits in lane c + 16 t2 of wave q; the four threads of one column in a wave trade
+// thread t2 register qq = 4 h1 + 2 h0 + l  <->  thread (h1 h0) register 4 l + t2: lane bit 5 against register bit 2, lane bit 4 against
+// register bit 1 (permlane swaps only), then a renaming of the registers.
+template <bool INV>
+__device__ __forceinline__ void lane_transpose4(cplx *x)
+{
+    if (INV) {
+        cplx y[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[r] = x[4 * (r & 1) + (r >> 1)];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = y[r];
+    }
+    lane_swap<32>(x[0], x[4]); lane_swap<32>(x[1], x[5]); lane_swap<32>(x[2], x[6]); lane_swap<32>(x[3], x[7]);
+    lane_swap<16>(x[0], x[2]); lane_swap<16>(x[1], x[3]); lane_swap<16>(x[4], x[6]); lane_swap<16>(x[5], x[7]);
+    if (!INV) {
+        cplx y[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) y[4 * (r & 1) + (r >> 1)] = x[r];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = y[r];
+    }
+}
+
 // Forward stage sequence of one column: x[r] = element t + (N/8) r (natural order) -> x[m] = spectrum at STORED position
 // 8 t + m (stage order, colfft_wavenumber).  A = N*CB exchange buffer [e][c], W = W_N^j table (the first barrier also makes
 // the caller's table writes visible).
@@ -188,6 +212,8 @@ __device__ __forceinline__ void fft_fwd_stages(cplx *x, cplx *A, const cplx *W, 
         // ---- stage 3: thread t owns stored positions p = 8 t .. 8 t + 7 (G groups of T2)
         if constexpr (T2 == 8 && CB == 8 && OCN_FFT_LANE_TRANSPOSE) {
             lane_transpose8(x);  // (the callers' next write into the exchange buffer comes after a barrier of their own)
+        } else if constexpr (T2 == 4 && CB == 16 && OCN_FFT_LANE_TRANSPOSE) {
+            lane_transpose4<false>(x);
         } else {
             __syncthreads();
 #pragma unroll
@@ -211,6 +237,8 @@ __device__ __forceinline__ void fft_inv_stages(cplx *x, cplx *A, const cplx *W, 
         radix_last<T2, true>(x);
         if constexpr (T2 == 8 && CB == 8 && OCN_FFT_LANE_TRANSPOSE) {
             lane_transpose8(x);
+        } else if constexpr (T2 == 4 && CB == 16 && OCN_FFT_LANE_TRANSPOSE) {
+            lane_transpose4<true>(x);
         } else {
             __syncthreads();
 #pragma unroll
